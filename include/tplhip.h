@@ -1,0 +1,166 @@
+/*
+ * tplhip.h -- C-ABI of libtplhip.so, the MI355X-native hot path for tpl.
+ *
+ * This is the drop-in boundary: plain C structs, pointers and sizes, no torch
+ * or C++ types.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference checkout, file:line).
+ *
+ * HP-1  DP (s,v,a) longitudinal planner   -> tplcpp.DynProgLonPlanner & friends
+ *       (library/src/python/bindings_dp_lon.cu:7-137, library/src/dyn_prog/lon_planner.cu)
+ * HP-2  genopt iLQR solver                -> genopt<sha1>.Optim
+ *       (library/tpl/optim/templates/optim.c:1179-1994)     [declared in tplhip_ilqr.h]
+ *
+ * All functions return 0 on success and a negative TPLHIP_E* code on failure;
+ * the message of the most recent failure on the calling thread is returned by
+ * tplhip_last_error().  Nothing in here falls back to a CPU implementation:
+ * without a usable HIP device every compute entry point fails with
+ * TPLHIP_EDEVICE.
+ */
+#ifndef TPLHIP_H
+#define TPLHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPLHIP_API __attribute__((visibility("default")))
+
+#define TPLHIP_OK        0
+#define TPLHIP_EINVAL   -1   /* bad argument / shape (reference: ValueError)            */
+#define TPLHIP_EDEVICE  -2   /* HIP runtime failure (reference: RuntimeError from CUDA) */
+#define TPLHIP_ESTATE   -3   /* call order / size mismatch (reference: RuntimeError)    */
+
+/* ---------------------------------------------------------------- PODs -- */
+
+/* DynProgLonPlannerParams, library/include/tplcpp/dyn_prog/lon_planner.cuh:7-53.
+ * Same fields, same order, same defaults (see tplhip_dp_lon_params_default). */
+typedef struct TplDpLonParams {
+    float s_min, s_max;
+    float v_min, v_max;
+    float a_min, a_max;
+    float j_min, j_max;
+    int32_t t_steps, s_steps, v_steps, a_steps;
+    float dt_start, dt;
+    float _s_step_size, _v_step_size, _a_step_size; /* derived, updateStepSizes :45-50 */
+    float time_gap, gap_min;
+    float w_progress, w_a, w_j, w_snap, w_safety_dist;
+    float path_step_size;
+    int32_t path_steps;
+    float width_veh, length_veh;
+} TplDpLonParams;
+
+/* LonState, lon_planner.cuh:55-67 */
+typedef struct TplLonState {
+    float t, s, v, a, j, cost, constr;
+} TplLonState;
+
+/* PathState, library/include/tplcpp/dyn_prog/common.cuh:98-110.
+ * A path is float[path_steps][7] in exactly this field order. */
+typedef struct TplPathState {
+    float x, y, s, l, k, v_max, distance;
+} TplPathState;
+
+/* DynProgEnvParams, library/include/tplcpp/dyn_prog/env.cuh:11-44 */
+typedef struct TplDpEnvParams {
+    float t_min, t_max;
+    float l_min, l_max;
+    float s_min, s_max;
+    float ds_max;
+    float dir_min, dir_max;
+    float dt, dt_start;
+    int32_t t_steps, l_steps, s_steps, dir_steps;
+    float scale_objects, dilation;
+    float _l_step_size, _s_step_size;               /* derived, updateStepSizes :39-43 */
+} TplDpEnvParams;
+
+typedef struct tplhip_dp_env tplhip_dp_env;   /* replaces DynProgEnvironment (the slice HP-1 touches) */
+typedef struct tplhip_dp_lon tplhip_dp_lon;   /* replaces DynProgLonPlanner */
+
+/* ------------------------------------------------------------- general -- */
+
+TPLHIP_API const char* tplhip_last_error(void);
+/* tplcpp.cuda_get_device_count, bindings_dp_common.cu:38-45 (0 on error) */
+TPLHIP_API int tplhip_device_count(void);
+TPLHIP_API const char* tplhip_version(void);
+
+TPLHIP_API void tplhip_dp_lon_params_default(TplDpLonParams* p);   /* lon_planner.cuh:9-43 defaults */
+TPLHIP_API void tplhip_dp_env_params_default(TplDpEnvParams* p);   /* env.cuh:13-37 defaults        */
+
+/* ------------------------------------------------- host-only helpers ---- */
+
+/* lonDynamics, lon_planner.cu:240-250 (bound as tplcpp.lon_dynamics, bindings_dp_lon.cu:85) */
+TPLHIP_API void tplhip_lon_dynamics(const TplLonState* x0, float j, float dt, TplLonState* out);
+/* LonTraj::state(t), lon_planner.cu:252-260 with InterpVars utils.hpp:53-86 */
+TPLHIP_API int tplhip_lon_traj_state(const TplLonState* states, int n, float t, TplLonState* out);
+
+/* -------------------------------------------- DP environment (HP-1 a11) -- */
+
+/* DynProgEnvironment(), env.cu:282-285.  device < 0 selects the last device
+ * like tpl/planning/__init__.py:2-7 does. */
+TPLHIP_API int tplhip_dp_env_create(int device, tplhip_dp_env** out);
+TPLHIP_API int tplhip_dp_env_destroy(tplhip_dp_env* env);
+/* DynProgEnvironment::reinitBuffers, env.cu:304-350: buffers are re-allocated
+ * only when t_steps/l_steps/s_steps change.  Step sizes are written back. */
+TPLHIP_API int tplhip_dp_env_reinit(tplhip_dp_env* env, TplDpEnvParams* ps);
+/* Contents of EnvironmentGpu::occ_map as DynProgEnvironment::getOccMap hands
+ * them out (bindings_dp_env.cu:84-90): float[l_steps][s_steps][t_steps], t
+ * fastest.  In the reference this table is produced by the OpenGL occupancy
+ * pipeline (env.cu:381-437), which is outside the hot path. */
+TPLHIP_API int tplhip_dp_env_set_occ_map(tplhip_dp_env* env, const float* occ_lst);
+TPLHIP_API int tplhip_dp_env_get_occ_map(tplhip_dp_env* env, float* occ_lst);
+/* Result of updateDistMapPath (env.cu:131-158) for the path of the most recent
+ * planner call: float[t_steps][s_steps], s fastest. */
+TPLHIP_API int tplhip_dp_env_get_dist_map_path(tplhip_dp_env* env, float* dist_ts);
+
+/* ----------------------------------------------------- DP planner (HP-1) -- */
+
+/* DynProgLonPlanner(), bindings_dp_lon.cu:120-121 */
+TPLHIP_API int tplhip_dp_lon_create(int device, tplhip_dp_lon** out);
+/* ~DynProgLonPlanner / clearBuffers, lon_planner.cu:262-282 */
+TPLHIP_API int tplhip_dp_lon_destroy(tplhip_dp_lon* h);
+/* DynProgLonPlanner::reinitBuffers, lon_planner.cu:284-326.  Writes the
+ * derived step sizes back into *ps.  Unlike the reference, device tables are
+ * re-allocated only when a size field (t/s/v/a_steps, path_steps) changed. */
+TPLHIP_API int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps);
+/* DynProgLonPlanner::update, lon_planner.cu:328-401 (binding :123-129).
+ * path: float[path_steps][7] host memory; out_traj: TplLonState[t_steps]. */
+TPLHIP_API int tplhip_dp_lon_update(tplhip_dp_lon* h, const TplLonState* init,
+                         const float* path, tplhip_dp_env* env,
+                         TplLonState* out_traj);
+/* Same backward sweep, n forward rollouts (one wave each) from n initial
+ * states; out_trajs: TplLonState[n][t_steps].  New functionality. */
+TPLHIP_API int tplhip_dp_lon_update_batch(tplhip_dp_lon* h, int n, const TplLonState* inits,
+                               const float* path, tplhip_dp_env* env,
+                               TplLonState* out_trajs);
+/* DynProgLonPlanner::reevalTraj, lon_planner.cu:403-470 (binding :130-136).
+ * len != t_steps -> TPLHIP_ESTATE like the reference's runtime_error (:423-425).
+ * Uses the value tables of the most recent update. */
+TPLHIP_API int tplhip_dp_lon_reeval(tplhip_dp_lon* h, const TplLonState* traj, int len,
+                         const float* path, tplhip_dp_env* env,
+                         TplLonState* out_traj);
+/* Debug / parity: copy value table of stage t, float[a_steps][v_steps][s_steps][4]
+ * = (cost, constr, j*, 0) as surf3Dwrite stores it (lon_planner.cu:203-208). */
+TPLHIP_API int tplhip_dp_lon_copy_table(tplhip_dp_lon* h, int t, float* out);
+
+/* ---- device-resident stepping, for measurement (bench.py) --------------- */
+
+/* Upload path + initial states once; afterwards tplhip_dp_lon_plan_resident
+ * enqueues one complete plan (dist map, t_steps-1 backward sweeps, n forward
+ * rollouts) on the planner's stream without touching host memory. */
+TPLHIP_API int tplhip_dp_lon_upload(tplhip_dp_lon* h, int n, const TplLonState* inits,
+                         const float* path);
+TPLHIP_API int tplhip_dp_lon_plan_resident(tplhip_dp_lon* h, tplhip_dp_env* env);
+TPLHIP_API int tplhip_dp_lon_sync(tplhip_dp_lon* h);
+TPLHIP_API int tplhip_dp_lon_download(tplhip_dp_lon* h, TplLonState* out_trajs);
+/* HIP-event timing of the backward sweeps (events recorded on the planner's
+ * stream around the loop of launches).  enable=1 starts accumulating; get
+ * returns the summed ms and the number of sweep launches since enable. */
+TPLHIP_API int tplhip_dp_lon_timing_enable(tplhip_dp_lon* h, int enable);
+TPLHIP_API int tplhip_dp_lon_timing_get(tplhip_dp_lon* h, double* sweep_ms, int64_t* sweep_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPLHIP_H */

@@ -1,0 +1,469 @@
+/*
+ * dp_lon_oracle.c -- CPU restatement of tpl's DP (s,v,a) longitudinal planner.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under tpl_amd/ may include, link or call
+ * this file; it is the checker for the HIP path (tests/, __graft_entry__.smoke,
+ * bench.py's cpu_baseline leg), never the thing shipped or measured.
+ *
+ * PARITY UNPINNED: the reference implementation is CUDA (3-D textures and
+ * surfaces, OpenGL interop) and can be neither built nor run in this image, and
+ * the reference's own tests hold no golden vector for this path.
+ * This file restates the reference *source semantics* line by line:
+ *
+ *   lonDynamics            library/src/dyn_prog/lon_planner.cu:240-250
+ *   interpPath             library/include/tplcpp/dyn_prog/common.cuh:112-139
+ *   stateCost/ActionCost   lon_planner.cu:40-65
+ *   evalNode<N>            lon_planner.cu:72-178
+ *   lonBackwardStep        lon_planner.cu:180-209
+ *   lonForwardStep         lon_planner.cu:211-225
+ *   lonReevalNode          lon_planner.cu:227-236
+ *   update / reevalTraj    lon_planner.cu:328-470 (driver order)
+ *   updateDistMapPath      library/src/dyn_prog/env.cu:131-158
+ *   interpDistMapPath      env.cu:254-264
+ *   LonTraj::state         lon_planner.cu:252-260, utils.hpp:53-86
+ *
+ * Arithmetic rules frozen here (DESIGN.md "HP-1 arithmetic contract"):
+ *  R1  Every expression is evaluated with the C++ types the reference source
+ *      gives it (float, or double where a double literal / double variable
+ *      promotes it), one IEEE-754 rounding per operation, NO fused
+ *      multiply-add contraction (build with -ffp-contract=off), except where
+ *      this file calls fmaf() explicitly (R3).
+ *  R2  tex3D linear filtering ("note T"): unnormalised coordinate x (already
+ *      including the reference's +0.5), xB = x - 0.5f, i = floor(xB),
+ *      alpha = xB - i, alpha_q = rintf(alpha*256)/256 (8 fractional bits, the
+ *      "9 bit fixed point" of arr_tex_surf.cuh:145), texel indices i and i+1
+ *      clamped to [0, n-1] (cudaAddressModeClamp).
+ *  R3  The trilinear blend order is: acceleration axis, then velocity axis,
+ *      then station axis; each 1-D blend is  lerp(p,q,w) = fmaf(q, w, p*(1-w))
+ *      with (1-w) exact.  All three stored channels (cost, constr, jerk) are
+ *      blended.  The 1-D dist-map lookup uses the same lerp.
+ *  R4  Stage t_steps-1 is always terminal in the backward sweep.  The
+ *      reference binds that stage's own array as both surface and texture
+ *      (lon_planner.cu:350-352), which is only well defined when the terminal
+ *      test of :93 fires; this rule defines the remaining case.
+ */
+#include "../include/tplhip.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stddef.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define DPO_API __attribute__((visibility("default")))
+
+static inline int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* ------------------------------------------------------------ dynamics -- */
+
+/* lon_planner.cu:240-250 */
+DPO_API void dpo_lon_dynamics(const TplLonState* x0, float j, float dt, TplLonState* out)
+{
+    TplLonState r;
+    memset(&r, 0, sizeof r);            /* LonState members default to 0 (lon_planner.cuh:55-67) */
+    r.t = x0->t + dt;
+    {
+        /* x0.s + x0.v*dt is float; the 0.5 and 1.0/6.0 literals promote the rest to double */
+        float  sf = x0->s + x0->v * dt;
+        double sd = (double)sf + ((0.5 * (double)x0->a) * (double)dt) * (double)dt;
+        sd = sd + ((((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt) * (double)dt;
+        r.s = fmaxf(x0->s, (float)sd);
+    }
+    {
+        float  vf = x0->v + x0->a * dt;
+        double vd = (double)vf + ((0.5 * (double)j) * (double)dt) * (double)dt;
+        r.v = fmaxf(0.0f, (float)vd);
+    }
+    r.a = x0->a + j * dt;
+    r.j = j;
+    *out = r;
+}
+
+/* ---------------------------------------------------------------- path -- */
+
+/* common.cuh:112-139; path is float[path_steps][7] = PathState */
+DPO_API void dpo_interp_path(const float* path, float distance, float path_step_size,
+                             int path_steps, TplPathState* out)
+{
+    TplPathState res;
+    memset(&res, 0, sizeof res);
+    if (path == NULL) { *out = res; return; }
+
+    float alpha = distance / path_step_size;
+    /* max(0, min(n-1, (int)floor(alpha))); the float->int conversion saturates
+     * on the device, which the float-side guard reproduces (plain C would be
+     * undefined for |alpha| >= 2^31) */
+    float flo = floorf(alpha), fhi = ceilf(alpha);
+    flo = flo < -1.0f ? -1.0f : (flo > (float)path_steps ? (float)path_steps : flo);
+    fhi = fhi < -1.0f ? -1.0f : (fhi > (float)path_steps ? (float)path_steps : fhi);
+    int i0 = clampi((int)flo, 0, path_steps - 1);
+    int i1 = clampi((int)fhi, 0, path_steps - 1);
+    alpha -= (float)i0;
+    float alpha_inv = (float)(1.0 - (double)alpha);
+
+    const float* p0 = path + (size_t)i0 * 7;
+    const float* p1 = path + (size_t)i1 * 7;
+    float* r = (float*)&res;
+    for (int c = 0; c < 7; ++c) {
+        r[c] = p0[c] * alpha_inv + p1[c] * alpha;
+    }
+    *out = res;
+}
+
+/* ------------------------------------------------- texture filter (R2) -- */
+
+typedef struct { int i0, i1; float w; } Tap;
+
+static inline Tap make_tap(float x_plus_half, int n)
+{
+    Tap t;
+    float xb = x_plus_half - 0.5f;
+    float fl = floorf(xb);
+    float alpha = xb - fl;
+    t.w = rintf(alpha * 256.0f) / 256.0f;
+    /* (int) of a float far outside int range is undefined; clamp in float first */
+    float lo = fl < -1.0f ? -1.0f : (fl > (float)n ? (float)n : fl);
+    int i = (int)lo;
+    t.i0 = clampi(i, 0, n - 1);
+    t.i1 = clampi(i + 1, 0, n - 1);
+    return t;
+}
+
+static inline float lerp1(float p, float q, float w) { return fmaf(q, w, p * (1.0f - w)); }
+
+/* ------------------------------------------------------------ dist map -- */
+
+static inline float env_t_idx(const TplDpEnvParams* ep, float t)
+{
+    /* env.cu:258: float t_idx = t < dt_start ? 0 : (roundf((t - dt_start) / dt) + 1.0); */
+    if (t < ep->dt_start) return 0.0f;
+    return (float)((double)roundf((t - ep->dt_start) / ep->dt) + 1.0);
+}
+
+/* env.cu:254-264 with get_cached (arr_tex_surf.cuh:142-149); dist is [t_steps][s_steps] */
+DPO_API float dpo_interp_dist_map_path(const TplDpEnvParams* ep, const float* dist_ts,
+                                        float t, float s)
+{
+    float t_idx = env_t_idx(ep, t);
+    float sc = (s - ep->s_min) / (ep->s_max - ep->s_min) * (float)(ep->s_steps - 1);
+    Tap tt = make_tap(t_idx + 0.5f, ep->t_steps);
+    Tap ts = make_tap(sc + 0.5f, ep->s_steps);
+    /* depth axis (size 1) always resolves to texel 0 with weight 0 */
+    const float* r0 = dist_ts + (size_t)tt.i0 * ep->s_steps;
+    const float* r1 = dist_ts + (size_t)tt.i1 * ep->s_steps;
+    float a = lerp1(r0[ts.i0], r1[ts.i0], tt.w);      /* t_idx is integral -> tt.w == 0 */
+    float b = lerp1(r0[ts.i1], r1[ts.i1], tt.w);
+    return lerp1(a, b, ts.w);
+}
+
+/* env.cu:131-158.  occ is [l_steps][s_steps][t_steps] (t fastest), point-read
+ * at integer texel centres with clamp addressing. */
+DPO_API void dpo_dist_map_path(const TplDpEnvParams* ep, const float* occ_lst,
+                               const float* path, int path_steps, float path_step_size,
+                               float* dist_ts)
+{
+    for (int idx_t = 0; idx_t < ep->t_steps; ++idx_t) {
+        float d = 10000.0f;
+        for (int idx_s = ep->s_steps - 1; idx_s >= 0; --idx_s) {
+            const float s = ep->s_min + (float)idx_s * ep->_s_step_size;
+            TplPathState cps;
+            dpo_interp_path(path, s, path_step_size, path_steps, &cps);
+            float fs = (cps.s - ep->s_min) / ep->_s_step_size;
+            float fl = (cps.l - ep->l_min) / ep->_l_step_size;
+            /* (int) truncation; guard the undefined out-of-range conversion */
+            fs = fs < -1.0f ? -1.0f : (fs > (float)ep->s_steps ? (float)ep->s_steps : fs);
+            fl = fl < -1.0f ? -1.0f : (fl > (float)ep->l_steps ? (float)ep->l_steps : fl);
+            int is = clampi((int)fs, 0, ep->s_steps - 1);
+            int il = clampi((int)fl, 0, ep->l_steps - 1);
+            float occ = occ_lst[((size_t)il * ep->s_steps + is) * ep->t_steps + idx_t];
+            if (occ > 0.0f) {
+                d = 0.0f;
+            } else {
+                d += ep->_s_step_size;
+            }
+            dist_ts[(size_t)idx_t * ep->s_steps + idx_s] = d;
+        }
+    }
+}
+
+/* ---------------------------------------------------------- value table -- */
+
+/* readNode lon_planner.cu:26-38; table is float[a][v][s][4] */
+DPO_API void dpo_read_node(const TplDpLonParams* p, const float* table,
+                           float s, float v, float a, float out[4])
+{
+    float cs = (s - p->s_min) / (p->s_max - p->s_min) * (float)(p->s_steps - 1);
+    float cv = (v - p->v_min) / (p->v_max - p->v_min) * (float)(p->v_steps - 1);
+    float ca = (a - p->a_min) / (p->a_max - p->a_min) * (float)(p->a_steps - 1);
+    /* "+ 0.5" is a double literal; tex3D takes float coordinates */
+    Tap ts = make_tap((float)((double)cs + 0.5), p->s_steps);
+    Tap tv = make_tap((float)((double)cv + 0.5), p->v_steps);
+    Tap ta = make_tap((float)((double)ca + 0.5), p->a_steps);
+
+    const size_t S = (size_t)p->s_steps, V = (size_t)p->v_steps;
+    const float* r00 = table + ((size_t)ta.i0 * V + tv.i0) * S * 4;   /* a0 v0 */
+    const float* r10 = table + ((size_t)ta.i1 * V + tv.i0) * S * 4;   /* a1 v0 */
+    const float* r01 = table + ((size_t)ta.i0 * V + tv.i1) * S * 4;   /* a0 v1 */
+    const float* r11 = table + ((size_t)ta.i1 * V + tv.i1) * S * 4;   /* a1 v1 */
+    for (int c = 0; c < 3; ++c) {
+        float lo, hi;
+        {
+            size_t k = (size_t)ts.i0 * 4 + c;
+            float b0 = lerp1(r00[k], r10[k], ta.w);
+            float b1 = lerp1(r01[k], r11[k], ta.w);
+            lo = lerp1(b0, b1, tv.w);
+        }
+        {
+            size_t k = (size_t)ts.i1 * 4 + c;
+            float b0 = lerp1(r00[k], r10[k], ta.w);
+            float b1 = lerp1(r01[k], r11[k], ta.w);
+            hi = lerp1(b0, b1, tv.w);
+        }
+        out[c] = lerp1(lo, hi, ts.w);
+    }
+    out[3] = 0.0f;
+}
+
+/* ------------------------------------------------------------- evalNode -- */
+
+typedef struct { float cost, constr; } ActionResult;
+
+/* lon_planner.cu:72-178 */
+DPO_API void dpo_eval_node(const TplDpLonParams* p, const TplDpEnvParams* ep, int N,
+                           TplLonState* tp, const float* table_next, const float* path,
+                           const float* dist_ts, float dt, int choose_action,
+                           int force_terminal)
+{
+    TplPathState cps;
+    dpo_interp_path(path, tp->s, p->path_step_size, p->path_steps, &cps);
+
+    const float v_max = cps.v_max;
+    const float s_dist = (float)((double)dpo_interp_dist_map_path(ep, dist_ts, tp->t, cps.s)
+                                 - (double)p->length_veh * 0.6);
+
+    /* stateCost :40-55 */
+    float state_cost = 0.0f;
+    state_cost += p->w_a * (tp->a * tp->a);
+    state_cost = (float)((double)state_cost + (double)p->w_progress * fabs(1000.0 - (double)tp->s));
+    {
+        float gap = tp->v * p->time_gap + p->gap_min - s_dist;
+        double m = (double)gap > 0.0 ? (double)gap : 0.0;           /* max(0.0, gap) */
+        state_cost = (float)((double)state_cost + (double)p->w_safety_dist * m);
+    }
+
+    float state_constr = 0.0f;
+    if (tp->v > v_max) {
+        state_constr += tp->v - v_max;
+    }
+
+    if (force_terminal || roundf(tp->t / p->dt) == (float)(p->t_steps - 1)) {
+        tp->cost = state_cost;
+        return;
+    }
+
+    ActionResult results[64];
+    if (N > 64) N = 64;
+
+    const int n_eval = choose_action ? N : 1;
+    for (int j_idx = 0; j_idx < n_eval; ++j_idx) {
+        const float j = choose_action
+            ? p->j_min + (p->j_max - p->j_min) * ((float)j_idx / (float)(N - 1))
+            : tp->j;
+
+        TplLonState tn;
+        dpo_lon_dynamics(tp, j, dt, &tn);
+
+        float cost = state_cost;
+        float constr = state_constr;
+
+        float node[4];
+        dpo_read_node(p, table_next, tn.s, tn.v, tn.a, node);
+        cost += node[0];
+        constr += node[1];
+        cost += p->w_snap * ((node[2] - j) * (node[2] - j));
+        {
+            float c = 0.0f;                                         /* stateActionCost :57-64 */
+            c += p->w_j * ((j * dt) * (j * dt));
+            cost += c;
+        }
+
+        TplPathState nps;
+        dpo_interp_path(path, tn.s, p->path_step_size, p->path_steps, &nps);
+        const double v_max_n = (double)nps.v_max;
+        if ((double)tn.v > v_max_n) {
+            constr = (float)((double)constr + ((double)tn.v - v_max_n));
+        }
+
+        const float s_change = tn.s - tp->s;
+        if (s_change > s_dist) {
+            constr += s_change - s_dist;
+        }
+        if (tn.a < p->a_min) {
+            constr += p->a_min - tn.a;
+        }
+        if (tn.a > p->a_max) {
+            constr += tn.a - p->a_max;
+        }
+        results[j_idx].cost = cost;
+        results[j_idx].constr = constr;
+    }
+
+    if (!choose_action) {
+        tp->cost = results[0].cost;
+        tp->constr = results[0].constr;
+        return;
+    }
+
+    float constr_min = INFINITY;
+    for (int k = 0; k < N; ++k) {
+        if (results[k].constr < constr_min) constr_min = results[k].constr;
+    }
+    float cost_min = INFINITY;
+    int idx_min = 0;
+    for (int k = 0; k < N; ++k) {
+        if (results[k].constr > constr_min) continue;
+        if (results[k].cost < cost_min) {
+            cost_min = results[k].cost;
+            idx_min = k;
+        }
+    }
+    tp->j = p->j_min + (p->j_max - p->j_min) * ((float)idx_min / (float)(N - 1));
+    tp->cost = cost_min;
+    tp->constr = constr_min;
+}
+
+/* --------------------------------------------------------------- sweeps -- */
+
+/* lonBackwardStep lon_planner.cu:180-209 over the whole grid of stage idx_t.
+ * table_out / table_next: float[a][v][s][4].  nthreads <= 0: all cores. */
+DPO_API void dpo_backward_stage(const TplDpLonParams* p, const TplDpEnvParams* ep, int idx_t,
+                                const float* table_next, float* table_out,
+                                const float* path, const float* dist_ts, int nthreads)
+{
+    const int S = p->s_steps, V = p->v_steps, A = p->a_steps;
+    const int force_terminal = (idx_t == p->t_steps - 1);           /* rule R4 */
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for collapse(2) schedule(static) num_threads(nthreads)
+#endif
+    for (int ia = 0; ia < A; ++ia) {
+        for (int iv = 0; iv < V; ++iv) {
+            for (int is = 0; is < S; ++is) {
+                TplLonState tp;
+                memset(&tp, 0, sizeof tp);
+                tp.t = p->dt_start + (float)(idx_t - 1) * p->dt;
+                tp.s = p->s_min + (float)is * p->_s_step_size;
+                tp.v = p->v_min + (float)iv * p->_v_step_size;
+                tp.a = p->a_min + (float)ia * p->_a_step_size;
+                dpo_eval_node(p, ep, 9, &tp, table_next, path, dist_ts, p->dt, 1, force_terminal);
+                float* o = table_out + (((size_t)ia * V + iv) * S + is) * 4;
+                o[0] = tp.cost; o[1] = tp.constr; o[2] = tp.j; o[3] = 0.0f;
+            }
+        }
+    }
+    (void)nthreads;
+}
+
+DPO_API size_t dpo_table_floats(const TplDpLonParams* p)
+{
+    return (size_t)p->s_steps * p->v_steps * p->a_steps * 4;
+}
+
+/* DynProgLonPlanner::update lon_planner.cu:328-401.
+ * tables: float[t_steps][a][v][s][4] scratch/out (stage 0 is never written, as
+ * in the reference); dist_ts: [env t_steps][env s_steps], already computed.
+ * inits/out_trajs: n rollouts sharing the backward sweep. */
+DPO_API int dpo_update(const TplDpLonParams* p, const TplDpEnvParams* ep,
+                       const float* path, const float* dist_ts,
+                       int n, const TplLonState* inits,
+                       float* tables, TplLonState* out_trajs, int nthreads)
+{
+    const int T = p->t_steps;
+    const size_t tf = dpo_table_floats(p);
+    if (T < 1) return -1;
+
+    for (int i = T - 1; i > 0; --i) {
+        int nx = i + 1 < T - 1 ? i + 1 : T - 1;
+        dpo_backward_stage(p, ep, i, tables + (size_t)nx * tf, tables + (size_t)i * tf,
+                           path, dist_ts, nthreads);
+    }
+    for (int r = 0; r < n; ++r) {
+        TplLonState* traj = out_trajs + (size_t)r * T;
+        traj[0] = inits[r];
+        for (int i = 0; i < T; ++i) {
+            float dt = (i == 0) ? p->dt_start : p->dt;
+            int nx = i + 1 < T - 1 ? i + 1 : T - 1;
+            dpo_eval_node(p, ep, 21, &traj[i], tables + (size_t)nx * tf, path, dist_ts, dt, 1, 0);
+            if (i < T - 1) {
+                dpo_lon_dynamics(&traj[i], traj[i].j, dt, &traj[i + 1]);
+            }
+        }
+    }
+    return 0;
+}
+
+/* DynProgLonPlanner::reevalTraj lon_planner.cu:403-470 */
+DPO_API int dpo_reeval(const TplDpLonParams* p, const TplDpEnvParams* ep,
+                       const float* path, const float* dist_ts,
+                       const float* tables, const TplLonState* traj, int len,
+                       TplLonState* out)
+{
+    const int T = p->t_steps;
+    const size_t tf = dpo_table_floats(p);
+    if (len != T) return -3;
+    memcpy(out, traj, sizeof(TplLonState) * (size_t)len);
+    for (int i = 0; i < len; ++i) {
+        float dt = (i == 0) ? p->dt_start : p->dt;
+        int nx = i + 1 < T - 1 ? i + 1 : T - 1;
+        dpo_eval_node(p, ep, 21, &out[i], tables + (size_t)nx * tf, path, dist_ts, dt, 0, 0);
+    }
+    return 0;
+}
+
+/* LonTraj::state lon_planner.cu:252-260; InterpVars utils.hpp:53-86 */
+DPO_API int dpo_traj_state(const TplLonState* states, int n, float t, TplLonState* out)
+{
+    if (n < 2) return -1;
+    const double v = (double)t;
+    int i_prev = 0;
+    if (v < (double)states[0].t) {
+        i_prev = 0;
+    } else if (v >= (double)states[n - 1].t) {
+        i_prev = n - 2;
+    } else {
+        for (int i = 1; i < n; ++i) {
+            if ((double)states[i - 1].t <= v && v < (double)states[i].t) {
+                i_prev = i - 1;
+                break;
+            }
+        }
+    }
+    float t_rel = t - states[i_prev].t;
+    dpo_lon_dynamics(&states[i_prev], states[i_prev].j, t_rel, out);
+    return 0;
+}
+
+DPO_API void dpo_update_step_sizes(TplDpLonParams* p)
+{
+    p->_s_step_size = (p->s_max - p->s_min) / (float)(p->s_steps - 1);
+    p->_v_step_size = (p->v_max - p->v_min) / (float)(p->v_steps - 1);
+    p->_a_step_size = (p->a_max - p->a_min) / (float)(p->a_steps - 1);
+}
+
+DPO_API void dpo_env_update_step_sizes(TplDpEnvParams* p)
+{
+    p->_l_step_size = (p->l_max - p->l_min) / (float)(p->l_steps - 1);
+    p->_s_step_size = (p->s_max - p->s_min) / (float)(p->s_steps - 1);
+}
+
+DPO_API int dpo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,93 @@
+"""ctypes wrapper around oracle/libdp_lon_oracle.so (test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product (tpl_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from tpl_amd._capi import TplDpEnvParams, TplDpLonParams, TplLonState, TplPathState
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "libdp_lon_oracle.so")
+
+_lib = None
+_fp = C.POINTER(C.c_float)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libdp_lon_oracle.so"])
+        l = C.CDLL(LIB)
+        l.dpo_interp_dist_map_path.restype = C.c_float
+        l.dpo_interp_dist_map_path.argtypes = [C.POINTER(TplDpEnvParams), _fp, C.c_float, C.c_float]
+        l.dpo_table_floats.restype = C.c_size_t
+        l.dpo_lon_dynamics.argtypes = [C.POINTER(TplLonState), C.c_float, C.c_float, C.POINTER(TplLonState)]
+        l.dpo_interp_path.argtypes = [_fp, C.c_float, C.c_float, C.c_int, C.POINTER(TplPathState)]
+        l.dpo_read_node.argtypes = [C.POINTER(TplDpLonParams), _fp, C.c_float, C.c_float, C.c_float, _fp]
+        l.dpo_eval_node.argtypes = [C.POINTER(TplDpLonParams), C.POINTER(TplDpEnvParams), C.c_int,
+                                    C.POINTER(TplLonState), _fp, _fp, _fp, C.c_float, C.c_int, C.c_int]
+        l.dpo_dist_map_path.argtypes = [C.POINTER(TplDpEnvParams), _fp, _fp, C.c_int, C.c_float, _fp]
+        l.dpo_backward_stage.argtypes = [C.POINTER(TplDpLonParams), C.POINTER(TplDpEnvParams), C.c_int,
+                                         _fp, _fp, _fp, _fp, C.c_int]
+        l.dpo_update.restype = C.c_int
+        l.dpo_update.argtypes = [C.POINTER(TplDpLonParams), C.POINTER(TplDpEnvParams), _fp, _fp, C.c_int,
+                                 C.POINTER(TplLonState), _fp, C.POINTER(TplLonState), C.c_int]
+        l.dpo_reeval.restype = C.c_int
+        l.dpo_reeval.argtypes = [C.POINTER(TplDpLonParams), C.POINTER(TplDpEnvParams), _fp, _fp, _fp,
+                                 C.POINTER(TplLonState), C.c_int, C.POINTER(TplLonState)]
+        l.dpo_traj_state.restype = C.c_int
+        l.dpo_traj_state.argtypes = [C.POINTER(TplLonState), C.c_int, C.c_float, C.POINTER(TplLonState)]
+        l.dpo_update_step_sizes.argtypes = [C.POINTER(TplDpLonParams)]
+        l.dpo_env_update_step_sizes.argtypes = [C.POINTER(TplDpEnvParams)]
+        _lib = l
+    return _lib
+
+
+def fptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+def cparams(p):
+    """Copy of the ctypes struct behind a tpl_amd params object, step sizes filled in."""
+    c = type(p._c)()
+    C.memmove(C.byref(c), C.byref(p._c), C.sizeof(c))
+    if isinstance(c, TplDpLonParams):
+        lib().dpo_update_step_sizes(C.byref(c))
+    else:
+        lib().dpo_env_update_step_sizes(C.byref(c))
+    return c
+
+
+def states_to_np(arr):
+    return np.array([[s.t, s.s, s.v, s.a, s.j, s.cost, s.constr] for s in arr], dtype=np.float32)
+
+
+def dist_map_path(ep, occ, path, path_steps, path_step):
+    dist = np.empty((ep.t_steps, ep.s_steps), dtype=np.float32)
+    occ = np.ascontiguousarray(occ, dtype=np.float32)
+    lib().dpo_dist_map_path(C.byref(ep), fptr(occ), fptr(path), path_steps, path_step, fptr(dist))
+    return dist
+
+
+def update(p, ep, path, occ, inits, nthreads=0, keep_tables=True):
+    """Full oracle plan.  p/ep: ctypes structs (cparams).  Returns (tables, trajs, dist)."""
+    path = np.ascontiguousarray(path, dtype=np.float32)
+    dist = dist_map_path(ep, occ, path, p.path_steps, p.path_step_size)
+    tf = lib().dpo_table_floats(C.byref(p))
+    tables = np.zeros((p.t_steps, p.a_steps, p.v_steps, p.s_steps, 4), dtype=np.float32)
+    assert tables.size == tf * p.t_steps
+    n = len(inits)
+    cin = (TplLonState * n)()
+    for i, s in enumerate(inits):
+        C.memmove(C.byref(cin[i]), C.byref(s._c), C.sizeof(TplLonState))
+    out = (TplLonState * (n * p.t_steps))()
+    rc = lib().dpo_update(C.byref(p), C.byref(ep), fptr(path), fptr(dist), n, cin, fptr(tables), out, nthreads)
+    assert rc == 0
+    trajs = states_to_np(out).reshape(n, p.t_steps, 7)
+    return tables, trajs, dist

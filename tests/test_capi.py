@@ -1,0 +1,70 @@
+"""The C-ABI library loads without a GPU and exports every symbol the headers declare."""
+import ctypes as C
+import glob
+import os
+import re
+
+import pytest
+
+from tpl_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    names = []
+    for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        text = open(h).read()
+        names += re.findall(r"TPLHIP_API\s+[\w\s\*]+?\b(tplhip_\w+)\s*\(", text)
+    return names
+
+
+def test_every_declared_symbol_is_exported():
+    lib = C.CDLL(_capi.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported by libtplhip.so"
+
+
+def test_python_signatures_cover_the_header():
+    declared = set(_declared())
+    try:
+        from tpl_amd import _capi_ilqr
+        known = set(_capi.SIGNATURES) | set(_capi_ilqr.SIGNATURES)
+    except ImportError:
+        known = set(_capi.SIGNATURES)
+    assert declared == known
+
+
+def test_no_gpu_means_loud_failure():
+    lib = _capi.load()
+    if lib.tplhip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    import tpl_amd
+    with pytest.raises(RuntimeError, match="no usable HIP device"):
+        tpl_amd.DynProgLonPlanner()
+    with pytest.raises(RuntimeError, match="no usable HIP device"):
+        tpl_amd.DynProgEnvironment()
+
+
+def test_param_surface_matches_reference_slots():
+    import tpl_amd
+    p = tpl_amd.DynProgLonPlannerParams()
+    # bindings_dp_lon.cu:36-64 order
+    assert p.__slots__ == [
+        "s_min", "s_max", "v_min", "v_max", "a_min", "a_max", "j_min", "j_max",
+        "t_steps", "s_steps", "v_steps", "a_steps", "dt", "dt_start", "time_gap", "gap_min",
+        "w_progress", "w_a", "w_j", "w_snap", "w_safety_dist", "path_step_size", "path_steps",
+        "width_veh", "length_veh"]
+    # lon_planner.cuh:9-43 defaults
+    assert (p.s_steps, p.v_steps, p.a_steps, p.t_steps) == (201, 37, 7, 10)
+    assert p.w_safety_dist == 10.0 and p.length_veh == 6.0 and p.path_step_size == 0.5
+    e = tpl_amd.DynProgEnvParams()
+    assert e.__slots__[-4:] == ["t_steps", "l_steps", "s_steps", "dir_steps"]
+    assert (e.t_steps, e.l_steps, e.s_steps) == (10, 21, 201)
+    s = tpl_amd.LonState()
+    s.s, s.v, s.a, s.j = 1, 2, 3, 4
+    assert list(s.as_numpy()) == [1.0, 2.0, 3.0, 4.0]
+    with pytest.raises(AttributeError):
+        p.nonexistent = 1

@@ -1,0 +1,195 @@
+"""GPU parity tests of HP-1: the HIP planner (through the C-ABI of libtplhip.so)
+against the CPU oracle on identical inputs.  Bar: bit-exact -- value tables
+(cost, constr, argmin jerk), distance maps and trajectories compare as raw
+bytes, which is stronger than "argmin indices bit-exact"."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_dp as O
+import tpl_amd
+from tpl_amd import scenarios as sc
+from tpl_amd._capi import TplLonState
+
+pytestmark = pytest.mark.gpu
+
+
+def _traj_np(traj):
+    return O.states_to_np([s._c for s in traj.states])
+
+
+def _run_both(p, ep, path, occ, inits):
+    env = tpl_amd.DynProgEnvironment()
+    env.reinit_buffers(ep)
+    env.set_occ_map(occ)
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p)
+    trajs = dp.update_batch(inits, path, env)
+    cp, cep = O.cparams(p), O.cparams(ep)
+    tables, otrajs, dist = O.update(cp, cep, path, occ, inits)
+    return dp, env, trajs, tables, otrajs, dist
+
+
+def _assert_tables_equal(dp, tables, T):
+    for t in range(1, T):
+        got = dp.copy_table(t)
+        want = tables[t]
+        if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+            bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+            i = tuple(bad[0])
+            raise AssertionError(f"stage {t}: {len(bad)} words differ, first at {i}: got {got[i]!r} want {want[i]!r}")
+
+
+GRID_CASES = [
+    # s, v, a, t, obstacles, dt_start
+    pytest.param(33, 9, 7, 5, sc.OBSTACLES_OVERTAKE, None, id="tiny-33x9x7"),
+    pytest.param(64, 12, 9, 6, sc.random_obstacles(4, 8), None, id="s64-exact-wave"),
+    pytest.param(201, 37, 20, 10, sc.OBSTACLES_OVERTAKE_TRAFFIC, None, id="reference-default-201x37x20"),
+    pytest.param(201, 37, 20, 10, sc.OBSTACLES_OVERTAKE, 0.6, id="default-dt_start-0.6"),
+    pytest.param(96, 10, 8, 6, (), 0.3, id="dt_start-0.3-rule-R4"),
+    pytest.param(512, 8, 6, 4, sc.random_obstacles(7, 5), None, id="s512-kchunk3"),
+    pytest.param(1000, 6, 5, 3, sc.random_obstacles(8, 5), None, id="s1000-kchunk1"),
+]
+
+
+@pytest.mark.parametrize("S,V,A,T,obst,dt_start", GRID_CASES)
+def test_tables_and_trajectories_bit_exact(S, V, A, T, obst, dt_start):
+    p = sc.lon_params(S, V, A, T, dt_start=dt_start)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31, dt_start=dt_start)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, obst)
+    inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(6, seed=5)
+    dp, env, trajs, tables, otrajs, dist = _run_both(p, ep, path, occ, inits)
+    assert np.array_equal(env.get_dist_map_path().view(np.uint32), dist.view(np.uint32))
+    _assert_tables_equal(dp, tables, T)
+    for r, tr in enumerate(trajs):
+        got = _traj_np(tr)
+        assert np.array_equal(got.view(np.uint32), otrajs[r].view(np.uint32)), (r, got, otrajs[r])
+
+
+def test_config2_full_plan_bit_exact():
+    # BASELINE configs[1]: 128x64x32 grid, 50 stages (oracle: ~1e8 action evaluations)
+    S, V, A, T = sc.GRIDS["config2"]
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
+    inits = [sc.initial_state(0.0, 8.0, 0.0)]
+    dp, env, trajs, tables, otrajs, dist = _run_both(p, ep, path, occ, inits)
+    _assert_tables_equal(dp, tables, T)
+    assert np.array_equal(_traj_np(trajs[0]).view(np.uint32), otrajs[0].view(np.uint32))
+    # single-rollout entry point returns the same plan
+    single = dp.update(inits[0], path, env)
+    assert np.array_equal(_traj_np(single).view(np.uint32), otrajs[0].view(np.uint32))
+
+
+def test_reeval_matches_oracle_and_checks_length():
+    S, V, A, T = 65, 10, 8, 6
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=101, l_steps=21)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
+    init = sc.initial_state(0.0, 9.0, 0.2)
+    dp, env, trajs, tables, otrajs, dist = _run_both(p, ep, path, occ, [init])
+    # perturb the stored jerks, re-cost on both sides
+    traj = trajs[0].copy()
+    for i, st in enumerate(traj.states):
+        st.j = st.j + 0.1 * ((i % 3) - 1)
+    got = dp.reeval_traj(traj, path, env)
+    cp, cep = O.cparams(p), O.cparams(ep)
+    arr = traj._as_array()
+    out = (TplLonState * T)()
+    rc = O.lib().dpo_reeval(C.byref(cp), C.byref(cep), O.fptr(path), O.fptr(dist), O.fptr(tables),
+                            arr, T, out)
+    assert rc == 0
+    assert np.array_equal(_traj_np(got).view(np.uint32), O.states_to_np(out).view(np.uint32))
+    # lon_planner.cu:423-425: wrong length -> RuntimeError
+    short = tpl_amd.LonTraj()
+    short.states = traj.states[:-1]
+    with pytest.raises(RuntimeError, match="trajectory size does not match t_steps"):
+        dp.reeval_traj(short, path, env)
+
+
+def test_error_behaviour():
+    p = sc.lon_params(33, 9, 7, 5)
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p)
+    env = tpl_amd.DynProgEnvironment()
+    with pytest.raises(ValueError, match="incorrect shape"):
+        dp.update(sc.initial_state(), np.zeros((10, 7), dtype=np.float32), env)
+    bad = sc.lon_params(2000, 9, 7, 5)
+    with pytest.raises(ValueError, match="s_steps"):
+        dp.reinit_buffers(bad)
+
+
+def test_reinit_keeps_tables_when_only_weights_change():
+    p = sc.lon_params(64, 10, 8, 5)
+    ep = sc.env_params(t_steps=5, s_steps=101, l_steps=21)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, ())
+    env = tpl_amd.DynProgEnvironment()
+    env.reinit_buffers(ep)
+    env.set_occ_map(occ)
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p)
+    a = dp.update(sc.initial_state(), path, env)
+    p.dt_start = 0.7           # what the Python caller changes every cycle
+    ep.dt_start = 0.7
+    env.reinit_buffers(ep)
+    dp.reinit_buffers(p)
+    b = dp.update(sc.initial_state(), path, env)
+    cp, cep = O.cparams(p), O.cparams(ep)
+    _, otrajs, _ = O.update(cp, cep, path, occ, [sc.initial_state()])
+    assert np.array_equal(_traj_np(b).view(np.uint32), otrajs[0].view(np.uint32))
+    assert not np.array_equal(_traj_np(a), _traj_np(b))
+
+
+@pytest.mark.parametrize("grid", ["target", "config4"])
+def test_full_size_spot_checks(grid):
+    """BASELINE full sizes: the oracle cannot sweep these in seconds, so check
+    size-independent properties: (1) the terminal stage against its closed form,
+    (2) random cells of two stages re-evaluated by the oracle's evalNode on the
+    GPU's own next-stage table (bit-exact), (3) the trajectory re-costed by
+    reeval equals the forward pass, stations are monotone, t advances by dt."""
+    S, V, A, T = sc.GRIDS[grid]
+    if grid == "config4":
+        T = 6                       # full 512x256x128 grid, fewer stages: 1.5 GiB of tables
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
+    env = tpl_amd.DynProgEnvironment()
+    env.reinit_buffers(ep)
+    env.set_occ_map(occ)
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p)
+    init = sc.initial_state(0.0, 8.0, 0.0)
+    traj = dp.update(init, path, env)
+    cp, cep = O.cparams(p), O.cparams(ep)
+    dist = O.dist_map_path(cep, occ, path, cp.path_steps, cp.path_step_size)
+    assert np.array_equal(env.get_dist_map_path().view(np.uint32), dist.view(np.uint32))
+
+    rng = np.random.default_rng(11)
+    for t in (T - 1, T - 2, 1):
+        nxt = dp.copy_table(min(T - 1, t + 1))
+        cur = dp.copy_table(t)
+        n = 1500
+        ia = rng.integers(0, A, n); iv = rng.integers(0, V, n); i_s = rng.integers(0, S, n)
+        for k in range(n):
+            tp = TplLonState()
+            tp.t = np.float32(cp.dt_start) + np.float32(t - 1) * np.float32(cp.dt)
+            tp.s = np.float32(cp.s_min) + np.float32(i_s[k]) * np.float32(cp._s_step_size)
+            tp.v = np.float32(cp.v_min) + np.float32(iv[k]) * np.float32(cp._v_step_size)
+            tp.a = np.float32(cp.a_min) + np.float32(ia[k]) * np.float32(cp._a_step_size)
+            O.lib().dpo_eval_node(C.byref(cp), C.byref(cep), 9, C.byref(tp), O.fptr(nxt), O.fptr(path),
+                                  O.fptr(dist), cp.dt, 1, 1 if t == T - 1 else 0)
+            want = np.array([tp.cost, tp.constr, tp.j, 0.0], dtype=np.float32)
+            got = cur[ia[k], iv[k], i_s[k]]
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (t, ia[k], iv[k], i_s[k], got, want)
+
+    tr = _traj_np(traj)
+    assert np.all(np.diff(tr[:, 1]) >= 0.0)
+    assert np.allclose(np.diff(tr[:, 0]), cp.dt)
+    again = _traj_np(dp.reeval_traj(traj, path, env))
+    assert np.array_equal(again[:, 5:].view(np.uint32), tr[:, 5:].view(np.uint32))

@@ -1,0 +1,253 @@
+"""CPU tests of the HP-1 oracle (oracle/dp_lon_oracle.c).
+
+The reference holds no golden vector for this path (parity
+unpinned), so the oracle is pinned with hand-derivable known-answer tests:
+closed-form dynamics, interpolation identities, the texture-filter rule, wall /
+empty-road scenarios and the tie-breaking rule of the lexicographic argmin.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_dp as O
+from tpl_amd import scenarios as sc
+from tpl_amd._capi import TplLonState, TplPathState
+
+
+def _state(t=0.0, s=0.0, v=0.0, a=0.0, j=0.0):
+    st = TplLonState()
+    st.t, st.s, st.v, st.a, st.j = t, s, v, a, j
+    return st
+
+
+def test_lon_dynamics_closed_form():
+    # lon_planner.cu:240-250: constant-jerk step, s and v clipped from below
+    x0 = _state(t=1.0, s=10.0, v=8.0, a=1.0)
+    out = TplLonState()
+    O.lib().dpo_lon_dynamics(C.byref(x0), 0.5, 2.0, C.byref(out))
+    assert out.t == pytest.approx(3.0)
+    assert out.s == pytest.approx(10.0 + 8.0 * 2 + 0.5 * 1.0 * 4 + 0.5 / 6 * 8, rel=1e-6)
+    assert out.v == pytest.approx(8.0 + 1.0 * 2 + 0.5 * 0.5 * 4, rel=1e-6)
+    assert out.a == pytest.approx(2.0)
+    assert out.j == 0.5
+    assert out.cost == 0.0 and out.constr == 0.0
+    # braking past standstill: v clips at 0, s never decreases
+    x0 = _state(s=5.0, v=1.0, a=-3.0)
+    O.lib().dpo_lon_dynamics(C.byref(x0), -3.0, 2.0, C.byref(out))
+    assert out.v == 0.0
+    assert out.s == 5.0
+
+
+def test_lon_dynamics_mixed_precision():
+    # the double literals of the reference promote the a/j terms: check one case
+    # against an explicit numpy restatement of the promotion rules
+    x0 = _state(s=np.float32(3.3), v=np.float32(7.7), a=np.float32(-1.1))
+    j, dt = np.float32(0.7), np.float32(0.9)
+    out = TplLonState()
+    O.lib().dpo_lon_dynamics(C.byref(x0), j, dt, C.byref(out))
+    s, v, a = np.float32(3.3), np.float32(7.7), np.float32(-1.1)
+    sf = np.float32(s + np.float32(v * dt))
+    sd = np.float64(sf) + ((0.5 * np.float64(a)) * np.float64(dt)) * np.float64(dt)
+    sd = sd + ((((1.0 / 6.0) * np.float64(j)) * np.float64(dt)) * np.float64(dt)) * np.float64(dt)
+    assert out.s == max(s, np.float32(sd))
+    vf = np.float32(v + np.float32(a * dt))
+    vd = np.float64(vf) + ((0.5 * np.float64(j)) * np.float64(dt)) * np.float64(dt)
+    assert out.v == max(np.float32(0), np.float32(vd))
+
+
+def test_interp_path_identities():
+    path = sc.straight_path(200, 1.0)
+    res = TplPathState()
+    # exactly on a sample
+    O.lib().dpo_interp_path(O.fptr(path), 57.0, 1.0, 200, C.byref(res))
+    assert res.s == 57.0 and res.v_max == path[57, 5]
+    # half way
+    O.lib().dpo_interp_path(O.fptr(path), 57.5, 1.0, 200, C.byref(res))
+    assert res.s == 57.5
+    assert res.v_max == np.float32(np.float32(path[57, 5] * np.float32(0.5)) + np.float32(path[58, 5] * np.float32(0.5)))
+    # clamps below and above (common.cuh:124-125)
+    O.lib().dpo_interp_path(O.fptr(path), -3.0, 1.0, 200, C.byref(res))
+    # i0 = i1 = 0, alpha = -3 -> extrapolates with weights (4, -3) of the same sample
+    assert res.v_max == pytest.approx(path[0, 5], rel=1e-6)
+    O.lib().dpo_interp_path(O.fptr(path), 1e9, 1.0, 200, C.byref(res))
+    assert np.isfinite(res.v_max)
+
+
+def _small():
+    p = sc.lon_params(s_steps=33, v_steps=9, a_steps=7, t_steps=5)
+    ep = sc.env_params(t_steps=5, s_steps=41, l_steps=11)
+    return O.cparams(p), O.cparams(ep)
+
+
+def test_read_node_grid_points_and_quantisation():
+    p, _ = _small()
+    rng = np.random.default_rng(0)
+    table = rng.uniform(0, 10, size=(p.a_steps, p.v_steps, p.s_steps, 4)).astype(np.float32)
+    out = np.zeros(4, dtype=np.float32)
+    # exactly on grid points the filter returns the texel (weights 0)
+    for (ia, iv, i_s) in [(0, 0, 0), (3, 4, 17), (6, 8, 32)]:
+        s = p.s_min + i_s * p._s_step_size
+        v = p.v_min + iv * p._v_step_size
+        a = p.a_min + ia * p._a_step_size
+        O.lib().dpo_read_node(C.byref(p), O.fptr(table), s, v, a, O.fptr(out))
+        assert np.allclose(out[:3], table[ia, iv, i_s, :3], rtol=2e-6)
+        assert out[3] == 0.0
+    # rule R2: weights have 8 fractional bits -> a station 1/1024 of a cell past a
+    # grid point still returns the grid value, 1/256 moves it by exactly one step
+    s0 = p.s_min + 10 * p._s_step_size
+    v0, a0 = p.v_min, p.a_min
+    O.lib().dpo_read_node(C.byref(p), O.fptr(table), s0 + p._s_step_size / 1024, v0, a0, O.fptr(out))
+    assert out[0] == pytest.approx(table[0, 0, 10, 0], rel=1e-6)
+    O.lib().dpo_read_node(C.byref(p), O.fptr(table), s0 + p._s_step_size * 0.5, v0, a0, O.fptr(out))
+    assert out[0] == pytest.approx(0.5 * (table[0, 0, 10, 0] + table[0, 0, 11, 0]), rel=1e-5)
+    # clamp addressing outside the grid
+    O.lib().dpo_read_node(C.byref(p), O.fptr(table), -50.0, -5.0, -9.0, O.fptr(out))
+    assert np.allclose(out[:3], table[0, 0, 0, :3], rtol=2e-6)
+    O.lib().dpo_read_node(C.byref(p), O.fptr(table), 1e4, 1e3, 99.0, O.fptr(out))
+    assert np.allclose(out[:3], table[-1, -1, -1, :3], rtol=2e-6)
+
+
+def test_dist_map_path_scan():
+    p, ep = _small()
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = np.zeros((ep.l_steps, ep.s_steps, ep.t_steps), dtype=np.float32)
+    il = int((0.0 - ep.l_min) / ep._l_step_size)
+    occ[il, 20, :] = 1.0
+    occ[il, 30, 2] = 3.0
+    dist = O.dist_map_path(ep, occ, path, p.path_steps, p.path_step_size)
+    ds = np.float32(ep._s_step_size)
+    # behind the last obstacle the scan counts up from 10000 (env.cu:142)
+    assert dist[0, ep.s_steps - 1] == np.float32(np.float32(10000.0) + ds)
+    assert dist[0, 20] == 0.0
+    assert dist[0, 19] == ds
+    assert dist[0, 18] == np.float32(ds + ds)
+    assert dist[2, 30] == 0.0 and dist[2, 29] == ds and dist[2, 20] == 0.0
+    assert dist[1, 30] != 0.0
+    # sequential float accumulation, not idx * ds
+    d = np.float32(0.0)
+    for _ in range(20):
+        d = np.float32(d + ds)
+    assert dist[0, 0] == d
+    # lookup: exact at cell centres, linear in between, slice picked by env.cu:258
+    f = O.lib().dpo_interp_dist_map_path
+    s19 = ep.s_min + 19 * ep._s_step_size
+    assert f(C.byref(ep), O.fptr(dist), 0.0, s19) == pytest.approx(ds, rel=1e-6)
+    assert f(C.byref(ep), O.fptr(dist), 2.0, ep.s_min + 29.5 * ep._s_step_size) == pytest.approx(0.5 * ds, rel=1e-3)
+    # t = dt_start + dt -> slice 2
+    assert f(C.byref(ep), O.fptr(dist), 2.0, ep.s_min + 30 * ep._s_step_size) == pytest.approx(0.0, abs=1e-6)
+
+
+def test_empty_road_cruise_and_terminal_stage():
+    # KAT (i): no obstacles, start at the speed limit with a = 0: the cheapest
+    # plan never violates a constraint and keeps |j| small
+    p, ep = _small()
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = np.zeros((ep.l_steps, ep.s_steps, ep.t_steps), dtype=np.float32)
+    tables, trajs, _ = O.update(p, ep, path, occ, [sc.initial_state(0.0, 8.0, 0.0)])
+    T = p.t_steps
+    # terminal stage stores (state_cost, 0, 0, 0) everywhere (lon_planner.cu:93-97)
+    assert np.all(tables[T - 1, ..., 1:] == 0.0)
+    assert np.all(tables[T - 1, ..., 0] > 0.0)
+    # stage 0 is never written (lon_planner.cu:347)
+    assert np.all(tables[0] == 0.0)
+    tr = trajs[0]
+    assert np.all(tr[1:-1, 6] < 0.1)                 # valid plan predicate of the caller
+    assert np.all(np.diff(tr[:, 1]) >= 0.0)          # stations never decrease
+    assert np.allclose(np.diff(tr[:, 0]), 1.0)       # t advances by dt
+
+
+def test_wall_raises_constraint():
+    # KAT (ii): a wall right ahead: every action from a fast cell overshoots s_dist
+    p, ep = _small()
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = np.zeros((ep.l_steps, ep.s_steps, ep.t_steps), dtype=np.float32)
+    occ[:, 8:, :] = 1.0                               # wall from s = 40 m on
+    dist = O.dist_map_path(ep, occ, path, p.path_steps, p.path_step_size)
+    T = p.t_steps
+    tf = int(O.lib().dpo_table_floats(C.byref(p)))
+    term = np.zeros(tf, dtype=np.float32)
+    O.lib().dpo_backward_stage(C.byref(p), C.byref(ep), T - 1, O.fptr(term), O.fptr(term),
+                               O.fptr(path), O.fptr(dist), 1)
+    stage = np.zeros(tf, dtype=np.float32)
+    O.lib().dpo_backward_stage(C.byref(p), C.byref(ep), T - 2, O.fptr(term), O.fptr(stage),
+                               O.fptr(path), O.fptr(dist), 1)
+    stage = stage.reshape(p.a_steps, p.v_steps, p.s_steps, 4)
+    ia0 = int(round((0.0 - p.a_min) / p._a_step_size))
+    # a cell 5 m in front of the wall driving 18 m/s cannot stop: constr > 0
+    i_s = int(round(35.0 / p._s_step_size))
+    iv = int(round(18.0 / p._v_step_size))
+    assert stage[ia0, iv, i_s, 1] > 1.0
+    # a standing cell far from the wall has a constraint-free action
+    assert stage[ia0, 0, 0, 1] == 0.0
+
+
+def test_tie_break_lowest_action():
+    # KAT (iv): with all weights zero every action costs the same -> index 0 wins
+    p, ep = _small()
+    p.w_progress = p.w_a = p.w_j = p.w_snap = p.w_safety_dist = 0.0
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    path[:, 5] = 1000.0                                # no speed limit
+    dist = np.full((ep.t_steps, ep.s_steps), 10000.0, dtype=np.float32)
+    table = np.zeros((p.a_steps, p.v_steps, p.s_steps, 4), dtype=np.float32)
+    tp = _state(t=1.0, s=10.0, v=5.0, a=0.0)
+    p.a_min, p.a_max = -100.0, 100.0                   # no acceleration constraint either
+    O.lib().dpo_update_step_sizes(C.byref(p))
+    O.lib().dpo_eval_node(C.byref(p), C.byref(ep), 9, C.byref(tp), O.fptr(table), O.fptr(path),
+                          O.fptr(dist), 1.0, 1, 0)
+    assert tp.j == p.j_min and tp.cost == 0.0 and tp.constr == 0.0
+    # constr has priority over cost: make action 0 violate, the next one wins
+    p.a_min = -2.5                                     # a' = 0 + j*dt < a_min only for j = -3
+    O.lib().dpo_update_step_sizes(C.byref(p))
+    table = np.zeros((p.a_steps, p.v_steps, p.s_steps, 4), dtype=np.float32)
+    tp = _state(t=1.0, s=10.0, v=5.0, a=0.0)
+    O.lib().dpo_eval_node(C.byref(p), C.byref(ep), 9, C.byref(tp), O.fptr(table), O.fptr(path),
+                          O.fptr(dist), 1.0, 1, 0)
+    j1 = np.float32(p.j_min) + np.float32(p.j_max - p.j_min) * (np.float32(1) / np.float32(8))
+    assert tp.j == j1 and tp.constr == 0.0
+
+
+def test_traj_state_brackets():
+    # LonTraj::state, lon_planner.cu:252-260 with InterpVars utils.hpp:59-78
+    n = 4
+    arr = (TplLonState * n)()
+    for i in range(n):
+        arr[i].t = float(i)
+        arr[i].s = 10.0 * i
+        arr[i].v = 10.0
+        arr[i].j = 0.0
+    out = TplLonState()
+    assert O.lib().dpo_traj_state(arr, n, 1.5, C.byref(out)) == 0
+    assert out.s == pytest.approx(15.0)
+    O.lib().dpo_traj_state(arr, n, -1.0, C.byref(out))      # before the first: extrapolate from state 0
+    assert out.s == pytest.approx(0.0)                      # s is clipped from below by lonDynamics
+    O.lib().dpo_traj_state(arr, n, 5.0, C.byref(out))       # past the end: from state n-2
+    assert out.s == pytest.approx(20.0 + 30.0)
+
+
+def test_product_host_helpers_match_oracle():
+    # tplhip_lon_dynamics / tplhip_lon_traj_state run on the host inside libtplhip.so
+    import tpl_amd
+    from tpl_amd import _capi
+    lib = _capi.load()
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        x0 = _state(t=rng.uniform(0, 5), s=rng.uniform(0, 200), v=rng.uniform(0, 36), a=rng.uniform(-3, 1.5))
+        j, dt = float(rng.uniform(-3, 2)), float(rng.uniform(0.05, 2))
+        a, b = TplLonState(), TplLonState()
+        O.lib().dpo_lon_dynamics(C.byref(x0), j, dt, C.byref(a))
+        lib.tplhip_lon_dynamics(C.byref(x0), j, dt, C.byref(b))
+        assert bytes(a) == bytes(b)
+    traj = tpl_amd.LonTraj()
+    for i in range(5):
+        st = tpl_amd.LonState()
+        st.t, st.s, st.v, st.a, st.j = float(i), 8.0 * i, 8.0, 0.1, 0.2
+        traj.states.append(st)
+    arr = traj._as_array()
+    for t in [-0.5, 0.0, 0.3, 2.0, 3.999, 4.0, 7.0]:
+        a = TplLonState()
+        O.lib().dpo_traj_state(arr, 5, t, C.byref(a))
+        b = traj.state(t)
+        assert bytes(a) == bytes(b._c)
+    many = traj.state(np.array([0.3, 2.0]))
+    assert many.shape == (2, 4)

@@ -1,0 +1,27 @@
+"""tpl_amd -- MI355X-native hot path for tpl (DP (s,v,a) planner + genopt iLQR).
+
+``tpl_amd.dyn_prog``  mirrors the HP-1 slice of the reference's ``tplcpp`` module,
+``tpl_amd.optim``     mirrors ``tpl.optim`` (genopt / optimizers) for HP-2.
+Everything computes in ``libtplhip.so``; importing this package without the
+built library raises ImportError.
+"""
+
+from . import _capi
+
+_capi.load()
+
+from .dyn_prog import (  # noqa: E402
+    DynProgEnvParams,
+    DynProgEnvironment,
+    DynProgLonPlanner,
+    DynProgLonPlannerParams,
+    LonState,
+    LonTraj,
+    cuda_get_device_count,
+    lon_dynamics,
+)
+
+__all__ = [
+    "DynProgEnvParams", "DynProgEnvironment", "DynProgLonPlanner", "DynProgLonPlannerParams",
+    "LonState", "LonTraj", "cuda_get_device_count", "lon_dynamics",
+]

@@ -1,0 +1,138 @@
+"""ctypes view of ``libtplhip.so`` (``include/tplhip.h``).
+
+This module only loads the shared library and declares its signatures.  There
+is no Python or CPU fallback for any compute entry point: if the library is
+missing, importing this module raises, and if no HIP device is usable the
+library itself reports ``TPLHIP_EDEVICE``.
+"""
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtplhip.so")
+
+TPLHIP_OK = 0
+TPLHIP_EINVAL = -1
+TPLHIP_EDEVICE = -2
+TPLHIP_ESTATE = -3
+
+
+class TplDpLonParams(C.Structure):
+    """DynProgLonPlannerParams, library/include/tplcpp/dyn_prog/lon_planner.cuh:7-53."""
+    _fields_ = [
+        ("s_min", C.c_float), ("s_max", C.c_float),
+        ("v_min", C.c_float), ("v_max", C.c_float),
+        ("a_min", C.c_float), ("a_max", C.c_float),
+        ("j_min", C.c_float), ("j_max", C.c_float),
+        ("t_steps", C.c_int32), ("s_steps", C.c_int32),
+        ("v_steps", C.c_int32), ("a_steps", C.c_int32),
+        ("dt_start", C.c_float), ("dt", C.c_float),
+        ("_s_step_size", C.c_float), ("_v_step_size", C.c_float), ("_a_step_size", C.c_float),
+        ("time_gap", C.c_float), ("gap_min", C.c_float),
+        ("w_progress", C.c_float), ("w_a", C.c_float), ("w_j", C.c_float),
+        ("w_snap", C.c_float), ("w_safety_dist", C.c_float),
+        ("path_step_size", C.c_float), ("path_steps", C.c_int32),
+        ("width_veh", C.c_float), ("length_veh", C.c_float),
+    ]
+
+
+class TplLonState(C.Structure):
+    """LonState, lon_planner.cuh:55-67."""
+    _fields_ = [(n, C.c_float) for n in ("t", "s", "v", "a", "j", "cost", "constr")]
+
+
+class TplPathState(C.Structure):
+    """PathState, library/include/tplcpp/dyn_prog/common.cuh:98-110."""
+    _fields_ = [(n, C.c_float) for n in ("x", "y", "s", "l", "k", "v_max", "distance")]
+
+
+class TplDpEnvParams(C.Structure):
+    """DynProgEnvParams, library/include/tplcpp/dyn_prog/env.cuh:11-44."""
+    _fields_ = [
+        ("t_min", C.c_float), ("t_max", C.c_float),
+        ("l_min", C.c_float), ("l_max", C.c_float),
+        ("s_min", C.c_float), ("s_max", C.c_float),
+        ("ds_max", C.c_float),
+        ("dir_min", C.c_float), ("dir_max", C.c_float),
+        ("dt", C.c_float), ("dt_start", C.c_float),
+        ("t_steps", C.c_int32), ("l_steps", C.c_int32),
+        ("s_steps", C.c_int32), ("dir_steps", C.c_int32),
+        ("scale_objects", C.c_float), ("dilation", C.c_float),
+        ("_l_step_size", C.c_float), ("_s_step_size", C.c_float),
+    ]
+
+
+_P = C.POINTER
+_vp = C.c_void_p
+_fp = _P(C.c_float)
+
+# name -> (restype, argtypes); mirrors include/tplhip.h declaration by declaration
+SIGNATURES = {
+    "tplhip_last_error": (C.c_char_p, []),
+    "tplhip_device_count": (C.c_int, []),
+    "tplhip_version": (C.c_char_p, []),
+    "tplhip_dp_lon_params_default": (None, [_P(TplDpLonParams)]),
+    "tplhip_dp_env_params_default": (None, [_P(TplDpEnvParams)]),
+    "tplhip_lon_dynamics": (None, [_P(TplLonState), C.c_float, C.c_float, _P(TplLonState)]),
+    "tplhip_lon_traj_state": (C.c_int, [_P(TplLonState), C.c_int, C.c_float, _P(TplLonState)]),
+    "tplhip_dp_env_create": (C.c_int, [C.c_int, _P(_vp)]),
+    "tplhip_dp_env_destroy": (C.c_int, [_vp]),
+    "tplhip_dp_env_reinit": (C.c_int, [_vp, _P(TplDpEnvParams)]),
+    "tplhip_dp_env_set_occ_map": (C.c_int, [_vp, _fp]),
+    "tplhip_dp_env_get_occ_map": (C.c_int, [_vp, _fp]),
+    "tplhip_dp_env_get_dist_map_path": (C.c_int, [_vp, _fp]),
+    "tplhip_dp_lon_create": (C.c_int, [C.c_int, _P(_vp)]),
+    "tplhip_dp_lon_destroy": (C.c_int, [_vp]),
+    "tplhip_dp_lon_reinit": (C.c_int, [_vp, _P(TplDpLonParams)]),
+    "tplhip_dp_lon_update": (C.c_int, [_vp, _P(TplLonState), _fp, _vp, _P(TplLonState)]),
+    "tplhip_dp_lon_update_batch": (C.c_int, [_vp, C.c_int, _P(TplLonState), _fp, _vp, _P(TplLonState)]),
+    "tplhip_dp_lon_reeval": (C.c_int, [_vp, _P(TplLonState), C.c_int, _fp, _vp, _P(TplLonState)]),
+    "tplhip_dp_lon_copy_table": (C.c_int, [_vp, C.c_int, _fp]),
+    "tplhip_dp_lon_upload": (C.c_int, [_vp, C.c_int, _P(TplLonState), _fp]),
+    "tplhip_dp_lon_plan_resident": (C.c_int, [_vp, _vp]),
+    "tplhip_dp_lon_sync": (C.c_int, [_vp]),
+    "tplhip_dp_lon_download": (C.c_int, [_vp, _P(TplLonState)]),
+    "tplhip_dp_lon_timing_enable": (C.c_int, [_vp, C.c_int]),
+    "tplhip_dp_lon_timing_get": (C.c_int, [_vp, _P(C.c_double), _P(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load ``libtplhip.so`` (once).  Raises ``ImportError`` if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C tpl_amd/csrc`. tpl_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    try:
+        from . import _capi_ilqr
+        _capi_ilqr.declare(lib)
+    except ImportError:
+        pass
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().tplhip_last_error()
+    return msg.decode("utf8", "replace") if msg else ""
+
+
+def check(rc):
+    """Map a status code to the exception type the reference raises."""
+    if rc == TPLHIP_OK:
+        return
+    msg = last_error()
+    if rc == TPLHIP_EINVAL:
+        raise ValueError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,994 @@
+// dp_lon.hip -- HP-1: DP (s,v,a) longitudinal planner, hand-written for gfx950.
+//
+// Replaces library/src/dyn_prog/lon_planner.cu (+ the updateDistMapPath slice
+// of env.cu) of the reference behind the C-ABI of include/tplhip.h.  This is a
+// re-design, not a translation:
+//
+//  * value tables are plain HBM arrays float4[t][a][v][s] (s fastest); the
+//    tex3D hardware filter of the reference is the software filter of
+//    dp_lon_math.h (rules R2/R3);
+//  * one backward stage = one launch of k_backward.  A workgroup owns whole
+//    (v,a) rows.  Because the successor (v',a') of action k and its two blend
+//    weights are the same for every station of a row, the row first blends the
+//    four neighbouring next-stage rows into ONE row per action, staged in LDS
+//    (coalesced 16 B/lane reads along s), and each cell then finishes with a
+//    1-D lerp between two LDS entries.  Per-(row,action) constants come from a
+//    descriptor table through scalar loads (SGPRs), per-(stage,station)
+//    constants from a prelude table;
+//  * stages are enqueued back to back on one HIP stream -- no host sync
+//    between sweeps (the reference synchronises after every stage,
+//    lon_planner.cu:358);
+//  * the forward rollout is ONE launch: one wavefront per rollout, the 21
+//    candidate jerks across lanes, lexicographic wave-level argmin.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dp_lon_math.h"
+#include "tplhip_common.h"
+
+using namespace tplhip;
+
+namespace {
+
+constexpr int N_BWD = 9;    // evalNode<9>,  lon_planner.cu:201
+constexpr int N_FWD = 21;   // evalNode<21>, lon_planner.cu:220
+
+// Per-(row, action) constants of the backward sweep.  Everything here depends
+// only on (v, a, jerk_k, dt) -- never on the station or the stage.
+struct alignas(16) ActDesc {
+    double a_term;      // ((0.5*a)*dt)*dt             lon_planner.cu:244
+    double j_term;      // ((((1/6)*j)*dt)*dt)*dt      lon_planner.cu:244
+    double tn_v_d;      // (double) successor velocity lon_planner.cu:245
+    float vdt;          // v*dt
+    float j;            // jerk of this action
+    float wj_cost;      // stateActionCost             lon_planner.cu:57-64
+    float amin_viol;    // a_min - a'  if a' < a_min else 0
+    float amax_viol;    // a' - a_max  if a' > a_max else 0
+    float wa, wv;       // quantised blend weights along a and v (rule R2)
+    short a0, a1, v0, v1;   // clamped texel rows
+    int pad;
+};
+static_assert(sizeof(ActDesc) == 64, "ActDesc must be 64 bytes");
+
+// ------------------------------------------------------------------------
+// descriptor table: one thread per (row, action)
+// ------------------------------------------------------------------------
+__global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p)
+{
+    const int nrows = p.v_steps * p.a_steps;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * N_BWD) return;
+    const int row = idx / N_BWD;
+    const int k = idx - row * N_BWD;
+    const int ia = row / p.v_steps;
+    const int iv = row - ia * p.v_steps;
+
+    TplLonState tp;
+    tp.t = 0.0f; tp.s = 0.0f; tp.j = 0.0f; tp.cost = 0.0f; tp.constr = 0.0f;
+    tp.v = p.v_min + (float)iv * p._v_step_size;      // lon_planner.cu:198
+    tp.a = p.a_min + (float)ia * p._a_step_size;      // lon_planner.cu:199
+    const float dt = p.dt;
+    const float j = action_jerk(p, k, N_BWD);
+    const TplLonState tn = lon_dynamics(tp, j, dt);
+
+    ActDesc d;
+    d.a_term = ((0.5 * (double)tp.a) * (double)dt) * (double)dt;
+    d.j_term = ((((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt) * (double)dt;
+    d.tn_v_d = (double)tn.v;
+    d.vdt = tp.v * dt;
+    d.j = j;
+    d.wj_cost = state_action_cost(p, j, dt);
+    d.amin_viol = (tn.a < p.a_min) ? (p.a_min - tn.a) : 0.0f;
+    d.amax_viol = (tn.a > p.a_max) ? (tn.a - p.a_max) : 0.0f;
+    const Tap tv = make_tap(node_coord(tn.v, p.v_min, p.v_max, p.v_steps), p.v_steps);
+    const Tap ta = make_tap(node_coord(tn.a, p.a_min, p.a_max, p.a_steps), p.a_steps);
+    d.wa = ta.w; d.wv = tv.w;
+    d.a0 = (short)ta.i0; d.a1 = (short)ta.i1;
+    d.v0 = (short)tv.i0; d.v1 = (short)tv.i1;
+    d.pad = 0;
+    acts[idx] = d;
+}
+
+// ------------------------------------------------------------------------
+// per-(stage, station) prelude: interpPath(tp.s), dist map lookup, progress
+// cost.  evalNode lon_planner.cu:80-86.  grid = t_steps blocks.
+// ------------------------------------------------------------------------
+__global__ void k_stage_prelude(float* __restrict__ pre_vmax, float* __restrict__ pre_sdist,
+                                double* __restrict__ pre_prog,
+                                const float* __restrict__ path, const float* __restrict__ dist_ts,
+                                TplDpLonParams p, TplDpEnvParams ep)
+{
+    const int idx_t = blockIdx.x;
+    if (idx_t < 1) return;
+    const float t = p.dt_start + (float)(idx_t - 1) * p.dt;       // lon_planner.cu:196
+    for (int is = threadIdx.x; is < p.s_steps; is += blockDim.x) {
+        const float s = p.s_min + (float)is * p._s_step_size;     // lon_planner.cu:197
+        const PathTap pt = path_tap(s, p.path_step_size, p.path_steps);
+        const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
+        const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
+        const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, t, cps_s)
+                                     - (double)p.length_veh * 0.6);
+        pre_vmax[(size_t)idx_t * p.s_steps + is] = v_max;
+        pre_sdist[(size_t)idx_t * p.s_steps + is] = s_dist;
+        if (idx_t == 1) {
+            pre_prog[is] = (double)p.w_progress * fabs(1000.0 - (double)s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
+// backward stage sweep (lonBackwardStep, lon_planner.cu:180-209)
+//
+// blockDim.x = s_pad * rows_per_block, s_pad = s_steps rounded up to 64, so a
+// wavefront never straddles two rows and the row index is wave-uniform.
+// KCHUNK actions are blended into LDS per barrier.
+// LDS: float4 R[KCHUNK][blockDim] | float path_vmax[path_steps]
+// ------------------------------------------------------------------------
+template <bool TERMINAL, int KCHUNK>
+__global__ void k_backward(const float4* __restrict__ next, float4* __restrict__ out,
+                           const ActDesc* __restrict__ acts,
+                           const float* __restrict__ path,
+                           const float* __restrict__ pre_vmax,    // this stage, [s_steps]
+                           const float* __restrict__ pre_sdist,   // this stage, [s_steps]
+                           const double* __restrict__ pre_prog,   // [s_steps]
+                           TplDpLonParams p, int s_pad, int rows_per_block, int nblocks)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so
+    // give each XCD one contiguous chunk of rows; neighbouring rows read
+    // overlapping next-stage rows and meet in that XCD's L2.  Placement only
+    // affects speed.
+    const int chunk = gridDim.x >> 3;
+    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (lb >= nblocks) return;
+
+    const int S = p.s_steps, V = p.v_steps;
+    const int nrows = V * p.a_steps;
+    const int tid = threadIdx.x;
+    const int rib = tid / s_pad;
+    const int is = tid - rib * s_pad;
+    const int row = __builtin_amdgcn_readfirstlane(lb * rows_per_block + rib);
+    const bool row_ok = row < nrows;
+    const bool active = row_ok && is < S;
+    const int ia = row / V;
+    const int iv = row - ia * V;
+
+    const float s = p.s_min + (float)is * p._s_step_size;
+    const float v = p.v_min + (float)iv * p._v_step_size;
+    const float a = p.a_min + (float)ia * p._a_step_size;
+
+    float v_max = 0.0f, s_dist = 0.0f;
+    double prog = 0.0;
+    if (active) {
+        v_max = pre_vmax[is];
+        s_dist = pre_sdist[is];
+        prog = pre_prog[is];
+    }
+
+    // stateCost lon_planner.cu:40-55 (progress term precomputed per station)
+    float sc = 0.0f;
+    sc += p.w_a * (a * a);
+    sc = (float)((double)sc + prog);
+    {
+        const float gap = v * p.time_gap + p.gap_min - s_dist;
+        const double m = fmax(0.0, (double)gap);
+        sc = (float)((double)sc + (double)p.w_safety_dist * m);
+    }
+    float sg = 0.0f;
+    if (v > v_max) sg += v - v_max;
+
+    if (TERMINAL) {
+        // lon_planner.cu:93-97: cost only; constr and j keep their zero init
+        if (active) out[(size_t)row * S + is] = make_float4(sc, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+
+    float4* R = reinterpret_cast<float4*>(smem);
+    float* pv = reinterpret_cast<float*>(smem + (size_t)KCHUNK * blockDim.x * sizeof(float4));
+    for (int i = tid; i < p.path_steps; i += blockDim.x) pv[i] = path[i * 7 + 5];
+
+    float res_c[N_BWD], res_g[N_BWD];
+
+#pragma unroll
+    for (int k0 = 0; k0 < N_BWD; k0 += KCHUNK) {
+        if (k0 > 0) __syncthreads();       // everyone is done reading R of the last chunk
+        // ---- phase 1: blend the four neighbouring next-stage rows (a, then v)
+#pragma unroll
+        for (int kk = 0; kk < KCHUNK; ++kk) {
+            const int k = k0 + kk;
+            if (active) {
+                const ActDesc* d = acts + (size_t)row * N_BWD + k;
+                const int a0 = d->a0, a1 = d->a1, v0 = d->v0, v1 = d->v1;
+                const float wa = d->wa, wv = d->wv;
+                const float4* r00 = next + ((size_t)a0 * V + v0) * S;
+                const float4* r10 = next + ((size_t)a1 * V + v0) * S;
+                const float4* r01 = next + ((size_t)a0 * V + v1) * S;
+                const float4* r11 = next + ((size_t)a1 * V + v1) * S;
+                const float4 b0 = lerp4(r00[is], r10[is], wa);
+                const float4 b1 = lerp4(r01[is], r11[is], wa);
+                R[kk * blockDim.x + tid] = lerp4(b0, b1, wv);
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: per-cell successor station, 1-D lerp, costs
+#pragma unroll
+        for (int kk = 0; kk < KCHUNK; ++kk) {
+            const int k = k0 + kk;
+            float c = 0.0f, g = 0.0f;
+            if (active) {
+                const ActDesc* d = acts + (size_t)row * N_BWD + k;
+                // lonDynamics station part, lon_planner.cu:244
+                const float sf = s + d->vdt;
+                double sd = (double)sf + d->a_term;
+                sd = sd + d->j_term;
+                const float tn_s = fmaxf(s, (float)sd);
+                // value table lookup along s
+                const Tap ts = make_tap(node_coord(tn_s, p.s_min, p.s_max, S), S);
+                const float4* Rk = R + kk * blockDim.x + rib * s_pad;
+                const float4 node = lerp4(Rk[ts.i0], Rk[ts.i1], ts.w);
+                // interpPath(tn.s).v_max, lon_planner.cu:114
+                const PathTap pt = path_tap(tn_s, p.path_step_size, p.path_steps);
+                const float vmn = path_lerp(pt, pv[pt.i0], pv[pt.i1]);
+
+                c = sc;
+                g = sg;
+                c += node.x;
+                g += node.y;
+                c += p.w_snap * ((node.z - d->j) * (node.z - d->j));
+                c += d->wj_cost;
+                const double vmn_d = (double)vmn;
+                if (d->tn_v_d > vmn_d) {
+                    g = (float)((double)g + (d->tn_v_d - vmn_d));
+                }
+                const float s_change = tn_s - s;
+                if (s_change > s_dist) {
+                    g += s_change - s_dist;
+                }
+                g += d->amin_viol;      // adding +0 when not violated leaves g unchanged
+                g += d->amax_viol;
+            }
+            res_c[k] = c;
+            res_g[k] = g;
+        }
+    }
+
+    if (!active) return;
+
+    // lexicographic argmin, lon_planner.cu:153-170
+    float constr_min = INFINITY;
+#pragma unroll
+    for (int k = 0; k < N_BWD; ++k) {
+        if (res_g[k] < constr_min) constr_min = res_g[k];
+    }
+    float cost_min = INFINITY;
+    int idx_min = 0;
+#pragma unroll
+    for (int k = 0; k < N_BWD; ++k) {
+        if (res_g[k] > constr_min) continue;
+        if (res_c[k] < cost_min) {
+            cost_min = res_c[k];
+            idx_min = k;
+        }
+    }
+    const float j_best = action_jerk(p, idx_min, N_BWD);
+    out[(size_t)row * S + is] = make_float4(cost_min, constr_min, j_best, 0.0f);
+}
+
+// ------------------------------------------------------------------------
+// evalNode at an arbitrary trajectory point, one wavefront, action k on lane k.
+// All lanes hold the same tp.  lon_planner.cu:72-178
+// ------------------------------------------------------------------------
+__device__ __forceinline__ float wave_min(float x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fminf(x, __shfl_xor(x, off, 64));
+    return x;
+}
+
+template <int N>
+__device__ __forceinline__ void eval_node_wave(TplLonState& tp, const float4* __restrict__ table_next,
+                                               const float* __restrict__ path,
+                                               const float* __restrict__ dist_ts,
+                                               const TplDpLonParams& p, const TplDpEnvParams& ep,
+                                               float dt, bool choose_action)
+{
+    const int lane = threadIdx.x & 63;
+
+    const PathTap pt = path_tap(tp.s, p.path_step_size, p.path_steps);
+    const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
+    const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
+    const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, tp.t, cps_s)
+                                 - (double)p.length_veh * 0.6);
+    const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist);
+    float sg = 0.0f;
+    if (tp.v > v_max) sg += tp.v - v_max;
+
+    if (roundf(tp.t / p.dt) == (float)(p.t_steps - 1)) {    // lon_planner.cu:93-97
+        tp.cost = sc;
+        return;
+    }
+
+    const int k = choose_action ? lane : 0;
+    const float j = choose_action ? action_jerk(p, k < N ? k : N - 1, N) : tp.j;
+    const TplLonState tn = lon_dynamics(tp, j, dt);
+    const float4 node = read_node(p, table_next, tn.s, tn.v, tn.a);
+    const PathTap pn = path_tap(tn.s, p.path_step_size, p.path_steps);
+    const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5]);
+    const ActionResult r = eval_action_tail(p, sc, sg, node, j, state_action_cost(p, j, dt),
+                                            tn.s, tn.v, tn.a, tp.s, s_dist, vmn);
+    if (!choose_action) {
+        tp.cost = r.cost;
+        tp.constr = r.constr;
+        return;
+    }
+
+    const bool valid = lane < N;
+    // constr_min: NaN never lowers the minimum (lon_planner.cu:155)
+    const float g_in = (valid && !(r.constr != r.constr)) ? r.constr : INFINITY;
+    const float constr_min = wave_min(g_in);
+    // candidates: not (constr > constr_min)  -- NaN constr stays a candidate (:163)
+    const bool cand = valid && !(r.constr > constr_min);
+    // first strictly smallest cost among candidates (:166); NaN / +inf cost never selected
+    const float c_in = (cand && r.cost < INFINITY) ? r.cost : INFINITY;
+    const float cost_min = wave_min(c_in);
+    const unsigned long long hit = __ballot(cand && c_in == cost_min && cost_min < INFINITY);
+    const int idx_min = hit ? (int)__builtin_ctzll(hit) : 0;
+
+    tp.j = action_jerk(p, idx_min, N);
+    tp.cost = cost_min;
+    tp.constr = constr_min;
+}
+
+// lonForwardStep chain, lon_planner.cu:211-225 + :365-386.  One wave per rollout.
+__global__ void k_forward(TplLonState* __restrict__ trajs, const TplLonState* __restrict__ inits,
+                          const float4* __restrict__ tables, size_t table_cells,
+                          const float* __restrict__ path, const float* __restrict__ dist_ts,
+                          TplDpLonParams p, TplDpEnvParams ep)
+{
+    const int r = blockIdx.x;
+    const int T = p.t_steps;
+    TplLonState tp = inits[r];
+    for (int i = 0; i < T; ++i) {
+        const float dt = (i == 0) ? p.dt_start : p.dt;
+        const int nx = min(T - 1, i + 1);
+        eval_node_wave<N_FWD>(tp, tables + (size_t)nx * table_cells, path, dist_ts, p, ep, dt, true);
+        if ((threadIdx.x & 63) == 0) trajs[(size_t)r * T + i] = tp;
+        if (i < T - 1) tp = lon_dynamics(tp, tp.j, dt);
+    }
+}
+
+// lonReevalNode, lon_planner.cu:227-236 + :439-455: nodes are independent, one thread each
+__global__ void k_reeval(TplLonState* __restrict__ traj,
+                         const float4* __restrict__ tables, size_t table_cells,
+                         const float* __restrict__ path, const float* __restrict__ dist_ts,
+                         TplDpLonParams p, TplDpEnvParams ep)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int T = p.t_steps;
+    if (i >= T) return;
+    TplLonState tp = traj[i];
+    const float dt = (i == 0) ? p.dt_start : p.dt;
+    const int nx = min(T - 1, i + 1);
+    const float4* table_next = tables + (size_t)nx * table_cells;
+
+    const PathTap pt = path_tap(tp.s, p.path_step_size, p.path_steps);
+    const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
+    const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
+    const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, tp.t, cps_s)
+                                 - (double)p.length_veh * 0.6);
+    const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist);
+    float sg = 0.0f;
+    if (tp.v > v_max) sg += tp.v - v_max;
+    if (roundf(tp.t / p.dt) == (float)(p.t_steps - 1)) {
+        tp.cost = sc;
+    } else {
+        const float j = tp.j;
+        const TplLonState tn = lon_dynamics(tp, j, dt);
+        const float4 node = read_node(p, table_next, tn.s, tn.v, tn.a);
+        const PathTap pn = path_tap(tn.s, p.path_step_size, p.path_steps);
+        const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5]);
+        const ActionResult r = eval_action_tail(p, sc, sg, node, j, state_action_cost(p, j, dt),
+                                                tn.s, tn.v, tn.a, tp.s, s_dist, vmn);
+        tp.cost = r.cost;
+        tp.constr = r.constr;
+    }
+    traj[i] = tp;
+}
+
+// ------------------------------------------------------------------------
+// updateDistMapPath, env.cu:131-158.  One block per time slice: the occupancy
+// lookups run in parallel into LDS, then one lane does the (order-dependent,
+// float-accumulating) backward scan, then the slice is written coalesced.
+// occ: [l][s][t] (t fastest).  dist: [t][s].
+// ------------------------------------------------------------------------
+__global__ void k_dist_map_path(float* __restrict__ dist_ts, const float* __restrict__ occ_lst,
+                                const float* __restrict__ path, int path_steps, float path_step_size,
+                                TplDpEnvParams ep)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* d_sh = reinterpret_cast<float*>(smem);      // [s_steps]: occupancy flag, then distance
+    const int idx_t = blockIdx.x;
+    const int S = ep.s_steps;
+    for (int idx_s = threadIdx.x; idx_s < S; idx_s += blockDim.x) {
+        const float s = ep.s_min + (float)idx_s * ep._s_step_size;
+        const PathTap pt = path_tap(s, path_step_size, path_steps);
+        const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
+        const float cps_l = path_lerp(pt, path[pt.i0 * 7 + 3], path[pt.i1 * 7 + 3]);
+        float fs = (cps_s - ep.s_min) / ep._s_step_size;
+        float fl = (cps_l - ep.l_min) / ep._l_step_size;
+        fs = fminf(fmaxf(fs, -1.0f), (float)ep.s_steps);
+        fl = fminf(fmaxf(fl, -1.0f), (float)ep.l_steps);
+        const int js = clampi((int)fs, 0, ep.s_steps - 1);
+        const int jl = clampi((int)fl, 0, ep.l_steps - 1);
+        d_sh[idx_s] = occ_lst[((size_t)jl * ep.s_steps + js) * ep.t_steps + idx_t];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float d = 10000.0f;
+        for (int idx_s = S - 1; idx_s >= 0; --idx_s) {
+            if (d_sh[idx_s] > 0.0f) d = 0.0f; else d += ep._s_step_size;
+            d_sh[idx_s] = d;
+        }
+    }
+    __syncthreads();
+    for (int idx_s = threadIdx.x; idx_s < S; idx_s += blockDim.x) {
+        dist_ts[(size_t)idx_t * S + idx_s] = d_sh[idx_s];
+    }
+}
+
+} // namespace
+
+// ==========================================================================
+// host side
+// ==========================================================================
+
+struct tplhip_dp_env {
+    int device = 0;
+    TplDpEnvParams params;
+    bool have_params = false;
+    float* d_occ = nullptr;     // [l][s][t]
+    float* d_dist = nullptr;    // [t][s]
+    bool have_occ = false;
+};
+
+struct tplhip_dp_lon {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    TplDpLonParams params;
+    bool have_params = false;
+
+    float4* d_tables = nullptr;         // [t_steps][a][v][s]
+    size_t table_cells = 0;
+    ActDesc* d_acts = nullptr;          // [a*v][9]
+    float* d_path = nullptr;            // [path_steps][7]
+    float* d_pre_vmax = nullptr;        // [t_steps][s]
+    float* d_pre_sdist = nullptr;       // [t_steps][s]
+    double* d_pre_prog = nullptr;       // [s]
+    TplLonState* d_inits = nullptr;
+    TplLonState* d_trajs = nullptr;
+    int cap_rollouts = 0;
+    int n_rollouts = 0;
+    bool tables_valid = false;
+
+    // launch geometry of k_backward
+    int s_pad = 0, rows_per_block = 0, nblocks = 0, grid = 0, kchunk = 0;
+    size_t lds_bytes = 0;
+
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double sweep_ms = 0.0;
+    int64_t sweep_launches = 0;
+};
+
+namespace {
+
+void update_step_sizes(TplDpLonParams* p)      // lon_planner.cuh:45-50
+{
+    p->_s_step_size = (p->s_max - p->s_min) / (float)(p->s_steps - 1);
+    p->_v_step_size = (p->v_max - p->v_min) / (float)(p->v_steps - 1);
+    p->_a_step_size = (p->a_max - p->a_min) / (float)(p->a_steps - 1);
+}
+
+void env_update_step_sizes(TplDpEnvParams* p)  // env.cuh:39-43
+{
+    p->_l_step_size = (p->l_max - p->l_min) / (float)(p->l_steps - 1);
+    p->_s_step_size = (p->s_max - p->s_min) / (float)(p->s_steps - 1);
+}
+
+int pick_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -1;
+    if (device < 0) device = n - 1;        // tpl/planning/__init__.py:2-7 picks the last device
+    if (device >= n) return -1;
+    return device;
+}
+
+void free_planner_buffers(tplhip_dp_lon* h)
+{
+    hipFree(h->d_tables);    h->d_tables = nullptr;
+    hipFree(h->d_acts);      h->d_acts = nullptr;
+    hipFree(h->d_path);      h->d_path = nullptr;
+    hipFree(h->d_pre_vmax);  h->d_pre_vmax = nullptr;
+    hipFree(h->d_pre_sdist); h->d_pre_sdist = nullptr;
+    hipFree(h->d_pre_prog);  h->d_pre_prog = nullptr;
+    h->tables_valid = false;
+}
+
+int ensure_rollouts(tplhip_dp_lon* h, int n)
+{
+    const int T = h->params.t_steps;
+    if (n <= h->cap_rollouts && h->d_trajs) return TPLHIP_OK;
+    hipFree(h->d_inits); hipFree(h->d_trajs);
+    h->d_inits = nullptr; h->d_trajs = nullptr; h->cap_rollouts = 0;
+    HIP_TRY(hipMalloc(&h->d_inits, sizeof(TplLonState) * (size_t)n), "rollout init allocation failed");
+    HIP_TRY(hipMalloc(&h->d_trajs, sizeof(TplLonState) * (size_t)n * T), "trajectory allocation failed");
+    h->cap_rollouts = n;
+    return TPLHIP_OK;
+}
+
+int check_env(tplhip_dp_lon* h, tplhip_dp_env* env)
+{
+    if (!h || !env) return tplhip_fail(TPLHIP_EINVAL, "null handle");
+    if (!h->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the planner");
+    if (!env->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the environment");
+    if (!env->have_occ) return tplhip_fail(TPLHIP_ESTATE, "environment holds no occupancy map");
+    if (env->device != h->device) return tplhip_fail(TPLHIP_EINVAL, "planner and environment live on different devices");
+    return TPLHIP_OK;
+}
+
+template <bool TERMINAL, int KCHUNK>
+void launch_backward(tplhip_dp_lon* h, int idx_t, int nx)
+{
+    const size_t S = (size_t)h->params.s_steps;
+    const size_t lds = TERMINAL ? 0 : h->lds_bytes;
+    hipLaunchKernelGGL((k_backward<TERMINAL, KCHUNK>), dim3(h->grid), dim3(h->s_pad * h->rows_per_block),
+                       lds, h->stream,
+                       h->d_tables + (size_t)nx * h->table_cells,
+                       h->d_tables + (size_t)idx_t * h->table_cells,
+                       h->d_acts, h->d_path,
+                       h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
+                       h->d_pre_prog, h->params, h->s_pad, h->rows_per_block, h->nblocks);
+}
+
+// device part of DynProgLonPlanner::update (lon_planner.cu:341-388), all async on h->stream
+int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env)
+{
+    const TplDpLonParams& p = h->params;
+    const int T = p.t_steps;
+
+    // env.updateDistMapPath, lon_planner.cu:343
+    hipLaunchKernelGGL(k_dist_map_path, dim3(env->params.t_steps), dim3(256),
+                       sizeof(float) * (size_t)env->params.s_steps, h->stream,
+                       env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params);
+    hipLaunchKernelGGL(k_stage_prelude, dim3(T), dim3(256), 0, h->stream,
+                       h->d_pre_vmax, h->d_pre_sdist, h->d_pre_prog, h->d_path, env->d_dist, p, env->params);
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing) {
+        HIP_TRY(hipEventCreate(&e0), "event creation failed");
+        HIP_TRY(hipEventCreate(&e1), "event creation failed");
+        HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
+    }
+    // backward pass, lon_planner.cu:347-361 -- no host sync between stages
+    for (int i = T - 1; i > 0; --i) {
+        const int nx = std::min(T - 1, i + 1);
+        if (i == T - 1) {
+            launch_backward<true, 9>(h, i, nx);                  // rule R4
+        } else if (h->kchunk == 9) {
+            launch_backward<false, 9>(h, i, nx);
+        } else if (h->kchunk == 3) {
+            launch_backward<false, 3>(h, i, nx);
+        } else {
+            launch_backward<false, 1>(h, i, nx);
+        }
+    }
+    if (h->timing) {
+        HIP_TRY(hipEventRecord(e1, h->stream), "event record failed");
+        h->events.emplace_back(e0, e1);
+        h->sweep_launches += (T - 1);
+    }
+    // forward pass, lon_planner.cu:365-386 -- one launch
+    hipLaunchKernelGGL(k_forward, dim3(h->n_rollouts), dim3(64), 0, h->stream,
+                       h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
+                       h->d_path, env->d_dist, p, env->params);
+    HIP_TRY(hipGetLastError(), "lon planner launch failed");
+    h->tables_valid = true;
+    return TPLHIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void tplhip_dp_lon_params_default(TplDpLonParams* p)
+{
+    // lon_planner.cuh:9-43
+    p->s_min = 0.0f; p->s_max = 200.0f; p->v_min = 0.0f; p->v_max = 36.0f;
+    p->a_min = -2.0f; p->a_max = 2.0f; p->j_min = -2.0f; p->j_max = 2.0f;
+    p->t_steps = 10; p->s_steps = 201; p->v_steps = 37; p->a_steps = 7;
+    p->dt_start = 1.0f; p->dt = 1.0f;
+    p->_s_step_size = 0.0f; p->_v_step_size = 0.0f; p->_a_step_size = 0.0f;
+    p->time_gap = 1.5f; p->gap_min = 1.0f;
+    p->w_progress = 1.0f; p->w_a = 0.5f; p->w_j = 0.5f; p->w_snap = 0.5f; p->w_safety_dist = 10.0f;
+    p->path_step_size = 0.5f; p->path_steps = 200;
+    p->width_veh = 2.0f; p->length_veh = 6.0f;
+}
+
+void tplhip_dp_env_params_default(TplDpEnvParams* p)
+{
+    // env.cuh:13-37
+    p->t_min = 0.0f; p->t_max = 10.0f; p->l_min = -5.0f; p->l_max = 5.0f;
+    p->s_min = 0.0f; p->s_max = 200.0f; p->ds_max = 36.0f;
+    p->dir_min = (float)-M_PI_2; p->dir_max = (float)M_PI_2;
+    p->dt = 1.0f; p->dt_start = 1.0f;
+    p->t_steps = 10; p->l_steps = 21; p->s_steps = 201; p->dir_steps = 21;
+    p->scale_objects = 1.0f; p->dilation = 2.0f;
+    p->_l_step_size = 0.0f; p->_s_step_size = 0.0f;
+}
+
+// ---- host-only helpers -----------------------------------------------------
+
+void tplhip_lon_dynamics(const TplLonState* x0, float j, float dt, TplLonState* out)
+{
+    // lon_planner.cu:240-250 (host instantiation of the __interop__ function)
+    TplLonState r;
+    r.t = x0->t + dt;
+    float sf = x0->s + x0->v * dt;
+    double sd = (double)sf + ((0.5 * (double)x0->a) * (double)dt) * (double)dt;
+    sd = sd + ((((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt) * (double)dt;
+    r.s = fmaxf(x0->s, (float)sd);
+    float vf = x0->v + x0->a * dt;
+    double vd = (double)vf + ((0.5 * (double)j) * (double)dt) * (double)dt;
+    r.v = fmaxf(0.0f, (float)vd);
+    r.a = x0->a + j * dt;
+    r.j = j;
+    r.cost = 0.0f;
+    r.constr = 0.0f;
+    *out = r;
+}
+
+int tplhip_lon_traj_state(const TplLonState* states, int n, float t, TplLonState* out)
+{
+    // LonTraj::state lon_planner.cu:252-260; bracket search InterpVars utils.hpp:59-78
+    if (!states || !out || n < 2) return tplhip_fail(TPLHIP_EINVAL, "trajectory needs at least two states");
+    const double v = (double)t;
+    int i_prev = 0;
+    if (v < (double)states[0].t) {
+        i_prev = 0;
+    } else if (v >= (double)states[n - 1].t) {
+        i_prev = n - 2;
+    } else {
+        for (int i = 1; i < n; ++i) {
+            if ((double)states[i - 1].t <= v && v < (double)states[i].t) { i_prev = i - 1; break; }
+        }
+    }
+    const float t_rel = t - states[i_prev].t;
+    tplhip_lon_dynamics(&states[i_prev], states[i_prev].j, t_rel, out);
+    return TPLHIP_OK;
+}
+
+// ---- environment -------------------------------------------------------------
+
+int tplhip_dp_env_create(int device, tplhip_dp_env** out)
+{
+    if (!out) return tplhip_fail(TPLHIP_EINVAL, "null out pointer");
+    const int dev = pick_device(device);
+    if (dev < 0) return tplhip_fail(TPLHIP_EDEVICE, "no usable HIP device (requested %d)", device);
+    tplhip_dp_env* e = new (std::nothrow) tplhip_dp_env();
+    if (!e) return tplhip_fail(TPLHIP_EDEVICE, "out of host memory");
+    e->device = dev;
+    tplhip_dp_env_params_default(&e->params);
+    *out = e;
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_env_destroy(tplhip_dp_env* env)
+{
+    if (!env) return TPLHIP_OK;
+    hipSetDevice(env->device);
+    hipFree(env->d_occ);
+    hipFree(env->d_dist);
+    delete env;
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_env_reinit(tplhip_dp_env* env, TplDpEnvParams* ps)
+{
+    if (!env || !ps) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (ps->t_steps < 1 || ps->s_steps < 2 || ps->l_steps < 2)
+        return tplhip_fail(TPLHIP_EINVAL, "environment needs t_steps >= 1, s_steps >= 2, l_steps >= 2");
+    HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
+    env_update_step_sizes(ps);
+    const bool full = !env->have_params || ps->t_steps != env->params.t_steps
+                      || ps->l_steps != env->params.l_steps || ps->s_steps != env->params.s_steps;
+    env->params = *ps;
+    env->have_params = true;
+    if (!full) return TPLHIP_OK;
+    hipFree(env->d_occ); hipFree(env->d_dist);
+    env->d_occ = nullptr; env->d_dist = nullptr;
+    const size_t n_occ = (size_t)ps->l_steps * ps->s_steps * ps->t_steps;
+    const size_t n_dist = (size_t)ps->t_steps * ps->s_steps;
+    HIP_TRY(hipMalloc(&env->d_occ, n_occ * sizeof(float)), "occupancy map allocation failed");
+    HIP_TRY(hipMalloc(&env->d_dist, n_dist * sizeof(float)), "distance map allocation failed");
+    // a freshly allocated cudaArray is read as all-free road until update() ran
+    HIP_TRY(hipMemset(env->d_occ, 0, n_occ * sizeof(float)), "occupancy map clear failed");
+    HIP_TRY(hipMemset(env->d_dist, 0, n_dist * sizeof(float)), "distance map clear failed");
+    env->have_occ = true;
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_env_set_occ_map(tplhip_dp_env* env, const float* occ_lst)
+{
+    if (!env || !occ_lst) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (!env->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the environment");
+    HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
+    const size_t n = (size_t)env->params.l_steps * env->params.s_steps * env->params.t_steps;
+    HIP_TRY(hipMemcpy(env->d_occ, occ_lst, n * sizeof(float), hipMemcpyHostToDevice), "copying occupancy map failed");
+    env->have_occ = true;
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_env_get_occ_map(tplhip_dp_env* env, float* occ_lst)
+{
+    if (!env || !occ_lst) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (!env->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the environment");
+    HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
+    const size_t n = (size_t)env->params.l_steps * env->params.s_steps * env->params.t_steps;
+    HIP_TRY(hipMemcpy(occ_lst, env->d_occ, n * sizeof(float), hipMemcpyDeviceToHost), "copying occupancy map failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_env_get_dist_map_path(tplhip_dp_env* env, float* dist_ts)
+{
+    if (!env || !dist_ts) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (!env->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the environment");
+    HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
+    const size_t n = (size_t)env->params.t_steps * env->params.s_steps;
+    HIP_TRY(hipMemcpy(dist_ts, env->d_dist, n * sizeof(float), hipMemcpyDeviceToHost), "copying distance map failed");
+    return TPLHIP_OK;
+}
+
+// ---- planner -----------------------------------------------------------------
+
+int tplhip_dp_lon_create(int device, tplhip_dp_lon** out)
+{
+    if (!out) return tplhip_fail(TPLHIP_EINVAL, "null out pointer");
+    const int dev = pick_device(device);
+    if (dev < 0) return tplhip_fail(TPLHIP_EDEVICE, "no usable HIP device (requested %d)", device);
+    HIP_TRY(hipSetDevice(dev), "hipSetDevice failed");
+    tplhip_dp_lon* h = new (std::nothrow) tplhip_dp_lon();
+    if (!h) return tplhip_fail(TPLHIP_EDEVICE, "out of host memory");
+    h->device = dev;
+    tplhip_dp_lon_params_default(&h->params);
+    hipError_t err = hipStreamCreate(&h->stream);
+    if (err != hipSuccess) {
+        delete h;
+        return tplhip_fail(TPLHIP_EDEVICE, "%s: stream creation failed", hipGetErrorString(err));
+    }
+    *out = h;
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_destroy(tplhip_dp_lon* h)
+{
+    if (!h) return TPLHIP_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (auto& ev : h->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    free_planner_buffers(h);
+    hipFree(h->d_inits);
+    hipFree(h->d_trajs);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
+{
+    if (!h || !ps) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (ps->t_steps < 1 || ps->s_steps < 2 || ps->v_steps < 2 || ps->a_steps < 2 || ps->path_steps < 1)
+        return tplhip_fail(TPLHIP_EINVAL, "planner needs t_steps >= 1, s/v/a_steps >= 2, path_steps >= 1");
+    if (ps->s_steps > 1024)
+        return tplhip_fail(TPLHIP_EINVAL, "s_steps = %d exceeds 1024 (one workgroup spans a row; the reference has the same limit)", ps->s_steps);
+    if (ps->v_steps > 32767 || ps->a_steps > 32767)
+        return tplhip_fail(TPLHIP_EINVAL, "v_steps / a_steps exceed 32767");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    update_step_sizes(ps);                                  // lon_planner.cu:286
+
+    if (h->have_params && std::memcmp(ps, &h->params, sizeof(TplDpLonParams)) == 0) {
+        return TPLHIP_OK;                                   // lon_planner.cu:288-290
+    }
+    const bool resize = !h->have_params || !h->d_tables
+        || ps->t_steps != h->params.t_steps || ps->s_steps != h->params.s_steps
+        || ps->v_steps != h->params.v_steps || ps->a_steps != h->params.a_steps
+        || ps->path_steps != h->params.path_steps;
+
+    HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
+    h->params = *ps;
+    h->have_params = true;
+    h->tables_valid = false;
+    const TplDpLonParams& p = h->params;
+    const size_t S = (size_t)p.s_steps;
+    const int nrows = p.v_steps * p.a_steps;
+
+    if (resize) {
+        free_planner_buffers(h);
+        hipFree(h->d_inits); hipFree(h->d_trajs);
+        h->d_inits = nullptr; h->d_trajs = nullptr; h->cap_rollouts = 0;
+        h->table_cells = S * p.v_steps * p.a_steps;
+        HIP_TRY(hipMalloc(&h->d_tables, sizeof(float4) * h->table_cells * (size_t)p.t_steps), "value table allocation failed");
+        HIP_TRY(hipMemsetAsync(h->d_tables, 0, sizeof(float4) * h->table_cells * (size_t)p.t_steps, h->stream), "value table clear failed");
+        HIP_TRY(hipMalloc(&h->d_acts, sizeof(ActDesc) * (size_t)nrows * N_BWD), "action table allocation failed");
+        HIP_TRY(hipMalloc(&h->d_path, sizeof(float) * 7 * (size_t)p.path_steps), "path array allocation failed");
+        HIP_TRY(hipMalloc(&h->d_pre_vmax, sizeof(float) * S * p.t_steps), "prelude allocation failed");
+        HIP_TRY(hipMalloc(&h->d_pre_sdist, sizeof(float) * S * p.t_steps), "prelude allocation failed");
+        HIP_TRY(hipMalloc(&h->d_pre_prog, sizeof(double) * S), "prelude allocation failed");
+    }
+
+    // launch geometry
+    h->s_pad = ((p.s_steps + 63) / 64) * 64;
+    h->rows_per_block = std::max(1, 256 / h->s_pad);
+    h->nblocks = (nrows + h->rows_per_block - 1) / h->rows_per_block;
+    h->grid = ((h->nblocks + 7) / 8) * 8;
+    const size_t threads = (size_t)h->s_pad * h->rows_per_block;
+    const size_t path_lds = sizeof(float) * (size_t)p.path_steps;
+    const size_t lds_max = 64 * 1024;                       // keep >= 2 workgroups per CU
+    h->kchunk = 9;
+    if (threads * 16 * 9 + path_lds > lds_max) h->kchunk = 3;
+    if (threads * 16 * 3 + path_lds > lds_max) h->kchunk = 1;
+    h->lds_bytes = threads * 16 * (size_t)h->kchunk + path_lds;
+    if (h->lds_bytes > 160 * 1024)
+        return tplhip_fail(TPLHIP_EINVAL, "path_steps = %d does not fit in LDS next to the row buffers", p.path_steps);
+
+    hipLaunchKernelGGL(k_build_actions, dim3((nrows * N_BWD + 255) / 256), dim3(256), 0, h->stream, h->d_acts, p);
+    HIP_TRY(hipGetLastError(), "action table launch failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "building the action table failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_upload(tplhip_dp_lon* h, int n, const TplLonState* inits, const float* path)
+{
+    if (!h || !inits || !path || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
+    if (!h->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the planner");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    int rc = ensure_rollouts(h, n);
+    if (rc) return rc;
+    h->n_rollouts = n;
+    // lon_planner.cu:334-338 and :365-368
+    HIP_TRY(hipMemcpyAsync(h->d_path, path, sizeof(float) * 7 * (size_t)h->params.path_steps,
+                           hipMemcpyHostToDevice, h->stream), "copying path failed");
+    HIP_TRY(hipMemcpyAsync(h->d_inits, inits, sizeof(TplLonState) * (size_t)n,
+                           hipMemcpyHostToDevice, h->stream), "copying initial states failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "upload failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_plan_resident(tplhip_dp_lon* h, tplhip_dp_env* env)
+{
+    int rc = check_env(h, env);
+    if (rc) return rc;
+    if (h->n_rollouts < 1) return tplhip_fail(TPLHIP_ESTATE, "nothing uploaded");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    return enqueue_plan(h, env);
+}
+
+int tplhip_dp_lon_sync(tplhip_dp_lon* h)
+{
+    if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "lon planner pass failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_download(tplhip_dp_lon* h, TplLonState* out_trajs)
+{
+    if (!h || !out_trajs) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (h->n_rollouts < 1) return tplhip_fail(TPLHIP_ESTATE, "nothing to download");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipMemcpyAsync(out_trajs, h->d_trajs, sizeof(TplLonState) * (size_t)h->n_rollouts * h->params.t_steps,
+                           hipMemcpyDeviceToHost, h->stream), "copying trajectory failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "lon planner forward pass failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_update_batch(tplhip_dp_lon* h, int n, const TplLonState* inits,
+                               const float* path, tplhip_dp_env* env, TplLonState* out_trajs)
+{
+    int rc = check_env(h, env);
+    if (rc) return rc;
+    if (!out_trajs) return tplhip_fail(TPLHIP_EINVAL, "null output");
+    rc = tplhip_dp_lon_upload(h, n, inits, path);
+    if (rc) return rc;
+    rc = enqueue_plan(h, env);
+    if (rc) return rc;
+    return tplhip_dp_lon_download(h, out_trajs);
+}
+
+int tplhip_dp_lon_update(tplhip_dp_lon* h, const TplLonState* init, const float* path,
+                         tplhip_dp_env* env, TplLonState* out_traj)
+{
+    return tplhip_dp_lon_update_batch(h, 1, init, path, env, out_traj);
+}
+
+int tplhip_dp_lon_reeval(tplhip_dp_lon* h, const TplLonState* traj, int len, const float* path,
+                         tplhip_dp_env* env, TplLonState* out_traj)
+{
+    int rc = check_env(h, env);
+    if (rc) return rc;
+    if (!traj || !path || !out_traj) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    const TplDpLonParams& p = h->params;
+    if (len != p.t_steps)                                     // lon_planner.cu:423-425
+        return tplhip_fail(TPLHIP_ESTATE, "trajectory size does not match t_steps");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    rc = ensure_rollouts(h, 1);
+    if (rc) return rc;
+    if (h->n_rollouts < 1) h->n_rollouts = 1;
+    HIP_TRY(hipMemcpyAsync(h->d_path, path, sizeof(float) * 7 * (size_t)p.path_steps,
+                           hipMemcpyHostToDevice, h->stream), "copying path failed");
+    HIP_TRY(hipMemcpyAsync(h->d_trajs, traj, sizeof(TplLonState) * (size_t)len,
+                           hipMemcpyHostToDevice, h->stream), "copying trajectory to gpu failed");
+    hipLaunchKernelGGL(k_dist_map_path, dim3(env->params.t_steps), dim3(256),
+                       sizeof(float) * (size_t)env->params.s_steps, h->stream,
+                       env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params);
+    hipLaunchKernelGGL(k_reeval, dim3((len + 63) / 64), dim3(64), 0, h->stream,
+                       h->d_trajs, h->d_tables, h->table_cells, h->d_path, env->d_dist, p, env->params);
+    HIP_TRY(hipGetLastError(), "reeval launch failed");
+    HIP_TRY(hipMemcpyAsync(out_traj, h->d_trajs, sizeof(TplLonState) * (size_t)len,
+                           hipMemcpyDeviceToHost, h->stream), "copying reevaluted trajectory to cpu failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "reeval pass failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_copy_table(tplhip_dp_lon* h, int t, float* out)
+{
+    if (!h || !out) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (!h->have_params || !h->d_tables) return tplhip_fail(TPLHIP_ESTATE, "no value tables allocated");
+    if (t < 0 || t >= h->params.t_steps) return tplhip_fail(TPLHIP_EINVAL, "stage %d out of range", t);
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
+    HIP_TRY(hipMemcpy(out, h->d_tables + (size_t)t * h->table_cells, sizeof(float4) * h->table_cells,
+                      hipMemcpyDeviceToHost), "copying value table failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_timing_enable(tplhip_dp_lon* h, int enable)
+{
+    if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
+    for (auto& ev : h->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    h->events.clear();
+    h->sweep_ms = 0.0;
+    h->sweep_launches = 0;
+    h->timing = enable != 0;
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_timing_get(tplhip_dp_lon* h, double* sweep_ms, int64_t* sweep_launches)
+{
+    if (!h || !sweep_ms || !sweep_launches) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
+    for (auto& ev : h->events) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second), "event query failed");
+        h->sweep_ms += (double)ms;
+        hipEventDestroy(ev.first);
+        hipEventDestroy(ev.second);
+    }
+    h->events.clear();
+    *sweep_ms = h->sweep_ms;
+    *sweep_launches = h->sweep_launches;
+    return TPLHIP_OK;
+}
+
+} // extern "C"

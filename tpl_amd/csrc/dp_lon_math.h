@@ -1,0 +1,207 @@
+// dp_lon_math.h -- device-side arithmetic of the DP (s,v,a) planner for gfx950.
+//
+// Every function states the reference lines it follows.  The arithmetic
+// contract (DESIGN.md "HP-1 arithmetic contract", rules R1-R4) is:
+//   R1  types exactly as the reference source promotes them, one rounding per
+//       operation, no FMA contraction (this TU is built -ffp-contract=off);
+//   R2  tex3D linear filter = floor/frac of (x-0.5), weight quantised to 8
+//       fractional bits, clamp addressing;
+//   R3  trilinear order a -> v -> s, lerp(p,q,w) = fmaf(q, w, p*(1-w));
+//   R4  stage t_steps-1 is always terminal in the backward sweep.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include "../../include/tplhip.h"
+
+namespace tplhip {
+
+struct Tap { int i0, i1; float w; };
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
+
+// R2.  x_plus_half is the coordinate as handed to tex3D (arr_tex_surf.cuh:142-149).
+__device__ __forceinline__ Tap make_tap(float x_plus_half, int n)
+{
+    Tap t;
+    float xb = x_plus_half - 0.5f;
+    float fl = floorf(xb);
+    float alpha = xb - fl;
+    t.w = rintf(alpha * 256.0f) / 256.0f;          // power-of-two scaling: exact
+    float lo = fminf(fmaxf(fl, -1.0f), (float)n);
+    int i = (int)lo;
+    t.i0 = clampi(i, 0, n - 1);
+    t.i1 = clampi(i + 1, 0, n - 1);
+    return t;
+}
+
+// R3
+__device__ __forceinline__ float lerp1(float p, float q, float w)
+{
+    return fmaf(q, w, p * (1.0f - w));
+}
+
+__device__ __forceinline__ float4 lerp4(float4 p, float4 q, float w)
+{
+    float iw = 1.0f - w;
+    float4 r;
+    r.x = fmaf(q.x, w, p.x * iw);
+    r.y = fmaf(q.y, w, p.y * iw);
+    r.z = fmaf(q.z, w, p.z * iw);
+    r.w = 0.0f;
+    return r;
+}
+
+// lonDynamics, lon_planner.cu:240-250
+__device__ __forceinline__ TplLonState lon_dynamics(const TplLonState& x0, float j, float dt)
+{
+    TplLonState r;
+    r.t = x0.t + dt;
+    float sf = x0.s + x0.v * dt;
+    double sd = (double)sf + ((0.5 * (double)x0.a) * (double)dt) * (double)dt;
+    sd = sd + ((((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt) * (double)dt;
+    r.s = fmaxf(x0.s, (float)sd);
+    float vf = x0.v + x0.a * dt;
+    double vd = (double)vf + ((0.5 * (double)j) * (double)dt) * (double)dt;
+    r.v = fmaxf(0.0f, (float)vd);
+    r.a = x0.a + j * dt;
+    r.j = j;
+    r.cost = 0.0f;
+    r.constr = 0.0f;
+    return r;
+}
+
+// interpPath, common.cuh:112-139, for one column of the path.  col points at
+// element 0 of that column, stride in floats.
+// (float)(1.0 - (double)alpha) == 1.0f - alpha for every float alpha: the
+// double difference is exact unless |alpha| < 2^-29, where both round to 1.0f.
+struct PathTap { int i0, i1; float a, ia; };
+
+__device__ __forceinline__ PathTap path_tap(float distance, float path_step_size, int path_steps)
+{
+    PathTap t;
+    float alpha = distance / path_step_size;
+    // guard the float->int conversion of far out-of-range values (UB in C)
+    float lo = fminf(fmaxf(floorf(alpha), -1.0f), (float)path_steps);
+    float hi = fminf(fmaxf(ceilf(alpha), -1.0f), (float)path_steps);
+    t.i0 = clampi((int)lo, 0, path_steps - 1);
+    t.i1 = clampi((int)hi, 0, path_steps - 1);
+    alpha -= (float)t.i0;
+    t.a = alpha;
+    t.ia = 1.0f - alpha;
+    return t;
+}
+
+__device__ __forceinline__ float path_lerp(const PathTap& t, float p0, float p1)
+{
+    return p0 * t.ia + p1 * t.a;
+}
+
+// env.cu:258
+__device__ __forceinline__ float env_t_idx(const TplDpEnvParams& ep, float t)
+{
+    if (t < ep.dt_start) return 0.0f;
+    return (float)((double)roundf((t - ep.dt_start) / ep.dt) + 1.0);
+}
+
+// interpDistMapPath, env.cu:254-264; dist is [t_steps][s_steps]
+template <typename PtrT>
+__device__ __forceinline__ float interp_dist_map_path(const TplDpEnvParams& ep, PtrT dist_ts,
+                                                      float t, float s)
+{
+    float t_idx = env_t_idx(ep, t);
+    float sc = (s - ep.s_min) / (ep.s_max - ep.s_min) * (float)(ep.s_steps - 1);
+    Tap tt = make_tap(t_idx + 0.5f, ep.t_steps);
+    Tap ts = make_tap(sc + 0.5f, ep.s_steps);
+    PtrT r0 = dist_ts + (size_t)tt.i0 * ep.s_steps;
+    PtrT r1 = dist_ts + (size_t)tt.i1 * ep.s_steps;
+    float a = lerp1(r0[ts.i0], r1[ts.i0], tt.w);
+    float b = lerp1(r0[ts.i1], r1[ts.i1], tt.w);
+    return lerp1(a, b, ts.w);
+}
+
+// coordinate of readNode, lon_planner.cu:34-37: float expression + double 0.5 -> float
+__device__ __forceinline__ float node_coord(float x, float x_min, float x_max, int steps)
+{
+    float c = (x - x_min) / (x_max - x_min) * (float)(steps - 1);
+    return (float)((double)c + 0.5);
+}
+
+// readNode with all eight taps from global memory (forward / reeval kernels).
+__device__ __forceinline__ float4 read_node(const TplDpLonParams& p, const float4* __restrict__ table,
+                                            float s, float v, float a)
+{
+    Tap ts = make_tap(node_coord(s, p.s_min, p.s_max, p.s_steps), p.s_steps);
+    Tap tv = make_tap(node_coord(v, p.v_min, p.v_max, p.v_steps), p.v_steps);
+    Tap ta = make_tap(node_coord(a, p.a_min, p.a_max, p.a_steps), p.a_steps);
+    const size_t S = (size_t)p.s_steps, V = (size_t)p.v_steps;
+    const float4* r00 = table + ((size_t)ta.i0 * V + tv.i0) * S;
+    const float4* r10 = table + ((size_t)ta.i1 * V + tv.i0) * S;
+    const float4* r01 = table + ((size_t)ta.i0 * V + tv.i1) * S;
+    const float4* r11 = table + ((size_t)ta.i1 * V + tv.i1) * S;
+    float4 lo = lerp4(lerp4(r00[ts.i0], r10[ts.i0], ta.w), lerp4(r01[ts.i0], r11[ts.i0], ta.w), tv.w);
+    float4 hi = lerp4(lerp4(r00[ts.i1], r10[ts.i1], ta.w), lerp4(r01[ts.i1], r11[ts.i1], ta.w), tv.w);
+    return lerp4(lo, hi, ts.w);
+}
+
+// stateCost, lon_planner.cu:40-55
+__device__ __forceinline__ float state_cost(const TplDpLonParams& p, float s, float v, float a, float s_dist)
+{
+    float cost = 0.0f;
+    cost += p.w_a * (a * a);
+    cost = (float)((double)cost + (double)p.w_progress * fabs(1000.0 - (double)s));
+    float gap = v * p.time_gap + p.gap_min - s_dist;
+    double m = fmax(0.0, (double)gap);
+    cost = (float)((double)cost + (double)p.w_safety_dist * m);
+    return cost;
+}
+
+// jerk of action k out of N, lon_planner.cu:148-149
+__device__ __forceinline__ float action_jerk(const TplDpLonParams& p, int k, int N)
+{
+    return p.j_min + (p.j_max - p.j_min) * ((float)k / (float)(N - 1));
+}
+
+struct ActionResult { float cost, constr; };
+
+// evalAction lambda, lon_planner.cu:99-137, with the node value already looked up
+__device__ __forceinline__ ActionResult eval_action_tail(const TplDpLonParams& p,
+                                                          float state_c, float state_g,
+                                                          float4 node, float j, float wj_cost,
+                                                          float tn_s, float tn_v, float tn_a,
+                                                          float tp_s, float s_dist, float v_max_next)
+{
+    float cost = state_c;
+    float constr = state_g;
+    cost += node.x;
+    constr += node.y;
+    cost += p.w_snap * ((node.z - j) * (node.z - j));
+    cost += wj_cost;
+    const double v_max = (double)v_max_next;
+    if ((double)tn_v > v_max) {
+        constr = (float)((double)constr + ((double)tn_v - v_max));
+    }
+    const float s_change = tn_s - tp_s;
+    if (s_change > s_dist) {
+        constr += s_change - s_dist;
+    }
+    if (tn_a < p.a_min) {
+        constr += p.a_min - tn_a;
+    }
+    if (tn_a > p.a_max) {
+        constr += tn_a - p.a_max;
+    }
+    ActionResult r;
+    r.cost = cost;
+    r.constr = constr;
+    return r;
+}
+
+// stateActionCost, lon_planner.cu:57-64
+__device__ __forceinline__ float state_action_cost(const TplDpLonParams& p, float j, float dt)
+{
+    float c = 0.0f;
+    c += p.w_j * ((j * dt) * (j * dt));
+    return c;
+}
+
+} // namespace tplhip

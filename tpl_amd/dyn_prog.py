@@ -1,0 +1,317 @@
+"""Python surface of the DP (s,v,a) longitudinal planner -- the part of the
+reference's pybind11 module ``tplcpp`` that HP-1 defines
+(library/src/python/bindings_dp_lon.cu:7-137, bindings_dp_env.cu:7-106).
+
+Same class names, attribute names, argument meaning and error behaviour, so
+``tpl.planning.dyn_prog.PolyLatDpLonPlanner`` can call these in place of
+``tplcpp.DynProgLonPlanner`` & friends.  All compute runs
+in ``libtplhip.so`` on the GPU; nothing here computes on the CPU.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import TplDpEnvParams, TplDpLonParams, TplLonState, check
+
+
+def _fptr(arr):
+    return arr.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class _StructView:
+    """Attribute access to a ctypes struct + the ``__slots__`` enumeration the
+    reference's param classes expose for otb.merge / structstore
+    (bindings_dp_lon.cu:36-64)."""
+
+    _ctype = None
+    _slot_names = ()
+
+    def __init__(self):
+        object.__setattr__(self, "_c", self._ctype())
+        self._set_defaults()
+
+    def _set_defaults(self):
+        pass
+
+    def __getattr__(self, name):
+        c = object.__getattribute__(self, "_c")
+        if name in type(self)._all_fields():
+            return getattr(c, name)
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in type(self)._all_fields():
+            setattr(self._c, name, value)
+        else:
+            raise AttributeError(f"{type(self).__name__} has no attribute {name!r}")
+
+    @classmethod
+    def _all_fields(cls):
+        return {f[0] for f in cls._ctype._fields_}
+
+    def __deepcopy__(self, memo):
+        other = type(self)()
+        C.memmove(C.byref(other._c), C.byref(self._c), C.sizeof(self._c))
+        return other
+
+    def __copy__(self):
+        return self.__deepcopy__({})
+
+    def __eq__(self, other):
+        return type(other) is type(self) and bytes(self._c) == bytes(other._c)
+
+    def __repr__(self):
+        body = ", ".join(f"{n}={getattr(self._c, n)!r}" for n in self._slot_names)
+        return f"{type(self).__name__}({body})"
+
+
+# pybind exposes ``__slots__`` as a read-only *instance* property; a property named
+# ``__slots__`` cannot be written in the class body (type() would consume it), so it
+# is attached afterwards.
+_StructView.__slots__ = property(lambda self: list(self._slot_names))
+
+
+class DynProgLonPlannerParams(_StructView):
+    """tplcpp.DynProgLonPlannerParams (bindings_dp_lon.cu:9-64)."""
+    _ctype = TplDpLonParams
+    _slot_names = (
+        "s_min", "s_max", "v_min", "v_max", "a_min", "a_max", "j_min", "j_max",
+        "t_steps", "s_steps", "v_steps", "a_steps", "dt", "dt_start",
+        "time_gap", "gap_min", "w_progress", "w_a", "w_j", "w_snap", "w_safety_dist",
+        "path_step_size", "path_steps", "width_veh", "length_veh")
+
+    def _set_defaults(self):
+        _capi.load().tplhip_dp_lon_params_default(C.byref(self._c))
+
+
+class DynProgEnvParams(_StructView):
+    """tplcpp.DynProgEnvParams (bindings_dp_env.cu:9-51)."""
+    _ctype = TplDpEnvParams
+    _slot_names = (
+        "t_min", "t_max", "l_min", "l_max", "s_min", "s_max", "ds_max", "dir_min", "dir_max",
+        "scale_objects", "dilation", "dt", "dt_start", "t_steps", "l_steps", "s_steps", "dir_steps")
+
+    def _set_defaults(self):
+        _capi.load().tplhip_dp_env_params_default(C.byref(self._c))
+
+
+class LonState(_StructView):
+    """tplcpp.LonState (bindings_dp_lon.cu:66-83)."""
+    _ctype = TplLonState
+    _slot_names = ("t", "s", "v", "a", "j", "cost", "constr")
+
+    @classmethod
+    def _from_c(cls, c):
+        st = cls()
+        C.memmove(C.byref(st._c), C.byref(c), C.sizeof(TplLonState))
+        return st
+
+    def as_numpy(self):
+        c = self._c
+        return np.array([c.s, c.v, c.a, c.j], dtype=np.float64)
+
+
+def lon_dynamics(x0, j, dt):
+    """tplcpp.lon_dynamics (bindings_dp_lon.cu:85; lon_planner.cu:240-250)."""
+    out = TplLonState()
+    _capi.load().tplhip_lon_dynamics(C.byref(x0._c), float(j), float(dt), C.byref(out))
+    return LonState._from_c(out)
+
+
+class LonTraj:
+    """tplcpp.LonTraj (bindings_dp_lon.cu:87-118)."""
+
+    def __init__(self):
+        self.states = []
+
+    @classmethod
+    def _from_array(cls, arr):
+        traj = cls()
+        traj.states = [LonState._from_c(c) for c in arr]
+        return traj
+
+    def _as_array(self):
+        arr = (TplLonState * len(self.states))()
+        for i, s in enumerate(self.states):
+            C.memmove(C.byref(arr[i]), C.byref(s._c), C.sizeof(TplLonState))
+        return arr
+
+    def copy(self):
+        return LonTraj._from_array(self._as_array())
+
+    def state(self, t):
+        lib = _capi.load()
+        arr = self._as_array()
+        if np.ndim(t) == 0:
+            out = TplLonState()
+            check(lib.tplhip_lon_traj_state(arr, len(self.states), float(t), C.byref(out)))
+            return LonState._from_c(out)
+        ts = np.asarray(t, dtype=np.float64)
+        if ts.ndim != 1:
+            raise ValueError(f"array has incorrect shape, expected: (-1,), got: {ts.shape}")
+        res = np.empty((ts.shape[0], 4), dtype=np.float64)
+        out = TplLonState()
+        for i, ti in enumerate(ts):
+            check(lib.tplhip_lon_traj_state(arr, len(self.states), float(ti), C.byref(out)))
+            res[i] = (out.s, out.v, out.a, out.j)
+        return res
+
+    def as_numpy(self):
+        res = np.empty((len(self.states), 4), dtype=np.float64)
+        for i, s in enumerate(self.states):
+            res[i] = (s._c.s, s._c.v, s._c.a, s._c.j)
+        return res
+
+
+class DynProgEnvironment:
+    """The slice of tplcpp.DynProgEnvironment (bindings_dp_env.cu:53-105) that
+    the longitudinal planner reads: its parameters and the Frenet occupancy map.
+
+    The reference fills ``occ_map`` with its OpenGL occupancy pipeline
+    (``insert_geometry`` + ``update``; env.cu:352-437), which is outside the hot
+    path; here the map is handed over with :meth:`set_occ_map` in the layout
+    ``get_occ_map`` returns it in (``[l_steps, s_steps, t_steps]`` float32).
+    """
+
+    def __init__(self, device=-1):
+        self._h = C.c_void_p()
+        self._lib = _capi.load()
+        check(self._lib.tplhip_dp_env_create(int(device), C.byref(self._h)))
+        self.params = DynProgEnvParams()
+        self.reinit_buffers(self.params, True)          # env.cu:282-285
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.tplhip_dp_env_destroy(h)
+            self._h = None
+
+    def reinit_buffers(self, params, force=False):
+        check(self._lib.tplhip_dp_env_reinit(self._h, C.byref(params._c)))
+        self.params = params.__deepcopy__({})
+
+    def _shape(self):
+        p = self.params
+        return (p.l_steps, p.s_steps, p.t_steps)
+
+    def set_occ_map(self, occ):
+        occ = np.ascontiguousarray(occ, dtype=np.float32)
+        if occ.shape != self._shape():
+            raise ValueError(f"array has incorrect shape, expected: {self._shape()}, got: {occ.shape}")
+        check(self._lib.tplhip_dp_env_set_occ_map(self._h, _fptr(occ)))
+
+    def get_occ_map(self):
+        occ = np.empty(self._shape(), dtype=np.float32)
+        check(self._lib.tplhip_dp_env_get_occ_map(self._h, _fptr(occ)))
+        return occ
+
+    def get_dist_map_path(self):
+        p = self.params
+        dist = np.empty((p.t_steps, p.s_steps), dtype=np.float32)
+        check(self._lib.tplhip_dp_env_get_dist_map_path(self._h, _fptr(dist)))
+        return dist
+
+    def update(self):
+        raise NotImplementedError(
+            "the OpenGL occupancy pipeline (env.cu:381-437) is outside the hot path; "
+            "hand the Frenet occupancy map over with set_occ_map()")
+
+
+class DynProgLonPlanner:
+    """tplcpp.DynProgLonPlanner (bindings_dp_lon.cu:120-136)."""
+
+    def __init__(self, device=-1):
+        self._h = C.c_void_p()
+        self._lib = _capi.load()
+        check(self._lib.tplhip_dp_lon_create(int(device), C.byref(self._h)))
+        self.params = DynProgLonPlannerParams()
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.tplhip_dp_lon_destroy(h)
+            self._h = None
+
+    def reinit_buffers(self, params):
+        check(self._lib.tplhip_dp_lon_reinit(self._h, C.byref(params._c)))
+        self.params = params.__deepcopy__({})
+
+    def _path(self, path):
+        # pybind force-casts the caller's float64 array to float32
+        # (bindings_dp_lon.cu:125-128, binding_helpers.hpp:19-20)
+        path = np.ascontiguousarray(path, dtype=np.float32)
+        want = (self.params.path_steps, 7)
+        if path.shape != want:
+            raise ValueError(f"array has incorrect shape, expected: {want}, got: {path.shape}")
+        return path
+
+    def update(self, initial_state, path, env):
+        path = self._path(path)
+        T = self.params.t_steps
+        out = (TplLonState * T)()
+        check(self._lib.tplhip_dp_lon_update(self._h, C.byref(initial_state._c), _fptr(path), env._h, out))
+        return LonTraj._from_array(out)
+
+    def update_batch(self, initial_states, path, env):
+        """n rollouts from n initial states over one backward sweep (new)."""
+        path = self._path(path)
+        n = len(initial_states)
+        T = self.params.t_steps
+        inits = (TplLonState * n)()
+        for i, s in enumerate(initial_states):
+            C.memmove(C.byref(inits[i]), C.byref(s._c), C.sizeof(TplLonState))
+        out = (TplLonState * (n * T))()
+        check(self._lib.tplhip_dp_lon_update_batch(self._h, n, inits, _fptr(path), env._h, out))
+        return [LonTraj._from_array(out[i * T:(i + 1) * T]) for i in range(n)]
+
+    def reeval_traj(self, traj, path, env):
+        path = self._path(path)
+        arr = traj._as_array()
+        out = (TplLonState * max(1, len(traj.states)))()
+        check(self._lib.tplhip_dp_lon_reeval(self._h, arr, len(traj.states), _fptr(path), env._h, out))
+        return LonTraj._from_array(out)
+
+    # ---- parity / measurement helpers (not in the reference) ------------------
+
+    def copy_table(self, t):
+        p = self.params
+        out = np.empty((p.a_steps, p.v_steps, p.s_steps, 4), dtype=np.float32)
+        check(self._lib.tplhip_dp_lon_copy_table(self._h, int(t), _fptr(out)))
+        return out
+
+    def upload(self, initial_states, path):
+        path = self._path(path)
+        n = len(initial_states)
+        inits = (TplLonState * n)()
+        for i, s in enumerate(initial_states):
+            C.memmove(C.byref(inits[i]), C.byref(s._c), C.sizeof(TplLonState))
+        check(self._lib.tplhip_dp_lon_upload(self._h, n, inits, _fptr(path)))
+        self._n_up = n
+
+    def plan_resident(self, env):
+        check(self._lib.tplhip_dp_lon_plan_resident(self._h, env._h))
+
+    def sync(self):
+        check(self._lib.tplhip_dp_lon_sync(self._h))
+
+    def download(self):
+        n, T = self._n_up, self.params.t_steps
+        out = (TplLonState * (n * T))()
+        check(self._lib.tplhip_dp_lon_download(self._h, out))
+        return [LonTraj._from_array(out[i * T:(i + 1) * T]) for i in range(n)]
+
+    def timing_enable(self, enable=True):
+        check(self._lib.tplhip_dp_lon_timing_enable(self._h, 1 if enable else 0))
+
+    def timing_get(self):
+        ms = C.c_double()
+        n = C.c_int64()
+        check(self._lib.tplhip_dp_lon_timing_get(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def cuda_get_device_count():
+    """tplcpp.cuda_get_device_count (bindings_dp_common.cu:38-45)."""
+    return _capi.load().tplhip_device_count()
