@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- measures BASELINE.json's metric on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one complete DP plan on device-resident inputs: distance map,
+t_steps-1 backward stage sweeps over the (s,v,a) grid, one forward rollout.
+value = stage sweeps per second over the whole job (all ranks), timed over
+exactly K steps between barrier + device synchronize on both sides, max over
+ranks.  For N > 1 the plans (independent scenarios) are sharded across ranks,
+no data-path collective: "scaling": "weak".
+
+Also on the line: "roofline" (HBM, algorithmic 32 B/cell/sweep over the sweep
+kernel's HIP-event time), "cpu_baseline" (the CPU oracle timed on a bounded
+sample on rank 0), and "secondary" (batched iLQR iterations/s etc.).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_CELL = 32            # read next float4 + write this float4
+
+
+def dp_setup(grid, device):
+    import tpl_amd
+    from tpl_amd import scenarios as sc
+    S, V, A, T = sc.GRIDS[grid]
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
+    env = tpl_amd.DynProgEnvironment(device)
+    env.reinit_buffers(ep)
+    env.set_occ_map(occ)
+    dp = tpl_amd.DynProgLonPlanner(device)
+    dp.reinit_buffers(p)
+    dp.upload([sc.initial_state(0.0, 8.0, 0.0)], path)
+    return dp, env, p, ep, path, occ
+
+
+def dp_cpu_baseline(p, ep, path, occ, budget_s=12.0):
+    """CPU oracle (port) on a bounded sample: whole stage sweeps of the same
+    grid, all host cores, until ~budget_s of wall time is spent."""
+    import ctypes as C
+    import numpy as np
+    import oracle_dp as O
+    cp, cep = O.cparams(p), O.cparams(ep)
+    dist = O.dist_map_path(cep, occ, path, cp.path_steps, cp.path_step_size)
+    tf = int(O.lib().dpo_table_floats(C.byref(cp)))
+    a = np.zeros(tf, dtype=np.float32)
+    b = np.zeros(tf, dtype=np.float32)
+    T = cp.t_steps
+    O.lib().dpo_backward_stage(C.byref(cp), C.byref(cep), T - 1, O.fptr(a), O.fptr(a), O.fptr(path), O.fptr(dist), 0)
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        O.lib().dpo_backward_stage(C.byref(cp), C.byref(cep), T - 2, O.fptr(a), O.fptr(b), O.fptr(path), O.fptr(dist), 0)
+        a, b = b, a
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    cores = int(O.lib().dpo_max_threads())
+    return {"value": n / el, "unit": "stage-sweeps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full stage sweeps of the same {cp.s_steps}x{cp.v_steps}x{cp.a_steps} grid "
+                      f"(oracle/dp_lon_oracle.c, OpenMP over rows)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", default="target", help="target (256x128x64, default) | config2 | config4 | default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    dp, env, p, ep, path, occ = dp_setup(args.grid, local_rank)
+    cells = p.s_steps * p.v_steps * p.a_steps
+    sweeps_per_step = p.t_steps - 1
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        dp.plan_resident(env)
+    dp.sync()
+    dp.timing_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dp.plan_resident(env)
+    dp.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    sweep_ms, sweep_launches = dp.timing_get()
+    dp.timing_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_sweeps = sweeps_per_step * args.steps * world
+    value = total_sweeps / elapsed
+
+    out = None
+    if rank == 0:
+        per_launch_s = (sweep_ms / 1e3) / max(1, sweep_launches)
+        achieved = cells * BYTES_PER_CELL / per_launch_s / 1e9
+        out = {
+            "metric": "dp_stage_sweeps_per_s",
+            "value": value,
+            "unit": "stage-sweeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"DP (s,v,a) planner, {p.s_steps}x{p.v_steps}x{p.a_steps} grid, "
+                            f"{p.t_steps} stages, straight 200 m path, 5 moving obstacles; "
+                            f"one step = dist map + {sweeps_per_step} backward sweeps + forward rollout",
+                "grid": [p.s_steps, p.v_steps, p.a_steps], "t_steps": p.t_steps,
+                "plans_per_step_per_gpu": 1, "parallelism": f"replicas x{world}",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_backward", "launch_us": per_launch_s * 1e6,
+                "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = dp_cpu_baseline(p, ep, path, occ)
+        if not args.no_secondary and world == 1:
+            try:
+                from tpl_amd.optim import bench_ilqr
+                out["secondary"] = bench_ilqr.run(local_rank)
+            except ImportError:
+                pass
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
