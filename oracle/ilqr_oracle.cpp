@@ -1,0 +1,739 @@
+/*
+ * ilqr_oracle.cpp -- CPU restatement of tpl's genopt iLQR solver.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under tpl_amd/ may include, link or call
+ * this file; it checks the HIP solver (tests/, __graft_entry__.smoke, bench.py's
+ * cpu_baseline leg) and is never the thing shipped or measured.
+ *
+ * PARITY PINNED: the reference solver (generated C + CPython type) builds and
+ * runs in this container; tests/golden/make_ilqr_goldens.py imports it and
+ * dumps inputs/outputs into tests/golden/ilqr_*.npz, and tests/test_ilqr_oracle.py
+ * checks this restatement against those fixtures (tolerance 1e-9 relative, far
+ * inside the 1e-5 the north star asks for; the reference itself is built
+ * -O3 -ffast-math so bitwise equality is not defined).
+ *
+ * Follows library/tpl/optim/templates/optim.c of the reference:
+ *   interpolation builtins   :297-486   (literal restatement incl. the size_t casts)
+ *   dynamics (EULER/HEUN/RK4) :657-730
+ *   lqrForwardPass           :732-792
+ *   testImprovement/lineSearch :840-873
+ *   solve_action             :243-291
+ *   ilqr                     :875-1008
+ *   update                   :1091-1160
+ *   shift                    :1162-1177
+ * The model routines (ctDynamics ... constraints) come from the generated
+ * <problem>.inc (the build's own generator, rules D1-D7 of tpl_amd/optim/genopt.py);
+ * they are pinned by the same golden fixtures.  The first-order variant
+ * ilr()/lrForwardPass (:794-838, :1010-1089) is restated too.
+ *
+ * Build: g++ -O2 -ffp-contract=off -DTPL_MODEL_INC='"<path>/<problem>.inc"' ...
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stddef.h>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TPL_HD
+#define ILQO_API extern "C" __attribute__((visibility("default")))
+
+/* ---- interpolation builtins, optim.c:297-486, restated literally -------------- */
+
+struct DynArr {
+    const double* data;
+    int64_t n0, n1;
+    int32_t ndim;
+    int32_t pad;
+};
+
+#define omin(a, b) (((a) < (b)) ? (a) : (b))
+#define omax(a, b) (((a) > (b)) ? (a) : (b))
+
+struct OInterp { double a, ia; size_t start, end; };
+
+/* The template converts a possibly negative double to size_t (optim.c:351-352).
+ * That conversion is undefined in C; every x86-64 build of the reference yields
+ * a value >= 2^63 for negative inputs (cvttsd2si path) or 2^64-1 (AVX-512
+ * vcvttsd2usi), i.e. "huge", which min(size-1, .) turns into size-1.  to_size_t
+ * pins that outcome instead of relying on the host compiler. */
+static inline size_t to_size_t(double v)
+{
+    if (v <= -1.0) return (size_t)-1;
+    if (v >= 18446744073709551615.0) return (size_t)-1;
+    return (size_t)v;      /* (-1, 0) truncates to 0 */
+}
+
+static inline void init_interp(OInterp* i, double x0, double dx, double x, size_t size)
+{
+    const double q = (x - x0) / dx;
+    i->start = omin(size - 1, omax((size_t)0, to_size_t(floor(q))));
+    i->end = omin(size - 1, omax((size_t)0, to_size_t(ceil(q))));
+    i->a = omin(omax(0.0, q - (double)i->start), 1.0);
+    i->ia = 1.0 - i->a;
+}
+
+static inline double tpl_get_array_value(const DynArr& A, double I) { return A.data[(size_t)I]; }
+
+static inline double tpl_box_interp(double dx, double x, const DynArr& arr)
+{
+    size_t l = (size_t)arr.n0;
+    if (l == 0) return 0.0;
+    size_t i = omin(l - 1, omax((size_t)0, to_size_t(floor(x / dx))));
+    return arr.data[i];
+}
+
+static inline double tpl_lerp(double x0, double dx, double x, const DynArr& arr)
+{
+    size_t l = (size_t)arr.n0;
+    if (l == 0) return 0.0;
+    OInterp i;
+    init_interp(&i, x0, dx, x, l);
+    return i.ia * arr.data[i.start] + i.a * arr.data[i.end];
+}
+
+static inline double short_angle_dist(double a0, double a1)
+{
+    double m = M_PI * 2;
+    double da = fmod(a1 - a0, m);
+    return fmod(2 * da, m) - da;
+}
+
+static inline double tpl_lerp_angle(double x0, double dx, double x, const DynArr& arr)
+{
+    size_t l = (size_t)arr.n0;
+    if (l == 0) return 0.0;
+    OInterp i;
+    init_interp(&i, x0, dx, x, l);
+    return arr.data[i.start] + short_angle_dist(arr.data[i.start], arr.data[i.end]) * i.a;
+}
+
+static inline double tpl_lerp_wrap(double len, double dx, double x, const DynArr& xs, const DynArr& arr)
+{
+    size_t l = (size_t)arr.n0;
+    if (l == 0) return 0.0;
+    double first = xs.data[0];
+    double last = first + (double)(l - 1) * dx;
+    double gap = len - (last - first);
+    x = fmod(x - first, len);
+    if (x < 0) x += len;
+    x += first;
+    double alpha;
+    size_t start, end;
+    if (x >= last && gap > 0) {
+        alpha = (x - last) / gap;
+        start = l - 1;
+        end = 0;
+    } else {
+        const double q = (x - first) / dx;
+        start = omin(l - 1, to_size_t(floor(q)));
+        end = omin(l - 1, to_size_t(ceil(q)));
+        alpha = q - (double)start;
+    }
+    return (1.0 - alpha) * arr.data[start] + alpha * arr.data[end];
+}
+
+static inline double tpl_blerp(double x0, double y0, double dx, double dy, double x, double y, const DynArr& arr)
+{
+    size_t rows = (size_t)arr.n0, cols = (size_t)arr.n1;
+    if (rows == 0 || cols == 0) return 0.0;
+    OInterp ix, iy;
+    init_interp(&ix, x0, dx, x, cols);
+    init_interp(&iy, y0, dy, y, rows);
+    double p0 = iy.ia * arr.data[iy.start * cols + ix.start] + iy.a * arr.data[iy.end * cols + ix.start];
+    double p1 = iy.ia * arr.data[iy.start * cols + ix.end] + iy.a * arr.data[iy.end * cols + ix.end];
+    return ix.ia * p0 + ix.a * p1;
+}
+
+/* ---- generated model ------------------------------------------------------------ */
+#include TPL_MODEL_INC
+
+#define X TPL_X
+#define U TPL_U
+#define C TPL_C
+#define CM TPL_CMAX
+
+enum { EULER = 0, HEUN = 1, RK4 = 2 };
+
+struct ParamStore {
+    /* owned copies of array parameters, in TPL_PARAM_LIST order */
+    std::vector<std::vector<double>> arrays;
+};
+
+struct OOpt {
+    int Tcap;
+    /* optim.c:508-622 */
+    std::vector<double> int_step, x, u, next_int_step, next_x, next_u, prev_x, prev_u, prev_k;
+    std::vector<double> fx, fu, lx, lu, lxx, luu, lux, g, k, K, lam, uMax, uMin;
+    double barrierWeight[CM], lgMultLimit[CM];
+    double trajCosts; int iterations; int lgIterations; double runtime; double alpha;
+    bool trajectoryChanged; bool improved; int terminationCondition;
+    double mu; int muStep; double minMu;
+    int maxIterations; int maxLgIterations; double minRelCostChange; double dt; int optStart; int T;
+    bool useQuadraticTerms; int integratorType;
+    Params params;
+    ParamStore store;
+};
+
+#define XR(o, t) (&(o)->x[(size_t)(t) * X])
+#define UR(o, t) (&(o)->u[(size_t)(t) * U])
+
+/* optim.c:657-730 */
+static void dynamics(OOpt* o, const double* x, const double* u, int t, double dt, int intType, double* res)
+{
+    switch (intType) {
+    case EULER: {
+        double k1[X];
+        ctDynamics(o->params, x, u, t, dt, k1, 1);
+        for (int i = 0; i < X; ++i) k1[i] = k1[i] * dt;
+        for (int i = 0; i < X; ++i) res[i] = x[i] + k1[i];
+        break;
+    }
+    case HEUN: {
+        double tmp[X], k1[X], k2[X];
+        ctDynamics(o->params, x, u, t, dt, k1, 1);
+        for (int i = 0; i < X; ++i) tmp[i] = k1[i] * dt;
+        for (int i = 0; i < X; ++i) tmp[i] = x[i] + tmp[i];
+        ctDynamics(o->params, tmp, u, t, dt, k2, 1);
+        for (int i = 0; i < X; ++i) tmp[i] = k1[i] + k2[i];
+        for (int i = 0; i < X; ++i) tmp[i] = tmp[i] * (dt / 2.0);
+        for (int i = 0; i < X; ++i) res[i] = x[i] + tmp[i];
+        break;
+    }
+    default: {
+        double tmp[X], k1[X], k2[X], k3[X], k4[X];
+        ctDynamics(o->params, x, u, t, dt, k1, 1);
+        for (int i = 0; i < X; ++i) tmp[i] = x[i] + k1[i] * (dt / 2.0);
+        ctDynamics(o->params, tmp, u, t, dt, k2, 1);
+        for (int i = 0; i < X; ++i) tmp[i] = x[i] + k2[i] * (dt / 2.0);
+        ctDynamics(o->params, tmp, u, t, dt, k3, 1);
+        for (int i = 0; i < X; ++i) tmp[i] = x[i] + k3[i] * dt;
+        ctDynamics(o->params, tmp, u, t, dt, k4, 1);
+        for (int i = 0; i < X; ++i) {
+            double acc = 0.0;
+            acc = k1[i] + acc;
+            acc = k2[i] * 2.0 + acc;
+            acc = k3[i] * 2.0 + acc;
+            acc = k4[i] + acc;
+            res[i] = x[i] + acc * (dt / 6.0);
+        }
+        break;
+    }
+    }
+}
+
+/* optim.c:732-792 */
+static double lqr_forward_pass(OOpt* o, double scale)
+{
+    double cost = 0.0, c = 0.0;
+    memcpy(&o->next_x[0], &o->x[0], sizeof(double) * X);
+    double xdiff[X];
+    for (int t = o->optStart; t < o->T; ++t) {
+        double* nx = &o->next_x[(size_t)t * X];
+        double* nu = &o->next_u[(size_t)t * U];
+        for (int i = 0; i < X; ++i) xdiff[i] = nx[i] - XR(o, t)[i];
+        for (int d = 0; d < U; ++d) nu[d] = o->k[(size_t)t * U + d] * scale;
+        for (int d = 0; d < U; ++d) nu[d] = nu[d] + UR(o, t)[d];
+        for (int d = 0; d < U; ++d)
+            for (int i = 0; i < X; ++i) nu[d] += o->K[((size_t)t * U + d) * X + i] * xdiff[i];
+        for (int d = 0; d < U; ++d)
+            nu[d] = omax(o->uMin[(size_t)t * U + d], omin(o->uMax[(size_t)t * U + d], nu[d]));
+        o->next_int_step[t] = o->dt;
+        dynamics(o, nx, nu, t, o->next_int_step[t], o->integratorType, &o->next_x[(size_t)(t + 1) * X]);
+        costs(o->params, nx, nu, &o->lam[(size_t)t * CM], o->barrierWeight, t, o->next_int_step[t], &c, 1);
+        cost += c;
+    }
+    o->next_int_step[o->T] = o->dt;
+    endCosts(o->params, &o->next_x[(size_t)o->T * X], o->T, o->next_int_step[o->T], &c, 1);
+    cost += c;
+    return cost;
+}
+
+/* optim.c:794-838 */
+static double lr_forward_pass(OOpt* o, double scale)
+{
+    double cost = 0.0, c = 0.0;
+    memcpy(&o->next_x[0], &o->x[0], sizeof(double) * X);
+    for (int t = o->optStart; t < o->T; ++t) {
+        double* nx = &o->next_x[(size_t)t * X];
+        double* nu = &o->next_u[(size_t)t * U];
+        for (int d = 0; d < U; ++d) nu[d] = o->k[(size_t)t * U + d] * scale;
+        for (int d = 0; d < U; ++d) nu[d] = UR(o, t)[d] - nu[d];
+        o->next_int_step[t] = o->dt;
+        dynamics(o, nx, nu, t, o->next_int_step[t], o->integratorType, &o->next_x[(size_t)(t + 1) * X]);
+        costs(o->params, nx, nu, &o->lam[(size_t)t * CM], o->barrierWeight, t, o->next_int_step[t], &c, 1);
+        cost += c;
+    }
+    o->next_int_step[o->T] = o->dt;
+    endCosts(o->params, &o->next_x[(size_t)o->T * X], o->T, o->next_int_step[o->T], &c, 1);
+    cost += c;
+    return cost;
+}
+
+/* optim.c:840-857.  copy() moves whole H_MAX arrays in the template; only rows
+ * up to T carry meaning. */
+static bool test_improvement(OOpt* o, double newCosts)
+{
+    if (newCosts < o->trajCosts && isfinite(newCosts) && newCosts >= 0.0) {
+        o->prev_x = o->x;
+        o->prev_k = o->k;
+        o->int_step = o->next_int_step;
+        o->x = o->next_x;
+        o->u = o->next_u;
+        o->trajCosts = newCosts;
+        o->trajectoryChanged = true;
+        o->improved = true;
+        return true;
+    }
+    return false;
+}
+
+/* optim.c:859-873 */
+static bool line_search(OOpt* o, double (*forward)(OOpt*, double))
+{
+    for (int i = 0; i < 8; ++i) {
+        o->alpha = 1.0 / pow(10, i);
+        double newCosts = forward(o, o->alpha);
+        if (test_improvement(o, newCosts)) return true;
+    }
+    return false;
+}
+
+/* optim.c:243-291 */
+static void solve_action(const double Quu[U][U], const double Qu[U], const double Qux[U][X],
+                         double* k, double* K, double mu)
+{
+#if TPL_U == 1
+    double inv = 0.0;
+    if (Quu[0][0] > 0.0) inv = -1.0 / (Quu[0][0] + mu);
+    k[0] = Qu[0] * inv;
+    for (int i = 0; i < X; ++i) K[i] = Qux[0][i] * inv;
+#else
+    double a = Quu[0][0] + mu;
+    double b = Quu[0][1];
+    double d = Quu[1][1] + mu;
+    double inv[2][2];
+    inv[0][0] = d; inv[0][1] = -b; inv[1][0] = -b; inv[1][1] = a;
+    double det = a * d - b * b;
+    double inv_det = -1.0f / det;
+    inv[0][0] *= inv_det;
+    inv[0][1] *= inv_det;
+    inv[1][0] = inv[0][1];
+    inv[1][1] *= inv_det;
+    for (int i = 0; i < 2; ++i) {
+        k[i] = 0.0;
+        for (int m = 0; m < 2; ++m) k[i] += inv[i][m] * Qu[m];
+    }
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < X; ++j) {
+            K[i * X + j] = 0.0;
+            for (int m = 0; m < 2; ++m) K[i * X + j] += inv[i][m] * Qux[m][j];
+        }
+#endif
+}
+
+static void refresh_derivatives(OOpt* o, bool second_order)
+{
+    for (int t = 0; t < o->T; ++t) {
+        stateJacobian(o->params, XR(o, t), UR(o, t), t, o->int_step[t], &o->fx[(size_t)t * X * X], 1);
+        actionJacobian(o->params, XR(o, t), UR(o, t), t, o->int_step[t], &o->fu[(size_t)t * X * U], 1);
+    }
+    for (int t = 0; t < o->T; ++t) {
+        const double* lm = &o->lam[(size_t)t * CM];
+        stateGradient(o->params, XR(o, t), UR(o, t), lm, o->barrierWeight, t, o->int_step[t], &o->lx[(size_t)t * X], 1);
+        actionGradient(o->params, XR(o, t), UR(o, t), lm, o->barrierWeight, t, o->int_step[t], &o->lu[(size_t)t * U], 1);
+        if (second_order) {
+            stateStateHessian(o->params, XR(o, t), UR(o, t), lm, o->barrierWeight, t, o->int_step[t], &o->lxx[(size_t)t * X * X], 1);
+            actionActionHessian(o->params, XR(o, t), UR(o, t), lm, o->barrierWeight, t, o->int_step[t], &o->luu[(size_t)t * U * U], 1);
+            actionStateHessian(o->params, XR(o, t), UR(o, t), lm, o->barrierWeight, t, o->int_step[t], &o->lux[(size_t)t * U * X], 1);
+        }
+    }
+    o->trajectoryChanged = false;
+}
+
+/* optim.c:875-1008 */
+static void ilqr(OOpt* o)
+{
+    double Vx[X], Vxx[X][X], Qx[X], Qu[U], Quu[U][U], Qxx[X][X], Qux[U][X];
+    for (int s = o->iterations; s < o->maxIterations; ++s) {
+        o->iterations = s + 1;
+        if (o->trajectoryChanged) refresh_derivatives(o, true);
+
+        endGradient(o->params, XR(o, o->T), o->T, o->int_step[o->T], Vx, 1);
+        endHessian(o->params, XR(o, o->T), o->T, o->int_step[o->T], &Vxx[0][0], 1);
+
+        double tmp_xx[X][X], tmp_xu[X][U], K_T[X][U];
+        for (int t = o->T - 1; t >= 0; --t) {
+            const double(*fx)[X] = (const double(*)[X]) & o->fx[(size_t)t * X * X];
+            const double(*fu)[U] = (const double(*)[U]) & o->fu[(size_t)t * X * U];
+            const double* lx = &o->lx[(size_t)t * X];
+            const double* lu = &o->lu[(size_t)t * U];
+            const double(*lxx)[X] = (const double(*)[X]) & o->lxx[(size_t)t * X * X];
+            const double(*luu)[U] = (const double(*)[U]) & o->luu[(size_t)t * U * U];
+            const double(*lux)[X] = (const double(*)[X]) & o->lux[(size_t)t * U * X];
+            double* k = &o->k[(size_t)t * U];
+            double(*K)[X] = (double(*)[X]) & o->K[(size_t)t * U * X];
+
+            /* Qx = lx + fx^T Vx ; Qu = lu + fu^T Vx */
+            for (int i = 0; i < X; ++i) {
+                double acc = 0.0;
+                for (int m = 0; m < X; ++m) acc += fx[m][i] * Vx[m];
+                Qx[i] = lx[i] + acc;
+            }
+            for (int i = 0; i < U; ++i) {
+                double acc = 0.0;
+                for (int m = 0; m < X; ++m) acc += fu[m][i] * Vx[m];
+                Qu[i] = lu[i] + acc;
+            }
+            /* tmp_xx = Vxx fx ; tmp_xu = Vxx fu */
+            for (int i = 0; i < X; ++i)
+                for (int j = 0; j < X; ++j) {
+                    double acc = 0.0;
+                    for (int m = 0; m < X; ++m) acc += Vxx[i][m] * fx[m][j];
+                    tmp_xx[i][j] = acc;
+                }
+            for (int i = 0; i < X; ++i)
+                for (int j = 0; j < U; ++j) {
+                    double acc = 0.0;
+                    for (int m = 0; m < X; ++m) acc += Vxx[i][m] * fu[m][j];
+                    tmp_xu[i][j] = acc;
+                }
+            /* Qxx = lxx + sym(fx^T tmp_xx): lower triangle computed, mirrored (mul_symm :159-180) */
+            for (int i = 0; i < X; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    double acc = 0.0;
+                    for (int m = 0; m < X; ++m) acc += fx[m][i] * tmp_xx[m][j];
+                    Qxx[i][j] = acc;
+                    Qxx[j][i] = acc;
+                }
+            for (int i = 0; i < X; ++i)
+                for (int j = 0; j < X; ++j) Qxx[i][j] = lxx[i][j] + Qxx[i][j];
+            for (int i = 0; i < U; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    double acc = 0.0;
+                    for (int m = 0; m < X; ++m) acc += fu[m][i] * tmp_xu[m][j];
+                    Quu[i][j] = acc;
+                    Quu[j][i] = acc;
+                }
+            for (int i = 0; i < U; ++i)
+                for (int j = 0; j < U; ++j) Quu[i][j] = luu[i][j] + Quu[i][j];
+            /* Qux = lux + fu^T tmp_xx */
+            for (int i = 0; i < U; ++i)
+                for (int j = 0; j < X; ++j) {
+                    double acc = 0.0;
+                    for (int m = 0; m < X; ++m) acc += fu[m][i] * tmp_xx[m][j];
+                    Qux[i][j] = lux[i][j] + acc;
+                }
+
+            solve_action(Quu, Qu, Qux, k, &K[0][0], o->mu);
+
+            /* control limits :950-963 */
+            for (int d = 0; d < U; ++d) {
+                double c = UR(o, t)[d] + k[d];
+                if (c > o->uMax[(size_t)t * U + d]) {
+                    k[d] = o->uMax[(size_t)t * U + d] - UR(o, t)[d];
+                    for (int i = 0; i < X; ++i) K[d][i] = 0.0;
+                }
+                if (c < o->uMin[(size_t)t * U + d]) {
+                    k[d] = o->uMin[(size_t)t * U + d] - UR(o, t)[d];
+                    for (int i = 0; i < X; ++i) K[d][i] = 0.0;
+                }
+            }
+
+            /* Vxx = K^T Qux + (K^T Qux)^T ; += (K^T Quu) K ; += Qxx */
+            for (int i = 0; i < X; ++i)
+                for (int d = 0; d < U; ++d) K_T[i][d] = K[d][i];
+            for (int i = 0; i < X; ++i)
+                for (int j = 0; j < X; ++j) {
+                    double acc = 0.0;
+                    for (int d = 0; d < U; ++d) acc += K_T[i][d] * Qux[d][j];
+                    tmp_xx[i][j] = acc;
+                }
+            for (int i = 0; i < X; ++i)
+                for (int j = 0; j < X; ++j) Vxx[i][j] = tmp_xx[j][i] + tmp_xx[i][j];
+            for (int i = 0; i < X; ++i)
+                for (int d = 0; d < U; ++d) {
+                    double acc = 0.0;
+                    for (int m = 0; m < U; ++m) acc += K_T[i][m] * Quu[m][d];
+                    tmp_xu[i][d] = acc;
+                }
+            for (int i = 0; i < X; ++i)
+                for (int j = 0; j < X; ++j)
+                    for (int d = 0; d < U; ++d) Vxx[i][j] += tmp_xu[i][d] * K[d][j];
+            for (int i = 0; i < X; ++i)
+                for (int j = 0; j < X; ++j) Vxx[i][j] = Vxx[i][j] + Qxx[i][j];
+
+            /* Vx = (K^T Quu) k ; += K^T Qu ; += Qux^T k ; += Qx */
+            for (int i = 0; i < X; ++i) {
+                double acc = 0.0;
+                for (int d = 0; d < U; ++d) acc += tmp_xu[i][d] * k[d];
+                Vx[i] = acc;
+            }
+            for (int i = 0; i < X; ++i)
+                for (int d = 0; d < U; ++d) Vx[i] += K_T[i][d] * Qu[d];
+            for (int i = 0; i < X; ++i)
+                for (int d = 0; d < U; ++d) Vx[i] += Qux[d][i] * k[d];
+            for (int i = 0; i < X; ++i) Vx[i] = Vx[i] + Qx[i];
+        }
+
+        double prevTrajCosts = o->trajCosts;
+        if (line_search(o, lqr_forward_pass)) {
+            o->muStep = omax(0, o->muStep - 1);
+        } else {
+            o->muStep = omin(o->muStep + 1, 7);
+        }
+        if (o->muStep == 0) o->mu = 0.0;
+        else o->mu = pow(10.0, o->muStep - 1);
+
+        double rel = fabs(o->trajCosts - prevTrajCosts) / o->trajCosts;
+        if (rel < o->minRelCostChange) {
+            o->terminationCondition = 2;
+            break;
+        }
+    }
+}
+
+/* optim.c:1010-1089 */
+static void ilr(OOpt* o)
+{
+    double Vx[X], Qx[X], Qu[U];
+    for (int s = o->iterations; s < o->maxIterations; ++s) {
+        o->iterations = s + 1;
+        if (o->trajectoryChanged) refresh_derivatives(o, false);
+        endGradient(o->params, XR(o, o->T), o->T, o->int_step[o->T], Vx, 1);
+        for (int t = o->T - 1; t >= 0; --t) {
+            const double(*fx)[X] = (const double(*)[X]) & o->fx[(size_t)t * X * X];
+            const double(*fu)[U] = (const double(*)[U]) & o->fu[(size_t)t * X * U];
+            for (int i = 0; i < X; ++i) {
+                double acc = 0.0;
+                for (int m = 0; m < X; ++m) acc += fx[m][i] * Vx[m];
+                Qx[i] = o->lx[(size_t)t * X + i] + acc;
+            }
+            for (int i = 0; i < U; ++i) {
+                double acc = 0.0;
+                for (int m = 0; m < X; ++m) acc += fu[m][i] * Vx[m];
+                Qu[i] = o->lu[(size_t)t * U + i] + acc;
+            }
+            for (int d = 0; d < U; ++d) {
+                o->g[(size_t)t * U + d] = Qu[d];
+                o->k[(size_t)t * U + d] = Qu[d];
+            }
+            for (int i = 0; i < X; ++i) Vx[i] = Qx[i];
+        }
+        for (int t = o->T - 1; t >= 0; --t) {
+            for (int d = 0; d < U; ++d) {
+                double c = UR(o, t)[d] - o->g[(size_t)t * U + d];
+                if (c > o->uMax[(size_t)t * U + d]) o->k[(size_t)t * U + d] = UR(o, t)[d] - o->uMax[(size_t)t * U + d];
+                if (c < o->uMin[(size_t)t * U + d]) o->k[(size_t)t * U + d] = UR(o, t)[d] - o->uMin[(size_t)t * U + d];
+            }
+        }
+        double prevTrajCosts = o->trajCosts;
+        line_search(o, lr_forward_pass);
+        double rel = fabs(o->trajCosts - prevTrajCosts) / o->trajCosts;
+        if (rel < o->minRelCostChange) {
+            o->terminationCondition = 2;
+            break;
+        }
+    }
+}
+
+/* optim.c:1091-1160 */
+static void update(OOpt* o)
+{
+    double c = 0.0;
+    o->trajCosts = 0.0;
+    for (int t = o->optStart; t < o->T; ++t) {
+        o->int_step[t] = o->dt;
+        dynamics(o, XR(o, t), UR(o, t), t, o->int_step[t], o->integratorType, XR(o, t + 1));
+        costs(o->params, XR(o, t), UR(o, t), &o->lam[(size_t)t * CM], o->barrierWeight, t, o->int_step[t], &c, 1);
+        o->trajCosts += c;
+    }
+    o->int_step[o->T] = o->dt;
+    endCosts(o->params, XR(o, o->T), o->T, o->int_step[o->T], &c, 1);
+    o->trajCosts += c;
+
+    for (o->lgIterations = 0; o->lgIterations < o->maxLgIterations; ++(o->lgIterations)) {
+        double constr[CM];
+        for (int t = o->optStart; t < o->T; ++t) {
+            for (int ci = 0; ci < CM; ++ci) constr[ci] = 0.0;
+            constraints(o->params, XR(o, t), UR(o, t), &o->lam[(size_t)t * CM], o->barrierWeight, t, o->int_step[t], constr, 1);
+            for (int ci = 0; ci < C; ++ci) {
+                double* lm = &o->lam[(size_t)t * CM + ci];
+                *lm = omin(o->lgMultLimit[ci], omax(0.0, *lm + o->barrierWeight[ci] * constr[ci]));
+            }
+        }
+        o->trajectoryChanged = true;
+        o->improved = false;
+        o->iterations = 0;
+        if (o->useQuadraticTerms) ilqr(o);
+        else ilr(o);
+    }
+    if (o->iterations == o->maxIterations) o->terminationCondition = 1;
+}
+
+/* optim.c:1162-1177 */
+static void shift(OOpt* o, int amount)
+{
+    amount = omax(0, amount);
+    for (int t = o->optStart; t < o->T + 1; ++t)
+        memmove(XR(o, t), XR(o, omin(o->T, t + amount)), sizeof(double) * X);
+    for (int t = o->optStart; t < o->T; ++t)
+        memmove(UR(o, t), UR(o, omin(o->T - 1, t + amount)), sizeof(double) * U);
+    for (int t = o->optStart; t < o->T; ++t)
+        memmove(&o->lam[(size_t)t * CM], &o->lam[(size_t)omin(o->T - 1, t + amount) * CM], sizeof(double) * CM);
+}
+
+/* ---- C interface for the tests ----------------------------------------------------- */
+
+/* parameter table in TPL_PARAM_LIST order */
+struct ParamRef { const char* name; int is_array; size_t offset; };
+#define TPL_PARAM_S(n) {#n, 0, offsetof(Params, n)},
+#define TPL_PARAM_A(n) {#n, 1, offsetof(Params, n)},
+static const ParamRef g_params[] = { TPL_PARAM_LIST {nullptr, 0, 0} };
+#undef TPL_PARAM_S
+#undef TPL_PARAM_A
+
+ILQO_API void ilqo_dims(int* x, int* u, int* c, int* np) { *x = X; *u = U; *c = C; *np = TPL_N_PARAMS; }
+ILQO_API const char* ilqo_param_name(int i) { return (i >= 0 && i < TPL_N_PARAMS) ? g_params[i].name : nullptr; }
+ILQO_API int ilqo_param_is_array(int i) { return (i >= 0 && i < TPL_N_PARAMS) ? g_params[i].is_array : -1; }
+
+ILQO_API void* ilqo_create(int Tcap)
+{
+    OOpt* o = new OOpt();
+    o->Tcap = Tcap;
+    const size_t R = (size_t)Tcap + 1;
+    o->int_step.assign(R, 0.0); o->next_int_step.assign(R, 0.0);
+    o->x.assign(R * X, 0.0); o->next_x.assign(R * X, 0.0); o->prev_x.assign(R * X, 0.0);
+    o->u.assign(R * U, 0.0); o->next_u.assign(R * U, 0.0); o->prev_u.assign(R * U, 0.0);
+    o->prev_k.assign(R * U, 0.0);
+    o->fx.assign(R * X * X, 0.0); o->fu.assign(R * X * U, 0.0);
+    o->lx.assign(R * X, 0.0); o->lu.assign(R * U, 0.0);
+    o->lxx.assign(R * X * X, 0.0); o->luu.assign(R * U * U, 0.0); o->lux.assign(R * U * X, 0.0);
+    o->g.assign(R * U, 0.0); o->k.assign(R * U, 0.0); o->K.assign(R * U * X, 0.0);
+    o->lam.assign(R * CM, 0.0);
+    o->uMax.assign(R * U, 0.0); o->uMin.assign(R * U, 0.0);
+    memset(&o->params, 0, sizeof(Params));
+    o->store.arrays.resize(TPL_N_PARAMS);
+    /* pyOptimAlloc optim.c:1894-1921 */
+    o->trajCosts = 0; o->iterations = 0; o->lgIterations = 0; o->runtime = 0; o->alpha = 0;
+    o->trajectoryChanged = false; o->improved = false; o->terminationCondition = 0;
+    o->mu = 0; o->muStep = 0; o->minMu = 0; o->optStart = 0; o->integratorType = EULER;
+    o->dt = 0.05; o->T = omin(20, Tcap); o->minRelCostChange = 1e-6; o->maxIterations = 5;
+    o->maxLgIterations = 1; o->useQuadraticTerms = true;
+    for (int i = 0; i < CM; ++i) { o->lgMultLimit[i] = INFINITY; o->barrierWeight[i] = 1.0; }
+    for (int t = 0; t < omin(20, Tcap); ++t)
+        for (int i = 0; i < U; ++i) { o->uMax[(size_t)t * U + i] = INFINITY; o->uMin[(size_t)t * U + i] = -INFINITY; }
+    return o;
+}
+
+ILQO_API void ilqo_destroy(void* h) { delete (OOpt*)h; }
+
+/* field ids of include/tplhip_ilqr.h (enum TplIlqrField) */
+ILQO_API double* ilqo_ptr(void* h, int f)
+{
+    OOpt* o = (OOpt*)h;
+    switch (f) {
+    case 0: return o->int_step.data();  case 1: return o->x.data();       case 2: return o->u.data();
+    case 3: return o->next_int_step.data(); case 4: return o->next_x.data(); case 5: return o->next_u.data();
+    case 6: return o->prev_x.data();    case 7: return o->prev_u.data();  case 8: return o->prev_k.data();
+    case 9: return o->fx.data();        case 10: return o->fu.data();     case 11: return o->lx.data();
+    case 12: return o->lu.data();       case 13: return o->lxx.data();    case 14: return o->luu.data();
+    case 15: return o->lux.data();      case 16: return o->g.data();      case 17: return o->k.data();
+    case 18: return o->K.data();        case 19: return o->lam.data();    case 20: return o->barrierWeight;
+    case 21: return o->lgMultLimit;     case 22: return o->uMax.data();   case 23: return o->uMin.data();
+    }
+    return nullptr;
+}
+
+/* scalar ids of include/tplhip_ilqr.h (enum TplIlqrScalar) */
+ILQO_API double ilqo_get(void* h, int s)
+{
+    OOpt* o = (OOpt*)h;
+    switch (s) {
+    case 0: return o->trajCosts; case 1: return o->iterations; case 2: return o->lgIterations;
+    case 3: return o->runtime; case 4: return o->alpha; case 5: return o->mu; case 6: return o->muStep;
+    case 7: return o->minMu; case 8: return o->trajectoryChanged; case 9: return o->improved;
+    case 10: return o->terminationCondition; case 11: return o->useQuadraticTerms; case 12: return o->dt;
+    case 13: return o->maxIterations; case 14: return o->maxLgIterations; case 15: return o->optStart;
+    case 16: return o->minRelCostChange; case 17: return o->T; case 18: return o->integratorType;
+    }
+    return NAN;
+}
+
+ILQO_API void ilqo_set(void* h, int s, double v)
+{
+    OOpt* o = (OOpt*)h;
+    switch (s) {
+    case 0: o->trajCosts = v; break; case 1: o->iterations = (int)v; break; case 2: o->lgIterations = (int)v; break;
+    case 3: o->runtime = v; break; case 4: o->alpha = v; break; case 5: o->mu = v; break; case 6: o->muStep = (int)v; break;
+    case 7: o->minMu = v; break; case 8: o->trajectoryChanged = v != 0; break; case 9: o->improved = v != 0; break;
+    case 10: o->terminationCondition = (int)v; break; case 11: o->useQuadraticTerms = v != 0; break; case 12: o->dt = v; break;
+    case 13: o->maxIterations = (int)v; break; case 14: o->maxLgIterations = (int)v; break; case 15: o->optStart = (int)v; break;
+    case 16: o->minRelCostChange = v; break;
+    case 17: o->T = omin(o->Tcap, omax(1, (int)v)); break;      /* set_horizon optim.c:1726-1734 */
+    case 18: o->integratorType = (int)v; break;
+    }
+}
+
+ILQO_API int ilqo_set_param_scalar(void* h, int i, double v)
+{
+    OOpt* o = (OOpt*)h;
+    if (i < 0 || i >= TPL_N_PARAMS || g_params[i].is_array) return -1;
+    *(double*)((char*)&o->params + g_params[i].offset) = v;
+    return 0;
+}
+
+ILQO_API int ilqo_set_param_array(void* h, int i, const double* data, int ndim, const int64_t* dims)
+{
+    OOpt* o = (OOpt*)h;
+    if (i < 0 || i >= TPL_N_PARAMS || !g_params[i].is_array) return -1;
+    size_t n = 1;
+    for (int d = 0; d < ndim; ++d) n *= (size_t)dims[d];
+    if (ndim == 0) n = 0;
+    o->store.arrays[i].assign(data, data + n);
+    DynArr* a = (DynArr*)((char*)&o->params + g_params[i].offset);
+    a->data = o->store.arrays[i].data();
+    a->ndim = ndim;
+    a->n0 = ndim > 0 ? dims[0] : 0;
+    a->n1 = ndim > 1 ? dims[1] : 0;
+    return 0;
+}
+
+ILQO_API void ilqo_update(void* h) { update((OOpt*)h); }
+ILQO_API void ilqo_shift(void* h, int amount) { shift((OOpt*)h, amount); }
+
+ILQO_API void ilqo_dynamics(void* h, const double* x, const double* u, int t, double dt, double* out)
+{
+    OOpt* o = (OOpt*)h;
+    dynamics(o, x, u, t, dt, o->integratorType, out);
+}
+
+ILQO_API void ilqo_ct_dynamics(void* h, const double* x, const double* u, int t, double dt, double* out)
+{
+    OOpt* o = (OOpt*)h;
+    ctDynamics(o->params, x, u, t, dt, out, 1);
+}
+
+/* cpu_baseline: update() of n independent problems, OpenMP over problems */
+ILQO_API void ilqo_update_many(void** hs, int n, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+    for (int i = 0; i < n; ++i) update((OOpt*)hs[i]);
+    (void)nthreads;
+}
+
+ILQO_API int ilqo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

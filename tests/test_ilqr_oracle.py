@@ -1,0 +1,72 @@
+"""CPU tests: the HP-2 oracle (oracle/ilqr_oracle.cpp + the build's own generated
+model code) against the golden vectors captured from the reference genopt
+solver (tests/golden/ilqr_*.npz, made by tests/golden/make_ilqr_goldens.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import ilqr_cases as cases
+import oracle_ilqr as OI
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _golden(name):
+    return np.load(os.path.join(GOLDEN, f"ilqr_{name}.npz"))
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_oracle_matches_reference_golden(name):
+    model, _, kw, _ = cases.CASES[name]
+    g = _golden(name)
+    opt = OI.OracleOptim(model)
+    cases.apply_inputs(opt, g)
+    # dynamics()/ct_dynamics() spot values (optim.c:1496-1652)
+    assert np.allclose(opt.dynamics(g["dyn.x"], g["dyn.u"], 3, 0.07), g["dyn.dynamics"], rtol=1e-12, atol=1e-14)
+    assert np.allclose(opt.ct_dynamics(g["dyn.x"], g["dyn.u"], 3, 0.07), g["dyn.ct_dynamics"], rtol=1e-12, atol=1e-14)
+    snaps = cases.run_sequence(opt, int(g["in.shift"]))
+    bad = cases.compare(snaps, g, first_order=bool(kw.get("first_order")))
+    assert not bad, "\n".join(bad)
+
+
+def test_setup_functions_reproduce_golden_inputs():
+    """The fixtures' "in.*" part is what tests/ilqr_cases.py sets up (so the HIP
+    tests, which configure through the same functions, start from the same inputs)."""
+    for name, (model, setup, kw, shift) in cases.CASES.items():
+        g = _golden(name)
+        opt = OI.OracleOptim(model)
+        setup(opt, **kw)
+        for f in cases.INPUT_ARRAYS:
+            assert np.array_equal(np.asarray(getattr(opt, f)), g["in." + f]), (name, f)
+        for p in opt.params.__slots__:
+            assert np.array_equal(np.asarray(getattr(opt.params, p)), g["in.param." + p]), (name, p)
+
+
+def test_lerp_border_behaviour_is_the_references():
+    """The reference clamps (size_t)floor(q): below the table start the lookup
+    returns the LAST sample (optim.c:347-355).  The MPC derivative code hits this
+    at s_r = 0 (finite difference at -5e-5); pinned by the goldens above, stated
+    explicitly here through ct_dynamics of the lateral model (lerp over t*dt)."""
+    opt = OI.OracleOptim("trajectory_tracking_mpc")
+    cases.mpc(opt, seed=0, curvature=0.02)
+    x = np.array(opt.x[0], dtype=np.float64)
+    x[5] = -0.25                       # half a ref_step before the table start
+    f_neg = opt.ct_dynamics(x, np.zeros(2), 0, 0.05)
+    x[5] = 99 * 0.5                    # last sample
+    f_last = opt.ct_dynamics(x, np.zeros(2), 0, 0.05)
+    # s_dot uses r_phi, r_x, r_y, r_k looked up at s_r: identical at both ends
+    assert f_neg[5] == pytest.approx(f_last[5], rel=1e-12)
+
+
+def test_default_values_match_pyOptimAlloc():
+    # optim.c:1894-1921
+    opt = OI.OracleOptim("lateral_profile")
+    assert (opt.dt, opt.horizon, opt.max_iterations, opt.max_lg_iterations) == (0.05, 20, 5, 1)
+    assert opt.min_rel_cost_change == 1e-6 and opt.use_quadratic_terms is True
+    assert np.all(np.isinf(opt.lg_mult_limit)) and np.all(opt.barrier_weight == 1.0)
+    assert np.all(opt.u_max == np.inf) and np.all(opt.u_min == -np.inf)
+    opt.horizon = 30                   # rows past the first 20 were never initialised: zeros
+    assert np.all(opt.u_max[20:] == 0.0)
+    opt.horizon = 1000                 # clamped to H_MAX-1 (optim.c:1726-1734)
+    assert opt.horizon == 299

@@ -1,0 +1,370 @@
+"""genopt for MI355X: turns a symbolic optimal-control problem into a batched
+HIP iLQR solver.
+
+Mirror of the reference's ``tpl.optim.genopt`` *interface*
+(library/tpl/optim/genopt.py:428-665: ``Config``, ``build``, ``build_parallel``)
+with its own generator.  The derivation rules that decide numerical results are
+the reference's and are reproduced exactly:
+
+  D1  discrete Jacobians are those of the Euler map ``x + dt*f(x,u)`` whatever
+      integrator rolls the trajectory out           (genopt.py:93-110)
+  D2  stage costs get the augmented-Lagrangian terms
+      ``g*lam + (0 if g<0 and |lam|<1e-4 else w*g**2)`` per constraint; end
+      costs do not                                   (genopt.py:73-90, 544-553)
+  D3  derivatives of the opaque interpolation functions become central finite
+      differences with step 1e-4 (second derivatives: 3-point stencil), applied
+      twice to Hessians                              (genopt.py:65-70, 134-135)
+  D4  Hessians must be symmetric at generation time  (genopt.py:129-132)
+  D5  ``symext.fixed`` sub-expressions are constants during differentiation and
+      renamed back afterwards                        (genopt.py:557-558)
+  D6  the symbols ``t`` and ``dt`` are the routine arguments "stage index as
+      double" and "integration step of that stage"   (optim.c:899-908)
+  D7  at most two actions                            (genopt.py:420-425)
+
+What differs is everything after the symbolic stage: instead of one C file with
+a CPython type per problem, the generator emits one C++ header of
+``__host__ __device__`` routines (``model.inc``); ``csrc/ilqr/ilqr_model.hip``
+includes it and is compiled by hipcc into ``models/libilqr_<name>.so`` whose
+C-ABI is ``include/tplhip_ilqr.h``.
+"""
+
+import hashlib
+import os
+import subprocess
+import sys
+
+import sympy as sp
+from sympy.printing.c import C99CodePrinter
+from sympy.printing.precedence import precedence
+
+from . import symext as spx
+
+FD_STEP = 10e-5          # genopt.py:65 (literal 10e-5 == 1e-4)
+LAMBDA_ZERO = 10e-5      # genopt.py:81
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+MODELS_DIR = os.path.join(_PKG, "models")
+CSRC_ILQR = os.path.join(_PKG, "csrc", "ilqr")
+
+
+class Config:
+    """Problem description; same constructor as the reference's genopt.Config
+    (genopt.py:428-449).  ``params`` is a list of symbols or a dict symbol ->
+    default value (None = no default)."""
+
+    def __init__(self, states, actions, params, dynamics, costs, end_costs=0.0,
+                 constraints=(), use_cache=True, output_dir=None, name=None):
+        self.states = list(states)
+        self.actions = list(actions)
+        self.params = params
+        self.dynamics = dynamics
+        self.costs = costs
+        self.end_costs = end_costs
+        self.constraints = list(constraints)
+        self.use_cache = use_cache
+        self.output_dir = output_dir
+        self.name = name
+
+    @property
+    def param_symbols(self):
+        return list(self.params.keys()) if isinstance(self.params, dict) else list(self.params)
+
+    @property
+    def param_defaults(self):
+        if isinstance(self.params, dict):
+            return {s.name: v for s, v in self.params.items() if v is not None}
+        return {}
+
+    def fingerprint(self):
+        """sha1 over the problem text (the reference hashes the same parts plus
+        its templates, genopt.py:493-505)."""
+        parts = [self.states, self.actions, self.param_symbols, self.dynamics,
+                 _as_matrix(self.costs), _as_matrix(self.end_costs), self.constraints]
+        h = hashlib.sha1()
+        h.update("|".join(str(p) for p in parts).encode("utf8"))
+        return h.hexdigest()
+
+
+def _as_matrix(e):
+    return e if isinstance(e, sp.MatrixBase) else sp.Matrix([e])
+
+
+# --------------------------------------------------------------------------
+# symbolic stage
+# --------------------------------------------------------------------------
+
+def _finite_differences(m):
+    """Rule D3."""
+    repl = {d: d.as_finite_difference(FD_STEP) for d in m.atoms(sp.Derivative)}
+    return m.subs(repl) if repl else m
+
+
+def _augmented(cost, constraints):
+    """Rule D2."""
+    cost = _as_matrix(cost)
+    for ci, g in enumerate(constraints):
+        lam = sp.Symbol(f"lg_mult[{ci}]")
+        w = sp.Symbol(f"lg_weight[{ci}]")
+        cost = cost + sp.Matrix([g * lam])
+        cost = cost + sp.Matrix([sp.Piecewise(
+            (0.0, (g < 0) & (sp.Abs(lam) < LAMBDA_ZERO)),
+            (w * g**2, True))])
+    return cost
+
+
+def _symmetric_hessian(cost, var, what):
+    h = sp.hessian(cost, var)
+    if h != h.T:
+        raise RuntimeError(f"non-symmetric Hessian of the {what}")          # rule D4
+    return _finite_differences(_finite_differences(h))
+
+
+def derive_routines(cfg):
+    """name -> sympy Matrix, in emission order.  Expressions are still written
+    in the user's symbols."""
+    if len(cfg.actions) > 2:
+        raise NotImplementedError("more than 2 actions are not supported")   # rule D7
+    xs, us = cfg.states, cfg.actions
+    nx = len(xs)
+    var = xs + us
+    dt = sp.Symbol("dt")
+    f = sp.Matrix(cfg.dynamics)
+
+    euler = sp.Matrix([xs[i] + dt * f[i] for i in range(nx)])               # rule D1
+    jac = _finite_differences(euler.jacobian(var))
+
+    stage = _augmented(cfg.costs, cfg.constraints)
+    grad = _finite_differences(stage.jacobian(var)).T
+    hess = _symmetric_hessian(stage, var, "stage costs")
+
+    end = _as_matrix(cfg.end_costs)
+    end_grad = _finite_differences(end.jacobian(xs)).T
+    end_hess = _symmetric_hessian(end, xs, "end costs")
+
+    routines = [
+        ("ctDynamics", f),
+        ("stateJacobian", jac[:, :nx]),
+        ("actionJacobian", jac[:, nx:]),
+        ("costs", stage),
+        ("stateGradient", grad[:nx, :]),
+        ("actionGradient", grad[nx:, :]),
+        ("stateStateHessian", hess[:nx, :nx]),
+        ("actionActionHessian", hess[nx:, nx:]),
+        ("actionStateHessian", hess[nx:, :nx]),
+        ("endCosts", end),
+        ("endGradient", end_grad),
+        ("endHessian", end_hess),
+        ("constraints", sp.Matrix(cfg.constraints) if cfg.constraints else sp.zeros(0, 1)),
+    ]
+    return [(n, spx.unfixed(sp.Matrix(m)) if m.shape[0] else m) for n, m in routines]   # rule D5
+
+
+# --------------------------------------------------------------------------
+# code emission
+# --------------------------------------------------------------------------
+
+_OPAQUE_C = {
+    "get_array_value": "tpl_get_array_value",
+    "box_interp": "tpl_box_interp",
+    "lerp": "tpl_lerp",
+    "lerp_angle": "tpl_lerp_angle",
+    "blerp": "tpl_blerp",
+    "lerp_wrap": "tpl_lerp_wrap",
+}
+
+
+class _Printer(C99CodePrinter):
+    """C99 printer; integer powers become multiplications (``pow`` in fp64 is a
+    log/exp pair on the GPU), x**-1 -> 1.0/x, x**0.5 -> sqrt."""
+
+    def __init__(self):
+        super().__init__({"allow_unknown_functions": True,
+                          "user_functions": dict(_OPAQUE_C)})
+
+    def _print_Pow(self, expr):
+        base, e = expr.base, expr.exp
+        prec = precedence(expr)
+        b = self.parenthesize(base, prec)
+        if e == -1:
+            return f"1.0/{b}"
+        if e == sp.Rational(1, 2) or e == 0.5:
+            return f"sqrt({self._print(base)})"
+        if e == sp.Rational(-1, 2) or e == -0.5:
+            return f"1.0/sqrt({self._print(base)})"
+        if e.is_Integer and 2 <= abs(int(e)) <= 8:
+            n = abs(int(e))
+            prod = "(" + "*".join([b] * n) + ")"
+            return prod if e > 0 else f"1.0/{prod}"
+        return f"pow({self._print(base)}, {self._print(e)})"
+
+
+def _vectorise(m, cfg):
+    """States -> x[i], actions -> u[i], scalar params -> P.name (rule D6 leaves
+    t and dt alone)."""
+    ren = {}
+    for i, s in enumerate(cfg.states):
+        ren[s] = sp.Symbol(f"x[{i}]")
+    for i, s in enumerate(cfg.actions):
+        ren[s] = sp.Symbol(f"u[{i}]")
+    for p in cfg.param_symbols:
+        ren[p] = sp.Symbol(f"P.{p.name}")
+    return m.xreplace(ren)
+
+
+_SIGNATURES = {
+    "end": "const Params& P, const double* x, double t, double dt, double* out, int os",
+    "aug": "const Params& P, const double* x, const double* u, const double* lg_mult, "
+           "const double* lg_weight, double t, double dt, double* out, int os",
+    "dyn": "const Params& P, const double* x, const double* u, double t, double dt, double* out, int os",
+}
+
+
+def _signature(name):
+    if name.startswith("end"):
+        return _SIGNATURES["end"]
+    if name in ("costs", "constraints") or name.endswith("Hessian") or name.endswith("Gradient"):
+        return _SIGNATURES["aug"]
+    return _SIGNATURES["dyn"]
+
+
+def _emit_routine(name, m, cfg, printer):
+    lines = [f"TPL_HD inline void {name}({_signature(name)}) {{"]
+    # keep every argument "used" so -Wall stays quiet for trivial routines
+    lines.append("    (void)P; (void)x; (void)t; (void)dt; (void)os;")
+    if "const double* u" in _signature(name):
+        lines.append("    (void)u;")
+    if "lg_mult" in _signature(name):
+        lines.append("    (void)lg_mult; (void)lg_weight;")
+    n = m.shape[0] * m.shape[1]
+    if n:
+        flat = [_vectorise(sp.sympify(e), cfg) for e in m]               # row-major
+        subs, reduced = sp.cse(flat, symbols=sp.numbered_symbols("w"))
+        for sym, e in subs:
+            lines.append(f"    const double {sym} = {printer.doprint(e)};")
+        for i, e in enumerate(reduced):
+            lines.append(f"    out[{i}*os] = {printer.doprint(e)};")
+    lines.append("}")
+    return "\n".join(lines)
+
+
+def emit_model(cfg, name):
+    """Text of model.inc for ``cfg``."""
+    printer = _Printer()
+    routines = derive_routines(cfg)
+    out = []
+    out.append("// generated by tpl_amd.optim.genopt -- do not edit")
+    out.append(f"// problem {name}  fingerprint {cfg.fingerprint()}")
+    out.append(f"#define TPL_MODEL_NAME \"{name}\"")
+    out.append(f"#define TPL_X {len(cfg.states)}")
+    out.append(f"#define TPL_U {len(cfg.actions)}")
+    out.append(f"#define TPL_C {len(cfg.constraints)}")
+    out.append(f"#define TPL_CMAX {max(1, len(cfg.constraints))}")
+    scal = [p for p in cfg.param_symbols if not isinstance(p, spx.ArraySymbol)]
+    arrs = [p for p in cfg.param_symbols if isinstance(p, spx.ArraySymbol)]
+    out.append("struct Params {")
+    for p in scal:
+        out.append(f"    double {p.name};")
+    for p in arrs:
+        out.append(f"    DynArr {p.name};")
+    if not scal and not arrs:
+        out.append("    double _unused;")
+    out.append("};")
+    # X-macro in declaration order of the Config (that order is the __slots__ order)
+    entries = []
+    for p in cfg.param_symbols:
+        kind = "A" if isinstance(p, spx.ArraySymbol) else "S"
+        entries.append(f"    TPL_PARAM_{kind}({p.name})")
+    out.append("#define TPL_PARAM_LIST \\\n" + " \\\n".join(entries) if entries else "#define TPL_PARAM_LIST")
+    out.append(f"#define TPL_N_PARAMS {len(cfg.param_symbols)}")
+    out.append("")
+    for rname, m in routines:
+        out.append(_emit_routine(rname, m, cfg, printer))
+        out.append("")
+    spx.clear_cache()
+    return "\n".join(out)
+
+
+# --------------------------------------------------------------------------
+# build + load
+# --------------------------------------------------------------------------
+
+def model_name(cfg):
+    return cfg.name or ("m" + cfg.fingerprint()[:16])
+
+
+def model_paths(name, out_dir=None):
+    d = out_dir or MODELS_DIR
+    return {
+        "inc": os.path.join(d, f"{name}.inc"),
+        "so": os.path.join(d, f"libilqr_{name}.so"),
+        "dir": d,
+    }
+
+
+def generate(cfg, name=None, out_dir=None, force=False):
+    """Write ``<name>.inc`` if missing or stale; returns its path."""
+    name = name or model_name(cfg)
+    paths = model_paths(name, out_dir)
+    os.makedirs(paths["dir"], exist_ok=True)
+    tag = f"fingerprint {cfg.fingerprint()}"
+    if not force and os.path.exists(paths["inc"]):
+        with open(paths["inc"]) as fd:
+            head = fd.read(400)
+        if tag in head:
+            return paths["inc"]
+    text = emit_model(cfg, name)
+    tmp = paths["inc"] + f".tmp{os.getpid()}"
+    with open(tmp, "w") as fd:
+        fd.write(text)
+    os.replace(tmp, paths["inc"])
+    return paths["inc"]
+
+
+def compile_model(name, out_dir=None, force=False):
+    """hipcc the solver template against ``<name>.inc`` -> libilqr_<name>.so."""
+    paths = model_paths(name, out_dir)
+    src = os.path.join(CSRC_ILQR, "ilqr_model.hip")
+    deps = [paths["inc"], src] + [os.path.join(CSRC_ILQR, f) for f in os.listdir(CSRC_ILQR) if f.endswith(".h")]
+    if not force and os.path.exists(paths["so"]):
+        if all(os.path.getmtime(paths["so"]) >= os.path.getmtime(d) for d in deps):
+            return paths["so"]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tmp = paths["so"] + f".tmp{os.getpid()}"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-fvisibility=hidden", "-fno-fast-math", "-Wall", "-Wno-unused-value", "-Wno-unused-function",
+           f"-DTPL_MODEL_INC=\"{paths['inc']}\"", "-I", os.path.join(_PKG, "..", "include"),
+           "-o", tmp, src]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if proc.returncode != 0:
+        raise RuntimeError("\n" + proc.stdout.decode("utf8", "replace"))
+    os.replace(tmp, paths["so"])
+    return paths["so"]
+
+
+def build_module(cfg, name=None, out_dir=None):
+    name = name or model_name(cfg)
+    generate(cfg, name, out_dir)
+    return compile_model(name, out_dir), name
+
+
+def build(cfg, name=None, out_dir=None):
+    """Generate + compile + load; returns a factory ``f(batch=1, horizon=None,
+    device=-1) -> Optim`` that also applies the Config's default parameter
+    values (the reference's ``get_opt_builder``, genopt.py:622-647)."""
+    from . import solver
+    so, name = build_module(cfg, name, out_dir or cfg.output_dir)
+    return solver.factory(so, cfg.param_defaults)
+
+
+def build_parallel(cfgs, names=None):
+    """The reference forks a pool for its gcc builds (genopt.py:658-665); hipcc
+    builds are run as concurrent subprocesses here."""
+    import concurrent.futures as cf
+    names = names or [model_name(c) for c in cfgs]
+    for c, n in zip(cfgs, names):
+        generate(c, n)
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(cfgs) or 1)) as ex:
+        sos = list(ex.map(compile_model, names))
+    from . import solver
+    return [solver.factory(so, c.param_defaults) for so, c in zip(sos, cfgs)]
