@@ -101,6 +101,8 @@ TPLHIP_API void tplhip_ilqr_dims(int* X, int* U, int* C, int* n_params);
 TPLHIP_API const char* tplhip_ilqr_param_name(int i);        /* Config order = Params.__slots__ order */
 TPLHIP_API int tplhip_ilqr_param_is_array(int i);
 TPLHIP_API const char* tplhip_ilqr_last_error(void);
+/* sha1 of the problem text the library was generated from (genopt.Config.fingerprint) */
+TPLHIP_API const char* tplhip_ilqr_fingerprint(void);
 
 /* ---- lifetime --------------------------------------------------------------- */
 /* t_cap: stages of storage per problem (horizon may be set to anything in

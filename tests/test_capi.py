@@ -11,12 +11,9 @@ from tpl_amd import _capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    names = []
-    for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
-        text = open(h).read()
-        names += re.findall(r"TPLHIP_API\s+[\w\s\*]+?\b(tplhip_\w+)\s*\(", text)
-    return names
+def _declared(header="tplhip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    return re.findall(r"TPLHIP_API\s+[\w\s\*]+?\b(tplhip_\w+)\s*\(", text)
 
 
 def test_every_declared_symbol_is_exported():
@@ -28,13 +25,26 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_python_signatures_cover_the_header():
-    declared = set(_declared())
-    try:
-        from tpl_amd import _capi_ilqr
-        known = set(_capi.SIGNATURES) | set(_capi_ilqr.SIGNATURES)
-    except ImportError:
-        known = set(_capi.SIGNATURES)
-    assert declared == known
+    assert set(_declared()) == set(_capi.SIGNATURES)
+    from tpl_amd.optim import solver
+    assert set(_declared("tplhip_ilqr.h")) == set(solver.SIGNATURES)
+
+
+def test_every_model_library_exports_the_ilqr_abi():
+    from tpl_amd.optim import optimizers as o, solver
+    names = _declared("tplhip_ilqr.h")
+    assert len(names) >= 20
+    for fn in o.CONFIG_FUNCTIONS + o.EXTRA_CONFIG_FUNCTIONS:
+        cfg = fn()
+        so = os.path.join(ROOT, "tpl_amd", "models", f"libilqr_{cfg.name}.so")
+        lib = solver.load_model(so)                 # declares every signature or raises
+        for n in names:
+            assert hasattr(lib, n), (cfg.name, n)
+        x, u, c, npar = (C.c_int(), C.c_int(), C.c_int(), C.c_int())
+        lib.tplhip_ilqr_dims(C.byref(x), C.byref(u), C.byref(c), C.byref(npar))
+        assert (x.value, u.value, c.value) == (len(cfg.states), len(cfg.actions), len(cfg.constraints))
+        assert [lib.tplhip_ilqr_param_name(i).decode() for i in range(npar.value)] == [p.name for p in cfg.param_symbols]
+        assert lib.tplhip_ilqr_fingerprint().decode() == cfg.fingerprint()
 
 
 def test_no_gpu_means_loud_failure():
@@ -46,6 +56,10 @@ def test_no_gpu_means_loud_failure():
         tpl_amd.DynProgLonPlanner()
     with pytest.raises(RuntimeError, match="no usable HIP device"):
         tpl_amd.DynProgEnvironment()
+    from tpl_amd.optim import genopt, optimizers as o
+    make = genopt.build(o.config_simple_vehicle(), "simple_vehicle")
+    with pytest.raises(RuntimeError, match="no usable HIP device"):
+        make()
 
 
 def test_param_surface_matches_reference_slots():

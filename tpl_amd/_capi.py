@@ -114,11 +114,6 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    try:
-        from . import _capi_ilqr
-        _capi_ilqr.declare(lib)
-    except ImportError:
-        pass
     _lib = lib
     return lib
 

@@ -1,0 +1,1125 @@
+// ilqr_model.hip -- HP-2: batched augmented-Lagrangian iLQR for ONE generated
+// model, hand-written for gfx950.  Compiled once per optimal-control problem
+// with -DTPL_MODEL_INC="<problem>.inc" into models/libilqr_<problem>.so; the
+// C-ABI is include/tplhip_ilqr.h.
+//
+// Replaces the solver half of the reference's per-problem C module
+// (library/tpl/optim/templates/optim.c:243-291, 657-1177).  MI355X-first design,
+// not a translation:
+//
+//  * ONE WAVEFRONT PER PROBLEM (64-thread workgroup), `batch` workgroups per
+//    launch, one launch per update() -- the whole outer loop (initial rollout,
+//    multiplier update, every iLQR iteration, line search) runs inside the
+//    kernel, so there is no host round trip per iteration;
+//  * derivative refresh and the multiplier update are parallel over the
+//    horizon (lane = stage);
+//  * the backward Riccati recursion is sequential in the stage but parallel
+//    over matrix entries: the stage's blocks are staged in LDS, lanes own
+//    entries of  W = Vxx [fx fu],  Q = L + [fx fu]^T W,  the gains and the new
+//    Vxx/Vx (four LDS exchanges per stage).  The matrices are <= 8x8, far too
+//    small and too latency-bound for MFMA (v_mfma_f64_16x16x4 would be >90 %
+//    padding); DESIGN.md has the numbers;
+//  * the eight line-search candidates alpha = 10^-i are rolled out
+//    CONCURRENTLY on eight lanes and the first improving one in the order
+//    i = 0..7 is taken, which is exactly the reference's accept-first result
+//    (optim.c:859-873) at the cost of a single rollout;
+//  * all state lives in HBM in the layout of the host mirrors (row-major
+//    [stage][...] per problem), so upload/download are plain copies and the
+//    backward pass reads each stage's blocks as contiguous, coalesced runs.
+// Arithmetic is fp64 like the reference.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "builtins.h"
+#include TPL_MODEL_INC
+#include "tplhip_ilqr.h"
+
+namespace {
+
+constexpr int NX = TPL_X;
+constexpr int NU = TPL_U;
+constexpr int NC = TPL_C;
+constexpr int NCM = TPL_CMAX;          // storage width of a multiplier row (>= 1)
+constexpr int NXU = NX + NU;
+constexpr int N_ALPHA = 8;             // optim.c:861
+constexpr int WAVE = 64;
+
+enum { EULER = 0, HEUN = 1, RK4 = 2 };
+
+// widths (doubles per row) of the per-stage fields, in TplIlqrField order
+__host__ __device__ constexpr int field_width(int f)
+{
+    switch (f) {
+    case TPL_F_INT_STEP: case TPL_F_NEXT_INT_STEP: return 1;
+    case TPL_F_X: case TPL_F_NEXT_X: case TPL_F_PREV_X: case TPL_F_LX: return NX;
+    case TPL_F_U: case TPL_F_NEXT_U: case TPL_F_PREV_U: case TPL_F_PREV_K: case TPL_F_LU:
+    case TPL_F_G: case TPL_F_K_FF: case TPL_F_U_MAX: case TPL_F_U_MIN: return NU;
+    case TPL_F_FX: case TPL_F_LXX: return NX * NX;
+    case TPL_F_FU: case TPL_F_LUX: case TPL_F_K_FB: return NX * NU;
+    case TPL_F_LUU: return NU * NU;
+    case TPL_F_LAGRANGE_MULTIPLIER: return NCM;
+    case TPL_F_BARRIER_WEIGHT: case TPL_F_LG_MULT_LIMIT: return NCM;   // one row
+    }
+    return 0;
+}
+
+__host__ __device__ constexpr bool field_is_per_stage(int f)
+{
+    return f != TPL_F_BARRIER_WEIGHT && f != TPL_F_LG_MULT_LIMIT;
+}
+
+struct DevState {
+    double* f[TPL_F_COUNT];            // device base of every field, [batch][rows][width]
+    double* scalars;                   // [batch][TPL_S_COUNT]
+    const Params* params;              // [batch]
+    double* cand_x;                    // [batch][N_ALPHA][rows][NX]   line-search candidates
+    double* cand_u;                    // [batch][N_ALPHA][rows][NU]
+    int rows;                          // t_cap + 1
+};
+
+__device__ __forceinline__ double* fld(const DevState& st, int f, int b)
+{
+    const int64_t rows = field_is_per_stage(f) ? st.rows : 1;
+    return st.f[f] + (int64_t)b * rows * field_width(f);
+}
+
+// dynamics(), optim.c:657-730
+__device__ __forceinline__ void dynamics(const Params& P, const double* x, const double* u, int t,
+                                         double dt, int int_type, double* res)
+{
+    double k1[NX];
+    ctDynamics(P, x, u, (double)t, dt, k1, 1);
+    if (int_type == EULER) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) res[i] = x[i] + k1[i] * dt;
+    } else if (int_type == HEUN) {
+        double tmp[NX], k2[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tmp[i] = x[i] + k1[i] * dt;
+        ctDynamics(P, tmp, u, (double)t, dt, k2, 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) res[i] = x[i] + (k1[i] + k2[i]) * (dt / 2.0);
+    } else {
+        double tmp[NX], k2[NX], k3[NX], k4[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tmp[i] = x[i] + k1[i] * (dt / 2.0);
+        ctDynamics(P, tmp, u, (double)t, dt, k2, 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tmp[i] = x[i] + k2[i] * (dt / 2.0);
+        ctDynamics(P, tmp, u, (double)t, dt, k3, 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tmp[i] = x[i] + k3[i] * dt;
+        ctDynamics(P, tmp, u, (double)t, dt, k4, 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double acc = k1[i] + 0.0;
+            acc = k2[i] * 2.0 + acc;
+            acc = k3[i] * 2.0 + acc;
+            acc = k4[i] + acc;
+            res[i] = x[i] + acc * (dt / 6.0);
+        }
+    }
+}
+
+// LDS working set of one problem
+struct Lds {
+    double Vxx[NX * NX];
+    double Vx[NX];
+    double F[NX * NXU];        // [fx | fu], row-major over the NXU columns
+    double l[NXU];             // [lx ; lu]
+    double Lxx[NX * NX];
+    double Lux[NU * NX];
+    double Luu[NU * NU];
+    double W[NX * NXU];        // Vxx [fx fu]
+    double q[NXU];             // [Qx ; Qu]
+    double Qxx[NX * NX];
+    double Qux[NU * NX];
+    double Quu[NU * NU];
+    double K[NU * NX];
+    double k[NU];
+    double ulim[3 * NU];       // u[t], uMax[t], uMin[t]
+    double red[N_ALPHA];
+};
+
+// ---------------------------------------------------------------------------
+// one update() of problem blockIdx.x  (optim.c:1091-1160)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
+{
+    __shared__ Lds s;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const Params& P = st.params[b];
+    double* sc = st.scalars + (int64_t)b * TPL_S_COUNT;
+
+    const int T = (int)sc[TPL_S_HORIZON];
+    const int opt_start = (int)sc[TPL_S_OPT_START];
+    const int max_iter = (int)sc[TPL_S_MAX_ITERATIONS];
+    const int max_lg = (int)sc[TPL_S_MAX_LG_ITERATIONS];
+    const int int_type = (int)sc[TPL_S_INTEGRATOR_TYPE];
+    const bool second_order = sc[TPL_S_USE_QUADRATIC_TERMS] != 0.0;
+    const double dt = sc[TPL_S_DT];
+    const double min_rel = sc[TPL_S_MIN_REL_COST_CHANGE];
+    double mu = sc[TPL_S_MU];
+    int mu_step = (int)sc[TPL_S_MU_STEP];
+    double alpha = sc[TPL_S_ALPHA];
+    int term = (int)sc[TPL_S_TERMINATION_CONDITION];
+    bool improved = sc[TPL_S_IMPROVED] != 0.0;
+    bool traj_changed = sc[TPL_S_TRAJECTORY_CHANGED] != 0.0;
+    int iterations = (int)sc[TPL_S_ITERATIONS];
+    int lg_it = 0;
+
+    double* X_ = fld(st, TPL_F_X, b);
+    double* U_ = fld(st, TPL_F_U, b);
+    double* IS = fld(st, TPL_F_INT_STEP, b);
+    double* NIS = fld(st, TPL_F_NEXT_INT_STEP, b);
+    double* NXT_X = fld(st, TPL_F_NEXT_X, b);
+    double* NXT_U = fld(st, TPL_F_NEXT_U, b);
+    double* PRV_X = fld(st, TPL_F_PREV_X, b);
+    double* PRV_K = fld(st, TPL_F_PREV_K, b);
+    double* FX = fld(st, TPL_F_FX, b);
+    double* FU = fld(st, TPL_F_FU, b);
+    double* LX = fld(st, TPL_F_LX, b);
+    double* LU = fld(st, TPL_F_LU, b);
+    double* LXX = fld(st, TPL_F_LXX, b);
+    double* LUU = fld(st, TPL_F_LUU, b);
+    double* LUX = fld(st, TPL_F_LUX, b);
+    double* G_ = fld(st, TPL_F_G, b);
+    double* KFF = fld(st, TPL_F_K_FF, b);
+    double* KFB = fld(st, TPL_F_K_FB, b);
+    double* LAM = fld(st, TPL_F_LAGRANGE_MULTIPLIER, b);
+    const double* BW = fld(st, TPL_F_BARRIER_WEIGHT, b);
+    const double* LGL = fld(st, TPL_F_LG_MULT_LIMIT, b);
+    const double* UMAX = fld(st, TPL_F_U_MAX, b);
+    const double* UMIN = fld(st, TPL_F_U_MIN, b);
+    double* CX = st.cand_x + (int64_t)b * N_ALPHA * st.rows * NX;
+    double* CU = st.cand_u + (int64_t)b * N_ALPHA * st.rows * NU;
+
+    // ---- initial trajectory rollout, optim.c:1101-1111 (serial in t: one lane)
+    double J = 0.0;
+    if (lane == 0) {
+        double x[NX], u[NU], xn[NX], c;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)opt_start * NX + i];
+        for (int t = opt_start; t < T; ++t) {
+#pragma unroll
+            for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
+            IS[t] = dt;
+            dynamics(P, x, u, t, dt, int_type, xn);
+            costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
+            J += c;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                x[i] = xn[i];
+                X_[(int64_t)(t + 1) * NX + i] = xn[i];
+            }
+        }
+        IS[T] = dt;
+        endCosts(P, x, (double)T, dt, &c, 1);
+        J += c;
+    }
+    J = __shfl(J, 0, WAVE);
+    __syncthreads();
+
+    for (lg_it = 0; lg_it < max_lg; ++lg_it) {
+        // ---- multiplier update, optim.c:1119-1132 (lane = stage)
+        if (NC > 0) {
+            for (int t = opt_start + lane; t < T; t += WAVE) {
+                double x[NX], u[NU], lam[NCM], g[NCM];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
+#pragma unroll
+                for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
+#pragma unroll
+                for (int c = 0; c < NCM; ++c) { lam[c] = LAM[(int64_t)t * NCM + c]; g[c] = 0.0; }
+                constraints(P, x, u, lam, BW, (double)t, IS[t], g, 1);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    double v = lam[c] + BW[c] * g[c];
+                    v = v > 0.0 ? v : 0.0;
+                    v = LGL[c] < v ? LGL[c] : v;
+                    LAM[(int64_t)t * NCM + c] = v;
+                }
+            }
+        }
+        __syncthreads();
+        traj_changed = true;
+        improved = false;
+        iterations = 0;
+
+        // ---- ilqr() optim.c:875-1008 / ilr() :1010-1089
+        for (int it = iterations; it < max_iter; ++it) {
+            iterations = it + 1;
+
+            if (traj_changed) {
+                // derivative refresh, optim.c:896-911 (lane = stage)
+                for (int t = lane; t < T; t += WAVE) {
+                    double x[NX], u[NU], lam[NCM];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
+#pragma unroll
+                    for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
+#pragma unroll
+                    for (int c = 0; c < NCM; ++c) lam[c] = LAM[(int64_t)t * NCM + c];
+                    const double ist = IS[t];
+                    stateJacobian(P, x, u, (double)t, ist, FX + (int64_t)t * NX * NX, 1);
+                    actionJacobian(P, x, u, (double)t, ist, FU + (int64_t)t * NX * NU, 1);
+                    stateGradient(P, x, u, lam, BW, (double)t, ist, LX + (int64_t)t * NX, 1);
+                    actionGradient(P, x, u, lam, BW, (double)t, ist, LU + (int64_t)t * NU, 1);
+                    if (second_order) {
+                        stateStateHessian(P, x, u, lam, BW, (double)t, ist, LXX + (int64_t)t * NX * NX, 1);
+                        actionActionHessian(P, x, u, lam, BW, (double)t, ist, LUU + (int64_t)t * NU * NU, 1);
+                        actionStateHessian(P, x, u, lam, BW, (double)t, ist, LUX + (int64_t)t * NU * NX, 1);
+                    }
+                }
+                traj_changed = false;
+                __syncthreads();
+            }
+
+            // value function at the end of the horizon, optim.c:914-916
+            if (lane == 0) {
+                double x[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)T * NX + i];
+                endGradient(P, x, (double)T, IS[T], s.Vx, 1);
+                if (second_order) endHessian(P, x, (double)T, IS[T], s.Vxx, 1);
+            }
+            __syncthreads();
+
+            if (second_order) {
+                // ---- backward Riccati pass, optim.c:926-985
+                for (int t = T - 1; t >= 0; --t) {
+                    // stage blocks -> LDS (coalesced runs of the row-major mirrors)
+                    for (int e = lane; e < NX * NX; e += WAVE) {
+                        const int i = e / NX, j = e - i * NX;
+                        s.F[i * NXU + j] = FX[(int64_t)t * NX * NX + e];
+                        s.Lxx[e] = LXX[(int64_t)t * NX * NX + e];
+                    }
+                    for (int e = lane; e < NX * NU; e += WAVE) {
+                        const int i = e / NU, j = e - i * NU;
+                        s.F[i * NXU + NX + j] = FU[(int64_t)t * NX * NU + e];
+                        s.Lux[e] = LUX[(int64_t)t * NU * NX + e];
+                    }
+                    if (lane < NX) s.l[lane] = LX[(int64_t)t * NX + lane];
+                    if (lane < NU) {
+                        s.l[NX + lane] = LU[(int64_t)t * NU + lane];
+                        s.ulim[lane] = U_[(int64_t)t * NU + lane];
+                        s.ulim[NU + lane] = UMAX[(int64_t)t * NU + lane];
+                        s.ulim[2 * NU + lane] = UMIN[(int64_t)t * NU + lane];
+                    }
+                    if (lane < NU * NU) s.Luu[lane] = LUU[(int64_t)t * NU * NU + lane];
+                    __syncthreads();
+
+                    // phase A: W = Vxx [fx fu];  q = l + [fx fu]^T Vx
+                    for (int e = lane; e < NX * NXU; e += WAVE) {
+                        const int i = e / NXU, j = e - i * NXU;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int m = 0; m < NX; ++m) acc += s.Vxx[i * NX + m] * s.F[m * NXU + j];
+                        s.W[e] = acc;
+                    }
+                    if (lane < NXU) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int m = 0; m < NX; ++m) acc += s.F[m * NXU + lane] * s.Vx[m];
+                        s.q[lane] = s.l[lane] + acc;
+                    }
+                    __syncthreads();
+
+                    // phase B: Qxx, Qux, Quu = L + F^T W  (symmetric blocks: lower triangle, mirrored)
+                    for (int e = lane; e < NX * NX + NU * NX + NU * NU; e += WAVE) {
+                        if (e < NX * NX) {
+                            int i = e / NX, j = e - i * NX;
+                            const int hi = i > j ? i : j, lo = i > j ? j : i;
+                            double acc = 0.0;
+#pragma unroll
+                            for (int m = 0; m < NX; ++m) acc += s.F[m * NXU + hi] * s.W[m * NXU + lo];
+                            s.Qxx[e] = s.Lxx[e] + acc;
+                        } else if (e < NX * NX + NU * NX) {
+                            const int r = e - NX * NX;
+                            const int d = r / NX, j = r - d * NX;
+                            double acc = 0.0;
+#pragma unroll
+                            for (int m = 0; m < NX; ++m) acc += s.F[m * NXU + NX + d] * s.W[m * NXU + j];
+                            s.Qux[r] = s.Lux[r] + acc;
+                        } else {
+                            const int r = e - NX * NX - NU * NX;
+                            const int d = r / NU, c = r - d * NU;
+                            const int hi = d > c ? d : c, lo = d > c ? c : d;
+                            double acc = 0.0;
+#pragma unroll
+                            for (int m = 0; m < NX; ++m) acc += s.F[m * NXU + NX + hi] * s.W[m * NXU + NX + lo];
+                            s.Quu[r] = s.Luu[r] + acc;
+                        }
+                    }
+                    __syncthreads();
+
+                    // phase C: gains (solve_action optim.c:243-291) + control-box projection (:950-963)
+                    if (lane < NU * (NX + 1)) {
+                        const int d = lane / (NX + 1), c = lane - d * (NX + 1);
+                        double inv[NU][NU];
+                        if constexpr (NU == 1) {
+                            inv[0][0] = (s.Quu[0] > 0.0) ? -1.0 / (s.Quu[0] + mu) : 0.0;
+                        } else {
+                            const double qa = s.Quu[0] + mu, qb = s.Quu[1], qd = s.Quu[NU + 1] + mu;
+                            const double det = qa * qd - qb * qb;
+                            const double inv_det = -1.0f / det;
+                            inv[0][0] = qd * inv_det;
+                            inv[0][NU - 1] = -qb * inv_det;
+                            inv[NU - 1][0] = inv[0][NU - 1];
+                            inv[NU - 1][NU - 1] = qa * inv_det;
+                        }
+                        double kd = 0.0;
+#pragma unroll
+                        for (int m = 0; m < NU; ++m) kd += inv[d][m] * s.q[NX + m];
+                        double val;
+                        if (c == NX) {
+                            val = kd;
+                        } else {
+                            val = 0.0;
+#pragma unroll
+                            for (int m = 0; m < NU; ++m) val += inv[d][m] * s.Qux[m * NX + c];
+                        }
+                        const double ud = s.ulim[d], umax = s.ulim[NU + d], umin = s.ulim[2 * NU + d];
+                        const double cd = ud + kd;
+                        if (cd > umax) val = (c == NX) ? umax - ud : 0.0;
+                        if (cd < umin) val = (c == NX) ? umin - ud : 0.0;
+                        if (c == NX) {
+                            s.k[d] = val;
+                            KFF[(int64_t)t * NU + d] = val;
+                        } else {
+                            s.K[d * NX + c] = val;
+                            KFB[(int64_t)t * NU * NX + d * NX + c] = val;
+                        }
+                    }
+                    __syncthreads();
+
+                    // phase D: value function update, optim.c:965-984 (same order of additions)
+                    double vxx_new = 0.0, vx_new = 0.0;
+                    if (lane < NX * NX) {
+                        const int i = lane / NX, j = lane - i * NX;
+                        double mij = 0.0, mji = 0.0;
+#pragma unroll
+                        for (int d = 0; d < NU; ++d) {
+                            mij += s.K[d * NX + i] * s.Qux[d * NX + j];
+                            mji += s.K[d * NX + j] * s.Qux[d * NX + i];
+                        }
+                        double v = mji + mij;
+#pragma unroll
+                        for (int d = 0; d < NU; ++d) {
+                            double kq = 0.0;                 // (K^T Quu)[i][d]
+#pragma unroll
+                            for (int m = 0; m < NU; ++m) kq += s.K[m * NX + i] * s.Quu[m * NU + d];
+                            v += kq * s.K[d * NX + j];
+                        }
+                        vxx_new = v + s.Qxx[lane];
+                    }
+                    if (lane < NX) {
+                        const int i = lane;
+                        double v = 0.0;
+#pragma unroll
+                        for (int d = 0; d < NU; ++d) {
+                            double kq = 0.0;
+#pragma unroll
+                            for (int m = 0; m < NU; ++m) kq += s.K[m * NX + i] * s.Quu[m * NU + d];
+                            v += kq * s.k[d];
+                        }
+#pragma unroll
+                        for (int d = 0; d < NU; ++d) v += s.K[d * NX + i] * s.q[NX + d];
+#pragma unroll
+                        for (int d = 0; d < NU; ++d) v += s.Qux[d * NX + i] * s.k[d];
+                        vx_new = v + s.q[i];
+                    }
+                    __syncthreads();
+                    if (lane < NX * NX) s.Vxx[lane] = vxx_new;
+                    if (lane < NX) s.Vx[lane] = vx_new;
+                    __syncthreads();
+                }
+            } else {
+                // ---- first-order backward pass, optim.c:1044-1073
+                for (int t = T - 1; t >= 0; --t) {
+                    double qx = 0.0, qu = 0.0;
+                    if (lane < NX) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int m = 0; m < NX; ++m) acc += FX[(int64_t)t * NX * NX + m * NX + lane] * s.Vx[m];
+                        qx = LX[(int64_t)t * NX + lane] + acc;
+                    }
+                    if (lane < NU) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int m = 0; m < NX; ++m) acc += FU[(int64_t)t * NX * NU + m * NU + lane] * s.Vx[m];
+                        qu = LU[(int64_t)t * NU + lane] + acc;
+                        G_[(int64_t)t * NU + lane] = qu;
+                        double kk = qu;
+                        const double c = U_[(int64_t)t * NU + lane] - qu;
+                        if (c > UMAX[(int64_t)t * NU + lane]) kk = U_[(int64_t)t * NU + lane] - UMAX[(int64_t)t * NU + lane];
+                        if (c < UMIN[(int64_t)t * NU + lane]) kk = U_[(int64_t)t * NU + lane] - UMIN[(int64_t)t * NU + lane];
+                        KFF[(int64_t)t * NU + lane] = kk;
+                    }
+                    __syncthreads();
+                    if (lane < NX) s.Vx[lane] = qx;
+                    __syncthreads();
+                }
+            }
+
+            // ---- line search, optim.c:859-873: all eight alphas at once, accept the first
+            const double J_prev = J;
+            double Jc = INFINITY;
+            if (lane < N_ALPHA) {
+                double a = 1.0;
+                for (int i = 0; i < lane; ++i) a *= 10.0;
+                a = 1.0 / a;                                   // 1.0 / pow(10, i)
+                double* cx = CX + (int64_t)lane * st.rows * NX;
+                double* cu = CU + (int64_t)lane * st.rows * NU;
+                double x[NX], xn[NX], u[NU], c;
+                // stages before opt_start are frozen (tpl never moves opt_start off 0)
+                for (int e = 0; e < opt_start * NX; ++e) cx[e] = X_[e];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { x[i] = X_[(int64_t)opt_start * NX + i]; cx[(int64_t)opt_start * NX + i] = x[i]; }
+                double cost = 0.0;
+                for (int t = opt_start; t < T; ++t) {
+                    // lqrForwardPass :745-758 / lrForwardPass :803-805
+#pragma unroll
+                    for (int d = 0; d < NU; ++d) {
+                        double ud;
+                        if (second_order) {
+                            ud = KFF[(int64_t)t * NU + d] * a;
+                            ud = ud + U_[(int64_t)t * NU + d];
+#pragma unroll
+                            for (int i = 0; i < NX; ++i)
+                                ud += KFB[(int64_t)t * NU * NX + d * NX + i] * (x[i] - X_[(int64_t)t * NX + i]);
+                            const double hi = UMAX[(int64_t)t * NU + d], lo = UMIN[(int64_t)t * NU + d];
+                            ud = hi < ud ? hi : ud;
+                            ud = lo > ud ? lo : ud;
+                        } else {
+                            ud = U_[(int64_t)t * NU + d] - KFF[(int64_t)t * NU + d] * a;
+                        }
+                        u[d] = ud;
+                        cu[(int64_t)t * NU + d] = ud;
+                    }
+                    dynamics(P, x, u, t, dt, int_type, xn);
+                    costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
+                    cost += c;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        x[i] = xn[i];
+                        cx[(int64_t)(t + 1) * NX + i] = xn[i];
+                    }
+                }
+                endCosts(P, x, (double)T, dt, &c, 1);
+                cost += c;
+                Jc = cost;
+            }
+            // testImprovement, optim.c:840-857
+            const bool ok = lane < N_ALPHA && Jc < J && isfinite(Jc) && Jc >= 0.0;
+            const unsigned long long okm = __ballot(ok);
+            const bool accepted = okm != 0ull;
+            const int pick = accepted ? (int)__builtin_ctzll(okm) : N_ALPHA - 1;
+            {
+                double a = 1.0;
+                for (int i = 0; i < pick; ++i) a *= 10.0;
+                alpha = 1.0 / a;
+            }
+            __syncthreads();                                   // candidates visible to the whole wave
+            {
+                const double* cx = CX + (int64_t)pick * st.rows * NX;
+                const double* cu = CU + (int64_t)pick * st.rows * NU;
+                if (accepted) {
+                    J = __shfl(Jc, pick, WAVE);
+                    for (int e = lane; e < (T + 1) * NX; e += WAVE) {
+                        PRV_X[e] = X_[e];
+                        const double v = cx[e];
+                        NXT_X[e] = v;
+                        X_[e] = v;
+                    }
+                    for (int e = lane; e < T * NU; e += WAVE) {
+                        PRV_K[e] = KFF[e];
+                        if (e >= opt_start * NU) {
+                            const double v = cu[e];
+                            NXT_U[e] = v;
+                            U_[e] = v;
+                        }
+                    }
+                    for (int e = lane; e < T + 1; e += WAVE) { NIS[e] = dt; IS[e] = dt; }
+                    traj_changed = true;
+                    improved = true;
+                } else {
+                    // the reference leaves the last tried rollout (alpha = 1e-7) in next_*
+                    for (int e = lane; e < (T + 1) * NX; e += WAVE) NXT_X[e] = cx[e];
+                    for (int e = lane + opt_start * NU; e < T * NU; e += WAVE) NXT_U[e] = cu[e];
+                    for (int e = lane; e < T + 1; e += WAVE) NIS[e] = dt;
+                }
+            }
+            __syncthreads();
+
+            if (second_order) {                                // mu schedule, optim.c:989-999
+                mu_step = accepted ? (mu_step - 1 > 0 ? mu_step - 1 : 0) : (mu_step + 1 < 7 ? mu_step + 1 : 7);
+                if (mu_step == 0) {
+                    mu = 0.0;
+                } else {
+                    double m = 1.0;
+                    for (int i = 0; i < mu_step - 1; ++i) m *= 10.0;
+                    mu = m;                                    // pow(10.0, muStep - 1)
+                }
+            }
+            const double rel = fabs(J - J_prev) / J;
+            if (rel < min_rel) {                               // optim.c:1001-1006
+                term = 2;
+                break;
+            }
+        }
+    }
+    if (iterations == max_iter) term = 1;                      // optim.c:1147-1149
+
+    if (lane == 0) {
+        sc[TPL_S_TRAJ_COSTS] = J;
+        sc[TPL_S_ITERATIONS] = (double)iterations;
+        sc[TPL_S_LG_ITERATIONS] = (double)lg_it;
+        sc[TPL_S_ALPHA] = alpha;
+        sc[TPL_S_MU] = mu;
+        sc[TPL_S_MU_STEP] = (double)mu_step;
+        sc[TPL_S_TRAJECTORY_CHANGED] = traj_changed ? 1.0 : 0.0;
+        sc[TPL_S_IMPROVED] = improved ? 1.0 : 0.0;
+        sc[TPL_S_TERMINATION_CONDITION] = (double)term;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+thread_local char g_error[1024] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr, context)                                                              \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess) return fail(TPLHIP_EDEVICE, "%s: %s", hipGetErrorString(e__), context); \
+    } while (0)
+
+struct ParamRef { const char* name; int is_array; size_t offset; };
+#define TPL_PARAM_S(n) {#n, 0, offsetof(Params, n)},
+#define TPL_PARAM_A(n) {#n, 1, offsetof(Params, n)},
+const ParamRef g_params[] = { TPL_PARAM_LIST {nullptr, 0, 0} };
+#undef TPL_PARAM_S
+#undef TPL_PARAM_A
+
+struct ArrayParam {
+    std::vector<double> host;        // [batch or 1] x elems
+    int ndim = 0;
+    int64_t dims[8] = {0};
+    int64_t elems = 0;               // per problem
+    int per_problem = 0;
+    double* dev = nullptr;
+    size_t dev_cap = 0;
+};
+
+// fields the kernel reads from the host's hands, and the ones update() returns eagerly
+const int kInputFields[] = {TPL_F_X, TPL_F_U, TPL_F_LAGRANGE_MULTIPLIER, TPL_F_BARRIER_WEIGHT,
+                            TPL_F_LG_MULT_LIMIT, TPL_F_U_MAX, TPL_F_U_MIN};
+const int kEagerFields[] = {TPL_F_INT_STEP, TPL_F_X, TPL_F_U, TPL_F_NEXT_INT_STEP, TPL_F_NEXT_X, TPL_F_NEXT_U,
+                            TPL_F_PREV_X, TPL_F_PREV_K, TPL_F_K_FF, TPL_F_K_FB, TPL_F_LAGRANGE_MULTIPLIER, TPL_F_G};
+
+} // namespace
+
+struct tplhip_ilqr {
+    int device = 0;
+    int batch = 1;
+    int t_cap = 0;
+    int rows = 0;
+    hipStream_t stream = nullptr;
+    std::vector<double> host[TPL_F_COUNT];
+    bool device_newer[TPL_F_COUNT] = {false};
+    std::vector<double> scalars;                 // [batch][S_COUNT]
+    std::vector<std::vector<double>> pscalar;    // [n_params][batch]
+    std::vector<ArrayParam> parray;              // [n_params]
+    std::vector<Params> hparams;                 // [batch], host-pointer version for dynamics()
+    std::vector<Params> dparams_host;            // [batch], device-pointer version (staging)
+    DevState dev{};
+    Params* d_params = nullptr;
+    double* d_snapshot[3] = {nullptr, nullptr, nullptr};   // x, u, lambda
+    double* d_snapshot_scalars = nullptr;
+    bool have_snapshot = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    bool timing = false;
+    double kernel_ms = 0.0;
+    int64_t launches = 0;
+};
+
+namespace {
+
+size_t field_elems(const tplhip_ilqr* h, int f)
+{
+    const size_t rows = field_is_per_stage(f) ? (size_t)h->rows : 1;
+    return (size_t)h->batch * rows * field_width(f);
+}
+
+int upload_params(tplhip_ilqr* h)
+{
+    for (int i = 0; i < TPL_N_PARAMS; ++i) {
+        if (!g_params[i].is_array) continue;
+        ArrayParam& a = h->parray[i];
+        const size_t bytes = a.host.size() * sizeof(double);
+        if (bytes > a.dev_cap) {
+            hipFree(a.dev);
+            a.dev = nullptr; a.dev_cap = 0;
+            HIP_TRY(hipMalloc(&a.dev, bytes), "parameter array allocation failed");
+            a.dev_cap = bytes;
+        }
+        if (bytes) HIP_TRY(hipMemcpyAsync(a.dev, a.host.data(), bytes, hipMemcpyHostToDevice, h->stream),
+                           "copying a parameter array failed");
+    }
+    for (int b = 0; b < h->batch; ++b) {
+        Params& P = h->dparams_host[b];
+        std::memset(&P, 0, sizeof(Params));
+        for (int i = 0; i < TPL_N_PARAMS; ++i) {
+            char* slot = (char*)&P + g_params[i].offset;
+            if (g_params[i].is_array) {
+                const ArrayParam& a = h->parray[i];
+                DynArr d;
+                d.data = a.dev ? a.dev + (a.per_problem ? (size_t)b * a.elems : 0) : nullptr;
+                d.ndim = a.ndim;
+                d.n0 = a.ndim > 0 ? a.dims[0] : 0;
+                d.n1 = a.ndim > 1 ? a.dims[1] : 0;
+                d.pad = 0;
+                std::memcpy(slot, &d, sizeof d);
+            } else {
+                std::memcpy(slot, &h->pscalar[i][b], sizeof(double));
+            }
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_params, h->dparams_host.data(), sizeof(Params) * (size_t)h->batch,
+                           hipMemcpyHostToDevice, h->stream), "copying parameters failed");
+    return TPLHIP_OK;
+}
+
+void host_params(tplhip_ilqr* h, int b, Params* P)
+{
+    std::memset(P, 0, sizeof(Params));
+    for (int i = 0; i < TPL_N_PARAMS; ++i) {
+        char* slot = (char*)P + g_params[i].offset;
+        if (g_params[i].is_array) {
+            const ArrayParam& a = h->parray[i];
+            DynArr d;
+            d.data = a.host.empty() ? nullptr : a.host.data() + (a.per_problem ? (size_t)b * a.elems : 0);
+            d.ndim = a.ndim;
+            d.n0 = a.ndim > 0 ? a.dims[0] : 0;
+            d.n1 = a.ndim > 1 ? a.dims[1] : 0;
+            d.pad = 0;
+            std::memcpy(slot, &d, sizeof d);
+        } else {
+            std::memcpy(slot, &h->pscalar[i][b], sizeof(double));
+        }
+    }
+}
+
+int upload_inputs(tplhip_ilqr* h)
+{
+    for (int f : kInputFields) {
+        HIP_TRY(hipMemcpyAsync(h->dev.f[f], h->host[f].data(), field_elems(h, f) * sizeof(double),
+                               hipMemcpyHostToDevice, h->stream), "copying solver state failed");
+        h->device_newer[f] = false;
+    }
+    HIP_TRY(hipMemcpyAsync(h->dev.scalars, h->scalars.data(), h->scalars.size() * sizeof(double),
+                           hipMemcpyHostToDevice, h->stream), "copying solver settings failed");
+    return upload_params(h);
+}
+
+int launch(tplhip_ilqr* h)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing) {
+        HIP_TRY(hipEventCreate(&e0), "event creation failed");
+        HIP_TRY(hipEventCreate(&e1), "event creation failed");
+        HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
+    }
+    hipLaunchKernelGGL(k_ilqr_update, dim3(h->batch), dim3(WAVE), 0, h->stream, h->dev);
+    HIP_TRY(hipGetLastError(), "solver launch failed");
+    if (h->timing) {
+        HIP_TRY(hipEventRecord(e1, h->stream), "event record failed");
+        h->events.emplace_back(e0, e1);
+        h->launches += 1;
+    }
+    for (int f = 0; f < TPL_F_COUNT; ++f) {
+        const bool input_only = f == TPL_F_BARRIER_WEIGHT || f == TPL_F_LG_MULT_LIMIT || f == TPL_F_U_MAX
+                                || f == TPL_F_U_MIN || f == TPL_F_PREV_U;
+        if (!input_only) h->device_newer[f] = true;
+    }
+    return TPLHIP_OK;
+}
+
+int fetch_field(tplhip_ilqr* h, int f)
+{
+    if (!h->device_newer[f]) return TPLHIP_OK;
+    HIP_TRY(hipMemcpyAsync(h->host[f].data(), h->dev.f[f], field_elems(h, f) * sizeof(double),
+                           hipMemcpyDeviceToHost, h->stream), "copying solver results failed");
+    h->device_newer[f] = false;
+    return TPLHIP_OK;
+}
+
+int check_settings(tplhip_ilqr* h)
+{
+    for (int b = 0; b < h->batch; ++b) {
+        double* sc = h->scalars.data() + (size_t)b * TPL_S_COUNT;
+        const int T = (int)sc[TPL_S_HORIZON];
+        if (T < 1 || T > h->t_cap)
+            return fail(TPLHIP_EINVAL, "horizon %d outside [1, %d] (t_cap of this solver object)", T, h->t_cap);
+        const int os = (int)sc[TPL_S_OPT_START];
+        if (os < 0 || os > T) return fail(TPLHIP_EINVAL, "opt_start %d outside [0, horizon]", os);
+        const int it = (int)sc[TPL_S_INTEGRATOR_TYPE];
+        if (it < 0 || it > 2) return fail(TPLHIP_EINVAL, "unknown integrator type %d", it);
+    }
+    return TPLHIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* tplhip_ilqr_model_name(void) { return TPL_MODEL_NAME; }
+void tplhip_ilqr_dims(int* X, int* U, int* C, int* n_params)
+{
+    if (X) *X = NX;
+    if (U) *U = NU;
+    if (C) *C = NC;
+    if (n_params) *n_params = TPL_N_PARAMS;
+}
+const char* tplhip_ilqr_param_name(int i) { return (i >= 0 && i < TPL_N_PARAMS) ? g_params[i].name : nullptr; }
+int tplhip_ilqr_param_is_array(int i) { return (i >= 0 && i < TPL_N_PARAMS) ? g_params[i].is_array : -1; }
+const char* tplhip_ilqr_last_error(void) { return g_error; }
+const char* tplhip_ilqr_fingerprint(void) { return TPL_MODEL_FINGERPRINT; }
+
+int tplhip_ilqr_create(int device, int batch, int t_cap, tplhip_ilqr** out)
+{
+    if (!out) return fail(TPLHIP_EINVAL, "null out pointer");
+    if (batch < 1) return fail(TPLHIP_EINVAL, "batch must be >= 1");
+    if (t_cap < 1 || t_cap > TPLHIP_ILQR_H_MAX - 1)
+        return fail(TPLHIP_EINVAL, "t_cap %d outside [1, %d]", t_cap, TPLHIP_ILQR_H_MAX - 1);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(TPLHIP_EDEVICE, "no usable HIP device (requested %d)", device);
+    if (device < 0) device = n - 1;
+    if (device >= n) return fail(TPLHIP_EDEVICE, "no usable HIP device (requested %d)", device);
+    HIP_TRY(hipSetDevice(device), "hipSetDevice failed");
+
+    tplhip_ilqr* h = new (std::nothrow) tplhip_ilqr();
+    if (!h) return fail(TPLHIP_EDEVICE, "out of host memory");
+    h->device = device;
+    h->batch = batch;
+    h->t_cap = t_cap;
+    h->rows = t_cap + 1;
+    h->dev.rows = h->rows;
+    hipError_t err = hipStreamCreate(&h->stream);
+    if (err != hipSuccess) { delete h; return fail(TPLHIP_EDEVICE, "%s: stream creation failed", hipGetErrorString(err)); }
+
+    for (int f = 0; f < TPL_F_COUNT; ++f) {
+        h->host[f].assign(field_elems(h, f), 0.0);
+        err = hipMalloc(&h->dev.f[f], std::max<size_t>(8, field_elems(h, f) * sizeof(double)));
+        if (err == hipSuccess) err = hipMemsetAsync(h->dev.f[f], 0, field_elems(h, f) * sizeof(double), h->stream);
+        if (err != hipSuccess) { tplhip_ilqr_destroy(h); return fail(TPLHIP_EDEVICE, "%s: solver state allocation failed", hipGetErrorString(err)); }
+    }
+    h->scalars.assign((size_t)batch * TPL_S_COUNT, 0.0);
+    h->pscalar.assign(TPL_N_PARAMS, std::vector<double>());
+    h->parray.assign(TPL_N_PARAMS, ArrayParam());
+    for (int i = 0; i < TPL_N_PARAMS; ++i)
+        if (!g_params[i].is_array) h->pscalar[i].assign(batch, 0.0);
+    h->hparams.resize(batch);
+    h->dparams_host.resize(batch);
+    const size_t cand_x = (size_t)batch * N_ALPHA * h->rows * NX, cand_u = (size_t)batch * N_ALPHA * h->rows * NU;
+    err = hipMalloc(&h->dev.scalars, h->scalars.size() * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&h->d_params, sizeof(Params) * (size_t)batch);
+    if (err == hipSuccess) err = hipMalloc(&h->dev.cand_x, cand_x * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&h->dev.cand_u, cand_u * sizeof(double));
+    if (err != hipSuccess) { tplhip_ilqr_destroy(h); return fail(TPLHIP_EDEVICE, "%s: solver workspace allocation failed", hipGetErrorString(err)); }
+    h->dev.params = h->d_params;
+
+    // defaults of pyOptimAlloc, optim.c:1894-1921
+    const int T0 = std::min(20, t_cap);
+    for (int b = 0; b < batch; ++b) {
+        double* sc = h->scalars.data() + (size_t)b * TPL_S_COUNT;
+        sc[TPL_S_DT] = 0.05;
+        sc[TPL_S_HORIZON] = T0;
+        sc[TPL_S_MIN_REL_COST_CHANGE] = 1e-6;
+        sc[TPL_S_MAX_ITERATIONS] = 5;
+        sc[TPL_S_MAX_LG_ITERATIONS] = 1;
+        sc[TPL_S_USE_QUADRATIC_TERMS] = 1.0;
+        for (int c = 0; c < NCM; ++c) {
+            h->host[TPL_F_LG_MULT_LIMIT][(size_t)b * NCM + c] = INFINITY;
+            h->host[TPL_F_BARRIER_WEIGHT][(size_t)b * NCM + c] = 1.0;
+        }
+        for (int t = 0; t < T0; ++t)
+            for (int d = 0; d < NU; ++d) {
+                h->host[TPL_F_U_MAX][((size_t)b * h->rows + t) * NU + d] = INFINITY;
+                h->host[TPL_F_U_MIN][((size_t)b * h->rows + t) * NU + d] = -INFINITY;
+            }
+    }
+    *out = h;
+    return TPLHIP_OK;
+}
+
+int tplhip_ilqr_destroy(tplhip_ilqr* h)
+{
+    if (!h) return TPLHIP_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (auto& ev : h->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    for (int f = 0; f < TPL_F_COUNT; ++f) hipFree(h->dev.f[f]);
+    for (auto& a : h->parray) hipFree(a.dev);
+    hipFree(h->dev.scalars);
+    hipFree(h->d_params);
+    hipFree(h->dev.cand_x);
+    hipFree(h->dev.cand_u);
+    for (double* p : h->d_snapshot) hipFree(p);
+    hipFree(h->d_snapshot_scalars);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return TPLHIP_OK;
+}
+
+int tplhip_ilqr_batch(tplhip_ilqr* h) { return h ? h->batch : 0; }
+int tplhip_ilqr_t_cap(tplhip_ilqr* h) { return h ? h->t_cap : 0; }
+
+double* tplhip_ilqr_ptr(tplhip_ilqr* h, int field, int64_t* problem_stride)
+{
+    if (!h || field < 0 || field >= TPL_F_COUNT) { fail(TPLHIP_EINVAL, "bad field id %d", field); return nullptr; }
+    if (h->device_newer[field]) {
+        hipSetDevice(h->device);
+        if (fetch_field(h, field) != TPLHIP_OK) return nullptr;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { fail(TPLHIP_EDEVICE, "copying solver results failed"); return nullptr; }
+    }
+    if (problem_stride) *problem_stride = (int64_t)((field_is_per_stage(field) ? h->rows : 1) * field_width(field));
+    return h->host[field].data();
+}
+
+double* tplhip_ilqr_scalars(tplhip_ilqr* h) { return h ? h->scalars.data() : nullptr; }
+
+double* tplhip_ilqr_param_scalar_ptr(tplhip_ilqr* h, int i)
+{
+    if (!h || i < 0 || i >= TPL_N_PARAMS || g_params[i].is_array) return nullptr;
+    return h->pscalar[i].data();
+}
+
+int tplhip_ilqr_set_param_array(tplhip_ilqr* h, int i, const double* data, int ndim, const int64_t* dims, int per_problem)
+{
+    if (!h || i < 0 || i >= TPL_N_PARAMS || !g_params[i].is_array) return fail(TPLHIP_EINVAL, "parameter %d is not an array parameter", i);
+    if (ndim < 0 || ndim > 8) return fail(TPLHIP_EINVAL, "bad ndim %d", ndim);
+    ArrayParam& a = h->parray[i];
+    int64_t elems = ndim > 0 ? 1 : 0;
+    for (int d = 0; d < ndim; ++d) { a.dims[d] = dims[d]; elems *= dims[d]; }
+    a.ndim = ndim;
+    a.elems = elems;
+    a.per_problem = per_problem ? 1 : 0;
+    const size_t total = (size_t)elems * (per_problem ? h->batch : 1);
+    if (total && !data) return fail(TPLHIP_EINVAL, "null data");
+    a.host.assign(data, data + total);
+    return TPLHIP_OK;
+}
+
+int tplhip_ilqr_get_param_array(tplhip_ilqr* h, int i, const double** data, int* ndim, int64_t* dims, int* per_problem)
+{
+    if (!h || i < 0 || i >= TPL_N_PARAMS || !g_params[i].is_array) return fail(TPLHIP_EINVAL, "parameter %d is not an array parameter", i);
+    const ArrayParam& a = h->parray[i];
+    if (data) *data = a.host.data();
+    if (ndim) *ndim = a.ndim;
+    if (dims) for (int d = 0; d < a.ndim; ++d) dims[d] = a.dims[d];
+    if (per_problem) *per_problem = a.per_problem;
+    return TPLHIP_OK;
+}
+
+int tplhip_ilqr_update(tplhip_ilqr* h)
+{
+    if (!h) return fail(TPLHIP_EINVAL, "null handle");
+    int rc = check_settings(h);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = upload_inputs(h);
+    if (rc) return rc;
+    rc = launch(h);
+    if (rc) return rc;
+    for (int f : kEagerFields) {
+        rc = fetch_field(h, f);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(h->scalars.data(), h->dev.scalars, h->scalars.size() * sizeof(double),
+                           hipMemcpyDeviceToHost, h->stream), "copying solver results failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "solver update failed");
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int b = 0; b < h->batch; ++b) h->scalars[(size_t)b * TPL_S_COUNT + TPL_S_RUNTIME] = ms;   // optim.c:1153-1159
+    return TPLHIP_OK;
+}
+
+int tplhip_ilqr_shift(tplhip_ilqr* h, int amount)
+{
+    // shift(), optim.c:1162-1177, on the host mirrors
+    if (!h) return fail(TPLHIP_EINVAL, "null handle");
+    if (amount < 0) amount = 0;
+    for (int f : {TPL_F_X, TPL_F_U, TPL_F_LAGRANGE_MULTIPLIER}) {
+        int64_t st = 0;
+        if (!tplhip_ilqr_ptr(h, f, &st)) return TPLHIP_EDEVICE;      // make sure the mirror is current
+    }
+    for (int b = 0; b < h->batch; ++b) {
+        const double* sc = h->scalars.data() + (size_t)b * TPL_S_COUNT;
+        const int T = (int)sc[TPL_S_HORIZON], os = (int)sc[TPL_S_OPT_START];
+        double* x = h->host[TPL_F_X].data() + (size_t)b * h->rows * NX;
+        double* u = h->host[TPL_F_U].data() + (size_t)b * h->rows * NU;
+        double* lm = h->host[TPL_F_LAGRANGE_MULTIPLIER].data() + (size_t)b * h->rows * NCM;
+        for (int t = os; t < T + 1; ++t)
+            std::memmove(x + (size_t)t * NX, x + (size_t)std::min(T, t + amount) * NX, sizeof(double) * NX);
+        for (int t = os; t < T; ++t)
+            std::memmove(u + (size_t)t * NU, u + (size_t)std::min(T - 1, t + amount) * NU, sizeof(double) * NU);
+        for (int t = os; t < T; ++t)
+            std::memmove(lm + (size_t)t * NCM, lm + (size_t)std::min(T - 1, t + amount) * NCM, sizeof(double) * NCM);
+    }
+    return TPLHIP_OK;
+}
+
+static void host_dynamics(const Params& P, const double* x, const double* u, int t, double dt, int int_type, double* res)
+{
+    // optim.c:657-730 on the host, for Optim.dynamics (dead-time compensation in the MPC controllers)
+    double k1[NX], k2[NX], k3[NX], k4[NX], tmp[NX];
+    ctDynamics(P, x, u, (double)t, dt, k1, 1);
+    if (int_type == EULER) {
+        for (int i = 0; i < NX; ++i) res[i] = x[i] + k1[i] * dt;
+    } else if (int_type == HEUN) {
+        for (int i = 0; i < NX; ++i) tmp[i] = x[i] + k1[i] * dt;
+        ctDynamics(P, tmp, u, (double)t, dt, k2, 1);
+        for (int i = 0; i < NX; ++i) res[i] = x[i] + (k1[i] + k2[i]) * (dt / 2.0);
+    } else {
+        for (int i = 0; i < NX; ++i) tmp[i] = x[i] + k1[i] * (dt / 2.0);
+        ctDynamics(P, tmp, u, (double)t, dt, k2, 1);
+        for (int i = 0; i < NX; ++i) tmp[i] = x[i] + k2[i] * (dt / 2.0);
+        ctDynamics(P, tmp, u, (double)t, dt, k3, 1);
+        for (int i = 0; i < NX; ++i) tmp[i] = x[i] + k3[i] * dt;
+        ctDynamics(P, tmp, u, (double)t, dt, k4, 1);
+        for (int i = 0; i < NX; ++i) {
+            double acc = k1[i] + 0.0;
+            acc = k2[i] * 2.0 + acc;
+            acc = k3[i] * 2.0 + acc;
+            acc = k4[i] + acc;
+            res[i] = x[i] + acc * (dt / 6.0);
+        }
+    }
+}
+
+int tplhip_ilqr_dynamics(tplhip_ilqr* h, int b, const double* x, const double* u, int t, double dt, double* out)
+{
+    if (!h || !x || !u || !out || b < 0 || b >= h->batch) return fail(TPLHIP_EINVAL, "bad argument");
+    Params P;
+    host_params(h, b, &P);
+    const int int_type = (int)h->scalars[(size_t)b * TPL_S_COUNT + TPL_S_INTEGRATOR_TYPE];
+    host_dynamics(P, x, u, t, dt, int_type, out);
+    return TPLHIP_OK;
+}
+
+int tplhip_ilqr_ct_dynamics(tplhip_ilqr* h, int b, const double* x, const double* u, int t, double dt, double* out)
+{
+    if (!h || !x || !u || !out || b < 0 || b >= h->batch) return fail(TPLHIP_EINVAL, "bad argument");
+    Params P;
+    host_params(h, b, &P);
+    ctDynamics(P, x, u, (double)t, dt, out, 1);
+    return TPLHIP_OK;
+}
+
+int tplhip_ilqr_upload(tplhip_ilqr* h)
+{
+    if (!h) return fail(TPLHIP_EINVAL, "null handle");
+    int rc = check_settings(h);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    rc = upload_inputs(h);
+    if (rc) return rc;
+    const int snap_fields[3] = {TPL_F_X, TPL_F_U, TPL_F_LAGRANGE_MULTIPLIER};
+    for (int i = 0; i < 3; ++i) {
+        const size_t bytes = field_elems(h, snap_fields[i]) * sizeof(double);
+        if (!h->d_snapshot[i]) HIP_TRY(hipMalloc(&h->d_snapshot[i], bytes), "snapshot allocation failed");
+        HIP_TRY(hipMemcpyAsync(h->d_snapshot[i], h->dev.f[snap_fields[i]], bytes, hipMemcpyDeviceToDevice, h->stream), "snapshot copy failed");
+    }
+    if (!h->d_snapshot_scalars) HIP_TRY(hipMalloc(&h->d_snapshot_scalars, h->scalars.size() * sizeof(double)), "snapshot allocation failed");
+    HIP_TRY(hipMemcpyAsync(h->d_snapshot_scalars, h->dev.scalars, h->scalars.size() * sizeof(double), hipMemcpyDeviceToDevice, h->stream), "snapshot copy failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "upload failed");
+    h->have_snapshot = true;
+    return TPLHIP_OK;
+}
+
+int tplhip_ilqr_restore(tplhip_ilqr* h)
+{
+    if (!h) return fail(TPLHIP_EINVAL, "null handle");
+    if (!h->have_snapshot) return fail(TPLHIP_ESTATE, "nothing uploaded");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    const int snap_fields[3] = {TPL_F_X, TPL_F_U, TPL_F_LAGRANGE_MULTIPLIER};
+    for (int i = 0; i < 3; ++i)
+        HIP_TRY(hipMemcpyAsync(h->dev.f[snap_fields[i]], h->d_snapshot[i], field_elems(h, snap_fields[i]) * sizeof(double),
+                               hipMemcpyDeviceToDevice, h->stream), "snapshot restore failed");
+    HIP_TRY(hipMemcpyAsync(h->dev.scalars, h->d_snapshot_scalars, h->scalars.size() * sizeof(double),
+                           hipMemcpyDeviceToDevice, h->stream), "snapshot restore failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_ilqr_run_resident(tplhip_ilqr* h)
+{
+    if (!h) return fail(TPLHIP_EINVAL, "null handle");
+    if (!h->have_snapshot) return fail(TPLHIP_ESTATE, "nothing uploaded");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    return launch(h);
+}
+
+int tplhip_ilqr_sync(tplhip_ilqr* h)
+{
+    if (!h) return fail(TPLHIP_EINVAL, "null handle");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "solver update failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_ilqr_download(tplhip_ilqr* h)
+{
+    if (!h) return fail(TPLHIP_EINVAL, "null handle");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    for (int f : kEagerFields) {
+        int rc = fetch_field(h, f);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(h->scalars.data(), h->dev.scalars, h->scalars.size() * sizeof(double),
+                           hipMemcpyDeviceToHost, h->stream), "copying solver results failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "solver update failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_ilqr_timing(tplhip_ilqr* h, int reset, double* kernel_ms, int64_t* launches)
+{
+    if (!h) return fail(TPLHIP_EINVAL, "null handle");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
+    for (auto& ev : h->events) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second), "event query failed");
+        h->kernel_ms += (double)ms;
+        hipEventDestroy(ev.first);
+        hipEventDestroy(ev.second);
+    }
+    h->events.clear();
+    if (kernel_ms) *kernel_ms = h->kernel_ms;
+    if (launches) *launches = h->launches;
+    if (reset) { h->kernel_ms = 0.0; h->launches = 0; }
+    h->timing = true;
+    return TPLHIP_OK;
+}
+
+} // extern "C"

@@ -256,6 +256,7 @@ def emit_model(cfg, name):
     out.append("// generated by tpl_amd.optim.genopt -- do not edit")
     out.append(f"// problem {name}  fingerprint {cfg.fingerprint()}")
     out.append(f"#define TPL_MODEL_NAME \"{name}\"")
+    out.append(f"#define TPL_MODEL_FINGERPRINT \"{cfg.fingerprint()}\"")
     out.append(f"#define TPL_X {len(cfg.states)}")
     out.append(f"#define TPL_U {len(cfg.actions)}")
     out.append(f"#define TPL_C {len(cfg.constraints)}")
@@ -348,12 +349,37 @@ def build_module(cfg, name=None, out_dir=None):
     return compile_model(name, out_dir), name
 
 
+def prebuilt(cfg, name=None, out_dir=None):
+    """Path of an already compiled library for exactly this problem, or None.
+    The check is the fingerprint the library exports, not file times (a snapshot
+    copied to another machine keeps its libraries but not their mtimes)."""
+    import ctypes
+    name = name or model_name(cfg)
+    so = model_paths(name, out_dir)["so"]
+    if not os.path.exists(so) or os.environ.get("TPL_AMD_REBUILD"):
+        return None
+    try:
+        lib = ctypes.CDLL(so)
+        lib.tplhip_ilqr_fingerprint.restype = ctypes.c_char_p
+        if lib.tplhip_ilqr_fingerprint().decode() == cfg.fingerprint():
+            return so
+    except (OSError, AttributeError):
+        pass
+    return None
+
+
 def build(cfg, name=None, out_dir=None):
     """Generate + compile + load; returns a factory ``f(batch=1, horizon=None,
     device=-1) -> Optim`` that also applies the Config's default parameter
-    values (the reference's ``get_opt_builder``, genopt.py:622-647)."""
+    values (the reference's ``get_opt_builder``, genopt.py:622-647).  A library
+    already built for the same problem text is reused (the reference caches by
+    sha1 the same way, genopt.py:486-523)."""
     from . import solver
-    so, name = build_module(cfg, name, out_dir or cfg.output_dir)
+    name = name or model_name(cfg)
+    out_dir = out_dir or cfg.output_dir
+    so = prebuilt(cfg, name, out_dir) if cfg.use_cache else None
+    if so is None:
+        so, name = build_module(cfg, name, out_dir)
     return solver.factory(so, cfg.param_defaults)
 
 
@@ -361,10 +387,15 @@ def build_parallel(cfgs, names=None):
     """The reference forks a pool for its gcc builds (genopt.py:658-665); hipcc
     builds are run as concurrent subprocesses here."""
     import concurrent.futures as cf
-    names = names or [model_name(c) for c in cfgs]
-    for c, n in zip(cfgs, names):
-        generate(c, n)
-    with cf.ThreadPoolExecutor(max_workers=min(8, len(cfgs) or 1)) as ex:
-        sos = list(ex.map(compile_model, names))
     from . import solver
+    names = names or [model_name(c) for c in cfgs]
+    sos = [prebuilt(c, n) if c.use_cache else None for c, n in zip(cfgs, names)]
+    todo = [n for n, so in zip(names, sos) if so is None]
+    for c, n, so in zip(cfgs, names, sos):
+        if so is None:
+            generate(c, n)
+    if todo:
+        with cf.ThreadPoolExecutor(max_workers=min(4, len(todo))) as ex:
+            built = dict(zip(todo, ex.map(compile_model, todo)))
+        sos = [so or built[n] for n, so in zip(names, sos)]
     return [solver.factory(so, c.param_defaults) for so, c in zip(sos, cfgs)]
