@@ -106,14 +106,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    from tpl_amd import sharding
+    import numpy as np
+
+    def step():
         dp.plan_resident(env)
+        if dist is not None:
+            # the path's only exchange: best-plan record of this rank -> all ranks (RCCL all-gather)
+            tr = np.array([[s.t, s.s, s.v, s.a, s.j, s.cost, s.constr] for s in dp.download()[0].states],
+                          dtype=np.float32)
+            sharding.allgather_best(sharding.plan_record(tr, rank), dist, torch.device("cuda", local_rank))
+
+    for _ in range(args.warmup):
+        step()
     dp.sync()
     dp.timing_enable(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dp.plan_resident(env)
+        step()
     dp.sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -150,7 +161,8 @@ def main():
                             f"{p.t_steps} stages, straight 200 m path, 5 moving obstacles; "
                             f"one step = dist map + {sweeps_per_step} backward sweeps + forward rollout",
                 "grid": [p.s_steps, p.v_steps, p.a_steps], "t_steps": p.t_steps,
-                "plans_per_step_per_gpu": 1, "parallelism": f"replicas x{world}",
+                "plans_per_step_per_gpu": 1,
+                "parallelism": f"independent plans x{world}" + (", all-gather of the best plan per step" if world > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -33,6 +33,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stddef.h>
+#include <algorithm>
 #include <vector>
 
 #ifdef _OPENMP
@@ -726,6 +727,27 @@ ILQO_API void ilqo_update_many(void** hs, int n, int nthreads)
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
 #endif
     for (int i = 0; i < n; ++i) update((OOpt*)hs[i]);
+    (void)nthreads;
+}
+
+/* cpu_baseline, timed part entirely in C: reset every problem to its initial
+ * state (x[0] = x0[i], u = 0, mu = 0, muStep = 0) and solve it, `reps` times */
+ILQO_API void ilqo_reset_and_update_many(void** hs, int n, const double* x0, int reps, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+    for (int i = 0; i < n; ++i) {
+        OOpt* o = (OOpt*)hs[i];
+        for (int r = 0; r < reps; ++r) {
+            memcpy(o->x.data(), x0 + (size_t)i * X, sizeof(double) * X);
+            std::fill(o->u.begin(), o->u.end(), 0.0);
+            o->mu = 0.0;
+            o->muStep = 0;
+            update(o);
+        }
+    }
     (void)nthreads;
 }
 

@@ -52,6 +52,7 @@ def load(model):
     lib.ilqo_dynamics.argtypes = [C.c_void_p, dptr, dptr, C.c_int, C.c_double, dptr]
     lib.ilqo_ct_dynamics.argtypes = [C.c_void_p, dptr, dptr, C.c_int, C.c_double, dptr]
     lib.ilqo_update_many.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
+    lib.ilqo_reset_and_update_many.argtypes = [C.POINTER(C.c_void_p), C.c_int, dptr, C.c_int, C.c_int]
     _libs[model] = lib
     return lib
 
