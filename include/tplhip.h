@@ -154,6 +154,8 @@ TPLHIP_API int tplhip_dp_lon_upload(tplhip_dp_lon* h, int n, const TplLonState* 
 TPLHIP_API int tplhip_dp_lon_plan_resident(tplhip_dp_lon* h, tplhip_dp_env* env);
 TPLHIP_API int tplhip_dp_lon_sync(tplhip_dp_lon* h);
 TPLHIP_API int tplhip_dp_lon_download(tplhip_dp_lon* h, TplLonState* out_trajs);
+/* Launch geometry and code path of the sweep kernel as a small JSON object (diagnostics). */
+TPLHIP_API int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n);
 /* HIP-event timing of the backward sweeps (events recorded on the planner's
  * stream around the loop of launches).  enable=1 starts accumulating; get
  * returns the summed ms and the number of sweep launches since enable. */

@@ -193,3 +193,45 @@ def test_full_size_spot_checks(grid):
     assert np.allclose(np.diff(tr[:, 0]), cp.dt)
     again = _traj_np(dp.reeval_traj(traj, path, env))
     assert np.array_equal(again[:, 5:].view(np.uint32), tr[:, 5:].view(np.uint32))
+
+
+def test_division_modes_agree(monkeypatch):
+    """The sweep forms its two divisions by run-time constants either with IEEE
+    division or with reciprocal forms that reinit proved exact by brute force
+    (k_verify_div); both code paths must give the same bits."""
+    S, V, A, T = 201, 20, 12, 6
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
+    tabs = {}
+    for mode in ("fast", "ieee"):
+        if mode == "ieee":
+            monkeypatch.setenv("TPLHIP_NO_FASTDIV", "1")
+        env = tpl_amd.DynProgEnvironment()
+        env.reinit_buffers(ep)
+        env.set_occ_map(occ)
+        dp = tpl_amd.DynProgLonPlanner()
+        dp.reinit_buffers(p)
+        info = dp.info()
+        assert (info["div_mode"] == 0) == (mode == "ieee"), info
+        dp.update(sc.initial_state(0.0, 8.0, 0.0), path, env)
+        tabs[mode] = [dp.copy_table(t) for t in range(1, T)]
+    for a, b in zip(tabs["fast"], tabs["ieee"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # a divisor the float reciprocal form is not exact for (0.3) must fall back, not guess
+    p2 = sc.lon_params(S, V, A, T)
+    p2.path_step_size = 0.3
+    p2.path_steps = 667
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p2)
+    assert dp.info()["div_mode"] in (0, 1, 2)
+    path2 = sc.straight_path(p2.path_steps, p2.path_step_size)
+    env = tpl_amd.DynProgEnvironment()
+    env.reinit_buffers(ep)
+    env.set_occ_map(occ)
+    trajs = dp.update_batch([sc.initial_state(0.0, 8.0, 0.0)], path2, env)
+    cp, cep = O.cparams(p2), O.cparams(ep)
+    tables, otrajs, _ = O.update(cp, cep, path2, occ, [sc.initial_state(0.0, 8.0, 0.0)])
+    _assert_tables_equal(dp, tables, T)
+    assert np.array_equal(_traj_np(trajs[0]).view(np.uint32), otrajs[0].view(np.uint32))

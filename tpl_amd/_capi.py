@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtplhip.so")
+# TPLHIP_LIB: alternative build of the same library (kernel ablations while tuning)
+LIB_PATH = os.environ.get("TPLHIP_LIB") or os.path.join(_HERE, "libtplhip.so")
 
 TPLHIP_OK = 0
 TPLHIP_EINVAL = -1
@@ -93,6 +94,7 @@ SIGNATURES = {
     "tplhip_dp_lon_plan_resident": (C.c_int, [_vp, _vp]),
     "tplhip_dp_lon_sync": (C.c_int, [_vp]),
     "tplhip_dp_lon_download": (C.c_int, [_vp, _P(TplLonState)]),
+    "tplhip_dp_lon_info": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "tplhip_dp_lon_timing_enable": (C.c_int, [_vp, C.c_int]),
     "tplhip_dp_lon_timing_get": (C.c_int, [_vp, _P(C.c_double), _P(C.c_int64)]),
 }

@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -45,17 +46,17 @@ constexpr int N_FWD = 21;   // evalNode<21>, lon_planner.cu:220
 struct alignas(16) ActDesc {
     double a_term;      // ((0.5*a)*dt)*dt             lon_planner.cu:244
     double j_term;      // ((((1/6)*j)*dt)*dt)*dt      lon_planner.cu:244
-    double tn_v_d;      // (double) successor velocity lon_planner.cu:245
     float vdt;          // v*dt
     float j;            // jerk of this action
     float wj_cost;      // stateActionCost             lon_planner.cu:57-64
-    float amin_viol;    // a_min - a'  if a' < a_min else 0
-    float amax_viol;    // a' - a_max  if a' > a_max else 0
+    float a_viol;       // (a_min - a') or (a' - a_max) if violated, else 0 (at most one is non-zero)
     float wa, wv;       // quantised blend weights along a and v (rule R2)
-    short a0, a1, v0, v1;   // clamped texel rows
-    int pad;
+    float iwa, iwv;     // 1 - wa, 1 - wv (exact: the weights are multiples of 1/256)
+    float tn_v;         // successor velocity          lon_planner.cu:245
+    int r00, r10, r01, r11;   // next-stage rows (a*V + v) of the corners (a0,v0) (a1,v0) (a0,v1) (a1,v1)
+    int pad[3];
 };
-static_assert(sizeof(ActDesc) == 64, "ActDesc must be 64 bytes");
+static_assert(sizeof(ActDesc) == 80, "ActDesc must be 80 bytes");
 
 // ------------------------------------------------------------------------
 // descriptor table: one thread per (row, action)
@@ -81,18 +82,22 @@ __global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p)
     ActDesc d;
     d.a_term = ((0.5 * (double)tp.a) * (double)dt) * (double)dt;
     d.j_term = ((((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt) * (double)dt;
-    d.tn_v_d = (double)tn.v;
     d.vdt = tp.v * dt;
     d.j = j;
     d.wj_cost = state_action_cost(p, j, dt);
-    d.amin_viol = (tn.a < p.a_min) ? (p.a_min - tn.a) : 0.0f;
-    d.amax_viol = (tn.a > p.a_max) ? (tn.a - p.a_max) : 0.0f;
+    // lon_planner.cu:125-130: a' < a_min and a' > a_max exclude each other, and adding the
+    // +0 of the branch not taken leaves a float unchanged, so one addend carries both tests
+    d.a_viol = (tn.a < p.a_min) ? (p.a_min - tn.a) : ((tn.a > p.a_max) ? (tn.a - p.a_max) : 0.0f);
     const Tap tv = make_tap(node_coord(tn.v, p.v_min, p.v_max, p.v_steps), p.v_steps);
     const Tap ta = make_tap(node_coord(tn.a, p.a_min, p.a_max, p.a_steps), p.a_steps);
     d.wa = ta.w; d.wv = tv.w;
-    d.a0 = (short)ta.i0; d.a1 = (short)ta.i1;
-    d.v0 = (short)tv.i0; d.v1 = (short)tv.i1;
-    d.pad = 0;
+    d.iwa = 1.0f - ta.w; d.iwv = 1.0f - tv.w;
+    d.tn_v = tn.v;
+    d.r00 = ta.i0 * p.v_steps + tv.i0;
+    d.r10 = ta.i1 * p.v_steps + tv.i0;
+    d.r01 = ta.i0 * p.v_steps + tv.i1;
+    d.r11 = ta.i1 * p.v_steps + tv.i1;
+    d.pad[0] = d.pad[1] = d.pad[2] = 0;
     acts[idx] = d;
 }
 
@@ -131,14 +136,20 @@ __global__ void k_stage_prelude(float* __restrict__ pre_vmax, float* __restrict_
 // KCHUNK actions are blended into LDS per barrier.
 // LDS: float4 R[KCHUNK][blockDim] | float path_vmax[path_steps]
 // ------------------------------------------------------------------------
-template <bool TERMINAL, int KCHUNK>
+// DIVMODE selects how the two divisions by run-time constants are formed; every mode is
+// bit-identical to IEEE division (modes 1/2 only after k_verify_div proved it, see reinit):
+//   0  IEEE division for both
+//   1  station range: (float)((double)x * rcp_d);  path step: x*r with one residual correction
+//   2  both through the double product
+template <bool TERMINAL, int KCHUNK, int DIVMODE>
 __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__ out,
                            const ActDesc* __restrict__ acts,
                            const float* __restrict__ path,
                            const float* __restrict__ pre_vmax,    // this stage, [s_steps]
                            const float* __restrict__ pre_sdist,   // this stage, [s_steps]
                            const double* __restrict__ pre_prog,   // [s_steps]
-                           TplDpLonParams p, int s_pad, int rows_per_block, int nblocks)
+                           TplDpLonParams p, int s_pad, int rows_per_block, int nblocks,
+                           float rcp_path_step, double rcp_path_step_d, double rcp_s_range_d)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -195,6 +206,8 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
     float* pv = reinterpret_cast<float*>(smem + (size_t)KCHUNK * blockDim.x * sizeof(float4));
     for (int i = tid; i < p.path_steps; i += blockDim.x) pv[i] = path[i * 7 + 5];
 
+    const float s_range = p.s_max - p.s_min;
+    const float s_scale = (float)(S - 1);
     float res_c[N_BWD], res_g[N_BWD];
 
 #pragma unroll
@@ -206,15 +219,16 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
             const int k = k0 + kk;
             if (active) {
                 const ActDesc* d = acts + (size_t)row * N_BWD + k;
-                const int a0 = d->a0, a1 = d->a1, v0 = d->v0, v1 = d->v1;
-                const float wa = d->wa, wv = d->wv;
-                const float4* r00 = next + ((size_t)a0 * V + v0) * S;
-                const float4* r10 = next + ((size_t)a1 * V + v0) * S;
-                const float4* r01 = next + ((size_t)a0 * V + v1) * S;
-                const float4* r11 = next + ((size_t)a1 * V + v1) * S;
-                const float4 b0 = lerp4(r00[is], r10[is], wa);
-                const float4 b1 = lerp4(r01[is], r11[is], wa);
-                R[kk * blockDim.x + tid] = lerp4(b0, b1, wv);
+                // (clamped successors name the same row twice; those repeats hit L1 -- branching
+                // around them serialises the loads and more than doubles the sweep time)
+                const float4 p00 = (next + (size_t)d->r00 * S)[is];
+                const float4 p10 = (next + (size_t)d->r10 * S)[is];
+                const float4 p01 = (next + (size_t)d->r01 * S)[is];
+                const float4 p11 = (next + (size_t)d->r11 * S)[is];
+                const float wa = d->wa, iwa = d->iwa, wv = d->wv, iwv = d->iwv;
+                const float4 b0 = lerp4w(p00, p10, wa, iwa);
+                const float4 b1 = lerp4w(p01, p11, wa, iwa);
+                R[kk * blockDim.x + tid] = lerp4w(b0, b1, wv, iwv);
             }
         }
         __syncthreads();
@@ -230,12 +244,23 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
                 double sd = (double)sf + d->a_term;
                 sd = sd + d->j_term;
                 const float tn_s = fmaxf(s, (float)sd);
-                // value table lookup along s
-                const Tap ts = make_tap(node_coord(tn_s, p.s_min, p.s_max, S), S);
+                // readNode coordinate along s (lon_planner.cu:35).  tn_s >= s >= s_min, so the
+                // coordinate is never negative and only the upper clamp can bite.
+                const float xs = tn_s - p.s_min;
+                const float qs = (DIVMODE == 0) ? xs / s_range : (float)((double)xs * rcp_s_range_d);
+                const float cs = qs * s_scale + 0.5f;         // == (float)((double)c + 0.5), see node_coord
+                const float xb = cs - 0.5f;
+                const float fl = floorf(xb);
+                const float ws = rintf((xb - fl) * 256.0f) * (1.0f / 256.0f);
+                const int i_lo = (int)fminf(fl, s_scale);
+                const int i_hi = min(i_lo + 1, S - 1);
                 const float4* Rk = R + kk * blockDim.x + rib * s_pad;
-                const float4 node = lerp4(Rk[ts.i0], Rk[ts.i1], ts.w);
+                const float4 node = lerp4(Rk[i_lo], Rk[i_hi], ws);
                 // interpPath(tn.s).v_max, lon_planner.cu:114
-                const PathTap pt = path_tap(tn_s, p.path_step_size, p.path_steps);
+                const float alpha = (DIVMODE == 0) ? tn_s / p.path_step_size
+                                  : (DIVMODE == 1) ? fast_div(tn_s, p.path_step_size, rcp_path_step)
+                                                   : (float)((double)tn_s * rcp_path_step_d);
+                const PathTap pt = path_tap_q(alpha, p.path_steps);
                 const float vmn = path_lerp(pt, pv[pt.i0], pv[pt.i1]);
 
                 c = sc;
@@ -244,16 +269,14 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
                 g += node.y;
                 c += p.w_snap * ((node.z - d->j) * (node.z - d->j));
                 c += d->wj_cost;
-                const double vmn_d = (double)vmn;
-                if (d->tn_v_d > vmn_d) {
-                    g = (float)((double)g + (d->tn_v_d - vmn_d));
-                }
+                // lon_planner.cu:114-118 compares and subtracts in double; float -> double is
+                // exact and order preserving, so the test itself can stay in float
+                if (d->tn_v > vmn) g = (float)((double)g + ((double)d->tn_v - (double)vmn));
                 const float s_change = tn_s - s;
                 if (s_change > s_dist) {
                     g += s_change - s_dist;
                 }
-                g += d->amin_viol;      // adding +0 when not violated leaves g unchanged
-                g += d->amax_viol;
+                g += d->a_viol;
             }
             res_c[k] = c;
             res_g[k] = g;
@@ -280,6 +303,32 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
     }
     const float j_best = action_jerk(p, idx_min, N_BWD);
     out[(size_t)row * S + is] = make_float4(cost_min, constr_min, j_best, 0.0f);
+}
+
+// ------------------------------------------------------------------------
+// Exhaustive check of the two cheap division forms against the IEEE quotient for EVERY
+// float in [0, x_max] (all three are odd-symmetric, so the sign is covered): ~1e9
+// candidates, about a millisecond, run once per divisor.
+//  * (float)((double)x * RN_d(1/c)) is provably the IEEE float quotient for normal results:
+//    the double product is within 2^-52 of x/c, a quotient of two 24-bit floats is never
+//    closer than 2^-49 (relative) to a rounding boundary of binary32 unless it is exactly
+//    representable, and it is never exactly a midpoint;
+//  * x*r + one fma residual correction in float is exact for many divisors (all powers of
+//    two) but not all (it fails for 200).
+// The proof is re-established by brute force anyway; a mode is only used if its flag stays 0.
+// ------------------------------------------------------------------------
+__global__ void k_verify_div(unsigned int* __restrict__ flags, float c, float r, double rd, unsigned int max_bits)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    bool bad_f = false, bad_d = false;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= max_bits; b += stride) {
+        const float x = __uint_as_float((unsigned int)b);
+        const unsigned int q = __float_as_uint(x / c);
+        bad_f |= (q != __float_as_uint(fast_div(x, c, r)));
+        bad_d |= (q != __float_as_uint((float)((double)x * rd)));
+    }
+    if (bad_f) atomicOr(&flags[0], 1u);      // float reciprocal + residual correction is not exact here
+    if (bad_d) atomicOr(&flags[1], 1u);      // double-product form is not exact here
 }
 
 // ------------------------------------------------------------------------
@@ -482,6 +531,15 @@ struct tplhip_dp_lon {
     int s_pad = 0, rows_per_block = 0, nblocks = 0, grid = 0, kchunk = 0;
     size_t lds_bytes = 0;
 
+    // cheap division forms, only used when k_verify_div proved them exact (see k_backward)
+    int div_mode = 0;
+    float rcp_path_step = 0.0f;
+    double rcp_path_step_d = 0.0, rcp_s_range_d = 0.0;
+    float verified_c[2] = {0.0f, 0.0f};      // divisors and range the proof covers
+    float verified_xmax = 0.0f;
+    int verified_mode = 0;
+    unsigned int* d_flag = nullptr;           // [4]: path {float, double}, range {float, double}
+
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double sweep_ms = 0.0;
@@ -545,18 +603,33 @@ int check_env(tplhip_dp_lon* h, tplhip_dp_env* env)
     return TPLHIP_OK;
 }
 
-template <bool TERMINAL, int KCHUNK>
+template <bool TERMINAL, int KCHUNK, int DIVMODE>
 void launch_backward(tplhip_dp_lon* h, int idx_t, int nx)
 {
     const size_t S = (size_t)h->params.s_steps;
     const size_t lds = TERMINAL ? 0 : h->lds_bytes;
-    hipLaunchKernelGGL((k_backward<TERMINAL, KCHUNK>), dim3(h->grid), dim3(h->s_pad * h->rows_per_block),
+    hipLaunchKernelGGL((k_backward<TERMINAL, KCHUNK, DIVMODE>), dim3(h->grid), dim3(h->s_pad * h->rows_per_block),
                        lds, h->stream,
                        h->d_tables + (size_t)nx * h->table_cells,
                        h->d_tables + (size_t)idx_t * h->table_cells,
                        h->d_acts, h->d_path,
                        h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
-                       h->d_pre_prog, h->params, h->s_pad, h->rows_per_block, h->nblocks);
+                       h->d_pre_prog, h->params, h->s_pad, h->rows_per_block, h->nblocks,
+                       h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d);
+}
+
+template <int DIVMODE>
+void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
+{
+    if (terminal) {
+        launch_backward<true, 9, 0>(h, i, nx);                       // rule R4 (no division in it)
+    } else if (h->kchunk == 9) {
+        launch_backward<false, 9, DIVMODE>(h, i, nx);
+    } else if (h->kchunk == 3) {
+        launch_backward<false, 3, DIVMODE>(h, i, nx);
+    } else {
+        launch_backward<false, 1, DIVMODE>(h, i, nx);
+    }
 }
 
 // device part of DynProgLonPlanner::update (lon_planner.cu:341-388), all async on h->stream
@@ -581,15 +654,9 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env)
     // backward pass, lon_planner.cu:347-361 -- no host sync between stages
     for (int i = T - 1; i > 0; --i) {
         const int nx = std::min(T - 1, i + 1);
-        if (i == T - 1) {
-            launch_backward<true, 9>(h, i, nx);                  // rule R4
-        } else if (h->kchunk == 9) {
-            launch_backward<false, 9>(h, i, nx);
-        } else if (h->kchunk == 3) {
-            launch_backward<false, 3>(h, i, nx);
-        } else {
-            launch_backward<false, 1>(h, i, nx);
-        }
+        if (h->div_mode == 1) launch_stage<1>(h, i, nx, i == T - 1);
+        else if (h->div_mode == 2) launch_stage<2>(h, i, nx, i == T - 1);
+        else launch_stage<0>(h, i, nx, i == T - 1);
     }
     if (h->timing) {
         HIP_TRY(hipEventRecord(e1, h->stream), "event record failed");
@@ -787,6 +854,7 @@ int tplhip_dp_lon_destroy(tplhip_dp_lon* h)
     free_planner_buffers(h);
     hipFree(h->d_inits);
     hipFree(h->d_trajs);
+    hipFree(h->d_flag);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return TPLHIP_OK;
@@ -845,12 +913,59 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     h->kchunk = 9;
     if (threads * 16 * 9 + path_lds > lds_max) h->kchunk = 3;
     if (threads * 16 * 3 + path_lds > lds_max) h->kchunk = 1;
+    if (const char* ov = std::getenv("TPLHIP_KCHUNK")) {       // tuning override: 9, 3 or 1
+        const int k = std::atoi(ov);
+        if ((k == 9 || k == 3 || k == 1) && threads * 16 * (size_t)k + path_lds <= 160 * 1024) h->kchunk = k;
+    }
     h->lds_bytes = threads * 16 * (size_t)h->kchunk + path_lds;
     if (h->lds_bytes > 160 * 1024)
         return tplhip_fail(TPLHIP_EINVAL, "path_steps = %d does not fit in LDS next to the row buffers", p.path_steps);
 
     hipLaunchKernelGGL(k_build_actions, dim3((nrows * N_BWD + 255) / 256), dim3(256), 0, h->stream, h->d_acts, p);
     HIP_TRY(hipGetLastError(), "action table launch failed");
+
+    // Division by the two run-time constants of the sweep (path step, station range): use the
+    // 3-instruction reciprocal form only if it is proven bit-identical to IEEE division for
+    // every float the sweep can feed it.  Largest dividend: s_max + the longest constant-jerk
+    // step, and |s_min|; the proof covers twice that.
+    {
+        const float s_range = p.s_max - p.s_min;
+        const double dt = (double)p.dt;
+        const double reach = std::fabs((double)p.v_max) * dt
+                             + 0.5 * std::max(std::fabs((double)p.a_min), std::fabs((double)p.a_max)) * dt * dt
+                             + std::max(std::fabs((double)p.j_min), std::fabs((double)p.j_max)) * dt * dt * dt / 6.0;
+        const float xmax = (float)(2.0 * (std::max(std::fabs((double)p.s_min), std::fabs((double)p.s_max)) + (double)s_range + reach));
+        h->rcp_path_step = 1.0f / p.path_step_size;
+        h->rcp_path_step_d = 1.0 / (double)p.path_step_size;
+        h->rcp_s_range_d = 1.0 / (double)s_range;
+        const bool cached = h->verified_c[0] == p.path_step_size && h->verified_c[1] == s_range && h->verified_xmax >= xmax;
+        if (!cached) {
+            h->verified_mode = 0;
+            if (std::isfinite(xmax) && xmax > 0.0f && s_range > 0.0f && p.path_step_size > 0.0f
+                && !std::getenv("TPLHIP_NO_FASTDIV")) {
+                if (!h->d_flag) HIP_TRY(hipMalloc(&h->d_flag, 4 * sizeof(unsigned int)), "flag allocation failed");
+                HIP_TRY(hipMemsetAsync(h->d_flag, 0, 4 * sizeof(unsigned int), h->stream), "flag clear failed");
+                unsigned int max_bits;
+                std::memcpy(&max_bits, &xmax, sizeof max_bits);
+                hipLaunchKernelGGL(k_verify_div, dim3(4096), dim3(256), 0, h->stream, h->d_flag,
+                                   p.path_step_size, h->rcp_path_step, h->rcp_path_step_d, max_bits);
+                hipLaunchKernelGGL(k_verify_div, dim3(4096), dim3(256), 0, h->stream, h->d_flag + 2,
+                                   s_range, 1.0f / s_range, h->rcp_s_range_d, max_bits);
+                HIP_TRY(hipGetLastError(), "division check launch failed");
+                unsigned int flags[4] = {1, 1, 1, 1};
+                HIP_TRY(hipMemcpyAsync(flags, h->d_flag, sizeof flags, hipMemcpyDeviceToHost, h->stream), "flag copy failed");
+                HIP_TRY(hipStreamSynchronize(h->stream), "division check failed");
+                if (flags[3] == 0) {                     // station range through the double product
+                    if (flags[0] == 0) h->verified_mode = 1;          // path step through float reciprocal
+                    else if (flags[1] == 0) h->verified_mode = 2;     // path step through the double product
+                }
+            }
+            h->verified_c[0] = p.path_step_size;
+            h->verified_c[1] = s_range;
+            h->verified_xmax = xmax;
+        }
+        h->div_mode = h->verified_mode;
+    }
     HIP_TRY(hipStreamSynchronize(h->stream), "building the action table failed");
     return TPLHIP_OK;
 }
@@ -957,6 +1072,17 @@ int tplhip_dp_lon_copy_table(tplhip_dp_lon* h, int t, float* out)
     HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
     HIP_TRY(hipMemcpy(out, h->d_tables + (size_t)t * h->table_cells, sizeof(float4) * h->table_cells,
                       hipMemcpyDeviceToHost), "copying value table failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
+{
+    if (!h || !buf || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
+    std::snprintf(buf, (size_t)n,
+                  "{\"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
+                  "\"div_mode\": %d, \"div_verified_up_to\": %g}",
+                  h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
+                  h->div_mode, (double)h->verified_xmax);
     return TPLHIP_OK;
 }
 

@@ -51,6 +51,17 @@ __device__ __forceinline__ float4 lerp4(float4 p, float4 q, float w)
     return r;
 }
 
+// lerp4 with the complement 1-w supplied (wave-uniform weights keep it in an SGPR)
+__device__ __forceinline__ float4 lerp4w(float4 p, float4 q, float w, float iw)
+{
+    float4 r;
+    r.x = fmaf(q.x, w, p.x * iw);
+    r.y = fmaf(q.y, w, p.y * iw);
+    r.z = fmaf(q.z, w, p.z * iw);
+    r.w = 0.0f;
+    return r;
+}
+
 // lonDynamics, lon_planner.cu:240-250
 __device__ __forceinline__ TplLonState lon_dynamics(const TplLonState& x0, float j, float dt)
 {
@@ -96,6 +107,32 @@ __device__ __forceinline__ float path_lerp(const PathTap& t, float p0, float p1)
     return p0 * t.ia + p1 * t.a;
 }
 
+// x / c with a precomputed r = RN(1/c): q0 = x*r, one exact residual, one correction.
+// NOT trusted by itself: the planner only uses it after k_verify_fast_div has compared it
+// with the IEEE quotient for every float of the range it will see (dp_lon.hip).
+__device__ __forceinline__ float fast_div(float x, float c, float r)
+{
+    const float q0 = x * r;
+    const float e = fmaf(-q0, c, x);
+    return fmaf(e, r, q0);
+}
+
+// path_tap with the quotient distance / path_step_size already formed.
+// ceil(alpha) = floor(alpha) + (alpha > floor(alpha)); both are clamped like common.cuh:124-125.
+__device__ __forceinline__ PathTap path_tap_q(float alpha, int path_steps)
+{
+    PathTap t;
+    const float fl = floorf(alpha);
+    const float lo = fminf(fmaxf(fl, -1.0f), (float)path_steps);   // keeps the float->int conversion defined
+    const int i = (int)lo;
+    t.i0 = clampi(i, 0, path_steps - 1);
+    t.i1 = clampi(i + (alpha > fl ? 1 : 0), 0, path_steps - 1);
+    alpha -= (float)t.i0;
+    t.a = alpha;
+    t.ia = 1.0f - alpha;
+    return t;
+}
+
 // env.cu:258
 __device__ __forceinline__ float env_t_idx(const TplDpEnvParams& ep, float t)
 {
@@ -119,11 +156,13 @@ __device__ __forceinline__ float interp_dist_map_path(const TplDpEnvParams& ep, 
     return lerp1(a, b, ts.w);
 }
 
-// coordinate of readNode, lon_planner.cu:34-37: float expression + double 0.5 -> float
+// coordinate of readNode, lon_planner.cu:34-37: float expression + double 0.5 -> float.
+// (float)((double)c + 0.5) == c + 0.5f for every float c: the double sum is exact, so both
+// are the single rounding of the exact sum to float.
 __device__ __forceinline__ float node_coord(float x, float x_min, float x_max, int steps)
 {
     float c = (x - x_min) / (x_max - x_min) * (float)(steps - 1);
-    return (float)((double)c + 0.5);
+    return c + 0.5f;
 }
 
 // readNode with all eight taps from global memory (forward / reeval kernels).

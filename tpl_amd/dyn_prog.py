@@ -302,6 +302,12 @@ class DynProgLonPlanner:
         check(self._lib.tplhip_dp_lon_download(self._h, out))
         return [LonTraj._from_array(out[i * T:(i + 1) * T]) for i in range(n)]
 
+    def info(self):
+        import json
+        buf = C.create_string_buffer(512)
+        check(self._lib.tplhip_dp_lon_info(self._h, buf, 512))
+        return json.loads(buf.value.decode())
+
     def timing_enable(self, enable=True):
         check(self._lib.tplhip_dp_lon_timing_enable(self._h, 1 if enable else 0))
 
