@@ -78,6 +78,8 @@ static inline void init_interp(OInterp* i, double x0, double dx, double x, size_
     i->ia = 1.0 - i->a;
 }
 
+static inline void tpl_sincos(double a, double* s, double* c) { *s = sin(a); *c = cos(a); }
+
 static inline double tpl_get_array_value(const DynArr& A, double I) { return A.data[(size_t)I]; }
 
 static inline double tpl_box_interp(double dx, double x, const DynArr& arr)

@@ -21,6 +21,13 @@
 #define TPL_HD
 #endif
 
+// sin and cos of one argument with a shared range reduction (generated code asks for the
+// pair where a routine needs both)
+TPL_HD inline void tpl_sincos(double a, double* s, double* c)
+{
+    sincos(a, s, c);
+}
+
 struct DynArr {
     const double* data;   // device pointer in kernels, host pointer on the host
     int64_t n0, n1;       // dims[0], dims[1] (n1 = 0 for 1-D)
@@ -86,12 +93,19 @@ TPL_HD inline double tpl_lerp(double x0, double dx, double x, const DynArr& arr)
     return i.ia * arr.data[i.start] + i.a * arr.data[i.end];
 }
 
+// fmod(x, m) for m > 0: |x| < m returns x itself (that IS fmod's exact result); only larger
+// arguments take the library's long-division loop, which is very slow in fp64 on the GPU.
+TPL_HD inline double tpl_fmod_pos(double x, double m)
+{
+    return (fabs(x) < m) ? x : fmod(x, m);
+}
+
 // shortAngleDist, optim.c:332-338
 TPL_HD inline double tpl_short_angle_dist(double a0, double a1)
 {
     const double m = M_PI * 2;
-    const double da = fmod(a1 - a0, m);
-    return fmod(2 * da, m) - da;
+    const double da = tpl_fmod_pos(a1 - a0, m);
+    return tpl_fmod_pos(2 * da, m) - da;
 }
 
 // __lerp_angle, optim.c:394-411

@@ -32,6 +32,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -75,13 +77,30 @@ __host__ __device__ constexpr bool field_is_per_stage(int f)
     return f != TPL_F_BARRIER_WEIGHT && f != TPL_F_LG_MULT_LIMIT;
 }
 
+#ifdef TPL_ILQR_STAMP      /* diagnostic build only: per-phase cycle sums, never in the shipped library */
+#define STAMP(slot) do { if (lane == 0) { const long long now__ = (long long)__builtin_amdgcn_s_memtime(); \
+                         stamps[slot] += now__ - t_last; t_last = now__; } } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 struct DevState {
     double* f[TPL_F_COUNT];            // device base of every field, [batch][rows][width]
     double* scalars;                   // [batch][TPL_S_COUNT]
     const Params* params;              // [batch]
     double* cand_x;                    // [batch][N_ALPHA][rows][NX]   line-search candidates
     double* cand_u;                    // [batch][N_ALPHA][rows][NU]
+    double* cand_c;                    // [batch][N_ALPHA][rows]       stage costs of the candidates
     int rows;                          // t_cap + 1
+    long long* stamps;                 // diagnostic builds only
+    // LDS residency (decided by the host per launch, see plan_lds):
+    int lds_traj;                      // 1: x, u, k, K, uMax, uMin of the problem are mirrored in LDS
+    int n_lds_arrays;                  // array parameters copied into LDS
+    const double* lds_src[TPL_N_PARAMS + 1];     // global source of array slot i (problem 0)
+    long long lds_src_stride[TPL_N_PARAMS + 1];  // doubles between problems (0: shared)
+    int lds_len[TPL_N_PARAMS + 1];               // doubles
+    int lds_off[TPL_N_PARAMS + 1];               // doubles from the dynamic LDS base
+    unsigned long long lds_dyn_flat;   // flat address the host assumed for the dynamic LDS base
 };
 
 __device__ __forceinline__ double* fld(const DevState& st, int f, int b)
@@ -128,14 +147,43 @@ __device__ __forceinline__ void dynamics(const Params& P, const double* x, const
     }
 }
 
+// The workgroup IS one wavefront.  LDS operations of a wave are issued and completed in
+// program order, so an exchange through LDS between its lanes needs no s_barrier and --
+// unlike __syncthreads(), which also drains vmcnt -- must not wait for the global loads
+// that were issued on purpose to fly across it: wait for the LDS queue only and stop
+// the compiler from moving memory operations across.
+__device__ __forceinline__ void lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Dot product of N terms read from LDS with strides sa / sb.  All 2N reads are issued
+// before the first multiply (sched_barrier): hipcc otherwise waits for the LDS after
+// every pair of terms, four round trips per product instead of one.
+template <int N>
+__device__ __forceinline__ double dot_lds(const double* a, int sa, const double* b, int sb)
+{
+    double x[N], y[N];
+#pragma unroll
+    for (int m = 0; m < N; ++m) { x[m] = a[m * sa]; y[m] = b[m * sb]; }
+    __builtin_amdgcn_sched_barrier(0);
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < N; ++m) acc = fma(x[m], y[m], acc);
+    return acc;
+}
+
 // LDS working set of one problem
 struct Lds {
     double Vxx[NX * NX];
     double Vx[NX];
     double F[NX * NXU];        // [fx | fu], row-major over the NXU columns
     double l[NXU];             // [lx ; lu]
-    double Lxx[NX * NX];
-    double Lux[NU * NX];
+    double Lxx[NX * NX];       // Lxx | Lux | Luu and Qxx | Qux | Quu are laid out back to back:
+    double Lux[NU * NX];       // phase B addresses them as one array
     double Luu[NU * NU];
     double W[NX * NXU];        // Vxx [fx fu]
     double q[NXU];             // [Qx ; Qu]
@@ -151,9 +199,18 @@ struct Lds {
 // ---------------------------------------------------------------------------
 // one update() of problem blockIdx.x  (optim.c:1091-1160)
 // ---------------------------------------------------------------------------
+// flat address of LDS offset 0 (the "shared aperture"); the host adds offsets to it to
+// build DynArr.data pointers that point into a workgroup's LDS
+__global__ void k_lds_aperture(unsigned long long* out)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn0[];
+    *out = (unsigned long long)(void*)dyn0;
+}
+
 __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
 {
     __shared__ Lds s;
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     const Params& P = st.params[b];
@@ -202,10 +259,51 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
     double* CX = st.cand_x + (int64_t)b * N_ALPHA * st.rows * NX;
     double* CU = st.cand_u + (int64_t)b * N_ALPHA * st.rows * NU;
 
-    // ---- initial trajectory rollout, optim.c:1101-1111 (serial in t: one lane)
+    // ---- LDS residency.  Array parameters: the host already pointed Params::<array>.data at
+    // (aperture + offset); copy the data there.  The sanity check keeps a wrong aperture guess
+    // from silently reading garbage: the problem is flagged and nothing is solved.
+    if (st.n_lds_arrays > 0 || st.lds_traj) {
+        if ((unsigned long long)(void*)dyn != st.lds_dyn_flat) {
+            if (lane == 0) sc[TPL_S_TERMINATION_CONDITION] = -99.0;
+            return;
+        }
+        for (int a = 0; a < st.n_lds_arrays; ++a) {
+            const double* src = st.lds_src[a] + (int64_t)b * st.lds_src_stride[a];
+            double* dst = dyn + st.lds_off[a];
+            for (int e = lane; e < st.lds_len[a]; e += WAVE) dst[e] = src[e];
+        }
+    }
+    // trajectory mirrors (generic pointers: LDS copy if it fits, else the global arrays)
+    const int R = st.rows;
+    double* XL = dyn;
+    double* UL = XL + (int64_t)R * NX;
+    double* KL = UL + (int64_t)R * NU;
+    double* KBL = KL + (int64_t)R * NU;
+    double* UMXL = KBL + (int64_t)R * NU * NX;
+    double* UMNL = UMXL + (int64_t)R * NU;
+    const bool lt = st.lds_traj != 0;
+    const double* Xr = lt ? XL : X_;
+    const double* Ur = lt ? UL : U_;
+    const double* KFFr = lt ? KL : KFF;
+    const double* KFBr = lt ? KBL : KFB;
+    const double* UMAXr = lt ? UMXL : UMAX;
+    const double* UMINr = lt ? UMNL : UMIN;
+    if (lt) {
+        for (int e = lane; e < T * NU; e += WAVE) { UMXL[e] = UMAX[e]; UMNL[e] = UMIN[e]; }
+    }
+    __syncthreads();
+
+#ifdef TPL_ILQR_STAMP
+    long long stamps[16] = {0};
+    long long t_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    // ---- initial trajectory rollout, optim.c:1101-1111.  The dynamics chain is serial in
+    // t (one lane); the stage costs only need (x_t, u_t), so they are evaluated for all
+    // stages in parallel afterwards and summed in the reference's order t = optStart..T-1.
     double J = 0.0;
+    double* CC = st.cand_c + (int64_t)b * N_ALPHA * st.rows;
     if (lane == 0) {
-        double x[NX], u[NU], xn[NX], c;
+        double x[NX], u[NU], xn[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)opt_start * NX + i];
         for (int t = opt_start; t < T; ++t) {
@@ -213,8 +311,6 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
             for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
             IS[t] = dt;
             dynamics(P, x, u, t, dt, int_type, xn);
-            costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
-            J += c;
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 x[i] = xn[i];
@@ -222,11 +318,42 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
             }
         }
         IS[T] = dt;
+    }
+    __syncthreads();
+    for (int t = opt_start + lane; t < T; t += WAVE) {
+        double x[NX], u[NU], c;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
+#pragma unroll
+        for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
+        costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
+        CC[t] = c;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        double x[NX], c;
+        int t = opt_start;
+        for (; t + 8 <= T; t += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = CC[t + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) J += v[q];
+        }
+        for (; t < T; ++t) J += CC[t];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)T * NX + i];
         endCosts(P, x, (double)T, dt, &c, 1);
         J += c;
     }
     J = __shfl(J, 0, WAVE);
     __syncthreads();
+    if (lt) {
+        for (int e = lane; e < (T + 1) * NX; e += WAVE) XL[e] = X_[e];
+        for (int e = lane; e < T * NU; e += WAVE) UL[e] = U_[e];
+    }
+    __syncthreads();
+    STAMP(0);
 
     for (lg_it = 0; lg_it < max_lg; ++lg_it) {
         // ---- multiplier update, optim.c:1119-1132 (lane = stage)
@@ -250,6 +377,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
             }
         }
         __syncthreads();
+        STAMP(1);
         traj_changed = true;
         improved = false;
         iterations = 0;
@@ -281,6 +409,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                 }
                 traj_changed = false;
                 __syncthreads();
+                STAMP(2);
             }
 
             // value function at the end of the horizon, optim.c:914-916
@@ -295,80 +424,146 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
 
             if (second_order) {
                 // ---- backward Riccati pass, optim.c:926-985
-                for (int t = T - 1; t >= 0; --t) {
-                    // stage blocks -> LDS (coalesced runs of the row-major mirrors)
-                    for (int e = lane; e < NX * NX; e += WAVE) {
-                        const int i = e / NX, j = e - i * NX;
-                        s.F[i * NXU + j] = FX[(int64_t)t * NX * NX + e];
-                        s.Lxx[e] = LXX[(int64_t)t * NX * NX + e];
+                // The stage blocks are read one stage AHEAD into registers (lane = entry) and
+                // parked in LDS during phase D of the stage before, so the HBM/L2 latency of stage
+                // t-1 hides under the dependent phases of stage t; four LDS exchanges per stage.
+                constexpr int E_XX = (NX * NX + WAVE - 1) / WAVE, E_XU = (NX * NU + WAVE - 1) / WAVE;
+                double r_fx[E_XX], r_lxx[E_XX], r_fu[E_XU], r_lux[E_XU], r_l = 0.0, r_luu = 0.0, r_ul[3] = {0.0, 0.0, 0.0};
+                auto fetch_stage = [&](int t) {
+#pragma unroll
+                    for (int q = 0; q < E_XX; ++q) {
+                        const int e = lane + q * WAVE;
+                        if (e < NX * NX) { r_fx[q] = FX[(int64_t)t * NX * NX + e]; r_lxx[q] = LXX[(int64_t)t * NX * NX + e]; }
                     }
-                    for (int e = lane; e < NX * NU; e += WAVE) {
-                        const int i = e / NU, j = e - i * NU;
-                        s.F[i * NXU + NX + j] = FU[(int64_t)t * NX * NU + e];
-                        s.Lux[e] = LUX[(int64_t)t * NU * NX + e];
+#pragma unroll
+                    for (int q = 0; q < E_XU; ++q) {
+                        const int e = lane + q * WAVE;
+                        if (e < NX * NU) { r_fu[q] = FU[(int64_t)t * NX * NU + e]; r_lux[q] = LUX[(int64_t)t * NU * NX + e]; }
                     }
-                    if (lane < NX) s.l[lane] = LX[(int64_t)t * NX + lane];
+                    if (lane < NX) r_l = LX[(int64_t)t * NX + lane];
+                    else if (lane < NXU) r_l = LU[(int64_t)t * NU + (lane - NX)];
+                    if (lane < NU * NU) r_luu = LUU[(int64_t)t * NU * NU + lane];
                     if (lane < NU) {
-                        s.l[NX + lane] = LU[(int64_t)t * NU + lane];
-                        s.ulim[lane] = U_[(int64_t)t * NU + lane];
-                        s.ulim[NU + lane] = UMAX[(int64_t)t * NU + lane];
-                        s.ulim[2 * NU + lane] = UMIN[(int64_t)t * NU + lane];
+                        r_ul[0] = U_[(int64_t)t * NU + lane];
+                        r_ul[1] = UMAX[(int64_t)t * NU + lane];
+                        r_ul[2] = UMIN[(int64_t)t * NU + lane];
                     }
-                    if (lane < NU * NU) s.Luu[lane] = LUU[(int64_t)t * NU * NU + lane];
-                    __syncthreads();
-
-                    // phase A: W = Vxx [fx fu];  q = l + [fx fu]^T Vx
-                    for (int e = lane; e < NX * NXU; e += WAVE) {
-                        const int i = e / NXU, j = e - i * NXU;
-                        double acc = 0.0;
+                };
+                auto park_stage = [&]() {
 #pragma unroll
-                        for (int m = 0; m < NX; ++m) acc += s.Vxx[i * NX + m] * s.F[m * NXU + j];
-                        s.W[e] = acc;
-                    }
-                    if (lane < NXU) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int m = 0; m < NX; ++m) acc += s.F[m * NXU + lane] * s.Vx[m];
-                        s.q[lane] = s.l[lane] + acc;
-                    }
-                    __syncthreads();
-
-                    // phase B: Qxx, Qux, Quu = L + F^T W  (symmetric blocks: lower triangle, mirrored)
-                    for (int e = lane; e < NX * NX + NU * NX + NU * NU; e += WAVE) {
+                    for (int q = 0; q < E_XX; ++q) {
+                        const int e = lane + q * WAVE;
                         if (e < NX * NX) {
-                            int i = e / NX, j = e - i * NX;
-                            const int hi = i > j ? i : j, lo = i > j ? j : i;
-                            double acc = 0.0;
-#pragma unroll
-                            for (int m = 0; m < NX; ++m) acc += s.F[m * NXU + hi] * s.W[m * NXU + lo];
-                            s.Qxx[e] = s.Lxx[e] + acc;
-                        } else if (e < NX * NX + NU * NX) {
-                            const int r = e - NX * NX;
-                            const int d = r / NX, j = r - d * NX;
-                            double acc = 0.0;
-#pragma unroll
-                            for (int m = 0; m < NX; ++m) acc += s.F[m * NXU + NX + d] * s.W[m * NXU + j];
-                            s.Qux[r] = s.Lux[r] + acc;
-                        } else {
-                            const int r = e - NX * NX - NU * NX;
-                            const int d = r / NU, c = r - d * NU;
-                            const int hi = d > c ? d : c, lo = d > c ? c : d;
-                            double acc = 0.0;
-#pragma unroll
-                            for (int m = 0; m < NX; ++m) acc += s.F[m * NXU + NX + hi] * s.W[m * NXU + NX + lo];
-                            s.Quu[r] = s.Luu[r] + acc;
+                            const int i = e / NX, j = e - i * NX;
+                            s.F[i * NXU + j] = r_fx[q];
+                            s.Lxx[e] = r_lxx[q];
                         }
                     }
-                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < E_XU; ++q) {
+                        const int e = lane + q * WAVE;
+                        if (e < NX * NU) {
+                            const int i = e / NU, j = e - i * NU;
+                            s.F[i * NXU + NX + j] = r_fu[q];
+                            s.Lux[e] = r_lux[q];
+                        }
+                    }
+                    if (lane < NXU) s.l[lane] = r_l;
+                    if (lane < NU * NU) s.Luu[lane] = r_luu;
+                    if (lane < NU) {
+                        s.ulim[lane] = r_ul[0];
+                        s.ulim[NU + lane] = r_ul[1];
+                        s.ulim[2 * NU + lane] = r_ul[2];
+                    }
+                };
+
+                // lane -> entry maps of phases A, B, D (they do not depend on the stage)
+                constexpr int N_XX = NX * (NX + 1) / 2, N_UX = NU * NX, N_UU = NU * (NU + 1) / 2;
+                constexpr int N_B = N_XX + N_UX + N_UU + NXU;
+                static_assert(NX * NXU <= 2 * WAVE && N_B <= 2 * WAVE, "state dimension too large for this kernel");
+                int b_colF[2], b_colW[2], b_out0[2], b_out1[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = lane + q * WAVE;
+                    int colF = 0, colW = 0, out0 = -1, out1 = -1;
+                    if (e < N_XX) {
+                        int hi = 0;
+                        while ((hi + 1) * (hi + 2) / 2 <= e) ++hi;             // row of the packed lower triangle
+                        const int lo = e - hi * (hi + 1) / 2;
+                        colF = hi; colW = lo; out0 = hi * NX + lo; out1 = lo * NX + hi;
+                    } else if (e < N_XX + N_UX) {
+                        const int r = e - N_XX, d = r / NX, jj = r - d * NX;
+                        colF = NX + d; colW = jj; out0 = out1 = NX * NX + r;
+                    } else if (e < N_XX + N_UX + N_UU) {
+                        const int r = e - N_XX - N_UX;
+                        int hi = 0;
+                        while ((hi + 1) * (hi + 2) / 2 <= r) ++hi;
+                        const int lo = r - hi * (hi + 1) / 2;
+                        colF = NX + hi; colW = NX + lo;
+                        out0 = NX * NX + NU * NX + hi * NU + lo; out1 = NX * NX + NU * NX + lo * NU + hi;
+                    } else if (e < N_B) {
+                        colF = e - (N_XX + N_UX + N_UU); colW = -1; out0 = out1 = colF;   // q entry
+                    }
+                    b_colF[q] = colF; b_colW[q] = colW; b_out0[q] = out0; b_out1[q] = out1;
+                }
+                // phase D: lanes [0, NX*NX) own Vxx entries, lanes [NX*NX, NX*NX+NX) own Vx entries
+                const bool d_vxx = lane < NX * NX, d_vx = lane >= NX * NX && lane < NX * NX + NX;
+                static_assert(NX * NX + NX <= WAVE || NX > 7, "phase D lane map");
+                const int d_i = d_vxx ? lane / NX : (d_vx ? lane - NX * NX : 0);
+                const int d_j = d_vxx ? lane - (lane / NX) * NX : 0;
+
+                fetch_stage(T - 1);
+                park_stage();
+                lds_sync();
+                if (T > 1) fetch_stage(T - 2);
+                for (int t = T - 1; t >= 0; --t) {
+                    STAMP(6);
+                    // phase A: W = Vxx [fx fu]
+#pragma unroll
+                    for (int q = 0; q < (NX * NXU + WAVE - 1) / WAVE; ++q) {
+                        const int e = lane + q * WAVE;
+                        if (e < NX * NXU) {
+                            const int i = e / NXU, j = e - i * NXU;
+                            s.W[e] = dot_lds<NX>(&s.Vxx[i * NX], 1, &s.F[j], NXU);
+                        }
+                    }
+                    lds_sync();
+                    STAMP(7);
+
+                    // phase B: Q = L + F^T W.  Only the lower triangles of the symmetric blocks are
+                    // formed and then mirrored, like mul_symm (optim.c:159-180); q = l + F^T Vx rides
+                    // along on otherwise idle lanes.
+#pragma unroll
+                    for (int q = 0; q < (N_B + WAVE - 1) / WAVE; ++q) {
+                        if (b_out0[q] >= 0) {
+                            if (b_colW[q] < 0) {
+                                s.q[b_out0[q]] = s.l[b_out0[q]] + dot_lds<NX>(&s.F[b_colF[q]], NXU, s.Vx, 1);
+                            } else {
+                                const double l0 = s.Lxx[b_out0[q]], l1 = s.Lxx[b_out1[q]];   // runs on into Lux / Luu
+                                const double acc = dot_lds<NX>(&s.F[b_colF[q]], NXU, &s.W[b_colW[q]], NXU);
+                                s.Qxx[b_out0[q]] = l0 + acc;                                   // runs on into Qux / Quu
+                                if (b_out1[q] != b_out0[q]) s.Qxx[b_out1[q]] = l1 + acc;
+                            }
+                        }
+                    }
+                    lds_sync();
+                    STAMP(8);
 
                     // phase C: gains (solve_action optim.c:243-291) + control-box projection (:950-963)
                     if (lane < NU * (NX + 1)) {
                         const int d = lane / (NX + 1), c = lane - d * (NX + 1);
+                        double quu[NU * NU], qu[NU], col[NU];
+#pragma unroll
+                        for (int m = 0; m < NU * NU; ++m) quu[m] = s.Quu[m];
+#pragma unroll
+                        for (int m = 0; m < NU; ++m) { qu[m] = s.q[NX + m]; col[m] = (c == NX) ? 0.0 : s.Qux[m * NX + (c == NX ? 0 : c)]; }
+                        const double ud = s.ulim[d], umax = s.ulim[NU + d], umin = s.ulim[2 * NU + d];
+                        __builtin_amdgcn_sched_barrier(0);
                         double inv[NU][NU];
                         if constexpr (NU == 1) {
-                            inv[0][0] = (s.Quu[0] > 0.0) ? -1.0 / (s.Quu[0] + mu) : 0.0;
+                            inv[0][0] = (quu[0] > 0.0) ? -1.0 / (quu[0] + mu) : 0.0;
                         } else {
-                            const double qa = s.Quu[0] + mu, qb = s.Quu[1], qd = s.Quu[NU + 1] + mu;
+                            const double qa = quu[0] + mu, qb = quu[1], qd = quu[NU + 1] + mu;
                             const double det = qa * qd - qb * qb;
                             const double inv_det = -1.0f / det;
                             inv[0][0] = qd * inv_det;
@@ -378,69 +573,76 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                         }
                         double kd = 0.0;
 #pragma unroll
-                        for (int m = 0; m < NU; ++m) kd += inv[d][m] * s.q[NX + m];
+                        for (int m = 0; m < NU; ++m) kd = fma(inv[d][m], qu[m], kd);
                         double val;
                         if (c == NX) {
                             val = kd;
                         } else {
                             val = 0.0;
 #pragma unroll
-                            for (int m = 0; m < NU; ++m) val += inv[d][m] * s.Qux[m * NX + c];
+                            for (int m = 0; m < NU; ++m) val = fma(inv[d][m], col[m], val);
                         }
-                        const double ud = s.ulim[d], umax = s.ulim[NU + d], umin = s.ulim[2 * NU + d];
                         const double cd = ud + kd;
                         if (cd > umax) val = (c == NX) ? umax - ud : 0.0;
                         if (cd < umin) val = (c == NX) ? umin - ud : 0.0;
                         if (c == NX) {
                             s.k[d] = val;
                             KFF[(int64_t)t * NU + d] = val;
+                            if (lt) KL[(int64_t)t * NU + d] = val;
                         } else {
                             s.K[d * NX + c] = val;
                             KFB[(int64_t)t * NU * NX + d * NX + c] = val;
+                            if (lt) KBL[(int64_t)t * NU * NX + d * NX + c] = val;
                         }
                     }
-                    __syncthreads();
+                    lds_sync();
+                    STAMP(9);
 
                     // phase D: value function update, optim.c:965-984 (same order of additions)
-                    double vxx_new = 0.0, vx_new = 0.0;
-                    if (lane < NX * NX) {
-                        const int i = lane / NX, j = lane - i * NX;
-                        double mij = 0.0, mji = 0.0;
+                    if (d_vxx || d_vx) {
+                        double Ki[NU], Kj[NU], Qi[NU], Qj[NU], quu[NU * NU], kk[NU], qu[NU];
 #pragma unroll
                         for (int d = 0; d < NU; ++d) {
-                            mij += s.K[d * NX + i] * s.Qux[d * NX + j];
-                            mji += s.K[d * NX + j] * s.Qux[d * NX + i];
+                            Ki[d] = s.K[d * NX + d_i]; Kj[d] = s.K[d * NX + d_j];
+                            Qi[d] = s.Qux[d * NX + d_i]; Qj[d] = s.Qux[d * NX + d_j];
+                            kk[d] = s.k[d]; qu[d] = s.q[NX + d];
                         }
-                        double v = mji + mij;
+#pragma unroll
+                        for (int m = 0; m < NU * NU; ++m) quu[m] = s.Quu[m];
+                        const double tail = d_vxx ? s.Qxx[lane] : s.q[d_i];
+                        __builtin_amdgcn_sched_barrier(0);
+                        double kq[NU];                                   // (K^T Quu)[i][d]
 #pragma unroll
                         for (int d = 0; d < NU; ++d) {
-                            double kq = 0.0;                 // (K^T Quu)[i][d]
+                            double a = 0.0;
 #pragma unroll
-                            for (int m = 0; m < NU; ++m) kq += s.K[m * NX + i] * s.Quu[m * NU + d];
-                            v += kq * s.K[d * NX + j];
+                            for (int m = 0; m < NU; ++m) a = fma(Ki[m], quu[m * NU + d], a);
+                            kq[d] = a;
                         }
-                        vxx_new = v + s.Qxx[lane];
+                        if (d_vxx) {
+                            double mij = 0.0, mji = 0.0;
+#pragma unroll
+                            for (int d = 0; d < NU; ++d) { mij = fma(Ki[d], Qj[d], mij); mji = fma(Kj[d], Qi[d], mji); }
+                            double v = mji + mij;
+#pragma unroll
+                            for (int d = 0; d < NU; ++d) v = fma(kq[d], Kj[d], v);
+                            s.Vxx[lane] = v + tail;
+                        } else {
+                            double v = 0.0;
+#pragma unroll
+                            for (int d = 0; d < NU; ++d) v = fma(kq[d], kk[d], v);
+#pragma unroll
+                            for (int d = 0; d < NU; ++d) v = fma(Ki[d], qu[d], v);
+#pragma unroll
+                            for (int d = 0; d < NU; ++d) v = fma(Qi[d], kk[d], v);
+                            s.Vx[d_i] = v + tail;
+                        }
                     }
-                    if (lane < NX) {
-                        const int i = lane;
-                        double v = 0.0;
-#pragma unroll
-                        for (int d = 0; d < NU; ++d) {
-                            double kq = 0.0;
-#pragma unroll
-                            for (int m = 0; m < NU; ++m) kq += s.K[m * NX + i] * s.Quu[m * NU + d];
-                            v += kq * s.k[d];
-                        }
-#pragma unroll
-                        for (int d = 0; d < NU; ++d) v += s.K[d * NX + i] * s.q[NX + d];
-#pragma unroll
-                        for (int d = 0; d < NU; ++d) v += s.Qux[d * NX + i] * s.k[d];
-                        vx_new = v + s.q[i];
-                    }
-                    __syncthreads();
-                    if (lane < NX * NX) s.Vxx[lane] = vxx_new;
-                    if (lane < NX) s.Vx[lane] = vx_new;
-                    __syncthreads();
+                    // stage t-1 is already in registers: park it for the next trip, then fetch t-2
+                    if (t > 0) park_stage();
+                    lds_sync();
+                    if (t > 1) fetch_stage(t - 2);
+                    STAMP(10);
                 }
             } else {
                 // ---- first-order backward pass, optim.c:1044-1073
@@ -463,6 +665,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                         if (c > UMAX[(int64_t)t * NU + lane]) kk = U_[(int64_t)t * NU + lane] - UMAX[(int64_t)t * NU + lane];
                         if (c < UMIN[(int64_t)t * NU + lane]) kk = U_[(int64_t)t * NU + lane] - UMIN[(int64_t)t * NU + lane];
                         KFF[(int64_t)t * NU + lane] = kk;
+                        if (lt) KL[(int64_t)t * NU + lane] = kk;
                     }
                     __syncthreads();
                     if (lane < NX) s.Vx[lane] = qx;
@@ -470,54 +673,107 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                 }
             }
 
+            STAMP(3);
             // ---- line search, optim.c:859-873: all eight alphas at once, accept the first
             const double J_prev = J;
             double Jc = INFINITY;
+            // pass A: the eight dynamics chains (lqrForwardPass :745-775 / lrForwardPass :803-818)
             if (lane < N_ALPHA) {
                 double a = 1.0;
                 for (int i = 0; i < lane; ++i) a *= 10.0;
                 a = 1.0 / a;                                   // 1.0 / pow(10, i)
                 double* cx = CX + (int64_t)lane * st.rows * NX;
                 double* cu = CU + (int64_t)lane * st.rows * NU;
-                double x[NX], xn[NX], u[NU], c;
+                double x[NX], xn[NX], u[NU];
                 // stages before opt_start are frozen (tpl never moves opt_start off 0)
                 for (int e = 0; e < opt_start * NX; ++e) cx[e] = X_[e];
 #pragma unroll
                 for (int i = 0; i < NX; ++i) { x[i] = X_[(int64_t)opt_start * NX + i]; cx[(int64_t)opt_start * NX + i] = x[i]; }
-                double cost = 0.0;
                 for (int t = opt_start; t < T; ++t) {
-                    // lqrForwardPass :745-758 / lrForwardPass :803-805
+                    // feedback law: all operands first, then the arithmetic (one memory round trip)
+                    double kff[NU], ub[NU], hi[NU], lo[NU], kfb[NU * NX], xr[NX];
+#pragma unroll
+                    for (int d = 0; d < NU; ++d) {
+                        kff[d] = KFFr[(int64_t)t * NU + d];
+                        ub[d] = Ur[(int64_t)t * NU + d];
+                        hi[d] = UMAXr[(int64_t)t * NU + d];
+                        lo[d] = UMINr[(int64_t)t * NU + d];
+                    }
+                    if (second_order) {
+#pragma unroll
+                        for (int e = 0; e < NU * NX; ++e) kfb[e] = KFBr[(int64_t)t * NU * NX + e];
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) xr[i] = Xr[(int64_t)t * NX + i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int d = 0; d < NU; ++d) {
                         double ud;
                         if (second_order) {
-                            ud = KFF[(int64_t)t * NU + d] * a;
-                            ud = ud + U_[(int64_t)t * NU + d];
+                            ud = kff[d] * a;
+                            ud = ud + ub[d];
 #pragma unroll
-                            for (int i = 0; i < NX; ++i)
-                                ud += KFB[(int64_t)t * NU * NX + d * NX + i] * (x[i] - X_[(int64_t)t * NX + i]);
-                            const double hi = UMAX[(int64_t)t * NU + d], lo = UMIN[(int64_t)t * NU + d];
-                            ud = hi < ud ? hi : ud;
-                            ud = lo > ud ? lo : ud;
+                            for (int i = 0; i < NX; ++i) ud += kfb[d * NX + i] * (x[i] - xr[i]);
+                            ud = hi[d] < ud ? hi[d] : ud;
+                            ud = lo[d] > ud ? lo[d] : ud;
                         } else {
-                            ud = U_[(int64_t)t * NU + d] - KFF[(int64_t)t * NU + d] * a;
+                            ud = ub[d] - kff[d] * a;
                         }
                         u[d] = ud;
                         cu[(int64_t)t * NU + d] = ud;
                     }
+                    STAMP(14);
                     dynamics(P, x, u, t, dt, int_type, xn);
-                    costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
-                    cost += c;
 #pragma unroll
                     for (int i = 0; i < NX; ++i) {
                         x[i] = xn[i];
                         cx[(int64_t)(t + 1) * NX + i] = xn[i];
                     }
+                    STAMP(15);
                 }
+            }
+            __syncthreads();
+            STAMP(11);
+            // pass B: stage costs of all candidates and stages, 64 at a time
+            {
+                const int n_t = T - opt_start;
+                for (int idx = lane; idx < N_ALPHA * n_t; idx += WAVE) {
+                    const int cand = idx & (N_ALPHA - 1);
+                    const int t = opt_start + (idx >> 3);
+                    const double* cx = CX + ((int64_t)cand * st.rows + t) * NX;
+                    const double* cu = CU + ((int64_t)cand * st.rows + t) * NU;
+                    double x[NX], u[NU], c;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) x[i] = cx[i];
+#pragma unroll
+                    for (int d = 0; d < NU; ++d) u[d] = cu[d];
+                    costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
+                    CC[(int64_t)cand * st.rows + t] = c;
+                }
+            }
+            __syncthreads();
+            STAMP(12);
+            // ordered sums, cost += c for t = optStart..T-1, then the end costs (:776-790)
+            if (lane < N_ALPHA) {
+                const double* cc = CC + (int64_t)lane * st.rows;
+                double cost = 0.0, c;
+                int t = opt_start;
+                for (; t + 8 <= T; t += 8) {                    // eight loads in flight, additions in order
+                    double v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = cc[t + q];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) cost += v[q];
+                }
+                for (; t < T; ++t) cost += cc[t];
+                double x[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x[i] = CX[((int64_t)lane * st.rows + T) * NX + i];
                 endCosts(P, x, (double)T, dt, &c, 1);
                 cost += c;
                 Jc = cost;
             }
+            STAMP(13);
             // testImprovement, optim.c:840-857
             const bool ok = lane < N_ALPHA && Jc < J && isfinite(Jc) && Jc >= 0.0;
             const unsigned long long okm = __ballot(ok);
@@ -539,6 +795,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                         const double v = cx[e];
                         NXT_X[e] = v;
                         X_[e] = v;
+                        if (lt) XL[e] = v;
                     }
                     for (int e = lane; e < T * NU; e += WAVE) {
                         PRV_K[e] = KFF[e];
@@ -546,6 +803,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                             const double v = cu[e];
                             NXT_U[e] = v;
                             U_[e] = v;
+                            if (lt) UL[e] = v;
                         }
                     }
                     for (int e = lane; e < T + 1; e += WAVE) { NIS[e] = dt; IS[e] = dt; }
@@ -560,6 +818,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
             }
             __syncthreads();
 
+            STAMP(5);
             if (second_order) {                                // mu schedule, optim.c:989-999
                 mu_step = accepted ? (mu_step - 1 > 0 ? mu_step - 1 : 0) : (mu_step + 1 < 7 ? mu_step + 1 : 7);
                 if (mu_step == 0) {
@@ -579,6 +838,9 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
     }
     if (iterations == max_iter) term = 1;                      // optim.c:1147-1149
 
+#ifdef TPL_ILQR_STAMP
+    if (lane == 0) for (int i = 0; i < 16; ++i) st.stamps[(int64_t)b * 16 + i] = stamps[i];
+#endif
     if (lane == 0) {
         sc[TPL_S_TRAJ_COSTS] = J;
         sc[TPL_S_ITERATIONS] = (double)iterations;
@@ -628,6 +890,7 @@ struct ArrayParam {
     int per_problem = 0;
     double* dev = nullptr;
     size_t dev_cap = 0;
+    long long lds_off = -1;          // doubles from the dynamic LDS base, -1: stays in global memory
 };
 
 // fields the kernel reads from the host's hands, and the ones update() returns eagerly
@@ -660,6 +923,9 @@ struct tplhip_ilqr {
     bool timing = false;
     double kernel_ms = 0.0;
     int64_t launches = 0;
+    unsigned long long lds_aperture = 0;         // flat address of LDS offset 0 (0: unknown, no LDS residency)
+    size_t lds_static = 0;                       // static LDS of k_ilqr_update
+    size_t lds_dyn_bytes = 0;                    // dynamic LDS of the next launch
 };
 
 namespace {
@@ -668,6 +934,38 @@ size_t field_elems(const tplhip_ilqr* h, int f)
 {
     const size_t rows = field_is_per_stage(f) ? (size_t)h->rows : 1;
     return (size_t)h->batch * rows * field_width(f);
+}
+
+// Decide what lives in LDS for the next launch.  One workgroup per SIMD must stay resident
+// (4 per CU, 160 KB of LDS per CU), so a workgroup may use ~36 KB on top of its static block.
+// Priority: array parameters (every ctDynamics waits on them), then the trajectory mirrors.
+void plan_lds(tplhip_ilqr* h)
+{
+    DevState& d = h->dev;
+    d.lds_traj = 0;
+    d.n_lds_arrays = 0;
+    d.lds_dyn_flat = 0;
+    h->lds_dyn_bytes = 0;
+    if (!h->lds_aperture || std::getenv("TPLHIP_ILQR_NO_LDS")) return;
+    const size_t budget = 36 * 1024 / sizeof(double);
+    const size_t traj = (size_t)h->rows * (NX + NU + NU + NU * NX + NU + NU);
+    size_t off = 0;
+    if (traj <= budget) { d.lds_traj = 1; off = traj; }
+    for (int i = 0; i < TPL_N_PARAMS; ++i) {
+        if (!g_params[i].is_array) continue;
+        const ArrayParam& a = h->parray[i];
+        if (a.elems <= 0 || !a.dev) continue;
+        if (off + (size_t)a.elems > budget) continue;
+        const int k = d.n_lds_arrays++;
+        d.lds_src[k] = a.dev;
+        d.lds_src_stride[k] = a.per_problem ? a.elems : 0;
+        d.lds_len[k] = (int)a.elems;
+        d.lds_off[k] = (int)off;
+        h->parray[i].lds_off = (long long)off;
+        off += ((size_t)a.elems + 1) & ~(size_t)1;          // keep 16-byte alignment
+    }
+    h->lds_dyn_bytes = off * sizeof(double);
+    d.lds_dyn_flat = h->lds_aperture + h->lds_static;
 }
 
 int upload_params(tplhip_ilqr* h)
@@ -685,6 +983,8 @@ int upload_params(tplhip_ilqr* h)
         if (bytes) HIP_TRY(hipMemcpyAsync(a.dev, a.host.data(), bytes, hipMemcpyHostToDevice, h->stream),
                            "copying a parameter array failed");
     }
+    for (auto& a : h->parray) a.lds_off = -1;
+    plan_lds(h);
     for (int b = 0; b < h->batch; ++b) {
         Params& P = h->dparams_host[b];
         std::memset(&P, 0, sizeof(Params));
@@ -694,6 +994,8 @@ int upload_params(tplhip_ilqr* h)
                 const ArrayParam& a = h->parray[i];
                 DynArr d;
                 d.data = a.dev ? a.dev + (a.per_problem ? (size_t)b * a.elems : 0) : nullptr;
+                if (a.lds_off >= 0)     // the kernel copies the array to this LDS address first
+                    d.data = (const double*)(uintptr_t)(h->dev.lds_dyn_flat + (unsigned long long)a.lds_off * sizeof(double));
                 d.ndim = a.ndim;
                 d.n0 = a.ndim > 0 ? a.dims[0] : 0;
                 d.n1 = a.ndim > 1 ? a.dims[1] : 0;
@@ -749,7 +1051,7 @@ int launch(tplhip_ilqr* h)
         HIP_TRY(hipEventCreate(&e1), "event creation failed");
         HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
     }
-    hipLaunchKernelGGL(k_ilqr_update, dim3(h->batch), dim3(WAVE), 0, h->stream, h->dev);
+    hipLaunchKernelGGL(k_ilqr_update, dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes, h->stream, h->dev);
     HIP_TRY(hipGetLastError(), "solver launch failed");
     if (h->timing) {
         HIP_TRY(hipEventRecord(e1, h->stream), "event record failed");
@@ -846,8 +1148,29 @@ int tplhip_ilqr_create(int device, int batch, int t_cap, tplhip_ilqr** out)
     if (err == hipSuccess) err = hipMalloc(&h->d_params, sizeof(Params) * (size_t)batch);
     if (err == hipSuccess) err = hipMalloc(&h->dev.cand_x, cand_x * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&h->dev.cand_u, cand_u * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc(&h->dev.cand_c, (size_t)batch * N_ALPHA * h->rows * sizeof(double));
     if (err != hipSuccess) { tplhip_ilqr_destroy(h); return fail(TPLHIP_EDEVICE, "%s: solver workspace allocation failed", hipGetErrorString(err)); }
     h->dev.params = h->d_params;
+    h->dev.stamps = nullptr;
+    {
+        // where LDS sits in the flat address space (constant per process and device)
+        unsigned long long* d_ap = nullptr;
+        hipFuncAttributes attr;
+        if (hipMalloc(&d_ap, sizeof(unsigned long long)) == hipSuccess) {
+            hipLaunchKernelGGL(k_lds_aperture, dim3(1), dim3(1), 16, h->stream, d_ap);
+            unsigned long long ap = 0;
+            if (hipMemcpyAsync(&ap, d_ap, sizeof ap, hipMemcpyDeviceToHost, h->stream) == hipSuccess
+                && hipStreamSynchronize(h->stream) == hipSuccess
+                && hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(k_ilqr_update)) == hipSuccess) {
+                h->lds_aperture = ap;
+                h->lds_static = attr.sharedSizeBytes;
+            }
+            hipFree(d_ap);
+        }
+    }
+#ifdef TPL_ILQR_STAMP
+    if (hipMalloc(&h->dev.stamps, sizeof(long long) * 16 * (size_t)batch) != hipSuccess) h->dev.stamps = nullptr;
+#endif
 
     // defaults of pyOptimAlloc, optim.c:1894-1921
     const int T0 = std::min(20, t_cap);
@@ -885,6 +1208,7 @@ int tplhip_ilqr_destroy(tplhip_ilqr* h)
     hipFree(h->d_params);
     hipFree(h->dev.cand_x);
     hipFree(h->dev.cand_u);
+    hipFree(h->dev.cand_c);
     for (double* p : h->d_snapshot) hipFree(p);
     hipFree(h->d_snapshot_scalars);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -960,6 +1284,9 @@ int tplhip_ilqr_update(tplhip_ilqr* h)
     HIP_TRY(hipMemcpyAsync(h->scalars.data(), h->dev.scalars, h->scalars.size() * sizeof(double),
                            hipMemcpyDeviceToHost, h->stream), "copying solver results failed");
     HIP_TRY(hipStreamSynchronize(h->stream), "solver update failed");
+    for (int b = 0; b < h->batch; ++b)
+        if (h->scalars[(size_t)b * TPL_S_COUNT + TPL_S_TERMINATION_CONDITION] == -99.0)
+            return fail(TPLHIP_EDEVICE, "LDS aperture mismatch: the solver kernel did not find its LDS where the host placed the parameter arrays");
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (int b = 0; b < h->batch; ++b) h->scalars[(size_t)b * TPL_S_COUNT + TPL_S_RUNTIME] = ms;   // optim.c:1153-1159
     return TPLHIP_OK;
@@ -1092,6 +1419,18 @@ int tplhip_ilqr_download(tplhip_ilqr* h)
 {
     if (!h) return fail(TPLHIP_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+#ifdef TPL_ILQR_STAMP
+    if (h->dev.stamps) {
+        std::vector<long long> st((size_t)h->batch * 16);
+        hipStreamSynchronize(h->stream);
+        hipMemcpy(st.data(), h->dev.stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        double sum[16] = {0};
+        for (int b = 0; b < h->batch; ++b) for (int i = 0; i < 16; ++i) sum[i] += (double)st[(size_t)b * 16 + i];
+        const char* names[16] = {"initial rollout", "multiplier update", "derivatives", "backward pass (rest)", "line-search rollouts", "accept/copy",
+                                 "bw: regs->LDS + fetch", "bw: phase A", "bw: phase B", "bw: phase C", "bw: phase D", "ls: dynamics chains (rest)", "ls: cost pass", "ls: sums", "ls/step: feedback law u", "ls/step: dynamics + stores"};
+        for (int i = 0; i < 16; ++i) std::fprintf(stderr, "[stamp] %-22s %12.0f s_memtime ticks per problem per update\n", names[i], sum[i] / h->batch);
+    }
+#endif
     for (int f : kEagerFields) {
         int rc = fetch_field(h, f);
         if (rc) return rc;

@@ -228,6 +228,103 @@ def _signature(name):
     return _SIGNATURES["dyn"]
 
 
+def _fuse_sincos(subs, reduced):
+    """sin(a) and cos(a) of the same argument share one range reduction when they are
+    asked for together (``sincos``); the values are the library's sin and cos.  After CSE
+    every such call is its own temporary ``w_i = sin(a)`` / ``w_j = cos(a)`` (or sits inside
+    an expression when it is used once); pairs are rewritten into one marker entry
+    ``(pair_id, a)`` that the emitter prints as ``tpl_sincos(a, &w_i, &w_j)``.
+
+    Returns (new_subs, {pair_id: (sin_symbol, cos_symbol)})."""
+    # first give single-use sin/cos calls a name, so pairs can be found uniformly
+    counter = [0]
+
+    def fresh():
+        counter[0] += 1
+        return sp.Symbol(f"sc{counter[0]}")
+
+    exprs = [e for _, e in subs] + list(reduced)
+    args_sin = {}
+    args_cos = {}
+    for e in exprs:
+        for f in e.atoms(sp.sin):
+            args_sin.setdefault(f.args[0], f)
+        for f in e.atoms(sp.cos):
+            args_cos.setdefault(f.args[0], f)
+    both = [a for a in args_sin if a in args_cos]
+    if not both:
+        return subs, {}
+    fused = {}
+    repl = {}
+    pairs = []
+    for a in both:
+        s_sym, c_sym, pid = fresh(), fresh(), fresh()
+        repl[args_sin[a]] = s_sym
+        repl[args_cos[a]] = c_sym
+        fused[pid] = (s_sym, c_sym)
+        pairs.append((pid, a, s_sym, c_sym))
+    # cos(a - b), sin(a + b), ... of two arguments whose (sin, cos) pairs exist anyway follow
+    # from the angle-sum identities: two multiplies and an add instead of another fp64
+    # range reduction + polynomial (the dominant cost of a rollout step on the GPU)
+    pair_of = {a: (s_, c_) for (_, a, s_, c_) in pairs}
+
+    def split_sum(arg):
+        if not isinstance(arg, sp.Add) or len(arg.args) != 2:
+            return None
+        p_, q_ = arg.args
+        for x_, y_, sign in ((p_, q_, 1), (p_, -q_, -1), (q_, -p_, -1), (-p_, q_, None)):
+            if sign is None:
+                continue
+            if x_ in pair_of and y_ in pair_of:
+                return x_, y_, sign              # arg == x_ + sign * y_
+        return None
+
+    for e in exprs:
+        for f in list(e.atoms(sp.sin)) + list(e.atoms(sp.cos)):
+            if f in repl:
+                continue
+            sp_ = split_sum(f.args[0])
+            if sp_ is None:
+                continue
+            x_, y_, sign = sp_
+            (sx, cx), (sy, cy) = pair_of[x_], pair_of[y_]
+            if isinstance(f, sp.cos):
+                repl[f] = cx * cy - sign * sx * sy
+            else:
+                repl[f] = sx * cy + sign * cx * sy
+
+    new_subs = []
+    emitted = set()
+
+    def ready(arg, defined):
+        return all((not str(fs).startswith("w")) or fs in defined for fs in arg.free_symbols)
+
+    defined = set()
+    pending = list(pairs)
+
+    def flush():
+        for pr in list(pending):
+            pid, a, s_sym, c_sym = pr
+            if ready(a, defined):
+                new_subs.append((pid, a))
+                pending.remove(pr)
+                defined.update((s_sym, c_sym))
+
+    flush()
+    for sym, e in subs:
+        e2 = e.xreplace(repl)
+        if e2 in (v for v in repl.values()):
+            # the temporary was exactly sin(a) or cos(a): keep its name as an alias of the fused value
+            new_subs.append((sym, e2))
+        else:
+            new_subs.append((sym, e2))
+        defined.add(sym)
+        flush()
+    assert not pending, "sincos fusion: argument never became available"
+    reduced[:] = [e.xreplace(repl) for e in reduced]
+    return new_subs, fused
+
+
 def _emit_routine(name, m, cfg, printer):
     lines = [f"TPL_HD inline void {name}({_signature(name)}) {{"]
     # keep every argument "used" so -Wall stays quiet for trivial routines
@@ -240,8 +337,13 @@ def _emit_routine(name, m, cfg, printer):
     if n:
         flat = [_vectorise(sp.sympify(e), cfg) for e in m]               # row-major
         subs, reduced = sp.cse(flat, symbols=sp.numbered_symbols("w"))
+        subs, fused = _fuse_sincos(subs, reduced)
         for sym, e in subs:
-            lines.append(f"    const double {sym} = {printer.doprint(e)};")
+            if sym in fused:                                             # (sin, cos) of one argument
+                s_sym, c_sym = fused[sym]
+                lines.append(f"    double {s_sym}, {c_sym}; tpl_sincos({printer.doprint(e)}, &{s_sym}, &{c_sym});")
+            else:
+                lines.append(f"    const double {sym} = {printer.doprint(e)};")
         for i, e in enumerate(reduced):
             lines.append(f"    out[{i}*os] = {printer.doprint(e)};")
     lines.append("}")
