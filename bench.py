@@ -174,11 +174,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = dp_cpu_baseline(p, ep, path, occ)
         if not args.no_secondary and world == 1:
-            try:
-                from tpl_amd.optim import bench_ilqr
-                out["secondary"] = bench_ilqr.run(local_rank)
-            except ImportError:
-                pass
+            from tpl_amd import latency
+            from tpl_amd.optim import bench_ilqr
+            out["secondary"] = {"batched_ilqr": bench_ilqr.run(local_rank),
+                                "plan_latency": latency.run(local_rank)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

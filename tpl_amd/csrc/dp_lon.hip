@@ -149,28 +149,45 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
                            const float* __restrict__ pre_sdist,   // this stage, [s_steps]
                            const double* __restrict__ pre_prog,   // [s_steps]
                            TplDpLonParams p, int s_pad, int rows_per_block, int nblocks,
-                           float rcp_path_step, double rcp_path_step_d, double rcp_s_range_d)
+                           float rcp_path_step, double rcp_path_step_d, double rcp_s_range_d,
+                           int tile_v, int tile_a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so
-    // give each XCD one contiguous chunk of rows; neighbouring rows read
-    // overlapping next-stage rows and meet in that XCD's L2.  Placement only
-    // affects speed.
-    const int chunk = gridDim.x >> 3;
-    const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (lb >= nblocks) return;
-
-    const int S = p.s_steps, V = p.v_steps;
-    const int nrows = V * p.a_steps;
+    // Traversal order (speed only; any order gives the same table).  Blocks b and b+8 share an
+    // XCD and its 4 MiB L2 (round-robin dispatch).  Action k of row (v,a) reads next-stage rows
+    // around (v + a dt + j_k dt^2/2, a + j_k dt): the a' windows of the nine actions are ~A/7 rows
+    // apart and slide by ONE row per a-step, the v' window by a fraction of a row.  So
+    //  * each XCD owns a contiguous range of v indices,
+    //  * inside it, strips of `tile_v` v-indices are walked from a = 0 upwards, a-tiles of
+    //    `tile_a` rows at a time (v fastest inside a tile):
+    // the rows one a-tile fetched for action k+1 are the rows the next a-tile needs for action
+    // k, and a strip's working set (9 windows x (tile_a+1) a-rows x (tile_v+3) v-rows) stays
+    // inside the L2.  The first version walked v fastest across the whole v axis: 440 MB of L2
+    // misses per 256x128x64 sweep against 33.5 MB of table.
+    const int S = p.s_steps, V = p.v_steps, A = p.a_steps;
+    const int nrows = V * A;
     const int tid = threadIdx.x;
     const int rib = tid / s_pad;
     const int is = tid - rib * s_pad;
-    const int row = __builtin_amdgcn_readfirstlane(lb * rows_per_block + rib);
-    const bool row_ok = row < nrows;
+    const int xcd = blockIdx.x & 7;
+    const int v_lo = (xcd * V) >> 3, v_hi = ((xcd + 1) * V) >> 3;      // this XCD's v range
+    const int vx = v_hi - v_lo;
+    const int q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * rows_per_block + rib);   // position in the XCD's order
+    const bool row_ok = q < vx * A;
+    int ia = 0, iv = 0;
+    if (row_ok) {
+        const int full = vx / tile_v;                                   // strips of full width
+        int strip = q / (A * tile_v), w = tile_v, rem = q - strip * (A * tile_v);
+        if (strip >= full) { strip = full; w = vx - full * tile_v; rem = q - full * (A * tile_v); }
+        const int tile = rem / (tile_a * w);
+        const int r = rem - tile * (tile_a * w);
+        ia = tile * tile_a + r / w;
+        iv = v_lo + strip * tile_v + (r - (r / w) * w);
+    }
+    const int row = ia * V + iv;
     const bool active = row_ok && is < S;
-    const int ia = row / V;
-    const int iv = row - ia * V;
+    (void)nblocks; (void)nrows;
 
     const float s = p.s_min + (float)is * p._s_step_size;
     const float v = p.v_min + (float)iv * p._v_step_size;
@@ -529,6 +546,7 @@ struct tplhip_dp_lon {
 
     // launch geometry of k_backward
     int s_pad = 0, rows_per_block = 0, nblocks = 0, grid = 0, kchunk = 0;
+    int tile_v = 8, tile_a = 8;          // traversal tiles, see k_backward
     size_t lds_bytes = 0;
 
     // cheap division forms, only used when k_verify_div proved them exact (see k_backward)
@@ -615,7 +633,7 @@ void launch_backward(tplhip_dp_lon* h, int idx_t, int nx)
                        h->d_acts, h->d_path,
                        h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
                        h->d_pre_prog, h->params, h->s_pad, h->rows_per_block, h->nblocks,
-                       h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d);
+                       h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a);
 }
 
 template <int DIVMODE>
@@ -906,12 +924,32 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     h->s_pad = ((p.s_steps + 63) / 64) * 64;
     h->rows_per_block = std::max(1, 256 / h->s_pad);
     h->nblocks = (nrows + h->rows_per_block - 1) / h->rows_per_block;
-    h->grid = ((h->nblocks + 7) / 8) * 8;
+    {
+        // every XCD gets the blocks of its own v range (ranges differ by at most one v index)
+        int max_rows = 0;
+        for (int x = 0; x < 8; ++x)
+            max_rows = std::max(max_rows, ((((x + 1) * p.v_steps) >> 3) - ((x * p.v_steps) >> 3)) * p.a_steps);
+        h->grid = 8 * ((max_rows + h->rows_per_block - 1) / h->rows_per_block);
+        h->tile_v = 8; h->tile_a = 8;
+        if (const char* ov = std::getenv("TPLHIP_TILE_V")) h->tile_v = std::max(1, std::atoi(ov));
+        if (const char* ov = std::getenv("TPLHIP_TILE_A")) h->tile_a = std::max(1, std::atoi(ov));
+    }
     const size_t threads = (size_t)h->s_pad * h->rows_per_block;
     const size_t path_lds = sizeof(float) * (size_t)p.path_steps;
     const size_t lds_max = 64 * 1024;                       // keep >= 2 workgroups per CU
-    h->kchunk = 9;
-    if (threads * 16 * 9 + path_lds > lds_max) h->kchunk = 3;
+    // Actions blended into LDS per barrier.  With the L2-friendly traversal the sweep is bound by
+    // VALU issue and by how well memory latency hides under it: 1 action per pass keeps the LDS
+    // block at 4 KB and the kernel at ~50 VGPRs (8 waves per SIMD) and wins everywhere it was
+    // measured (256x128x64: 55.0 us vs 56.2 (3) vs 61.8 (9); 512x256x128: 526 / 555 / 575 us).
+    // A grid that fits the chip in one residency round (config 2, the reference default grid)
+    // has nothing to overlap with and prefers fewer barriers: 3 per pass (10.7 vs 12.0 us).
+    {
+        int n_cu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        const size_t waves = (size_t)h->nblocks * (threads / 64);
+        h->kchunk = (waves <= (size_t)n_cu * 4 * 8) ? 3 : 1;
+    }
     if (threads * 16 * 3 + path_lds > lds_max) h->kchunk = 1;
     if (const char* ov = std::getenv("TPLHIP_KCHUNK")) {       // tuning override: 9, 3 or 1
         const int k = std::atoi(ov);
@@ -1080,9 +1118,9 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
     if (!h || !buf || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
     std::snprintf(buf, (size_t)n,
                   "{\"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
-                  "\"div_mode\": %d, \"div_verified_up_to\": %g}",
+                  "\"div_mode\": %d, \"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d}",
                   h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
-                  h->div_mode, (double)h->verified_xmax);
+                  h->div_mode, (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid);
     return TPLHIP_OK;
 }
 

@@ -1,0 +1,71 @@
+"""Plan-latency measurement through the drop-in surface (BASELINE configs[0],
+"p50 plan latency on default scenario"): host buffers in, host buffers out, one
+vehicle, exactly how tpl's planner / controller plugins would call the engines.
+
+* MPC: a closed loop of the kinematic single-track ego model (the generated
+  model's own ``dynamics``) under ``trajectory_tracking_mpc`` with N = 20
+  (the template's default horizon, optim.c:1900), tracking a straight 8 m/s plan,
+  one ``Optim.update()`` per 10 ms tick like tplsim's fixed_time_step.
+* DP: ``DynProgLonPlanner.update`` on the reference's default grid
+  (201 x 37 x 20, 10 stages; data/params/planning/default/state.json).
+"""
+import time
+
+import numpy as np
+
+
+def mpc_closed_loop(device=0, ticks=300, horizon=20):
+    from .optim import bench_ilqr, genopt, optimizers as o
+    make = genopt.build(o.config_trajectory_tracking_mpc(), "trajectory_tracking_mpc")
+    opt = make(device=device)
+    opt.horizon = horizon
+    x = np.array([0.0, 0.4, 0.05, 0.0, 6.0, 0.0, 0.0])
+    bench_ilqr._configure(opt, x)
+    opt.min_rel_cost_change = 1e-6
+    opt.horizon = horizon
+    lat = []
+    for k in range(ticks):
+        opt.x[0] = x
+        t0 = time.perf_counter()
+        opt.update()
+        lat.append((time.perf_counter() - t0) * 1e3)
+        # apply the first control for one tick of 10 ms, then warm-start like the controller does
+        x = opt.dynamics(x, opt.u[0], 0, 0.01)
+        x[5] = max(0.0, x[0])                      # arc length of the projection on the straight plan
+        opt.shift(0)
+    lat = np.array(lat[10:])
+    return {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+            "mean_iterations": float(np.mean(opt.iterations)), "ticks": int(len(lat)),
+            "what": f"Optim.update() of trajectory_tracking_mpc, batch 1, N={horizon}, HEUN, <=20 iterations, "
+                    "host mirrors in and out (H2D + kernel + D2H)"}
+
+
+def dp_default_plan(device=0, plans=60):
+    import tpl_amd
+    from . import scenarios as sc
+    S, V, A, T = sc.GRIDS["default"]
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    env = tpl_amd.DynProgEnvironment(device)
+    env.reinit_buffers(ep)
+    env.set_occ_map(sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC))
+    dp = tpl_amd.DynProgLonPlanner(device)
+    lat = []
+    init = sc.initial_state(0.0, 8.0, 0.0)
+    for k in range(plans):
+        p.dt_start = 1.0 - 0.01 * (k % 50)          # the caller changes dt_start every cycle
+        ep.dt_start = p.dt_start
+        t0 = time.perf_counter()
+        env.reinit_buffers(ep)
+        dp.reinit_buffers(p)
+        dp.update(init, path, env)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = np.array(lat[5:])
+    return {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "plans": int(len(lat)),
+            "what": "reinit_buffers + DynProgLonPlanner.update on the reference default grid 201x37x20, 10 stages, "
+                    "host path in, host trajectory out"}
+
+
+def run(device=0):
+    return {"mpc_closed_loop": mpc_closed_loop(device), "dp_default_plan": dp_default_plan(device)}
