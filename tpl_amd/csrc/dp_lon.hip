@@ -141,7 +141,7 @@ __global__ void k_stage_prelude(float* __restrict__ pre_vmax, float* __restrict_
 //   0  IEEE division for both
 //   1  station range: (float)((double)x * rcp_d);  path step: x*r with one residual correction
 //   2  both through the double product
-template <bool TERMINAL, int KCHUNK, int DIVMODE>
+template <bool TERMINAL, int KCHUNK, int DIVMODE, bool USE_BUF>
 __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__ out,
                            const ActDesc* __restrict__ acts,
                            const float* __restrict__ path,
@@ -187,7 +187,7 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
     }
     const int row = ia * V + iv;
     const bool active = row_ok && is < S;
-    (void)nblocks; (void)nrows;
+    (void)nblocks;
 
     const float s = p.s_min + (float)is * p._s_step_size;
     const float v = p.v_min + (float)iv * p._v_step_size;
@@ -221,6 +221,9 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
 
     float4* R = reinterpret_cast<float4*>(smem);
     float* pv = reinterpret_cast<float*>(smem + (size_t)KCHUNK * blockDim.x * sizeof(float4));
+    // (USE_BUF: the host checked that one stage table is addressable with 32-bit byte offsets)
+    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float4*>(next), 0, USE_BUF ? (int)((size_t)nrows * S * sizeof(float4)) : 0, 0x00020000);
     for (int i = tid; i < p.path_steps; i += blockDim.x) pv[i] = path[i * 7 + 5];
 
     const float s_range = p.s_max - p.s_min;
@@ -238,10 +241,23 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
                 const ActDesc* d = acts + (size_t)row * N_BWD + k;
                 // (clamped successors name the same row twice; those repeats hit L1 -- branching
                 // around them serialises the loads and more than doubles the sweep time)
-                const float4 p00 = (next + (size_t)d->r00 * S)[is];
-                const float4 p10 = (next + (size_t)d->r10 * S)[is];
-                const float4 p01 = (next + (size_t)d->r01 * S)[is];
-                const float4 p11 = (next + (size_t)d->r11 * S)[is];
+                float4 p00, p10, p01, p11;
+                if (USE_BUF) {
+                    // buffer loads: 128-bit descriptor of the whole next-stage table, row base as
+                    // SCALAR offset, station as one 32-bit lane offset shared by all 36 loads of the
+                    // cell -- no per-load 64-bit address arithmetic on the VALU
+                    const unsigned voff = (unsigned)is * 16u;
+                    const unsigned row_bytes = (unsigned)S * 16u;
+                    p00 = buf_load4(next_rsrc, voff, (unsigned)d->r00 * row_bytes);
+                    p10 = buf_load4(next_rsrc, voff, (unsigned)d->r10 * row_bytes);
+                    p01 = buf_load4(next_rsrc, voff, (unsigned)d->r01 * row_bytes);
+                    p11 = buf_load4(next_rsrc, voff, (unsigned)d->r11 * row_bytes);
+                } else {
+                    p00 = (next + (size_t)d->r00 * S)[is];
+                    p10 = (next + (size_t)d->r10 * S)[is];
+                    p01 = (next + (size_t)d->r01 * S)[is];
+                    p11 = (next + (size_t)d->r11 * S)[is];
+                }
                 const float wa = d->wa, iwa = d->iwa, wv = d->wv, iwv = d->iwv;
                 const float4 b0 = lerp4w(p00, p10, wa, iwa);
                 const float4 b1 = lerp4w(p01, p11, wa, iwa);
@@ -621,12 +637,12 @@ int check_env(tplhip_dp_lon* h, tplhip_dp_env* env)
     return TPLHIP_OK;
 }
 
-template <bool TERMINAL, int KCHUNK, int DIVMODE>
-void launch_backward(tplhip_dp_lon* h, int idx_t, int nx)
+template <bool TERMINAL, int KCHUNK, int DIVMODE, bool USE_BUF>
+void launch_backward_b(tplhip_dp_lon* h, int idx_t, int nx)
 {
     const size_t S = (size_t)h->params.s_steps;
     const size_t lds = TERMINAL ? 0 : h->lds_bytes;
-    hipLaunchKernelGGL((k_backward<TERMINAL, KCHUNK, DIVMODE>), dim3(h->grid), dim3(h->s_pad * h->rows_per_block),
+    hipLaunchKernelGGL((k_backward<TERMINAL, KCHUNK, DIVMODE, USE_BUF>), dim3(h->grid), dim3(h->s_pad * h->rows_per_block),
                        lds, h->stream,
                        h->d_tables + (size_t)nx * h->table_cells,
                        h->d_tables + (size_t)idx_t * h->table_cells,
@@ -636,11 +652,21 @@ void launch_backward(tplhip_dp_lon* h, int idx_t, int nx)
                        h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a);
 }
 
+template <bool TERMINAL, int KCHUNK, int DIVMODE>
+void launch_backward(tplhip_dp_lon* h, int idx_t, int nx)
+{
+    // buffer loads need 32-bit byte offsets inside one stage table
+    if (!TERMINAL && h->table_cells * sizeof(float4) < 0xffffffffull && !std::getenv("TPLHIP_NO_BUFLOAD"))
+        launch_backward_b<TERMINAL, KCHUNK, DIVMODE, true>(h, idx_t, nx);
+    else
+        launch_backward_b<TERMINAL, KCHUNK, DIVMODE, false>(h, idx_t, nx);
+}
+
 template <int DIVMODE>
 void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
 {
     if (terminal) {
-        launch_backward<true, 9, 0>(h, i, nx);                       // rule R4 (no division in it)
+        launch_backward<true, 1, 0>(h, i, nx);                       // rule R4 (no division in it)
     } else if (h->kchunk == 9) {
         launch_backward<false, 9, DIVMODE>(h, i, nx);
     } else if (h->kchunk == 3) {

@@ -51,6 +51,14 @@ __device__ __forceinline__ float4 lerp4(float4 p, float4 q, float w)
     return r;
 }
 
+// 16-byte buffer load: descriptor + 32-bit lane offset + scalar offset
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset)
+{
+    const v4f32 r = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voffset, (int)soffset, 0));
+    return make_float4(r.x, r.y, r.z, r.w);
+}
+
 // lerp4 with the complement 1-w supplied (wave-uniform weights keep it in an SGPR)
 __device__ __forceinline__ float4 lerp4w(float4 p, float4 q, float w, float iw)
 {
