@@ -171,6 +171,16 @@ def main():
                 "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
             },
         }
+        # L2<->fabric bytes per sweep launch from the committed PMC pass of this kernel (rocprofv3
+        # cannot run inside the timed process; see profiles/README.md for the command)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_dp_traffic.json")) as fd:
+                tr = json.load(fd).get(f"{p.s_steps}x{p.v_steps}x{p.a_steps}")
+            if tr:
+                out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/r01_dp_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+        except OSError:
+            pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = dp_cpu_baseline(p, ep, path, occ)
         if not args.no_secondary and world == 1:
