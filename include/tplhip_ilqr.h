@@ -36,6 +36,7 @@ extern "C" {
 #define TPLHIP_EDEVICE  -2
 #define TPLHIP_ESTATE   -3
 #endif
+#define TPLHIP_EASSERT  -4   /* a shape check of the reference template failed (reference: AssertionError, optim.c:15-44, 1195-1200) */
 
 #define TPLHIP_ILQR_H_MAX 300   /* optim.c:49: stages are clamped to [1, H_MAX-1] (:1726-1734) */
 

@@ -36,6 +36,21 @@ def reference_factory(model):
         cfg = genopt.Config([x, y, heading], [v, steer], [x_trg, y_trg, w_e_pos, w_e_v, w_steer],
                             sp.Matrix([v * sp.cos(heading), v * sp.sin(heading), v * steer]),
                             miss + w_e_v * v**2 + w_steer * steer**2, miss, use_cache=True)
+    elif model == "builtin_probe":
+        # same problem statement as tpl_amd.optim.optimizers.config_builtin_probe, written with the
+        # reference's own symext classes (its generator keys on their types)
+        import sympy as sp
+        from tpl.optim import symext as rspx
+        t, dt, x, y, u = sp.symbols("t dt x y u")
+        w_f, w_u, x0g, y0g, dxg, dyg, loop_len, loop_dx = sp.symbols("w_f w_u x0g y0g dxg dyg loop_len loop_dx")
+        field, loop_xs, loop_vals, steps, gains = (rspx.ArraySymbol(n) for n in "field loop_xs loop_vals steps gains".split())
+        f_xy = rspx.blerp(x0g, y0g, dxg, dyg, x, y, field)
+        drift = rspx.lerp_wrap(loop_len, loop_dx, x, loop_xs, loop_vals)
+        gain = rspx.box_interp(dt, t * dt, steps) * rspx.get_array_value(gains, t)
+        cfg = genopt.Config([x, y], [u],
+                            [w_f, w_u, x0g, y0g, dxg, dyg, loop_len, loop_dx, field, loop_xs, loop_vals, steps, gains],
+                            sp.Matrix([sp.cos(y) + drift, gain * u]), w_f * f_xy**2 + w_u * u**2,
+                            end_costs=w_f * f_xy**2, constraints=[y - 2.0], use_cache=True)
     else:
         cfg = getattr(ref_opts, "config_" + model)()
     cfg.output_dir = "/tmp/genopt_oracle/"
@@ -44,7 +59,10 @@ def reference_factory(model):
 
 def main():
     factories = {}
+    only = set(sys.argv[1:])
     for name, (model, setup, kw, shift) in cases.CASES.items():
+        if only and name not in only:
+            continue
         if model not in factories:
             factories[model] = reference_factory(model)
         opt = factories[model]()

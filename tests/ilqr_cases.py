@@ -200,6 +200,28 @@ def simple_vehicle(opt, seed=0, first_order=False):
     opt.u[:, 1] = 0.0
 
 
+def builtin_probe(opt, seed=0):
+    """blerp / lerp_wrap / box_interp / get_array_value (see optimizers.config_builtin_probe)."""
+    rng = np.random.default_rng(700 + seed)
+    opt.integrator_type = opt.HEUN
+    opt.step = 0.1
+    opt.horizon = 25
+    opt.max_iterations = 6
+    opt.lg_mult_limit = 5.0
+    opt.barrier_weight[:] = 50.0
+    opt.lagrange_multiplier[:] = 0.0
+    opt.u_min[:] = -2.0
+    opt.u_max[:] = 2.0
+    gy, gx = np.meshgrid(np.linspace(-3, 3, 9), np.linspace(-2, 6, 13), indexing="ij")   # [rows = y][cols = x]
+    field = 0.3 * (gx - 3.0) ** 2 + 0.5 * (gy - 1.0) ** 2 + 0.2 * np.sin(gx * gy)
+    loop_xs = np.arange(8) * 0.5
+    _set_params(opt, w_f=1.0, w_u=0.1, x0g=-2.0, y0g=-3.0, dxg=8.0 / 12, dyg=6.0 / 8, loop_len=4.5, loop_dx=0.5,
+                field=field, loop_xs=loop_xs, loop_vals=0.2 * np.cos(loop_xs * 1.3),
+                steps=np.array([1.0, 0.5, 1.5, 1.0]), gains=np.linspace(1.0, 2.0, 26))
+    opt.x[0] = np.array([rng.uniform(-1.0, 0.0), rng.uniform(-1.0, 1.0)])
+    opt.u[:] = 0.1
+
+
 # case name -> (model name, setup function, kwargs, warm-start shift between update 1 and 2)
 CASES = {
     "mpc_straight_s0": ("trajectory_tracking_mpc", mpc, dict(seed=0), 1),
@@ -214,6 +236,7 @@ CASES = {
     "velocity_time": ("velocity_profile_time", velocity_time, dict(seed=0), 1),
     "simple_vehicle": ("simple_vehicle", simple_vehicle, dict(seed=0), 0),
     "simple_vehicle_first_order": ("simple_vehicle", simple_vehicle, dict(seed=1, first_order=True), 0),
+    "builtin_probe": ("builtin_probe", builtin_probe, dict(seed=0), 1),
 }
 
 ARRAY_FIELDS = ["int_step", "x", "u", "next_int_step", "next_x", "next_u", "prev_x", "prev_u", "prev_k",

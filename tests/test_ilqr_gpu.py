@@ -131,3 +131,52 @@ def test_deepcopy_and_getstate():
     twin.update()
     opt.update()
     assert np.array_equal(twin.x, opt.x)
+
+
+def test_array_shape_assertions_like_the_template():
+    """check(ARR.ndim == 1) inside the builtins -> AssertionError after update() (optim.c:375-392, 1195-1200)."""
+    opt = _factory("lateral_profile")()
+    cases.lateral(opt, seed=0)
+    opt.params.k_ref = np.zeros((4, 4))                       # lerp over a 2-D array
+    with pytest.raises(AssertionError, match="k_ref.ndim == 1"):
+        opt.update()
+    fresh = _factory("lateral_profile")()                      # array parameters never set: ndim 0
+    with pytest.raises(AssertionError, match="ndim == 1"):
+        fresh.update()
+    probe = _factory("builtin_probe")()
+    cases.builtin_probe(probe, seed=0)
+    probe.params.loop_vals = np.zeros(5)                       # lerp_wrap: xs and values differ in length
+    with pytest.raises(AssertionError, match="dims"):
+        probe.update()
+
+
+def test_long_horizon_and_per_problem_parameters():
+    """T = 299 (the template's capacity) runs with the trajectory mirrors outside LDS;
+    per-problem array parameters give every problem of a batch its own reference course."""
+    make = _factory("lateral_profile")
+    opt = make()
+    cases.lateral(opt, seed=0, horizon=299)
+    ref = OI.OracleOptim("lateral_profile")
+    cases.lateral(ref, seed=0, horizon=299)
+    opt.update()
+    ref.update()
+    assert cases.scaled_err(opt.x, ref.x) < 1e-6 and opt.iterations == ref.iterations
+    B = 3
+    batch = make(batch=B, horizon=60)
+    cases.lateral(batch, seed=0, horizon=60)
+    s = np.arange(60) * 0.5
+    lowers = np.stack([-2.0 + (1.5 + 0.5 * b) * np.exp(-((s - 12.0 - 3 * b) / 4.0) ** 2) for b in range(B)])
+    batch.set_param_per_problem("d_lower_constr", lowers)
+    batch.x[...] = 0.0                      # (the set-up function addresses an unbatched object)
+    batch.x[:, 0, 0] = 0.1
+    batch.u[...] = 0.0
+    batch.update()
+    for b in range(B):
+        one = OI.OracleOptim("lateral_profile")
+        cases.lateral(one, seed=0, horizon=60)
+        one.params.d_lower_constr = lowers[b]
+        one.x[...] = 0.0
+        one.x[0, 0] = 0.1
+        one.update()
+        assert cases.scaled_err(batch.x[b], one.x) < 1e-6, b
+        assert int(batch.iterations[b]) == one.iterations

@@ -1075,8 +1075,30 @@ int fetch_field(tplhip_ilqr* h, int f)
     return TPLHIP_OK;
 }
 
+// The reference template asserts the shapes of array parameters inside its builtins
+// (check(ARR.ndim == 1) ..., optim.c:375-486) and surfaces the first failure as an
+// AssertionError after update() (:1195-1200).  Same conditions, checked before the launch.
+int check_param_shapes(tplhip_ilqr* h)
+{
+    static const int nd[][2] = TPL_NDIM_CHECKS;
+    static const int same[][2] = TPL_SAME_LEN_CHECKS;
+    for (int k = 0; nd[k][0] >= 0; ++k) {
+        const ArrayParam& a = h->parray[nd[k][0]];
+        if (a.ndim != nd[k][1])
+            return fail(TPLHIP_EASSERT, "params.%s.ndim == %d", g_params[nd[k][0]].name, nd[k][1]);
+    }
+    for (int k = 0; same[k][0] >= 0; ++k) {
+        const ArrayParam& a = h->parray[same[k][0]];
+        const ArrayParam& b = h->parray[same[k][1]];
+        if (a.dims[0] != b.dims[0])
+            return fail(TPLHIP_EASSERT, "params.%s.dims[0] == params.%s.dims[0]", g_params[same[k][1]].name, g_params[same[k][0]].name);
+    }
+    return TPLHIP_OK;
+}
+
 int check_settings(tplhip_ilqr* h)
 {
+    if (int rc = check_param_shapes(h)) return rc;
     for (int b = 0; b < h->batch; ++b) {
         double* sc = h->scalars.data() + (size_t)b * TPL_S_COUNT;
         const int T = (int)sc[TPL_S_HORIZON];

@@ -350,6 +350,30 @@ def _emit_routine(name, m, cfg, printer):
     return "\n".join(lines)
 
 
+def _array_checks(cfg, routines):
+    """Shape requirements the reference template asserts at run time (the ``check(ARR.ndim == 1)``
+    macros around its builtins, optim.c:375-486): (param index, required ndim) pairs and pairs of
+    parameters whose first dimensions must agree (lerp_wrap)."""
+    index = {p: i for i, p in enumerate(cfg.param_symbols)}
+    ndim, same = {}, set()
+    for _, m in routines:
+        for f in m.atoms(sp.Function):
+            fname = type(f).__name__
+            arrs = [a for a in f.args if isinstance(a, spx.ArraySymbol)]
+            if fname in ("lerp", "lerp_angle", "box_interp"):
+                for a in arrs:
+                    ndim[index[a]] = 1
+            elif fname == "blerp":
+                for a in arrs:
+                    ndim[index[a]] = 2
+            elif fname == "lerp_wrap":
+                for a in arrs:
+                    ndim[index[a]] = 1
+                if len(arrs) == 2:
+                    same.add((index[arrs[0]], index[arrs[1]]))
+    return sorted(ndim.items()), sorted(same)
+
+
 def emit_model(cfg, name):
     """Text of model.inc for ``cfg``."""
     printer = _Printer()
@@ -380,6 +404,10 @@ def emit_model(cfg, name):
         entries.append(f"    TPL_PARAM_{kind}({p.name})")
     out.append("#define TPL_PARAM_LIST \\\n" + " \\\n".join(entries) if entries else "#define TPL_PARAM_LIST")
     out.append(f"#define TPL_N_PARAMS {len(cfg.param_symbols)}")
+    nd, same = _array_checks(cfg, routines)
+    out.append("// run-time shape requirements of the builtins: {param, ndim} and {param, param} with equal dims[0]")
+    out.append("#define TPL_NDIM_CHECKS " + ("{" + ", ".join(f"{{{i}, {n}}}" for i, n in nd) + ", {-1, 0}}" if nd else "{{-1, 0}}"))
+    out.append("#define TPL_SAME_LEN_CHECKS " + ("{" + ", ".join(f"{{{a}, {b}}}" for a, b in same) + ", {-1, -1}}" if same else "{{-1, -1}}"))
     out.append("")
     for rname, m in routines:
         out.append(_emit_routine(rname, m, cfg, printer))

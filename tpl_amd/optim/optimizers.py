@@ -265,6 +265,27 @@ def config_simple_vehicle():
         name="simple_vehicle")
 
 
+def config_builtin_probe():
+    """Not a tpl problem: a small OCP that exercises the interpolation builtins no shipped
+    problem uses (``blerp``, ``lerp_wrap``) next to ``box_interp`` / ``get_array_value``, so
+    their semantics (optim.c:357-373, 413-486) are pinned by a golden vector as well."""
+    t, dt = _symbols("t dt")
+    x, y, u = _symbols("x y u")
+    w_f, w_u, x0g, y0g, dxg, dyg, loop_len, loop_dx = _symbols("w_f w_u x0g y0g dxg dyg loop_len loop_dx")
+    field, loop_xs, loop_vals, steps, gains = A("field"), A("loop_xs"), A("loop_vals"), A("steps"), A("gains")
+    f_xy = spx.blerp(x0g, y0g, dxg, dyg, x, y, field)                  # potential field over (x, y)
+    drift = spx.lerp_wrap(loop_len, loop_dx, x, loop_xs, loop_vals)    # periodic drift along x
+    gain = spx.box_interp(dt, t * dt, steps) * spx.get_array_value(gains, t)
+    dynamics = sp.Matrix([sp.cos(y) + drift, gain * u])
+    costs = w_f * f_xy**2 + w_u * u**2
+    end_costs = w_f * f_xy**2
+    return genopt.Config(
+        [x, y], [u],
+        [w_f, w_u, x0g, y0g, dxg, dyg, loop_len, loop_dx, field, loop_xs, loop_vals, steps, gains],
+        dynamics, costs, end_costs=end_costs, constraints=[y - 2.0],
+        name="builtin_probe")
+
+
 # the six problems the reference builds at application start (optimizers.py:562-569)
 CONFIG_FUNCTIONS = [
     config_trajectory_tracking_mpc,
@@ -275,7 +296,7 @@ CONFIG_FUNCTIONS = [
     config_ref_line_smoother_dk,
 ]
 # additionally pre-built here: the seventh definition and the smoke model
-EXTRA_CONFIG_FUNCTIONS = [config_velocity_profile_time, config_simple_vehicle]
+EXTRA_CONFIG_FUNCTIONS = [config_velocity_profile_time, config_simple_vehicle, config_builtin_probe]
 
 
 def _name_of(fn):

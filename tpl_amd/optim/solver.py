@@ -96,6 +96,8 @@ def _check(lib, rc):
     msg = (lib.tplhip_ilqr_last_error() or b"").decode("utf8", "replace")
     if rc == -1:
         raise ValueError(msg)
+    if rc == -4:
+        raise AssertionError(msg)        # the template's check() failures (optim.c:1195-1200)
     raise RuntimeError(msg)
 
 
