@@ -54,7 +54,8 @@ struct alignas(16) ActDesc {
     float iwa, iwv;     // 1 - wa, 1 - wv (exact: the weights are multiples of 1/256)
     float tn_v;         // successor velocity          lon_planner.cu:245
     int r00, r10, r01, r11;   // next-stage rows (a*V + v) of the corners (a0,v0) (a1,v0) (a0,v1) (a1,v1)
-    int pad[3];
+    int pad;
+    double tn_v_d;      // (double)tn_v, for the double-precision speed-limit term (:114-118)
 };
 static_assert(sizeof(ActDesc) == 80, "ActDesc must be 80 bytes");
 
@@ -97,7 +98,8 @@ __global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p)
     d.r10 = ta.i1 * p.v_steps + tv.i0;
     d.r01 = ta.i0 * p.v_steps + tv.i1;
     d.r11 = ta.i1 * p.v_steps + tv.i1;
-    d.pad[0] = d.pad[1] = d.pad[2] = 0;
+    d.pad = 0;
+    d.tn_v_d = (double)tn.v;
     acts[idx] = d;
 }
 
@@ -304,7 +306,7 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
                 c += d->wj_cost;
                 // lon_planner.cu:114-118 compares and subtracts in double; float -> double is
                 // exact and order preserving, so the test itself can stay in float
-                if (d->tn_v > vmn) g = (float)((double)g + ((double)d->tn_v - (double)vmn));
+                if (d->tn_v > vmn) g = (float)((double)g + (d->tn_v_d - (double)vmn));
                 const float s_change = tn_s - s;
                 if (s_change > s_dist) {
                     g += s_change - s_dist;

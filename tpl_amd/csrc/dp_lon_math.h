@@ -126,16 +126,19 @@ __device__ __forceinline__ float fast_div(float x, float c, float r)
 }
 
 // path_tap with the quotient distance / path_step_size already formed.
-// ceil(alpha) = floor(alpha) + (alpha > floor(alpha)); both are clamped like common.cuh:124-125.
+// i0 = clamp((int)floor(a), 0, n-1), i1 = clamp((int)ceil(a), 0, n-1) (common.cuh:124-125), with
+// ceil(a) = floor(a) + (a > floor(a)).  The clamps are done on the (integral) floats -- exact
+// below 2^24 -- so (float)i0 needs no conversion back and each clamp is one v_med3_f32.
 __device__ __forceinline__ PathTap path_tap_q(float alpha, int path_steps)
 {
     PathTap t;
+    const float top = (float)(path_steps - 1);
     const float fl = floorf(alpha);
-    const float lo = fminf(fmaxf(fl, -1.0f), (float)path_steps);   // keeps the float->int conversion defined
-    const int i = (int)lo;
-    t.i0 = clampi(i, 0, path_steps - 1);
-    t.i1 = clampi(i + (alpha > fl ? 1 : 0), 0, path_steps - 1);
-    alpha -= (float)t.i0;
+    const float f0 = __builtin_amdgcn_fmed3f(fl, 0.0f, top);
+    const float f1 = __builtin_amdgcn_fmed3f(fl + (alpha > fl ? 1.0f : 0.0f), 0.0f, top);
+    t.i0 = (int)f0;
+    t.i1 = (int)f1;
+    alpha -= f0;
     t.a = alpha;
     t.ia = 1.0f - alpha;
     return t;
