@@ -4,7 +4,7 @@
 // of env.cu) of the reference behind the C-ABI of include/tplhip.h.  This is a
 // re-design, not a translation:
 //
-//  * value tables are plain HBM arrays float4[t][a][v][s] (s fastest); the
+//  * value tables are plain HBM arrays Node[t][a][v][s] (12-byte cells, s fastest); the
 //    tex3D hardware filter of the reference is the software filter of
 //    dp_lon_math.h (rules R2/R3);
 //  * one backward stage = one launch of k_backward.  A workgroup owns whole
@@ -144,7 +144,7 @@ __global__ void k_stage_prelude(float* __restrict__ pre_vmax, float* __restrict_
 //   1  station range: (float)((double)x * rcp_d);  path step: x*r with one residual correction
 //   2  both through the double product
 template <bool TERMINAL, int KCHUNK, int DIVMODE, bool USE_BUF>
-__global__ void k_backward(const float4* __restrict__ next, float4* __restrict__ out,
+__global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out,
                            const ActDesc* __restrict__ acts,
                            const float* __restrict__ path,
                            const float* __restrict__ pre_vmax,    // this stage, [s_steps]
@@ -217,7 +217,7 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
 
     if (TERMINAL) {
         // lon_planner.cu:93-97: cost only; constr and j keep their zero init
-        if (active) out[(size_t)row * S + is] = make_float4(sc, 0.0f, 0.0f, 0.0f);
+        if (active) st_node(out + (size_t)row * S + is, sc, 0.0f, 0.0f);
         return;
     }
 
@@ -225,7 +225,7 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
     float* pv = reinterpret_cast<float*>(smem + (size_t)KCHUNK * blockDim.x * sizeof(float4));
     // (USE_BUF: the host checked that one stage table is addressable with 32-bit byte offsets)
     const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float4*>(next), 0, USE_BUF ? (int)((size_t)nrows * S * sizeof(float4)) : 0, 0x00020000);
+        const_cast<Node*>(next), 0, USE_BUF ? (int)((size_t)nrows * S * sizeof(Node)) : 0, 0x00020000);
     for (int i = tid; i < p.path_steps; i += blockDim.x) pv[i] = path[i * 7 + 5];
 
     const float s_range = p.s_max - p.s_min;
@@ -248,17 +248,17 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
                     // buffer loads: 128-bit descriptor of the whole next-stage table, row base as
                     // SCALAR offset, station as one 32-bit lane offset shared by all 36 loads of the
                     // cell -- no per-load 64-bit address arithmetic on the VALU
-                    const unsigned voff = (unsigned)is * 16u;
-                    const unsigned row_bytes = (unsigned)S * 16u;
-                    p00 = buf_load4(next_rsrc, voff, (unsigned)d->r00 * row_bytes);
-                    p10 = buf_load4(next_rsrc, voff, (unsigned)d->r10 * row_bytes);
-                    p01 = buf_load4(next_rsrc, voff, (unsigned)d->r01 * row_bytes);
-                    p11 = buf_load4(next_rsrc, voff, (unsigned)d->r11 * row_bytes);
+                    const unsigned voff = (unsigned)is * 12u;
+                    const unsigned row_bytes = (unsigned)S * 12u;
+                    p00 = buf_load_node(next_rsrc, voff, (unsigned)d->r00 * row_bytes);
+                    p10 = buf_load_node(next_rsrc, voff, (unsigned)d->r10 * row_bytes);
+                    p01 = buf_load_node(next_rsrc, voff, (unsigned)d->r01 * row_bytes);
+                    p11 = buf_load_node(next_rsrc, voff, (unsigned)d->r11 * row_bytes);
                 } else {
-                    p00 = (next + (size_t)d->r00 * S)[is];
-                    p10 = (next + (size_t)d->r10 * S)[is];
-                    p01 = (next + (size_t)d->r01 * S)[is];
-                    p11 = (next + (size_t)d->r11 * S)[is];
+                    p00 = ld_node(next + (size_t)d->r00 * S + is);
+                    p10 = ld_node(next + (size_t)d->r10 * S + is);
+                    p01 = ld_node(next + (size_t)d->r01 * S + is);
+                    p11 = ld_node(next + (size_t)d->r11 * S + is);
                 }
                 const float wa = d->wa, iwa = d->iwa, wv = d->wv, iwv = d->iwv;
                 const float4 b0 = lerp4w(p00, p10, wa, iwa);
@@ -337,7 +337,250 @@ __global__ void k_backward(const float4* __restrict__ next, float4* __restrict__
         }
     }
     const float j_best = action_jerk(p, idx_min, N_BWD);
-    out[(size_t)row * S + is] = make_float4(cost_min, constr_min, j_best, 0.0f);
+    st_node(out + (size_t)row * S + is, cost_min, constr_min, j_best);
+}
+
+// ------------------------------------------------------------------------
+// Two stations per lane (the large-grid form of k_backward, one action per barrier).
+//
+// The sweep is bound by VALU issue, and about half of a cell's instructions are plain fp32
+// add / mul / fma.  gfx950 issues those two-wide (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32)
+// at the cost of one: a lane that owns the stations is and is + half of its row carries both
+// through the same instruction stream as a float2, and everything that is per (row, action)
+// -- descriptor scalars, row offsets, broadcast moves -- is paid once for two cells.  Each
+// component still sees exactly the operations of k_backward (no contraction, same order).
+// blockDim.x = half * rows_per_block with half = s_pad2 / 2, s_pad2 = s_steps rounded up to 128.
+// LDS: float4 R[2 buffers][rows_per_block][2*half + 1] | float path_vmax[path_steps]
+// ------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 f2_floor(f2 x) { return (f2){floorf(x.x), floorf(x.y)}; }
+__device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int DIVMODE, bool USE_BUF>
+__global__ void __launch_bounds__(512) k_backward2(const Node* __restrict__ next, Node* __restrict__ out,
+                            const ActDesc* __restrict__ acts,
+                            const float* __restrict__ path,
+                            const float* __restrict__ pre_vmax,    // this stage, [s_steps]
+                            const float* __restrict__ pre_sdist,   // this stage, [s_steps]
+                            const double* __restrict__ pre_prog,   // [s_steps]
+                            TplDpLonParams p, int half, int rows_per_block,
+                            float rcp_path_step, double rcp_path_step_d, double rcp_s_range_d,
+                            int tile_v, int tile_a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // traversal order: as k_backward
+    const int S = p.s_steps, V = p.v_steps, A = p.a_steps;
+    const int nrows = V * A;
+    const int tid = threadIdx.x;
+    const int rib = tid / half;
+    const int il = tid - rib * half;
+    const int xcd = blockIdx.x & 7;
+    const int v_lo = (xcd * V) >> 3, v_hi = ((xcd + 1) * V) >> 3;
+    const int vx = v_hi - v_lo;
+    const int q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * rows_per_block + rib);
+    const bool row_ok = q < vx * A;
+    int ia = 0, iv = 0;
+    if (row_ok) {
+        const int full = vx / tile_v;
+        int strip = q / (A * tile_v), w = tile_v, rem = q - strip * (A * tile_v);
+        if (strip >= full) { strip = full; w = vx - full * tile_v; rem = q - full * (A * tile_v); }
+        const int tile = rem / (tile_a * w);
+        const int r = rem - tile * (tile_a * w);
+        ia = tile * tile_a + r / w;
+        iv = v_lo + strip * tile_v + (r - (r / w) * w);
+    }
+    const int row = ia * V + iv;
+
+    // the two stations of this lane; a station past the row end computes on the last one and
+    // is never stored (keeps the loads unconditional and the barriers uniform)
+    const int is0 = il, is1 = il + half;
+    const bool act0 = row_ok && is0 < S, act1 = row_ok && is1 < S;
+    const int js0 = min(is0, S - 1), js1 = min(is1, S - 1);
+
+    const f2 s = {p.s_min + (float)js0 * p._s_step_size, p.s_min + (float)js1 * p._s_step_size};
+    const float v = p.v_min + (float)iv * p._v_step_size;
+    const float a = p.a_min + (float)ia * p._a_step_size;
+
+    const f2 v_max = {pre_vmax[js0], pre_vmax[js1]};
+    const f2 s_dist = {pre_sdist[js0], pre_sdist[js1]};
+    const double prog0 = pre_prog[js0], prog1 = pre_prog[js1];
+
+    // stateCost lon_planner.cu:40-55
+    f2 sc;
+    {
+        float c0 = 0.0f;
+        c0 += p.w_a * (a * a);
+        const f2 gap = (v * p.time_gap + p.gap_min) - s_dist;
+        float x0 = (float)((double)c0 + prog0), x1 = (float)((double)c0 + prog1);
+        x0 = (float)((double)x0 + (double)p.w_safety_dist * fmax(0.0, (double)gap.x));
+        x1 = (float)((double)x1 + (double)p.w_safety_dist * fmax(0.0, (double)gap.y));
+        sc = (f2){x0, x1};
+    }
+    f2 sg;
+    sg.x = 0.0f; if (v > v_max.x) sg.x += v - v_max.x;
+    sg.y = 0.0f; if (v > v_max.y) sg.y += v - v_max.y;
+
+    float4* R = reinterpret_cast<float4*>(smem);
+    float* pv = reinterpret_cast<float*>(smem + (size_t)2 * (2 * half + 1) * rows_per_block * sizeof(float4));
+    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<Node*>(next), 0, USE_BUF ? (int)((size_t)nrows * S * sizeof(Node)) : 0, 0x00020000);
+    for (int i = tid; i < p.path_steps; i += blockDim.x) pv[i] = path[i * 7 + 5];
+
+    const float s_range = p.s_max - p.s_min;
+    const float s_scale = (float)(S - 1);
+    const float path_top = (float)(p.path_steps - 1);
+    // row buffer: stations 0..S-1 plus ONE duplicate of station S-1 at slot S, so the upper tap of
+    // the 1-D lerp, min(i_lo + 1, S - 1), is always the slot after the lower one and both come
+    // from one ds_read2.  Lanes past the row end recompute station S-1 into their own slots
+    // (slot S included when S < 2*half); when the row is full the lane of S-1 writes slot S too.
+    const int row_slots = 2 * half + 1;
+    const int buf_slots = row_slots * rows_per_block;      // one of the two alternating buffers
+    float4* Rrow = R + rib * row_slots;
+    const bool dup_last = (is1 == S - 1) && (S == 2 * half);
+    f2 res0[N_BWD], res1[N_BWD];      // (cost, constr) of action k at station 0 / 1
+
+    // Software pipeline over the nine actions: the eight row loads of action k+1 are issued
+    // right after action k's blend has gone to LDS, so they are in flight while phase 2 of
+    // action k runs.  The barrier is a bare s_barrier behind an LDS-only wait (__syncthreads
+    // would also drain vmcnt, i.e. wait for the prefetch).  Two LDS row buffers alternate, so
+    // one barrier per action is enough: whoever writes buffer (k+1)&1 has passed barrier k,
+    // which every lane reaches only after its phase 2 of action k-1 -- the last reader of it.
+    float4 ld[8];
+    auto issue_loads = [&](int k) {
+        const ActDesc* d = acts + (size_t)row * N_BWD + k;
+        if (USE_BUF) {
+            const unsigned row_bytes = (unsigned)S * 12u;
+            const unsigned o0 = (unsigned)js0 * 12u, o1 = (unsigned)js1 * 12u;
+            const unsigned b00 = (unsigned)d->r00 * row_bytes, b10 = (unsigned)d->r10 * row_bytes;
+            const unsigned b01 = (unsigned)d->r01 * row_bytes, b11 = (unsigned)d->r11 * row_bytes;
+            ld[0] = buf_load_node(next_rsrc, o0, b00); ld[4] = buf_load_node(next_rsrc, o1, b00);
+            ld[1] = buf_load_node(next_rsrc, o0, b10); ld[5] = buf_load_node(next_rsrc, o1, b10);
+            ld[2] = buf_load_node(next_rsrc, o0, b01); ld[6] = buf_load_node(next_rsrc, o1, b01);
+            ld[3] = buf_load_node(next_rsrc, o0, b11); ld[7] = buf_load_node(next_rsrc, o1, b11);
+        } else {
+            const Node* r00 = next + (size_t)d->r00 * S; const Node* r10 = next + (size_t)d->r10 * S;
+            const Node* r01 = next + (size_t)d->r01 * S; const Node* r11 = next + (size_t)d->r11 * S;
+            ld[0] = ld_node(r00 + js0); ld[4] = ld_node(r00 + js1); ld[1] = ld_node(r10 + js0); ld[5] = ld_node(r10 + js1);
+            ld[2] = ld_node(r01 + js0); ld[6] = ld_node(r01 + js1); ld[3] = ld_node(r11 + js0); ld[7] = ld_node(r11 + js1);
+        }
+    };
+    issue_loads(0);
+
+#pragma unroll
+    for (int k = 0; k < N_BWD; ++k) {
+        const ActDesc* d = acts + (size_t)row * N_BWD + k;
+        float4* Rk = Rrow + (k & 1) * buf_slots;
+        // ---- phase 1: blend the four neighbouring next-stage rows (a, then v), both stations
+        {
+            const float wa = d->wa, iwa = d->iwa, wv = d->wv, iwv = d->iwv;
+            const float4 r0 = lerp4w(lerp4w(ld[0], ld[1], wa, iwa), lerp4w(ld[2], ld[3], wa, iwa), wv, iwv);
+            const float4 r1 = lerp4w(lerp4w(ld[4], ld[5], wa, iwa), lerp4w(ld[6], ld[7], wa, iwa), wv, iwv);
+            Rk[is0] = r0;
+            Rk[is1] = r1;
+            if (dup_last) Rk[S] = r1;
+        }
+        if (k + 1 < N_BWD) issue_loads(k + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ---- phase 2: successor station, 1-D lerp, costs -- the two stations as one float2
+        {
+            // lonDynamics station part, lon_planner.cu:244
+            const f2 sf = s + d->vdt;
+            double sd0 = (double)sf.x + d->a_term, sd1 = (double)sf.y + d->a_term;
+            sd0 = sd0 + d->j_term; sd1 = sd1 + d->j_term;
+            const f2 tn_s = {fmaxf(s.x, (float)sd0), fmaxf(s.y, (float)sd1)};
+            // readNode coordinate along s (lon_planner.cu:35); tn_s >= s >= s_min
+            const f2 xs = tn_s - p.s_min;
+            f2 qs;
+            if (DIVMODE == 0) qs = (f2){xs.x / s_range, xs.y / s_range};
+            else qs = (f2){(float)((double)xs.x * rcp_s_range_d), (float)((double)xs.y * rcp_s_range_d)};
+            const f2 cs = qs * s_scale + 0.5f;
+            const f2 xb = cs - 0.5f;
+            const f2 fl = f2_floor(xb);
+            const f2 w256 = (xb - fl) * 256.0f;
+            const f2 ws = (f2){rintf(w256.x), rintf(w256.y)} * (1.0f / 256.0f);
+            const f2 iws = 1.0f - ws;
+            const int lo0 = (int)fminf(fl.x, s_scale), lo1 = (int)fminf(fl.y, s_scale);
+            const float4 nl0 = Rk[lo0], nh0 = Rk[lo0 + 1], nl1 = Rk[lo1], nh1 = Rk[lo1 + 1];
+            // lerp (rule R3).  (cost, constr) of one station sit in adjacent registers of its LDS
+            // read, so that pair is blended as a float2 per station; the jerk components are
+            // blended one by one and travel on as the pair across stations.
+            const f2 cg0 = f2_fma((f2){nh0.x, nh0.y}, (f2){ws.x, ws.x}, (f2){nl0.x, nl0.y} * iws.x);
+            const f2 cg1 = f2_fma((f2){nh1.x, nh1.y}, (f2){ws.y, ws.y}, (f2){nl1.x, nl1.y} * iws.y);
+            float nj0 = fmaf(nh0.z, ws.x, nl0.z * iws.x), nj1 = fmaf(nh1.z, ws.y, nl1.z * iws.y);
+            // (keeps the two blends above scalar: pairing them across stations would need four
+            // register moves to line up the LDS results)
+            asm volatile("" : "+v"(nj0), "+v"(nj1));
+            const f2 node_j = {nj0, nj1};
+            // interpPath(tn.s).v_max, lon_planner.cu:114
+            f2 alpha;
+            if (DIVMODE == 0) alpha = (f2){tn_s.x / p.path_step_size, tn_s.y / p.path_step_size};
+            else if (DIVMODE == 1) {
+                const f2 q0 = tn_s * rcp_path_step;
+                const f2 e = f2_fma(-q0, (f2){p.path_step_size, p.path_step_size}, tn_s);
+                alpha = f2_fma(e, (f2){rcp_path_step, rcp_path_step}, q0);
+            } else alpha = (f2){(float)((double)tn_s.x * rcp_path_step_d), (float)((double)tn_s.y * rcp_path_step_d)};
+            const f2 afl = f2_floor(alpha);
+            const f2 up = {alpha.x > afl.x ? 1.0f : 0.0f, alpha.y > afl.y ? 1.0f : 0.0f};
+            const f2 aup = afl + up;
+            const f2 f0 = {__builtin_amdgcn_fmed3f(afl.x, 0.0f, path_top), __builtin_amdgcn_fmed3f(afl.y, 0.0f, path_top)};
+            const f2 f1 = {__builtin_amdgcn_fmed3f(aup.x, 0.0f, path_top), __builtin_amdgcn_fmed3f(aup.y, 0.0f, path_top)};
+            const f2 pa = alpha - f0;
+            const f2 pia = 1.0f - pa;
+            const f2 pv0 = {pv[(int)f0.x], pv[(int)f0.y]};
+            const f2 pv1 = {pv[(int)f1.x], pv[(int)f1.y]};
+            const f2 vmn = pv0 * pia + pv1 * pa;
+
+            // (cost, constr) per station as a pair
+            f2 r0 = (f2){sc.x, sg.x} + cg0;
+            f2 r1 = (f2){sc.y, sg.y} + cg1;
+            const f2 dj = node_j - d->j;
+            const f2 snap = p.w_snap * (dj * dj);
+            r0.x += snap.x;
+            r1.x += snap.y;
+            // lon_planner.cu:114-118 (double compare == float compare, double subtraction)
+            const float lim0 = (float)((double)r0.y + (d->tn_v_d - (double)vmn.x));
+            const float lim1 = (float)((double)r1.y + (d->tn_v_d - (double)vmn.y));
+            r0.y = (d->tn_v > vmn.x) ? lim0 : r0.y;
+            r1.y = (d->tn_v > vmn.y) ? lim1 : r1.y;
+            const f2 s_change = tn_s - s;
+            const f2 over = s_change - s_dist;
+            const f2 g_over = (f2){r0.y, r1.y} + over;
+            r0.y = (s_change.x > s_dist.x) ? g_over.x : r0.y;
+            r1.y = (s_change.y > s_dist.y) ? g_over.y : r1.y;
+            // c += wj_cost and g += a_viol are the last addends of their sums in k_backward too
+            const f2 tail = {d->wj_cost, d->a_viol};
+            f2 o0 = r0 + tail, o1 = r1 + tail;
+            // pin the results here: with nothing but the final argmin using them, the compiler
+            // otherwise sinks the tail of this action below the next barrier and spills its inputs
+            asm volatile("" : "+v"(o0), "+v"(o1));
+            res0[k] = o0;
+            res1[k] = o1;
+        }
+    }
+
+    // lexicographic argmin, lon_planner.cu:153-170, per station (selects, no divergence)
+#pragma unroll
+    for (int cidx = 0; cidx < 2; ++cidx) {
+        const f2* res = cidx == 0 ? res0 : res1;
+        float constr_min = INFINITY;
+#pragma unroll
+        for (int k = 0; k < N_BWD; ++k) {
+            constr_min = (res[k].y < constr_min) ? res[k].y : constr_min;
+        }
+        float cost_min = INFINITY;
+        int idx_min = 0;
+#pragma unroll
+        for (int k = 0; k < N_BWD; ++k) {
+            const bool take = !(res[k].y > constr_min) && (res[k].x < cost_min);
+            cost_min = take ? res[k].x : cost_min;
+            idx_min = take ? k : idx_min;
+        }
+        const float j_best = action_jerk(p, idx_min, N_BWD);
+        if (cidx == 0 ? act0 : act1)
+            st_node(out + (size_t)row * S + (cidx == 0 ? is0 : is1), cost_min, constr_min, j_best);
+    }
 }
 
 // ------------------------------------------------------------------------
@@ -378,7 +621,7 @@ __device__ __forceinline__ float wave_min(float x)
 }
 
 template <int N>
-__device__ __forceinline__ void eval_node_wave(TplLonState& tp, const float4* __restrict__ table_next,
+__device__ __forceinline__ void eval_node_wave(TplLonState& tp, const Node* __restrict__ table_next,
                                                const float* __restrict__ path,
                                                const float* __restrict__ dist_ts,
                                                const TplDpLonParams& p, const TplDpEnvParams& ep,
@@ -433,7 +676,7 @@ __device__ __forceinline__ void eval_node_wave(TplLonState& tp, const float4* __
 
 // lonForwardStep chain, lon_planner.cu:211-225 + :365-386.  One wave per rollout.
 __global__ void k_forward(TplLonState* __restrict__ trajs, const TplLonState* __restrict__ inits,
-                          const float4* __restrict__ tables, size_t table_cells,
+                          const Node* __restrict__ tables, size_t table_cells,
                           const float* __restrict__ path, const float* __restrict__ dist_ts,
                           TplDpLonParams p, TplDpEnvParams ep)
 {
@@ -451,7 +694,7 @@ __global__ void k_forward(TplLonState* __restrict__ trajs, const TplLonState* __
 
 // lonReevalNode, lon_planner.cu:227-236 + :439-455: nodes are independent, one thread each
 __global__ void k_reeval(TplLonState* __restrict__ traj,
-                         const float4* __restrict__ tables, size_t table_cells,
+                         const Node* __restrict__ tables, size_t table_cells,
                          const float* __restrict__ path, const float* __restrict__ dist_ts,
                          TplDpLonParams p, TplDpEnvParams ep)
 {
@@ -461,7 +704,7 @@ __global__ void k_reeval(TplLonState* __restrict__ traj,
     TplLonState tp = traj[i];
     const float dt = (i == 0) ? p.dt_start : p.dt;
     const int nx = min(T - 1, i + 1);
-    const float4* table_next = tables + (size_t)nx * table_cells;
+    const Node* table_next = tables + (size_t)nx * table_cells;
 
     const PathTap pt = path_tap(tp.s, p.path_step_size, p.path_steps);
     const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
@@ -549,7 +792,7 @@ struct tplhip_dp_lon {
     TplDpLonParams params;
     bool have_params = false;
 
-    float4* d_tables = nullptr;         // [t_steps][a][v][s]
+    Node* d_tables = nullptr;           // [t_steps][a][v][s], 12-byte cells
     size_t table_cells = 0;
     ActDesc* d_acts = nullptr;          // [a*v][9]
     float* d_path = nullptr;            // [path_steps][7]
@@ -564,6 +807,7 @@ struct tplhip_dp_lon {
 
     // launch geometry of k_backward
     int s_pad = 0, rows_per_block = 0, nblocks = 0, grid = 0, kchunk = 0;
+    int cells = 1;                       // stations per lane: 2 selects k_backward2 (s_pad = 2 * half)
     int tile_v = 8, tile_a = 8;          // traversal tiles, see k_backward
     size_t lds_bytes = 0;
 
@@ -658,16 +902,62 @@ template <bool TERMINAL, int KCHUNK, int DIVMODE>
 void launch_backward(tplhip_dp_lon* h, int idx_t, int nx)
 {
     // buffer loads need 32-bit byte offsets inside one stage table
-    if (!TERMINAL && h->table_cells * sizeof(float4) < 0xffffffffull && !std::getenv("TPLHIP_NO_BUFLOAD"))
+    if (!TERMINAL && h->table_cells * sizeof(Node) < 0xffffffffull && !std::getenv("TPLHIP_NO_BUFLOAD"))
         launch_backward_b<TERMINAL, KCHUNK, DIVMODE, true>(h, idx_t, nx);
     else
         launch_backward_b<TERMINAL, KCHUNK, DIVMODE, false>(h, idx_t, nx);
 }
 
+template <int DIVMODE, bool USE_BUF>
+void launch_backward2_b(tplhip_dp_lon* h, int idx_t, int nx)
+{
+    const size_t S = (size_t)h->params.s_steps;
+    const int half = h->s_pad / 2;
+    hipLaunchKernelGGL((k_backward2<DIVMODE, USE_BUF>), dim3(h->grid), dim3(half * h->rows_per_block),
+                       h->lds_bytes, h->stream,
+                       h->d_tables + (size_t)nx * h->table_cells,
+                       h->d_tables + (size_t)idx_t * h->table_cells,
+                       h->d_acts, h->d_path,
+                       h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
+                       h->d_pre_prog, h->params, half, h->rows_per_block,
+                       h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a);
+}
+
+template <int DIVMODE>
+void launch_backward2(tplhip_dp_lon* h, int idx_t, int nx)
+{
+    if (h->table_cells * sizeof(Node) < 0xffffffffull && !std::getenv("TPLHIP_NO_BUFLOAD"))
+        launch_backward2_b<DIVMODE, true>(h, idx_t, nx);
+    else
+        launch_backward2_b<DIVMODE, false>(h, idx_t, nx);
+}
+
+// the terminal stage of the two-station geometry: k_backward<true> with one station per lane
+void launch_terminal(tplhip_dp_lon* h, int idx_t)
+{
+    const size_t S = (size_t)h->params.s_steps;
+    const int s_pad1 = ((h->params.s_steps + 63) / 64) * 64;
+    const int rpb = std::max(1, 256 / s_pad1);
+    int max_rows = 0;
+    for (int x = 0; x < 8; ++x)
+        max_rows = std::max(max_rows, ((((x + 1) * h->params.v_steps) >> 3) - ((x * h->params.v_steps) >> 3)) * h->params.a_steps);
+    const int grid = 8 * ((max_rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL((k_backward<true, 1, 0, false>), dim3(grid), dim3(s_pad1 * rpb), 0, h->stream,
+                       h->d_tables + (size_t)idx_t * h->table_cells,
+                       h->d_tables + (size_t)idx_t * h->table_cells,
+                       h->d_acts, h->d_path,
+                       h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
+                       h->d_pre_prog, h->params, s_pad1, rpb, 0,
+                       h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a);
+}
+
 template <int DIVMODE>
 void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
 {
-    if (terminal) {
+    if (h->cells == 2) {
+        if (terminal) launch_terminal(h, i);                         // rule R4
+        else launch_backward2<DIVMODE>(h, i, nx);
+    } else if (terminal) {
         launch_backward<true, 1, 0>(h, i, nx);                       // rule R4 (no division in it)
     } else if (h->kchunk == 9) {
         launch_backward<false, 9, DIVMODE>(h, i, nx);
@@ -939,8 +1229,8 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         hipFree(h->d_inits); hipFree(h->d_trajs);
         h->d_inits = nullptr; h->d_trajs = nullptr; h->cap_rollouts = 0;
         h->table_cells = S * p.v_steps * p.a_steps;
-        HIP_TRY(hipMalloc(&h->d_tables, sizeof(float4) * h->table_cells * (size_t)p.t_steps), "value table allocation failed");
-        HIP_TRY(hipMemsetAsync(h->d_tables, 0, sizeof(float4) * h->table_cells * (size_t)p.t_steps, h->stream), "value table clear failed");
+        HIP_TRY(hipMalloc(&h->d_tables, sizeof(Node) * h->table_cells * (size_t)p.t_steps), "value table allocation failed");
+        HIP_TRY(hipMemsetAsync(h->d_tables, 0, sizeof(Node) * h->table_cells * (size_t)p.t_steps, h->stream), "value table clear failed");
         HIP_TRY(hipMalloc(&h->d_acts, sizeof(ActDesc) * (size_t)nrows * N_BWD), "action table allocation failed");
         HIP_TRY(hipMalloc(&h->d_path, sizeof(float) * 7 * (size_t)p.path_steps), "path array allocation failed");
         HIP_TRY(hipMalloc(&h->d_pre_vmax, sizeof(float) * S * p.t_steps), "prelude allocation failed");
@@ -984,6 +1274,28 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         if ((k == 9 || k == 3 || k == 1) && threads * 16 * (size_t)k + path_lds <= 160 * 1024) h->kchunk = k;
     }
     h->lds_bytes = threads * 16 * (size_t)h->kchunk + path_lds;
+    // Large grids (one action per barrier) run two stations per lane, see k_backward2.
+    h->cells = 1;
+    {
+        const char* ov = std::getenv("TPLHIP_CELLS");
+        const int want = ov ? std::atoi(ov) : 2;
+        if (h->kchunk == 1 && want == 2) {
+            h->cells = 2;
+            h->s_pad = ((p.s_steps + 127) / 128) * 128;
+            const int half = h->s_pad / 2;
+            h->rows_per_block = std::max(1, 128 / half);
+            if (const char* ov = std::getenv("TPLHIP_RPB")) {
+                const int r = std::atoi(ov);
+                if (r >= 1 && half * r <= 512) h->rows_per_block = r;
+            }
+            h->nblocks = (nrows + h->rows_per_block - 1) / h->rows_per_block;
+            int max_rows = 0;
+            for (int x = 0; x < 8; ++x)
+                max_rows = std::max(max_rows, ((((x + 1) * p.v_steps) >> 3) - ((x * p.v_steps) >> 3)) * p.a_steps);
+            h->grid = 8 * ((max_rows + h->rows_per_block - 1) / h->rows_per_block);
+            h->lds_bytes = (size_t)2 * (h->s_pad + 1) * h->rows_per_block * 16 + path_lds;
+        }
+    }
     if (h->lds_bytes > 160 * 1024)
         return tplhip_fail(TPLHIP_EINVAL, "path_steps = %d does not fit in LDS next to the row buffers", p.path_steps);
 
@@ -1136,8 +1448,13 @@ int tplhip_dp_lon_copy_table(tplhip_dp_lon* h, int t, float* out)
     if (t < 0 || t >= h->params.t_steps) return tplhip_fail(TPLHIP_EINVAL, "stage %d out of range", t);
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
-    HIP_TRY(hipMemcpy(out, h->d_tables + (size_t)t * h->table_cells, sizeof(float4) * h->table_cells,
+    // the C-ABI hands out the reference's float4 cells (cost, constr, j, 0); the device keeps 12
+    std::vector<Node> tmp(h->table_cells);
+    HIP_TRY(hipMemcpy(tmp.data(), h->d_tables + (size_t)t * h->table_cells, sizeof(Node) * h->table_cells,
                       hipMemcpyDeviceToHost), "copying value table failed");
+    for (size_t i = 0; i < h->table_cells; ++i) {
+        out[4 * i + 0] = tmp[i].c; out[4 * i + 1] = tmp[i].g; out[4 * i + 2] = tmp[i].j; out[4 * i + 3] = 0.0f;
+    }
     return TPLHIP_OK;
 }
 
@@ -1146,9 +1463,9 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
     if (!h || !buf || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
     std::snprintf(buf, (size_t)n,
                   "{\"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
-                  "\"div_mode\": %d, \"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d}",
+                  "\"div_mode\": %d, \"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"cells\": %d}",
                   h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
-                  h->div_mode, (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid);
+                  h->div_mode, (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->cells);
     return TPLHIP_OK;
 }
 

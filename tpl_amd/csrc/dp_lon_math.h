@@ -51,12 +51,31 @@ __device__ __forceinline__ float4 lerp4(float4 p, float4 q, float w)
     return r;
 }
 
-// 16-byte buffer load: descriptor + 32-bit lane offset + scalar offset
-typedef float v4f32 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset)
+// One cell of a value table in HBM: 12 bytes.  The reference keeps float4 texels whose fourth
+// component is never read (lon_planner.cu:34-37); dropping it cuts a quarter of the bytes every
+// sweep pulls through L2 -- which is what bounds the sweep.  In registers and LDS a node travels
+// as a float4 with w = 0.
+struct Node { float c, g, j; };
+static_assert(sizeof(Node) == 12, "Node must be 12 bytes");
+
+__device__ __forceinline__ float4 ld_node(const Node* __restrict__ p)
 {
-    const v4f32 r = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voffset, (int)soffset, 0));
-    return make_float4(r.x, r.y, r.z, r.w);
+    const Node n = *p;
+    return make_float4(n.c, n.g, n.j, 0.0f);
+}
+
+__device__ __forceinline__ void st_node(Node* __restrict__ p, float c, float g, float j)
+{
+    Node n; n.c = c; n.g = g; n.j = j;
+    *p = n;
+}
+
+// 12-byte buffer load: descriptor + 32-bit lane offset + scalar offset
+typedef float v3f32 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ float4 buf_load_node(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset)
+{
+    const v3f32 r = __builtin_bit_cast(v3f32, __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)voffset, (int)soffset, 0));
+    return make_float4(r.x, r.y, r.z, 0.0f);
 }
 
 // lerp4 with the complement 1-w supplied (wave-uniform weights keep it in an SGPR)
@@ -177,19 +196,21 @@ __device__ __forceinline__ float node_coord(float x, float x_min, float x_max, i
 }
 
 // readNode with all eight taps from global memory (forward / reeval kernels).
-__device__ __forceinline__ float4 read_node(const TplDpLonParams& p, const float4* __restrict__ table,
+__device__ __forceinline__ float4 read_node(const TplDpLonParams& p, const Node* __restrict__ table,
                                             float s, float v, float a)
 {
     Tap ts = make_tap(node_coord(s, p.s_min, p.s_max, p.s_steps), p.s_steps);
     Tap tv = make_tap(node_coord(v, p.v_min, p.v_max, p.v_steps), p.v_steps);
     Tap ta = make_tap(node_coord(a, p.a_min, p.a_max, p.a_steps), p.a_steps);
     const size_t S = (size_t)p.s_steps, V = (size_t)p.v_steps;
-    const float4* r00 = table + ((size_t)ta.i0 * V + tv.i0) * S;
-    const float4* r10 = table + ((size_t)ta.i1 * V + tv.i0) * S;
-    const float4* r01 = table + ((size_t)ta.i0 * V + tv.i1) * S;
-    const float4* r11 = table + ((size_t)ta.i1 * V + tv.i1) * S;
-    float4 lo = lerp4(lerp4(r00[ts.i0], r10[ts.i0], ta.w), lerp4(r01[ts.i0], r11[ts.i0], ta.w), tv.w);
-    float4 hi = lerp4(lerp4(r00[ts.i1], r10[ts.i1], ta.w), lerp4(r01[ts.i1], r11[ts.i1], ta.w), tv.w);
+    const Node* r00 = table + ((size_t)ta.i0 * V + tv.i0) * S;
+    const Node* r10 = table + ((size_t)ta.i1 * V + tv.i0) * S;
+    const Node* r01 = table + ((size_t)ta.i0 * V + tv.i1) * S;
+    const Node* r11 = table + ((size_t)ta.i1 * V + tv.i1) * S;
+    float4 lo = lerp4(lerp4(ld_node(r00 + ts.i0), ld_node(r10 + ts.i0), ta.w),
+                      lerp4(ld_node(r01 + ts.i0), ld_node(r11 + ts.i0), ta.w), tv.w);
+    float4 hi = lerp4(lerp4(ld_node(r00 + ts.i1), ld_node(r10 + ts.i1), ta.w),
+                      lerp4(ld_node(r01 + ts.i1), ld_node(r11 + ts.i1), ta.w), tv.w);
     return lerp4(lo, hi, ts.w);
 }
 
