@@ -79,6 +79,11 @@ static inline void init_interp(OInterp* i, double x0, double dx, double x, size_
 }
 
 static inline void tpl_sincos(double a, double* s, double* c) { *s = sin(a); *c = cos(a); }
+// the generated text names these; here they are the C library's functions (the product has its
+// own short kernels, tpl_amd/csrc/ilqr/builtins.h -- deliberately not shared)
+static inline double tpl_sin(double a) { return sin(a); }
+static inline double tpl_cos(double a) { return cos(a); }
+static inline double tpl_tan(double a) { return tan(a); }
 
 static inline double tpl_get_array_value(const DynArr& A, double I) { return A.data[(size_t)I]; }
 

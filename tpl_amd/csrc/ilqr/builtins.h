@@ -21,11 +21,75 @@
 #define TPL_HD
 #endif
 
-// sin and cos of one argument with a shared range reduction (generated code asks for the
-// pair where a routine needs both)
+// ---- sin / cos / tan ------------------------------------------------------
+// The line-search rollouts are chains of dependent dynamics evaluations on a
+// single wavefront, so what the trigonometric calls cost is their INSTRUCTION
+// COUNT: the device library's fp64 sincos is ~95 instructions on its small-argument
+// path and tan ~115, against ~35 here for one shared reduction plus both kernels.
+//   k = rint(a * 2/pi);  r = a - k*pi/2 in two FMAs (hi part exact for |a| < 1e5, the
+//   lo part rounds once);  sin r, cos r by the classic degree-13/14 minimax polynomials
+//   on |r| <= pi/4 (coefficients of the public-domain fdlibm __kernel_sin/__kernel_cos);
+//   quadrant by k mod 4.
+// Accuracy ~1 ulp (tan ~2.5 ulp as sin/cos), far inside the solver's 1e-5 contract; the
+// CPU oracle uses the C library's functions and does not share this code.  |a| >= 1e5,
+// infinities and NaNs go to the library.
+TPL_HD inline void tpl_sincos_core(double a, double* s, double* c)
+{
+    const double k = rint(a * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632679489655800e+00, a);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = fma(z * r, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + (z * z) * pc);
+    const int n = (int)k;
+    const double ss = (n & 1) ? cr : sr;
+    const double cc = (n & 1) ? sr : cr;
+    *s = (n & 2) ? -ss : ss;
+    *c = ((n + 1) & 2) ? -cc : cc;
+}
+
+// Rare slow paths are guarded by a WAVE-UNIFORM test on the device: a per-lane `if` around a
+// library call costs ~135 cycles per call site in exec-mask bookkeeping and result merging even
+// when no lane takes it (measured, tools/micro/trig_probe.hip); a ballot is one compare and a
+// scalar branch.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TPL_ANY_LANE(cond) (__builtin_amdgcn_ballot_w64(cond) != 0ull)
+#else
+#define TPL_ANY_LANE(cond) (cond)
+#endif
+
 TPL_HD inline void tpl_sincos(double a, double* s, double* c)
 {
-    sincos(a, s, c);
+    tpl_sincos_core(a, s, c);
+    if (TPL_ANY_LANE(!(fabs(a) < 1.0e5))) {
+        if (!(fabs(a) < 1.0e5)) sincos(a, s, c);
+    }
+}
+
+TPL_HD inline double tpl_sin(double a) { double s, c; tpl_sincos(a, &s, &c); return s; }
+TPL_HD inline double tpl_cos(double a) { double s, c; tpl_sincos(a, &s, &c); return c; }
+
+TPL_HD inline double tpl_tan(double a)
+{
+    double s, c;
+    tpl_sincos_core(a, &s, &c);
+    double r = s / c;
+    if (TPL_ANY_LANE(!(fabs(a) < 1.0e5))) {
+        if (!(fabs(a) < 1.0e5)) r = tan(a);
+    }
+    return r;
 }
 
 struct DynArr {
@@ -35,34 +99,39 @@ struct DynArr {
     int32_t pad;
 };
 
-// (size_t)floor(q) clamped to [0, n-1] the way optim.c:351 does it
+// (size_t)floor(q) clamped to [0, n-1] the way optim.c:351 does it: a negative value wraps to a
+// huge unsigned number and clamps to n-1.  The clamp is done on the (integral) double so the
+// index needs one f64->i32 conversion and the weight no conversion back (there is no single
+// f64<->i64 instruction; array lengths are far below 2^31).
+TPL_HD inline double tpl_idxf(double f, double nm1)
+{
+    return (f <= -1.0 || f >= nm1) ? nm1 : f;    // f in (-1, n-1): -0.0 -> index 0
+}
+
 TPL_HD inline int64_t tpl_idx_floor(double q, int64_t n)
 {
-    const double f = floor(q);
-    if (f <= -1.0) return n - 1;                 // negative -> wraps -> min(n-1, huge)
-    if (f >= (double)(n - 1)) return n - 1;
-    return (int64_t)f;                           // f in (-1, n-1): -0.0 -> 0
+    return (int64_t)(int)tpl_idxf(floor(q), (double)(n - 1));
 }
 
 // (size_t)ceil(q) clamped to [0, n-1] the way optim.c:352 does it
 TPL_HD inline int64_t tpl_idx_ceil(double q, int64_t n)
 {
-    const double c = ceil(q);
-    if (c <= -1.0) return n - 1;
-    if (c >= (double)(n - 1)) return n - 1;
-    return (int64_t)c;                           // c in (-1, 0] -> 0
+    return (int64_t)(int)tpl_idxf(ceil(q), (double)(n - 1));
 }
 
-struct TplInterp { double a, ia; int64_t start, end; };
+struct TplInterp { double a, ia; int start, end; };
 
 // initInterp, optim.c:347-355
 TPL_HD inline TplInterp tpl_init_interp(double x0, double dx, double x, int64_t n)
 {
     TplInterp i;
     const double q = (x - x0) / dx;
-    i.start = tpl_idx_floor(q, n);
-    i.end = tpl_idx_ceil(q, n);
-    double a = q - (double)i.start;
+    const double nm1 = (double)(int)(n - 1);
+    const double fs = tpl_idxf(floor(q), nm1);
+    const double fe = tpl_idxf(ceil(q), nm1);
+    i.start = (int)fs;
+    i.end = (int)fe;
+    double a = q - fs;                           // == q - (double)start
     a = a > 0.0 ? a : 0.0;                       // min(max(0.0, .), 1.0)
     a = a < 1.0 ? a : 1.0;
     i.a = a;
@@ -97,7 +166,11 @@ TPL_HD inline double tpl_lerp(double x0, double dx, double x, const DynArr& arr)
 // arguments take the library's long-division loop, which is very slow in fp64 on the GPU.
 TPL_HD inline double tpl_fmod_pos(double x, double m)
 {
-    return (fabs(x) < m) ? x : fmod(x, m);
+    double r = x;
+    if (TPL_ANY_LANE(!(fabs(x) < m))) {
+        if (!(fabs(x) < m)) r = fmod(x, m);
+    }
+    return r;
 }
 
 // shortAngleDist, optim.c:332-338

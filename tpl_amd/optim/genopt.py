@@ -77,13 +77,17 @@ class Config:
         return {}
 
     def fingerprint(self):
-        """sha1 over the problem text (the reference hashes the same parts plus
-        its templates, genopt.py:493-505)."""
-        parts = [self.states, self.actions, self.param_symbols, self.dynamics,
+        """sha1 over the problem text and the emitter revision (the reference hashes
+        the same parts plus its templates, genopt.py:493-505)."""
+        parts = [EMITTER_REVISION, self.states, self.actions, self.param_symbols, self.dynamics,
                  _as_matrix(self.costs), _as_matrix(self.end_costs), self.constraints]
         h = hashlib.sha1()
         h.update("|".join(str(p) for p in parts).encode("utf8"))
         return h.hexdigest()
+
+
+# bump when the emitted text for an unchanged problem changes (invalidates cached models)
+EMITTER_REVISION = "emit-2: tpl_sin/tpl_cos/tpl_tan"
 
 
 def _as_matrix(e):
@@ -179,8 +183,10 @@ class _Printer(C99CodePrinter):
     log/exp pair on the GPU), x**-1 -> 1.0/x, x**0.5 -> sqrt."""
 
     def __init__(self):
-        super().__init__({"allow_unknown_functions": True,
-                          "user_functions": dict(_OPAQUE_C)})
+        fns = dict(_OPAQUE_C)
+        # short-kernel sin/cos/tan of builtins.h (the rollout chains pay per instruction)
+        fns.update({"sin": "tpl_sin", "cos": "tpl_cos", "tan": "tpl_tan"})
+        super().__init__({"allow_unknown_functions": True, "user_functions": fns})
 
     def _print_Pow(self, expr):
         base, e = expr.base, expr.exp
