@@ -28,6 +28,27 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_CELL = 32            # read next float4 + write this float4
 
 
+def env_cpu_baseline(reps=20):
+    """The occupancy-pipeline oracle (oracle/dp_env_oracle.c, one thread) on the scene of
+    latency.env_update -- the checker timed as a baseline, never the product."""
+    import numpy as np
+    import oracle_env as oe
+    from tpl_amd import scenarios
+    ep = scenarios.env_params(t_steps=10, s_steps=201, l_steps=31)
+    rl, step, objs = scenarios.env_scene("arc", seed=1, n_objects=10)
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        o = oe.OracleEnv(ep)
+        o.set_ref_line(rl, step)
+        for g, st in objs:
+            o.insert_geometry(g, st)
+        o.update()
+        t.append((time.perf_counter() - t0) * 1e3)
+    return {"value": float(np.median(t)), "unit": "ms per update", "cores": 1, "kind": "port",
+            "sample": f"{reps} updates of the same scene"}
+
+
 def dp_setup(grid, device):
     import tpl_amd
     from tpl_amd import scenarios as sc
@@ -189,6 +210,7 @@ def main():
             from tpl_amd.optim import bench_ilqr
             out["secondary"] = {"batched_ilqr": bench_ilqr.run(local_rank),
                                 "plan_latency": latency.run(local_rank)}
+            out["secondary"]["plan_latency"]["env_update"]["cpu_baseline"] = env_cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

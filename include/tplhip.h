@@ -114,6 +114,33 @@ TPLHIP_API int tplhip_dp_env_get_occ_map(tplhip_dp_env* env, float* occ_lst);
  * planner call: float[t_steps][s_steps], s fastest. */
 TPLHIP_API int tplhip_dp_env_get_dist_map_path(tplhip_dp_env* env, float* dist_ts);
 
+/* ------------------------ occupancy pipeline (env.cu:352-437) -- */
+
+/* DynProgEnvironment::setRefLine (env.cu:376-379) + the RefLine constructor
+ * (utils.hpp:184-214): ref_line is float64[n][9] = {x, y, heading, s, k, v_max,
+ * d_left, d_right, semantic}; the bounding-box centre is subtracted and kept. */
+TPLHIP_API int tplhip_dp_env_set_ref_line(tplhip_dp_env* env, const double* ref_line, int n, float step_size);
+/* RefLine::x_offset / y_offset (bindings_dp_common.cu:34-35) */
+TPLHIP_API int tplhip_dp_env_ref_line_offset(tplhip_dp_env* env, double* x_offset, double* y_offset);
+/* DynProgEnvironment::insertGeometry (env.cu:352-374): geom is float64[n][3] =
+ * (x, y, t) triangle-soup vertices; queued until the next update().  TPLHIP_ESTATE
+ * ("cannot insert dyn object points with ref_line of 0 steps") without a reference line. */
+TPLHIP_API int tplhip_dp_env_insert_geometry(tplhip_dp_env* env, const double* geom, int n, int stationary);
+/* DynProgEnvironment::update (env.cu:381-437): rasterise the queued triangles
+ * (replaces occupancy_renderer.cu:275-320), occupancyToFrenet, closeIntersections,
+ * updateDistMapLon.  TPLHIP_ESTATE with the reference's message when the reference
+ * line is shorter than s_max. */
+TPLHIP_API int tplhip_dp_env_update(tplhip_dp_env* env);
+/* get_occ_map_cartesian (bindings_dp_env.cu:76-83): uint32[size][size], size from
+ * tplhip_dp_env_cart_size (1 before the first update, like the reference's 1x1 frame buffer) */
+TPLHIP_API int tplhip_dp_env_cart_size(tplhip_dp_env* env, int* size_pixels);
+TPLHIP_API int tplhip_dp_env_get_occ_map_cartesian(tplhip_dp_env* env, uint32_t* out);
+/* getDistMapLon (env.cu:474-489): float[l_steps][s_steps][t_steps][2] =
+ * (distance to the next occupied cell ahead, behind) */
+TPLHIP_API int tplhip_dp_env_get_dist_map_lon(tplhip_dp_env* env, float* out);
+/* DynProgEnvironment::getDist (env.cu:439-450): filtered occupancy at (t, s, l) */
+TPLHIP_API int tplhip_dp_env_get_dist(tplhip_dp_env* env, float t, float s, float l, float* out);
+
 /* ----------------------------------------------------- DP planner (HP-1) -- */
 
 /* DynProgLonPlanner(), bindings_dp_lon.cu:120-121 */

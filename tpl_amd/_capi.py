@@ -83,6 +83,14 @@ SIGNATURES = {
     "tplhip_dp_env_set_occ_map": (C.c_int, [_vp, _fp]),
     "tplhip_dp_env_get_occ_map": (C.c_int, [_vp, _fp]),
     "tplhip_dp_env_get_dist_map_path": (C.c_int, [_vp, _fp]),
+    "tplhip_dp_env_set_ref_line": (C.c_int, [_vp, _P(C.c_double), C.c_int, C.c_float]),
+    "tplhip_dp_env_ref_line_offset": (C.c_int, [_vp, _P(C.c_double), _P(C.c_double)]),
+    "tplhip_dp_env_insert_geometry": (C.c_int, [_vp, _P(C.c_double), C.c_int, C.c_int]),
+    "tplhip_dp_env_update": (C.c_int, [_vp]),
+    "tplhip_dp_env_cart_size": (C.c_int, [_vp, _P(C.c_int)]),
+    "tplhip_dp_env_get_occ_map_cartesian": (C.c_int, [_vp, _P(C.c_uint32)]),
+    "tplhip_dp_env_get_dist_map_lon": (C.c_int, [_vp, _fp]),
+    "tplhip_dp_env_get_dist": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, _fp]),
     "tplhip_dp_lon_create": (C.c_int, [C.c_int, _P(_vp)]),
     "tplhip_dp_lon_destroy": (C.c_int, [_vp]),
     "tplhip_dp_lon_reinit": (C.c_int, [_vp, _P(TplDpLonParams)]),

@@ -33,6 +33,7 @@
 
 #include "dp_lon_math.h"
 #include "tplhip_common.h"
+#include "dp_env_internal.h"
 
 using namespace tplhip;
 
@@ -777,15 +778,6 @@ __global__ void k_dist_map_path(float* __restrict__ dist_ts, const float* __rest
 // host side
 // ==========================================================================
 
-struct tplhip_dp_env {
-    int device = 0;
-    TplDpEnvParams params;
-    bool have_params = false;
-    float* d_occ = nullptr;     // [l][s][t]
-    float* d_dist = nullptr;    // [t][s]
-    bool have_occ = false;
-};
-
 struct tplhip_dp_lon {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1100,6 +1092,11 @@ int tplhip_dp_env_destroy(tplhip_dp_env* env)
     hipSetDevice(env->device);
     hipFree(env->d_occ);
     hipFree(env->d_dist);
+    hipFree(env->d_cart);
+    hipFree(env->d_vtx);
+    hipFree(env->d_frames);
+    hipFree(env->d_semantic);
+    hipFree(env->d_dist_lon);
     delete env;
     return TPLHIP_OK;
 }
@@ -1116,12 +1113,15 @@ int tplhip_dp_env_reinit(tplhip_dp_env* env, TplDpEnvParams* ps)
     env->params = *ps;
     env->have_params = true;
     if (!full) return TPLHIP_OK;
-    hipFree(env->d_occ); hipFree(env->d_dist);
-    env->d_occ = nullptr; env->d_dist = nullptr;
+    hipFree(env->d_occ); hipFree(env->d_dist); hipFree(env->d_dist_lon); hipFree(env->d_frames);
+    env->d_occ = nullptr; env->d_dist = nullptr; env->d_dist_lon = nullptr; env->d_frames = nullptr;
     const size_t n_occ = (size_t)ps->l_steps * ps->s_steps * ps->t_steps;
     const size_t n_dist = (size_t)ps->t_steps * ps->s_steps;
     HIP_TRY(hipMalloc(&env->d_occ, n_occ * sizeof(float)), "occupancy map allocation failed");
     HIP_TRY(hipMalloc(&env->d_dist, n_dist * sizeof(float)), "distance map allocation failed");
+    HIP_TRY(hipMalloc(&env->d_dist_lon, n_occ * 2 * sizeof(float)), "longitudinal distance map allocation failed");
+    HIP_TRY(hipMalloc(&env->d_frames, sizeof(tplhip::StationFrame) * (size_t)ps->s_steps), "station frame allocation failed");
+    HIP_TRY(hipMemset(env->d_dist_lon, 0, n_occ * 2 * sizeof(float)), "longitudinal distance map clear failed");
     // a freshly allocated cudaArray is read as all-free road until update() ran
     HIP_TRY(hipMemset(env->d_occ, 0, n_occ * sizeof(float)), "occupancy map clear failed");
     HIP_TRY(hipMemset(env->d_dist, 0, n_dist * sizeof(float)), "distance map clear failed");

@@ -165,14 +165,25 @@ class LonTraj:
         return res
 
 
-class DynProgEnvironment:
-    """The slice of tplcpp.DynProgEnvironment (bindings_dp_env.cu:53-105) that
-    the longitudinal planner reads: its parameters and the Frenet occupancy map.
+class RefLine:
+    """tplcpp.RefLine as far as Python callers read it (bindings_dp_common.cu:21-36):
+    the centred points, the step size and the offsets that were subtracted."""
 
-    The reference fills ``occ_map`` with its OpenGL occupancy pipeline
-    (``insert_geometry`` + ``update``; env.cu:352-437), which is outside the hot
-    path; here the map is handed over with :meth:`set_occ_map` in the layout
-    ``get_occ_map`` returns it in (``[l_steps, s_steps, t_steps]`` float32).
+    def __init__(self, points=None, step_size=0.0, x_offset=0.0, y_offset=0.0):
+        self.points = np.zeros((0, 9)) if points is None else points
+        self.step_size = step_size
+        self.x_offset = x_offset
+        self.y_offset = y_offset
+
+
+class DynProgEnvironment:
+    """tplcpp.DynProgEnvironment (bindings_dp_env.cu:53-105).
+
+    ``set_ref_line`` + ``insert_geometry`` + ``update`` run the occupancy pipeline
+    (env.cu:352-437) on the GPU: the triangle soup is rasterised by a compute
+    kernel instead of OpenGL (tpl_amd/csrc/dp_env.hip).  ``set_occ_map`` is an
+    addition: it hands a Frenet occupancy map over directly, in the layout
+    ``get_occ_map`` returns (``[l_steps, s_steps, t_steps]`` float32).
     """
 
     def __init__(self, device=-1):
@@ -180,6 +191,7 @@ class DynProgEnvironment:
         self._lib = _capi.load()
         check(self._lib.tplhip_dp_env_create(int(device), C.byref(self._h)))
         self.params = DynProgEnvParams()
+        self.ref_line = RefLine()
         self.reinit_buffers(self.params, True)          # env.cu:282-285
 
     def __del__(self):
@@ -213,10 +225,53 @@ class DynProgEnvironment:
         check(self._lib.tplhip_dp_env_get_dist_map_path(self._h, _fptr(dist)))
         return dist
 
+    # ---- occupancy pipeline, bindings_dp_env.cu:64-105 ----
+
+    def set_ref_line(self, ref_line, step_size):
+        ref_line = np.ascontiguousarray(ref_line, dtype=np.float64)
+        if ref_line.ndim != 2 or ref_line.shape[1] != 9:
+            raise ValueError(f"array has incorrect shape, expected: (-1, 9), got: {ref_line.shape}")
+        check(self._lib.tplhip_dp_env_set_ref_line(self._h, ref_line.ctypes.data_as(C.POINTER(C.c_double)),
+                                                   ref_line.shape[0], float(step_size)))
+        xo, yo = C.c_double(), C.c_double()
+        check(self._lib.tplhip_dp_env_ref_line_offset(self._h, C.byref(xo), C.byref(yo)))
+        pts = ref_line.copy()
+        pts[:, 0] -= xo.value
+        pts[:, 1] -= yo.value
+        self.ref_line = RefLine(pts, np.float32(step_size), xo.value, yo.value)
+
+    def insert_geometry(self, geom, stationary):
+        geom = np.ascontiguousarray(geom, dtype=np.float64)
+        if geom.ndim != 2 or geom.shape[1] != 3:
+            raise ValueError(f"array has incorrect shape, expected: (-1, 3), got: {geom.shape}")
+        check(self._lib.tplhip_dp_env_insert_geometry(self._h, geom.ctypes.data_as(C.POINTER(C.c_double)),
+                                                      geom.shape[0], 1 if stationary else 0))
+
     def update(self):
-        raise NotImplementedError(
-            "the OpenGL occupancy pipeline (env.cu:381-437) is outside the hot path; "
-            "hand the Frenet occupancy map over with set_occ_map()")
+        check(self._lib.tplhip_dp_env_update(self._h))
+
+    def get_occ_map_cartesian(self):
+        n = C.c_int()
+        check(self._lib.tplhip_dp_env_cart_size(self._h, C.byref(n)))
+        img = np.zeros((n.value, n.value), dtype=np.uint32)
+        check(self._lib.tplhip_dp_env_get_occ_map_cartesian(self._h, img.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return img
+
+    def get_dist_map_lon(self):
+        out = np.empty(self._shape() + (2,), dtype=np.float32)
+        check(self._lib.tplhip_dp_env_get_dist_map_lon(self._h, _fptr(out)))
+        return out
+
+    def get_dist_map_dir(self, idx_t):
+        # the reference never launches updateDirDistMap (env.cu:160-217 has no caller), so the
+        # array it hands out is the zero-initialised allocation
+        p = self.params
+        return np.zeros((p.dir_steps, p.l_steps, p.s_steps), dtype=np.float32)
+
+    def get_dist(self, t, s, l, dt=0.0):
+        out = C.c_float()
+        check(self._lib.tplhip_dp_env_get_dist(self._h, float(t), float(s), float(l), C.byref(out)))
+        return out.value
 
 
 class DynProgLonPlanner:

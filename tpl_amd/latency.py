@@ -67,5 +67,31 @@ def dp_default_plan(device=0, plans=60):
                     "host path in, host trajectory out"}
 
 
+def env_update(device=0, updates=60, n_objects=10):
+    """The occupancy pipeline as dp_env.py:128-170 drives it per planning cycle:
+    reinit_buffers + set_ref_line + insert_geometry per predicted object + update()."""
+    import tpl_amd
+    from . import scenarios as sc
+    ep = sc.env_params(t_steps=10, s_steps=201, l_steps=31)
+    rl, step, objs = sc.env_scene("arc", seed=1, n_objects=n_objects)
+    env = tpl_amd.DynProgEnvironment(device)
+    lat = []
+    for k in range(updates):
+        t0 = time.perf_counter()
+        env.reinit_buffers(ep)
+        env.set_ref_line(rl, step)
+        for g, st in objs:
+            env.insert_geometry(g, st)
+        env.update()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = np.array(lat[5:])
+    n_tri = sum(len(g) for g, _ in objs) // 3
+    return {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "updates": int(len(lat)),
+            "triangles": int(n_tri),
+            "what": f"reinit_buffers + set_ref_line + {n_objects} x insert_geometry + update(): {n_tri} triangles into an "
+                    "840x840 image, 201x31x10 Frenet cells, distance maps; host geometry in"}
+
+
 def run(device=0):
-    return {"mpc_closed_loop": mpc_closed_loop(device), "dp_default_plan": dp_default_plan(device)}
+    return {"mpc_closed_loop": mpc_closed_loop(device), "dp_default_plan": dp_default_plan(device),
+            "env_update": env_update(device)}

@@ -110,3 +110,98 @@ def random_initial_states(n, seed=5):
     v0 = rng.uniform(2.0, 14.0, size=n)
     a0 = rng.uniform(-1.0, 1.0, size=n)
     return [initial_state(0.0, float(v), float(a)) for v, a in zip(v0, a0)]
+
+
+# --------------------------------------------------------------------------
+# inputs of the occupancy pipeline: reference lines and the
+# triangle soups tpl's prediction code hands to insert_geometry
+# --------------------------------------------------------------------------
+
+def ref_line_straight(n=440, step=0.5, x0=100.0, y0=-40.0, heading=0.3, d_left=4.5, d_right=4.5,
+                      v_max=13.9, semantic_range=None):
+    """float64[n, 9] = RefLinePoint{x, y, heading, s, k, v_max, d_left, d_right, semantic}:
+    a straight road through (x0, y0)."""
+    s = np.arange(n, dtype=np.float64) * step
+    rl = np.zeros((n, 9))
+    rl[:, 0] = x0 + s * np.cos(heading)
+    rl[:, 1] = y0 + s * np.sin(heading)
+    rl[:, 2] = heading
+    rl[:, 3] = s
+    rl[:, 5] = v_max
+    rl[:, 6] = d_left
+    rl[:, 7] = d_right
+    if semantic_range is not None:
+        rl[semantic_range[0]:semantic_range[1], 8] = 1.0
+    return rl
+
+
+def ref_line_arc(n=440, step=0.5, radius=120.0, x0=-30.0, y0=10.0, heading0=2.9, d_left=5.0, d_right=3.0,
+                 v_max=11.0, semantic_range=None):
+    """A left-hand arc whose heading crosses +-pi (exercises the short-angle interpolation)."""
+    s = np.arange(n, dtype=np.float64) * step
+    h = heading0 + s / radius
+    rl = np.zeros((n, 9))
+    rl[:, 0] = x0 + radius * (np.sin(h) - np.sin(heading0))
+    rl[:, 1] = y0 - radius * (np.cos(h) - np.cos(heading0))
+    rl[:, 2] = np.arctan2(np.sin(h), np.cos(h))
+    rl[:, 3] = s
+    rl[:, 4] = 1.0 / radius
+    rl[:, 5] = v_max
+    rl[:, 6] = d_left
+    rl[:, 7] = d_right
+    if semantic_range is not None:
+        rl[semantic_range[0]:semantic_range[1], 8] = 1.0
+    return rl
+
+
+def frenet_to_cart(rl, step, s, l):
+    """Point at station s, lateral offset l of a reference line (linear between samples)."""
+    a = np.clip(s / step, 0, len(rl) - 1)
+    i0 = int(np.floor(a))
+    i1 = min(i0 + 1, len(rl) - 1)
+    w = a - i0
+    x = rl[i0, 0] * (1 - w) + rl[i1, 0] * w
+    y = rl[i0, 1] * (1 - w) + rl[i1, 1] * w
+    h = rl[i0, 2]
+    return x - l * np.sin(h), y + l * np.cos(h)
+
+
+def prediction_soup(rl, step, s0, v, length, l_lo, l_hi, ts, sweep=0.5, station_step=5.0):
+    """Triangle soup float64[n, 3] = (x, y, t) shaped like tpl's prediction geometry
+    (utils.cpp:576-693): per time ts[i] the object covers stations
+    [s0 + v t - length/2, s0 + v t + length/2 + max(sweep, dt) v], cut into quads of at most
+    ``station_step`` metres, two triangles each, between the lateral offsets l_lo and l_hi."""
+    out = []
+    for i, t in enumerate(ts):
+        dt = (ts[i + 1] - t) if i + 1 < len(ts) else (ts[i] - ts[i - 1] if i > 0 else 1.0)
+        a = s0 + v * t - 0.5 * length
+        b = s0 + v * t + 0.5 * length + max(sweep, dt) * v
+        k = max(1, int(np.ceil((b - a) / station_step)))
+        cuts = np.linspace(a, b, k + 1)
+        for c0, c1 in zip(cuts[:-1], cuts[1:]):
+            p00 = frenet_to_cart(rl, step, c0, l_lo)
+            p10 = frenet_to_cart(rl, step, c1, l_lo)
+            p01 = frenet_to_cart(rl, step, c0, l_hi)
+            p11 = frenet_to_cart(rl, step, c1, l_hi)
+            for p in (p00, p10, p01, p01, p10, p11):
+                out.append((p[0], p[1], t))
+    return np.array(out, dtype=np.float64).reshape(-1, 3)
+
+
+def env_scene(kind="straight", seed=0, n_objects=6, t_steps=10, dt=1.0):
+    """(ref_line, step, [(geom, stationary), ...]) for the occupancy pipeline tests and bench."""
+    rng = np.random.default_rng(seed)
+    step = 0.5
+    if kind == "straight":
+        rl = ref_line_straight(step=step, semantic_range=(150, 190))
+    else:
+        rl = ref_line_arc(step=step, semantic_range=(120, 170))
+    ts = np.array([0.0] + [dt + i * dt for i in range(t_steps - 1)])
+    objs = []
+    for k in range(n_objects):
+        stationary = (k % 3 == 2)
+        s0 = float(rng.uniform(20.0, 180.0))
+        v = 0.0 if stationary else float(rng.uniform(0.5, 9.0))
+        lc = float(rng.uniform(-3.0, 3.0))
+        objs.append((prediction_soup(rl, step, s0, v, 4.5, lc - 1.0, lc + 1.0, ts), stationary))
+    return rl, step, objs
