@@ -49,6 +49,32 @@ def env_cpu_baseline(reps=20):
             "sample": f"{reps} updates of the same scene"}
 
 
+def poly_lat_cpu_baseline(reps=10):
+    """oracle/poly_lat_oracle.c (one thread) on the scene of latency.poly_lat_update."""
+    import numpy as np
+    import oracle_env as oe
+    import oracle_poly_lat as opl
+    import tpl_amd
+    from tpl_amd import scenarios
+    ep = scenarios.env_params(t_steps=10, s_steps=201, l_steps=31)
+    rl, step, objs = scenarios.env_scene("arc", seed=1, n_objects=10)
+    o = oe.OracleEnv(ep)
+    o.set_ref_line(rl, step)
+    for g, st in objs:
+        o.insert_geometry(g, st)
+    _, occ, _ = o.update()
+    start = tpl_amd.PolyLatTrajPoint()
+    start.s, start.l, start.dl, start.v = 5.0, 0.4, 0.05, 8.0
+    p = tpl_amd.PolyLatPlannerParams()
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        opl.plan(p, o.c, start, o.ref, o.step, o.offsets, occ)
+        t.append((time.perf_counter() - t0) * 1e3)
+    return {"value": float(np.median(t)), "unit": "ms per update", "cores": 1, "kind": "port",
+            "sample": f"{reps} updates of the same scene"}
+
+
 def dp_setup(grid, device):
     import tpl_amd
     from tpl_amd import scenarios as sc
@@ -211,6 +237,7 @@ def main():
             out["secondary"] = {"batched_ilqr": bench_ilqr.run(local_rank),
                                 "plan_latency": latency.run(local_rank)}
             out["secondary"]["plan_latency"]["env_update"]["cpu_baseline"] = env_cpu_baseline()
+            out["secondary"]["plan_latency"]["poly_lat_update"]["cpu_baseline"] = poly_lat_cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

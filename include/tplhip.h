@@ -189,6 +189,67 @@ TPLHIP_API int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n);
 TPLHIP_API int tplhip_dp_lon_timing_enable(tplhip_dp_lon* h, int enable);
 TPLHIP_API int tplhip_dp_lon_timing_get(tplhip_dp_lon* h, double* sweep_ms, int64_t* sweep_launches);
 
+/* ------------- lateral polynomial planner (poly_lat_planner.cu) -- */
+
+/* PolyLatPlannerParams, poly_lat_planner.cuh:11-59 (field order kept) */
+typedef struct TplPolyLatParams {
+    float l_min, l_max, s_min, s_max;
+    int s_steps;
+    float l_dst_min, l_dst_max, s_dst_min, s_dst_max;
+    int l_dst_steps, s_dst_steps;
+    float l_trg;
+    float w_l, w_k, w_dl, w_ddl, w_dddl, w_right, w_len;
+    float k_abs_max, a_lat_abs_max;
+    float width_veh, length_veh;
+    float _s_step_size, _l_dst_step_size, _s_dst_step_size;
+} TplPolyLatParams;
+
+/* PolyLatTrajPoint, poly_lat_planner.cuh:61-76 (72 bytes with natural alignment) */
+typedef struct TplPolyLatTrajPoint {
+    float t, l, dl, ddl, dddl, s, v;
+    double x, y;
+    float heading;
+    double distance;
+    float k;
+} TplPolyLatTrajPoint;
+
+/* PolyQuintic, poly_interp.cuh:34-61 */
+typedef struct TplPolyQuintic {
+    double x0, x1, d;
+    double c[6];
+} TplPolyQuintic;
+
+typedef struct tplhip_poly_lat tplhip_poly_lat;
+
+TPLHIP_API void tplhip_poly_lat_params_default(TplPolyLatParams* p);
+/* PolyQuintic(x0, y0, dy0, ddy0, x1, y1, dy1, ddy1) and f / df / ddf / dddf (order = 0..3),
+ * poly_interp.cu:96-168, 384-416.  Host only. */
+TPLHIP_API void tplhip_poly_quintic_init(TplPolyQuintic* q, double x0, double y0, double dy0, double ddy0,
+                                         double x1, double y1, double dy1, double ddy1);
+TPLHIP_API double tplhip_poly_quintic_eval(const TplPolyQuintic* q, int order, double x);
+
+TPLHIP_API int tplhip_poly_lat_create(int device, tplhip_poly_lat** out);
+TPLHIP_API int tplhip_poly_lat_destroy(tplhip_poly_lat* h);
+/* PolyLatPlanner::reinitBuffers, poly_lat_planner.cu:330-352; step sizes are written back */
+TPLHIP_API int tplhip_poly_lat_reinit(tplhip_poly_lat* h, TplPolyLatParams* ps);
+/* PolyLatPlanner::update, poly_lat_planner.cu:354-486: evaluates the l_dst x s_dst lattice of
+ * quintic paths on the environment (reference line + occupancy of its last update), selects
+ * one, and returns its s_steps points (x, y include the reference line offsets), the quintic
+ * and the selected lattice indices. */
+TPLHIP_API int tplhip_poly_lat_update(tplhip_poly_lat* h, const TplPolyLatTrajPoint* start, tplhip_dp_env* env,
+                                      TplPolyLatTrajPoint* out_points, TplPolyQuintic* out_poly,
+                                      int* best_idx_l_dst, int* best_idx_s_dst);
+/* Debug / parity: the node lattice after the last update, float[l_dst][s_dst][s][4] =
+ * (l, v, collision station or 10000, local cost); element s = 0 of every path holds
+ * (.., .., min collision station, path cost) like the reference's path_nodes. */
+TPLHIP_API int tplhip_poly_lat_copy_nodes(tplhip_poly_lat* h, float* out);
+/* PolyLatTraj::updateTimeDistCurv / lerp, poly_lat_planner.cu:255-320.  Host only.  The
+ * reference reads one element past the end for the LAST point's curvature (undefined);
+ * here that curvature is 0. */
+TPLHIP_API int tplhip_poly_lat_traj_update(TplPolyLatTrajPoint* points, int n);
+TPLHIP_API int tplhip_poly_lat_traj_lerp(const TplPolyLatTrajPoint* points, int n, double distance,
+                                         TplPolyLatTrajPoint* out);
+
 #ifdef __cplusplus
 }
 #endif

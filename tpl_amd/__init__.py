@@ -21,7 +21,16 @@ from .dyn_prog import (  # noqa: E402
     lon_dynamics,
 )
 
+from .poly_lat import (  # noqa: E402
+    PolyLatPlanner,
+    PolyLatPlannerParams,
+    PolyLatTraj,
+    PolyLatTrajPoint,
+    PolyQuintic,
+)
+
 __all__ = [
+    "PolyLatPlanner", "PolyLatPlannerParams", "PolyLatTraj", "PolyLatTrajPoint", "PolyQuintic",
     "DynProgEnvParams", "DynProgEnvironment", "DynProgLonPlanner", "DynProgLonPlannerParams",
     "LonState", "LonTraj", "cuda_get_device_count", "lon_dynamics",
 ]

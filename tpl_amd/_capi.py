@@ -64,6 +64,41 @@ class TplDpEnvParams(C.Structure):
     ]
 
 
+class TplPolyLatParams(C.Structure):
+    """PolyLatPlannerParams, library/include/tplcpp/dyn_prog/poly_lat_planner.cuh:11-59."""
+    _fields_ = [
+        ("l_min", C.c_float), ("l_max", C.c_float), ("s_min", C.c_float), ("s_max", C.c_float),
+        ("s_steps", C.c_int32),
+        ("l_dst_min", C.c_float), ("l_dst_max", C.c_float), ("s_dst_min", C.c_float), ("s_dst_max", C.c_float),
+        ("l_dst_steps", C.c_int32), ("s_dst_steps", C.c_int32),
+        ("l_trg", C.c_float),
+        ("w_l", C.c_float), ("w_k", C.c_float), ("w_dl", C.c_float), ("w_ddl", C.c_float),
+        ("w_dddl", C.c_float), ("w_right", C.c_float), ("w_len", C.c_float),
+        ("k_abs_max", C.c_float), ("a_lat_abs_max", C.c_float),
+        ("width_veh", C.c_float), ("length_veh", C.c_float),
+        ("_s_step_size", C.c_float), ("_l_dst_step_size", C.c_float), ("_s_dst_step_size", C.c_float),
+    ]
+
+
+class TplPolyLatTrajPoint(C.Structure):
+    """PolyLatTrajPoint, poly_lat_planner.cuh:61-76."""
+    _fields_ = [
+        ("t", C.c_float), ("l", C.c_float), ("dl", C.c_float), ("ddl", C.c_float), ("dddl", C.c_float),
+        ("s", C.c_float), ("v", C.c_float),
+        ("x", C.c_double), ("y", C.c_double),
+        ("heading", C.c_float),
+        ("distance", C.c_double),
+        ("k", C.c_float),
+    ]
+
+
+class TplPolyQuintic(C.Structure):
+    """PolyQuintic, library/include/tplcpp/poly_interp.cuh:34-61."""
+    _fields_ = [("x0", C.c_double), ("x1", C.c_double), ("d", C.c_double), ("c", C.c_double * 6)]
+
+
+assert C.sizeof(TplPolyLatTrajPoint) == 72
+
 _P = C.POINTER
 _vp = C.c_void_p
 _fp = _P(C.c_float)
@@ -91,6 +126,17 @@ SIGNATURES = {
     "tplhip_dp_env_get_occ_map_cartesian": (C.c_int, [_vp, _P(C.c_uint32)]),
     "tplhip_dp_env_get_dist_map_lon": (C.c_int, [_vp, _fp]),
     "tplhip_dp_env_get_dist": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, _fp]),
+    "tplhip_poly_lat_params_default": (None, [_P(TplPolyLatParams)]),
+    "tplhip_poly_quintic_init": (None, [_P(TplPolyQuintic)] + [C.c_double] * 8),
+    "tplhip_poly_quintic_eval": (C.c_double, [_P(TplPolyQuintic), C.c_int, C.c_double]),
+    "tplhip_poly_lat_create": (C.c_int, [C.c_int, _P(_vp)]),
+    "tplhip_poly_lat_destroy": (C.c_int, [_vp]),
+    "tplhip_poly_lat_reinit": (C.c_int, [_vp, _P(TplPolyLatParams)]),
+    "tplhip_poly_lat_update": (C.c_int, [_vp, _P(TplPolyLatTrajPoint), _vp, _P(TplPolyLatTrajPoint),
+                                         _P(TplPolyQuintic), _P(C.c_int), _P(C.c_int)]),
+    "tplhip_poly_lat_copy_nodes": (C.c_int, [_vp, _fp]),
+    "tplhip_poly_lat_traj_update": (C.c_int, [_P(TplPolyLatTrajPoint), C.c_int]),
+    "tplhip_poly_lat_traj_lerp": (C.c_int, [_P(TplPolyLatTrajPoint), C.c_int, C.c_double, _P(TplPolyLatTrajPoint)]),
     "tplhip_dp_lon_create": (C.c_int, [C.c_int, _P(_vp)]),
     "tplhip_dp_lon_destroy": (C.c_int, [_vp]),
     "tplhip_dp_lon_reinit": (C.c_int, [_vp, _P(TplDpLonParams)]),

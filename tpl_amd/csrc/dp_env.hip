@@ -234,50 +234,6 @@ __global__ void k_get_dist(float* __restrict__ out, const float* __restrict__ oc
     out[0] = lerp1(lerp1(b00, b10, ts.w), lerp1(b01, b11, ts.w), tt.w);
 }
 
-// ---- host-side reference line arithmetic --------------------------------------
-
-// normalizeAngle / shortAngleDist, utils.hpp:21-53
-double normalize_angle(double x)
-{
-    x = std::fmod(x, 2 * M_PI);
-    x = std::fmod(x + 2 * M_PI, 2 * M_PI);
-    if (x > M_PI) x -= 2 * M_PI;
-    return x;
-}
-
-double short_angle_dist(double x, double y)
-{
-    x = normalize_angle(x);
-    y = normalize_angle(y);
-    double a0 = y - x;
-    const double a1 = y - x + 2 * M_PI;
-    const double a2 = y - x - 2 * M_PI;
-    if (std::fabs(a1) < std::fabs(a0)) a0 = a1;
-    if (std::fabs(a2) < std::fabs(a0)) a0 = a2;
-    return a0;
-}
-
-// interpRefLine, utils.hpp:148-173, reduced to what occupancyToFrenet reads
-StationFrame station_frame(const std::vector<RefPoint>& rl, float step_size, float s)
-{
-    const int len = (int)rl.size();
-    float a = s / step_size;
-    const int i0 = std::max(0, std::min(len - 1, (int)std::floor(a)));
-    const int i1 = std::max(0, std::min(len - 1, (int)std::ceil(a)));
-    a -= (float)i0;
-    const float ia = (float)(1.0 - (double)a);
-    StationFrame f;
-    f.x = rl[i0].x * (double)ia + rl[i1].x * (double)a;
-    f.y = rl[i0].y * (double)ia + rl[i1].y * (double)a;
-    const double heading = rl[i0].heading + short_angle_dist(rl[i0].heading, rl[i1].heading) * (double)a;
-    f.sin_h = std::sin(heading);
-    f.cos_h = std::cos(heading);
-    f.v_max = rl[i0].v_max * (double)ia + rl[i1].v_max * (double)a;
-    f.d_left = rl[i0].d_left * (double)ia + rl[i1].d_left * (double)a;
-    f.d_right = rl[i0].d_right * (double)ia + rl[i1].d_right * (double)a;
-    return f;
-}
-
 template <typename T>
 int ensure_capacity(T** ptr, size_t* cap, size_t need, const char* what)
 {

@@ -3,6 +3,8 @@
 // occupancy -> longitudinal distance map).
 #pragma once
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <vector>
 
@@ -21,7 +23,50 @@ struct EnvVertex { float x, y; uint32_t flags; };
 // What occupancyToFrenet (env.cu:11-63) needs of interpRefLine(s) for one station: computed once
 // per station on the host in the reference's mixed float/double arithmetic (the reference
 // recomputes it, sin and cos included, for every (t, s, l) cell)
-struct StationFrame { double x, y, sin_h, cos_h, d_left, d_right, v_max; };
+struct StationFrame { double x, y, sin_h, cos_h, d_left, d_right, v_max, k, heading; };
+
+// normalizeAngle / shortAngleDist, utils.hpp:21-53
+inline double normalize_angle(double x)
+{
+    x = std::fmod(x, 2 * M_PI);
+    x = std::fmod(x + 2 * M_PI, 2 * M_PI);
+    if (x > M_PI) x -= 2 * M_PI;
+    return x;
+}
+
+inline double short_angle_dist(double x, double y)
+{
+    x = normalize_angle(x);
+    y = normalize_angle(y);
+    double a0 = y - x;
+    const double a1 = y - x + 2 * M_PI;
+    const double a2 = y - x - 2 * M_PI;
+    if (std::fabs(a1) < std::fabs(a0)) a0 = a1;
+    if (std::fabs(a2) < std::fabs(a0)) a0 = a2;
+    return a0;
+}
+
+// interpRefLine, utils.hpp:148-173, at one station (host)
+inline StationFrame station_frame(const std::vector<RefPoint>& rl, float step_size, float s)
+{
+    const int len = (int)rl.size();
+    float a = s / step_size;
+    const int i0 = std::max(0, std::min(len - 1, (int)std::floor(a)));
+    const int i1 = std::max(0, std::min(len - 1, (int)std::ceil(a)));
+    a -= (float)i0;
+    const float ia = (float)(1.0 - (double)a);
+    StationFrame f;
+    f.x = rl[i0].x * (double)ia + rl[i1].x * (double)a;
+    f.y = rl[i0].y * (double)ia + rl[i1].y * (double)a;
+    f.heading = rl[i0].heading + short_angle_dist(rl[i0].heading, rl[i1].heading) * (double)a;
+    f.sin_h = std::sin(f.heading);
+    f.cos_h = std::cos(f.heading);
+    f.k = rl[i0].k * (double)ia + rl[i1].k * (double)a;
+    f.v_max = rl[i0].v_max * (double)ia + rl[i1].v_max * (double)a;
+    f.d_left = rl[i0].d_left * (double)ia + rl[i1].d_left * (double)a;
+    f.d_right = rl[i0].d_right * (double)ia + rl[i1].d_right * (double)a;
+    return f;
+}
 
 }  // namespace tplhip
 

@@ -92,6 +92,41 @@ def env_update(device=0, updates=60, n_objects=10):
                     "840x840 image, 201x31x10 Frenet cells, distance maps; host geometry in"}
 
 
+def poly_lat_scene(device=0):
+    import tpl_amd
+    from . import scenarios as sc
+    ep = sc.env_params(t_steps=10, s_steps=201, l_steps=31)
+    rl, step, objs = sc.env_scene("arc", seed=1, n_objects=10)
+    env = tpl_amd.DynProgEnvironment(device)
+    env.reinit_buffers(ep)
+    env.set_ref_line(rl, step)
+    for g, st in objs:
+        env.insert_geometry(g, st)
+    env.update()
+    start = tpl_amd.PolyLatTrajPoint()
+    start.s, start.l, start.dl, start.v = 5.0, 0.4, 0.05, 8.0
+    return ep, rl, step, objs, env, start
+
+
+def poly_lat_update(device=0, updates=60):
+    """PolyLatPlanner.update with the reference's default lattice (21 x 13 quintics x 201 stations)."""
+    import tpl_amd
+    ep, rl, step, objs, env, start = poly_lat_scene(device)
+    p = tpl_amd.PolyLatPlannerParams()
+    pl = tpl_amd.PolyLatPlanner(device)
+    lat = []
+    for k in range(updates):
+        start.l = 0.4 + 0.001 * (k % 7)
+        t0 = time.perf_counter()
+        pl.reinit_buffers(p)
+        pl.update(start, env)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = np.array(lat[5:])
+    return {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "updates": int(len(lat)),
+            "what": "reinit_buffers + PolyLatPlanner.update: 21 x 13 quintic paths x 201 stations (local costs, travel "
+                    "times, collision look-ups, selection) + final trajectory; host start state in, host trajectory out"}
+
+
 def run(device=0):
     return {"mpc_closed_loop": mpc_closed_loop(device), "dp_default_plan": dp_default_plan(device),
-            "env_update": env_update(device)}
+            "env_update": env_update(device), "poly_lat_update": poly_lat_update(device)}
