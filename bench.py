@@ -134,10 +134,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal hook for a one-GPU box: TPL_BENCH_REHEARSAL=1 runs the N > 1 code path with every rank on
+    # device 0 and the all-gather over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearsal = world > 1 and os.environ.get("TPL_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
     if not torch.cuda.is_available():
@@ -156,22 +164,31 @@ def main():
     from tpl_amd import sharding
     import numpy as np
 
-    def step():
-        dp.plan_resident(env)
-        if dist is not None:
-            # the path's only exchange: best-plan record of this rank -> all ranks (RCCL all-gather)
-            tr = np.array([[s.t, s.s, s.v, s.a, s.j, s.cost, s.constr] for s in dp.download()[0].states],
-                          dtype=np.float32)
-            sharding.allgather_best(sharding.plan_record(tr, rank), dist, torch.device("cuda", local_rank))
+    # N > 1: the path's only exchange is the best-plan record of every rank -> all ranks (RCCL
+    # all-gather of 1.4 KB).  It is pipelined one step deep: the plan of step k is copied
+    # out behind its kernels, and gathered while the GPU already runs step k+1.
+    def exchange(slot):
+        tr = np.array([[s.t, s.s, s.v, s.a, s.j, s.cost, s.constr] for s in dp.collect_download(slot)[0].states],
+                      dtype=np.float32)
+        sharding.allgather_best(sharding.plan_record(tr, rank), dist,
+                                torch.device("cpu") if rehearsal else torch.device("cuda", local_rank))
 
-    for _ in range(args.warmup):
-        step()
+    def run(n):
+        for k in range(n):
+            dp.plan_resident(env)
+            if dist is not None:
+                dp.stage_download(k & 1)
+                if k > 0:
+                    exchange((k - 1) & 1)
+        if dist is not None and n > 0:
+            exchange((n - 1) & 1)
+
+    run(args.warmup)
     dp.sync()
     dp.timing_enable(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     dp.sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -179,7 +196,7 @@ def main():
     dp.timing_enable(False)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -181,6 +181,12 @@ TPLHIP_API int tplhip_dp_lon_upload(tplhip_dp_lon* h, int n, const TplLonState* 
 TPLHIP_API int tplhip_dp_lon_plan_resident(tplhip_dp_lon* h, tplhip_dp_env* env);
 TPLHIP_API int tplhip_dp_lon_sync(tplhip_dp_lon* h);
 TPLHIP_API int tplhip_dp_lon_download(tplhip_dp_lon* h, TplLonState* out_trajs);
+/* Pipelined form of download for callers that keep enqueuing plans: stage_download enqueues the
+ * copy of the plan just enqueued into one of two pinned host slots (behind it on the stream, so a
+ * following plan_resident does not disturb it); collect_download waits for THAT copy only and
+ * hands the trajectories out -- the next plan keeps the GPU busy meanwhile. */
+TPLHIP_API int tplhip_dp_lon_stage_download(tplhip_dp_lon* h, int slot);
+TPLHIP_API int tplhip_dp_lon_collect_download(tplhip_dp_lon* h, int slot, TplLonState* out_trajs);
 /* Launch geometry and code path of the sweep kernel as a small JSON object (diagnostics). */
 TPLHIP_API int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n);
 /* HIP-event timing of the backward sweeps (events recorded on the planner's

@@ -235,3 +235,35 @@ def test_division_modes_agree(monkeypatch):
     tables, otrajs, _ = O.update(cp, cep, path2, occ, [sc.initial_state(0.0, 8.0, 0.0)])
     _assert_tables_equal(dp, tables, T)
     assert np.array_equal(_traj_np(trajs[0]).view(np.uint32), otrajs[0].view(np.uint32))
+
+
+def test_pipelined_downloads_match_the_blocking_one():
+    """stage_download / collect_download (two slots, a plan enqueued behind each copy) hand out the
+    same trajectories as the blocking download of the same plans."""
+    S, V, A, T = 64, 24, 12, 8
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    env = tpl_amd.DynProgEnvironment()
+    env.reinit_buffers(ep)
+    env.set_occ_map(sc.occ_map(ep, sc.OBSTACLES_OVERTAKE))
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p)
+    inits = [[sc.initial_state(0.0, 4.0 + k, 0.0)] for k in range(4)]
+    want = []
+    for ini in inits:
+        dp.upload(ini, path)
+        dp.plan_resident(env)
+        want.append(_traj_np(dp.download()[0]))
+    got = []
+    for k, ini in enumerate(inits):
+        dp.upload(ini, path)
+        dp.plan_resident(env)
+        dp.stage_download(k & 1)
+        if k > 0:
+            got.append(_traj_np(dp.collect_download((k - 1) & 1)[0]))
+    got.append(_traj_np(dp.collect_download((len(inits) - 1) & 1)[0]))
+    for a, b in zip(got, want):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    with pytest.raises(RuntimeError, match="no download staged"):
+        dp.collect_download(0)

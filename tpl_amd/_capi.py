@@ -148,6 +148,8 @@ SIGNATURES = {
     "tplhip_dp_lon_plan_resident": (C.c_int, [_vp, _vp]),
     "tplhip_dp_lon_sync": (C.c_int, [_vp]),
     "tplhip_dp_lon_download": (C.c_int, [_vp, _P(TplLonState)]),
+    "tplhip_dp_lon_stage_download": (C.c_int, [_vp, C.c_int]),
+    "tplhip_dp_lon_collect_download": (C.c_int, [_vp, C.c_int, _P(TplLonState)]),
     "tplhip_dp_lon_info": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "tplhip_dp_lon_timing_enable": (C.c_int, [_vp, C.c_int]),
     "tplhip_dp_lon_timing_get": (C.c_int, [_vp, _P(C.c_double), _P(C.c_int64)]),

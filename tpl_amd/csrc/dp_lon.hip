@@ -812,6 +812,12 @@ struct tplhip_dp_lon {
     int verified_mode = 0;
     unsigned int* d_flag = nullptr;           // [4]: path {float, double}, range {float, double}
 
+    // two staged downloads in flight (pinned host buffers + completion events)
+    TplLonState* h_stage[2] = {nullptr, nullptr};
+    size_t stage_cap[2] = {0, 0};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};
+
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double sweep_ms = 0.0;
@@ -1191,6 +1197,10 @@ int tplhip_dp_lon_destroy(tplhip_dp_lon* h)
     hipFree(h->d_inits);
     hipFree(h->d_trajs);
     hipFree(h->d_flag);
+    for (int i = 0; i < 2; ++i) {
+        if (h->h_stage[i]) hipHostFree(h->h_stage[i]);
+        if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]);
+    }
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return TPLHIP_OK;
@@ -1390,6 +1400,37 @@ int tplhip_dp_lon_download(tplhip_dp_lon* h, TplLonState* out_trajs)
     HIP_TRY(hipMemcpyAsync(out_trajs, h->d_trajs, sizeof(TplLonState) * (size_t)h->n_rollouts * h->params.t_steps,
                            hipMemcpyDeviceToHost, h->stream), "copying trajectory failed");
     HIP_TRY(hipStreamSynchronize(h->stream), "lon planner forward pass failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_stage_download(tplhip_dp_lon* h, int slot)
+{
+    if (!h || slot < 0 || slot > 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
+    if (h->n_rollouts < 1) return tplhip_fail(TPLHIP_ESTATE, "nothing to download");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    const size_t n = (size_t)h->n_rollouts * h->params.t_steps;
+    if (n > h->stage_cap[slot]) {
+        if (h->h_stage[slot]) hipHostFree(h->h_stage[slot]);
+        h->h_stage[slot] = nullptr; h->stage_cap[slot] = 0;
+        HIP_TRY(hipHostMalloc(&h->h_stage[slot], sizeof(TplLonState) * n, hipHostMallocDefault), "pinned buffer allocation failed");
+        h->stage_cap[slot] = n;
+    }
+    if (!h->stage_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[slot], hipEventDisableTiming), "event creation failed");
+    HIP_TRY(hipMemcpyAsync(h->h_stage[slot], h->d_trajs, sizeof(TplLonState) * n, hipMemcpyDeviceToHost, h->stream),
+            "copying trajectory failed");
+    HIP_TRY(hipEventRecord(h->stage_ev[slot], h->stream), "event record failed");
+    h->stage_busy[slot] = true;
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_collect_download(tplhip_dp_lon* h, int slot, TplLonState* out_trajs)
+{
+    if (!h || !out_trajs || slot < 0 || slot > 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
+    if (!h->stage_busy[slot]) return tplhip_fail(TPLHIP_ESTATE, "no download staged in slot %d", slot);
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipEventSynchronize(h->stage_ev[slot]), "lon planner forward pass failed");
+    std::memcpy(out_trajs, h->h_stage[slot], sizeof(TplLonState) * (size_t)h->n_rollouts * h->params.t_steps);
+    h->stage_busy[slot] = false;
     return TPLHIP_OK;
 }
 

@@ -357,6 +357,15 @@ class DynProgLonPlanner:
         check(self._lib.tplhip_dp_lon_download(self._h, out))
         return [LonTraj._from_array(out[i * T:(i + 1) * T]) for i in range(n)]
 
+    def stage_download(self, slot):
+        check(self._lib.tplhip_dp_lon_stage_download(self._h, int(slot)))
+
+    def collect_download(self, slot):
+        n, T = self._n_up, self.params.t_steps
+        out = (TplLonState * (n * T))()
+        check(self._lib.tplhip_dp_lon_collect_download(self._h, int(slot), out))
+        return [LonTraj._from_array(out[i * T:(i + 1) * T]) for i in range(n)]
+
     def info(self):
         import json
         buf = C.create_string_buffer(512)
