@@ -75,6 +75,33 @@ def poly_lat_cpu_baseline(reps=10):
             "sample": f"{reps} updates of the same scene"}
 
 
+def lat_lon_cpu_baseline(reps=3):
+    """oracle/lat_lon_oracle.c (OpenMP over cells) on the scene and grid of latency.lat_lon_update."""
+    import numpy as np
+    import oracle_env as oe
+    import oracle_lat_lon as oll
+    import tpl_amd
+    from tpl_amd import scenarios
+    ep = scenarios.env_params(t_steps=10, s_steps=201, l_steps=31)
+    rl, step, objs = scenarios.env_scene("arc", seed=1, n_objects=10)
+    o = oe.OracleEnv(ep)
+    o.set_ref_line(rl, step)
+    for g, st in objs:
+        o.insert_geometry(g, st)
+    _, _, dist_lon = o.update()
+    p = tpl_amd.DynProgLatLonPlannerParams()
+    p.length_veh, p.width_veh = 4.9, 1.9
+    start = tpl_amd.LatLonState()
+    start.s, start.ds, start.l = 2.0, 8.0, 0.3
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        oll.update_traj_dp(p, o.c, dist_lon, o.ref, o.step, start)
+        t.append((time.perf_counter() - t0) * 1e3)
+    return {"value": float(np.median(t)), "unit": "ms per update_traj_dp", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{reps} plans of the same scene (OpenMP over cells)"}
+
+
 def dp_setup(grid, device):
     import tpl_amd
     from tpl_amd import scenarios as sc
@@ -255,6 +282,7 @@ def main():
                                 "plan_latency": latency.run(local_rank)}
             out["secondary"]["plan_latency"]["env_update"]["cpu_baseline"] = env_cpu_baseline()
             out["secondary"]["plan_latency"]["poly_lat_update"]["cpu_baseline"] = poly_lat_cpu_baseline()
+            out["secondary"]["plan_latency"]["lat_lon_update"]["cpu_baseline"] = lat_lon_cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -256,6 +256,71 @@ TPLHIP_API int tplhip_poly_lat_traj_update(TplPolyLatTrajPoint* points, int n);
 TPLHIP_API int tplhip_poly_lat_traj_lerp(const TplPolyLatTrajPoint* points, int n, double distance,
                                          TplPolyLatTrajPoint* out);
 
+/* --------- lateral/longitudinal DP planner (lat_lon_planner.cu) -- */
+
+/* DynProgLatLonPlannerParams, lat_lon_planner.cuh:9-62 (field order kept) */
+typedef struct TplLatLonParams {
+    float s_min, s_max, ds_min, ds_max, l_min, l_max;
+    float dds_min, dds_max, dl_min, dl_max;
+    int t_steps, s_steps, ds_steps, l_steps;
+    float dt, dt_start, dt_smooth_traj;
+    float dds_start, w_dds_start, angle_start, w_angle_start;
+    float l_trg;
+    float w_progress, w_dds, w_ddds, w_l, w_dl, w_ddl, w_safety_dist, w_xing_slow;
+    float slope_abs_max;
+    float w_lat_dist, d_lat_comf;
+    float time_gap, gap_min;
+    float t_st_min, t_st_max, s_st, w_spatio_temporal;
+    float width_veh, length_veh;
+} TplLatLonParams;
+
+/* LatLonState, lat_lon_planner.cuh:81-103 (48 bytes) */
+typedef struct TplLatLonState {
+    float t;
+    float s, ds, dds, ddds;
+    float l, dl, ddl, dddl;
+    float cost, constr;
+    uint8_t flags_constr;            /* LatLonConstr: 1 occupancy, 2 velocity, 4 angle */
+} TplLatLonState;
+
+/* LatLonCartState, lat_lon_planner.cuh:64-79 (88 bytes) */
+typedef struct TplLatLonCartState {
+    double t, distance, x, y, v, a, heading, k, cost, constr;
+    uint8_t flags_constr;
+} TplLatLonCartState;
+
+typedef struct tplhip_lat_lon tplhip_lat_lon;
+
+TPLHIP_API void tplhip_lat_lon_params_default(TplLatLonParams* p);
+/* dp_lat_lon_planner_cu::dynamics, lat_lon_planner.cu:10-22.  Host. */
+TPLHIP_API void tplhip_lat_lon_dynamics(const TplLatLonState* x0, float dds, float dl, float dt, TplLatLonState* out);
+/* LatLonTraj::state / lerp, LatLonCartTraj::lerp, lat_lon_planner.cu:432-486.  Host. */
+TPLHIP_API int tplhip_lat_lon_traj_state(const TplLatLonState* states, int n, float t, TplLatLonState* out);
+TPLHIP_API int tplhip_lat_lon_traj_lerp(const TplLatLonState* states, int n, float t, TplLatLonState* out);
+TPLHIP_API int tplhip_lat_lon_cart_lerp(const TplLatLonCartState* states, int n, float t, TplLatLonCartState* out);
+
+TPLHIP_API int tplhip_lat_lon_create(int device, tplhip_lat_lon** out);
+TPLHIP_API int tplhip_lat_lon_destroy(tplhip_lat_lon* h);
+/* DynProgLatLonPlanner::reinitBuffers, lat_lon_planner.cu:515-577 */
+TPLHIP_API int tplhip_lat_lon_reinit(tplhip_lat_lon* h, const TplLatLonParams* ps, int force);
+/* updateTrajDp, :579-643: states[0] is the start state; the t_steps states of the DP plan come
+ * back in states[0..t_steps-1].  Needs an environment whose update() ran. */
+TPLHIP_API int tplhip_lat_lon_update_traj_dp(tplhip_lat_lon* h, tplhip_dp_env* env, TplLatLonState* states);
+/* updateTrajSmooth, :645-760 (host: resampling + two LQR smoothing passes, utils.hpp:278-348).
+ * smooth0 = trajSmooth.states[0]; out holds up to cap states, *n_out their number. */
+TPLHIP_API int tplhip_lat_lon_update_traj_smooth(tplhip_lat_lon* h, const TplLatLonState* traj_dp, int n_dp,
+                                                 const TplLatLonState* smooth0, TplLatLonState* out, int cap, int* n_out);
+/* frenetToCartesian, :768-817 (host), on the reference line the environment holds */
+TPLHIP_API int tplhip_lat_lon_frenet_to_cartesian(tplhip_dp_env* env, const TplLatLonState* traj, int n,
+                                                  TplLatLonCartState* out);
+/* reevalTraj, :819-859 */
+TPLHIP_API int tplhip_lat_lon_reeval_traj(tplhip_lat_lon* h, tplhip_dp_env* env, const TplLatLonState* traj, int n,
+                                          TplLatLonState* out);
+/* copyBackwardPassTex / queryBackwardPassTex, :861-901: float[l_steps][ds_steps][s_steps][4] =
+ * (cost, constr, dds*, dl*) of stage idx_t; the query is the point-sampled lookup */
+TPLHIP_API int tplhip_lat_lon_copy_backward_pass_tex(tplhip_lat_lon* h, int idx_t, float* out);
+TPLHIP_API int tplhip_lat_lon_query_backward_pass_tex(tplhip_lat_lon* h, int idx_t, float s, float ds, float l, float* out4);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,7 +219,7 @@ PLO_API void plo_lattice(const TplPolyLatParams* p, const TplDpEnvParams* ep, co
                 cost += p->w_dl * sqf(pdl);
                 cost += p->w_ddl * sqf(pddl);
                 cost += p->w_dddl * sqf(pdddl);
-                if (fabsf(pk) > fabsf(rp.k)) cost += p->w_k * sqf(pk);
+                if (fabsf(pk) > fabsf((float)rp.k)) cost += p->w_k * sqf(pk);      /* fabsf(double) converts first */
                 cost += 10e6 * constr;
                 float* n = NODE(idx_l_dst, idx_s_dst, idx_s);
                 n[0] = pl; n[1] = pv; n[2] = 0.0; n[3] = cost;

@@ -21,6 +21,14 @@ from .dyn_prog import (  # noqa: E402
     lon_dynamics,
 )
 
+from .lat_lon import (  # noqa: E402
+    DynProgLatLonPlanner,
+    DynProgLatLonPlannerParams,
+    LatLonCartState,
+    LatLonCartTraj,
+    LatLonState,
+    LatLonTraj,
+)
 from .poly_lat import (  # noqa: E402
     PolyLatPlanner,
     PolyLatPlannerParams,
@@ -30,6 +38,8 @@ from .poly_lat import (  # noqa: E402
 )
 
 __all__ = [
+    "DynProgLatLonPlanner", "DynProgLatLonPlannerParams", "LatLonCartState", "LatLonCartTraj", "LatLonState",
+    "LatLonTraj",
     "PolyLatPlanner", "PolyLatPlannerParams", "PolyLatTraj", "PolyLatTrajPoint", "PolyQuintic",
     "DynProgEnvParams", "DynProgEnvironment", "DynProgLonPlanner", "DynProgLonPlannerParams",
     "LonState", "LonTraj", "cuda_get_device_count", "lon_dynamics",

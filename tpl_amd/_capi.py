@@ -99,6 +99,34 @@ class TplPolyQuintic(C.Structure):
 
 assert C.sizeof(TplPolyLatTrajPoint) == 72
 
+
+class TplLatLonParams(C.Structure):
+    """DynProgLatLonPlannerParams, library/include/tplcpp/dyn_prog/lat_lon_planner.cuh:9-62."""
+    _fields_ = (
+        [(n, C.c_float) for n in ("s_min", "s_max", "ds_min", "ds_max", "l_min", "l_max",
+                                  "dds_min", "dds_max", "dl_min", "dl_max")]
+        + [(n, C.c_int32) for n in ("t_steps", "s_steps", "ds_steps", "l_steps")]
+        + [(n, C.c_float) for n in ("dt", "dt_start", "dt_smooth_traj", "dds_start", "w_dds_start", "angle_start",
+                                    "w_angle_start", "l_trg", "w_progress", "w_dds", "w_ddds", "w_l", "w_dl", "w_ddl",
+                                    "w_safety_dist", "w_xing_slow", "slope_abs_max", "w_lat_dist", "d_lat_comf",
+                                    "time_gap", "gap_min", "t_st_min", "t_st_max", "s_st", "w_spatio_temporal",
+                                    "width_veh", "length_veh")])
+
+
+class TplLatLonState(C.Structure):
+    """LatLonState, lat_lon_planner.cuh:81-103."""
+    _fields_ = [(n, C.c_float) for n in ("t", "s", "ds", "dds", "ddds", "l", "dl", "ddl", "dddl", "cost", "constr")] \
+        + [("flags_constr", C.c_uint8)]
+
+
+class TplLatLonCartState(C.Structure):
+    """LatLonCartState, lat_lon_planner.cuh:64-79."""
+    _fields_ = [(n, C.c_double) for n in ("t", "distance", "x", "y", "v", "a", "heading", "k", "cost", "constr")] \
+        + [("flags_constr", C.c_uint8)]
+
+
+assert C.sizeof(TplLatLonState) == 48 and C.sizeof(TplLatLonCartState) == 88
+
 _P = C.POINTER
 _vp = C.c_void_p
 _fp = _P(C.c_float)
@@ -126,6 +154,21 @@ SIGNATURES = {
     "tplhip_dp_env_get_occ_map_cartesian": (C.c_int, [_vp, _P(C.c_uint32)]),
     "tplhip_dp_env_get_dist_map_lon": (C.c_int, [_vp, _fp]),
     "tplhip_dp_env_get_dist": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, _fp]),
+    "tplhip_lat_lon_params_default": (None, [_P(TplLatLonParams)]),
+    "tplhip_lat_lon_dynamics": (None, [_P(TplLatLonState), C.c_float, C.c_float, C.c_float, _P(TplLatLonState)]),
+    "tplhip_lat_lon_traj_state": (C.c_int, [_P(TplLatLonState), C.c_int, C.c_float, _P(TplLatLonState)]),
+    "tplhip_lat_lon_traj_lerp": (C.c_int, [_P(TplLatLonState), C.c_int, C.c_float, _P(TplLatLonState)]),
+    "tplhip_lat_lon_cart_lerp": (C.c_int, [_P(TplLatLonCartState), C.c_int, C.c_float, _P(TplLatLonCartState)]),
+    "tplhip_lat_lon_create": (C.c_int, [C.c_int, _P(_vp)]),
+    "tplhip_lat_lon_destroy": (C.c_int, [_vp]),
+    "tplhip_lat_lon_reinit": (C.c_int, [_vp, _P(TplLatLonParams), C.c_int]),
+    "tplhip_lat_lon_update_traj_dp": (C.c_int, [_vp, _vp, _P(TplLatLonState)]),
+    "tplhip_lat_lon_update_traj_smooth": (C.c_int, [_vp, _P(TplLatLonState), C.c_int, _P(TplLatLonState),
+                                                    _P(TplLatLonState), C.c_int, _P(C.c_int)]),
+    "tplhip_lat_lon_frenet_to_cartesian": (C.c_int, [_vp, _P(TplLatLonState), C.c_int, _P(TplLatLonCartState)]),
+    "tplhip_lat_lon_reeval_traj": (C.c_int, [_vp, _vp, _P(TplLatLonState), C.c_int, _P(TplLatLonState)]),
+    "tplhip_lat_lon_copy_backward_pass_tex": (C.c_int, [_vp, C.c_int, _fp]),
+    "tplhip_lat_lon_query_backward_pass_tex": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, C.c_float, _fp]),
     "tplhip_poly_lat_params_default": (None, [_P(TplPolyLatParams)]),
     "tplhip_poly_quintic_init": (None, [_P(TplPolyQuintic)] + [C.c_double] * 8),
     "tplhip_poly_quintic_eval": (C.c_double, [_P(TplPolyQuintic), C.c_int, C.c_double]),

@@ -127,6 +127,39 @@ def poly_lat_update(device=0, updates=60):
                     "times, collision look-ups, selection) + final trajectory; host start state in, host trajectory out"}
 
 
+def lat_lon_update(device=0, updates=40):
+    """DynProgLatLonPlanner.update_traj_dp on the reference's default grid (201 x 37 x 21, 10 stages,
+    49 actions backward, 441 forward) + smoothing + Cartesian conversion."""
+    import tpl_amd
+    ep, rl, step, objs, env, _ = poly_lat_scene(device)
+    p = tpl_amd.DynProgLatLonPlannerParams()
+    p.length_veh, p.width_veh = 4.9, 1.9
+    pl = tpl_amd.DynProgLatLonPlanner(device)
+    start = tpl_amd.LatLonState()
+    start.s, start.ds, start.l = 2.0, 8.0, 0.3
+    lat, lat_dp = [], []
+    for k in range(updates):
+        start.l = 0.3 + 0.001 * (k % 5)
+        t0 = time.perf_counter()
+        pl.reinit_buffers(p)
+        pl.traj_dp[0] = start
+        pl.traj_smooth[0] = start
+        pl.update_traj_dp(env)
+        t1 = time.perf_counter()
+        pl.update_traj_smooth(env)
+        pl.update_traj_cart(env)
+        lat.append((time.perf_counter() - t0) * 1e3)
+        lat_dp.append((t1 - t0) * 1e3)
+    lat, lat_dp = np.array(lat[5:]), np.array(lat_dp[5:])
+    cells = p.s_steps * p.ds_steps * p.l_steps
+    return {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+            "update_traj_dp_p50_ms": float(np.percentile(lat_dp, 50)), "updates": int(len(lat)),
+            "cell_updates_per_s": float(cells * (p.t_steps - 1) / (np.percentile(lat_dp, 50) * 1e-3)),
+            "what": "reinit_buffers + update_traj_dp (9 backward stages of 201x37x21 cells x 49 actions, forward "
+                    "rollout of 441 actions per stage) + update_traj_smooth + update_traj_cart; host states in and out"}
+
+
 def run(device=0):
     return {"mpc_closed_loop": mpc_closed_loop(device), "dp_default_plan": dp_default_plan(device),
-            "env_update": env_update(device), "poly_lat_update": poly_lat_update(device)}
+            "env_update": env_update(device), "poly_lat_update": poly_lat_update(device),
+            "lat_lon_update": lat_lon_update(device)}
