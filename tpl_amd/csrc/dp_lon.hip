@@ -359,7 +359,7 @@ __device__ __forceinline__ f2 f2_floor(f2 x) { return (f2){floorf(x.x), floorf(x
 __device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 template <int DIVMODE, bool USE_BUF>
-__global__ void __launch_bounds__(512) k_backward2(const Node* __restrict__ next, Node* __restrict__ out,
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) k_backward2(const Node* __restrict__ next, Node* __restrict__ out,
                             const ActDesc* __restrict__ acts,
                             const float* __restrict__ path,
                             const float* __restrict__ pre_vmax,    // this stage, [s_steps]
@@ -440,14 +440,21 @@ __global__ void __launch_bounds__(512) k_backward2(const Node* __restrict__ next
     const int buf_slots = row_slots * rows_per_block;      // one of the two alternating buffers
     float4* Rrow = R + rib * row_slots;
     const bool dup_last = (is1 == S - 1) && (S == 2 * half);
-    f2 res0[N_BWD], res1[N_BWD];      // (cost, constr) of action k at station 0 / 1
+    // Running lexicographic argmin per station, (constr, cost, action), instead of keeping all nine
+    // results for the two passes of lon_planner.cu:153-170: 6 registers instead of 36, i.e. one more
+    // resident wave per SIMD.  A lower constraint value opens a new class (cost reset to +inf, action
+    // to 0, exactly the second pass' start values); inside the class the first strictly lower cost
+    // wins.  Identical to the two passes unless a constraint value is NaN -- excluded by the host for
+    // this kernel (tplhip_dp_lon::params_bounded / path_bounded).
+    float bg0 = INFINITY, bc0 = INFINITY, bg1 = INFINITY, bc1 = INFINITY;
+    int bk0 = 0, bk1 = 0;
 
-    // Software pipeline over the nine actions: the eight row loads of action k+1 are issued
-    // right after action k's blend has gone to LDS, so they are in flight while phase 2 of
-    // action k runs.  The barrier is a bare s_barrier behind an LDS-only wait (__syncthreads
-    // would also drain vmcnt, i.e. wait for the prefetch).  Two LDS row buffers alternate, so
-    // one barrier per action is enough: whoever writes buffer (k+1)&1 has passed barrier k,
-    // which every lane reaches only after its phase 2 of action k-1 -- the last reader of it.
+    // One barrier per action: two LDS row buffers alternate, and whoever writes buffer (k+1)&1 has
+    // passed barrier k, which every lane reaches only after its phase 2 of action k-1 -- the last
+    // reader of that buffer.  The barrier is a bare s_barrier behind an LDS-only wait.
+    // (Issuing the eight row loads of action k+1 before phase 2 of action k -- a software pipeline
+    // -- was measured and dropped: the 24 registers it holds cost two resident waves per SIMD,
+    // 51.4 vs 49.2 us per 256x128x64 sweep.)
     float4 ld[8];
     auto issue_loads = [&](int k) {
         const ActDesc* d = acts + (size_t)row * N_BWD + k;
@@ -467,12 +474,12 @@ __global__ void __launch_bounds__(512) k_backward2(const Node* __restrict__ next
             ld[2] = ld_node(r01 + js0); ld[6] = ld_node(r01 + js1); ld[3] = ld_node(r11 + js0); ld[7] = ld_node(r11 + js1);
         }
     };
-    issue_loads(0);
 
 #pragma unroll
     for (int k = 0; k < N_BWD; ++k) {
         const ActDesc* d = acts + (size_t)row * N_BWD + k;
         float4* Rk = Rrow + (k & 1) * buf_slots;
+        issue_loads(k);
         // ---- phase 1: blend the four neighbouring next-stage rows (a, then v), both stations
         {
             const float wa = d->wa, iwa = d->iwa, wv = d->wv, iwv = d->iwv;
@@ -482,7 +489,6 @@ __global__ void __launch_bounds__(512) k_backward2(const Node* __restrict__ next
             Rk[is1] = r1;
             if (dup_last) Rk[S] = r1;
         }
-        if (k + 1 < N_BWD) issue_loads(k + 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // ---- phase 2: successor station, 1-D lerp, costs -- the two stations as one float2
         {
@@ -555,33 +561,20 @@ __global__ void __launch_bounds__(512) k_backward2(const Node* __restrict__ next
             f2 o0 = r0 + tail, o1 = r1 + tail;
             // pin the results here: with nothing but the final argmin using them, the compiler
             // otherwise sinks the tail of this action below the next barrier and spills its inputs
-            asm volatile("" : "+v"(o0), "+v"(o1));
-            res0[k] = o0;
-            res1[k] = o1;
+            {
+                const bool lower0 = o0.y < bg0, lower1 = o1.y < bg1;
+                bg0 = lower0 ? o0.y : bg0; bc0 = lower0 ? INFINITY : bc0; bk0 = lower0 ? 0 : bk0;
+                bg1 = lower1 ? o1.y : bg1; bc1 = lower1 ? INFINITY : bc1; bk1 = lower1 ? 0 : bk1;
+                const bool take0 = !(o0.y > bg0) && (o0.x < bc0), take1 = !(o1.y > bg1) && (o1.x < bc1);
+                bc0 = take0 ? o0.x : bc0; bk0 = take0 ? k : bk0;
+                bc1 = take1 ? o1.x : bc1; bk1 = take1 ? k : bk1;
+                asm volatile("" : "+v"(bg0), "+v"(bc0), "+v"(bk0), "+v"(bg1), "+v"(bc1), "+v"(bk1));
+            }
         }
     }
 
-    // lexicographic argmin, lon_planner.cu:153-170, per station (selects, no divergence)
-#pragma unroll
-    for (int cidx = 0; cidx < 2; ++cidx) {
-        const f2* res = cidx == 0 ? res0 : res1;
-        float constr_min = INFINITY;
-#pragma unroll
-        for (int k = 0; k < N_BWD; ++k) {
-            constr_min = (res[k].y < constr_min) ? res[k].y : constr_min;
-        }
-        float cost_min = INFINITY;
-        int idx_min = 0;
-#pragma unroll
-        for (int k = 0; k < N_BWD; ++k) {
-            const bool take = !(res[k].y > constr_min) && (res[k].x < cost_min);
-            cost_min = take ? res[k].x : cost_min;
-            idx_min = take ? k : idx_min;
-        }
-        const float j_best = action_jerk(p, idx_min, N_BWD);
-        if (cidx == 0 ? act0 : act1)
-            st_node(out + (size_t)row * S + (cidx == 0 ? is0 : is1), cost_min, constr_min, j_best);
-    }
+    if (act0) st_node(out + (size_t)row * S + is0, bc0, bg0, action_jerk(p, bk0, N_BWD));
+    if (act1) st_node(out + (size_t)row * S + is1, bc1, bg1, action_jerk(p, bk1, N_BWD));
 }
 
 // ------------------------------------------------------------------------
@@ -800,6 +793,13 @@ struct tplhip_dp_lon {
     // launch geometry of k_backward
     int s_pad = 0, rows_per_block = 0, nblocks = 0, grid = 0, kchunk = 0;
     int cells = 1;                       // stations per lane: 2 selects k_backward2 (s_pad = 2 * half)
+    // k_backward2 keeps a RUNNING lexicographic argmin, which equals the reference's two-pass argmin
+    // whenever no NaN can occur; that is guaranteed when every parameter and path value is finite
+    // and below 1e6 in magnitude (see reinit).  Otherwise the plan runs k_backward<.., 1, ..> with
+    // the geometry below.
+    bool params_bounded = false, path_bounded = false, env_bounded = false;
+    int x_s_pad = 0, x_rpb = 0, x_nblocks = 0, x_grid = 0;
+    size_t x_lds = 0;
     int tile_v = 8, tile_a = 8;          // traversal tiles, see k_backward
     size_t lds_bytes = 0;
 
@@ -949,12 +949,30 @@ void launch_terminal(tplhip_dp_lon* h, int idx_t)
                        h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a);
 }
 
+// two-pass argmin kernel on the fallback geometry (inputs outside the bounded range)
+template <int DIVMODE>
+void launch_exact(tplhip_dp_lon* h, int idx_t, int nx)
+{
+    const size_t S = (size_t)h->params.s_steps;
+    const bool buf = h->table_cells * sizeof(Node) < 0xffffffffull && !std::getenv("TPLHIP_NO_BUFLOAD");
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(h->x_grid), dim3(h->x_s_pad * h->x_rpb), h->x_lds, h->stream,
+                           h->d_tables + (size_t)nx * h->table_cells, h->d_tables + (size_t)idx_t * h->table_cells,
+                           h->d_acts, h->d_path, h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
+                           h->d_pre_prog, h->params, h->x_s_pad, h->x_rpb, h->x_nblocks,
+                           h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a);
+    };
+    if (buf) go(k_backward<false, 1, DIVMODE, true>);
+    else go(k_backward<false, 1, DIVMODE, false>);
+}
+
 template <int DIVMODE>
 void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
 {
     if (h->cells == 2) {
         if (terminal) launch_terminal(h, i);                         // rule R4
-        else launch_backward2<DIVMODE>(h, i, nx);
+        else if (h->params_bounded && h->path_bounded && h->env_bounded) launch_backward2<DIVMODE>(h, i, nx);
+        else launch_exact<DIVMODE>(h, i, nx);
     } else if (terminal) {
         launch_backward<true, 1, 0>(h, i, nx);                       // rule R4 (no division in it)
     } else if (h->kchunk == 9) {
@@ -971,6 +989,13 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env)
 {
     const TplDpLonParams& p = h->params;
     const int T = p.t_steps;
+    {
+        const TplDpEnvParams& e = env->params;
+        const float vals[] = {e.s_min, e.s_max, e.l_min, e.l_max, e.dt, e.dt_start};
+        bool ok = true;
+        for (float v : vals) ok = ok && std::isfinite(v) && std::fabs(v) < 1e6f;
+        h->env_bounded = ok;
+    }
 
     // env.updateDistMapPath, lon_planner.cu:343
     hipLaunchKernelGGL(k_dist_map_path, dim3(env->params.t_steps), dim3(256),
@@ -1284,6 +1309,21 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         if ((k == 9 || k == 3 || k == 1) && threads * 16 * (size_t)k + path_lds <= 160 * 1024) h->kchunk = k;
     }
     h->lds_bytes = threads * 16 * (size_t)h->kchunk + path_lds;
+    // fallback geometry of the two-pass kernel (one station per lane, one action per barrier)
+    h->x_s_pad = h->s_pad; h->x_rpb = h->rows_per_block; h->x_nblocks = h->nblocks; h->x_grid = h->grid;
+    h->x_lds = threads * 16 + path_lds;
+    // "bounded": every float parameter finite and < 1e6 in magnitude, at most 1e5 stages.  Then no
+    // cost or constraint sum of the sweep can overflow (largest single term ~ w * (1e6)^2 = 1e18, at
+    // most 1e5 of them), no infinity and hence no NaN can appear, and a running lexicographic argmin
+    // is identical to the two-pass argmin of lon_planner.cu:153-170.
+    {
+        const float vals[] = {p.s_min, p.s_max, p.v_min, p.v_max, p.a_min, p.a_max, p.j_min, p.j_max, p.dt_start, p.dt,
+                              p.time_gap, p.gap_min, p.w_progress, p.w_a, p.w_j, p.w_snap, p.w_safety_dist,
+                              p.path_step_size, p.width_veh, p.length_veh};
+        bool ok = p.t_steps <= 100000;
+        for (float v : vals) ok = ok && std::isfinite(v) && std::fabs(v) < 1e6f;
+        h->params_bounded = ok;
+    }
     // Large grids (one action per barrier) run two stations per lane, see k_backward2.
     h->cells = 1;
     {
@@ -1366,6 +1406,12 @@ int tplhip_dp_lon_upload(tplhip_dp_lon* h, int n, const TplLonState* inits, cons
     int rc = ensure_rollouts(h, n);
     if (rc) return rc;
     h->n_rollouts = n;
+    {
+        bool ok = true;
+        const size_t n_path = 7 * (size_t)h->params.path_steps;
+        for (size_t i = 0; i < n_path; ++i) ok = ok && std::isfinite(path[i]) && std::fabs(path[i]) < 1e6f;
+        h->path_bounded = ok;
+    }
     // lon_planner.cu:334-338 and :365-368
     HIP_TRY(hipMemcpyAsync(h->d_path, path, sizeof(float) * 7 * (size_t)h->params.path_steps,
                            hipMemcpyHostToDevice, h->stream), "copying path failed");
@@ -1504,9 +1550,11 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
     if (!h || !buf || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
     std::snprintf(buf, (size_t)n,
                   "{\"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
-                  "\"div_mode\": %d, \"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"cells\": %d}",
+                  "\"div_mode\": %d, \"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"cells\": %d, "
+                  "\"bounded_inputs\": %d}",
                   h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
-                  h->div_mode, (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->cells);
+                  h->div_mode, (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->cells,
+                  (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0);
     return TPLHIP_OK;
 }
 
