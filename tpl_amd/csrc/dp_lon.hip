@@ -359,7 +359,7 @@ __device__ __forceinline__ f2 f2_floor(f2 x) { return (f2){floorf(x.x), floorf(x
 __device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 template <int DIVMODE, bool USE_BUF>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) k_backward2(const Node* __restrict__ next, Node* __restrict__ out,
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) k_backward2(const Node* __restrict__ next, Node* __restrict__ out,
                             const ActDesc* __restrict__ acts,
                             const float* __restrict__ path,
                             const float* __restrict__ pre_vmax,    // this stage, [s_steps]
@@ -529,8 +529,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))
                 alpha = f2_fma(e, (f2){rcp_path_step, rcp_path_step}, q0);
             } else alpha = (f2){(float)((double)tn_s.x * rcp_path_step_d), (float)((double)tn_s.y * rcp_path_step_d)};
             const f2 afl = f2_floor(alpha);
-            const f2 up = {alpha.x > afl.x ? 1.0f : 0.0f, alpha.y > afl.y ? 1.0f : 0.0f};
-            const f2 aup = afl + up;
+            const f2 aup = {ceilf(alpha.x), ceilf(alpha.y)};
             const f2 f0 = {__builtin_amdgcn_fmed3f(afl.x, 0.0f, path_top), __builtin_amdgcn_fmed3f(afl.y, 0.0f, path_top)};
             const f2 f1 = {__builtin_amdgcn_fmed3f(aup.x, 0.0f, path_top), __builtin_amdgcn_fmed3f(aup.y, 0.0f, path_top)};
             const f2 pa = alpha - f0;
@@ -547,15 +546,20 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))
             r0.x += snap.x;
             r1.x += snap.y;
             // lon_planner.cu:114-118 (double compare == float compare, double subtraction)
-            const float lim0 = (float)((double)r0.y + (d->tn_v_d - (double)vmn.x));
-            const float lim1 = (float)((double)r1.y + (d->tn_v_d - (double)vmn.y));
-            r0.y = (d->tn_v > vmn.x) ? lim0 : r0.y;
-            r1.y = (d->tn_v > vmn.y) ? lim1 : r1.y;
+            // lon_planner.cu:114-118: if (tn.v > v_max) constr += tn.v - v_max, in double.  The
+            // addend max(tn.v - v_max, 0) is that difference exactly when the test holds and +0.0
+            // otherwise, and g + 0.0 == g (g is a sum of non-negative terms, never -0): one
+            // v_max_f64 instead of compare + select.  Same for the station-change term in float.
+            r0.y = (float)((double)r0.y + fmax(d->tn_v_d - (double)vmn.x, 0.0));
+            r1.y = (float)((double)r1.y + fmax(d->tn_v_d - (double)vmn.y, 0.0));
             const f2 s_change = tn_s - s;
             const f2 over = s_change - s_dist;
-            const f2 g_over = (f2){r0.y, r1.y} + over;
-            r0.y = (s_change.x > s_dist.x) ? g_over.x : r0.y;
-            r1.y = (s_change.y > s_dist.y) ? g_over.y : r1.y;
+            const f2 over_pos = {fmaxf(over.x, 0.0f), fmaxf(over.y, 0.0f)};
+            {
+                const f2 gg = (f2){r0.y, r1.y} + over_pos;
+                r0.y = gg.x;
+                r1.y = gg.y;
+            }
             // c += wj_cost and g += a_viol are the last addends of their sums in k_backward too
             const f2 tail = {d->wj_cost, d->a_viol};
             f2 o0 = r0 + tail, o1 = r1 + tail;
