@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 python bench.py --steps 20 --warmup 3 > "$OUT/bench_target.json" 2> "$OUT/bench_target.err"
 python bench.py --steps 20 --warmup 3 --grid config2 --no-cpu-baseline --no-secondary > "$OUT/bench_config2.json" 2>/dev/null
 python bench.py --steps 5 --warmup 1 --grid config4 --no-cpu-baseline --no-secondary > "$OUT/bench_config4.json" 2>/dev/null
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp && export PYTHONPATH="$REPO${PYTHONPATH:+:$PYTHONPATH}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_dp" -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/trace_dp.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_ilqr" -- python3 -m tpl_amd.optim.bench_ilqr > "$OUT/trace_ilqr.log" 2>&1
 cd "$REPO"
