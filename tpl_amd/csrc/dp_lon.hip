@@ -358,14 +358,19 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 f2_floor(f2 x) { return (f2){floorf(x.x), floorf(x.y)}; }
 __device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <int DIVMODE, bool USE_BUF>
+// HALF_CT > 0: rows are full (s_steps == 2 * HALF_CT), so the second station of a lane sits at a
+// compile-time distance from the first: its table and LDS addresses become immediate offsets of
+// the first station's (two registers and their arithmetic less -- the difference between 7 and 8
+// resident waves per SIMD, i.e. between 2.3 and exactly 2 residency rounds on 256x128x64).
+// HALF_CT == 0: ragged rows, distances and clamps at run time.
+template <int DIVMODE, bool USE_BUF, int HALF_CT>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) k_backward2(const Node* __restrict__ next, Node* __restrict__ out,
                             const ActDesc* __restrict__ acts,
                             const float* __restrict__ path,
                             const float* __restrict__ pre_vmax,    // this stage, [s_steps]
                             const float* __restrict__ pre_sdist,   // this stage, [s_steps]
                             const double* __restrict__ pre_prog,   // [s_steps]
-                            TplDpLonParams p, int half, int rows_per_block,
+                            TplDpLonParams p, int half_rt, int rows_per_block,
                             float rcp_path_step, double rcp_path_step_d, double rcp_s_range_d,
                             int tile_v, int tile_a)
 {
@@ -375,6 +380,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))
     const int S = p.s_steps, V = p.v_steps, A = p.a_steps;
     const int nrows = V * A;
     const int tid = threadIdx.x;
+    const int half = HALF_CT ? HALF_CT : half_rt;
     const int rib = tid / half;
     const int il = tid - rib * half;
     const int xcd = blockIdx.x & 7;
@@ -397,8 +403,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))
     // the two stations of this lane; a station past the row end computes on the last one and
     // is never stored (keeps the loads unconditional and the barriers uniform)
     const int is0 = il, is1 = il + half;
-    const bool act0 = row_ok && is0 < S, act1 = row_ok && is1 < S;
-    const int js0 = min(is0, S - 1), js1 = min(is1, S - 1);
+    const bool act0 = row_ok && (HALF_CT ? true : is0 < S), act1 = row_ok && (HALF_CT ? true : is1 < S);
+    const int js0 = HALF_CT ? is0 : min(is0, S - 1), js1 = HALF_CT ? is1 : min(is1, S - 1);
 
     const f2 s = {p.s_min + (float)js0 * p._s_step_size, p.s_min + (float)js1 * p._s_step_size};
     const float v = p.v_min + (float)iv * p._v_step_size;
@@ -439,7 +445,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))
     const int row_slots = 2 * half + 1;
     const int buf_slots = row_slots * rows_per_block;      // one of the two alternating buffers
     float4* Rrow = R + rib * row_slots;
-    const bool dup_last = (is1 == S - 1) && (S == 2 * half);
+    const bool dup_last = HALF_CT ? (il == HALF_CT - 1) : ((is1 == S - 1) && (S == 2 * half));
     // Running lexicographic argmin per station, (constr, cost, action), instead of keeping all nine
     // results for the two passes of lon_planner.cu:153-170: 6 registers instead of 36, i.e. one more
     // resident wave per SIMD.  A lower constraint value opens a new class (cost reset to +inf, action
@@ -802,6 +808,7 @@ struct tplhip_dp_lon {
     // and below 1e6 in magnitude (see reinit).  Otherwise the plan runs k_backward<.., 1, ..> with
     // the geometry below.
     bool params_bounded = false, path_bounded = false, env_bounded = false;
+    bool use_buf = false;                // buffer loads: one stage table addressable with 32-bit byte offsets
     int x_s_pad = 0, x_rpb = 0, x_nblocks = 0, x_grid = 0;
     size_t x_lds = 0;
     int tile_v = 8, tile_a = 8;          // traversal tiles, see k_backward
@@ -904,7 +911,7 @@ template <bool TERMINAL, int KCHUNK, int DIVMODE>
 void launch_backward(tplhip_dp_lon* h, int idx_t, int nx)
 {
     // buffer loads need 32-bit byte offsets inside one stage table
-    if (!TERMINAL && h->table_cells * sizeof(Node) < 0xffffffffull && !std::getenv("TPLHIP_NO_BUFLOAD"))
+    if (!TERMINAL && h->use_buf)
         launch_backward_b<TERMINAL, KCHUNK, DIVMODE, true>(h, idx_t, nx);
     else
         launch_backward_b<TERMINAL, KCHUNK, DIVMODE, false>(h, idx_t, nx);
@@ -915,7 +922,12 @@ void launch_backward2_b(tplhip_dp_lon* h, int idx_t, int nx)
 {
     const size_t S = (size_t)h->params.s_steps;
     const int half = h->s_pad / 2;
-    hipLaunchKernelGGL((k_backward2<DIVMODE, USE_BUF>), dim3(h->grid), dim3(half * h->rows_per_block),
+    const bool full = h->params.s_steps == 2 * half;
+    auto kern = (full && half == 64) ? k_backward2<DIVMODE, USE_BUF, 64>
+              : (full && half == 128) ? k_backward2<DIVMODE, USE_BUF, 128>
+              : (full && half == 256) ? k_backward2<DIVMODE, USE_BUF, 256>
+                                      : k_backward2<DIVMODE, USE_BUF, 0>;
+    hipLaunchKernelGGL(kern, dim3(h->grid), dim3(half * h->rows_per_block),
                        h->lds_bytes, h->stream,
                        h->d_tables + (size_t)nx * h->table_cells,
                        h->d_tables + (size_t)idx_t * h->table_cells,
@@ -928,7 +940,7 @@ void launch_backward2_b(tplhip_dp_lon* h, int idx_t, int nx)
 template <int DIVMODE>
 void launch_backward2(tplhip_dp_lon* h, int idx_t, int nx)
 {
-    if (h->table_cells * sizeof(Node) < 0xffffffffull && !std::getenv("TPLHIP_NO_BUFLOAD"))
+    if (h->use_buf)
         launch_backward2_b<DIVMODE, true>(h, idx_t, nx);
     else
         launch_backward2_b<DIVMODE, false>(h, idx_t, nx);
@@ -958,7 +970,7 @@ template <int DIVMODE>
 void launch_exact(tplhip_dp_lon* h, int idx_t, int nx)
 {
     const size_t S = (size_t)h->params.s_steps;
-    const bool buf = h->table_cells * sizeof(Node) < 0xffffffffull && !std::getenv("TPLHIP_NO_BUFLOAD");
+    const bool buf = h->use_buf;
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(h->x_grid), dim3(h->x_s_pad * h->x_rpb), h->x_lds, h->stream,
                            h->d_tables + (size_t)nx * h->table_cells, h->d_tables + (size_t)idx_t * h->table_cells,
@@ -1313,6 +1325,7 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         if ((k == 9 || k == 3 || k == 1) && threads * 16 * (size_t)k + path_lds <= 160 * 1024) h->kchunk = k;
     }
     h->lds_bytes = threads * 16 * (size_t)h->kchunk + path_lds;
+    h->use_buf = h->table_cells * sizeof(Node) < 0xffffffffull && !std::getenv("TPLHIP_NO_BUFLOAD");
     // fallback geometry of the two-pass kernel (one station per lane, one action per barrier)
     h->x_s_pad = h->s_pad; h->x_rpb = h->rows_per_block; h->x_nblocks = h->nblocks; h->x_grid = h->grid;
     h->x_lds = threads * 16 + path_lds;
