@@ -588,6 +588,203 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))
 }
 
 // ------------------------------------------------------------------------
+// Two vertically adjacent ROWS per lane: cells (v, a, s) and (v+1, a, s).
+//
+// What bounds k_backward2 next to VALU issue is the number of vector-memory lane-loads: 36 per
+// cell whatever their width.  Action k of row (v+1, a) lands exactly one v' row above
+// action k of row (v, a), so the two rows' 2x2 source windows overlap in two of their four rows:
+// a lane that owns the same station in both rows needs 6 row loads per action instead of 8, and
+// one of the three a-blends is shared as well.  Whether the windows really overlap (they do not
+// where a successor speed is clamped at the grid edge) is read off the two action descriptors
+// -- a wave-uniform test -- and the lane falls back to 8 loads there.  The station, and with it
+// the stage prelude, is shared by the two cells; everything per (row, action) is per cell.
+// blockDim.x = s_pad (stations, multiple of 64); one workgroup per row pair; needs V % 16 == 0
+// so that every XCD's v range splits into pairs.
+// LDS: float4 R[2 rows][2 buffers][s_pad + 1] | float path_vmax[path_steps]
+// ------------------------------------------------------------------------
+template <int DIVMODE, bool USE_BUF>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8))) k_backward2v(
+                            const Node* __restrict__ next, Node* __restrict__ out,
+                            const ActDesc* __restrict__ acts,
+                            const float* __restrict__ path,
+                            const float* __restrict__ pre_vmax, const float* __restrict__ pre_sdist,
+                            const double* __restrict__ pre_prog,
+                            TplDpLonParams p, int s_pad,
+                            float rcp_path_step, double rcp_path_step_d, double rcp_s_range_d,
+                            int tile_v, int tile_a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = p.s_steps, V = p.v_steps, A = p.a_steps;
+    const int nrows = V * A;
+    const int is = threadIdx.x;
+    // traversal: as k_backward, in units of row pairs (strips of tile_v rows = tile_v/2 pairs)
+    const int xcd = blockIdx.x & 7;
+    const int v_lo = (xcd * V) >> 3, v_hi = ((xcd + 1) * V) >> 3;
+    const int vx = (v_hi - v_lo) >> 1, tv = max(1, tile_v >> 1);
+    const int q = (int)(blockIdx.x >> 3);
+    if (q >= vx * A) return;                                   // whole workgroup, before any barrier
+    int ia, iv;
+    {
+        const int full = vx / tv;
+        int strip = q / (A * tv), w = tv, rem = q - strip * (A * tv);
+        if (strip >= full) { strip = full; w = vx - full * tv; rem = q - full * (A * tv); }
+        const int tile = rem / (tile_a * w);
+        const int r = rem - tile * (tile_a * w);
+        ia = tile * tile_a + r / w;
+        iv = v_lo + 2 * (strip * tv + (r - (r / w) * w));
+    }
+    const int row0 = ia * V + iv, row1 = row0 + 1;
+    const bool active = is < S;
+    const int js = min(is, S - 1);
+
+    const float s = p.s_min + (float)js * p._s_step_size;
+    const f2 v = {p.v_min + (float)iv * p._v_step_size, p.v_min + (float)(iv + 1) * p._v_step_size};
+    const float a = p.a_min + (float)ia * p._a_step_size;
+    const float v_max = pre_vmax[js];
+    const float s_dist = pre_sdist[js];
+    const double prog = pre_prog[js];
+
+    // stateCost lon_planner.cu:40-55
+    f2 sc, sg;
+    {
+        float c0 = 0.0f;
+        c0 += p.w_a * (a * a);
+        const float x = (float)((double)c0 + prog);
+        const f2 gap = (v * p.time_gap + p.gap_min) - s_dist;
+        sc.x = (float)((double)x + (double)p.w_safety_dist * fmax(0.0, (double)gap.x));
+        sc.y = (float)((double)x + (double)p.w_safety_dist * fmax(0.0, (double)gap.y));
+        sg.x = 0.0f; if (v.x > v_max) sg.x += v.x - v_max;
+        sg.y = 0.0f; if (v.y > v_max) sg.y += v.y - v_max;
+    }
+
+    const int row_slots = s_pad + 1;
+    float4* R = reinterpret_cast<float4*>(smem);               // [row c][buffer b][slot]
+    float* pv = reinterpret_cast<float*>(smem + (size_t)4 * row_slots * sizeof(float4));
+    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<Node*>(next), 0, USE_BUF ? (int)((size_t)nrows * S * sizeof(Node)) : 0, 0x00020000);
+    for (int i = is; i < p.path_steps; i += blockDim.x) pv[i] = path[i * 7 + 5];
+
+    const float s_range = p.s_max - p.s_min;
+    const float s_scale = (float)(S - 1);
+    const float path_top = (float)(p.path_steps - 1);
+    const bool dup_last = is == S - 1;
+    float bg0 = INFINITY, bc0 = INFINITY, bg1 = INFINITY, bc1 = INFINITY;     // running argmin, see k_backward2
+    int bk0 = 0, bk1 = 0;
+
+    auto load_row = [&](int r) -> float4 {
+        if (USE_BUF) return buf_load_node(next_rsrc, (unsigned)js * 12u, (unsigned)r * ((unsigned)S * 12u));
+        return ld_node(next + (size_t)r * S + js);
+    };
+
+#pragma unroll
+    for (int k = 0; k < N_BWD; ++k) {
+        const ActDesc* d0 = acts + (size_t)row0 * N_BWD + k;
+        const ActDesc* d1 = acts + (size_t)row1 * N_BWD + k;
+        float4* Rk0 = R + (k & 1) * row_slots;
+        float4* Rk1 = R + (2 + (k & 1)) * row_slots;
+        // ---- phase 1
+        {
+            const float wa0 = d0->wa, iwa0 = d0->iwa, wv0 = d0->wv, iwv0 = d0->iwv;
+            const float wa1 = d1->wa, iwa1 = d1->iwa, wv1 = d1->wv, iwv1 = d1->iwv;
+            // the upper half of row 0's window is the lower half of row 1's, blended with the same weight
+            const bool shared = d0->r01 == d1->r00 && d0->r11 == d1->r10
+                                && __float_as_uint(wa0) == __float_as_uint(wa1);
+            const float4 p00 = load_row(d0->r00), p10 = load_row(d0->r10);
+            const float4 p01 = load_row(d0->r01), p11 = load_row(d0->r11);
+            const float4 q01 = load_row(d1->r01), q11 = load_row(d1->r11);
+            const float4 a0 = lerp4w(p00, p10, wa0, iwa0);
+            const float4 a1 = lerp4w(p01, p11, wa0, iwa0);
+            float4 b0;
+            if (shared) {
+                b0 = a1;
+            } else {
+                const float4 q00 = load_row(d1->r00), q10 = load_row(d1->r10);
+                b0 = lerp4w(q00, q10, wa1, iwa1);
+            }
+            const float4 b1 = lerp4w(q01, q11, wa1, iwa1);
+            const float4 r0 = lerp4w(a0, a1, wv0, iwv0);
+            const float4 r1 = lerp4w(b0, b1, wv1, iwv1);
+            Rk0[is] = r0;
+            Rk1[is] = r1;
+            if (dup_last) { Rk0[S] = r0; Rk1[S] = r1; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ---- phase 2: the two rows as one float2
+        {
+            const f2 sf = s + (f2){d0->vdt, d1->vdt};
+            double sd0 = (double)sf.x + d0->a_term, sd1 = (double)sf.y + d1->a_term;
+            sd0 = sd0 + d0->j_term; sd1 = sd1 + d1->j_term;
+            const f2 tn_s = {fmaxf(s, (float)sd0), fmaxf(s, (float)sd1)};
+            const f2 xs = tn_s - p.s_min;
+            f2 qs;
+            if (DIVMODE == 0) qs = (f2){xs.x / s_range, xs.y / s_range};
+            else qs = (f2){(float)((double)xs.x * rcp_s_range_d), (float)((double)xs.y * rcp_s_range_d)};
+            const f2 cs = qs * s_scale + 0.5f;
+            const f2 xb = cs - 0.5f;
+            const f2 fl = f2_floor(xb);
+            const f2 w256 = (xb - fl) * 256.0f;
+            const f2 ws = (f2){rintf(w256.x), rintf(w256.y)} * (1.0f / 256.0f);
+            const f2 iws = 1.0f - ws;
+            const int lo0 = (int)fminf(fl.x, s_scale), lo1 = (int)fminf(fl.y, s_scale);
+            const float4 nl0 = Rk0[lo0], nh0 = Rk0[lo0 + 1], nl1 = Rk1[lo1], nh1 = Rk1[lo1 + 1];
+            const f2 cg0 = f2_fma((f2){nh0.x, nh0.y}, (f2){ws.x, ws.x}, (f2){nl0.x, nl0.y} * iws.x);
+            const f2 cg1 = f2_fma((f2){nh1.x, nh1.y}, (f2){ws.y, ws.y}, (f2){nl1.x, nl1.y} * iws.y);
+            float nj0 = fmaf(nh0.z, ws.x, nl0.z * iws.x), nj1 = fmaf(nh1.z, ws.y, nl1.z * iws.y);
+            asm volatile("" : "+v"(nj0), "+v"(nj1));
+            const f2 node_j = {nj0, nj1};
+            f2 alpha;
+            if (DIVMODE == 0) alpha = (f2){tn_s.x / p.path_step_size, tn_s.y / p.path_step_size};
+            else if (DIVMODE == 1) {
+                const f2 q0 = tn_s * rcp_path_step;
+                const f2 e = f2_fma(-q0, (f2){p.path_step_size, p.path_step_size}, tn_s);
+                alpha = f2_fma(e, (f2){rcp_path_step, rcp_path_step}, q0);
+            } else alpha = (f2){(float)((double)tn_s.x * rcp_path_step_d), (float)((double)tn_s.y * rcp_path_step_d)};
+            const f2 afl = f2_floor(alpha);
+            const f2 aup = {ceilf(alpha.x), ceilf(alpha.y)};
+            const f2 f0 = {__builtin_amdgcn_fmed3f(afl.x, 0.0f, path_top), __builtin_amdgcn_fmed3f(afl.y, 0.0f, path_top)};
+            const f2 f1 = {__builtin_amdgcn_fmed3f(aup.x, 0.0f, path_top), __builtin_amdgcn_fmed3f(aup.y, 0.0f, path_top)};
+            const f2 pa = alpha - f0;
+            const f2 pia = 1.0f - pa;
+            const f2 pv0 = {pv[(int)f0.x], pv[(int)f0.y]};
+            const f2 pv1 = {pv[(int)f1.x], pv[(int)f1.y]};
+            const f2 vmn = pv0 * pia + pv1 * pa;
+
+            f2 r0 = (f2){sc.x, sg.x} + cg0;
+            f2 r1 = (f2){sc.y, sg.y} + cg1;
+            const f2 dj = node_j - (f2){d0->j, d1->j};
+            const f2 snap = p.w_snap * (dj * dj);
+            r0.x += snap.x;
+            r1.x += snap.y;
+            r0.y = (float)((double)r0.y + fmax(d0->tn_v_d - (double)vmn.x, 0.0));      // see k_backward2
+            r1.y = (float)((double)r1.y + fmax(d1->tn_v_d - (double)vmn.y, 0.0));
+            const f2 s_change = tn_s - s;
+            const f2 over = s_change - s_dist;
+            const f2 over_pos = {fmaxf(over.x, 0.0f), fmaxf(over.y, 0.0f)};
+            {
+                const f2 gg = (f2){r0.y, r1.y} + over_pos;
+                r0.y = gg.x;
+                r1.y = gg.y;
+            }
+            const f2 o0 = r0 + (f2){d0->wj_cost, d0->a_viol};
+            const f2 o1 = r1 + (f2){d1->wj_cost, d1->a_viol};
+            {
+                const bool lower0 = o0.y < bg0, lower1 = o1.y < bg1;
+                bg0 = lower0 ? o0.y : bg0; bc0 = lower0 ? INFINITY : bc0; bk0 = lower0 ? 0 : bk0;
+                bg1 = lower1 ? o1.y : bg1; bc1 = lower1 ? INFINITY : bc1; bk1 = lower1 ? 0 : bk1;
+                const bool take0 = !(o0.y > bg0) && (o0.x < bc0), take1 = !(o1.y > bg1) && (o1.x < bc1);
+                bc0 = take0 ? o0.x : bc0; bk0 = take0 ? k : bk0;
+                bc1 = take1 ? o1.x : bc1; bk1 = take1 ? k : bk1;
+                asm volatile("" : "+v"(bg0), "+v"(bc0), "+v"(bk0), "+v"(bg1), "+v"(bc1), "+v"(bk1));
+            }
+        }
+    }
+    if (active) {
+        st_node(out + (size_t)row0 * S + is, bc0, bg0, action_jerk(p, bk0, N_BWD));
+        st_node(out + (size_t)row1 * S + is, bc1, bg1, action_jerk(p, bk1, N_BWD));
+    }
+}
+
+// ------------------------------------------------------------------------
 // Exhaustive check of the two cheap division forms against the IEEE quotient for EVERY
 // float in [0, x_max] (all three are odd-symmetric, so the sign is covered): ~1e9
 // candidates, about a millisecond, run once per divisor.
@@ -809,6 +1006,9 @@ struct tplhip_dp_lon {
     // the geometry below.
     bool params_bounded = false, path_bounded = false, env_bounded = false;
     bool use_buf = false;                // buffer loads: one stage table addressable with 32-bit byte offsets
+    bool vpair = false;                  // k_backward2v (two rows per lane) instead of k_backward2
+    int vp_s_pad = 0, vp_grid = 0;
+    size_t vp_lds = 0;
     int x_s_pad = 0, x_rpb = 0, x_nblocks = 0, x_grid = 0;
     size_t x_lds = 0;
     int tile_v = 8, tile_a = 8;          // traversal tiles, see k_backward
@@ -946,6 +1146,21 @@ void launch_backward2(tplhip_dp_lon* h, int idx_t, int nx)
         launch_backward2_b<DIVMODE, false>(h, idx_t, nx);
 }
 
+template <int DIVMODE>
+void launch_backward2v(tplhip_dp_lon* h, int idx_t, int nx)
+{
+    const size_t S = (size_t)h->params.s_steps;
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(h->vp_grid), dim3(h->vp_s_pad), h->vp_lds, h->stream,
+                           h->d_tables + (size_t)nx * h->table_cells, h->d_tables + (size_t)idx_t * h->table_cells,
+                           h->d_acts, h->d_path, h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
+                           h->d_pre_prog, h->params, h->vp_s_pad,
+                           h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a);
+    };
+    if (h->use_buf) go(k_backward2v<DIVMODE, true>);
+    else go(k_backward2v<DIVMODE, false>);
+}
+
 // the terminal stage of the two-station geometry: k_backward<true> with one station per lane
 void launch_terminal(tplhip_dp_lon* h, int idx_t)
 {
@@ -987,7 +1202,10 @@ void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
 {
     if (h->cells == 2) {
         if (terminal) launch_terminal(h, i);                         // rule R4
-        else if (h->params_bounded && h->path_bounded && h->env_bounded) launch_backward2<DIVMODE>(h, i, nx);
+        else if (h->params_bounded && h->path_bounded && h->env_bounded) {
+            if (h->vpair) launch_backward2v<DIVMODE>(h, i, nx);
+            else launch_backward2<DIVMODE>(h, i, nx);
+        }
         else launch_exact<DIVMODE>(h, i, nx);
     } else if (terminal) {
         launch_backward<true, 1, 0>(h, i, nx);                       // rule R4 (no division in it)
@@ -1361,6 +1579,13 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
                 max_rows = std::max(max_rows, ((((x + 1) * p.v_steps) >> 3) - ((x * p.v_steps) >> 3)) * p.a_steps);
             h->grid = 8 * ((max_rows + h->rows_per_block - 1) / h->rows_per_block);
             h->lds_bytes = (size_t)2 * (h->s_pad + 1) * h->rows_per_block * 16 + path_lds;
+            // two rows per lane where every XCD's v range splits into pairs
+            h->vp_s_pad = ((p.s_steps + 63) / 64) * 64;
+            h->vp_lds = (size_t)4 * (h->vp_s_pad + 1) * 16 + path_lds;
+            h->vp_grid = 8 * ((p.v_steps / 16) * p.a_steps);
+            const char* vo = std::getenv("TPLHIP_VPAIR");
+            h->vpair = (vo ? std::atoi(vo) != 0 : true) && p.v_steps % 16 == 0 && h->vp_s_pad <= 1024
+                       && (h->tile_v % 2 == 0) && h->vp_lds <= 64 * 1024;
         }
     }
     if (h->lds_bytes > 160 * 1024)
@@ -1568,10 +1793,10 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
     std::snprintf(buf, (size_t)n,
                   "{\"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
                   "\"div_mode\": %d, \"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"cells\": %d, "
-                  "\"bounded_inputs\": %d}",
+                  "\"bounded_inputs\": %d, \"vpair\": %d}",
                   h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
                   h->div_mode, (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->cells,
-                  (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0);
+                  (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0, (h->cells == 2 && h->vpair) ? 1 : 0);
     return TPLHIP_OK;
 }
 
