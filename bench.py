@@ -258,7 +258,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "k_backward2" if dp.info().get("cells") == 2 else "k_backward",
+                "kernel": ("k_backward2v" if dp.info().get("vpair") else "k_backward2") if dp.info().get("cells") == 2
+                          else "k_backward",
                 "launch_us": per_launch_s * 1e6,
                 "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
             },

@@ -24,7 +24,7 @@ def entry(v):
     fetch = v["FETCH_SIZE"] * 1024.0
     write = v["WRITE_SIZE"] * 1024.0
     return {
-        "kernel": "k_backward2",
+        "kernel": "k_backward2v",
         "fetch_size_bytes_raw": fetch,
         "write_size_bytes": write,
         "traffic_bytes_per_launch": 2.0 * fetch + write,
