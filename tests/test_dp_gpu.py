@@ -50,11 +50,19 @@ GRID_CASES = [
     pytest.param(96, 10, 8, 6, (), 0.3, id="dt_start-0.3-rule-R4"),
     pytest.param(512, 8, 6, 4, sc.random_obstacles(7, 5), None, id="s512-kchunk3"),
     pytest.param(1000, 6, 5, 3, sc.random_obstacles(8, 5), None, id="s1000-kchunk1"),
+    # grids several residency rounds deep select the two-cells-per-lane kernels:
+    pytest.param(201, 48, 44, 4, sc.OBSTACLES_OVERTAKE_TRAFFIC, None, id="ragged-rows-two-rows-per-lane"),
+    pytest.param(201, 50, 42, 4, sc.random_obstacles(3, 6), 0.4, id="ragged-rows-two-stations-per-lane"),
+    pytest.param(256, 40, 52, 4, sc.OBSTACLES_OVERTAKE, None, id="full-rows-two-stations-per-lane"),
+    pytest.param(128, 64, 66, 3, sc.random_obstacles(9, 7), None, id="s128-two-rows-per-lane"),
 ]
+
+EXPECTED_KERNEL = {"ragged-rows-two-rows-per-lane": (2, 1), "ragged-rows-two-stations-per-lane": (2, 0),
+                   "full-rows-two-stations-per-lane": (2, 0), "s128-two-rows-per-lane": (2, 1)}
 
 
 @pytest.mark.parametrize("S,V,A,T,obst,dt_start", GRID_CASES)
-def test_tables_and_trajectories_bit_exact(S, V, A, T, obst, dt_start):
+def test_tables_and_trajectories_bit_exact(S, V, A, T, obst, dt_start, request):
     p = sc.lon_params(S, V, A, T, dt_start=dt_start)
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31, dt_start=dt_start)
     path = sc.straight_path(p.path_steps, p.path_step_size)
@@ -62,6 +70,10 @@ def test_tables_and_trajectories_bit_exact(S, V, A, T, obst, dt_start):
     inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(6, seed=5)
     dp, env, trajs, tables, otrajs, dist = _run_both(p, ep, path, occ, inits)
     assert np.array_equal(env.get_dist_map_path().view(np.uint32), dist.view(np.uint32))
+    case = request.node.callspec.id
+    if case in EXPECTED_KERNEL:
+        info = dp.info()
+        assert (info["cells"], info["vpair"]) == EXPECTED_KERNEL[case], info
     _assert_tables_equal(dp, tables, T)
     for r, tr in enumerate(trajs):
         got = _traj_np(tr)
