@@ -136,3 +136,23 @@ def test_planner_on_rendered_scene_matches_oracle_plan():
                    dtype=np.float32)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert got[:, 6].max() == 0.0 and got[-1, 1] > 30.0          # a feasible plan that moves
+
+
+def test_unusual_parameters_and_bit_31():
+    """s_min > 0, asymmetric lateral range, wide dilation, 33 time slices: slice 31 shares its bit with
+    the stationary flag and slices >= 32 have no bit at all (rule G3) -- oracle and GPU must agree on
+    what that means."""
+    ep = sc.env_params(t_steps=33, s_steps=150, l_steps=17)
+    ep.s_min, ep.s_max, ep.l_min, ep.l_max, ep.dilation = 10.0, 160.0, -2.5, 6.0, 2.4
+    ep.dt, ep.dt_start = 0.2, 0.1
+    rl = sc.ref_line_arc(n=400, step=0.5, radius=80.0, semantic_range=(60, 200))
+    ts = np.array([0.0] + [0.1 + 0.2 * i for i in range(32)])
+    objs = [(sc.prediction_soup(rl, 0.5, 40.0, 6.0, 4.5, -1.0, 1.0, ts), False),
+            (sc.prediction_soup(rl, 0.5, 90.0, 0.0, 4.5, 1.0, 3.0, ts[:3]), True),
+            (sc.prediction_soup(rl, 0.5, 120.0, 1.0, 4.5, -2.0, 0.0, ts), False)]
+    env, ref = _run_both(ep, rl, 0.5, objs)
+    _assert_same(env, ref)
+    occ = ref[1]
+    assert occ.shape == (17, 150, 33)
+    assert (occ[:, :, 32] == 1.0).sum() == 0          # no bit for slice 32
+    assert (occ == 3.0).any() and (occ[:, :, 5] == 1.0).any()
