@@ -231,3 +231,54 @@ TPL_HD inline double tpl_blerp(double x0, double y0, double dx, double dy, doubl
     const double p1 = iy.ia * arr.data[iy.start * cols + ix.end] + iy.a * arr.data[iy.end * cols + ix.end];
     return ix.ia * p0 + ix.a * p1;
 }
+
+// ---- quad-cooperative helpers (generated <routine>Q code, device only) -----------------------
+// Four neighbouring lanes (a "quad") hold the same arguments; each evaluates one of up to four
+// independent sub-expressions and the results are exchanged with DPP quad-permute moves (two
+// 32-bit moves per double, no LDS round trip).
+#if defined(__HIPCC__)
+__device__ inline int tpl_quad_lane() { return (int)(__lane_id() & 3u); }
+
+__device__ inline double tpl_quad_bcast(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (src) {      // the DPP control is an immediate: quad_perm:[src, src, src, src]
+    case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xf, 0xf, true); break;
+    case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xf, 0xf, true); break;
+    case 2: lo = __builtin_amdgcn_mov_dpp(lo, 0xaa, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xaa, 0xf, 0xf, true); break;
+    default: lo = __builtin_amdgcn_mov_dpp(lo, 0xff, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xff, 0xf, 0xf, true); break;
+    }
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double tpl_quad_pick(int q, double a0, double a1, double a2, double a3)
+{
+    return (q == 0) ? a0 : (q == 1) ? a1 : (q == 2) ? a2 : a3;
+}
+
+// lane q of the quad: tpl_lerp (or tpl_lerp_angle where bit q of angle_mask is set) of arrs[q]
+__device__ inline double tpl_quad_lookup(int q, double x0, double dx, double x, const DynArr* const arrs[4],
+                                         unsigned angle_mask)
+{
+    const DynArr* arr = (q == 0) ? arrs[0] : (q == 1) ? arrs[1] : (q == 2) ? arrs[2] : arrs[3];
+    const int64_t n = arr->n0;
+    if (n == 0) return 0.0;
+    const TplInterp i = tpl_init_interp(x0, dx, x, n);
+    const double p0 = arr->data[i.start], p1 = arr->data[i.end];
+    const double lin = i.ia * p0 + i.a * p1;                              // tpl_lerp
+    if (angle_mask == 0u) return lin;
+    const double ang = p0 + tpl_short_angle_dist(p0, p1) * i.a;           // tpl_lerp_angle
+    return ((angle_mask >> q) & 1u) ? ang : lin;
+}
+
+// tan(a) from the (sin a, cos a) pair a quad batch produced: what tpl_tan computes
+__device__ inline double tpl_tan_sc(double a, double s, double c)
+{
+    double r = s / c;
+    if (TPL_ANY_LANE(!(fabs(a) < 1.0e5))) {
+        if (!(fabs(a) < 1.0e5)) r = tan(a);
+    }
+    return r;
+}
+#endif
+

@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "builtins.h"
+#define TPL_QUAD_ROUTINES 1       /* the model file also emits the quad-cooperative ctDynamicsQ */
 #include TPL_MODEL_INC
 #include "tplhip_ilqr.h"
 
@@ -145,6 +146,50 @@ __device__ __forceinline__ void dynamics(const Params& P, const double* x, const
             res[i] = x[i] + acc * (dt / 6.0);
         }
     }
+}
+
+// dynamics() for a quad of lanes that all hold the same (x, u): the model's quad-cooperative
+// ctDynamicsQ spreads its independent look-ups and sin/cos evaluations over the four lanes.  Every
+// lane gets the full result.  Models without such structure run the plain routine on every lane.
+__device__ __forceinline__ void dynamics_quad(const Params& P, const double* x, const double* u, int t,
+                                              double dt, int int_type, double* res)
+{
+#if defined(TPL_HAS_QUAD_DYNAMICS)
+    double k1[NX];
+    ctDynamicsQ(P, x, u, (double)t, dt, k1, 1);
+    if (int_type == EULER) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) res[i] = x[i] + k1[i] * dt;
+    } else if (int_type == HEUN) {
+        double tmp[NX], k2[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tmp[i] = x[i] + k1[i] * dt;
+        ctDynamicsQ(P, tmp, u, (double)t, dt, k2, 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) res[i] = x[i] + (k1[i] + k2[i]) * (dt / 2.0);
+    } else {
+        double tmp[NX], k2[NX], k3[NX], k4[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tmp[i] = x[i] + k1[i] * (dt / 2.0);
+        ctDynamicsQ(P, tmp, u, (double)t, dt, k2, 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tmp[i] = x[i] + k2[i] * (dt / 2.0);
+        ctDynamicsQ(P, tmp, u, (double)t, dt, k3, 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tmp[i] = x[i] + k3[i] * dt;
+        ctDynamicsQ(P, tmp, u, (double)t, dt, k4, 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double acc = k1[i] + 0.0;
+            acc = k2[i] * 2.0 + acc;
+            acc = k3[i] * 2.0 + acc;
+            acc = k4[i] + acc;
+            res[i] = x[i] + acc * (dt / 6.0);
+        }
+    }
+#else
+    dynamics(P, x, u, t, dt, int_type, res);
+#endif
 }
 
 // The workgroup IS one wavefront.  LDS operations of a wave are issued and completed in
@@ -302,22 +347,22 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
     // stages in parallel afterwards and summed in the reference's order t = optStart..T-1.
     double J = 0.0;
     double* CC = st.cand_c + (int64_t)b * N_ALPHA * st.rows;
-    if (lane == 0) {
+    if (lane < 4) {                                    // one quad: see dynamics_quad
         double x[NX], u[NU], xn[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)opt_start * NX + i];
         for (int t = opt_start; t < T; ++t) {
 #pragma unroll
             for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
-            IS[t] = dt;
-            dynamics(P, x, u, t, dt, int_type, xn);
+            if (lane == 0) IS[t] = dt;
+            dynamics_quad(P, x, u, t, dt, int_type, xn);
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 x[i] = xn[i];
-                X_[(int64_t)(t + 1) * NX + i] = xn[i];
+                if (lane == 0) X_[(int64_t)(t + 1) * NX + i] = xn[i];
             }
         }
-        IS[T] = dt;
+        if (lane == 0) IS[T] = dt;
     }
     __syncthreads();
     for (int t = opt_start + lane; t < T; t += WAVE) {
@@ -678,17 +723,22 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
             const double J_prev = J;
             double Jc = INFINITY;
             // pass A: the eight dynamics chains (lqrForwardPass :745-775 / lrForwardPass :803-818)
-            if (lane < N_ALPHA) {
+            // Candidate c runs on the QUAD of lanes 4c .. 4c+3: all four hold the same state and
+            // control, the model's dynamics spread their independent look-ups and sin/cos evaluations
+            // over them (dynamics_quad), lane 4c alone writes the candidate arrays.
+            if (lane < 4 * N_ALPHA) {
+                const int cand = lane >> 2;
+                const bool writer = (lane & 3) == 0;
                 double a = 1.0;
-                for (int i = 0; i < lane; ++i) a *= 10.0;
+                for (int i = 0; i < cand; ++i) a *= 10.0;
                 a = 1.0 / a;                                   // 1.0 / pow(10, i)
-                double* cx = CX + (int64_t)lane * st.rows * NX;
-                double* cu = CU + (int64_t)lane * st.rows * NU;
+                double* cx = CX + (int64_t)cand * st.rows * NX;
+                double* cu = CU + (int64_t)cand * st.rows * NU;
                 double x[NX], xn[NX], u[NU];
                 // stages before opt_start are frozen (tpl never moves opt_start off 0)
-                for (int e = 0; e < opt_start * NX; ++e) cx[e] = X_[e];
+                if (writer) for (int e = 0; e < opt_start * NX; ++e) cx[e] = X_[e];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) { x[i] = X_[(int64_t)opt_start * NX + i]; cx[(int64_t)opt_start * NX + i] = x[i]; }
+                for (int i = 0; i < NX; ++i) { x[i] = X_[(int64_t)opt_start * NX + i]; if (writer) cx[(int64_t)opt_start * NX + i] = x[i]; }
                 for (int t = opt_start; t < T; ++t) {
                     // feedback law: all operands first, then the arithmetic (one memory round trip)
                     double kff[NU], ub[NU], hi[NU], lo[NU], kfb[NU * NX], xr[NX];
@@ -720,14 +770,14 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                             ud = ub[d] - kff[d] * a;
                         }
                         u[d] = ud;
-                        cu[(int64_t)t * NU + d] = ud;
+                        if (writer) cu[(int64_t)t * NU + d] = ud;
                     }
                     STAMP(14);
-                    dynamics(P, x, u, t, dt, int_type, xn);
+                    dynamics_quad(P, x, u, t, dt, int_type, xn);
 #pragma unroll
                     for (int i = 0; i < NX; ++i) {
                         x[i] = xn[i];
-                        cx[(int64_t)(t + 1) * NX + i] = xn[i];
+                        if (writer) cx[(int64_t)(t + 1) * NX + i] = xn[i];
                     }
                     STAMP(15);
                 }

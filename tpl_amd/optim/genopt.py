@@ -29,6 +29,7 @@ C-ABI is ``include/tplhip_ilqr.h``.
 """
 
 import hashlib
+import re
 import os
 import subprocess
 import sys
@@ -87,7 +88,7 @@ class Config:
 
 
 # bump when the emitted text for an unchanged problem changes (invalidates cached models)
-EMITTER_REVISION = "emit-2: tpl_sin/tpl_cos/tpl_tan"
+EMITTER_REVISION = "emit-3: tpl_sin/tpl_cos/tpl_tan, quad-cooperative ctDynamics"
 
 
 def _as_matrix(e):
@@ -356,6 +357,197 @@ def _emit_routine(name, m, cfg, printer):
     return "\n".join(lines)
 
 
+def _temp_deps(expr):
+    """Temporaries (w*, sc*, ql*) an expression reads; x[i], u[i], P.* and t/dt are inputs."""
+    return {fs for fs in expr.free_symbols if re.match(r"^(w|sc|ql)\d+$", str(fs))}
+
+
+def _emit_routine_quad(name, m, cfg, printer):
+    """``name`` for a QUAD of lanes that all hold the same arguments: mutually independent table
+    look-ups at the same abscissa and mutually independent sin/cos evaluations are spread over the
+    four lanes (one each), evaluated once, and broadcast back with DPP moves.  On a single
+    wavefront -- how the solver runs its line-search rollouts -- a routine costs its instruction
+    count, and for tpl's vehicle models this halves it (tools/micro/ctq_probe.hip).  Every lane
+    returns exactly what the plain routine returns: the look-up and sin/cos code is the same, only
+    which lane runs it changes; tan(a) is sin/cos from the same pair like tpl_tan.
+
+    Returns None when there is nothing to spread (the template then calls the plain routine)."""
+    n = m.shape[0] * m.shape[1]
+    if not n:
+        return None
+    flat = [_vectorise(sp.sympify(e), cfg) for e in m]
+    subs, reduced = sp.cse(flat, symbols=sp.numbered_symbols("w"))
+    subs, fused = _fuse_sincos(subs, reduced)
+    exprs = lambda: [e for _, e in subs] + list(reduced)
+
+    counter = [0]
+
+    def fresh(prefix):
+        counter[0] += 1
+        return sp.Symbol(f"{prefix}{1000 + counter[0]}")
+
+    # ---- table look-ups that share (x0, dx, x)
+    groups = {}
+    for e in exprs():
+        for f in e.atoms(sp.Function):
+            if type(f).__name__ in ("lerp", "lerp_angle") and len(f.args) == 4:
+                groups.setdefault(tuple(f.args[:3]), {}).setdefault(f, None)
+    lerp_batches, repl = [], {}
+    for key, calls in groups.items():
+        calls = list(calls)
+        if len(calls) < 2:
+            continue
+        for i in range(0, len(calls), 4):
+            chunk = calls[i:i + 4]
+            if len(chunk) < 2:
+                continue
+            syms = [fresh("ql") for _ in chunk]
+            for f, sy in zip(chunk, syms):
+                repl[f] = sy
+            lerp_batches.append({"key": key, "members": [(sy, f.args[3], type(f).__name__ == "lerp_angle")
+                                                         for f, sy in zip(chunk, syms)]})
+    if repl:
+        subs = [(sym, e.xreplace(repl)) for sym, e in subs]
+        reduced = [e.xreplace(repl) for e in reduced]
+
+    # ---- sin/cos pairs (from _fuse_sincos), lone sin / cos, tan
+    tasks = []                                   # (arg, s_sym, c_sym)
+    keep = []
+    for sym, e in subs:
+        if sym in fused:
+            tasks.append((e, fused[sym][0], fused[sym][1]))
+        else:
+            keep.append((sym, e))
+    subs = keep
+    lone = {}
+    for e in exprs():
+        for f in list(e.atoms(sp.sin)) + list(e.atoms(sp.cos)) + list(e.atoms(sp.tan)):
+            lone.setdefault(f.args[0], None)
+    trepl = {}
+    for arg in lone:
+        s_sym, c_sym = fresh("sc"), fresh("sc")
+        tasks.append((arg, s_sym, c_sym))
+        trepl[sp.sin(arg)] = s_sym
+        trepl[sp.cos(arg)] = c_sym
+        trepl[sp.tan(arg)] = sp.Function("tpl_tan_sc")(arg, s_sym, c_sym)
+    if trepl:
+        subs = [(sym, e.xreplace(trepl)) for sym, e in subs]
+        reduced = [e.xreplace(trepl) for e in reduced]
+        tasks = [(a.xreplace(trepl), s_, c_) for a, s_, c_ in tasks]
+    if not lerp_batches and len(tasks) < 2:
+        return None
+
+    # dependency levels of the sin/cos tasks among themselves (through the temporaries)
+    defs = {sym: e for sym, e in subs}
+    for b in lerp_batches:
+        for sy, _, _ in b["members"]:
+            defs[sy] = sp.Add(*[k for k in b["key"]]) if b["key"] else sp.Integer(0)
+    out_of = {}
+    for i, (_, s_, c_) in enumerate(tasks):
+        out_of[s_] = i
+        out_of[c_] = i
+
+    def closure(expr, seen=None):
+        seen = set() if seen is None else seen
+        for fs in _temp_deps(expr):
+            if fs in seen:
+                continue
+            seen.add(fs)
+            if fs in defs:
+                closure(defs[fs], seen)
+        return seen
+
+    level = {}
+
+    def task_level(i, stack=()):
+        if i in level:
+            return level[i]
+        dep = {out_of[fs] for fs in closure(tasks[i][0]) if fs in out_of and out_of[fs] != i}
+        level[i] = 0 if not dep else 1 + max(task_level(j, stack + (i,)) for j in dep if j not in stack)
+        return level[i]
+
+    for i in range(len(tasks)):
+        task_level(i)
+    trig_batches = []
+    for lv in sorted(set(level.values())):
+        idx = [i for i in range(len(tasks)) if level[i] == lv]
+        for i in range(0, len(idx), 4):
+            trig_batches.append([tasks[j] for j in idx[i:i + 4]])
+
+    # ---- schedule: original order, every batch as soon as all its arguments exist
+    items = [("assign", sym, e) for sym, e in subs]
+    items += [("qlerp", b) for b in lerp_batches] + [("qtrig", b) for b in trig_batches]
+
+    def deps(it):
+        if it[0] == "assign":
+            return _temp_deps(it[2])
+        if it[0] == "qlerp":
+            d = set()
+            for k in it[1]["key"]:
+                d |= _temp_deps(sp.sympify(k))
+            return d
+        d = set()
+        for a, _, _ in it[1]:
+            d |= _temp_deps(a)
+        return d
+
+    def provides(it):
+        if it[0] == "assign":
+            return {it[1]}
+        if it[0] == "qlerp":
+            return {sy for sy, _, _ in it[1]["members"]}
+        return {x for _, s_, c_ in it[1] for x in (s_, c_)}
+
+    lines = [f"__device__ inline void {name}Q({_signature(name)}) {{"]
+    lines.append("    (void)P; (void)x; (void)t; (void)dt; (void)os;")
+    if "const double* u" in _signature(name):
+        lines.append("    (void)u;")
+    lines.append("    const int qlane = tpl_quad_lane();")
+    defined, pending = set(), list(items)
+    # batches first in the scan so that they are issued the moment they become possible
+    pending.sort(key=lambda it: 0 if it[0] != "assign" else 1)
+    while pending:
+        for it in pending:
+            if deps(it) <= defined:
+                break
+        else:
+            raise AssertionError("quad scheduling: cyclic dependency")
+        pending.remove(it)
+        defined |= provides(it)
+        if it[0] == "assign":
+            lines.append(f"    const double {it[1]} = {printer.doprint(it[2])};")
+        elif it[0] == "qlerp":
+            b = it[1]
+            x0, dx, xx = (printer.doprint(k) for k in b["key"])
+            mem = b["members"] + [b["members"][-1]] * (4 - len(b["members"]))
+            arrs = ", ".join(f"&{printer.doprint(a)}" for _, a, _ in mem)
+            mask = sum((1 << i) for i, (_, _, ang) in enumerate(mem) if ang)
+            names = [str(sy) for sy, _, _ in b["members"]]
+            lines.append(f"    double {', '.join(names)};")
+            lines.append("    {")
+            lines.append(f"        const DynArr* qa[4] = {{{arrs}}};")
+            lines.append(f"        const double qv = tpl_quad_lookup(qlane, {x0}, {dx}, {xx}, qa, {mask}u);")
+            for i, nm in enumerate(names):
+                lines.append(f"        {nm} = tpl_quad_bcast(qv, {i});")
+            lines.append("    }")
+        else:
+            b = it[1]
+            args = [printer.doprint(a) for a, _, _ in b]
+            args4 = args + [args[-1]] * (4 - len(args))
+            names = [str(x) for _, s_, c_ in b for x in (s_, c_)]
+            lines.append(f"    double {', '.join(names)};")
+            lines.append("    {")
+            lines.append(f"        const double qarg = tpl_quad_pick(qlane, {', '.join(args4)});")
+            lines.append("        double qs, qc; tpl_sincos(qarg, &qs, &qc);")
+            for i, (_, s_, c_) in enumerate(b):
+                lines.append(f"        {s_} = tpl_quad_bcast(qs, {i}); {c_} = tpl_quad_bcast(qc, {i});")
+            lines.append("    }")
+    for i, e in enumerate(reduced):
+        lines.append(f"    out[{i}*os] = {printer.doprint(e)};")
+    lines.append("}")
+    return "\n".join(lines)
+
+
 def _array_checks(cfg, routines):
     """Shape requirements the reference template asserts at run time (the ``check(ARR.ndim == 1)``
     macros around its builtins, optim.c:375-486): (param index, required ndim) pairs and pairs of
@@ -418,6 +610,18 @@ def emit_model(cfg, name):
     for rname, m in routines:
         out.append(_emit_routine(rname, m, cfg, printer))
         out.append("")
+    # quad-cooperative form of the dynamics for the line-search rollouts (device only; the template
+    # defines TPL_QUAD_ROUTINES before it includes this file, the CPU oracle does not)
+    quad = None
+    for rname, m in routines:
+        if rname == "ctDynamics":
+            quad = _emit_routine_quad(rname, m, cfg, printer)
+    out.append("#if defined(TPL_QUAD_ROUTINES)")
+    if quad:
+        out.append("#define TPL_HAS_QUAD_DYNAMICS 1")
+        out.append(quad)
+    out.append("#endif")
+    out.append("")
     spx.clear_cache()
     return "\n".join(out)
 
