@@ -70,3 +70,20 @@ def test_default_values_match_pyOptimAlloc():
     assert np.all(opt.u_max[20:] == 0.0)
     opt.horizon = 1000                 # clamped to H_MAX-1 (optim.c:1726-1734)
     assert opt.horizon == 299
+
+
+def test_quad_cooperative_dynamics_are_emitted_where_they_pay():
+    """The generator emits ctDynamicsQ (look-ups and sin/cos spread over a quad of lanes) for models
+    whose dynamics hold at least two independent look-ups or trigonometric evaluations, inside the
+    TPL_QUAD_ROUTINES guard (the CPU oracle never sees it), and nothing for the others."""
+    from tpl_amd.optim import genopt, optimizers as o
+    txt = genopt.emit_model(o.config_trajectory_tracking_mpc(), "trajectory_tracking_mpc")
+    guard = txt.index("#if defined(TPL_QUAD_ROUTINES)")
+    q = txt[guard:]
+    assert "#define TPL_HAS_QUAD_DYNAMICS 1" in q and "void ctDynamicsQ(" in q
+    assert q.count("tpl_quad_lookup(") == 1            # ref_phi, ref_k, ref_x, ref_y at x[5]: one batch
+    assert q.count("tpl_sincos(qarg") == 1             # sin/cos of x[2], of the reference heading, tan(x[3])
+    assert "tpl_tan_sc(x[3]" in q and "tpl_lerp(" not in q
+    assert "ctDynamicsQ" not in txt[:guard]
+    plain = genopt.emit_model(o.config_velocity_profile_time(), "velocity_profile_time")
+    assert "TPL_HAS_QUAD_DYNAMICS" not in plain and "ctDynamicsQ" not in plain
