@@ -241,6 +241,82 @@ struct Lds {
     double red[N_ALPHA];
 };
 
+// The line-search rollouts as a function of their own (NOT inlined): inside k_ilqr_update the
+// derivative refresh drives the register allocation to 500 registers with most long-lived values
+// parked in AGPRs, and the rollout loop -- a chain of dependent instructions on a single wavefront,
+// where every extra move is paid in full -- would shuttle its operands through them.  A real call
+// gives the loop a register file of its own; the call itself happens once per line search.
+struct RolloutArgs {
+    double* CX; double* CU;
+    const double* X_; const double* KFFr; const double* Ur; const double* UMAXr; const double* UMINr;
+    const double* KFBr; const double* Xr;
+    const Params* P;
+    double dt;
+    int rows, opt_start, T, int_type;
+    bool second_order;
+};
+
+__device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs A, int lane)
+{
+    // Candidate c runs on the QUAD of lanes 4c .. 4c+3: all four hold the same state and
+    // control, the model's dynamics spread their independent look-ups and sin/cos evaluations
+    // over them (dynamics_quad), lane 4c alone writes the candidate arrays.
+    if (lane < 4 * N_ALPHA) {
+        const int cand = lane >> 2;
+        const bool writer = (lane & 3) == 0;
+        double a = 1.0;
+        for (int i = 0; i < cand; ++i) a *= 10.0;
+        a = 1.0 / a;                                   // 1.0 / pow(10, i)
+        double* cx = A.CX + (int64_t)cand * A.rows * NX;
+        double* cu = A.CU + (int64_t)cand * A.rows * NU;
+        double x[NX], xn[NX], u[NU];
+        // stages before A.opt_start are frozen (tpl never moves A.opt_start off 0)
+        if (writer) for (int e = 0; e < A.opt_start * NX; ++e) cx[e] = A.X_[e];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { x[i] = A.X_[(int64_t)A.opt_start * NX + i]; if (writer) cx[(int64_t)A.opt_start * NX + i] = x[i]; }
+        for (int t = A.opt_start; t < A.T; ++t) {
+            // feedback law: all operands first, then the arithmetic (one memory round trip)
+            double kff[NU], ub[NU], hi[NU], lo[NU], kfb[NU * NX], xr[NX];
+#pragma unroll
+            for (int d = 0; d < NU; ++d) {
+                kff[d] = A.KFFr[(int64_t)t * NU + d];
+                ub[d] = A.Ur[(int64_t)t * NU + d];
+                hi[d] = A.UMAXr[(int64_t)t * NU + d];
+                lo[d] = A.UMINr[(int64_t)t * NU + d];
+            }
+            if (A.second_order) {
+#pragma unroll
+                for (int e = 0; e < NU * NX; ++e) kfb[e] = A.KFBr[(int64_t)t * NU * NX + e];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xr[i] = A.Xr[(int64_t)t * NX + i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < NU; ++d) {
+                double ud;
+                if (A.second_order) {
+                    ud = kff[d] * a;
+                    ud = ud + ub[d];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) ud += kfb[d * NX + i] * (x[i] - xr[i]);
+                    ud = hi[d] < ud ? hi[d] : ud;
+                    ud = lo[d] > ud ? lo[d] : ud;
+                } else {
+                    ud = ub[d] - kff[d] * a;
+                }
+                u[d] = ud;
+                if (writer) cu[(int64_t)t * NU + d] = ud;
+            }
+                                dynamics_quad(*A.P, x, u, t, A.dt, A.int_type, xn);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                x[i] = xn[i];
+                if (writer) cx[(int64_t)(t + 1) * NX + i] = xn[i];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // one update() of problem blockIdx.x  (optim.c:1091-1160)
 // ---------------------------------------------------------------------------
@@ -723,64 +799,12 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
             const double J_prev = J;
             double Jc = INFINITY;
             // pass A: the eight dynamics chains (lqrForwardPass :745-775 / lrForwardPass :803-818)
-            // Candidate c runs on the QUAD of lanes 4c .. 4c+3: all four hold the same state and
-            // control, the model's dynamics spread their independent look-ups and sin/cos evaluations
-            // over them (dynamics_quad), lane 4c alone writes the candidate arrays.
-            if (lane < 4 * N_ALPHA) {
-                const int cand = lane >> 2;
-                const bool writer = (lane & 3) == 0;
-                double a = 1.0;
-                for (int i = 0; i < cand; ++i) a *= 10.0;
-                a = 1.0 / a;                                   // 1.0 / pow(10, i)
-                double* cx = CX + (int64_t)cand * st.rows * NX;
-                double* cu = CU + (int64_t)cand * st.rows * NU;
-                double x[NX], xn[NX], u[NU];
-                // stages before opt_start are frozen (tpl never moves opt_start off 0)
-                if (writer) for (int e = 0; e < opt_start * NX; ++e) cx[e] = X_[e];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) { x[i] = X_[(int64_t)opt_start * NX + i]; if (writer) cx[(int64_t)opt_start * NX + i] = x[i]; }
-                for (int t = opt_start; t < T; ++t) {
-                    // feedback law: all operands first, then the arithmetic (one memory round trip)
-                    double kff[NU], ub[NU], hi[NU], lo[NU], kfb[NU * NX], xr[NX];
-#pragma unroll
-                    for (int d = 0; d < NU; ++d) {
-                        kff[d] = KFFr[(int64_t)t * NU + d];
-                        ub[d] = Ur[(int64_t)t * NU + d];
-                        hi[d] = UMAXr[(int64_t)t * NU + d];
-                        lo[d] = UMINr[(int64_t)t * NU + d];
-                    }
-                    if (second_order) {
-#pragma unroll
-                        for (int e = 0; e < NU * NX; ++e) kfb[e] = KFBr[(int64_t)t * NU * NX + e];
-#pragma unroll
-                        for (int i = 0; i < NX; ++i) xr[i] = Xr[(int64_t)t * NX + i];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int d = 0; d < NU; ++d) {
-                        double ud;
-                        if (second_order) {
-                            ud = kff[d] * a;
-                            ud = ud + ub[d];
-#pragma unroll
-                            for (int i = 0; i < NX; ++i) ud += kfb[d * NX + i] * (x[i] - xr[i]);
-                            ud = hi[d] < ud ? hi[d] : ud;
-                            ud = lo[d] > ud ? lo[d] : ud;
-                        } else {
-                            ud = ub[d] - kff[d] * a;
-                        }
-                        u[d] = ud;
-                        if (writer) cu[(int64_t)t * NU + d] = ud;
-                    }
-                    STAMP(14);
-                    dynamics_quad(P, x, u, t, dt, int_type, xn);
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) {
-                        x[i] = xn[i];
-                        if (writer) cx[(int64_t)(t + 1) * NX + i] = xn[i];
-                    }
-                    STAMP(15);
-                }
+            {
+                RolloutArgs ra;
+                ra.CX = CX; ra.CU = CU; ra.X_ = X_; ra.KFFr = KFFr; ra.Ur = Ur; ra.UMAXr = UMAXr; ra.UMINr = UMINr;
+                ra.KFBr = KFBr; ra.Xr = Xr; ra.P = &P; ra.dt = dt; ra.rows = st.rows; ra.opt_start = opt_start;
+                ra.T = T; ra.int_type = int_type; ra.second_order = second_order;
+                line_search_rollouts(ra, lane);
             }
             __syncthreads();
             STAMP(11);
