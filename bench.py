@@ -284,6 +284,28 @@ def main():
             out["secondary"]["plan_latency"]["env_update"]["cpu_baseline"] = env_cpu_baseline()
             out["secondary"]["plan_latency"]["poly_lat_update"]["cpu_baseline"] = poly_lat_cpu_baseline()
             out["secondary"]["plan_latency"]["lat_lon_update"]["cpu_baseline"] = lat_lon_cpu_baseline()
+            out["secondary"]["batched_ilqr"].pop("best_record", None)
+
+    # N > 1: the batched iLQR shards the same way -- every rank solves its own block of 1024 initial
+    # states (seed = rank), the timed region is barrier-bracketed and the MAX over ranks, and the only
+    # exchange is the all-gather of each rank's best {cost, id, x, u} record.
+    if not args.no_secondary and world > 1:
+        from tpl_amd.optim import bench_ilqr
+        res = bench_ilqr.run(local_rank, cpu_budget_s=0, seed=rank, barrier=barrier, id_offset=rank * 1024)
+        dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
+        t = torch.tensor([res["elapsed_s"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        best = sharding.allgather_best(res.pop("best_record"), dist, dev)
+        if rank == 0:
+            el = float(t.item())
+            res["value"] = world * res["updates"] * res["iterations_per_update"] / el
+            res["problem_iterations_per_s"] = res["value"] * res["config"]["batch"]
+            res["ms_per_update"] = el / res["updates"] * 1e3
+            res["n_gpus"] = world
+            res["config"]["parallelism"] = f"{world} x 1024 independent problems, all-gather of the best plan"
+            res["best_plan"] = {"cost": float(best[1]), "id": int(best[2])}
+            out["secondary"] = {"batched_ilqr": res}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

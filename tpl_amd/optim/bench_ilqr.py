@@ -49,11 +49,14 @@ def initial_states(batch, seed=0):
     return x0
 
 
-def run(device=0, batch=1024, horizon=50, updates=10, warmup=2, cpu_budget_s=10.0):
+def run(device=0, batch=1024, horizon=50, updates=10, warmup=2, cpu_budget_s=10.0, seed=0, barrier=None,
+        id_offset=0):
+    """One rank's share of the batched-iLQR workload.  `seed` picks this rank's block of initial states,
+    `barrier` (N > 1) brackets the timed region, `id_offset` is the global id of this rank's problem 0."""
     from . import genopt, optimizers as o
     make = genopt.build(o.config_trajectory_tracking_mpc(), "trajectory_tracking_mpc")
     opt = make(batch=batch, horizon=horizon, device=device)
-    x0 = initial_states(batch)
+    x0 = initial_states(batch, seed)
     _configure(opt, x0)
     opt.upload()
     for _ in range(warmup):
@@ -61,11 +64,15 @@ def run(device=0, batch=1024, horizon=50, updates=10, warmup=2, cpu_budget_s=10.
         opt.run_resident()
     opt.sync()
     opt.timing(reset=True)
+    if barrier is not None:
+        barrier()
     t0 = time.perf_counter()
     for _ in range(updates):
         opt.restore()
         opt.run_resident()
     opt.sync()
+    if barrier is not None:
+        barrier()
     el = time.perf_counter() - t0
     kernel_ms, launches = opt.timing(reset=True)
     opt.download()
@@ -81,7 +88,13 @@ def run(device=0, batch=1024, horizon=50, updates=10, warmup=2, cpu_budget_s=10.
         "ms_per_update": el / updates * 1e3,
         "kernel_ms_per_update": kernel_ms / max(1, launches),
         "all_finite": bool(np.all(np.isfinite(opt.traj_costs))),
+        "elapsed_s": el, "updates": updates, "iterations_per_update": iters,
     }
+    # this rank's best problem as the fixed-size record of SURVEY 8e: {constr, cost, id, x[T+1,X], u[T,U]}
+    b = int(np.argmin(np.where(np.isfinite(opt.traj_costs), opt.traj_costs, np.inf)))
+    out["best_record"] = np.concatenate([[0.0, float(opt.traj_costs[b]), float(id_offset + b)],
+                                         np.asarray(opt.x[b], dtype=np.float64).ravel(),
+                                         np.asarray(opt.u[b], dtype=np.float64).ravel()])
     if cpu_budget_s > 0:
         out["cpu_baseline"] = cpu_baseline(x0, horizon, cpu_budget_s)
     return out
@@ -123,4 +136,6 @@ def cpu_baseline(x0, horizon, budget_s):
 if __name__ == "__main__":
     import json
     sys.path.insert(0, ROOT)
-    print(json.dumps(run()))
+    res = run(cpu_budget_s=0.0 if "--no-cpu-baseline" in sys.argv else 10.0)
+    res.pop("best_record", None)
+    print(json.dumps(res))
