@@ -102,6 +102,32 @@ def lat_lon_cpu_baseline(reps=3):
             "sample": f"{reps} plans of the same scene (OpenMP over cells)"}
 
 
+def mpc_cpu_baseline(ticks=300, horizon=20):
+    """oracle/ilqr_oracle.cpp (one thread, one problem) in the closed loop of latency.mpc_closed_loop:
+    what the reference's CPU genopt solver costs per controller tick on this host."""
+    import numpy as np
+    import oracle_ilqr as OI
+    from tpl_amd.optim import bench_ilqr
+    opt = OI.OracleOptim("trajectory_tracking_mpc")
+    opt.horizon = horizon
+    x = np.array([0.0, 0.4, 0.05, 0.0, 6.0, 0.0, 0.0])
+    bench_ilqr._configure(opt, x)
+    opt.min_rel_cost_change = 1e-6
+    opt.horizon = horizon
+    lat = []
+    for _ in range(ticks):
+        opt.x[0] = x
+        t0 = time.perf_counter()
+        opt.update()
+        lat.append((time.perf_counter() - t0) * 1e3)
+        x = opt.dynamics(x, opt.u[0], 0, 0.01)
+        x[5] = max(0.0, x[0])
+        opt.shift(0)
+    lat = np.array(lat[10:])
+    return {"value": float(np.percentile(lat, 50)), "unit": "ms per update (p50)", "cores": 1, "kind": "port",
+            "p99_ms": float(np.percentile(lat, 99)), "sample": f"{len(lat)} ticks of the same closed loop"}
+
+
 def dp_setup(grid, device):
     import tpl_amd
     from tpl_amd import scenarios as sc
@@ -281,6 +307,7 @@ def main():
             from tpl_amd.optim import bench_ilqr
             out["secondary"] = {"batched_ilqr": bench_ilqr.run(local_rank),
                                 "plan_latency": latency.run(local_rank)}
+            out["secondary"]["plan_latency"]["mpc_closed_loop"]["cpu_baseline"] = mpc_cpu_baseline()
             out["secondary"]["plan_latency"]["env_update"]["cpu_baseline"] = env_cpu_baseline()
             out["secondary"]["plan_latency"]["poly_lat_update"]["cpu_baseline"] = poly_lat_cpu_baseline()
             out["secondary"]["plan_latency"]["lat_lon_update"]["cpu_baseline"] = lat_lon_cpu_baseline()

@@ -29,6 +29,7 @@
 // Arithmetic is fp64 like the reference.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -36,6 +37,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <iterator>
 #include <new>
 #include <vector>
 
@@ -962,8 +964,7 @@ struct ArrayParam {
     int64_t dims[8] = {0};
     int64_t elems = 0;               // per problem
     int per_problem = 0;
-    double* dev = nullptr;
-    size_t dev_cap = 0;
+    double* dev = nullptr;           // into the handle's device parameter arena (not owned)
     long long lds_off = -1;          // doubles from the dynamic LDS base, -1: stays in global memory
 };
 
@@ -973,6 +974,25 @@ const int kInputFields[] = {TPL_F_X, TPL_F_U, TPL_F_LAGRANGE_MULTIPLIER, TPL_F_B
 const int kEagerFields[] = {TPL_F_INT_STEP, TPL_F_X, TPL_F_U, TPL_F_NEXT_INT_STEP, TPL_F_NEXT_X, TPL_F_NEXT_U,
                             TPL_F_PREV_X, TPL_F_PREV_K, TPL_F_K_FF, TPL_F_K_FB, TPL_F_LAGRANGE_MULTIPLIER, TPL_F_G};
 
+// One arena on each side, same offsets: the host mirrors are page-locked and ordered so that
+// everything update() hands to the kernel (input-only fields, the scalars, x / u / lambda) is ONE
+// contiguous range and everything it returns eagerly (the scalars, x / u / lambda, the rest of
+// kEagerFields) is another -- one copy in, one copy out, instead of one per field from pageable
+// memory (20 copies of a few KB each were 40 % of a batch-1 MPC tick).  -1 marks the scalars.
+const int kArenaOrder[] = {TPL_F_BARRIER_WEIGHT, TPL_F_LG_MULT_LIMIT, TPL_F_U_MAX, TPL_F_U_MIN,
+                           -1, TPL_F_X, TPL_F_U, TPL_F_LAGRANGE_MULTIPLIER,
+                           TPL_F_INT_STEP, TPL_F_NEXT_INT_STEP, TPL_F_NEXT_X, TPL_F_NEXT_U, TPL_F_PREV_X,
+                           TPL_F_PREV_K, TPL_F_K_FF, TPL_F_K_FB, TPL_F_G};
+const size_t kArenaAlign = 32;       // doubles: every segment starts on a 256-byte boundary
+
+struct Span {                        // a segment of the host arena
+    double* p = nullptr;
+    size_t n = 0;
+    double* data() const { return p; }
+    size_t size() const { return n; }
+    double& operator[](size_t i) const { return p[i]; }
+};
+
 } // namespace
 
 struct tplhip_ilqr {
@@ -981,13 +1001,20 @@ struct tplhip_ilqr {
     int t_cap = 0;
     int rows = 0;
     hipStream_t stream = nullptr;
-    std::vector<double> host[TPL_F_COUNT];
+    double* h_arena = nullptr;                   // page-locked host mirrors, layout kArenaOrder
+    double* d_arena = nullptr;                   // the same layout on the device
+    size_t arena_elems = 0;
+    size_t in_lo = 0, in_hi = 0;                 // [lo, hi) doubles: what update() uploads
+    size_t out_lo = 0, out_hi = 0;               // ... and what it brings back
+    Span host[TPL_F_COUNT];
     bool device_newer[TPL_F_COUNT] = {false};
-    std::vector<double> scalars;                 // [batch][S_COUNT]
+    Span scalars;                                // [batch][S_COUNT]
     std::vector<std::vector<double>> pscalar;    // [n_params][batch]
     std::vector<ArrayParam> parray;              // [n_params]
     std::vector<Params> hparams;                 // [batch], host-pointer version for dynamics()
-    std::vector<Params> dparams_host;            // [batch], device-pointer version (staging)
+    char* h_parena = nullptr;                    // page-locked staging: [Params x batch][array parameters ...]
+    char* d_parena = nullptr;                    // its device twin; d_params = its head
+    size_t parena_cap = 0;
     DevState dev{};
     Params* d_params = nullptr;
     double* d_snapshot[3] = {nullptr, nullptr, nullptr};   // x, u, lambda
@@ -1044,23 +1071,39 @@ void plan_lds(tplhip_ilqr* h)
 
 int upload_params(tplhip_ilqr* h)
 {
+    // layout of the parameter arena: the Params records, then every non-empty array parameter
+    auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    size_t need = pad(sizeof(Params) * (size_t)h->batch);
+    for (int i = 0; i < TPL_N_PARAMS; ++i)
+        if (g_params[i].is_array) need += pad(h->parray[i].host.size() * sizeof(double));
+    if (need > h->parena_cap) {
+        HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
+        if (h->h_parena) hipHostFree(h->h_parena);
+        hipFree(h->d_parena);
+        h->h_parena = nullptr; h->d_parena = nullptr; h->parena_cap = 0;
+        const size_t cap = need + need / 2;
+        HIP_TRY(hipHostMalloc((void**)&h->h_parena, cap, hipHostMallocDefault), "parameter staging allocation failed");
+        HIP_TRY(hipMalloc((void**)&h->d_parena, cap), "parameter array allocation failed");
+        h->parena_cap = cap;
+        h->d_params = reinterpret_cast<Params*>(h->d_parena);
+        h->dev.params = h->d_params;
+    }
+    size_t off = pad(sizeof(Params) * (size_t)h->batch);
     for (int i = 0; i < TPL_N_PARAMS; ++i) {
         if (!g_params[i].is_array) continue;
         ArrayParam& a = h->parray[i];
         const size_t bytes = a.host.size() * sizeof(double);
-        if (bytes > a.dev_cap) {
-            hipFree(a.dev);
-            a.dev = nullptr; a.dev_cap = 0;
-            HIP_TRY(hipMalloc(&a.dev, bytes), "parameter array allocation failed");
-            a.dev_cap = bytes;
-        }
-        if (bytes) HIP_TRY(hipMemcpyAsync(a.dev, a.host.data(), bytes, hipMemcpyHostToDevice, h->stream),
-                           "copying a parameter array failed");
+        a.dev = nullptr;
+        if (!bytes) continue;
+        std::memcpy(h->h_parena + off, a.host.data(), bytes);
+        a.dev = reinterpret_cast<double*>(h->d_parena + off);
+        off += pad(bytes);
     }
     for (auto& a : h->parray) a.lds_off = -1;
     plan_lds(h);
+    Params* staged = reinterpret_cast<Params*>(h->h_parena);
     for (int b = 0; b < h->batch; ++b) {
-        Params& P = h->dparams_host[b];
+        Params& P = staged[b];
         std::memset(&P, 0, sizeof(Params));
         for (int i = 0; i < TPL_N_PARAMS; ++i) {
             char* slot = (char*)&P + g_params[i].offset;
@@ -1080,8 +1123,7 @@ int upload_params(tplhip_ilqr* h)
             }
         }
     }
-    HIP_TRY(hipMemcpyAsync(h->d_params, h->dparams_host.data(), sizeof(Params) * (size_t)h->batch,
-                           hipMemcpyHostToDevice, h->stream), "copying parameters failed");
+    HIP_TRY(hipMemcpyAsync(h->d_parena, h->h_parena, off, hipMemcpyHostToDevice, h->stream), "copying parameters failed");
     return TPLHIP_OK;
 }
 
@@ -1107,13 +1149,9 @@ void host_params(tplhip_ilqr* h, int b, Params* P)
 
 int upload_inputs(tplhip_ilqr* h)
 {
-    for (int f : kInputFields) {
-        HIP_TRY(hipMemcpyAsync(h->dev.f[f], h->host[f].data(), field_elems(h, f) * sizeof(double),
-                               hipMemcpyHostToDevice, h->stream), "copying solver state failed");
-        h->device_newer[f] = false;
-    }
-    HIP_TRY(hipMemcpyAsync(h->dev.scalars, h->scalars.data(), h->scalars.size() * sizeof(double),
-                           hipMemcpyHostToDevice, h->stream), "copying solver settings failed");
+    HIP_TRY(hipMemcpyAsync(h->d_arena + h->in_lo, h->h_arena + h->in_lo, (h->in_hi - h->in_lo) * sizeof(double),
+                           hipMemcpyHostToDevice, h->stream), "copying solver state failed");
+    for (int f : kInputFields) h->device_newer[f] = false;
     return upload_params(h);
 }
 
@@ -1137,6 +1175,15 @@ int launch(tplhip_ilqr* h)
                                 || f == TPL_F_U_MIN || f == TPL_F_PREV_U;
         if (!input_only) h->device_newer[f] = true;
     }
+    return TPLHIP_OK;
+}
+
+// the scalars and all of kEagerFields in one copy (they are one range of the arena)
+int fetch_eager(tplhip_ilqr* h)
+{
+    HIP_TRY(hipMemcpyAsync(h->h_arena + h->out_lo, h->d_arena + h->out_lo, (h->out_hi - h->out_lo) * sizeof(double),
+                           hipMemcpyDeviceToHost, h->stream), "copying solver results failed");
+    for (int f : kEagerFields) h->device_newer[f] = false;
     return TPLHIP_OK;
 }
 
@@ -1226,27 +1273,47 @@ int tplhip_ilqr_create(int device, int batch, int t_cap, tplhip_ilqr** out)
     hipError_t err = hipStreamCreate(&h->stream);
     if (err != hipSuccess) { delete h; return fail(TPLHIP_EDEVICE, "%s: stream creation failed", hipGetErrorString(err)); }
 
-    for (int f = 0; f < TPL_F_COUNT; ++f) {
-        h->host[f].assign(field_elems(h, f), 0.0);
-        err = hipMalloc(&h->dev.f[f], std::max<size_t>(8, field_elems(h, f) * sizeof(double)));
-        if (err == hipSuccess) err = hipMemsetAsync(h->dev.f[f], 0, field_elems(h, f) * sizeof(double), h->stream);
+    {
+        // arena layout: kArenaOrder first, then the fields update() only fetches on demand
+        std::vector<int> order(std::begin(kArenaOrder), std::end(kArenaOrder));
+        for (int f = 0; f < TPL_F_COUNT; ++f)
+            if (std::find(order.begin(), order.end(), f) == order.end()) order.push_back(f);
+        auto pad = [](size_t n) { return (n + kArenaAlign - 1) / kArenaAlign * kArenaAlign; };
+        size_t off[TPL_F_COUNT + 1] = {0}, off_scalars = 0, total = 0;
+        for (int f : order) {
+            (f < 0 ? off_scalars : off[f]) = total;
+            total += pad(f < 0 ? (size_t)batch * TPL_S_COUNT : field_elems(h, f));
+        }
+        h->arena_elems = total;
+        err = hipHostMalloc((void**)&h->h_arena, total * sizeof(double), hipHostMallocDefault);
+        if (err == hipSuccess) err = hipMalloc((void**)&h->d_arena, total * sizeof(double));
+        if (err == hipSuccess) err = hipMemsetAsync(h->d_arena, 0, total * sizeof(double), h->stream);
         if (err != hipSuccess) { tplhip_ilqr_destroy(h); return fail(TPLHIP_EDEVICE, "%s: solver state allocation failed", hipGetErrorString(err)); }
+        std::memset(h->h_arena, 0, total * sizeof(double));
+        for (int f = 0; f < TPL_F_COUNT; ++f) {
+            h->host[f].p = h->h_arena + off[f];
+            h->host[f].n = field_elems(h, f);
+            h->dev.f[f] = h->d_arena + off[f];
+        }
+        h->scalars.p = h->h_arena + off_scalars;
+        h->scalars.n = (size_t)batch * TPL_S_COUNT;
+        h->dev.scalars = h->d_arena + off_scalars;
+        h->in_lo = off[kArenaOrder[0]];
+        h->in_hi = off[TPL_F_LAGRANGE_MULTIPLIER] + pad(field_elems(h, TPL_F_LAGRANGE_MULTIPLIER));
+        h->out_lo = off_scalars;
+        h->out_hi = off[TPL_F_G] + pad(field_elems(h, TPL_F_G));
     }
-    h->scalars.assign((size_t)batch * TPL_S_COUNT, 0.0);
     h->pscalar.assign(TPL_N_PARAMS, std::vector<double>());
     h->parray.assign(TPL_N_PARAMS, ArrayParam());
     for (int i = 0; i < TPL_N_PARAMS; ++i)
         if (!g_params[i].is_array) h->pscalar[i].assign(batch, 0.0);
     h->hparams.resize(batch);
-    h->dparams_host.resize(batch);
     const size_t cand_x = (size_t)batch * N_ALPHA * h->rows * NX, cand_u = (size_t)batch * N_ALPHA * h->rows * NU;
-    err = hipMalloc(&h->dev.scalars, h->scalars.size() * sizeof(double));
-    if (err == hipSuccess) err = hipMalloc(&h->d_params, sizeof(Params) * (size_t)batch);
-    if (err == hipSuccess) err = hipMalloc(&h->dev.cand_x, cand_x * sizeof(double));
+    err = hipMalloc(&h->dev.cand_x, cand_x * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&h->dev.cand_u, cand_u * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&h->dev.cand_c, (size_t)batch * N_ALPHA * h->rows * sizeof(double));
     if (err != hipSuccess) { tplhip_ilqr_destroy(h); return fail(TPLHIP_EDEVICE, "%s: solver workspace allocation failed", hipGetErrorString(err)); }
-    h->dev.params = h->d_params;
+    h->dev.params = nullptr;                                // set by the first upload_params
     h->dev.stamps = nullptr;
     {
         // where LDS sits in the flat address space (constant per process and device)
@@ -1298,10 +1365,10 @@ int tplhip_ilqr_destroy(tplhip_ilqr* h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& ev : h->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-    for (int f = 0; f < TPL_F_COUNT; ++f) hipFree(h->dev.f[f]);
-    for (auto& a : h->parray) hipFree(a.dev);
-    hipFree(h->dev.scalars);
-    hipFree(h->d_params);
+    hipFree(h->d_arena);
+    if (h->h_arena) hipHostFree(h->h_arena);
+    hipFree(h->d_parena);
+    if (h->h_parena) hipHostFree(h->h_parena);
     hipFree(h->dev.cand_x);
     hipFree(h->dev.cand_u);
     hipFree(h->dev.cand_c);
@@ -1373,12 +1440,8 @@ int tplhip_ilqr_update(tplhip_ilqr* h)
     if (rc) return rc;
     rc = launch(h);
     if (rc) return rc;
-    for (int f : kEagerFields) {
-        rc = fetch_field(h, f);
-        if (rc) return rc;
-    }
-    HIP_TRY(hipMemcpyAsync(h->scalars.data(), h->dev.scalars, h->scalars.size() * sizeof(double),
-                           hipMemcpyDeviceToHost, h->stream), "copying solver results failed");
+    rc = fetch_eager(h);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream), "solver update failed");
     for (int b = 0; b < h->batch; ++b)
         if (h->scalars[(size_t)b * TPL_S_COUNT + TPL_S_TERMINATION_CONDITION] == -99.0)
@@ -1527,12 +1590,8 @@ int tplhip_ilqr_download(tplhip_ilqr* h)
         for (int i = 0; i < 16; ++i) std::fprintf(stderr, "[stamp] %-22s %12.0f s_memtime ticks per problem per update\n", names[i], sum[i] / h->batch);
     }
 #endif
-    for (int f : kEagerFields) {
-        int rc = fetch_field(h, f);
-        if (rc) return rc;
-    }
-    HIP_TRY(hipMemcpyAsync(h->scalars.data(), h->dev.scalars, h->scalars.size() * sizeof(double),
-                           hipMemcpyDeviceToHost, h->stream), "copying solver results failed");
+    int rc = fetch_eager(h);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream), "solver update failed");
     return TPLHIP_OK;
 }
