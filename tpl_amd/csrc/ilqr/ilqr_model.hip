@@ -210,8 +210,8 @@ __device__ __forceinline__ void lds_sync()
 // Dot product of N terms read from LDS with strides sa / sb.  All 2N reads are issued
 // before the first multiply (sched_barrier): hipcc otherwise waits for the LDS after
 // every pair of terms, four round trips per product instead of one.
-template <int N>
-__device__ __forceinline__ double dot_lds(const double* a, int sa, const double* b, int sb)
+template <int N, class PA, class PB>
+__device__ __forceinline__ double dot_lds(PA a, int sa, PB b, int sb)
 {
     double x[N], y[N];
 #pragma unroll
@@ -242,6 +242,285 @@ struct Lds {
     double ulim[3 * NU];       // u[t], uMax[t], uMin[t]
     double red[N_ALPHA];
 };
+
+// ---- backward Riccati pass, optim.c:926-985, as a function of its own (NOT inlined) -- same reason as
+// line_search_rollouts: inside k_ilqr_update its loop ran with 85 AGPR moves, 30 SGPR-spill reloads
+// and 6 scratch stores per stage (of 513 instructions), all issued by the one wavefront of the SIMD.
+// The LDS block comes in as an LDS pointer (ds_* addressing in here too), everything uniform is
+// made uniform again with readfirstlane (function arguments count as divergent).
+typedef __attribute__((address_space(3))) Lds LdsAS;
+typedef const __attribute__((address_space(1))) double* GlbCD;    // global-memory pointers: global_load /
+typedef __attribute__((address_space(1))) double* GlbD;           // global_store (a generic pointer would be a
+typedef __attribute__((address_space(3))) double* LdsD;           // flat access, which also counts as an LDS one)
+struct RiccatiArgs {
+    const double* FX; const double* LXX; const double* FU; const double* LUX; const double* LX; const double* LU;
+    const double* LUU; const double* U_; const double* UMAX; const double* UMIN;
+    double* KFF; double* KFB; double* KL; double* KBL;
+    double mu;
+    int T;
+    int lt;
+    long long* stamp_acc;      // diagnostic builds only: this problem's stamp slots
+};
+
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long uni_u64(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ GlbCD uni_g(const double* p) { return (GlbCD)uni_u64((unsigned long long)p); }
+__device__ __forceinline__ GlbD uni_g(double* p) { return (GlbD)uni_u64((unsigned long long)p); }
+__device__ __forceinline__ LdsD uni_l(double* p) { return (LdsD)(unsigned)uni_i((int)(unsigned)(unsigned long long)(LdsD)p); }
+__device__ __forceinline__ double uni_d(double d)
+{
+    return __longlong_as_double((long long)uni_u64((unsigned long long)__double_as_longlong(d)));
+}
+
+__device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, LdsAS* s)
+{
+    const int lane = (int)threadIdx.x;
+    const GlbCD FX = uni_g(A.FX), LXX = uni_g(A.LXX), FU = uni_g(A.FU), LUX = uni_g(A.LUX), LX = uni_g(A.LX),
+                LU = uni_g(A.LU), LUU = uni_g(A.LUU), U_ = uni_g(A.U_), UMAX = uni_g(A.UMAX), UMIN = uni_g(A.UMIN);
+    const GlbD KFF = uni_g(A.KFF), KFB = uni_g(A.KFB);
+    const LdsD KL = uni_l(A.KL), KBL = uni_l(A.KBL);          // the LDS mirrors of the gains (used when lt)
+    const double mu = uni_d(A.mu);
+    const int T = uni_i(A.T);
+    const bool lt = uni_i(A.lt) != 0;
+#ifdef TPL_ILQR_STAMP
+    long long bacc[5] = {0, 0, 0, 0, 0};
+    long long b_last = (long long)__builtin_amdgcn_s_memtime();
+#define BSTAMP(i) do { const long long now__ = (long long)__builtin_amdgcn_s_memtime(); bacc[i] += now__ - b_last; b_last = now__; } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
+    {
+        // ---- backward Riccati pass, optim.c:926-985
+        // The stage blocks are read one stage AHEAD into registers (lane = entry) and
+        // parked in LDS during phase D of the stage before, so the HBM/L2 latency of stage
+        // t-1 hides under the dependent phases of stage t; four LDS exchanges per stage.
+        constexpr int E_XX = (NX * NX + WAVE - 1) / WAVE, E_XU = (NX * NU + WAVE - 1) / WAVE;
+        double r_fx[E_XX], r_lxx[E_XX], r_fu[E_XU], r_lux[E_XU], r_l = 0.0, r_luu = 0.0, r_ul[3] = {0.0, 0.0, 0.0};
+        auto fetch_stage = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < E_XX; ++q) {
+                const int e = lane + q * WAVE;
+                if (e < NX * NX) { r_fx[q] = FX[(int64_t)t * NX * NX + e]; r_lxx[q] = LXX[(int64_t)t * NX * NX + e]; }
+            }
+#pragma unroll
+            for (int q = 0; q < E_XU; ++q) {
+                const int e = lane + q * WAVE;
+                if (e < NX * NU) { r_fu[q] = FU[(int64_t)t * NX * NU + e]; r_lux[q] = LUX[(int64_t)t * NU * NX + e]; }
+            }
+            if (lane < NX) r_l = LX[(int64_t)t * NX + lane];
+            else if (lane < NXU) r_l = LU[(int64_t)t * NU + (lane - NX)];
+            if (lane < NU * NU) r_luu = LUU[(int64_t)t * NU * NU + lane];
+            if (lane < NU) {
+                r_ul[0] = U_[(int64_t)t * NU + lane];
+                r_ul[1] = UMAX[(int64_t)t * NU + lane];
+                r_ul[2] = UMIN[(int64_t)t * NU + lane];
+            }
+        };
+        auto park_stage = [&]() {
+#pragma unroll
+            for (int q = 0; q < E_XX; ++q) {
+                const int e = lane + q * WAVE;
+                if (e < NX * NX) {
+                    const int i = e / NX, j = e - i * NX;
+                    s->F[i * NXU + j] = r_fx[q];
+                    s->Lxx[e] = r_lxx[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < E_XU; ++q) {
+                const int e = lane + q * WAVE;
+                if (e < NX * NU) {
+                    const int i = e / NU, j = e - i * NU;
+                    s->F[i * NXU + NX + j] = r_fu[q];
+                    s->Lux[e] = r_lux[q];
+                }
+            }
+            if (lane < NXU) s->l[lane] = r_l;
+            if (lane < NU * NU) s->Luu[lane] = r_luu;
+            if (lane < NU) {
+                s->ulim[lane] = r_ul[0];
+                s->ulim[NU + lane] = r_ul[1];
+                s->ulim[2 * NU + lane] = r_ul[2];
+            }
+        };
+
+        // lane -> entry maps of phases A, B, D (they do not depend on the stage)
+        constexpr int N_XX = NX * (NX + 1) / 2, N_UX = NU * NX, N_UU = NU * (NU + 1) / 2;
+        constexpr int N_B = N_XX + N_UX + N_UU + NXU;
+        static_assert(NX * NXU <= 2 * WAVE && N_B <= 2 * WAVE, "state dimension too large for this kernel");
+        int b_colF[2], b_colW[2], b_out0[2], b_out1[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = lane + q * WAVE;
+            int colF = 0, colW = 0, out0 = -1, out1 = -1;
+            if (e < N_XX) {
+                int hi = 0;
+                while ((hi + 1) * (hi + 2) / 2 <= e) ++hi;             // row of the packed lower triangle
+                const int lo = e - hi * (hi + 1) / 2;
+                colF = hi; colW = lo; out0 = hi * NX + lo; out1 = lo * NX + hi;
+            } else if (e < N_XX + N_UX) {
+                const int r = e - N_XX, d = r / NX, jj = r - d * NX;
+                colF = NX + d; colW = jj; out0 = out1 = NX * NX + r;
+            } else if (e < N_XX + N_UX + N_UU) {
+                const int r = e - N_XX - N_UX;
+                int hi = 0;
+                while ((hi + 1) * (hi + 2) / 2 <= r) ++hi;
+                const int lo = r - hi * (hi + 1) / 2;
+                colF = NX + hi; colW = NX + lo;
+                out0 = NX * NX + NU * NX + hi * NU + lo; out1 = NX * NX + NU * NX + lo * NU + hi;
+            } else if (e < N_B) {
+                colF = e - (N_XX + N_UX + N_UU); colW = -1; out0 = out1 = colF;   // q entry
+            }
+            b_colF[q] = colF; b_colW[q] = colW; b_out0[q] = out0; b_out1[q] = out1;
+        }
+        // phase D: lanes [0, NX*NX) own Vxx entries, lanes [NX*NX, NX*NX+NX) own Vx entries
+        const bool d_vxx = lane < NX * NX, d_vx = lane >= NX * NX && lane < NX * NX + NX;
+        static_assert(NX * NX + NX <= WAVE || NX > 7, "phase D lane map");
+        const int d_i = d_vxx ? lane / NX : (d_vx ? lane - NX * NX : 0);
+        const int d_j = d_vxx ? lane - (lane / NX) * NX : 0;
+
+        fetch_stage(T - 1);
+        park_stage();
+        lds_sync();
+        if (T > 1) fetch_stage(T - 2);
+        for (int t = T - 1; t >= 0; --t) {
+            BSTAMP(0);
+            // phase A: W = Vxx [fx fu]
+#pragma unroll
+            for (int q = 0; q < (NX * NXU + WAVE - 1) / WAVE; ++q) {
+                const int e = lane + q * WAVE;
+                if (e < NX * NXU) {
+                    const int i = e / NXU, j = e - i * NXU;
+                    s->W[e] = dot_lds<NX>(&s->Vxx[i * NX], 1, &s->F[j], NXU);
+                }
+            }
+            lds_sync();
+
+            BSTAMP(1);
+            // phase B: Q = L + F^T W.  Only the lower triangles of the symmetric blocks are
+            // formed and then mirrored, like mul_symm (optim.c:159-180); q = l + F^T Vx rides
+            // along on otherwise idle lanes->
+#pragma unroll
+            for (int q = 0; q < (N_B + WAVE - 1) / WAVE; ++q) {
+                if (b_out0[q] >= 0) {
+                    if (b_colW[q] < 0) {
+                        s->q[b_out0[q]] = s->l[b_out0[q]] + dot_lds<NX>(&s->F[b_colF[q]], NXU, s->Vx, 1);
+                    } else {
+                        const double l0 = s->Lxx[b_out0[q]], l1 = s->Lxx[b_out1[q]];   // runs on into Lux / Luu
+                        const double acc = dot_lds<NX>(&s->F[b_colF[q]], NXU, &s->W[b_colW[q]], NXU);
+                        s->Qxx[b_out0[q]] = l0 + acc;                                   // runs on into Qux / Quu
+                        if (b_out1[q] != b_out0[q]) s->Qxx[b_out1[q]] = l1 + acc;
+                    }
+                }
+            }
+            lds_sync();
+
+            BSTAMP(2);
+            // phase C: gains (solve_action optim.c:243-291) + control-box projection (:950-963)
+            if (lane < NU * (NX + 1)) {
+                const int d = lane / (NX + 1), c = lane - d * (NX + 1);
+                double quu[NU * NU], qu[NU], col[NU];
+#pragma unroll
+                for (int m = 0; m < NU * NU; ++m) quu[m] = s->Quu[m];
+#pragma unroll
+                for (int m = 0; m < NU; ++m) { qu[m] = s->q[NX + m]; col[m] = (c == NX) ? 0.0 : s->Qux[m * NX + (c == NX ? 0 : c)]; }
+                const double ud = s->ulim[d], umax = s->ulim[NU + d], umin = s->ulim[2 * NU + d];
+                __builtin_amdgcn_sched_barrier(0);
+                double inv[NU][NU];
+                if constexpr (NU == 1) {
+                    inv[0][0] = (quu[0] > 0.0) ? -1.0 / (quu[0] + mu) : 0.0;
+                } else {
+                    const double qa = quu[0] + mu, qb = quu[1], qd = quu[NU + 1] + mu;
+                    const double det = qa * qd - qb * qb;
+                    const double inv_det = -1.0f / det;
+                    inv[0][0] = qd * inv_det;
+                    inv[0][NU - 1] = -qb * inv_det;
+                    inv[NU - 1][0] = inv[0][NU - 1];
+                    inv[NU - 1][NU - 1] = qa * inv_det;
+                }
+                double kd = 0.0;
+#pragma unroll
+                for (int m = 0; m < NU; ++m) kd = fma(inv[d][m], qu[m], kd);
+                double val;
+                if (c == NX) {
+                    val = kd;
+                } else {
+                    val = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NU; ++m) val = fma(inv[d][m], col[m], val);
+                }
+                const double cd = ud + kd;
+                if (cd > umax) val = (c == NX) ? umax - ud : 0.0;
+                if (cd < umin) val = (c == NX) ? umin - ud : 0.0;
+                if (c == NX) {
+                    s->k[d] = val;
+                    KFF[(int64_t)t * NU + d] = val;
+                    if (lt) KL[(int64_t)t * NU + d] = val;
+                } else {
+                    s->K[d * NX + c] = val;
+                    KFB[(int64_t)t * NU * NX + d * NX + c] = val;
+                    if (lt) KBL[(int64_t)t * NU * NX + d * NX + c] = val;
+                }
+            }
+            lds_sync();
+
+            BSTAMP(3);
+            // phase D: value function update, optim.c:965-984 (same order of additions)
+            if (d_vxx || d_vx) {
+                double Ki[NU], Kj[NU], Qi[NU], Qj[NU], quu[NU * NU], kk[NU], qu[NU];
+#pragma unroll
+                for (int d = 0; d < NU; ++d) {
+                    Ki[d] = s->K[d * NX + d_i]; Kj[d] = s->K[d * NX + d_j];
+                    Qi[d] = s->Qux[d * NX + d_i]; Qj[d] = s->Qux[d * NX + d_j];
+                    kk[d] = s->k[d]; qu[d] = s->q[NX + d];
+                }
+#pragma unroll
+                for (int m = 0; m < NU * NU; ++m) quu[m] = s->Quu[m];
+                const double tail = d_vxx ? s->Qxx[lane] : s->q[d_i];
+                __builtin_amdgcn_sched_barrier(0);
+                double kq[NU];                                   // (K^T Quu)[i][d]
+#pragma unroll
+                for (int d = 0; d < NU; ++d) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NU; ++m) a = fma(Ki[m], quu[m * NU + d], a);
+                    kq[d] = a;
+                }
+                if (d_vxx) {
+                    double mij = 0.0, mji = 0.0;
+#pragma unroll
+                    for (int d = 0; d < NU; ++d) { mij = fma(Ki[d], Qj[d], mij); mji = fma(Kj[d], Qi[d], mji); }
+                    double v = mji + mij;
+#pragma unroll
+                    for (int d = 0; d < NU; ++d) v = fma(kq[d], Kj[d], v);
+                    s->Vxx[lane] = v + tail;
+                } else {
+                    double v = 0.0;
+#pragma unroll
+                    for (int d = 0; d < NU; ++d) v = fma(kq[d], kk[d], v);
+#pragma unroll
+                    for (int d = 0; d < NU; ++d) v = fma(Ki[d], qu[d], v);
+#pragma unroll
+                    for (int d = 0; d < NU; ++d) v = fma(Qi[d], kk[d], v);
+                    s->Vx[d_i] = v + tail;
+                }
+            }
+            // stage t-1 is already in registers: park it for the next trip, then fetch t-2
+            if (t > 0) park_stage();
+            lds_sync();
+            if (t > 1) fetch_stage(t - 2);
+            BSTAMP(4);
+        }
+    }
+#ifdef TPL_ILQR_STAMP
+    if (lane == 0 && A.stamp_acc) for (int i = 0; i < 5; ++i) A.stamp_acc[6 + i] += bacc[i];
+#endif
+}
 
 // The line-search rollouts as a function of their own (NOT inlined): inside k_ilqr_update the
 // derivative refresh drives the register allocation to 500 registers with most long-lived values
@@ -418,6 +697,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
 
 #ifdef TPL_ILQR_STAMP
     long long stamps[16] = {0};
+    if (lane == 0 && st.stamps) for (int i = 6; i <= 10; ++i) st.stamps[(int64_t)b * 16 + i] = 0;
     long long t_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
     // ---- initial trajectory rollout, optim.c:1101-1111.  The dynamics chain is serial in
@@ -546,227 +826,16 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
             __syncthreads();
 
             if (second_order) {
-                // ---- backward Riccati pass, optim.c:926-985
-                // The stage blocks are read one stage AHEAD into registers (lane = entry) and
-                // parked in LDS during phase D of the stage before, so the HBM/L2 latency of stage
-                // t-1 hides under the dependent phases of stage t; four LDS exchanges per stage.
-                constexpr int E_XX = (NX * NX + WAVE - 1) / WAVE, E_XU = (NX * NU + WAVE - 1) / WAVE;
-                double r_fx[E_XX], r_lxx[E_XX], r_fu[E_XU], r_lux[E_XU], r_l = 0.0, r_luu = 0.0, r_ul[3] = {0.0, 0.0, 0.0};
-                auto fetch_stage = [&](int t) {
-#pragma unroll
-                    for (int q = 0; q < E_XX; ++q) {
-                        const int e = lane + q * WAVE;
-                        if (e < NX * NX) { r_fx[q] = FX[(int64_t)t * NX * NX + e]; r_lxx[q] = LXX[(int64_t)t * NX * NX + e]; }
-                    }
-#pragma unroll
-                    for (int q = 0; q < E_XU; ++q) {
-                        const int e = lane + q * WAVE;
-                        if (e < NX * NU) { r_fu[q] = FU[(int64_t)t * NX * NU + e]; r_lux[q] = LUX[(int64_t)t * NU * NX + e]; }
-                    }
-                    if (lane < NX) r_l = LX[(int64_t)t * NX + lane];
-                    else if (lane < NXU) r_l = LU[(int64_t)t * NU + (lane - NX)];
-                    if (lane < NU * NU) r_luu = LUU[(int64_t)t * NU * NU + lane];
-                    if (lane < NU) {
-                        r_ul[0] = U_[(int64_t)t * NU + lane];
-                        r_ul[1] = UMAX[(int64_t)t * NU + lane];
-                        r_ul[2] = UMIN[(int64_t)t * NU + lane];
-                    }
-                };
-                auto park_stage = [&]() {
-#pragma unroll
-                    for (int q = 0; q < E_XX; ++q) {
-                        const int e = lane + q * WAVE;
-                        if (e < NX * NX) {
-                            const int i = e / NX, j = e - i * NX;
-                            s.F[i * NXU + j] = r_fx[q];
-                            s.Lxx[e] = r_lxx[q];
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < E_XU; ++q) {
-                        const int e = lane + q * WAVE;
-                        if (e < NX * NU) {
-                            const int i = e / NU, j = e - i * NU;
-                            s.F[i * NXU + NX + j] = r_fu[q];
-                            s.Lux[e] = r_lux[q];
-                        }
-                    }
-                    if (lane < NXU) s.l[lane] = r_l;
-                    if (lane < NU * NU) s.Luu[lane] = r_luu;
-                    if (lane < NU) {
-                        s.ulim[lane] = r_ul[0];
-                        s.ulim[NU + lane] = r_ul[1];
-                        s.ulim[2 * NU + lane] = r_ul[2];
-                    }
-                };
-
-                // lane -> entry maps of phases A, B, D (they do not depend on the stage)
-                constexpr int N_XX = NX * (NX + 1) / 2, N_UX = NU * NX, N_UU = NU * (NU + 1) / 2;
-                constexpr int N_B = N_XX + N_UX + N_UU + NXU;
-                static_assert(NX * NXU <= 2 * WAVE && N_B <= 2 * WAVE, "state dimension too large for this kernel");
-                int b_colF[2], b_colW[2], b_out0[2], b_out1[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int e = lane + q * WAVE;
-                    int colF = 0, colW = 0, out0 = -1, out1 = -1;
-                    if (e < N_XX) {
-                        int hi = 0;
-                        while ((hi + 1) * (hi + 2) / 2 <= e) ++hi;             // row of the packed lower triangle
-                        const int lo = e - hi * (hi + 1) / 2;
-                        colF = hi; colW = lo; out0 = hi * NX + lo; out1 = lo * NX + hi;
-                    } else if (e < N_XX + N_UX) {
-                        const int r = e - N_XX, d = r / NX, jj = r - d * NX;
-                        colF = NX + d; colW = jj; out0 = out1 = NX * NX + r;
-                    } else if (e < N_XX + N_UX + N_UU) {
-                        const int r = e - N_XX - N_UX;
-                        int hi = 0;
-                        while ((hi + 1) * (hi + 2) / 2 <= r) ++hi;
-                        const int lo = r - hi * (hi + 1) / 2;
-                        colF = NX + hi; colW = NX + lo;
-                        out0 = NX * NX + NU * NX + hi * NU + lo; out1 = NX * NX + NU * NX + lo * NU + hi;
-                    } else if (e < N_B) {
-                        colF = e - (N_XX + N_UX + N_UU); colW = -1; out0 = out1 = colF;   // q entry
-                    }
-                    b_colF[q] = colF; b_colW[q] = colW; b_out0[q] = out0; b_out1[q] = out1;
-                }
-                // phase D: lanes [0, NX*NX) own Vxx entries, lanes [NX*NX, NX*NX+NX) own Vx entries
-                const bool d_vxx = lane < NX * NX, d_vx = lane >= NX * NX && lane < NX * NX + NX;
-                static_assert(NX * NX + NX <= WAVE || NX > 7, "phase D lane map");
-                const int d_i = d_vxx ? lane / NX : (d_vx ? lane - NX * NX : 0);
-                const int d_j = d_vxx ? lane - (lane / NX) * NX : 0;
-
-                fetch_stage(T - 1);
-                park_stage();
-                lds_sync();
-                if (T > 1) fetch_stage(T - 2);
-                for (int t = T - 1; t >= 0; --t) {
-                    STAMP(6);
-                    // phase A: W = Vxx [fx fu]
-#pragma unroll
-                    for (int q = 0; q < (NX * NXU + WAVE - 1) / WAVE; ++q) {
-                        const int e = lane + q * WAVE;
-                        if (e < NX * NXU) {
-                            const int i = e / NXU, j = e - i * NXU;
-                            s.W[e] = dot_lds<NX>(&s.Vxx[i * NX], 1, &s.F[j], NXU);
-                        }
-                    }
-                    lds_sync();
-                    STAMP(7);
-
-                    // phase B: Q = L + F^T W.  Only the lower triangles of the symmetric blocks are
-                    // formed and then mirrored, like mul_symm (optim.c:159-180); q = l + F^T Vx rides
-                    // along on otherwise idle lanes.
-#pragma unroll
-                    for (int q = 0; q < (N_B + WAVE - 1) / WAVE; ++q) {
-                        if (b_out0[q] >= 0) {
-                            if (b_colW[q] < 0) {
-                                s.q[b_out0[q]] = s.l[b_out0[q]] + dot_lds<NX>(&s.F[b_colF[q]], NXU, s.Vx, 1);
-                            } else {
-                                const double l0 = s.Lxx[b_out0[q]], l1 = s.Lxx[b_out1[q]];   // runs on into Lux / Luu
-                                const double acc = dot_lds<NX>(&s.F[b_colF[q]], NXU, &s.W[b_colW[q]], NXU);
-                                s.Qxx[b_out0[q]] = l0 + acc;                                   // runs on into Qux / Quu
-                                if (b_out1[q] != b_out0[q]) s.Qxx[b_out1[q]] = l1 + acc;
-                            }
-                        }
-                    }
-                    lds_sync();
-                    STAMP(8);
-
-                    // phase C: gains (solve_action optim.c:243-291) + control-box projection (:950-963)
-                    if (lane < NU * (NX + 1)) {
-                        const int d = lane / (NX + 1), c = lane - d * (NX + 1);
-                        double quu[NU * NU], qu[NU], col[NU];
-#pragma unroll
-                        for (int m = 0; m < NU * NU; ++m) quu[m] = s.Quu[m];
-#pragma unroll
-                        for (int m = 0; m < NU; ++m) { qu[m] = s.q[NX + m]; col[m] = (c == NX) ? 0.0 : s.Qux[m * NX + (c == NX ? 0 : c)]; }
-                        const double ud = s.ulim[d], umax = s.ulim[NU + d], umin = s.ulim[2 * NU + d];
-                        __builtin_amdgcn_sched_barrier(0);
-                        double inv[NU][NU];
-                        if constexpr (NU == 1) {
-                            inv[0][0] = (quu[0] > 0.0) ? -1.0 / (quu[0] + mu) : 0.0;
-                        } else {
-                            const double qa = quu[0] + mu, qb = quu[1], qd = quu[NU + 1] + mu;
-                            const double det = qa * qd - qb * qb;
-                            const double inv_det = -1.0f / det;
-                            inv[0][0] = qd * inv_det;
-                            inv[0][NU - 1] = -qb * inv_det;
-                            inv[NU - 1][0] = inv[0][NU - 1];
-                            inv[NU - 1][NU - 1] = qa * inv_det;
-                        }
-                        double kd = 0.0;
-#pragma unroll
-                        for (int m = 0; m < NU; ++m) kd = fma(inv[d][m], qu[m], kd);
-                        double val;
-                        if (c == NX) {
-                            val = kd;
-                        } else {
-                            val = 0.0;
-#pragma unroll
-                            for (int m = 0; m < NU; ++m) val = fma(inv[d][m], col[m], val);
-                        }
-                        const double cd = ud + kd;
-                        if (cd > umax) val = (c == NX) ? umax - ud : 0.0;
-                        if (cd < umin) val = (c == NX) ? umin - ud : 0.0;
-                        if (c == NX) {
-                            s.k[d] = val;
-                            KFF[(int64_t)t * NU + d] = val;
-                            if (lt) KL[(int64_t)t * NU + d] = val;
-                        } else {
-                            s.K[d * NX + c] = val;
-                            KFB[(int64_t)t * NU * NX + d * NX + c] = val;
-                            if (lt) KBL[(int64_t)t * NU * NX + d * NX + c] = val;
-                        }
-                    }
-                    lds_sync();
-                    STAMP(9);
-
-                    // phase D: value function update, optim.c:965-984 (same order of additions)
-                    if (d_vxx || d_vx) {
-                        double Ki[NU], Kj[NU], Qi[NU], Qj[NU], quu[NU * NU], kk[NU], qu[NU];
-#pragma unroll
-                        for (int d = 0; d < NU; ++d) {
-                            Ki[d] = s.K[d * NX + d_i]; Kj[d] = s.K[d * NX + d_j];
-                            Qi[d] = s.Qux[d * NX + d_i]; Qj[d] = s.Qux[d * NX + d_j];
-                            kk[d] = s.k[d]; qu[d] = s.q[NX + d];
-                        }
-#pragma unroll
-                        for (int m = 0; m < NU * NU; ++m) quu[m] = s.Quu[m];
-                        const double tail = d_vxx ? s.Qxx[lane] : s.q[d_i];
-                        __builtin_amdgcn_sched_barrier(0);
-                        double kq[NU];                                   // (K^T Quu)[i][d]
-#pragma unroll
-                        for (int d = 0; d < NU; ++d) {
-                            double a = 0.0;
-#pragma unroll
-                            for (int m = 0; m < NU; ++m) a = fma(Ki[m], quu[m * NU + d], a);
-                            kq[d] = a;
-                        }
-                        if (d_vxx) {
-                            double mij = 0.0, mji = 0.0;
-#pragma unroll
-                            for (int d = 0; d < NU; ++d) { mij = fma(Ki[d], Qj[d], mij); mji = fma(Kj[d], Qi[d], mji); }
-                            double v = mji + mij;
-#pragma unroll
-                            for (int d = 0; d < NU; ++d) v = fma(kq[d], Kj[d], v);
-                            s.Vxx[lane] = v + tail;
-                        } else {
-                            double v = 0.0;
-#pragma unroll
-                            for (int d = 0; d < NU; ++d) v = fma(kq[d], kk[d], v);
-#pragma unroll
-                            for (int d = 0; d < NU; ++d) v = fma(Ki[d], qu[d], v);
-#pragma unroll
-                            for (int d = 0; d < NU; ++d) v = fma(Qi[d], kk[d], v);
-                            s.Vx[d_i] = v + tail;
-                        }
-                    }
-                    // stage t-1 is already in registers: park it for the next trip, then fetch t-2
-                    if (t > 0) park_stage();
-                    lds_sync();
-                    if (t > 1) fetch_stage(t - 2);
-                    STAMP(10);
-                }
+                RiccatiArgs ra;
+                ra.FX = FX; ra.LXX = LXX; ra.FU = FU; ra.LUX = LUX; ra.LX = LX; ra.LU = LU; ra.LUU = LUU;
+                ra.U_ = U_; ra.UMAX = UMAX; ra.UMIN = UMIN; ra.KFF = KFF; ra.KFB = KFB; ra.KL = KL; ra.KBL = KBL;
+                ra.mu = mu; ra.T = T; ra.lt = lt ? 1 : 0;
+#ifdef TPL_ILQR_STAMP
+                ra.stamp_acc = st.stamps ? st.stamps + (int64_t)b * 16 : nullptr;
+#else
+                ra.stamp_acc = nullptr;
+#endif
+                riccati_backward(ra, (LdsAS*)&s);
             } else {
                 // ---- first-order backward pass, optim.c:1044-1073
                 for (int t = T - 1; t >= 0; --t) {
@@ -915,7 +984,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
     if (iterations == max_iter) term = 1;                      // optim.c:1147-1149
 
 #ifdef TPL_ILQR_STAMP
-    if (lane == 0) for (int i = 0; i < 16; ++i) st.stamps[(int64_t)b * 16 + i] = stamps[i];
+    if (lane == 0) for (int i = 0; i < 16; ++i) if (i < 6 || i > 10) st.stamps[(int64_t)b * 16 + i] = stamps[i];
 #endif
     if (lane == 0) {
         sc[TPL_S_TRAJ_COSTS] = J;
