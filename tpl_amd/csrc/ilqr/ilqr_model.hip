@@ -39,6 +39,7 @@
 #include <cstring>
 #include <iterator>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "builtins.h"
@@ -223,6 +224,8 @@ __device__ __forceinline__ double dot_lds(PA a, int sa, PB b, int sb)
     return acc;
 }
 
+constexpr int ROLL_RING = 8;
+
 // LDS working set of one problem
 struct Lds {
     double Vxx[NX * NX];
@@ -241,6 +244,10 @@ struct Lds {
     double k[NU];
     double ulim[3 * NU];       // u[t], uMax[t], uMin[t]
     double red[N_ALPHA];
+    // line-search rollouts: RING stages of every candidate's (x_{t+1}, u_t) collect here and go out
+    // to the candidate arrays in one coalesced sweep of all 64 lanes (see line_search_rollouts)
+    double ring_x[N_ALPHA * ROLL_RING * NX];
+    double ring_u[N_ALPHA * ROLL_RING * NU];
 };
 
 // ---- backward Riccati pass, optim.c:926-985, as a function of its own (NOT inlined) -- same reason as
@@ -251,7 +258,8 @@ struct Lds {
 typedef __attribute__((address_space(3))) Lds LdsAS;
 typedef const __attribute__((address_space(1))) double* GlbCD;    // global-memory pointers: global_load /
 typedef __attribute__((address_space(1))) double* GlbD;           // global_store (a generic pointer would be a
-typedef __attribute__((address_space(3))) double* LdsD;           // flat access, which also counts as an LDS one)
+typedef __attribute__((address_space(3))) double* LdsD;
+typedef const __attribute__((address_space(3))) double* LdsCD;           // flat access, which also counts as an LDS one)
 struct RiccatiArgs {
     const double* FX; const double* LXX; const double* FU; const double* LUX; const double* LX; const double* LU;
     const double* LUU; const double* U_; const double* UMAX; const double* UMIN;
@@ -271,7 +279,11 @@ __device__ __forceinline__ unsigned long long uni_u64(unsigned long long v)
 }
 __device__ __forceinline__ GlbCD uni_g(const double* p) { return (GlbCD)uni_u64((unsigned long long)p); }
 __device__ __forceinline__ GlbD uni_g(double* p) { return (GlbD)uni_u64((unsigned long long)p); }
-__device__ __forceinline__ LdsD uni_l(double* p) { return (LdsD)(unsigned)uni_i((int)(unsigned)(unsigned long long)(LdsD)p); }
+// a generic pointer into LDS -> LDS pointer: the low half of the flat address IS the LDS offset.  (A
+// plain address-space cast also emits a null test against the shared aperture, which this hipcc
+// mis-selects in some kernels: "Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base".)
+__device__ __forceinline__ LdsCD uni_l(const double* p) { return (LdsCD)(unsigned)uni_i((int)(unsigned)(unsigned long long)p); }
+__device__ __forceinline__ LdsD uni_l(double* p) { return (LdsD)(unsigned)uni_i((int)(unsigned)(unsigned long long)p); }
 __device__ __forceinline__ double uni_d(double d)
 {
     return __longlong_as_double((long long)uni_u64((unsigned long long)__double_as_longlong(d)));
@@ -537,64 +549,128 @@ struct RolloutArgs {
     bool second_order;
 };
 
-__device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs A, int lane)
+template <bool LT>
+__device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs A, LdsAS* s)
 {
     // Candidate c runs on the QUAD of lanes 4c .. 4c+3: all four hold the same state and
     // control, the model's dynamics spread their independent look-ups and sin/cos evaluations
-    // over them (dynamics_quad), lane 4c alone writes the candidate arrays.
-    if (lane < 4 * N_ALPHA) {
-        const int cand = lane >> 2;
-        const bool writer = (lane & 3) == 0;
-        double a = 1.0;
-        for (int i = 0; i < cand; ++i) a *= 10.0;
-        a = 1.0 / a;                                   // 1.0 / pow(10, i)
-        double* cx = A.CX + (int64_t)cand * A.rows * NX;
-        double* cu = A.CU + (int64_t)cand * A.rows * NU;
-        double x[NX], xn[NX], u[NU];
-        // stages before A.opt_start are frozen (tpl never moves A.opt_start off 0)
-        if (writer) for (int e = 0; e < A.opt_start * NX; ++e) cx[e] = A.X_[e];
+    // over them (dynamics_quad), lane 4c alone records the candidate.
+    //
+    // Where the results go matters more than it looks: loads and stores of a wavefront share ONE
+    // counter (vmcnt) and complete in order, so a load that follows a store to global memory
+    // waits for that store's acknowledgement from L2 -- with nine stores per stage every stage
+    // paid a full write round trip (0.5 ms of a 5 ms update).  The stage results therefore
+    // collect in an LDS ring and leave every ROLL_RING stages in one coalesced sweep of all 64
+    // lanes; the operands of the feedback law are read through pointers of the address space they
+    // live in (LDS mirrors when LT, else global memory), not through flat accesses.
+    using RP = typename std::conditional<LT, LdsCD, GlbCD>::type;
+    const int lane = (int)threadIdx.x;
+    const GlbD CX = uni_g(A.CX), CU = uni_g(A.CU);
+    const GlbCD X_ = uni_g(A.X_);
+    RP KFFr, Ur, UMAXr, UMINr, KFBr, Xr;
+    if constexpr (LT) {
+        KFFr = uni_l(A.KFFr); Ur = uni_l(A.Ur); UMAXr = uni_l(A.UMAXr); UMINr = uni_l(A.UMINr);
+        KFBr = uni_l(A.KFBr); Xr = uni_l(A.Xr);
+    } else {
+        KFFr = uni_g(A.KFFr); Ur = uni_g(A.Ur); UMAXr = uni_g(A.UMAXr); UMINr = uni_g(A.UMINr);
+        KFBr = uni_g(A.KFBr); Xr = uni_g(A.Xr);
+    }
+    const Params* P = (const Params*)uni_u64((unsigned long long)A.P);
+    const double dt = uni_d(A.dt);
+    const int rows = uni_i(A.rows), opt_start = uni_i(A.opt_start), T = uni_i(A.T), int_type = uni_i(A.int_type);
+    const bool second_order = uni_i(A.second_order ? 1 : 0) != 0;
+
+    const bool active = lane < 4 * N_ALPHA;
+    const int cand = lane >> 2;
+    const bool writer = active && (lane & 3) == 0;
+    double a = 1.0;
+    for (int i = 0; i < cand; ++i) a *= 10.0;
+    a = 1.0 / a;                                       // 1.0 / pow(10, i)
+    double x[NX], xn[NX], u[NU];
+    // stages up to opt_start are frozen (tpl never moves opt_start off 0)
+    for (int e = lane; e < N_ALPHA * (opt_start + 1) * NX; e += WAVE) {
+        const int c = e / ((opt_start + 1) * NX), off = e - c * ((opt_start + 1) * NX);
+        CX[(int64_t)c * rows * NX + off] = X_[off];
+    }
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { x[i] = A.X_[(int64_t)A.opt_start * NX + i]; if (writer) cx[(int64_t)A.opt_start * NX + i] = x[i]; }
-        for (int t = A.opt_start; t < A.T; ++t) {
-            // feedback law: all operands first, then the arithmetic (one memory round trip)
-            double kff[NU], ub[NU], hi[NU], lo[NU], kfb[NU * NX], xr[NX];
+    for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)opt_start * NX + i];
+
+    for (int t0 = opt_start; t0 < T; t0 += ROLL_RING) {
+        const int n = (T - t0 < ROLL_RING) ? T - t0 : ROLL_RING;
+        if (active) {
+            for (int k = 0; k < n; ++k) {
+                const int t = t0 + k;
+                // feedback law: all operands first, then the arithmetic (one memory round trip)
+                double kff[NU], ub[NU], hi[NU], lo[NU], kfb[NU * NX], xr[NX];
 #pragma unroll
-            for (int d = 0; d < NU; ++d) {
-                kff[d] = A.KFFr[(int64_t)t * NU + d];
-                ub[d] = A.Ur[(int64_t)t * NU + d];
-                hi[d] = A.UMAXr[(int64_t)t * NU + d];
-                lo[d] = A.UMINr[(int64_t)t * NU + d];
-            }
-            if (A.second_order) {
-#pragma unroll
-                for (int e = 0; e < NU * NX; ++e) kfb[e] = A.KFBr[(int64_t)t * NU * NX + e];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) xr[i] = A.Xr[(int64_t)t * NX + i];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int d = 0; d < NU; ++d) {
-                double ud;
-                if (A.second_order) {
-                    ud = kff[d] * a;
-                    ud = ud + ub[d];
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) ud += kfb[d * NX + i] * (x[i] - xr[i]);
-                    ud = hi[d] < ud ? hi[d] : ud;
-                    ud = lo[d] > ud ? lo[d] : ud;
-                } else {
-                    ud = ub[d] - kff[d] * a;
+                for (int d = 0; d < NU; ++d) {
+                    kff[d] = KFFr[(int64_t)t * NU + d];
+                    ub[d] = Ur[(int64_t)t * NU + d];
+                    hi[d] = UMAXr[(int64_t)t * NU + d];
+                    lo[d] = UMINr[(int64_t)t * NU + d];
                 }
-                u[d] = ud;
-                if (writer) cu[(int64_t)t * NU + d] = ud;
-            }
-                                dynamics_quad(*A.P, x, u, t, A.dt, A.int_type, xn);
+                if (second_order) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                x[i] = xn[i];
-                if (writer) cx[(int64_t)(t + 1) * NX + i] = xn[i];
+                    for (int e = 0; e < NU * NX; ++e) kfb[e] = KFBr[(int64_t)t * NU * NX + e];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) xr[i] = Xr[(int64_t)t * NX + i];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int d = 0; d < NU; ++d) {
+                    double ud;
+                    if (second_order) {
+                        ud = kff[d] * a;
+                        ud = ud + ub[d];
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) ud += kfb[d * NX + i] * (x[i] - xr[i]);
+                        ud = hi[d] < ud ? hi[d] : ud;
+                        ud = lo[d] > ud ? lo[d] : ud;
+                    } else {
+                        ud = ub[d] - kff[d] * a;
+                    }
+                    u[d] = ud;
+                    if (writer) s->ring_u[(cand * ROLL_RING + k) * NU + d] = ud;
+                }
+                dynamics_quad(*P, x, u, t, dt, int_type, xn);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    x[i] = xn[i];
+                    if (writer) s->ring_x[(cand * ROLL_RING + k) * NX + i] = xn[i];
+                }
             }
         }
+        lds_sync();
+        // the ring goes out: candidate c, stages t0 .. t0+n-1 are n*NX (n*NU) consecutive doubles
+        // on both sides
+        if (n == ROLL_RING) {
+#pragma unroll
+            for (int q = 0; q < (N_ALPHA * ROLL_RING * NX + WAVE - 1) / WAVE; ++q) {
+                const int e = lane + q * WAVE;
+                if (e < N_ALPHA * ROLL_RING * NX) {
+                    const int c = e / (ROLL_RING * NX), off = e - c * (ROLL_RING * NX);
+                    CX[(int64_t)c * rows * NX + (int64_t)(t0 + 1) * NX + off] = s->ring_x[e];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < (N_ALPHA * ROLL_RING * NU + WAVE - 1) / WAVE; ++q) {
+                const int e = lane + q * WAVE;
+                if (e < N_ALPHA * ROLL_RING * NU) {
+                    const int c = e / (ROLL_RING * NU), off = e - c * (ROLL_RING * NU);
+                    CU[(int64_t)c * rows * NU + (int64_t)t0 * NU + off] = s->ring_u[e];
+                }
+            }
+        } else {
+            for (int e = lane; e < N_ALPHA * n * NX; e += WAVE) {
+                const int c = e / (n * NX), off = e - c * (n * NX);
+                CX[(int64_t)c * rows * NX + (int64_t)(t0 + 1) * NX + off] = s->ring_x[c * ROLL_RING * NX + off];
+            }
+            for (int e = lane; e < N_ALPHA * n * NU; e += WAVE) {
+                const int c = e / (n * NU), off = e - c * (n * NU);
+                CU[(int64_t)c * rows * NU + (int64_t)t0 * NU + off] = s->ring_u[c * ROLL_RING * NU + off];
+            }
+        }
+        lds_sync();
     }
 }
 
@@ -835,7 +911,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
 #else
                 ra.stamp_acc = nullptr;
 #endif
-                riccati_backward(ra, (LdsAS*)&s);
+                riccati_backward(ra, (LdsAS*)(unsigned)(unsigned long long)&s);
             } else {
                 // ---- first-order backward pass, optim.c:1044-1073
                 for (int t = T - 1; t >= 0; --t) {
@@ -875,7 +951,8 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                 ra.CX = CX; ra.CU = CU; ra.X_ = X_; ra.KFFr = KFFr; ra.Ur = Ur; ra.UMAXr = UMAXr; ra.UMINr = UMINr;
                 ra.KFBr = KFBr; ra.Xr = Xr; ra.P = &P; ra.dt = dt; ra.rows = st.rows; ra.opt_start = opt_start;
                 ra.T = T; ra.int_type = int_type; ra.second_order = second_order;
-                line_search_rollouts(ra, lane);
+                if (lt) line_search_rollouts<true>(ra, (LdsAS*)(unsigned)(unsigned long long)&s);
+                else line_search_rollouts<false>(ra, (LdsAS*)(unsigned)(unsigned long long)&s);
             }
             __syncthreads();
             STAMP(11);
@@ -1117,7 +1194,7 @@ void plan_lds(tplhip_ilqr* h)
     d.lds_dyn_flat = 0;
     h->lds_dyn_bytes = 0;
     if (!h->lds_aperture || std::getenv("TPLHIP_ILQR_NO_LDS")) return;
-    const size_t budget = 36 * 1024 / sizeof(double);
+    const size_t budget = (39 * 1024 - sizeof(Lds)) / sizeof(double);
     const size_t traj = (size_t)h->rows * (NX + NU + NU + NU * NX + NU + NU);
     size_t off = 0;
     if (traj <= budget) { d.lds_traj = 1; off = traj; }
