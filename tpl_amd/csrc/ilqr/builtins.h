@@ -257,14 +257,20 @@ __device__ inline double tpl_quad_pick(int q, double a0, double a1, double a2, d
 }
 
 // lane q of the quad: tpl_lerp (or tpl_lerp_angle where bit q of angle_mask is set) of arrs[q]
-__device__ inline double tpl_quad_lookup(int q, double x0, double dx, double x, const DynArr* const arrs[4],
-                                         unsigned angle_mask)
+__device__ inline double tpl_quad_lookup(int q, double x0, double dx, double x, const DynArr& a0, const DynArr& a1,
+                                         const DynArr& a2, const DynArr& a3, unsigned angle_mask)
 {
-    const DynArr* arr = (q == 0) ? arrs[0] : (q == 1) ? arrs[1] : (q == 2) ? arrs[2] : arrs[3];
-    const int64_t n = arr->n0;
+    // Four separate references and a select over the VALUES (length, base pointer): the descriptors
+    // stay plain member reads of the parameter record, which may then live in registers.  (An array
+    // of descriptor pointers indexed by the lane ends up in a stack slot.)
+    const int64_t n0 = a0.n0, n1 = a1.n0, n2 = a2.n0, n3 = a3.n0;         // read all four first: a lazy ?:
+    const double* const d0 = a0.data; const double* const d1 = a1.data;   // chain is turned back into ONE
+    const double* const d2 = a2.data; const double* const d3 = a3.data;   // load through a selected address
+    const int64_t n = (q == 0) ? n0 : (q == 1) ? n1 : (q == 2) ? n2 : n3;
+    const double* data = (q == 0) ? d0 : (q == 1) ? d1 : (q == 2) ? d2 : d3;
     if (n == 0) return 0.0;
     const TplInterp i = tpl_init_interp(x0, dx, x, n);
-    const double p0 = arr->data[i.start], p1 = arr->data[i.end];
+    const double p0 = data[i.start], p1 = data[i.end];
     const double lin = i.ia * p0 + i.a * p1;                              // tpl_lerp
     if (angle_mask == 0u) return lin;
     const double ang = p0 + tpl_short_angle_dist(p0, p1) * i.a;           // tpl_lerp_angle

@@ -33,6 +33,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdint>
 #include <cstdlib>
 #include <cstdio>
@@ -534,6 +535,25 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
 #endif
 }
 
+// The parameter record through the constant address space, field by field (typed, so the copy
+// ends up in registers and not in a stack slot).
+__device__ __forceinline__ void load_params_uniform(Params& dst, const Params* src_generic)
+{
+    typedef const __attribute__((address_space(4))) char* CstC;
+    typedef const __attribute__((address_space(4))) double* CstD;
+    typedef const __attribute__((address_space(4))) long long* CstL;
+    typedef const __attribute__((address_space(4))) int* CstI;
+    const CstC base = (CstC)uni_u64((unsigned long long)src_generic);
+#define TPL_PARAM_S(n) dst.n = *(CstD)(base + offsetof(Params, n));
+#define TPL_PARAM_A(n) { const CstC q = base + offsetof(Params, n); \
+        dst.n.data = (const double*)(unsigned long long)*(CstL)(q + offsetof(DynArr, data)); \
+        dst.n.n0 = *(CstL)(q + offsetof(DynArr, n0)); dst.n.n1 = *(CstL)(q + offsetof(DynArr, n1)); \
+        dst.n.ndim = *(CstI)(q + offsetof(DynArr, ndim)); dst.n.pad = 0; }
+    TPL_PARAM_LIST
+#undef TPL_PARAM_S
+#undef TPL_PARAM_A
+}
+
 // The line-search rollouts as a function of their own (NOT inlined): inside k_ilqr_update the
 // derivative refresh drives the register allocation to 500 registers with most long-lived values
 // parked in AGPRs, and the rollout loop -- a chain of dependent instructions on a single wavefront,
@@ -547,6 +567,7 @@ struct RolloutArgs {
     double dt;
     int rows, opt_start, T, int_type;
     bool second_order;
+    long long* stamp_acc;      // diagnostic builds only
 };
 
 template <bool LT>
@@ -575,11 +596,23 @@ __device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs
         KFFr = uni_g(A.KFFr); Ur = uni_g(A.Ur); UMAXr = uni_g(A.UMAXr); UMINr = uni_g(A.UMINr);
         KFBr = uni_g(A.KFBr); Xr = uni_g(A.Xr);
     }
-    const Params* P = (const Params*)uni_u64((unsigned long long)A.P);
+    // The parameter record is read-only for the whole launch: fetch it ONCE, with scalar loads from
+    // the constant address space, into registers.  Through the generic pointer every use inside the
+    // dynamics was a flat load on the dependent chain (nothing can be hoisted over the ring stores).
+    Params Pl;
+    load_params_uniform(Pl, A.P);
+    const Params* P = &Pl;
     const double dt = uni_d(A.dt);
     const int rows = uni_i(A.rows), opt_start = uni_i(A.opt_start), T = uni_i(A.T), int_type = uni_i(A.int_type);
     const bool second_order = uni_i(A.second_order ? 1 : 0) != 0;
 
+#ifdef TPL_ILQR_STAMP
+    long long racc[3] = {0, 0, 0};
+    long long r_last = (long long)__builtin_amdgcn_s_memtime();
+#define RSTAMP(i) do { const long long now__ = (long long)__builtin_amdgcn_s_memtime(); racc[i] += now__ - r_last; r_last = now__; } while (0)
+#else
+#define RSTAMP(i) do { } while (0)
+#endif
     const bool active = lane < 4 * N_ALPHA;
     const int cand = lane >> 2;
     const bool writer = active && (lane & 3) == 0;
@@ -632,12 +665,14 @@ __device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs
                     u[d] = ud;
                     if (writer) s->ring_u[(cand * ROLL_RING + k) * NU + d] = ud;
                 }
+                RSTAMP(0);
                 dynamics_quad(*P, x, u, t, dt, int_type, xn);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     x[i] = xn[i];
                     if (writer) s->ring_x[(cand * ROLL_RING + k) * NX + i] = xn[i];
                 }
+                RSTAMP(1);
             }
         }
         lds_sync();
@@ -671,7 +706,11 @@ __device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs
             }
         }
         lds_sync();
+        RSTAMP(2);
     }
+#ifdef TPL_ILQR_STAMP
+    if (lane == 0 && A.stamp_acc) { A.stamp_acc[14] += racc[0]; A.stamp_acc[15] += racc[1]; A.stamp_acc[4] += racc[2]; }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -773,7 +812,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
 
 #ifdef TPL_ILQR_STAMP
     long long stamps[16] = {0};
-    if (lane == 0 && st.stamps) for (int i = 6; i <= 10; ++i) st.stamps[(int64_t)b * 16 + i] = 0;
+    if (lane == 0 && st.stamps) for (int i = 4; i < 16; ++i) st.stamps[(int64_t)b * 16 + i] = 0;
     long long t_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
     // ---- initial trajectory rollout, optim.c:1101-1111.  The dynamics chain is serial in
@@ -951,6 +990,11 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                 ra.CX = CX; ra.CU = CU; ra.X_ = X_; ra.KFFr = KFFr; ra.Ur = Ur; ra.UMAXr = UMAXr; ra.UMINr = UMINr;
                 ra.KFBr = KFBr; ra.Xr = Xr; ra.P = &P; ra.dt = dt; ra.rows = st.rows; ra.opt_start = opt_start;
                 ra.T = T; ra.int_type = int_type; ra.second_order = second_order;
+#ifdef TPL_ILQR_STAMP
+                ra.stamp_acc = st.stamps ? st.stamps + (int64_t)b * 16 : nullptr;
+#else
+                ra.stamp_acc = nullptr;
+#endif
                 if (lt) line_search_rollouts<true>(ra, (LdsAS*)(unsigned)(unsigned long long)&s);
                 else line_search_rollouts<false>(ra, (LdsAS*)(unsigned)(unsigned long long)&s);
             }
@@ -1061,7 +1105,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
     if (iterations == max_iter) term = 1;                      // optim.c:1147-1149
 
 #ifdef TPL_ILQR_STAMP
-    if (lane == 0) for (int i = 0; i < 16; ++i) if (i < 6 || i > 10) st.stamps[(int64_t)b * 16 + i] = stamps[i];
+    if (lane == 0) for (int i = 0; i < 16; ++i) if (i < 4 || i == 5 || (i > 10 && i < 14)) st.stamps[(int64_t)b * 16 + i] = stamps[i];
 #endif
     if (lane == 0) {
         sc[TPL_S_TRAJ_COSTS] = J;
@@ -1731,7 +1775,7 @@ int tplhip_ilqr_download(tplhip_ilqr* h)
         hipMemcpy(st.data(), h->dev.stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
         double sum[16] = {0};
         for (int b = 0; b < h->batch; ++b) for (int i = 0; i < 16; ++i) sum[i] += (double)st[(size_t)b * 16 + i];
-        const char* names[16] = {"initial rollout", "multiplier update", "derivatives", "backward pass (rest)", "line-search rollouts", "accept/copy",
+        const char* names[16] = {"initial rollout", "multiplier update", "derivatives", "backward pass (rest)", "ls: ring flush", "accept/copy",
                                  "bw: regs->LDS + fetch", "bw: phase A", "bw: phase B", "bw: phase C", "bw: phase D", "ls: dynamics chains (rest)", "ls: cost pass", "ls: sums", "ls/step: feedback law u", "ls/step: dynamics + stores"};
         for (int i = 0; i < 16; ++i) std::fprintf(stderr, "[stamp] %-22s %12.0f s_memtime ticks per problem per update\n", names[i], sum[i] / h->batch);
     }

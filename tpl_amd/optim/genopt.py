@@ -88,7 +88,7 @@ class Config:
 
 
 # bump when the emitted text for an unchanged problem changes (invalidates cached models)
-EMITTER_REVISION = "emit-3: tpl_sin/tpl_cos/tpl_tan, quad-cooperative ctDynamics"
+EMITTER_REVISION = "emit-4: quad look-ups take their four arrays as separate references"
 
 
 def _as_matrix(e):
@@ -520,13 +520,12 @@ def _emit_routine_quad(name, m, cfg, printer):
             b = it[1]
             x0, dx, xx = (printer.doprint(k) for k in b["key"])
             mem = b["members"] + [b["members"][-1]] * (4 - len(b["members"]))
-            arrs = ", ".join(f"&{printer.doprint(a)}" for _, a, _ in mem)
+            arrs = ", ".join(printer.doprint(a) for _, a, _ in mem)
             mask = sum((1 << i) for i, (_, _, ang) in enumerate(mem) if ang)
             names = [str(sy) for sy, _, _ in b["members"]]
             lines.append(f"    double {', '.join(names)};")
             lines.append("    {")
-            lines.append(f"        const DynArr* qa[4] = {{{arrs}}};")
-            lines.append(f"        const double qv = tpl_quad_lookup(qlane, {x0}, {dx}, {xx}, qa, {mask}u);")
+            lines.append(f"        const double qv = tpl_quad_lookup(qlane, {x0}, {dx}, {xx}, {arrs}, {mask}u);")
             for i, nm in enumerate(names):
                 lines.append(f"        {nm} = tpl_quad_bcast(qv, {i});")
             lines.append("    }")
