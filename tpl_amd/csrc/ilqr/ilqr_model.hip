@@ -730,7 +730,10 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
-    const Params& P = st.params[b];
+    const Params* const P_mem = &st.params[b];
+    Params P_regs;
+    load_params_uniform(P_regs, P_mem);               // read-only for the launch: registers, not memory
+    const Params& P = P_regs;
     double* sc = st.scalars + (int64_t)b * TPL_S_COUNT;
 
     const int T = (int)sc[TPL_S_HORIZON];
@@ -988,7 +991,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
             {
                 RolloutArgs ra;
                 ra.CX = CX; ra.CU = CU; ra.X_ = X_; ra.KFFr = KFFr; ra.Ur = Ur; ra.UMAXr = UMAXr; ra.UMINr = UMINr;
-                ra.KFBr = KFBr; ra.Xr = Xr; ra.P = &P; ra.dt = dt; ra.rows = st.rows; ra.opt_start = opt_start;
+                ra.KFBr = KFBr; ra.Xr = Xr; ra.P = P_mem; ra.dt = dt; ra.rows = st.rows; ra.opt_start = opt_start;
                 ra.T = T; ra.int_type = int_type; ra.second_order = second_order;
 #ifdef TPL_ILQR_STAMP
                 ra.stamp_acc = st.stamps ? st.stamps + (int64_t)b * 16 : nullptr;
