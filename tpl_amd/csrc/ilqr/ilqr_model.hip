@@ -232,19 +232,15 @@ struct Lds {
     double Vxx[NX * NX];
     double Vx[NX];
     double F[NX * NXU];        // [fx | fu], row-major over the NXU columns
-    double l[NXU];             // [lx ; lu]
-    double Lxx[NX * NX];       // Lxx | Lux | Luu and Qxx | Qux | Quu are laid out back to back:
-    double Lux[NU * NX];       // phase B addresses them as one array
-    double Luu[NU * NU];
-    double W[NX * NXU];        // Vxx [fx fu]
+    double W[NX * (NXU + 1)];  // Vxx [fx fu], and Vx as one more column (second-order pass)
     double q[NXU];             // [Qx ; Qu]
     double Qxx[NX * NX];
     double Qux[NU * NX];
     double Quu[NU * NU];
     double K[NU * NX];
     double k[NU];
-    double ulim[3 * NU];       // u[t], uMax[t], uMin[t]
     double red[N_ALPHA];
+    double dump[2];            // where lanes without an entry park what they loaded
     // line-search rollouts: RING stages of every candidate's (x_{t+1}, u_t) collect here and go out
     // to the candidate arrays in one coalesced sweep of all 64 lanes (see line_search_rollouts)
     double ring_x[N_ALPHA * ROLL_RING * NX];
@@ -307,228 +303,254 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
 #else
 #define BSTAMP(i) do { } while (0)
 #endif
-    {
-        // ---- backward Riccati pass, optim.c:926-985
-        // The stage blocks are read one stage AHEAD into registers (lane = entry) and
-        // parked in LDS during phase D of the stage before, so the HBM/L2 latency of stage
-        // t-1 hides under the dependent phases of stage t; four LDS exchanges per stage.
-        constexpr int E_XX = (NX * NX + WAVE - 1) / WAVE, E_XU = (NX * NU + WAVE - 1) / WAVE;
-        double r_fx[E_XX], r_lxx[E_XX], r_fu[E_XU], r_lux[E_XU], r_l = 0.0, r_luu = 0.0, r_ul[3] = {0.0, 0.0, 0.0};
-        auto fetch_stage = [&](int t) {
-#pragma unroll
-            for (int q = 0; q < E_XX; ++q) {
-                const int e = lane + q * WAVE;
-                if (e < NX * NX) { r_fx[q] = FX[(int64_t)t * NX * NX + e]; r_lxx[q] = LXX[(int64_t)t * NX * NX + e]; }
-            }
-#pragma unroll
-            for (int q = 0; q < E_XU; ++q) {
-                const int e = lane + q * WAVE;
-                if (e < NX * NU) { r_fu[q] = FU[(int64_t)t * NX * NU + e]; r_lux[q] = LUX[(int64_t)t * NU * NX + e]; }
-            }
-            if (lane < NX) r_l = LX[(int64_t)t * NX + lane];
-            else if (lane < NXU) r_l = LU[(int64_t)t * NU + (lane - NX)];
-            if (lane < NU * NU) r_luu = LUU[(int64_t)t * NU * NU + lane];
-            if (lane < NU) {
-                r_ul[0] = U_[(int64_t)t * NU + lane];
-                r_ul[1] = UMAX[(int64_t)t * NU + lane];
-                r_ul[2] = UMIN[(int64_t)t * NU + lane];
-            }
-        };
-        auto park_stage = [&]() {
-#pragma unroll
-            for (int q = 0; q < E_XX; ++q) {
-                const int e = lane + q * WAVE;
-                if (e < NX * NX) {
-                    const int i = e / NX, j = e - i * NX;
-                    s->F[i * NXU + j] = r_fx[q];
-                    s->Lxx[e] = r_lxx[q];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < E_XU; ++q) {
-                const int e = lane + q * WAVE;
-                if (e < NX * NU) {
-                    const int i = e / NU, j = e - i * NU;
-                    s->F[i * NXU + NX + j] = r_fu[q];
-                    s->Lux[e] = r_lux[q];
-                }
-            }
-            if (lane < NXU) s->l[lane] = r_l;
-            if (lane < NU * NU) s->Luu[lane] = r_luu;
-            if (lane < NU) {
-                s->ulim[lane] = r_ul[0];
-                s->ulim[NU + lane] = r_ul[1];
-                s->ulim[2 * NU + lane] = r_ul[2];
-            }
-        };
+    // What a stage needs from memory, and where it goes (one stage ahead, so the latency of stage
+    // t-1 hides under the dependent phases of stage t):
+    //   [fx | fu]  -> registers (lane = entry) -> LDS block F at the end of stage t: every lane reads
+    //                 whole columns of it in phases A and B;
+    //   the entries of lxx / lux / luu / lx / lu are addends of exactly one Q entry each: the lane
+    //                 that owns the Q entry keeps them in registers, they never touch LDS;
+    //   u, uMax, uMin: registers of the phase-C lanes.
+    // Every lane walks its own pointers down the stages (one 64-bit add each); lanes without an
+    // entry load a valid neighbour and park it in a dump slot, so nothing in the loop needs a
+    // lane mask of its own.
+    constexpr int WS = NXU + 1;                        // row stride of W: column NXU carries Vx
+    constexpr int E_XX = (NX * NX + WAVE - 1) / WAVE, E_XU = (NX * NU + WAVE - 1) / WAVE;
+    constexpr int N_XX = NX * (NX + 1) / 2, N_UX = NU * NX, N_UU = NU * (NU + 1) / 2;
+    constexpr int N_B = N_XX + N_UX + N_UU + NXU;
+    constexpr int E_B = (N_B + WAVE - 1) / WAVE, E_A = (NX * NXU + WAVE - 1) / WAVE;
+    static_assert(NX * NXU <= 2 * WAVE && N_B <= 2 * WAVE, "state dimension too large for this kernel");
+    static_assert(NX * NX + NX <= WAVE || NX > 7, "phase D lane map");
+    static_assert(NU * (NX + 1) <= WAVE, "phase C lane map");
 
-        // lane -> entry maps of phases A, B, D (they do not depend on the stage)
-        constexpr int N_XX = NX * (NX + 1) / 2, N_UX = NU * NX, N_UU = NU * (NU + 1) / 2;
-        constexpr int N_B = N_XX + N_UX + N_UU + NXU;
-        static_assert(NX * NXU <= 2 * WAVE && N_B <= 2 * WAVE, "state dimension too large for this kernel");
-        int b_colF[2], b_colW[2], b_out0[2], b_out1[2];
+    const LdsD dump = &s->dump[0];
+    // ---- F: sources and LDS destinations
+    GlbCD p_fx[E_XX], p_fu[E_XU];
+    LdsD d_fx[E_XX], d_fu[E_XU];
+    double r_fx[E_XX], r_fu[E_XU];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < E_XX; ++q) {
+        const int e = lane + q * WAVE, ec = e < NX * NX ? e : NX * NX - 1;
+        const int i = ec / NX, j = ec - i * NX;
+        p_fx[q] = FX + (int64_t)(T - 1) * NX * NX + ec;
+        d_fx[q] = e < NX * NX ? &s->F[i * NXU + j] : dump;
+    }
+#pragma unroll
+    for (int q = 0; q < E_XU; ++q) {
+        const int e = lane + q * WAVE, ec = e < NX * NU ? e : NX * NU - 1;
+        const int i = ec / NU, j = ec - i * NU;
+        p_fu[q] = FU + (int64_t)(T - 1) * NX * NU + ec;
+        d_fu[q] = e < NX * NU ? &s->F[i * NXU + NX + j] : dump;
+    }
+    // ---- phase B: entry -> columns of F and W, the two addends, the one or two destinations
+    int b_colF[E_B], b_colW[E_B];
+    bool b_two[E_B];
+    LdsD b_dst0[E_B], b_dst1[E_B];
+    GlbCD p_l0[E_B], p_l1[E_B];
+    long long b_step[E_B];                             // doubles per stage of the array the addends come from
+    double r_l0[E_B], r_l1[E_B];
+#pragma unroll
+    for (int q = 0; q < E_B; ++q) {
+        const int e = lane + q * WAVE;
+        int colF = 0, colW = 0;
+        GlbCD l0 = LX, l1 = LX;
+        long long step = NX;
+        LdsD o0 = dump, o1 = dump;
+        bool two = false;
+        if (e < N_XX) {
+            int hi = 0;
+            while ((hi + 1) * (hi + 2) / 2 <= e) ++hi;                 // row of the packed lower triangle
+            const int lo = e - hi * (hi + 1) / 2;
+            colF = hi; colW = lo; step = NX * NX;
+            l0 = LXX + hi * NX + lo; l1 = LXX + lo * NX + hi;
+            o0 = &s->Qxx[hi * NX + lo]; o1 = &s->Qxx[lo * NX + hi]; two = hi != lo;
+        } else if (e < N_XX + N_UX) {
+            const int r = e - N_XX, d = r / NX, jj = r - d * NX;
+            colF = NX + d; colW = jj; step = NU * NX;
+            l0 = l1 = LUX + r;
+            o0 = o1 = &s->Qux[r];
+        } else if (e < N_XX + N_UX + N_UU) {
+            const int r = e - N_XX - N_UX;
+            int hi = 0;
+            while ((hi + 1) * (hi + 2) / 2 <= r) ++hi;
+            const int lo = r - hi * (hi + 1) / 2;
+            colF = NX + hi; colW = NX + lo; step = NU * NU;
+            l0 = LUU + hi * NU + lo; l1 = LUU + lo * NU + hi;
+            o0 = &s->Quu[hi * NU + lo]; o1 = &s->Quu[lo * NU + hi]; two = hi != lo;
+        } else if (e < N_B) {
+            const int c = e - (N_XX + N_UX + N_UU);                   // q = l + F^T Vx: Vx is column NXU of W
+            colF = c; colW = NXU;
+            if (c < NX) { l0 = l1 = LX + c; step = NX; } else { l0 = l1 = LU + (c - NX); step = NU; }
+            o0 = o1 = &s->q[c];
+        }
+        b_colF[q] = colF; b_colW[q] = colW; b_two[q] = two; b_dst0[q] = o0; b_dst1[q] = o1;
+        b_step[q] = -step;
+        p_l0[q] = l0 + (int64_t)(T - 1) * step; p_l1[q] = l1 + (int64_t)(T - 1) * step;
+    }
+    // ---- phase C lanes: (d, c), c == NX is the feed-forward entry
+    const bool c_lane = lane < NU * (NX + 1);
+    const int c_d = c_lane ? lane / (NX + 1) : 0, c_c = c_lane ? lane - c_d * (NX + 1) : 0;
+    GlbCD p_u = U_ + (int64_t)(T - 1) * NU + c_d, p_umax = UMAX + (int64_t)(T - 1) * NU + c_d,
+          p_umin = UMIN + (int64_t)(T - 1) * NU + c_d;
+    double r_u, r_umax, r_umin;
+    // ---- phase D: lanes [0, NX*NX) own Vxx entries, lanes [NX*NX, NX*NX+NX) own Vx entries
+    const bool d_vxx = lane < NX * NX, d_vx = lane >= NX * NX && lane < NX * NX + NX;
+    const int d_i = d_vxx ? lane / NX : (d_vx ? lane - NX * NX : 0);
+    const int d_j = d_vxx ? lane - (lane / NX) * NX : 0;
+
+    auto fetch_F = [&]() {
+#pragma unroll
+        for (int q = 0; q < E_XX; ++q) { r_fx[q] = *p_fx[q]; p_fx[q] -= NX * NX; }
+#pragma unroll
+        for (int q = 0; q < E_XU; ++q) { r_fu[q] = *p_fu[q]; p_fu[q] -= NX * NU; }
+    };
+    auto park_F = [&]() {
+#pragma unroll
+        for (int q = 0; q < E_XX; ++q) *d_fx[q] = r_fx[q];
+#pragma unroll
+        for (int q = 0; q < E_XU; ++q) *d_fu[q] = r_fu[q];
+    };
+    auto fetch_L = [&]() {
+#pragma unroll
+        for (int q = 0; q < E_B; ++q) {
+            r_l0[q] = *p_l0[q]; r_l1[q] = *p_l1[q];
+            p_l0[q] += b_step[q]; p_l1[q] += b_step[q];
+        }
+    };
+    auto fetch_ulim = [&]() {
+        r_u = *p_u; r_umax = *p_umax; r_umin = *p_umin;
+        p_u -= NU; p_umax -= NU; p_umin -= NU;
+    };
+
+    if (lane < NX) s->W[lane * WS + NXU] = s->Vx[lane];
+    fetch_F();
+    park_F();
+    fetch_L();
+    fetch_ulim();
+    lds_sync();
+    if (T > 1) fetch_F();
+    for (int t = T - 1; t >= 0; --t) {
+        BSTAMP(0);
+        // phase A: W = Vxx [fx fu]
+#pragma unroll
+        for (int q = 0; q < E_A; ++q) {
             const int e = lane + q * WAVE;
-            int colF = 0, colW = 0, out0 = -1, out1 = -1;
-            if (e < N_XX) {
-                int hi = 0;
-                while ((hi + 1) * (hi + 2) / 2 <= e) ++hi;             // row of the packed lower triangle
-                const int lo = e - hi * (hi + 1) / 2;
-                colF = hi; colW = lo; out0 = hi * NX + lo; out1 = lo * NX + hi;
-            } else if (e < N_XX + N_UX) {
-                const int r = e - N_XX, d = r / NX, jj = r - d * NX;
-                colF = NX + d; colW = jj; out0 = out1 = NX * NX + r;
-            } else if (e < N_XX + N_UX + N_UU) {
-                const int r = e - N_XX - N_UX;
-                int hi = 0;
-                while ((hi + 1) * (hi + 2) / 2 <= r) ++hi;
-                const int lo = r - hi * (hi + 1) / 2;
-                colF = NX + hi; colW = NX + lo;
-                out0 = NX * NX + NU * NX + hi * NU + lo; out1 = NX * NX + NU * NX + lo * NU + hi;
-            } else if (e < N_B) {
-                colF = e - (N_XX + N_UX + N_UU); colW = -1; out0 = out1 = colF;   // q entry
+            if (e < NX * NXU) {
+                const int i = e / NXU, j = e - i * NXU;
+                s->W[i * WS + j] = dot_lds<NX>(&s->Vxx[i * NX], 1, &s->F[j], NXU);
             }
-            b_colF[q] = colF; b_colW[q] = colW; b_out0[q] = out0; b_out1[q] = out1;
         }
-        // phase D: lanes [0, NX*NX) own Vxx entries, lanes [NX*NX, NX*NX+NX) own Vx entries
-        const bool d_vxx = lane < NX * NX, d_vx = lane >= NX * NX && lane < NX * NX + NX;
-        static_assert(NX * NX + NX <= WAVE || NX > 7, "phase D lane map");
-        const int d_i = d_vxx ? lane / NX : (d_vx ? lane - NX * NX : 0);
-        const int d_j = d_vxx ? lane - (lane / NX) * NX : 0;
-
-        fetch_stage(T - 1);
-        park_stage();
         lds_sync();
-        if (T > 1) fetch_stage(T - 2);
-        for (int t = T - 1; t >= 0; --t) {
-            BSTAMP(0);
-            // phase A: W = Vxx [fx fu]
-#pragma unroll
-            for (int q = 0; q < (NX * NXU + WAVE - 1) / WAVE; ++q) {
-                const int e = lane + q * WAVE;
-                if (e < NX * NXU) {
-                    const int i = e / NXU, j = e - i * NXU;
-                    s->W[e] = dot_lds<NX>(&s->Vxx[i * NX], 1, &s->F[j], NXU);
-                }
-            }
-            lds_sync();
+        BSTAMP(1);
 
-            BSTAMP(1);
-            // phase B: Q = L + F^T W.  Only the lower triangles of the symmetric blocks are
-            // formed and then mirrored, like mul_symm (optim.c:159-180); q = l + F^T Vx rides
-            // along on otherwise idle lanes->
+        // phase B: Q = L + F^T W, q = l + F^T Vx.  Only the lower triangles of the symmetric blocks
+        // are formed and then mirrored, like mul_symm (optim.c:159-180).
 #pragma unroll
-            for (int q = 0; q < (N_B + WAVE - 1) / WAVE; ++q) {
-                if (b_out0[q] >= 0) {
-                    if (b_colW[q] < 0) {
-                        s->q[b_out0[q]] = s->l[b_out0[q]] + dot_lds<NX>(&s->F[b_colF[q]], NXU, s->Vx, 1);
-                    } else {
-                        const double l0 = s->Lxx[b_out0[q]], l1 = s->Lxx[b_out1[q]];   // runs on into Lux / Luu
-                        const double acc = dot_lds<NX>(&s->F[b_colF[q]], NXU, &s->W[b_colW[q]], NXU);
-                        s->Qxx[b_out0[q]] = l0 + acc;                                   // runs on into Qux / Quu
-                        if (b_out1[q] != b_out0[q]) s->Qxx[b_out1[q]] = l1 + acc;
-                    }
-                }
+        for (int q = 0; q < E_B; ++q) {
+            if (lane + q * WAVE < N_B) {
+                const double acc = dot_lds<NX>(&s->F[b_colF[q]], NXU, &s->W[b_colW[q]], WS);
+                *b_dst0[q] = r_l0[q] + acc;
+                if (b_two[q]) *b_dst1[q] = r_l1[q] + acc;
             }
-            lds_sync();
-
-            BSTAMP(2);
-            // phase C: gains (solve_action optim.c:243-291) + control-box projection (:950-963)
-            if (lane < NU * (NX + 1)) {
-                const int d = lane / (NX + 1), c = lane - d * (NX + 1);
-                double quu[NU * NU], qu[NU], col[NU];
-#pragma unroll
-                for (int m = 0; m < NU * NU; ++m) quu[m] = s->Quu[m];
-#pragma unroll
-                for (int m = 0; m < NU; ++m) { qu[m] = s->q[NX + m]; col[m] = (c == NX) ? 0.0 : s->Qux[m * NX + (c == NX ? 0 : c)]; }
-                const double ud = s->ulim[d], umax = s->ulim[NU + d], umin = s->ulim[2 * NU + d];
-                __builtin_amdgcn_sched_barrier(0);
-                double inv[NU][NU];
-                if constexpr (NU == 1) {
-                    inv[0][0] = (quu[0] > 0.0) ? -1.0 / (quu[0] + mu) : 0.0;
-                } else {
-                    const double qa = quu[0] + mu, qb = quu[1], qd = quu[NU + 1] + mu;
-                    const double det = qa * qd - qb * qb;
-                    const double inv_det = -1.0f / det;
-                    inv[0][0] = qd * inv_det;
-                    inv[0][NU - 1] = -qb * inv_det;
-                    inv[NU - 1][0] = inv[0][NU - 1];
-                    inv[NU - 1][NU - 1] = qa * inv_det;
-                }
-                double kd = 0.0;
-#pragma unroll
-                for (int m = 0; m < NU; ++m) kd = fma(inv[d][m], qu[m], kd);
-                double val;
-                if (c == NX) {
-                    val = kd;
-                } else {
-                    val = 0.0;
-#pragma unroll
-                    for (int m = 0; m < NU; ++m) val = fma(inv[d][m], col[m], val);
-                }
-                const double cd = ud + kd;
-                if (cd > umax) val = (c == NX) ? umax - ud : 0.0;
-                if (cd < umin) val = (c == NX) ? umin - ud : 0.0;
-                if (c == NX) {
-                    s->k[d] = val;
-                    KFF[(int64_t)t * NU + d] = val;
-                    if (lt) KL[(int64_t)t * NU + d] = val;
-                } else {
-                    s->K[d * NX + c] = val;
-                    KFB[(int64_t)t * NU * NX + d * NX + c] = val;
-                    if (lt) KBL[(int64_t)t * NU * NX + d * NX + c] = val;
-                }
-            }
-            lds_sync();
-
-            BSTAMP(3);
-            // phase D: value function update, optim.c:965-984 (same order of additions)
-            if (d_vxx || d_vx) {
-                double Ki[NU], Kj[NU], Qi[NU], Qj[NU], quu[NU * NU], kk[NU], qu[NU];
-#pragma unroll
-                for (int d = 0; d < NU; ++d) {
-                    Ki[d] = s->K[d * NX + d_i]; Kj[d] = s->K[d * NX + d_j];
-                    Qi[d] = s->Qux[d * NX + d_i]; Qj[d] = s->Qux[d * NX + d_j];
-                    kk[d] = s->k[d]; qu[d] = s->q[NX + d];
-                }
-#pragma unroll
-                for (int m = 0; m < NU * NU; ++m) quu[m] = s->Quu[m];
-                const double tail = d_vxx ? s->Qxx[lane] : s->q[d_i];
-                __builtin_amdgcn_sched_barrier(0);
-                double kq[NU];                                   // (K^T Quu)[i][d]
-#pragma unroll
-                for (int d = 0; d < NU; ++d) {
-                    double a = 0.0;
-#pragma unroll
-                    for (int m = 0; m < NU; ++m) a = fma(Ki[m], quu[m * NU + d], a);
-                    kq[d] = a;
-                }
-                if (d_vxx) {
-                    double mij = 0.0, mji = 0.0;
-#pragma unroll
-                    for (int d = 0; d < NU; ++d) { mij = fma(Ki[d], Qj[d], mij); mji = fma(Kj[d], Qi[d], mji); }
-                    double v = mji + mij;
-#pragma unroll
-                    for (int d = 0; d < NU; ++d) v = fma(kq[d], Kj[d], v);
-                    s->Vxx[lane] = v + tail;
-                } else {
-                    double v = 0.0;
-#pragma unroll
-                    for (int d = 0; d < NU; ++d) v = fma(kq[d], kk[d], v);
-#pragma unroll
-                    for (int d = 0; d < NU; ++d) v = fma(Ki[d], qu[d], v);
-#pragma unroll
-                    for (int d = 0; d < NU; ++d) v = fma(Qi[d], kk[d], v);
-                    s->Vx[d_i] = v + tail;
-                }
-            }
-            // stage t-1 is already in registers: park it for the next trip, then fetch t-2
-            if (t > 0) park_stage();
-            lds_sync();
-            if (t > 1) fetch_stage(t - 2);
-            BSTAMP(4);
         }
+        if (t > 0) fetch_L();                                  // the addends of stage t-1
+        lds_sync();
+        BSTAMP(2);
+
+        // phase C: gains (solve_action optim.c:243-291) + control-box projection (:950-963)
+        if (c_lane) {
+            const int d = c_d, c = c_c;
+            double quu[NU * NU], qu[NU], col[NU];
+#pragma unroll
+            for (int m = 0; m < NU * NU; ++m) quu[m] = s->Quu[m];
+#pragma unroll
+            for (int m = 0; m < NU; ++m) { qu[m] = s->q[NX + m]; col[m] = (c == NX) ? 0.0 : s->Qux[m * NX + (c == NX ? 0 : c)]; }
+            const double ud = r_u, umax = r_umax, umin = r_umin;
+            __builtin_amdgcn_sched_barrier(0);
+            double inv[NU][NU];
+            if constexpr (NU == 1) {
+                inv[0][0] = (quu[0] > 0.0) ? -1.0 / (quu[0] + mu) : 0.0;
+            } else {
+                const double qa = quu[0] + mu, qb = quu[1], qd = quu[NU + 1] + mu;
+                const double det = qa * qd - qb * qb;
+                const double inv_det = -1.0f / det;
+                inv[0][0] = qd * inv_det;
+                inv[0][NU - 1] = -qb * inv_det;
+                inv[NU - 1][0] = inv[0][NU - 1];
+                inv[NU - 1][NU - 1] = qa * inv_det;
+            }
+            double kd = 0.0;
+#pragma unroll
+            for (int m = 0; m < NU; ++m) kd = fma(inv[d][m], qu[m], kd);
+            double val;
+            if (c == NX) {
+                val = kd;
+            } else {
+                val = 0.0;
+#pragma unroll
+                for (int m = 0; m < NU; ++m) val = fma(inv[d][m], col[m], val);
+            }
+            const double cd = ud + kd;
+            if (cd > umax) val = (c == NX) ? umax - ud : 0.0;
+            if (cd < umin) val = (c == NX) ? umin - ud : 0.0;
+            if (c == NX) {
+                s->k[d] = val;
+                KFF[(int64_t)t * NU + d] = val;
+                if (lt) KL[(int64_t)t * NU + d] = val;
+            } else {
+                s->K[d * NX + c] = val;
+                KFB[(int64_t)t * NU * NX + d * NX + c] = val;
+                if (lt) KBL[(int64_t)t * NU * NX + d * NX + c] = val;
+            }
+            if (t > 0) fetch_ulim();
+        }
+        lds_sync();
+        BSTAMP(3);
+
+        // phase D: value function update, optim.c:965-984 (same order of additions)
+        if (d_vxx || d_vx) {
+            double Ki[NU], Kj[NU], Qi[NU], Qj[NU], quu[NU * NU], kk[NU], qu[NU];
+#pragma unroll
+            for (int d = 0; d < NU; ++d) {
+                Ki[d] = s->K[d * NX + d_i]; Kj[d] = s->K[d * NX + d_j];
+                Qi[d] = s->Qux[d * NX + d_i]; Qj[d] = s->Qux[d * NX + d_j];
+                kk[d] = s->k[d]; qu[d] = s->q[NX + d];
+            }
+#pragma unroll
+            for (int m = 0; m < NU * NU; ++m) quu[m] = s->Quu[m];
+            const double tail = d_vxx ? s->Qxx[lane] : s->q[d_i];
+            __builtin_amdgcn_sched_barrier(0);
+            double kq[NU];                                   // (K^T Quu)[i][d]
+#pragma unroll
+            for (int d = 0; d < NU; ++d) {
+                double a = 0.0;
+#pragma unroll
+                for (int m = 0; m < NU; ++m) a = fma(Ki[m], quu[m * NU + d], a);
+                kq[d] = a;
+            }
+            if (d_vxx) {
+                double mij = 0.0, mji = 0.0;
+#pragma unroll
+                for (int d = 0; d < NU; ++d) { mij = fma(Ki[d], Qj[d], mij); mji = fma(Kj[d], Qi[d], mji); }
+                double v = mji + mij;
+#pragma unroll
+                for (int d = 0; d < NU; ++d) v = fma(kq[d], Kj[d], v);
+                s->Vxx[lane] = v + tail;
+            } else {
+                double v = 0.0;
+#pragma unroll
+                for (int d = 0; d < NU; ++d) v = fma(kq[d], kk[d], v);
+#pragma unroll
+                for (int d = 0; d < NU; ++d) v = fma(Ki[d], qu[d], v);
+#pragma unroll
+                for (int d = 0; d < NU; ++d) v = fma(Qi[d], kk[d], v);
+                s->W[d_i * WS + NXU] = v + tail;             // Vx, where phase B of the next stage reads it
+            }
+        }
+        // [fx | fu] of stage t-1 is already in registers: park it for the next trip, then fetch t-2
+        if (t > 0) park_F();
+        lds_sync();
+        if (t > 1) fetch_F();
+        BSTAMP(4);
     }
 #ifdef TPL_ILQR_STAMP
     if (lane == 0 && A.stamp_acc) for (int i = 0; i < 5; ++i) A.stamp_acc[6 + i] += bacc[i];
