@@ -452,8 +452,11 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
                 if (b_two[q]) *b_dst1[q] = r_l1[q] + acc;
             }
         }
-        if (t > 0) fetch_L();                                  // the addends of stage t-1
         lds_sync();
+        // F of stage t has been read for the last time: [fx | fu] of stage t-1 (in registers since
+        // the stage before) takes its place.  Loads and stores of a wavefront complete in order, so
+        // this wait sits BEFORE the gain stores of phase C and after nothing recent.
+        if (t > 0) park_F();
         BSTAMP(2);
 
         // phase C: gains (solve_action optim.c:243-291) + control-box projection (:950-963)
@@ -501,8 +504,11 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
                 KFB[(int64_t)t * NU * NX + d * NX + c] = val;
                 if (lt) KBL[(int64_t)t * NU * NX + d * NX + c] = val;
             }
-            if (t > 0) fetch_ulim();
         }
+        // ALL requests of the stage in one place, after the gain stores: stage t-2 of F, stage t-1 of
+        // the addends and limits.  Everything the loop waits for was then issued most of a stage ago.
+        if (t > 1) fetch_F();
+        if (t > 0) { fetch_L(); fetch_ulim(); }
         lds_sync();
         BSTAMP(3);
 
@@ -546,10 +552,7 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
                 s->W[d_i * WS + NXU] = v + tail;             // Vx, where phase B of the next stage reads it
             }
         }
-        // [fx | fu] of stage t-1 is already in registers: park it for the next trip, then fetch t-2
-        if (t > 0) park_F();
         lds_sync();
-        if (t > 1) fetch_F();
         BSTAMP(4);
     }
 #ifdef TPL_ILQR_STAMP
