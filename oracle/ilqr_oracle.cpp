@@ -120,6 +120,16 @@ static inline double tpl_lerp_angle(double x0, double dx, double x, const DynArr
     return arr.data[i.start] + short_angle_dist(arr.data[i.start], arr.data[i.end]) * i.a;
 }
 
+// The generator batches look-ups that share an abscissa (the product reads all tables in one
+// memory round trip); here a batch is just its members, one builtin call each.
+template <int N>
+static inline void tpl_lerp_batch(double x0, double dx, double x, const DynArr* const (&arrs)[N], unsigned angle_mask,
+                                  double (&out)[N])
+{
+    for (int i = 0; i < N; ++i)
+        out[i] = ((angle_mask >> i) & 1u) ? tpl_lerp_angle(x0, dx, x, *arrs[i]) : tpl_lerp(x0, dx, x, *arrs[i]);
+}
+
 static inline double tpl_lerp_wrap(double len, double dx, double x, const DynArr& xs, const DynArr& arr)
 {
     size_t l = (size_t)arr.n0;

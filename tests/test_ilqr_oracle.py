@@ -87,3 +87,19 @@ def test_quad_cooperative_dynamics_are_emitted_where_they_pay():
     assert "ctDynamicsQ" not in txt[:guard]
     plain = genopt.emit_model(o.config_velocity_profile_time(), "velocity_profile_time")
     assert "TPL_HAS_QUAD_DYNAMICS" not in plain and "ctDynamicsQ" not in plain
+
+
+def test_lookups_at_one_abscissa_are_batched_in_every_routine():
+    """Look-ups that share (x0, dx, x) come out as ONE tpl_lerp_batch (one division, one memory
+    round trip); a lone look-up stays the plain builtin.  The oracle's tpl_lerp_batch is nothing but
+    its members, so the golden cases check the batched product against the unbatched arithmetic."""
+    import re
+    from tpl_amd.optim import genopt, optimizers as o
+    txt = genopt.emit_model(o.config_trajectory_tracking_mpc(), "trajectory_tracking_mpc")
+    plain = txt[:txt.index("#if defined(TPL_QUAD_ROUTINES)")]
+    costs = plain[plain.index("void costs("):plain.index("void stateGradient(")]
+    assert costs.count("tpl_lerp_batch<5>(0.0, P.ref_step, x[5]") == 1      # ref_phi/x/y/k/v: one batch
+    assert "tpl_lerp(" not in costs and "tpl_lerp_angle(" not in costs
+    for m in re.finditer(r"const DynArr\* const qa\[(\d+)\] = \{([^}]*)\};\s*double qo\[(\d+)\];\s*tpl_lerp_batch<(\d+)>", plain):
+        n = int(m.group(1))
+        assert n >= 2 and n == int(m.group(3)) == int(m.group(4)) and m.group(2).count("&P.") == n

@@ -190,6 +190,49 @@ TPL_HD inline double tpl_lerp_angle(double x0, double dx, double x, const DynArr
     return arr.data[i.start] + tpl_short_angle_dist(arr.data[i.start], arr.data[i.end]) * i.a;
 }
 
+// Several __lerp / __lerp_angle look-ups at ONE abscissa (the generator batches them): the
+// division, floor and ceil are shared, every table is read before the first value is used, and per
+// table the arithmetic is exactly tpl_lerp's / tpl_lerp_angle's (bit i of angle_mask picks the
+// latter).  An empty table yields 0.0 like the builtins (p0 = p1 = a = 0 gives exactly that).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TPL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TPL_SCHED_FENCE() do { } while (0)
+#endif
+template <int N>
+TPL_HD inline void tpl_lerp_batch(double x0, double dx, double x, const DynArr* const (&arrs)[N], unsigned angle_mask,
+                                  double (&out)[N])
+{
+    const double q = (x - x0) / dx;
+    const double fq = floor(q), cq = ceil(q);
+    double a[N], p0[N], p1[N];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < N; ++i) {
+        const int64_t n = arrs[i]->n0;
+        a[i] = 0.0; p0[i] = 0.0; p1[i] = 0.0;
+        if (n != 0) {
+            const double nm1 = (double)(int)(n - 1);
+            const double fs = tpl_idxf(fq, nm1), fe = tpl_idxf(cq, nm1);
+            double w = q - fs;
+            w = w > 0.0 ? w : 0.0;
+            w = w < 1.0 ? w : 1.0;
+            a[i] = w;
+            p0[i] = arrs[i]->data[(int)fs];
+            p1[i] = arrs[i]->data[(int)fe];
+        }
+    }
+    TPL_SCHED_FENCE();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < N; ++i) {
+        if ((angle_mask >> i) & 1u) out[i] = p0[i] + tpl_short_angle_dist(p0[i], p1[i]) * a[i];
+        else out[i] = (1.0 - a[i]) * p0[i] + a[i] * p1[i];
+    }
+}
+
 // __lerp_wrap, optim.c:413-456 (no index clamping in the template; callers keep x in range)
 TPL_HD inline double tpl_lerp_wrap(double len, double dx, double x, const DynArr& xs, const DynArr& arr)
 {

@@ -88,7 +88,7 @@ class Config:
 
 
 # bump when the emitted text for an unchanged problem changes (invalidates cached models)
-EMITTER_REVISION = "emit-4: quad look-ups take their four arrays as separate references"
+EMITTER_REVISION = "emit-5: look-ups that share an abscissa are batched in every routine"
 
 
 def _as_matrix(e):
@@ -345,7 +345,50 @@ def _emit_routine(name, m, cfg, printer):
         flat = [_vectorise(sp.sympify(e), cfg) for e in m]               # row-major
         subs, reduced = sp.cse(flat, symbols=sp.numbered_symbols("w"))
         subs, fused = _fuse_sincos(subs, reduced)
-        for sym, e in subs:
+        subs, reduced, batches = _batch_lookups(subs, reduced)
+        # schedule: the original order, every look-up batch as soon as its abscissa exists
+        items = [("assign", sym, e) for sym, e in subs] + [("batch", b) for b in batches]
+
+        def deps(it):
+            if it[0] == "assign":
+                return _temp_deps(it[2])
+            d = set()
+            for k in it[1]["key"]:
+                d |= _temp_deps(sp.sympify(k))
+            return d
+
+        def provides(it):
+            if it[0] == "assign":
+                return set(fused[it[1]]) | {it[1]} if it[1] in fused else {it[1]}
+            return {sy for sy, _, _ in it[1]["members"]}
+
+        defined, pending = set(), list(items)
+        pending.sort(key=lambda it: 0 if it[0] == "batch" else 1)
+        while pending:
+            for it in pending:
+                if deps(it) <= defined:
+                    break
+            else:
+                raise AssertionError("look-up batching: cyclic dependency")
+            pending.remove(it)
+            defined |= provides(it)
+            if it[0] == "batch":
+                b = it[1]
+                x0, dx, xx = (printer.doprint(k) for k in b["key"])
+                nmem = len(b["members"])
+                arrs = ", ".join(f"&{printer.doprint(a)}" for _, a, _ in b["members"])
+                mask = sum((1 << i) for i, (_, _, ang) in enumerate(b["members"]) if ang)
+                names = [str(sy) for sy, _, _ in b["members"]]
+                lines.append(f"    double {', '.join(names)};")
+                lines.append("    {")
+                lines.append(f"        const DynArr* const qa[{nmem}] = {{{arrs}}};")
+                lines.append(f"        double qo[{nmem}];")
+                lines.append(f"        tpl_lerp_batch<{nmem}>({x0}, {dx}, {xx}, qa, {mask}u, qo);")
+                for i, nm in enumerate(names):
+                    lines.append(f"        {nm} = qo[{i}];")
+                lines.append("    }")
+                continue
+            _, sym, e = it
             if sym in fused:                                             # (sin, cos) of one argument
                 s_sym, c_sym = fused[sym]
                 lines.append(f"    double {s_sym}, {c_sym}; tpl_sincos({printer.doprint(e)}, &{s_sym}, &{c_sym});")
@@ -355,6 +398,36 @@ def _emit_routine(name, m, cfg, printer):
             lines.append(f"    out[{i}*os] = {printer.doprint(e)};")
     lines.append("}")
     return "\n".join(lines)
+
+
+def _batch_lookups(subs, reduced, chunk=8):
+    """lerp / lerp_angle calls that share (x0, dx, x) become ONE ``tpl_lerp_batch``: the division,
+    floor and ceil of the abscissa are done once, all table reads are issued before the first is
+    used (one memory round trip instead of one per table).  Per table the arithmetic is the
+    builtin's own.  Returns (subs, reduced, batches)."""
+    groups = {}
+    for e in [e for _, e in subs] + list(reduced):
+        for f in e.atoms(sp.Function):
+            if type(f).__name__ in ("lerp", "lerp_angle") and len(f.args) == 4:
+                groups.setdefault(tuple(f.args[:3]), {}).setdefault(f, None)
+    batches, repl, n = [], {}, 0
+    for key, calls in groups.items():
+        calls = list(calls)
+        for i in range(0, len(calls), chunk):
+            part = calls[i:i + chunk]
+            if len(part) < 2:
+                continue
+            members = []
+            for f in part:
+                n += 1
+                sy = sp.Symbol(f"ql{2000 + n}")
+                repl[f] = sy
+                members.append((sy, f.args[3], type(f).__name__ == "lerp_angle"))
+            batches.append({"key": key, "members": members})
+    if repl:
+        subs = [(sym, e.xreplace(repl)) for sym, e in subs]
+        reduced = [e.xreplace(repl) for e in reduced]
+    return subs, reduced, batches
 
 
 def _temp_deps(expr):
