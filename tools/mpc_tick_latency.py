@@ -1,3 +1,4 @@
+"""p50 wall time of Optim.update() in the closed MPC loop of tpl_amd/latency.py, with the kernel share."""
 import sys, time, numpy as np
 sys.path.insert(0, ".")
 from tpl_amd.optim import bench_ilqr, genopt, optimizers as o
