@@ -105,20 +105,40 @@ __device__ __forceinline__ float dist_at(const DistSrc& d, const TplDpEnvParams&
     return dist_lon_x(d.dist_lon, ep, d.t, d.s, l);
 }
 
-// Evaluator::getMid, lat_lon_planner.cu:83-124
+// Evaluator::getMid, lat_lon_planner.cu:83-124.  WAVE_PAR: called by a whole, converged wavefront
+// with identical arguments (the forward rollout); the outward walks of both sides then run one
+// offset per lane -- lanes 0..31 to the left, 32..63 to the right -- and the first hit in the
+// reference's order is the lowest set bit of a ballot: one memory round trip instead of up to
+// 2 * l_steps dependent ones.
+template <bool WAVE_PAR>
 __device__ __forceinline__ float3 get_mid(const TplLatLonParams& p, const TplDpEnvParams& ep, const DistSrc& src,
                                           const TplLatLonState& tp, float dt)
 {
     const float l_step_size = (p.l_max - p.l_min) / (float)(p.l_steps - 1);
     const float mean_dist = fmaxf((float)((double)p.length_veh * 0.5), tp.ds * dt);
     float l_left = 0.0f, l_right = 0.0f;
-    for (int i = 0; i < p.l_steps; ++i) {
-        const float l = tp.l + (float)i * l_step_size;
-        if (dist_at(src, ep, l) < mean_dist) { l_left = l; break; }
-    }
-    for (int i = 0; i < p.l_steps; ++i) {
-        const float l = tp.l - (float)i * l_step_size;
-        if (dist_at(src, ep, l) < mean_dist) { l_right = l; break; }
+    if constexpr (WAVE_PAR) {
+        const int ln = (int)(threadIdx.x & 63u);
+        const bool right = ln >= 32;
+        bool f_left = false, f_right = false;
+        for (int i0 = 0; i0 < p.l_steps && !(f_left && f_right); i0 += 32) {
+            const int i = i0 + (ln & 31);
+            const float l = right ? tp.l - (float)i * l_step_size : tp.l + (float)i * l_step_size;
+            const bool hit = i < p.l_steps && dist_at(src, ep, l) < mean_dist;
+            const unsigned long long m = __ballot(hit);
+            const unsigned ml = (unsigned)m, mr = (unsigned)(m >> 32);
+            if (!f_left && ml) { l_left = tp.l + (float)(i0 + __ffs(ml) - 1) * l_step_size; f_left = true; }
+            if (!f_right && mr) { l_right = tp.l - (float)(i0 + __ffs(mr) - 1) * l_step_size; f_right = true; }
+        }
+    } else {
+        for (int i = 0; i < p.l_steps; ++i) {
+            const float l = tp.l + (float)i * l_step_size;
+            if (dist_at(src, ep, l) < mean_dist) { l_left = l; break; }
+        }
+        for (int i = 0; i < p.l_steps; ++i) {
+            const float l = tp.l - (float)i * l_step_size;
+            if (dist_at(src, ep, l) < mean_dist) { l_right = l; break; }
+        }
     }
     float3 res;
     const float mid = (float)((double)l_right + (double)(l_left - l_right) * 0.5);
@@ -131,6 +151,7 @@ __device__ __forceinline__ float3 get_mid(const TplLatLonParams& p, const TplDpE
 }
 
 // Evaluator::evalState, :126-166
+template <bool WAVE_PAR = false>
 __device__ __forceinline__ Eval eval_state(const TplLatLonParams& p, const TplDpEnvParams& ep, const DistSrc& src,
                                            const TplLatLonState& tp, float dt, float4 rp)
 {
@@ -140,7 +161,7 @@ __device__ __forceinline__ Eval eval_state(const TplLatLonParams& p, const TplDp
     const float d_right_ref = (float)(-((double)rp.z - (double)p.width_veh * 0.5));
     r.cost = (float)((double)r.cost + 1000.0 * (double)fmaxf(0.0f, tp.l - d_left_ref));
     r.cost = (float)((double)r.cost + 1000.0 * (double)fmaxf(0.0f, d_right_ref - tp.l));
-    const float3 mid = get_mid(p, ep, src, tp, dt);
+    const float3 mid = get_mid<WAVE_PAR>(p, ep, src, tp, dt);
     r.cost += p.w_l * sqf(mid.x - tp.l);
     if (tp.l < mid.y) r.cost += p.w_lat_dist * sqf(mid.y - tp.l);
     if (tp.l > mid.z) r.cost += p.w_lat_dist * sqf(mid.z - tp.l);
@@ -152,12 +173,13 @@ __device__ __forceinline__ Eval eval_state(const TplLatLonParams& p, const TplDp
 }
 
 // Evaluator::finalState, :68-81
+template <bool WAVE_PAR = false>
 __device__ __forceinline__ Eval final_state(const TplLatLonParams& p, const TplDpEnvParams& ep, const DistSrc& src,
                                             const TplLatLonState& tp, float dt, float4 rp)
 {
     Eval r = {0.0f, 0.0f, 0u};
     if (roundf(rp.w) == 1.0f) r.cost += p.w_xing_slow;
-    const float3 mid = get_mid(p, ep, src, tp, dt);
+    const float3 mid = get_mid<WAVE_PAR>(p, ep, src, tp, dt);
     r.cost += p.w_l * sqf(mid.x - tp.l);
     return r;
 }
@@ -262,7 +284,7 @@ __global__ void k_ll_prelude(float4* __restrict__ ref_s, float* __restrict__ pro
 // backwardStep, lat_lon_planner.cu:276-327.  grid (ds_steps, l_steps), lanes over s.
 // tables: float4[l][ds][s].
 // ------------------------------------------------------------------------
-__global__ void k_ll_backward(float4* __restrict__ nodes, const float4* __restrict__ next, int idx_t,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_ll_backward(float4* __restrict__ nodes, const float4* __restrict__ next, int idx_t,
                               const float4* __restrict__ ref_s, const float* __restrict__ profile,
                               TplLatLonParams p, TplDpEnvParams ep, float step_s, float step_ds, float step_l)
 {
@@ -284,36 +306,63 @@ __global__ void k_ll_backward(float4* __restrict__ nodes, const float4* __restri
         const Eval st = eval_state(p, ep, src, tp, dt, rp);
         float tot_cost, tot_constr, best_dds = 0.0f, best_dl = 0.0f;
         if (idx_t < p.t_steps - 1) {
-            // findBestAction<7, 7>, :206-273
+            // findBestAction<7, 7>, :206-273.  The successor's station and speed depend on the
+            // longitudinal action only, its offset on the lateral one: 7 + 7 + 7 index computations
+            // (a division each) instead of 3 x 49, and the seven table cells of a lateral action
+            // are requested together, one lateral action ahead of their use.
             constexpr int NDDS = 7, NDL = 7;
             tot_cost = INFINITY; tot_constr = INFINITY;
+            float a_dds[NDDS], tn_s[NDDS];
+            int base[NDDS];
+#pragma unroll
+            for (int k = 0; k < NDDS; ++k) {
+                a_dds[k] = action_dds(p, k, NDDS);
+                const TplLatLonState tn = ll_dynamics(tp, a_dds[k], 0.0f, dt);
+                tn_s[k] = tn.s;
+                base[k] = point_idx(tn.ds, p.ds_min, step_ds, p.ds_steps) * p.s_steps
+                          + point_idx(tn.s, p.s_min, step_s, p.s_steps);
+            }
             float d_fwd_left = 0.0f, d_fwd_right = 0.0f;
+            float4 nn[NDDS];
+            {
+                const int row0 = point_idx(tp.l, p.l_min, step_l, p.l_steps) * p.ds_steps * p.s_steps;
+#pragma unroll
+                for (int k = 0; k < NDDS; ++k) nn[k] = next[(size_t)(row0 + base[k])];
+            }
             for (int dl_idx = 0; dl_idx < NDL; ++dl_idx) {
                 const float dl = action_dl(p, dl_idx, NDL);
+                const float tn_l = tp.l + dl * dt;
                 float d_fwd;
                 if (dl_idx == 0) {
                     const float d = dist_at(src, ep, tp.l);
                     d_fwd_left = d; d_fwd_right = d; d_fwd = d;
                 } else if (dl_idx <= NDL / 2) {
-                    const float d = dist_at(src, ep, tp.l + dl * dt);
+                    const float d = dist_at(src, ep, tn_l);
                     d_fwd_left = fminf(d, d_fwd_left);
                     d_fwd = d_fwd_left;
                 } else {
-                    const float d = dist_at(src, ep, tp.l + dl * dt);
+                    const float d = dist_at(src, ep, tn_l);
                     d_fwd_right = fminf(d, d_fwd_right);
                     d_fwd = d_fwd_right;
                 }
                 d_fwd = (float)((double)d_fwd - (double)p.length_veh * 0.5);
                 const float d_safety = d_fwd - p.gap_min - tp.ds * p.time_gap;
+                // the cells of the NEXT lateral action fly while this one is evaluated
+                float4 cur[NDDS];
+#pragma unroll
+                for (int k = 0; k < NDDS; ++k) cur[k] = nn[k];
+                if (dl_idx + 1 < NDL) {
+                    const float l1 = tp.l + action_dl(p, dl_idx + 1, NDL) * dt;
+                    const int row1 = point_idx(l1, p.l_min, step_l, p.l_steps) * p.ds_steps * p.s_steps;
+#pragma unroll
+                    for (int k = 0; k < NDDS; ++k) nn[k] = next[(size_t)(row1 + base[k])];
+                }
+#pragma unroll
                 for (int dds_idx = 0; dds_idx < NDDS; ++dds_idx) {
-                    const float dds = action_dds(p, dds_idx, NDDS);
-                    const TplLatLonState tn = ll_dynamics(tp, dds, dl, dt);
-                    const int is = point_idx(tn.s, p.s_min, step_s, p.s_steps);
-                    const int id = point_idx(tn.ds, p.ds_min, step_ds, p.ds_steps);
-                    const int il = point_idx(tn.l, p.l_min, step_l, p.l_steps);
-                    const float4 nn = next[((size_t)il * p.ds_steps + id) * p.s_steps + is];
-                    const Eval a = eval_action(p, tp, dt, d_fwd, d_safety, dds, dl, tn.s, tn.l, nn.z, nn.w);
-                    const float c = a.cost + nn.x, g = a.constr + nn.y;
+                    const float dds = a_dds[dds_idx];
+                    const float4 v = cur[dds_idx];
+                    const Eval a = eval_action(p, tp, dt, d_fwd, d_safety, dds, dl, tn_s[dds_idx], tn_l, v.z, v.w);
+                    const float c = a.cost + v.x, g = a.constr + v.y;
                     if (eval_less(c, g, tot_cost, tot_constr)) {
                         tot_cost = c; tot_constr = g;
                         best_dds = dds; best_dl = dl;
@@ -330,34 +379,45 @@ __global__ void k_ll_backward(float4* __restrict__ nodes, const float4* __restri
 }
 
 // ------------------------------------------------------------------------
-// forwardStep x t_steps, lat_lon_planner.cu:329-355, 613-632: one wavefront, the 21 x 21 actions
-// of a stage across its lanes.  traj: LatLonState[t_steps], traj[0] = start state.
+// forwardStep x t_steps, lat_lon_planner.cu:329-355, 613-632, in ONE launch: a workgroup of seven
+// wavefronts, one of the 21 x 21 actions of a stage per thread.  A stage is a handful of memory
+// round trips -- reference line, the lateral clearance walk (get_mid<true>), the 21 forward
+// distances, the eight table cells of every action, all requested side by side -- and the state
+// moves from stage to stage in registers (every thread applies the chosen action), not through
+// memory.  traj: LatLonState[t_steps], traj[0] = start state.
 // ------------------------------------------------------------------------
-__global__ void k_ll_forward(TplLatLonState* __restrict__ traj, const float4* __restrict__ tables, size_t table_cells,
-                             const float4* __restrict__ ref, int n_ref, float ref_step,
-                             const float* __restrict__ dist_lon, TplLatLonParams p, TplDpEnvParams ep,
-                             float step_s, float step_ds, float step_l)
+constexpr int LL_FWD_THREADS = 448;                     // 441 actions, 7 wavefronts
+
+__global__ __launch_bounds__(LL_FWD_THREADS)
+void k_ll_forward(TplLatLonState* __restrict__ traj, const float4* __restrict__ tables, size_t table_cells,
+                  const float4* __restrict__ ref, int n_ref, float ref_step,
+                  const float* __restrict__ dist_lon, TplLatLonParams p, TplDpEnvParams ep,
+                  float step_s, float step_ds, float step_l)
 {
-    constexpr int NDDS = 21, NDL = 21;
+    constexpr int NDDS = 21, NDL = 21, NW = LL_FWD_THREADS / 64;
     __shared__ float sh_dfwd[NDL];
-    const int lane = threadIdx.x;
+    __shared__ float sh_c[NW], sh_g[NW], sh_ac[NW], sh_ag[NW];
+    __shared__ unsigned sh_fl[NW];
+    __shared__ int sh_a[NW];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    TplLatLonState tp = traj[0];
     for (int idx_t = 0; idx_t < p.t_steps; ++idx_t) {
         const float dt = (idx_t == 0) ? p.dt_start : p.dt;
-        TplLatLonState tp = traj[idx_t];
         const float4 rp = ref_tex(ref, n_ref, ref_step, tp.s);
         DistSrc src;
         src.profile = nullptr; src.dist_lon = dist_lon; src.t = tp.t; src.s = tp.s;
-        const Eval st = eval_state(p, ep, src, tp, dt, rp);        // every lane, same result
+        const Eval st = eval_state<true>(p, ep, src, tp, dt, rp);  // every thread, same result
         tp.cost = st.cost; tp.constr = st.constr; tp.flags_constr = (uint8_t)st.flags;
         if (idx_t < p.t_steps - 1) {
             const float4* next = tables + (size_t)min(p.t_steps - 1, idx_t + 1) * table_cells;
             // forward distances of the 21 lateral rates; running minima per side as in :223-246
-            if (lane < NDL) sh_dfwd[lane] = dist_at(src, ep, tp.l + action_dl(p, lane, NDL) * dt);
+            if (tid < NDL) sh_dfwd[tid] = dist_at(src, ep, tp.l + action_dl(p, tid, NDL) * dt);
             __syncthreads();
             float best_c = INFINITY, best_g = INFINITY, best_ac = 0.0f, best_ag = 0.0f;
             unsigned best_fl = 0u;
             int best_a = 0x7fffffff;
-            for (int a = lane; a < NDL * NDDS; a += 64) {
+            if (tid < NDL * NDDS) {
+                const int a = tid;
                 const int dl_idx = a / NDDS, dds_idx = a - dl_idx * NDDS;
                 const float dl = action_dl(p, dl_idx, NDL);
                 float d_fwd = sh_dfwd[0];
@@ -377,7 +437,8 @@ __global__ void k_ll_forward(TplLatLonState* __restrict__ traj, const float4* __
                     best_c = c; best_g = g; best_ac = ev.cost; best_ag = ev.constr; best_fl = ev.flags; best_a = a;
                 }
             }
-            // wave argmin: smaller (constr, cost), ties -> the action that comes first in loop order
+            // argmin: smaller (constr, cost), ties -> the action that comes first in loop order;
+            // inside each wavefront by butterflies, across the seven through LDS
             for (int off = 32; off > 0; off >>= 1) {
                 const float oc = __shfl_xor(best_c, off, 64), og = __shfl_xor(best_g, off, 64);
                 const float oac = __shfl_xor(best_ac, off, 64), oag = __shfl_xor(best_ag, off, 64);
@@ -386,6 +447,20 @@ __global__ void k_ll_forward(TplLatLonState* __restrict__ traj, const float4* __
                 const bool take = eval_less(oc, og, best_c, best_g)
                                   || (!eval_less(best_c, best_g, oc, og) && oa < best_a);
                 if (take) { best_c = oc; best_g = og; best_ac = oac; best_ag = oag; best_fl = ofl; best_a = oa; }
+            }
+            if (lane == 0) {
+                sh_c[wave] = best_c; sh_g[wave] = best_g; sh_ac[wave] = best_ac; sh_ag[wave] = best_ag;
+                sh_fl[wave] = best_fl; sh_a[wave] = best_a;
+            }
+            __syncthreads();
+            best_c = sh_c[0]; best_g = sh_g[0]; best_ac = sh_ac[0]; best_ag = sh_ag[0]; best_fl = sh_fl[0]; best_a = sh_a[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const float oc = sh_c[w], og = sh_g[w];
+                const int oa = sh_a[w];
+                const bool take = eval_less(oc, og, best_c, best_g)
+                                  || (!eval_less(best_c, best_g, oc, og) && oa < best_a);
+                if (take) { best_c = oc; best_g = og; best_ac = sh_ac[w]; best_ag = sh_ag[w]; best_fl = sh_fl[w]; best_a = oa; }
             }
             if (best_a != 0x7fffffff) {
                 const int dl_idx = best_a / NDDS, dds_idx = best_a - dl_idx * NDDS;
@@ -398,14 +473,16 @@ __global__ void k_ll_forward(TplLatLonState* __restrict__ traj, const float4* __
                 // no action compared below (inf, inf): minRes keeps its default and dds/dl their old values
                 tp.cost += 0.0f; tp.constr += 0.0f;
             }
-            if (lane == 0) {
+            const TplLatLonState tn = ll_dynamics(tp, tp.dds, tp.dl, dt);
+            if (tid == 0) {
                 traj[idx_t] = tp;
-                traj[idx_t + 1] = ll_dynamics(tp, tp.dds, tp.dl, dt);
+                traj[idx_t + 1] = tn;
             }
-        } else if (lane == 0) {
+            tp = tn;                                     // what the next stage would read back
+            __syncthreads();                             // sh_* are rewritten by the next stage
+        } else if (tid == 0) {
             traj[idx_t] = tp;
         }
-        __syncthreads();
     }
 }
 
@@ -780,14 +857,14 @@ int tplhip_lat_lon_update_traj_dp(tplhip_lat_lon* h, tplhip_dp_env* env, TplLatL
             "copying trajectory to gpu failed");
     hipLaunchKernelGGL(k_ll_prelude, dim3(p.t_steps), dim3(256), 0, h->stream,
                        h->d_ref_s, h->d_profile, h->d_ref, n_ref, env->ref_step, env->d_dist_lon, p, ep, ss);
-    const int threads = std::min(1024, ((p.s_steps + 63) / 64) * 64);
+    const int threads = std::min(256, ((p.s_steps + 63) / 64) * 64);     // k_ll_backward's launch bound
     for (int i = p.t_steps - 1; i > 0; --i) {
         const int nx = std::min(p.t_steps - 1, i + 1);
         hipLaunchKernelGGL(k_ll_backward, dim3(p.ds_steps, p.l_steps), dim3(threads), 0, h->stream,
                            h->d_tables + (size_t)i * h->table_cells, h->d_tables + (size_t)nx * h->table_cells, i,
                            h->d_ref_s, h->d_profile, p, ep, ss, sd, sl);
     }
-    hipLaunchKernelGGL(k_ll_forward, dim3(1), dim3(64), 0, h->stream,
+    hipLaunchKernelGGL(k_ll_forward, dim3(1), dim3(LL_FWD_THREADS), 0, h->stream,
                        h->d_traj, h->d_tables, h->table_cells, h->d_ref, n_ref, env->ref_step, env->d_dist_lon,
                        p, ep, ss, sd, sl);
     HIP_TRY(hipGetLastError(), "lon planner backward pass failed");
