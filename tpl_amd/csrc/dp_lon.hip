@@ -876,19 +876,51 @@ __device__ __forceinline__ void eval_node_wave(TplLonState& tp, const Node* __re
 }
 
 // lonForwardStep chain, lon_planner.cu:211-225 + :365-386.  One wave per rollout.
+// A step is a chain of dependent look-ups (path -> distance map -> next-stage table), and loads and
+// stores of a wavefront complete in order: the trajectory therefore collects in an LDS ring that
+// leaves in one coalesced write every FWD_RING steps (a store per step would put a write
+// acknowledgement in front of the next step's first load), and where they fit (IN_LDS) the path and
+// the distance map are copied to LDS once, so only the table reads of a step go to memory.
+constexpr int FWD_RING = 16;
+
+template <bool IN_LDS>
 __global__ void k_forward(TplLonState* __restrict__ trajs, const TplLonState* __restrict__ inits,
                           const Node* __restrict__ tables, size_t table_cells,
                           const float* __restrict__ path, const float* __restrict__ dist_ts,
                           TplDpLonParams p, TplDpEnvParams ep)
 {
+    extern __shared__ __attribute__((aligned(16))) char fwd_smem[];
+    float* ring = reinterpret_cast<float*>(fwd_smem);                       // FWD_RING x LonState (7 floats)
+    float* l_path = ring + FWD_RING * 7;
+    float* l_dist = l_path + p.path_steps * 7;
+    const int lane = threadIdx.x;
+    if constexpr (IN_LDS) {
+        for (int e = lane; e < p.path_steps * 7; e += 64) l_path[e] = path[e];
+        for (int e = lane; e < ep.t_steps * ep.s_steps; e += 64) l_dist[e] = dist_ts[e];
+        __syncthreads();
+    }
+    const float* pth = IN_LDS ? l_path : path;
+    const float* dst = IN_LDS ? l_dist : dist_ts;
     const int r = blockIdx.x;
     const int T = p.t_steps;
+    static_assert(sizeof(TplLonState) == 7 * sizeof(float), "LonState is seven floats");
+    float* out = reinterpret_cast<float*>(trajs + (size_t)r * T);
     TplLonState tp = inits[r];
     for (int i = 0; i < T; ++i) {
         const float dt = (i == 0) ? p.dt_start : p.dt;
         const int nx = min(T - 1, i + 1);
-        eval_node_wave<N_FWD>(tp, tables + (size_t)nx * table_cells, path, dist_ts, p, ep, dt, true);
-        if ((threadIdx.x & 63) == 0) trajs[(size_t)r * T + i] = tp;
+        eval_node_wave<N_FWD>(tp, tables + (size_t)nx * table_cells, pth, dst, p, ep, dt, true);
+        const int slot = i % FWD_RING;
+        if (lane == 0) {
+            float* q = ring + slot * 7;
+            q[0] = tp.t; q[1] = tp.s; q[2] = tp.v; q[3] = tp.a; q[4] = tp.j; q[5] = tp.cost; q[6] = tp.constr;
+        }
+        if (slot == FWD_RING - 1 || i == T - 1) {
+            __syncthreads();
+            const int n = (slot + 1) * 7, base = (i - slot) * 7;
+            for (int e = lane; e < n; e += 64) out[base + e] = ring[e];
+            __syncthreads();
+        }
         if (i < T - 1) tp = lon_dynamics(tp, tp.j, dt);
     }
 }
@@ -1257,9 +1289,18 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env)
         h->sweep_launches += (T - 1);
     }
     // forward pass, lon_planner.cu:365-386 -- one launch
-    hipLaunchKernelGGL(k_forward, dim3(h->n_rollouts), dim3(64), 0, h->stream,
-                       h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
-                       h->d_path, env->d_dist, p, env->params);
+    {
+        const size_t ring_b = sizeof(float) * 7 * FWD_RING;
+        const size_t maps_b = sizeof(float) * ((size_t)p.path_steps * 7 + (size_t)env->params.t_steps * env->params.s_steps);
+        if (ring_b + maps_b <= 60 * 1024)
+            hipLaunchKernelGGL(k_forward<true>, dim3(h->n_rollouts), dim3(64), ring_b + maps_b, h->stream,
+                               h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
+                               h->d_path, env->d_dist, p, env->params);
+        else
+            hipLaunchKernelGGL(k_forward<false>, dim3(h->n_rollouts), dim3(64), ring_b, h->stream,
+                               h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
+                               h->d_path, env->d_dist, p, env->params);
+    }
     HIP_TRY(hipGetLastError(), "lon planner launch failed");
     h->tables_valid = true;
     return TPLHIP_OK;
