@@ -28,6 +28,7 @@
 //   nothing; both windings are drawn (no culling in the reference).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -191,27 +192,45 @@ __global__ void k_close_intersections(float* __restrict__ occ, const float* __re
 }
 
 // ------------------------------------------------------------------------
-// updateDistMapLon, env.cu:95-129.  One thread per (l, t): the two scans along s are order
-// dependent float accumulations.  dist_lon: [l][s][t][2].
+// updateDistMapLon, env.cu:95-129.  The two scans along s are order-dependent float
+// accumulations, one chain per (l, t).  A workgroup takes one l and a block of DML_TC time
+// slices: the occupancy tile comes into LDS in one coalesced pass, the chains run from and to LDS
+// (a chain that loads and stores global memory in turn pays a write acknowledgement per station),
+// and the result leaves in one coalesced pass.  dist_lon: [l][s][t][2].
 // ------------------------------------------------------------------------
-__global__ void k_dist_map_lon(float* __restrict__ dist_lon, const float* __restrict__ occ, TplDpEnvParams ep)
+constexpr int DML_TC = 16;                            // time slices per workgroup where LDS allows
+
+__global__ void k_dist_map_lon(float* __restrict__ dist_lon, const float* __restrict__ occ, TplDpEnvParams ep, int tc_cap)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= ep.l_steps * ep.t_steps) return;
-    const int idx_l = idx / ep.t_steps;
-    const int idx_t = idx - idx_l * ep.t_steps;
-    const size_t stride = (size_t)ep.t_steps;
-    const float* o = occ + (size_t)idx_l * ep.s_steps * stride + idx_t;
-    float* d2 = dist_lon + ((size_t)idx_l * ep.s_steps * stride + idx_t) * 2;
-    float d = 10000.0f;
-    for (int idx_s = ep.s_steps - 1; idx_s >= 0; --idx_s) {
-        if (o[(size_t)idx_s * stride] > 0.0f) d = 0.0f; else d += ep._s_step_size;
-        d2[(size_t)idx_s * stride * 2] = d;
+    extern __shared__ __attribute__((aligned(16))) float dml_sh[];
+    const int S = ep.s_steps, T = ep.t_steps;
+    const int idx_l = blockIdx.x, t0 = blockIdx.y * tc_cap;
+    const int tc = min(tc_cap, T - t0);
+    float* sh_o = dml_sh;                               // [S][tc]
+    float* sh_d = dml_sh + S * tc_cap;                  // [S][tc][2]
+    const float* o = occ + (size_t)idx_l * S * T + t0;
+    float* d2 = dist_lon + ((size_t)idx_l * S * T + t0) * 2;
+    for (int e = threadIdx.x; e < S * tc; e += blockDim.x) {
+        const int is = e / tc, tt = e - is * tc;
+        sh_o[e] = o[(size_t)is * T + tt];
     }
-    d = 10000.0f;
-    for (int idx_s = 0; idx_s < ep.s_steps; ++idx_s) {
-        if (o[(size_t)idx_s * stride] > 0.0f) d = 0.0f; else d += ep._s_step_size;
-        d2[(size_t)idx_s * stride * 2 + 1] = d;
+    __syncthreads();
+    for (int tt = threadIdx.x; tt < tc; tt += blockDim.x) {
+        float d = 10000.0f;
+        for (int idx_s = S - 1; idx_s >= 0; --idx_s) {
+            if (sh_o[idx_s * tc + tt] > 0.0f) d = 0.0f; else d += ep._s_step_size;
+            sh_d[(idx_s * tc + tt) * 2] = d;
+        }
+        d = 10000.0f;
+        for (int idx_s = 0; idx_s < S; ++idx_s) {
+            if (sh_o[idx_s * tc + tt] > 0.0f) d = 0.0f; else d += ep._s_step_size;
+            sh_d[(idx_s * tc + tt) * 2 + 1] = d;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < S * tc * 2; e += blockDim.x) {
+        const int is = e / (tc * 2), r = e - is * (tc * 2);
+        d2[(size_t)is * T * 2 + r] = sh_d[e];
     }
 }
 
@@ -353,8 +372,14 @@ int tplhip_dp_env_update(tplhip_dp_env* env)
                        env->d_occ, env->d_cart, W, env->d_frames, ep);
     hipLaunchKernelGGL(k_close_intersections, dim3((ep.t_steps * ep.s_steps + 255) / 256), dim3(256), 0, st,
                        env->d_occ, env->d_semantic, (int)n_ref, env->ref_step, ep);
-    hipLaunchKernelGGL(k_dist_map_lon, dim3((ep.l_steps * ep.t_steps + 63) / 64), dim3(64), 0, st,
-                       env->d_dist_lon, env->d_occ, ep);
+    {
+        // LDS per workgroup: 12 bytes per (station, slice); at most 60 KB
+        const int tc_cap = std::max(1, std::min(DML_TC, (int)(60 * 1024 / (12 * (size_t)ep.s_steps))));
+        if (12 * (size_t)ep.s_steps * tc_cap > 64 * 1024)
+            return tplhip_fail(TPLHIP_EINVAL, "s_steps = %d is too large for the distance-map kernel", ep.s_steps);
+        hipLaunchKernelGGL(k_dist_map_lon, dim3(ep.l_steps, (ep.t_steps + tc_cap - 1) / tc_cap), dim3(256),
+                           sizeof(float) * 3 * (size_t)ep.s_steps * tc_cap, st, env->d_dist_lon, env->d_occ, ep, tc_cap);
+    }
     HIP_TRY(hipGetLastError(), "occupancy pipeline launch failed");
     HIP_TRY(hipStreamSynchronize(st), "updating the environment failed");
     env->vertices.clear();            // occupancy_renderer.cu:311
