@@ -80,18 +80,42 @@ class PolyLatTraj:
     """tplcpp.PolyLatTraj (bindings_dp_poly_lat.cu:47-100)."""
 
     def __init__(self):
-        self.points = []
+        self._points = []
+        self._arr = None                       # C array of a fresh result; `points` not built yet
         self.poly = PolyQuintic()
         self.cost = 0.0
 
+    # `points` is the reference's list of PolyLatTrajPoint.  A planner result arrives as one C array
+    # and the list (one Python object per station) is only built when somebody asks for it: lerp,
+    # as_numpy and the planners' own use go through the array.
+    @property
+    def points(self):
+        if self._points is None:
+            self._points = [PolyLatTrajPoint._from_c(c) for c in self._arr]
+            self._arr = None
+        return self._points
+
+    @points.setter
+    def points(self, value):
+        self._points = value
+        self._arr = None
+
+    def __len__(self):
+        return len(self._arr) if self._points is None else len(self._points)
+
     def _as_array(self):
-        arr = (TplPolyLatTrajPoint * len(self.points))()
-        for i, p in enumerate(self.points):
+        if self._points is None:
+            arr = (TplPolyLatTrajPoint * len(self._arr))()
+            C.memmove(arr, self._arr, C.sizeof(arr))
+            return arr
+        arr = (TplPolyLatTrajPoint * len(self._points))()
+        for i, p in enumerate(self._points):
             C.memmove(C.byref(arr[i]), C.byref(p._c), C.sizeof(TplPolyLatTrajPoint))
         return arr
 
     def _take(self, arr):
-        self.points = [PolyLatTrajPoint._from_c(c) for c in arr]
+        self._arr = arr
+        self._points = None
 
     def update_time_dist_curv(self):
         arr = self._as_array()
@@ -125,14 +149,18 @@ class PolyLatTraj:
         return res
 
     def as_numpy(self):
-        res = np.empty((len(self.points), 12), dtype=np.float64)
-        for i, p in enumerate(self.points):
-            res[i] = [getattr(p._c, f) for f in _FIELDS12]
+        arr = self._as_array()
+        res = np.empty((len(arr), 12), dtype=np.float64)
+        for i, c in enumerate(arr):
+            res[i] = [getattr(c, f) for f in _FIELDS12]
         return res
 
     def copy(self):
         other = PolyLatTraj()
-        other.points = [p.copy() for p in self.points]
+        if self._points is None:
+            other._take(self._as_array())
+        else:
+            other.points = [p.copy() for p in self._points]
         C.memmove(C.byref(other.poly._c), C.byref(self.poly._c), C.sizeof(TplPolyQuintic))
         other.cost = self.cost
         return other
