@@ -67,7 +67,27 @@ class _Traj:
     _fields = ()
 
     def __init__(self):
-        self.states = [self._state_cls()]          # std::vector<...> states{1}
+        self._states = [self._state_cls()]         # std::vector<...> states{1}
+        self._arr = None                           # (C array, length) of a fresh result; list not built yet
+
+    # `states` is the reference's list of state objects.  Results of the planner arrive as one C
+    # array; the list (one Python object per state) is built when somebody asks for it, while
+    # state(t), lerp(t), as_numpy() and the planner's own calls work on the array.
+    @property
+    def states(self):
+        if self._states is None:
+            arr, n = self._arr
+            self._states = [self._state_cls._from_c(arr[i]) for i in range(n)]
+            self._arr = None
+        return self._states
+
+    @states.setter
+    def states(self, value):
+        self._states = value
+        self._arr = None
+
+    def __len__(self):
+        return self._arr[1] if self._states is None else len(self._states)
 
     def __getitem__(self, idx):
         return self.states[idx]
@@ -76,24 +96,33 @@ class _Traj:
         self.states[idx] = val.__deepcopy__({})
 
     def _as_array(self):
-        arr = (self._ctype * len(self.states))()
-        for i, s in enumerate(self.states):
+        if self._states is None:
+            src, n = self._arr
+            arr = (self._ctype * n)()
+            C.memmove(arr, src, C.sizeof(arr))
+            return arr
+        arr = (self._ctype * len(self._states))()
+        for i, s in enumerate(self._states):
             C.memmove(C.byref(arr[i]), C.byref(s._c), C.sizeof(self._ctype))
         return arr
 
     def _take(self, arr, n=None):
-        n = len(arr) if n is None else n
-        self.states = [self._state_cls._from_c(arr[i]) for i in range(n)]
+        self._arr = (arr, len(arr) if n is None else n)
+        self._states = None
 
     def as_numpy(self):
-        res = np.empty((len(self.states), len(self._fields)), dtype=np.float64)
-        for i, s in enumerate(self.states):
-            res[i] = [getattr(s._c, f) for f in self._fields]
+        arr = self._as_array()
+        res = np.empty((len(arr), len(self._fields)), dtype=np.float64)
+        for i, c in enumerate(arr):
+            res[i] = [getattr(c, f) for f in self._fields]
         return res
 
     def copy(self):
         other = type(self)()
-        other.states = [s.__deepcopy__({}) for s in self.states]
+        if self._states is None:
+            other._take(self._as_array())
+        else:
+            other.states = [s.__deepcopy__({}) for s in self._states]
         return other
 
     def _many(self, fn, ts):
@@ -181,16 +210,16 @@ class DynProgLatLonPlanner:
 
     def update_traj_dp(self, env):
         T = self.params.t_steps
-        st = self.traj_dp.states
-        self.traj_dp.states = (st + [LatLonState() for _ in range(T)])[:T]        # states.resize(t_steps)
-        arr = self.traj_dp._as_array()
+        cur = self.traj_dp._as_array()
+        arr = (TplLatLonState * T)()                                             # states.resize(t_steps)
+        C.memmove(arr, cur, min(len(cur), T) * C.sizeof(TplLatLonState))
         check(self._lib.tplhip_lat_lon_update_traj_dp(self._h, env._h, arr))
         self.traj_dp._take(arr)
 
     def update_traj_smooth(self, env):
         dp = self.traj_dp._as_array()
-        x0 = self.traj_smooth.states[0]._c
-        cap = max(2, int(self.traj_dp.states[-1].t / self.params.dt_smooth_traj) + 2)
+        x0 = self.traj_smooth._as_array()[0]
+        cap = max(2, int(dp[len(dp) - 1].t / self.params.dt_smooth_traj) + 2)
         out = (TplLatLonState * cap)()
         n = C.c_int()
         check(self._lib.tplhip_lat_lon_update_traj_smooth(self._h, dp, len(dp), C.byref(x0), out, cap, C.byref(n)))
