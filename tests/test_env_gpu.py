@@ -156,3 +156,13 @@ def test_unusual_parameters_and_bit_31():
     assert occ.shape == (17, 150, 33)
     assert (occ[:, :, 32] == 1.0).sum() == 0          # no bit for slice 32
     assert (occ == 3.0).any() and (occ[:, :, 5] == 1.0).any()
+
+
+@pytest.mark.gpu
+def test_long_station_axis_narrows_the_distance_map_tiles():
+    """450 stations: the LDS tiles of the distance-map scans hold 11 time slices instead of 16, and
+    25 slices make three tiles with a ragged last one."""
+    ep = sc.env_params(t_steps=25, s_steps=450, l_steps=13)
+    rl, step, objs = sc.env_scene("arc", seed=5, n_objects=6)
+    env, ref = _run_both(ep, rl, step, objs)
+    _assert_same(env, ref)

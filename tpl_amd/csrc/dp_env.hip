@@ -216,13 +216,37 @@ __global__ void k_dist_map_lon(float* __restrict__ dist_lon, const float* __rest
     }
     __syncthreads();
     for (int tt = threadIdx.x; tt < tc; tt += blockDim.x) {
+        // eight occupancy flags are read before the chain runs over them (the reads do not depend on
+        // the running distance; one at a time each step of the chain would wait for its LDS read)
         float d = 10000.0f;
-        for (int idx_s = S - 1; idx_s >= 0; --idx_s) {
+        int idx_s = S - 1;
+        for (; idx_s >= 7; idx_s -= 8) {
+            float o8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o8[k] = sh_o[(idx_s - k) * tc + tt];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (o8[k] > 0.0f) d = 0.0f; else d += ep._s_step_size;
+                sh_d[((idx_s - k) * tc + tt) * 2] = d;
+            }
+        }
+        for (; idx_s >= 0; --idx_s) {
             if (sh_o[idx_s * tc + tt] > 0.0f) d = 0.0f; else d += ep._s_step_size;
             sh_d[(idx_s * tc + tt) * 2] = d;
         }
         d = 10000.0f;
-        for (int idx_s = 0; idx_s < S; ++idx_s) {
+        idx_s = 0;
+        for (; idx_s + 8 <= S; idx_s += 8) {
+            float o8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o8[k] = sh_o[(idx_s + k) * tc + tt];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (o8[k] > 0.0f) d = 0.0f; else d += ep._s_step_size;
+                sh_d[((idx_s + k) * tc + tt) * 2 + 1] = d;
+            }
+        }
+        for (; idx_s < S; ++idx_s) {
             if (sh_o[idx_s * tc + tt] > 0.0f) d = 0.0f; else d += ep._s_step_size;
             sh_d[(idx_s * tc + tt) * 2 + 1] = d;
         }
