@@ -1084,20 +1084,44 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                 const double* cu = CU + (int64_t)pick * st.rows * NU;
                 if (accepted) {
                     J = __shfl(Jc, pick, WAVE);
-                    for (int e = lane; e < (T + 1) * NX; e += WAVE) {
-                        PRV_X[e] = X_[e];
-                        const double v = cx[e];
-                        NXT_X[e] = v;
-                        X_[e] = v;
-                        if (lt) XL[e] = v;
+                    // (all loads of a block of eight rows before its stores: loads and stores of a
+                    // wavefront complete in order, a load behind a store waits for the write)
+                    for (int e0 = 0; e0 < (T + 1) * NX; e0 += WAVE * 8) {
+                        double ox[8], nv[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int e = e0 + k * WAVE + lane;
+                            if (e < (T + 1) * NX) { ox[k] = X_[e]; nv[k] = cx[e]; }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int e = e0 + k * WAVE + lane;
+                            if (e < (T + 1) * NX) {
+                                PRV_X[e] = ox[k];
+                                NXT_X[e] = nv[k];
+                                X_[e] = nv[k];
+                                if (lt) XL[e] = nv[k];
+                            }
+                        }
                     }
-                    for (int e = lane; e < T * NU; e += WAVE) {
-                        PRV_K[e] = KFF[e];
-                        if (e >= opt_start * NU) {
-                            const double v = cu[e];
-                            NXT_U[e] = v;
-                            U_[e] = v;
-                            if (lt) UL[e] = v;
+                    for (int e0 = 0; e0 < T * NU; e0 += WAVE * 4) {
+                        double ok_[4], nu_[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int e = e0 + k * WAVE + lane;
+                            if (e < T * NU) { ok_[k] = KFF[e]; nu_[k] = (e >= opt_start * NU) ? cu[e] : 0.0; }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int e = e0 + k * WAVE + lane;
+                            if (e < T * NU) {
+                                PRV_K[e] = ok_[k];
+                                if (e >= opt_start * NU) {
+                                    NXT_U[e] = nu_[k];
+                                    U_[e] = nu_[k];
+                                    if (lt) UL[e] = nu_[k];
+                                }
+                            }
                         }
                     }
                     for (int e = lane; e < T + 1; e += WAVE) { NIS[e] = dt; IS[e] = dt; }
@@ -1105,8 +1129,32 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                     improved = true;
                 } else {
                     // the reference leaves the last tried rollout (alpha = 1e-7) in next_*
-                    for (int e = lane; e < (T + 1) * NX; e += WAVE) NXT_X[e] = cx[e];
-                    for (int e = lane + opt_start * NU; e < T * NU; e += WAVE) NXT_U[e] = cu[e];
+                    for (int e0 = 0; e0 < (T + 1) * NX; e0 += WAVE * 8) {
+                        double nv[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int e = e0 + k * WAVE + lane;
+                            if (e < (T + 1) * NX) nv[k] = cx[e];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int e = e0 + k * WAVE + lane;
+                            if (e < (T + 1) * NX) NXT_X[e] = nv[k];
+                        }
+                    }
+                    for (int e0 = opt_start * NU; e0 < T * NU; e0 += WAVE * 4) {
+                        double nu_[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int e = e0 + k * WAVE + lane;
+                            if (e < T * NU) nu_[k] = cu[e];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int e = e0 + k * WAVE + lane;
+                            if (e < T * NU) NXT_U[e] = nu_[k];
+                        }
+                    }
                     for (int e = lane; e < T + 1; e += WAVE) NIS[e] = dt;
                 }
             }
