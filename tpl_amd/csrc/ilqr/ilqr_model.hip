@@ -1029,6 +1029,8 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
             __syncthreads();
             STAMP(11);
             // pass B: stage costs of all candidates and stages, 64 at a time
+            const int cc_rows = T + 1;
+            const bool cc_lds = N_ALPHA * cc_rows <= N_ALPHA * ROLL_RING * NX;
             {
                 const int n_t = T - opt_start;
                 for (int idx = lane; idx < N_ALPHA * n_t; idx += WAVE) {
@@ -1042,14 +1044,17 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
 #pragma unroll
                     for (int d = 0; d < NU; ++d) u[d] = cu[d];
                     costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
-                    CC[(int64_t)cand * st.rows + t] = c;
+                    // into LDS where the rollouts' ring (idle now) can hold them: a store to global
+                    // memory would put a write acknowledgement in front of the next pass' loads
+                    if (cc_lds) s.ring_x[cand * cc_rows + t] = c;
+                    else CC[(int64_t)cand * st.rows + t] = c;
                 }
             }
             __syncthreads();
             STAMP(12);
             // ordered sums, cost += c for t = optStart..T-1, then the end costs (:776-790)
             if (lane < N_ALPHA) {
-                const double* cc = CC + (int64_t)lane * st.rows;
+                const double* cc = cc_lds ? &s.ring_x[lane * cc_rows] : CC + (int64_t)lane * st.rows;
                 double cost = 0.0, c;
                 int t = opt_start;
                 for (; t + 8 <= T; t += 8) {                    // eight loads in flight, additions in order
