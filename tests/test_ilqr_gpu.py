@@ -180,3 +180,46 @@ def test_long_horizon_and_per_problem_parameters():
         one.update()
         assert cases.scaled_err(batch.x[b], one.x) < 1e-6, b
         assert int(batch.iterations[b]) == one.iterations
+
+
+@pytest.mark.parametrize("horizon,t_cap", [(37, 37), (21, None), (60, 60), (13, 13)])
+def test_ragged_horizons_match_oracle(horizon, t_cap):
+    """Horizons that are not a multiple of the rollout ring (8 stages) and both homes of the
+    trajectory mirrors: t_cap = horizon puts them in LDS, the default capacity of 299 stages leaves
+    them in global memory.  60 stages no longer fit the cost block into the LDS ring."""
+    make = _factory("trajectory_tracking_mpc")
+    opt = make(horizon=t_cap) if t_cap else make()
+    ref = OI.OracleOptim("trajectory_tracking_mpc")
+    for o in (opt, ref):
+        cases.mpc(o, seed=2, curvature=0.01, min_rel=0.0)
+        o.horizon = horizon
+        o.max_iterations = 6
+        o.x[0] = np.array([0.0, 0.3, -0.05, 0.0, 7.0, 0.0, 0.0])
+    for _ in range(2):
+        opt.update()
+        ref.update()
+        assert int(opt.iterations) == int(ref.iterations) and float(opt.alpha) == float(ref.alpha)
+        assert cases.scaled_err(opt.x[:horizon + 1], ref.x[:horizon + 1]) < 1e-6
+        assert cases.scaled_err(opt.u[:horizon], ref.u[:horizon]) < 1e-6
+        assert abs(float(opt.traj_costs) - float(ref.traj_costs)) < 1e-8 * abs(float(ref.traj_costs))
+
+
+def test_frozen_prefix_stays_frozen():
+    """opt_start > 0.  No tpl caller moves it off 0, and the reference's own line search then starts
+    from next_x[optStart], a row nothing ever initialises (optim.c:737-742), and copies that stale
+    prefix over x on acceptance -- not a behaviour to reproduce.  Here the stages before opt_start
+    are kept, the rollouts start from x[opt_start], and the cost (summed from opt_start like the
+    reference's) does not get worse."""
+    make = _factory("trajectory_tracking_mpc")
+    opt = make(horizon=30)
+    cases.mpc(opt, seed=2, curvature=0.01, min_rel=0.0)
+    opt.horizon = 30
+    opt.max_iterations = 5
+    opt.x[0] = np.array([0.0, 0.3, -0.05, 0.0, 7.0, 0.0, 0.0])
+    opt.update()                                      # a consistent trajectory to freeze a prefix of
+    x_before, u_before, j_before = np.array(opt.x), np.array(opt.u), float(opt.traj_costs)
+    opt.opt_start = 4
+    opt.update()
+    assert np.array_equal(np.asarray(opt.x[:5]), x_before[:5]) and np.array_equal(np.asarray(opt.u[:4]), u_before[:4])
+    assert np.isfinite(float(opt.traj_costs)) and float(opt.traj_costs) <= j_before * (1 + 1e-12)
+    assert not np.array_equal(np.asarray(opt.x[6:]), x_before[6:])
