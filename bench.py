@@ -298,6 +298,17 @@ def main():
             if tr:
                 out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = "profiles/r01_dp_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+                # what actually binds the sweep: VALU issue.  Instructions per wave from the same PMC
+                # passes (SQ_INSTS_VALU / SQ_WAVES), 4 cycles per wave instruction, 1024 SIMDs, against the
+                # measured launch time at the 2.4 GHz peak clock (the real clock under this load is lower,
+                # so the true fraction is higher).  Informative; `frac` above stays the prescribed HBM one.
+                if out["roofline"]["kernel"] in ("k_backward2v", "k_backward2") and tr.get("valu_insts_per_wave"):
+                    waves = cells / 128.0
+                    busy = tr["valu_insts_per_wave"] * waves * 4.0 / 1024.0
+                    out["roofline"]["valu_issue"] = {
+                        "insts_per_wave": tr["valu_insts_per_wave"], "waves_per_launch": waves,
+                        "busy_cycles_per_simd": busy, "launch_cycles_at_2.4GHz": per_launch_s * 2.4e9,
+                        "frac": busy / (per_launch_s * 2.4e9)}
         except OSError:
             pass
         if not args.no_cpu_baseline and world == 1:
