@@ -288,8 +288,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                               const float4* __restrict__ ref_s, const float* __restrict__ profile,
                               TplLatLonParams p, TplDpEnvParams ep, float step_s, float step_ds, float step_l)
 {
-    const int idx_ds = blockIdx.x, idx_l = blockIdx.y;
-    for (int idx_s = threadIdx.x; idx_s < p.s_steps; idx_s += blockDim.x) {
+    // the (s, ds) cells of one lateral offset, flattened: every wavefront is full (rows of 201
+    // stations would leave a fifth of the lanes of a 256-thread row block idle)
+    const int idx_l = blockIdx.y;
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell < p.s_steps * p.ds_steps) {
+        const int idx_ds = cell / p.s_steps, idx_s = cell - idx_ds * p.s_steps;
         TplLatLonState tp;
         tp.t = p.dt_start + (float)(idx_t - 1) * p.dt;
         tp.s = p.s_min + (float)idx_s * step_s;
@@ -857,10 +861,11 @@ int tplhip_lat_lon_update_traj_dp(tplhip_lat_lon* h, tplhip_dp_env* env, TplLatL
             "copying trajectory to gpu failed");
     hipLaunchKernelGGL(k_ll_prelude, dim3(p.t_steps), dim3(256), 0, h->stream,
                        h->d_ref_s, h->d_profile, h->d_ref, n_ref, env->ref_step, env->d_dist_lon, p, ep, ss);
-    const int threads = std::min(256, ((p.s_steps + 63) / 64) * 64);     // k_ll_backward's launch bound
+    const int threads = 256;                                             // k_ll_backward's launch bound
+    const int row_blocks = (p.s_steps * p.ds_steps + threads - 1) / threads;
     for (int i = p.t_steps - 1; i > 0; --i) {
         const int nx = std::min(p.t_steps - 1, i + 1);
-        hipLaunchKernelGGL(k_ll_backward, dim3(p.ds_steps, p.l_steps), dim3(threads), 0, h->stream,
+        hipLaunchKernelGGL(k_ll_backward, dim3(row_blocks, p.l_steps), dim3(threads), 0, h->stream,
                            h->d_tables + (size_t)i * h->table_cells, h->d_tables + (size_t)nx * h->table_cells, i,
                            h->d_ref_s, h->d_profile, p, ep, ss, sd, sl);
     }
