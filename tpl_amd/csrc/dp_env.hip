@@ -124,44 +124,54 @@ __device__ __forceinline__ uint32_t fetch_px(const uint32_t* __restrict__ img, i
 }
 
 // ------------------------------------------------------------------------
-// occupancyToFrenet, env.cu:11-63.  One thread per Frenet cell (s, l); the time-bit word of the
-// dilation disc is expanded to all slices.  occ: [l][s][t], t fastest.
+// occupancyToFrenet, env.cu:11-63.  One workgroup per station: the (lateral cell, disc sample)
+// pairs -- 31 x 144 point samples for the default parameters -- are spread over its threads and
+// OR-ed into one word per cell in LDS (the reference walks the 144 samples of a cell one after
+// the other, and once per time slice); the time-bit word of a cell is then expanded to all
+// slices by all threads.  occ: [l][s][t], t fastest.
 // ------------------------------------------------------------------------
+constexpr int OTF_MAX_L = 1024;
+
 __global__ void k_occ_to_frenet(float* __restrict__ occ, const uint32_t* __restrict__ img, int W,
                                 const StationFrame* __restrict__ frames, TplDpEnvParams ep)
 {
+    __shared__ uint32_t sh_bits[OTF_MAX_L];
+    __shared__ float sh_px[OTF_MAX_L], sh_py[OTF_MAX_L];
     const int idx_s = blockIdx.x;
-    const int idx_l = threadIdx.x;
-    if (idx_s >= ep.s_steps || idx_l >= ep.l_steps) return;
-
+    const int L = ep.l_steps, T = ep.t_steps;
     const int dil_steps = (int)ceilf(ep.dilation * PPM);
-    const float l = ep.l_min + (float)idx_l * ep._l_step_size;
     const StationFrame f = frames[idx_s];
-
-    const float x = (float)(f.x - (double)l * f.sin_h);
-    const float y = (float)(f.y + (double)l * f.cos_h);
-    const float x_pixels = (float)((double)(x * PPM) + (double)(float)W / 2.0);
-    const float y_pixels = (float)((double)(y * PPM) + (double)(float)W / 2.0);
-
-    uint32_t bits = 0;
-    for (int i = -dil_steps; i < dil_steps; ++i) {
-        for (int j = -dil_steps; j < dil_steps; ++j) {
-            if (sqrtf((float)(i * i + j * j)) > (float)dil_steps) continue;
-            bits |= fetch_px(img, W, x_pixels + (float)i, y_pixels + (float)j);
-        }
+    for (int idx_l = threadIdx.x; idx_l < L; idx_l += blockDim.x) {
+        const float l = ep.l_min + (float)idx_l * ep._l_step_size;
+        const float x = (float)(f.x - (double)l * f.sin_h);
+        const float y = (float)(f.y + (double)l * f.cos_h);
+        sh_px[idx_l] = (float)((double)(x * PPM) + (double)(float)W / 2.0);
+        sh_py[idx_l] = (float)((double)(y * PPM) + (double)(float)W / 2.0);
+        sh_bits[idx_l] = 0u;
     }
-
-    const bool stationary = (bits >> 31) != 0u;
-    const bool outside = ((double)l > f.d_left || (double)l < -f.d_right)
-                         || (idx_l == 0 || idx_l == ep.l_steps - 1)
-                         || (f.v_max < 0.1);
-    float* out = occ + ((size_t)idx_l * ep.s_steps + idx_s) * ep.t_steps;
-    for (int t = 0; t < ep.t_steps; ++t) {
+    __syncthreads();
+    const int side = 2 * dil_steps, nq = side * side;
+    for (int w = threadIdx.x; w < L * nq; w += blockDim.x) {
+        const int idx_l = w / nq, q = w - idx_l * nq;
+        const int i = q / side - dil_steps, j = q - (q / side) * side - dil_steps;
+        if (sqrtf((float)(i * i + j * j)) > (float)dil_steps) continue;
+        const uint32_t px = fetch_px(img, W, sh_px[idx_l] + (float)i, sh_py[idx_l] + (float)j);
+        if (px) atomicOr(&sh_bits[idx_l], px);
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < L * T; w += blockDim.x) {
+        const int idx_l = w / T, t = w - idx_l * T;
+        const float l = ep.l_min + (float)idx_l * ep._l_step_size;
+        const uint32_t bits = sh_bits[idx_l];
+        const bool stationary = (bits >> 31) != 0u;
+        const bool outside = ((double)l > f.d_left || (double)l < -f.d_right)
+                             || (idx_l == 0 || idx_l == L - 1)
+                             || (f.v_max < 0.1);
         // (occ & (1 << t)): a shift by >= 32 yields 0 on the reference's hardware
         float val = (t < 32 && ((bits >> t) & 1u)) ? 1.0f : 0.0f;
         if (stationary) val = 3.0f;
         if (outside) val = 2.0f;
-        out[t] = val;
+        occ[((size_t)idx_l * ep.s_steps + idx_s) * T + t] = val;
     }
 }
 
@@ -392,7 +402,7 @@ int tplhip_dp_env_update(tplhip_dp_env* env)
         hipLaunchKernelGGL(k_raster_or, dim3((unsigned)(n_vtx / 3)), dim3(64), 0, st,
                            env->d_cart, W, env->d_vtx, (int)(n_vtx / 3), scale);
     }
-    hipLaunchKernelGGL(k_occ_to_frenet, dim3(ep.s_steps), dim3(((ep.l_steps + 63) / 64) * 64), 0, st,
+    hipLaunchKernelGGL(k_occ_to_frenet, dim3(ep.s_steps), dim3(256), 0, st,
                        env->d_occ, env->d_cart, W, env->d_frames, ep);
     hipLaunchKernelGGL(k_close_intersections, dim3((ep.t_steps * ep.s_steps + 255) / 256), dim3(256), 0, st,
                        env->d_occ, env->d_semantic, (int)n_ref, env->ref_step, ep);
