@@ -225,40 +225,32 @@ __global__ void k_dist_map_lon(float* __restrict__ dist_lon, const float* __rest
         sh_o[e] = o[(size_t)is * T + tt];
     }
     __syncthreads();
-    for (int tt = threadIdx.x; tt < tc; tt += blockDim.x) {
-        // eight occupancy flags are read before the chain runs over them (the reads do not depend on
-        // the running distance; one at a time each step of the chain would wait for its LDS read)
+    // one thread per (slice, direction): the towards-the-ego and away-from-the-ego chains of a slice
+    // are independent.  Eight occupancy flags are read before the chain runs over them (the reads
+    // do not depend on the running distance; one at a time each step would wait for its LDS read).
+    for (int w = threadIdx.x; w < 2 * tc; w += blockDim.x) {
+        const int tt = w % tc;
+        const bool fwd = w >= tc;
         float d = 10000.0f;
-        int idx_s = S - 1;
-        for (; idx_s >= 7; idx_s -= 8) {
+        int k0 = 0;
+        for (; k0 + 8 <= S; k0 += 8) {
             float o8[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o8[k] = sh_o[(idx_s - k) * tc + tt];
+            for (int k = 0; k < 8; ++k) {
+                const int idx_s = fwd ? k0 + k : S - 1 - (k0 + k);
+                o8[k] = sh_o[idx_s * tc + tt];
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
+                const int idx_s = fwd ? k0 + k : S - 1 - (k0 + k);
                 if (o8[k] > 0.0f) d = 0.0f; else d += ep._s_step_size;
-                sh_d[((idx_s - k) * tc + tt) * 2] = d;
+                sh_d[(idx_s * tc + tt) * 2 + (fwd ? 1 : 0)] = d;
             }
         }
-        for (; idx_s >= 0; --idx_s) {
+        for (; k0 < S; ++k0) {
+            const int idx_s = fwd ? k0 : S - 1 - k0;
             if (sh_o[idx_s * tc + tt] > 0.0f) d = 0.0f; else d += ep._s_step_size;
-            sh_d[(idx_s * tc + tt) * 2] = d;
-        }
-        d = 10000.0f;
-        idx_s = 0;
-        for (; idx_s + 8 <= S; idx_s += 8) {
-            float o8[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o8[k] = sh_o[(idx_s + k) * tc + tt];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (o8[k] > 0.0f) d = 0.0f; else d += ep._s_step_size;
-                sh_d[((idx_s + k) * tc + tt) * 2 + 1] = d;
-            }
-        }
-        for (; idx_s < S; ++idx_s) {
-            if (sh_o[idx_s * tc + tt] > 0.0f) d = 0.0f; else d += ep._s_step_size;
-            sh_d[(idx_s * tc + tt) * 2 + 1] = d;
+            sh_d[(idx_s * tc + tt) * 2 + (fwd ? 1 : 0)] = d;
         }
     }
     __syncthreads();
