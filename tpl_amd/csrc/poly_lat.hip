@@ -98,6 +98,7 @@ __global__ void k_poly_lat_paths(float4* __restrict__ nodes, float2* __restrict_
     float* sh_z = sh_w + S;
     float* sh_x = sh_z + S;
     float* sh_y = sh_x + S;
+    double* sh_q = reinterpret_cast<double*>(smem + sizeof(float) * 6 * (size_t)((S + 1) & ~1));   // 8-byte aligned
 
     const int idx_l_dst = blockIdx.x;
     const int idx_s_dst = blockIdx.y;
@@ -164,13 +165,27 @@ __global__ void k_poly_lat_paths(float4* __restrict__ nodes, float2* __restrict_
             const float dx = sh_x[idx_s] - sh_x[idx_s - 1], dy = sh_y[idx_s] - sh_y[idx_s - 1];
             inc = sqrtf(dx * dx + dy * dy);
         }
-        sh_z[idx_s] = inc;
+        // the quotient of the running sum's step, in parallel: the chain below is then one
+        // double addition per station instead of an IEEE double division
+        sh_q[idx_s] = (double)inc / fmax(1.0, (double)sh_v[idx_s]);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         float t = 0.0f;
-        for (int idx_s = 0; idx_s < S; ++idx_s) {
-            if (idx_s > 0) t = (float)((double)t + (double)sh_z[idx_s] / fmax(1.0, (double)sh_v[idx_s]));
+        sh_z[0] = 0.0f;
+        int idx_s = 1;
+        for (; idx_s + 8 <= S; idx_s += 8) {
+            double q8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q8[k] = sh_q[idx_s + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                t = (float)((double)t + q8[k]);
+                sh_z[idx_s + k] = t;
+            }
+        }
+        for (; idx_s < S; ++idx_s) {
+            t = (float)((double)t + sh_q[idx_s]);
             sh_z[idx_s] = t;
         }
     }
@@ -219,7 +234,8 @@ __global__ void k_poly_lat_select(int* __restrict__ best, const float2* __restri
     // (2 x 273 dependent reads of global memory were 39 us of a 70 us update)
     extern __shared__ __attribute__((aligned(8))) float2 path_res[];
     const int n_paths = p.l_dst_steps * p.s_dst_steps;
-    for (int i = threadIdx.x; i < n_paths; i += blockDim.x) path_res[i] = path_res_g[i];
+    const int n_pad = (n_paths + 7) & ~7;            // padding entries: infinite cost, ignored by both passes
+    for (int i = threadIdx.x; i < n_pad; i += blockDim.x) path_res[i] = i < n_paths ? path_res_g[i] : make_float2(0.0f, INFINITY);
     __syncthreads();
     if (threadIdx.x != 0) return;
     int min_idx_l_dst = p.l_dst_steps / 2 + 1;
@@ -229,23 +245,36 @@ __global__ void k_poly_lat_select(int* __restrict__ best, const float2* __restri
     const int cl = min(min_idx_l_dst, p.l_dst_steps - 1);
     float max_collision_dist = path_res[cl * p.s_dst_steps + min_idx_s_dst].x;
     float min_cost = INFINITY;
-    for (int il = 0; il < p.l_dst_steps; ++il)
-        for (int is = 0; is < p.s_dst_steps; ++is) {
-            const float2 n = path_res[il * p.s_dst_steps + is];
-            if ((double)n.y >= 1e6) continue;
-            if (n.x > max_collision_dist + p.length_veh) max_collision_dist = n.x;
+    // (both passes walk the paths in the reference's order, l_dst outer, s_dst inner; eight entries
+    // are read from LDS before the order-dependent updates run over them, and the updates are
+    // selects, not branches: on one lane a taken branch costs more than the arithmetic it skips.
+    // Padding entries carry an infinite cost, which both passes ignore.)
+    for (int i0 = 0; i0 < n_paths; i0 += 8) {
+        float2 n8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) n8[k] = path_res[i0 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float2 n = n8[k];
+            const bool upd = !((double)n.y >= 1e6) && n.x > max_collision_dist + p.length_veh;
+            max_collision_dist = upd ? n.x : max_collision_dist;
         }
-    for (int il = 0; il < p.l_dst_steps; ++il)
-        for (int is = 0; is < p.s_dst_steps; ++is) {
-            const float2 n = path_res[il * p.s_dst_steps + is];
-            if (fabs((double)(n.x - max_collision_dist)) > 1.0) continue;
-            if (n.y < min_cost) {
-                min_cost = n.y;
-                max_collision_dist = n.x;
-                min_idx_l_dst = il;
-                min_idx_s_dst = is;
-            }
+    }
+    int min_i = -1;
+    for (int i0 = 0; i0 < n_paths; i0 += 8) {
+        float2 n8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) n8[k] = path_res[i0 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float2 n = n8[k];
+            const bool ok = !(fabs((double)(n.x - max_collision_dist)) > 1.0) && n.y < min_cost;
+            min_cost = ok ? n.y : min_cost;
+            max_collision_dist = ok ? n.x : max_collision_dist;
+            min_i = ok ? i0 + k : min_i;
         }
+    }
+    if (min_i >= 0) { min_idx_l_dst = min_i / p.s_dst_steps; min_idx_s_dst = min_i - min_idx_l_dst * p.s_dst_steps; }
     best[0] = min_idx_l_dst;
     best[1] = min_idx_s_dst;
 }
@@ -391,9 +420,9 @@ int tplhip_poly_lat_update(tplhip_poly_lat* h, const TplPolyLatTrajPoint* start,
             "copying station frames failed");
     const int threads = ((S + 63) / 64) * 64;
     hipLaunchKernelGGL(k_poly_lat_paths, dim3(p.l_dst_steps, p.s_dst_steps), dim3(std::min(threads, 1024)),
-                       sizeof(float) * 6 * (size_t)S, st,
+                       sizeof(float) * 6 * (size_t)((S + 1) & ~1) + sizeof(double) * (size_t)S, st,
                        h->d_nodes, h->d_path_res, h->d_frames, env->d_occ, *start, p, env->params);
-    hipLaunchKernelGGL(k_poly_lat_select, dim3(1), dim3(64), sizeof(float2) * (size_t)p.l_dst_steps * p.s_dst_steps, st,
+    hipLaunchKernelGGL(k_poly_lat_select, dim3(1), dim3(64), sizeof(float2) * (((size_t)p.l_dst_steps * p.s_dst_steps + 7) & ~(size_t)7), st,
                        h->d_best, h->d_path_res, p);
     HIP_TRY(hipGetLastError(), "evaluating local path costs failed");
     int best[2] = {0, 0};
