@@ -1,0 +1,36 @@
+#!/bin/bash
+# Same-box A/B of iLQR solver revisions (launch times differ by +-2 % between the boxes of the
+# pool, so two builds are only comparable inside ONE gpurun call).
+#   here:        bash tools/ab_ilqr.sh build <rev> [<rev> ...]     (rev: a git revision or HEAD/WORK for the tree)
+#   on the box:  gpurun -- 'bash tools/ab_ilqr.sh run [rounds]'
+# Builds land in tools/ab_tmp/ (git-ignored, travels with the snapshot).
+set -eu
+cd "$(dirname "$0")/.."
+INC="$PWD/tpl_amd/models/trajectory_tracking_mpc.inc"
+LIB=tpl_amd/models/libilqr_trajectory_tracking_mpc.so
+case "${1:-}" in
+build)
+    shift
+    mkdir -p tools/ab_tmp
+    for rev in "$@"; do
+        src=/tmp/ab_ilqr_$$.hip
+        if [ "$rev" = WORK ]; then cp tpl_amd/csrc/ilqr/ilqr_model.hip $src; else git show "$rev:tpl_amd/csrc/ilqr/ilqr_model.hip" > $src; fi
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -fno-fast-math \
+            -ffp-contract=off -DTPL_MODEL_INC="\"$INC\"" -I include -I tpl_amd/csrc/ilqr \
+            -o "tools/ab_tmp/$rev.so" -x hip $src 2> "tools/ab_tmp/$rev.log" || { echo "$rev: build failed"; exit 1; }
+        rm -f $src
+        echo "built tools/ab_tmp/$rev.so (headers and model text of the working tree)"
+    done ;;
+run)
+    cp $LIB tools/ab_tmp/.shipped.so
+    for r in $(seq 1 "${2:-2}"); do
+        for so in tools/ab_tmp/*.so; do
+            cp "$so" $LIB
+            printf "%-14s " "$(basename "$so" .so)"
+            python3 -m tpl_amd.optim.bench_ilqr --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; print(round(json.loads(sys.stdin.read())['value'], 1))"
+        done
+    done
+    cp tools/ab_tmp/.shipped.so $LIB ;;
+*)
+    echo "usage: $0 build <rev>... | run [rounds]"; exit 2 ;;
+esac
