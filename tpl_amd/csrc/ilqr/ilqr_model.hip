@@ -469,28 +469,27 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
             for (int m = 0; m < NU; ++m) { qu[m] = s->q[NX + m]; col[m] = (c == NX) ? 0.0 : s->Qux[m * NX + (c == NX ? 0 : c)]; }
             const double ud = r_u, umax = r_umax, umin = r_umin;
             __builtin_amdgcn_sched_barrier(0);
-            double inv[NU][NU];
+            double inv_d[NU];                                  // row d of the inverse: the lane's own
             if constexpr (NU == 1) {
-                inv[0][0] = (quu[0] > 0.0) ? -1.0 / (quu[0] + mu) : 0.0;
+                inv_d[0] = (quu[0] > 0.0) ? -1.0 / (quu[0] + mu) : 0.0;
             } else {
                 const double qa = quu[0] + mu, qb = quu[1], qd = quu[NU + 1] + mu;
                 const double det = qa * qd - qb * qb;
                 const double inv_det = -1.0f / det;
-                inv[0][0] = qd * inv_det;
-                inv[0][NU - 1] = -qb * inv_det;
-                inv[NU - 1][0] = inv[0][NU - 1];
-                inv[NU - 1][NU - 1] = qa * inv_det;
+                // inv = [[qd, -qb], [-qb, qa]] * inv_det: the row is picked before the products
+                inv_d[0] = (d == 0 ? qd : -qb) * inv_det;
+                inv_d[NU - 1] = (d == 0 ? -qb : qa) * inv_det;
             }
             double kd = 0.0;
 #pragma unroll
-            for (int m = 0; m < NU; ++m) kd = fma(inv[d][m], qu[m], kd);
+            for (int m = 0; m < NU; ++m) kd = fma(inv_d[m], qu[m], kd);
             double val;
             if (c == NX) {
                 val = kd;
             } else {
                 val = 0.0;
 #pragma unroll
-                for (int m = 0; m < NU; ++m) val = fma(inv[d][m], col[m], val);
+                for (int m = 0; m < NU; ++m) val = fma(inv_d[m], col[m], val);
             }
             const double cd = ud + kd;
             if (cd > umax) val = (c == NX) ? umax - ud : 0.0;
@@ -600,7 +599,8 @@ __device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs
 {
     // Candidate c runs on the QUAD of lanes 4c .. 4c+3: all four hold the same state and
     // control, the model's dynamics spread their independent look-ups and sin/cos evaluations
-    // over them (dynamics_quad), lane 4c alone records the candidate.
+    // over them (dynamics_quad); all four record the candidate (same values, same LDS slots --
+    // a lane mask around the ring writes costs more than the redundant writes).
     //
     // Where the results go matters more than it looks: loads and stores of a wavefront share ONE
     // counter (vmcnt) and complete in order, so a load that follows a store to global memory
@@ -640,7 +640,6 @@ __device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs
 #endif
     const bool active = lane < 4 * N_ALPHA;
     const int cand = lane >> 2;
-    const bool writer = active && (lane & 3) == 0;
     double a = 1.0;
     for (int i = 0; i < cand; ++i) a *= 10.0;
     a = 1.0 / a;                                       // 1.0 / pow(10, i)
@@ -688,14 +687,14 @@ __device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs
                         ud = ub[d] - kff[d] * a;
                     }
                     u[d] = ud;
-                    if (writer) s->ring_u[(cand * ROLL_RING + k) * NU + d] = ud;
+                    s->ring_u[(cand * ROLL_RING + k) * NU + d] = ud;      // (all four lanes: same value, same slot)
                 }
                 RSTAMP(0);
                 dynamics_quad(*P, x, u, t, dt, int_type, xn);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     x[i] = xn[i];
-                    if (writer) s->ring_x[(cand * ROLL_RING + k) * NX + i] = xn[i];
+                    s->ring_x[(cand * ROLL_RING + k) * NX + i] = xn[i];
                 }
                 RSTAMP(1);
             }
