@@ -343,7 +343,6 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
     }
     // ---- phase B: entry -> columns of F and W, the two addends, the one or two destinations
     int b_colF[E_B], b_colW[E_B];
-    bool b_two[E_B];
     LdsD b_dst0[E_B], b_dst1[E_B];
     GlbCD p_l0[E_B], p_l1[E_B];
     long long b_step[E_B];                             // doubles per stage of the array the addends come from
@@ -355,14 +354,13 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
         GlbCD l0 = LX, l1 = LX;
         long long step = NX;
         LdsD o0 = dump, o1 = dump;
-        bool two = false;
         if (e < N_XX) {
             int hi = 0;
             while ((hi + 1) * (hi + 2) / 2 <= e) ++hi;                 // row of the packed lower triangle
             const int lo = e - hi * (hi + 1) / 2;
             colF = hi; colW = lo; step = NX * NX;
             l0 = LXX + hi * NX + lo; l1 = LXX + lo * NX + hi;
-            o0 = &s->Qxx[hi * NX + lo]; o1 = &s->Qxx[lo * NX + hi]; two = hi != lo;
+            o0 = &s->Qxx[hi * NX + lo]; o1 = &s->Qxx[lo * NX + hi];
         } else if (e < N_XX + N_UX) {
             const int r = e - N_XX, d = r / NX, jj = r - d * NX;
             colF = NX + d; colW = jj; step = NU * NX;
@@ -375,14 +373,14 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
             const int lo = r - hi * (hi + 1) / 2;
             colF = NX + hi; colW = NX + lo; step = NU * NU;
             l0 = LUU + hi * NU + lo; l1 = LUU + lo * NU + hi;
-            o0 = &s->Quu[hi * NU + lo]; o1 = &s->Quu[lo * NU + hi]; two = hi != lo;
+            o0 = &s->Quu[hi * NU + lo]; o1 = &s->Quu[lo * NU + hi];
         } else if (e < N_B) {
             const int c = e - (N_XX + N_UX + N_UU);                   // q = l + F^T Vx: Vx is column NXU of W
             colF = c; colW = NXU;
             if (c < NX) { l0 = l1 = LX + c; step = NX; } else { l0 = l1 = LU + (c - NX); step = NU; }
             o0 = o1 = &s->q[c];
         }
-        b_colF[q] = colF; b_colW[q] = colW; b_two[q] = two; b_dst0[q] = o0; b_dst1[q] = o1;
+        b_colF[q] = colF; b_colW[q] = colW; b_dst0[q] = o0; b_dst1[q] = o1;
         b_step[q] = -step;
         p_l0[q] = l0 + (int64_t)(T - 1) * step; p_l1[q] = l1 + (int64_t)(T - 1) * step;
     }
@@ -392,6 +390,12 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
     GlbCD p_u = U_ + (int64_t)(T - 1) * NU + c_d, p_umax = UMAX + (int64_t)(T - 1) * NU + c_d,
           p_umin = UMIN + (int64_t)(T - 1) * NU + c_d;
     double r_u, r_umax, r_umin;
+    const int c_step = (c_c == NX) ? NU : NU * NX;                  // doubles per stage of the lane's gain array
+    const LdsD c_lds = (c_c == NX) ? &s->k[c_d] : &s->K[c_d * NX + (c_c == NX ? 0 : c_c)];
+    GlbD c_glb = (c_c == NX) ? KFF + (int64_t)(T - 1) * NU + c_d
+                             : KFB + (int64_t)(T - 1) * NU * NX + c_d * NX + (c_c == NX ? 0 : c_c);
+    LdsD c_mir = (c_c == NX) ? KL + (int64_t)(T - 1) * NU + c_d
+                             : KBL + (int64_t)(T - 1) * NU * NX + c_d * NX + (c_c == NX ? 0 : c_c);
     // ---- phase D: lanes [0, NX*NX) own Vxx entries, lanes [NX*NX, NX*NX+NX) own Vx entries
     const bool d_vxx = lane < NX * NX, d_vx = lane >= NX * NX && lane < NX * NX + NX;
     const int d_i = d_vxx ? lane / NX : (d_vx ? lane - NX * NX : 0);
@@ -433,11 +437,10 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
         // phase A: W = Vxx [fx fu]
 #pragma unroll
         for (int q = 0; q < E_A; ++q) {
-            const int e = lane + q * WAVE;
-            if (e < NX * NXU) {
-                const int i = e / NXU, j = e - i * NXU;
-                s->W[i * WS + j] = dot_lds<NX>(&s->Vxx[i * NX], 1, &s->F[j], NXU);
-            }
+            // (no lane mask: lanes past the last entry repeat it -- same value, same slot)
+            const int e = min(lane + q * WAVE, NX * NXU - 1);
+            const int i = e / NXU, j = e - i * NXU;
+            s->W[i * WS + j] = dot_lds<NX>(&s->Vxx[i * NX], 1, &s->F[j], NXU);
         }
         lds_sync();
         BSTAMP(1);
@@ -446,11 +449,11 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
         // are formed and then mirrored, like mul_symm (optim.c:159-180).
 #pragma unroll
         for (int q = 0; q < E_B; ++q) {
-            if (lane + q * WAVE < N_B) {
-                const double acc = dot_lds<NX>(&s->F[b_colF[q]], NXU, &s->W[b_colW[q]], WS);
-                *b_dst0[q] = r_l0[q] + acc;
-                if (b_two[q]) *b_dst1[q] = r_l1[q] + acc;
-            }
+            // (no lane masks: lanes without an entry work on column 0 and write the dump slot; an
+            // entry without a mirror image has dst1 == dst0 and l1 == l0: the same value twice)
+            const double acc = dot_lds<NX>(&s->F[b_colF[q]], NXU, &s->W[b_colW[q]], WS);
+            *b_dst0[q] = r_l0[q] + acc;
+            *b_dst1[q] = r_l1[q] + acc;
         }
         lds_sync();
         // F of stage t has been read for the last time: [fx | fu] of stage t-1 (in registers since
@@ -494,15 +497,12 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
             const double cd = ud + kd;
             if (cd > umax) val = (c == NX) ? umax - ud : 0.0;
             if (cd < umin) val = (c == NX) ? umin - ud : 0.0;
-            if (c == NX) {
-                s->k[d] = val;
-                KFF[(int64_t)t * NU + d] = val;
-                if (lt) KL[(int64_t)t * NU + d] = val;
-            } else {
-                s->K[d * NX + c] = val;
-                KFB[(int64_t)t * NU * NX + d * NX + c] = val;
-                if (lt) KBL[(int64_t)t * NU * NX + d * NX + c] = val;
-            }
+            // one store path for feed-forward and feedback entries: the lane walks its own pointers
+            *c_lds = val;
+            *c_glb = val;
+            if (lt) *c_mir = val;
+            c_glb -= c_step;
+            c_mir -= c_step;
         }
         // ALL requests of the stage in one place, after the gain stores: stage t-2 of F, stage t-1 of
         // the addends and limits.  Everything the loop waits for was then issued most of a stage ago.
