@@ -594,7 +594,7 @@ struct RolloutArgs {
     long long* stamp_acc;      // diagnostic builds only
 };
 
-template <bool LT>
+template <bool LT, bool SECOND_ORDER, int INT_TYPE>
 __device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs A, LdsAS* s)
 {
     // Candidate c runs on the QUAD of lanes 4c .. 4c+3: all four hold the same state and
@@ -628,8 +628,9 @@ __device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs
     load_params_uniform(Pl, A.P);
     const Params* P = &Pl;
     const double dt = uni_d(A.dt);
-    const int rows = uni_i(A.rows), opt_start = uni_i(A.opt_start), T = uni_i(A.T), int_type = uni_i(A.int_type);
-    const bool second_order = uni_i(A.second_order ? 1 : 0) != 0;
+    const int rows = uni_i(A.rows), opt_start = uni_i(A.opt_start), T = uni_i(A.T);
+    constexpr int int_type = INT_TYPE;                 // compile time: the integrator's branches fold
+    constexpr bool second_order = SECOND_ORDER;        // compile time: two uniform branches per stage less
 
 #ifdef TPL_ILQR_STAMP
     long long racc[3] = {0, 0, 0};
@@ -1022,8 +1023,15 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
 #else
                 ra.stamp_acc = nullptr;
 #endif
-                if (lt) line_search_rollouts<true>(ra, (LdsAS*)(unsigned)(unsigned long long)&s);
-                else line_search_rollouts<false>(ra, (LdsAS*)(unsigned)(unsigned long long)&s);
+                LdsAS* const sl = (LdsAS*)(unsigned)(unsigned long long)&s;
+                auto roll = [&](auto lt_c, auto so_c) {
+                    constexpr bool L = decltype(lt_c)::value, S2 = decltype(so_c)::value;
+                    if (int_type == EULER) line_search_rollouts<L, S2, EULER>(ra, sl);
+                    else if (int_type == HEUN) line_search_rollouts<L, S2, HEUN>(ra, sl);
+                    else line_search_rollouts<L, S2, RK4>(ra, sl);
+                };
+                if (lt) { if (second_order) roll(std::true_type{}, std::true_type{}); else roll(std::true_type{}, std::false_type{}); }
+                else { if (second_order) roll(std::false_type{}, std::true_type{}); else roll(std::false_type{}, std::false_type{}); }
             }
             __syncthreads();
             STAMP(11);
