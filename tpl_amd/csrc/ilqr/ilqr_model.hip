@@ -400,6 +400,8 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
     const bool d_vxx = lane < NX * NX, d_vx = lane >= NX * NX && lane < NX * NX + NX;
     const int d_i = d_vxx ? lane / NX : (d_vx ? lane - NX * NX : 0);
     const int d_j = d_vxx ? lane - (lane / NX) * NX : 0;
+    const LdsD d_dst = d_vxx ? &s->Vxx[lane] : (d_vx ? &s->W[d_i * WS + NXU] : dump);
+    const LdsCD d_tail = d_vxx ? (LdsCD)&s->Qxx[lane] : (LdsCD)&s->q[d_i];
 
     auto fetch_F = [&]() {
 #pragma unroll
@@ -511,8 +513,10 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
         lds_sync();
         BSTAMP(3);
 
-        // phase D: value function update, optim.c:965-984 (same order of additions)
-        if (d_vxx || d_vx) {
+        // phase D: value function update, optim.c:965-984 (same order of additions).  No lane
+        // masks: every lane runs both the Vxx and the Vx form (six FMAs more) on clamped indices
+        // and stores the one that is its own -- or to the dump slot.
+        {
             double Ki[NU], Kj[NU], Qi[NU], Qj[NU], quu[NU * NU], kk[NU], qu[NU];
 #pragma unroll
             for (int d = 0; d < NU; ++d) {
@@ -522,7 +526,7 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
             }
 #pragma unroll
             for (int m = 0; m < NU * NU; ++m) quu[m] = s->Quu[m];
-            const double tail = d_vxx ? s->Qxx[lane] : s->q[d_i];
+            const double tail = *d_tail;
             __builtin_amdgcn_sched_barrier(0);
             double kq[NU];                                   // (K^T Quu)[i][d]
 #pragma unroll
@@ -532,24 +536,20 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
                 for (int m = 0; m < NU; ++m) a = fma(Ki[m], quu[m * NU + d], a);
                 kq[d] = a;
             }
-            if (d_vxx) {
-                double mij = 0.0, mji = 0.0;
+            double mij = 0.0, mji = 0.0;
 #pragma unroll
-                for (int d = 0; d < NU; ++d) { mij = fma(Ki[d], Qj[d], mij); mji = fma(Kj[d], Qi[d], mji); }
-                double v = mji + mij;
+            for (int d = 0; d < NU; ++d) { mij = fma(Ki[d], Qj[d], mij); mji = fma(Kj[d], Qi[d], mji); }
+            double v1 = mji + mij;
 #pragma unroll
-                for (int d = 0; d < NU; ++d) v = fma(kq[d], Kj[d], v);
-                s->Vxx[lane] = v + tail;
-            } else {
-                double v = 0.0;
+            for (int d = 0; d < NU; ++d) v1 = fma(kq[d], Kj[d], v1);
+            double v2 = 0.0;
 #pragma unroll
-                for (int d = 0; d < NU; ++d) v = fma(kq[d], kk[d], v);
+            for (int d = 0; d < NU; ++d) v2 = fma(kq[d], kk[d], v2);
 #pragma unroll
-                for (int d = 0; d < NU; ++d) v = fma(Ki[d], qu[d], v);
+            for (int d = 0; d < NU; ++d) v2 = fma(Ki[d], qu[d], v2);
 #pragma unroll
-                for (int d = 0; d < NU; ++d) v = fma(Qi[d], kk[d], v);
-                s->W[d_i * WS + NXU] = v + tail;             // Vx, where phase B of the next stage reads it
-            }
+            for (int d = 0; d < NU; ++d) v2 = fma(Qi[d], kk[d], v2);
+            *d_dst = (d_vxx ? v1 : v2) + tail;               // Vxx entry, or Vx where phase B reads it
         }
         lds_sync();
         BSTAMP(4);
