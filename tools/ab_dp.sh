@@ -1,0 +1,38 @@
+#!/bin/bash
+# Same-box A/B of libtplhip.so revisions on the headline bench (see tools/ab_ilqr.sh for why).
+#   here:        bash tools/ab_dp.sh build <rev|WORK> [<rev> ...] [-- extra hipcc flags]
+#   on the box:  gpurun -- 'bash tools/ab_dp.sh run [rounds] [grid]'
+set -eu
+cd "$(dirname "$0")/.."
+SRCS="common.hip dp_lon.hip dp_env.hip poly_lat.hip lat_lon.hip"
+case "${1:-}" in
+build)
+    shift
+    revs=(); extra=()
+    while [ $# -gt 0 ]; do if [ "$1" = "--" ]; then shift; extra=("$@"); break; fi; revs+=("$1"); shift; done
+    mkdir -p tools/ab_tmp
+    for rev in "${revs[@]}"; do
+        d=$(mktemp -d)
+        for f in $SRCS dp_lon_math.h dp_env_internal.h; do
+            if [ "$rev" = WORK ]; then cp tpl_amd/csrc/$f $d/; else git show "$rev:tpl_amd/csrc/$f" > $d/$f; fi
+        done
+        (cd $d && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+            -fvisibility=hidden -I"$OLDPWD/include" "${extra[@]}" -shared -o "$OLDPWD/tools/ab_tmp/tplhip_$rev.so" $SRCS) \
+            2> "tools/ab_tmp/tplhip_$rev.log" || { echo "$rev: build failed"; exit 1; }
+        rm -rf $d
+        echo "built tools/ab_tmp/tplhip_$rev.so"
+    done ;;
+run)
+    cp tpl_amd/libtplhip.so tools/ab_tmp/.shipped_tplhip
+    for r in $(seq 1 "${2:-2}"); do
+        for so in tools/ab_tmp/tplhip_*.so; do
+            cp "$so" tpl_amd/libtplhip.so
+            printf "%-22s " "$(basename "$so" .so)"
+            python bench.py --steps 20 --warmup 3 --grid "${3:-target}" --no-cpu-baseline --no-secondary 2>/dev/null \
+              | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['roofline']['launch_us'],2), 'us/sweep', round(d['value']), 'sweeps/s')"
+        done
+    done
+    cp tools/ab_tmp/.shipped_tplhip tpl_amd/libtplhip.so ;;
+*)
+    echo "usage: $0 build <rev|WORK>... [-- flags] | run [rounds] [grid]"; exit 2 ;;
+esac
