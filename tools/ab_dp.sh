@@ -13,7 +13,7 @@ build)
     mkdir -p tools/ab_tmp
     for rev in "${revs[@]}"; do
         d=$(mktemp -d)
-        for f in $SRCS dp_lon_math.h dp_env_internal.h; do
+        for f in $SRCS dp_lon_math.h dp_env_internal.h tplhip_common.h; do
             if [ "$rev" = WORK ]; then cp tpl_amd/csrc/$f $d/; else git show "$rev:tpl_amd/csrc/$f" > $d/$f; fi
         done
         (cd $d && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
