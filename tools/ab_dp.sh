@@ -12,14 +12,15 @@ build)
     while [ $# -gt 0 ]; do if [ "$1" = "--" ]; then shift; extra=("$@"); break; fi; revs+=("$1"); shift; done
     mkdir -p tools/ab_tmp
     for rev in "${revs[@]}"; do
-        d=$(mktemp -d)
+        top=$(mktemp -d); d=$top/tpl_amd/csrc
+        mkdir -p $d; ln -s "$PWD/include" $top/include           # the sources include ../../include/tplhip.h
         for f in $SRCS dp_lon_math.h dp_env_internal.h tplhip_common.h; do
             if [ "$rev" = WORK ]; then cp tpl_amd/csrc/$f $d/; else git show "$rev:tpl_amd/csrc/$f" > $d/$f; fi
         done
         (cd $d && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
             -fvisibility=hidden -I"$OLDPWD/include" "${extra[@]}" -shared -o "$OLDPWD/tools/ab_tmp/tplhip_$rev.so" $SRCS) \
             2> "tools/ab_tmp/tplhip_$rev.log" || { echo "$rev: build failed"; exit 1; }
-        rm -rf $d
+        rm -rf $top
         echo "built tools/ab_tmp/tplhip_$rev.so"
     done ;;
 run)
