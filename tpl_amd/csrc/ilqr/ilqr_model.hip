@@ -237,8 +237,6 @@ struct Lds {
     double Qxx[NX * NX];
     double Qux[NU * NX];
     double Quu[NU * NU];
-    double K[NU * NX];
-    double k[NU];
     double red[N_ALPHA];
     double dump[2];            // where lanes without an entry park what they loaded
     // line-search rollouts: RING stages of every candidate's (x_{t+1}, u_t) collect here and go out
@@ -387,11 +385,10 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
     // ---- phase C lanes: (d, c), c == NX is the feed-forward entry
     const bool c_lane = lane < NU * (NX + 1);
     const int c_d = c_lane ? lane / (NX + 1) : 0, c_c = c_lane ? lane - c_d * (NX + 1) : 0;
-    GlbCD p_u = U_ + (int64_t)(T - 1) * NU + c_d, p_umax = UMAX + (int64_t)(T - 1) * NU + c_d,
-          p_umin = UMIN + (int64_t)(T - 1) * NU + c_d;
-    double r_u, r_umax, r_umin;
+    GlbCD p_u = U_ + (int64_t)(T - 1) * NU, p_umax = UMAX + (int64_t)(T - 1) * NU, p_umin = UMIN + (int64_t)(T - 1) * NU;
+    double r_u[NU], r_umax[NU], r_umin[NU];                         // every lane holds the limits of the stage
+    const int c_col = (c_c == NX) ? 0 : c_c;                        // column of K a store lane writes
     const int c_step = (c_c == NX) ? NU : NU * NX;                  // doubles per stage of the lane's gain array
-    const LdsD c_lds = (c_c == NX) ? &s->k[c_d] : &s->K[c_d * NX + (c_c == NX ? 0 : c_c)];
     GlbD c_glb = (c_c == NX) ? KFF + (int64_t)(T - 1) * NU + c_d
                              : KFB + (int64_t)(T - 1) * NU * NX + c_d * NX + (c_c == NX ? 0 : c_c);
     LdsD c_mir = (c_c == NX) ? KL + (int64_t)(T - 1) * NU + c_d
@@ -423,7 +420,8 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
         }
     };
     auto fetch_ulim = [&]() {
-        r_u = *p_u; r_umax = *p_umax; r_umin = *p_umin;
+#pragma unroll
+        for (int d = 0; d < NU; ++d) { r_u[d] = p_u[d]; r_umax[d] = p_umax[d]; r_umin[d] = p_umin[d]; }
         p_u -= NU; p_umax -= NU; p_umin -= NU;
     };
 
@@ -464,70 +462,68 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
         if (t > 0) park_F();
         BSTAMP(2);
 
-        // phase C: gains (solve_action optim.c:243-291) + control-box projection (:950-963)
-        if (c_lane) {
-            const int d = c_d, c = c_c;
-            double quu[NU * NU], qu[NU], col[NU];
+        // phases C + D in one: gains (solve_action optim.c:243-291), control-box projection
+        // (:950-963) and the value function update (:965-984, same order of additions).  The gains
+        // are a handful of operations on six shared numbers, so EVERY lane forms them -- on a SIMD
+        // that costs what sixteen lanes cost -- together with the columns of K it needs; the
+        // sixteen (d, c) lanes also store them.  One LDS exchange per stage less.
+        {
+            double quu[NU * NU], qu[NU], Qi[NU], Qj[NU], Qc[NU];
 #pragma unroll
             for (int m = 0; m < NU * NU; ++m) quu[m] = s->Quu[m];
 #pragma unroll
-            for (int m = 0; m < NU; ++m) { qu[m] = s->q[NX + m]; col[m] = (c == NX) ? 0.0 : s->Qux[m * NX + (c == NX ? 0 : c)]; }
-            const double ud = r_u, umax = r_umax, umin = r_umin;
+            for (int m = 0; m < NU; ++m) {
+                qu[m] = s->q[NX + m];
+                Qi[m] = s->Qux[m * NX + d_i]; Qj[m] = s->Qux[m * NX + d_j]; Qc[m] = s->Qux[m * NX + c_col];
+            }
+            const double tail = *d_tail;
             __builtin_amdgcn_sched_barrier(0);
-            double inv_d[NU];                                  // row d of the inverse: the lane's own
+            double inv[NU][NU];
             if constexpr (NU == 1) {
-                inv_d[0] = (quu[0] > 0.0) ? -1.0 / (quu[0] + mu) : 0.0;
+                inv[0][0] = (quu[0] > 0.0) ? -1.0 / (quu[0] + mu) : 0.0;
             } else {
                 const double qa = quu[0] + mu, qb = quu[1], qd = quu[NU + 1] + mu;
                 const double det = qa * qd - qb * qb;
                 const double inv_det = -1.0f / det;
-                // inv = [[qd, -qb], [-qb, qa]] * inv_det: the row is picked before the products
-                inv_d[0] = (d == 0 ? qd : -qb) * inv_det;
-                inv_d[NU - 1] = (d == 0 ? -qb : qa) * inv_det;
+                inv[0][0] = qd * inv_det;
+                inv[0][NU - 1] = -qb * inv_det;
+                inv[NU - 1][0] = inv[0][NU - 1];
+                inv[NU - 1][NU - 1] = qa * inv_det;
             }
-            double kd = 0.0;
-#pragma unroll
-            for (int m = 0; m < NU; ++m) kd = fma(inv_d[m], qu[m], kd);
-            double val;
-            if (c == NX) {
-                val = kd;
-            } else {
-                val = 0.0;
-#pragma unroll
-                for (int m = 0; m < NU; ++m) val = fma(inv_d[m], col[m], val);
-            }
-            const double cd = ud + kd;
-            if (cd > umax) val = (c == NX) ? umax - ud : 0.0;
-            if (cd < umin) val = (c == NX) ? umin - ud : 0.0;
-            // one store path for feed-forward and feedback entries: the lane walks its own pointers
-            *c_lds = val;
-            *c_glb = val;
-            if (lt) *c_mir = val;
-            c_glb -= c_step;
-            c_mir -= c_step;
-        }
-        // ALL requests of the stage in one place, after the gain stores: stage t-2 of F, stage t-1 of
-        // the addends and limits.  Everything the loop waits for was then issued most of a stage ago.
-        if (t > 1) fetch_F();
-        if (t > 0) { fetch_L(); fetch_ulim(); }
-        lds_sync();
-        BSTAMP(3);
-
-        // phase D: value function update, optim.c:965-984 (same order of additions).  No lane
-        // masks: every lane runs both the Vxx and the Vx form (six FMAs more) on clamped indices
-        // and stores the one that is its own -- or to the dump slot.
-        {
-            double Ki[NU], Kj[NU], Qi[NU], Qj[NU], quu[NU * NU], kk[NU], qu[NU];
+            double kk[NU], Ki[NU], Kj[NU], Kc[NU];
 #pragma unroll
             for (int d = 0; d < NU; ++d) {
-                Ki[d] = s->K[d * NX + d_i]; Kj[d] = s->K[d * NX + d_j];
-                Qi[d] = s->Qux[d * NX + d_i]; Qj[d] = s->Qux[d * NX + d_j];
-                kk[d] = s->k[d]; qu[d] = s->q[NX + d];
-            }
+                double kd = 0.0, ki = 0.0, kj = 0.0, kc = 0.0;
 #pragma unroll
-            for (int m = 0; m < NU * NU; ++m) quu[m] = s->Quu[m];
-            const double tail = *d_tail;
-            __builtin_amdgcn_sched_barrier(0);
+                for (int m = 0; m < NU; ++m) {
+                    kd = fma(inv[d][m], qu[m], kd);
+                    ki = fma(inv[d][m], Qi[m], ki);
+                    kj = fma(inv[d][m], Qj[m], kj);
+                    kc = fma(inv[d][m], Qc[m], kc);
+                }
+                const double cd = r_u[d] + kd;
+                const bool hi = cd > r_umax[d], lo = cd < r_umin[d];
+                kk[d] = lo ? r_umin[d] - r_u[d] : (hi ? r_umax[d] - r_u[d] : kd);
+                Ki[d] = (hi || lo) ? 0.0 : ki;
+                Kj[d] = (hi || lo) ? 0.0 : kj;
+                Kc[d] = (hi || lo) ? 0.0 : kc;
+            }
+            if (c_lane) {
+                // one store path for feed-forward and feedback entries: the lane walks its own pointers
+                double val = (c_c == NX) ? kk[0] : Kc[0];
+#pragma unroll
+                for (int d = 1; d < NU; ++d) val = (c_d == d) ? ((c_c == NX) ? kk[d] : Kc[d]) : val;
+                *c_glb = val;
+                if (lt) *c_mir = val;
+                c_glb -= c_step;
+                c_mir -= c_step;
+            }
+            // ALL requests of the stage in one place, after the gain stores: stage t-2 of F, stage
+            // t-1 of the addends and limits.  Everything the loop waits for was then issued most of
+            // a stage ago.
+            if (t > 1) fetch_F();
+            if (t > 0) { fetch_L(); fetch_ulim(); }
+
             double kq[NU];                                   // (K^T Quu)[i][d]
 #pragma unroll
             for (int d = 0; d < NU; ++d) {
