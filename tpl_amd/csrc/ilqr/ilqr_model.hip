@@ -654,37 +654,40 @@ __device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs
         if (active) {
             for (int k = 0; k < n; ++k) {
                 const int t = t0 + k;
-                // feedback law: all operands first, then the arithmetic (one memory round trip)
-                double kff[NU], ub[NU], hi[NU], lo[NU], kfb[NU * NX], xr[NX];
+                // feedback law: lane q of the quad forms control q % NU (its own row of K, read through
+                // a lane-dependent address), the quad then exchanges the controls with DPP moves --
+                // half the arithmetic and loads of every lane forming both.  All operands first, then
+                // the arithmetic (one memory round trip); the order of the additions is the reference's.
+                {
+                    const int my_d = (NU > 1 && NU <= 4) ? (lane & 3) % NU : 0;
+                    const double kff = KFFr[(int64_t)t * NU + my_d];
+                    const double ub = Ur[(int64_t)t * NU + my_d];
+                    const double hi = UMAXr[(int64_t)t * NU + my_d];
+                    const double lo = UMINr[(int64_t)t * NU + my_d];
+                    double kfb[NX], xr[NX];
+                    if (second_order) {
 #pragma unroll
-                for (int d = 0; d < NU; ++d) {
-                    kff[d] = KFFr[(int64_t)t * NU + d];
-                    ub[d] = Ur[(int64_t)t * NU + d];
-                    hi[d] = UMAXr[(int64_t)t * NU + d];
-                    lo[d] = UMINr[(int64_t)t * NU + d];
-                }
-                if (second_order) {
+                        for (int i = 0; i < NX; ++i) kfb[i] = KFBr[(int64_t)t * NU * NX + my_d * NX + i];
 #pragma unroll
-                    for (int e = 0; e < NU * NX; ++e) kfb[e] = KFBr[(int64_t)t * NU * NX + e];
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) xr[i] = Xr[(int64_t)t * NX + i];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int d = 0; d < NU; ++d) {
+                        for (int i = 0; i < NX; ++i) xr[i] = Xr[(int64_t)t * NX + i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                     double ud;
                     if (second_order) {
-                        ud = kff[d] * a;
-                        ud = ud + ub[d];
+                        ud = kff * a;
+                        ud = ud + ub;
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) ud += kfb[d * NX + i] * (x[i] - xr[i]);
-                        ud = hi[d] < ud ? hi[d] : ud;
-                        ud = lo[d] > ud ? lo[d] : ud;
+                        for (int i = 0; i < NX; ++i) ud += kfb[i] * (x[i] - xr[i]);
+                        ud = hi < ud ? hi : ud;
+                        ud = lo > ud ? lo : ud;
                     } else {
-                        ud = ub[d] - kff[d] * a;
+                        ud = ub - kff * a;
                     }
-                    u[d] = ud;
-                    s->ring_u[(cand * ROLL_RING + k) * NU + d] = ud;      // (all four lanes: same value, same slot)
+#pragma unroll
+                    for (int d = 0; d < NU; ++d) {
+                        u[d] = (NU > 1 && NU <= 4) ? tpl_quad_bcast(ud, d) : ud;
+                        s->ring_u[(cand * ROLL_RING + k) * NU + d] = u[d];    // (all four lanes: same value, same slot)
+                    }
                 }
                 RSTAMP(0);
                 dynamics_quad(*P, x, u, t, dt, int_type, xn);
