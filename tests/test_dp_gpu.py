@@ -289,9 +289,12 @@ def test_unbounded_inputs_take_the_two_pass_kernel_and_still_match():
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
     occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
     init = [sc.initial_state(0.0, 8.0, 0.0)]
-    for w_progress, bounded in ((0.1, 1), (2.5e6, 0)):
+    # (the third case is bounded but starts its arclength below zero: the two-station kernels read
+    # the path's second tap as "the next slot", which needs s >= 0, so it takes the fallback too)
+    for w_progress, s_min, bounded in ((0.1, 0.0, 1), (2.5e6, 0.0, 0), (0.1, -7.5, 0)):
         p = sc.lon_params(S, V, A, T)
         p.w_progress = w_progress
+        p.s_min = s_min
         path = sc.straight_path(p.path_steps, p.path_step_size)
         env = tpl_amd.DynProgEnvironment()
         env.reinit_buffers(ep)

@@ -227,7 +227,7 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
     // (USE_BUF: the host checked that one stage table is addressable with 32-bit byte offsets)
     const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<Node*>(next), 0, USE_BUF ? (int)((size_t)nrows * S * sizeof(Node)) : 0, 0x00020000);
-    for (int i = tid; i < p.path_steps; i += blockDim.x) pv[i] = path[i * 7 + 5];
+    for (int i = tid; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];   // last sample twice
 
     const float s_range = p.s_max - p.s_min;
     const float s_scale = (float)(S - 1);
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))
     float* pv = reinterpret_cast<float*>(smem + (size_t)2 * (2 * half + 1) * rows_per_block * sizeof(float4));
     const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<Node*>(next), 0, USE_BUF ? (int)((size_t)nrows * S * sizeof(Node)) : 0, 0x00020000);
-    for (int i = tid; i < p.path_steps; i += blockDim.x) pv[i] = path[i * 7 + 5];
+    for (int i = tid; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];   // last sample twice
 
     const float s_range = p.s_max - p.s_min;
     const float s_scale = (float)(S - 1);
@@ -534,14 +534,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))
                 const f2 e = f2_fma(-q0, (f2){p.path_step_size, p.path_step_size}, tn_s);
                 alpha = f2_fma(e, (f2){rcp_path_step, rcp_path_step}, q0);
             } else alpha = (f2){(float)((double)tn_s.x * rcp_path_step_d), (float)((double)tn_s.y * rcp_path_step_d)};
+            // alpha >= 0 here (tn_s >= s >= s_min >= 0, the host checks it), so i0 = min(floor, n-1)
+            // and the second tap is ALWAYS the next slot: ceil = floor + 1 unless alpha is integral,
+            // where the weight of the second tap is 0 and any finite value there gives the same sum
+            // (its product is a zero, and the sign of a zero v_max is invisible downstream); past the
+            // end both taps are the last sample, which the path buffer carries twice.
             const f2 afl = f2_floor(alpha);
-            const f2 aup = {ceilf(alpha.x), ceilf(alpha.y)};
-            const f2 f0 = {__builtin_amdgcn_fmed3f(afl.x, 0.0f, path_top), __builtin_amdgcn_fmed3f(afl.y, 0.0f, path_top)};
-            const f2 f1 = {__builtin_amdgcn_fmed3f(aup.x, 0.0f, path_top), __builtin_amdgcn_fmed3f(aup.y, 0.0f, path_top)};
+            const f2 f0 = {fminf(afl.x, path_top), fminf(afl.y, path_top)};
             const f2 pa = alpha - f0;
             const f2 pia = 1.0f - pa;
-            const f2 pv0 = {pv[(int)f0.x], pv[(int)f0.y]};
-            const f2 pv1 = {pv[(int)f1.x], pv[(int)f1.y]};
+            const int t0 = (int)f0.x, t1 = (int)f0.y;
+            const f2 pv0 = {pv[t0], pv[t1]};
+            const f2 pv1 = {pv[t0 + 1], pv[t1 + 1]};
             const f2 vmn = pv0 * pia + pv1 * pa;
 
             // (cost, constr) per station as a pair
@@ -662,7 +666,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8)
     float* pv = reinterpret_cast<float*>(smem + (size_t)4 * row_slots * sizeof(float4));
     const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<Node*>(next), 0, USE_BUF ? (int)((size_t)nrows * S * sizeof(Node)) : 0, 0x00020000);
-    for (int i = is; i < p.path_steps; i += blockDim.x) pv[i] = path[i * 7 + 5];
+    for (int i = is; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];     // last sample twice
 
     const float s_range = p.s_max - p.s_min;
     const float s_scale = (float)(S - 1);
@@ -739,14 +743,18 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8)
                 const f2 e = f2_fma(-q0, (f2){p.path_step_size, p.path_step_size}, tn_s);
                 alpha = f2_fma(e, (f2){rcp_path_step, rcp_path_step}, q0);
             } else alpha = (f2){(float)((double)tn_s.x * rcp_path_step_d), (float)((double)tn_s.y * rcp_path_step_d)};
+            // alpha >= 0 here (tn_s >= s >= s_min >= 0, the host checks it), so i0 = min(floor, n-1)
+            // and the second tap is ALWAYS the next slot: ceil = floor + 1 unless alpha is integral,
+            // where the weight of the second tap is 0 and any finite value there gives the same sum
+            // (its product is a zero, and the sign of a zero v_max is invisible downstream); past the
+            // end both taps are the last sample, which the path buffer carries twice.
             const f2 afl = f2_floor(alpha);
-            const f2 aup = {ceilf(alpha.x), ceilf(alpha.y)};
-            const f2 f0 = {__builtin_amdgcn_fmed3f(afl.x, 0.0f, path_top), __builtin_amdgcn_fmed3f(afl.y, 0.0f, path_top)};
-            const f2 f1 = {__builtin_amdgcn_fmed3f(aup.x, 0.0f, path_top), __builtin_amdgcn_fmed3f(aup.y, 0.0f, path_top)};
+            const f2 f0 = {fminf(afl.x, path_top), fminf(afl.y, path_top)};
             const f2 pa = alpha - f0;
             const f2 pia = 1.0f - pa;
-            const f2 pv0 = {pv[(int)f0.x], pv[(int)f0.y]};
-            const f2 pv1 = {pv[(int)f1.x], pv[(int)f1.y]};
+            const int t0 = (int)f0.x, t1 = (int)f0.y;
+            const f2 pv0 = {pv[t0], pv[t1]};
+            const f2 pv1 = {pv[t0 + 1], pv[t1 + 1]};
             const f2 vmn = pv0 * pia + pv1 * pa;
 
             f2 r0 = (f2){sc.x, sg.x} + cg0;
@@ -1569,7 +1577,7 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         if (const char* ov = std::getenv("TPLHIP_TILE_A")) h->tile_a = std::max(1, std::atoi(ov));
     }
     const size_t threads = (size_t)h->s_pad * h->rows_per_block;
-    const size_t path_lds = sizeof(float) * (size_t)p.path_steps;
+    const size_t path_lds = sizeof(float) * ((size_t)p.path_steps + 1);       // + the duplicate of the last sample
     const size_t lds_max = 64 * 1024;                       // keep >= 2 workgroups per CU
     // Actions blended into LDS per barrier.  With the L2-friendly traversal the sweep is bound by
     // VALU issue and by how well memory latency hides under it: 1 action per pass keeps the LDS
@@ -1604,6 +1612,8 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
                               p.path_step_size, p.width_veh, p.length_veh};
         bool ok = p.t_steps <= 100000;
         for (float v : vals) ok = ok && std::isfinite(v) && std::fabs(v) < 1e6f;
+        // the two-station kernels also read the path's second tap as "the next slot": needs arclength >= 0
+        ok = ok && p.s_min >= 0.0f && p.path_step_size > 0.0f;
         h->params_bounded = ok;
     }
     // Large grids (one action per barrier) run two stations per lane, see k_backward2.
