@@ -88,7 +88,7 @@ class Config:
 
 
 # bump when the emitted text for an unchanged problem changes (invalidates cached models)
-EMITTER_REVISION = "emit-5: look-ups that share an abscissa are batched in every routine"
+EMITTER_REVISION = "emit-6: deterministic order of batch members"
 
 
 def _as_matrix(e):
@@ -332,6 +332,64 @@ def _fuse_sincos(subs, reduced):
     return new_subs, fused
 
 
+def _emit_exprs(flat, printer, lines, dest):
+    """CSE + sincos fusion + look-up batching + scheduling of a list of expressions; appends the
+    statements to ``lines``; ``dest(i)`` is the lvalue that receives expression i."""
+    subs, reduced = sp.cse(flat, symbols=sp.numbered_symbols("w"))
+    subs, fused = _fuse_sincos(subs, reduced)
+    subs, reduced, batches = _batch_lookups(subs, reduced)
+    # schedule: the original order, every look-up batch as soon as its abscissa exists
+    items = [("assign", sym, e) for sym, e in subs] + [("batch", b) for b in batches]
+
+    def deps(it):
+        if it[0] == "assign":
+            return _temp_deps(it[2])
+        d = set()
+        for k in it[1]["key"]:
+            d |= _temp_deps(sp.sympify(k))
+        return d
+
+    def provides(it):
+        if it[0] == "assign":
+            return set(fused[it[1]]) | {it[1]} if it[1] in fused else {it[1]}
+        return {sy for sy, _, _ in it[1]["members"]}
+
+    defined, pending = set(), list(items)
+    pending.sort(key=lambda it: 0 if it[0] == "batch" else 1)
+    while pending:
+        for it in pending:
+            if deps(it) <= defined:
+                break
+        else:
+            raise AssertionError("look-up batching: cyclic dependency")
+        pending.remove(it)
+        defined |= provides(it)
+        if it[0] == "batch":
+            b = it[1]
+            x0, dx, xx = (printer.doprint(k) for k in b["key"])
+            nmem = len(b["members"])
+            arrs = ", ".join(f"&{printer.doprint(a)}" for _, a, _ in b["members"])
+            mask = sum((1 << i) for i, (_, _, ang) in enumerate(b["members"]) if ang)
+            names = [str(sy) for sy, _, _ in b["members"]]
+            lines.append(f"    double {', '.join(names)};")
+            lines.append("    {")
+            lines.append(f"        const DynArr* const qa[{nmem}] = {{{arrs}}};")
+            lines.append(f"        double qo[{nmem}];")
+            lines.append(f"        tpl_lerp_batch<{nmem}>({x0}, {dx}, {xx}, qa, {mask}u, qo);")
+            for i, nm in enumerate(names):
+                lines.append(f"        {nm} = qo[{i}];")
+            lines.append("    }")
+            continue
+        _, sym, e = it
+        if sym in fused:                                             # (sin, cos) of one argument
+            s_sym, c_sym = fused[sym]
+            lines.append(f"    double {s_sym}, {c_sym}; tpl_sincos({printer.doprint(e)}, &{s_sym}, &{c_sym});")
+        else:
+            lines.append(f"    const double {sym} = {printer.doprint(e)};")
+    for i, e in enumerate(reduced):
+        lines.append(f"    {dest(i)} = {printer.doprint(e)};")
+
+
 def _emit_routine(name, m, cfg, printer):
     lines = [f"TPL_HD inline void {name}({_signature(name)}) {{"]
     # keep every argument "used" so -Wall stays quiet for trivial routines
@@ -343,59 +401,7 @@ def _emit_routine(name, m, cfg, printer):
     n = m.shape[0] * m.shape[1]
     if n:
         flat = [_vectorise(sp.sympify(e), cfg) for e in m]               # row-major
-        subs, reduced = sp.cse(flat, symbols=sp.numbered_symbols("w"))
-        subs, fused = _fuse_sincos(subs, reduced)
-        subs, reduced, batches = _batch_lookups(subs, reduced)
-        # schedule: the original order, every look-up batch as soon as its abscissa exists
-        items = [("assign", sym, e) for sym, e in subs] + [("batch", b) for b in batches]
-
-        def deps(it):
-            if it[0] == "assign":
-                return _temp_deps(it[2])
-            d = set()
-            for k in it[1]["key"]:
-                d |= _temp_deps(sp.sympify(k))
-            return d
-
-        def provides(it):
-            if it[0] == "assign":
-                return set(fused[it[1]]) | {it[1]} if it[1] in fused else {it[1]}
-            return {sy for sy, _, _ in it[1]["members"]}
-
-        defined, pending = set(), list(items)
-        pending.sort(key=lambda it: 0 if it[0] == "batch" else 1)
-        while pending:
-            for it in pending:
-                if deps(it) <= defined:
-                    break
-            else:
-                raise AssertionError("look-up batching: cyclic dependency")
-            pending.remove(it)
-            defined |= provides(it)
-            if it[0] == "batch":
-                b = it[1]
-                x0, dx, xx = (printer.doprint(k) for k in b["key"])
-                nmem = len(b["members"])
-                arrs = ", ".join(f"&{printer.doprint(a)}" for _, a, _ in b["members"])
-                mask = sum((1 << i) for i, (_, _, ang) in enumerate(b["members"]) if ang)
-                names = [str(sy) for sy, _, _ in b["members"]]
-                lines.append(f"    double {', '.join(names)};")
-                lines.append("    {")
-                lines.append(f"        const DynArr* const qa[{nmem}] = {{{arrs}}};")
-                lines.append(f"        double qo[{nmem}];")
-                lines.append(f"        tpl_lerp_batch<{nmem}>({x0}, {dx}, {xx}, qa, {mask}u, qo);")
-                for i, nm in enumerate(names):
-                    lines.append(f"        {nm} = qo[{i}];")
-                lines.append("    }")
-                continue
-            _, sym, e = it
-            if sym in fused:                                             # (sin, cos) of one argument
-                s_sym, c_sym = fused[sym]
-                lines.append(f"    double {s_sym}, {c_sym}; tpl_sincos({printer.doprint(e)}, &{s_sym}, &{c_sym});")
-            else:
-                lines.append(f"    const double {sym} = {printer.doprint(e)};")
-        for i, e in enumerate(reduced):
-            lines.append(f"    out[{i}*os] = {printer.doprint(e)};")
+        _emit_exprs(flat, printer, lines, lambda i: f"out[{i}*os]")
     lines.append("}")
     return "\n".join(lines)
 
@@ -407,7 +413,7 @@ def _batch_lookups(subs, reduced, chunk=8):
     builtin's own.  Returns (subs, reduced, batches)."""
     groups = {}
     for e in [e for _, e in subs] + list(reduced):
-        for f in e.atoms(sp.Function):
+        for f in sorted(e.atoms(sp.Function), key=str):     # (a set: fix the order)
             if type(f).__name__ in ("lerp", "lerp_angle") and len(f.args) == 4:
                 groups.setdefault(tuple(f.args[:3]), {}).setdefault(f, None)
     batches, repl, n = [], {}, 0
@@ -462,7 +468,7 @@ def _emit_routine_quad(name, m, cfg, printer):
     # ---- table look-ups that share (x0, dx, x)
     groups = {}
     for e in exprs():
-        for f in e.atoms(sp.Function):
+        for f in sorted(e.atoms(sp.Function), key=str):     # (a set: fix the order)
             if type(f).__name__ in ("lerp", "lerp_angle") and len(f.args) == 4:
                 groups.setdefault(tuple(f.args[:3]), {}).setdefault(f, None)
     lerp_batches, repl = [], {}
