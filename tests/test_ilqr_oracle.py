@@ -103,3 +103,22 @@ def test_lookups_at_one_abscissa_are_batched_in_every_routine():
     for m in re.finditer(r"const DynArr\* const qa\[(\d+)\] = \{([^}]*)\};\s*double qo\[(\d+)\];\s*tpl_lerp_batch<(\d+)>", plain):
         n = int(m.group(1))
         assert n >= 2 and n == int(m.group(3)) == int(m.group(4)) and m.group(2).count("&P.") == n
+
+
+def test_generated_text_does_not_depend_on_the_hash_seed():
+    """Batches are collected from sympy sets; their member order must not follow the interpreter's
+    hash seed (the committed models/<problem>.inc has to be reproducible)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import hashlib, sys; sys.path.insert(0, %r); "
+            "from tpl_amd.optim import genopt, optimizers as o; "
+            "print(hashlib.sha1(genopt.emit_model(o.config_trajectory_tracking_mpc(), 'trajectory_tracking_mpc').encode()).hexdigest())" % root)
+    digests = set()
+    for seed in ("1", "2", "77"):
+        env = dict(os.environ, PYTHONHASHSEED=seed)
+        digests.add(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True, text=True).stdout.strip())
+    assert len(digests) == 1, digests
+    with open(os.path.join(root, "tpl_amd", "models", "trajectory_tracking_mpc.inc")) as fd:
+        import hashlib
+        assert hashlib.sha1(fd.read().encode()).hexdigest() in digests       # and it is the text that is built
