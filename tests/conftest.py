@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A tree that was never built (fresh clone): build once, like `__graft_entry__.build()` does --
+    # the HIP libraries (hipcc cross-compiles without a GPU), the generated solver models and the
+    # CPU oracles the tests check them against.  Nothing is built when the artefacts are there.
+    need = [os.path.join(ROOT, "tpl_amd", "libtplhip.so"),
+            os.path.join(ROOT, "tpl_amd", "models", "libilqr_trajectory_tracking_mpc.so"),
+            os.path.join(ROOT, "oracle", "libdp_lon_oracle.so"),
+            os.path.join(ROOT, "oracle", "libilqr_oracle_trajectory_tracking_mpc.so")]
+    if not all(os.path.exists(f) for f in need):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def _have_gpu():
