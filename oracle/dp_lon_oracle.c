@@ -41,7 +41,29 @@
  *      reference binds that stage's own array as both surface and texture
  *      (lon_planner.cu:350-352), which is only well defined when the terminal
  *      test of :93 fires; this rule defines the remaining case.
+ *
+ * SENSITIVITY BUILDS.  R1-R3 freeze choices the reference BINARY may make
+ * differently (nvcc contracts a*b+c into FMAs in device code by default; the
+ * rounding of the texture unit's 1.8 fixed-point weight and its internal blend
+ * arithmetic are not documented).  The default build is the contract above; the
+ * switches below build variants of this file that tests/dp_sensitivity_study.py
+ * runs against it to MEASURE how far those choices move tables and plans
+ * ("HP-1 parity envelope").  They never build the checker the HIP
+ * path is compared with.
+ *   -DDPO_WEIGHT_QUANT=0   un-quantised filter weights
+ *   -DDPO_WEIGHT_QUANT=2   weights truncated to 8 fractional bits (floor) instead of rint
+ *   -DDPO_LERP_FORM=1      blend = p*(1-w) + q*w, every operation rounded (no fma)
+ *   -DDPO_LERP_FORM=2      blend = p + w*(q-p)
+ *   -ffp-contract=fast -mfma (instead of -ffp-contract=off): the compiler fuses
+ *                          multiply-adds of lonDynamics / interpPath / the cost sums
+ *                          like nvcc's default -fmad=true does
  */
+#ifndef DPO_WEIGHT_QUANT
+#define DPO_WEIGHT_QUANT 1
+#endif
+#ifndef DPO_LERP_FORM
+#define DPO_LERP_FORM 0
+#endif
 #include "../include/tplhip.h"
 
 #include <math.h>
@@ -123,7 +145,13 @@ static inline Tap make_tap(float x_plus_half, int n)
     float xb = x_plus_half - 0.5f;
     float fl = floorf(xb);
     float alpha = xb - fl;
+#if DPO_WEIGHT_QUANT == 1
     t.w = rintf(alpha * 256.0f) / 256.0f;
+#elif DPO_WEIGHT_QUANT == 2
+    t.w = floorf(alpha * 256.0f) / 256.0f;
+#else
+    t.w = alpha;
+#endif
     /* (int) of a float far outside int range is undefined; clamp in float first */
     float lo = fl < -1.0f ? -1.0f : (fl > (float)n ? (float)n : fl);
     int i = (int)lo;
@@ -132,7 +160,19 @@ static inline Tap make_tap(float x_plus_half, int n)
     return t;
 }
 
-static inline float lerp1(float p, float q, float w) { return fmaf(q, w, p * (1.0f - w)); }
+static inline float lerp1(float p, float q, float w)
+{
+#if DPO_LERP_FORM == 0
+    return fmaf(q, w, p * (1.0f - w));
+#elif DPO_LERP_FORM == 1
+    volatile float a = p * (1.0f - w), b = q * w;       /* volatile: keeps the two products rounded in every build */
+    return a + b;
+#else
+    volatile float d = q - p;
+    volatile float e = w * d;
+    return p + e;
+#endif
+}
 
 /* ------------------------------------------------------------ dist map -- */
 

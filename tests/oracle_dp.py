@@ -23,7 +23,20 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libdp_lon_oracle.so"])
-        l = C.CDLL(LIB)
+        _lib = _declare(C.CDLL(LIB))
+    return _lib
+
+
+def use(path=None):
+    """Route this module's helpers through another build of the same restatement: a sensitivity
+    variant (oracle/_sens/, see the header of dp_lon_oracle.c) or the -O3 -march=native build the
+    cpu_baseline leg times (oracle/_native/).  ``None`` returns to the default checker."""
+    global _lib
+    _lib = None if path is None else _declare(C.CDLL(path))
+
+
+def _declare(l):
+    if True:
         l.dpo_interp_dist_map_path.restype = C.c_float
         l.dpo_interp_dist_map_path.argtypes = [C.POINTER(TplDpEnvParams), _fp, C.c_float, C.c_float]
         l.dpo_table_floats.restype = C.c_size_t
@@ -45,8 +58,7 @@ def lib():
         l.dpo_traj_state.argtypes = [C.POINTER(TplLonState), C.c_int, C.c_float, C.POINTER(TplLonState)]
         l.dpo_update_step_sizes.argtypes = [C.POINTER(TplDpLonParams)]
         l.dpo_env_update_step_sizes.argtypes = [C.POINTER(TplDpEnvParams)]
-        _lib = l
-    return _lib
+    return l
 
 
 def fptr(a):

@@ -21,9 +21,11 @@ from .dyn_prog import (  # noqa: E402
     lon_dynamics,
 )
 
+from .dyn_prog import RefLine  # noqa: E402
 from .lat_lon import (  # noqa: E402
     DynProgLatLonPlanner,
     DynProgLatLonPlannerParams,
+    LatDistances,
     LatLonCartState,
     LatLonCartTraj,
     LatLonState,
@@ -42,5 +44,5 @@ __all__ = [
     "LatLonTraj",
     "PolyLatPlanner", "PolyLatPlannerParams", "PolyLatTraj", "PolyLatTrajPoint", "PolyQuintic",
     "DynProgEnvParams", "DynProgEnvironment", "DynProgLonPlanner", "DynProgLonPlannerParams",
-    "LonState", "LonTraj", "cuda_get_device_count", "lon_dynamics",
+    "LonState", "LonTraj", "RefLine", "LatDistances", "cuda_get_device_count", "lon_dynamics",
 ]

@@ -1033,6 +1033,8 @@ struct tplhip_dp_lon {
     double* d_pre_prog = nullptr;       // [s]
     TplLonState* d_inits = nullptr;
     TplLonState* d_trajs = nullptr;
+    TplLonState* d_reeval = nullptr;     // [t_steps], reeval's own buffer (keeps the rollouts of the last plan intact)
+    int cap_reeval = 0;
     int cap_rollouts = 0;
     int n_rollouts = 0;
     bool tables_valid = false;
@@ -1066,6 +1068,7 @@ struct tplhip_dp_lon {
     // two staged downloads in flight (pinned host buffers + completion events)
     TplLonState* h_stage[2] = {nullptr, nullptr};
     size_t stage_cap[2] = {0, 0};
+    size_t stage_n[2] = {0, 0};          // states staged in each slot (rollouts x t_steps at staging time)
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     bool stage_busy[2] = {false, false};
 
@@ -1108,6 +1111,14 @@ void free_planner_buffers(tplhip_dp_lon* h)
     hipFree(h->d_pre_sdist); h->d_pre_sdist = nullptr;
     hipFree(h->d_pre_prog);  h->d_pre_prog = nullptr;
     h->tables_valid = false;
+}
+
+bool path_is_bounded(const float* path, int path_steps)
+{
+    bool ok = true;
+    const size_t n_path = 7 * (size_t)path_steps;
+    for (size_t i = 0; i < n_path; ++i) ok = ok && std::isfinite(path[i]) && std::fabs(path[i]) < 1e6f;
+    return ok;
 }
 
 int ensure_rollouts(tplhip_dp_lon* h, int n)
@@ -1504,6 +1515,7 @@ int tplhip_dp_lon_destroy(tplhip_dp_lon* h)
     free_planner_buffers(h);
     hipFree(h->d_inits);
     hipFree(h->d_trajs);
+    hipFree(h->d_reeval);
     hipFree(h->d_flag);
     for (int i = 0; i < 2; ++i) {
         if (h->h_stage[i]) hipHostFree(h->h_stage[i]);
@@ -1546,6 +1558,8 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         free_planner_buffers(h);
         hipFree(h->d_inits); hipFree(h->d_trajs);
         h->d_inits = nullptr; h->d_trajs = nullptr; h->cap_rollouts = 0;
+        h->n_rollouts = 0; h->path_bounded = false;          // nothing uploaded any more
+        h->stage_busy[0] = h->stage_busy[1] = false;
         h->table_cells = S * p.v_steps * p.a_steps;
         HIP_TRY(hipMalloc(&h->d_tables, sizeof(Node) * h->table_cells * (size_t)p.t_steps), "value table allocation failed");
         HIP_TRY(hipMemsetAsync(h->d_tables, 0, sizeof(Node) * h->table_cells * (size_t)p.t_steps, h->stream), "value table clear failed");
@@ -1705,12 +1719,7 @@ int tplhip_dp_lon_upload(tplhip_dp_lon* h, int n, const TplLonState* inits, cons
     int rc = ensure_rollouts(h, n);
     if (rc) return rc;
     h->n_rollouts = n;
-    {
-        bool ok = true;
-        const size_t n_path = 7 * (size_t)h->params.path_steps;
-        for (size_t i = 0; i < n_path; ++i) ok = ok && std::isfinite(path[i]) && std::fabs(path[i]) < 1e6f;
-        h->path_bounded = ok;
-    }
+    h->path_bounded = path_is_bounded(path, h->params.path_steps);
     // lon_planner.cu:334-338 and :365-368
     HIP_TRY(hipMemcpyAsync(h->d_path, path, sizeof(float) * 7 * (size_t)h->params.path_steps,
                            hipMemcpyHostToDevice, h->stream), "copying path failed");
@@ -1765,6 +1774,7 @@ int tplhip_dp_lon_stage_download(tplhip_dp_lon* h, int slot)
             "copying trajectory failed");
     HIP_TRY(hipEventRecord(h->stage_ev[slot], h->stream), "event record failed");
     h->stage_busy[slot] = true;
+    h->stage_n[slot] = n;
     return TPLHIP_OK;
 }
 
@@ -1773,8 +1783,15 @@ int tplhip_dp_lon_collect_download(tplhip_dp_lon* h, int slot, TplLonState* out_
     if (!h || !out_trajs || slot < 0 || slot > 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
     if (!h->stage_busy[slot]) return tplhip_fail(TPLHIP_ESTATE, "no download staged in slot %d", slot);
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    // the caller sizes out_trajs from the CURRENT rollout count and horizon: a slot staged under
+    // other sizes (upload / reinit in between) cannot be handed out
+    if (h->stage_n[slot] != (size_t)h->n_rollouts * h->params.t_steps) {
+        h->stage_busy[slot] = false;
+        return tplhip_fail(TPLHIP_ESTATE, "slot %d was staged with %zu states, the planner now holds %zu",
+                           slot, h->stage_n[slot], (size_t)h->n_rollouts * h->params.t_steps);
+    }
     HIP_TRY(hipEventSynchronize(h->stage_ev[slot]), "lon planner forward pass failed");
-    std::memcpy(out_trajs, h->h_stage[slot], sizeof(TplLonState) * (size_t)h->n_rollouts * h->params.t_steps);
+    std::memcpy(out_trajs, h->h_stage[slot], sizeof(TplLonState) * h->stage_n[slot]);
     h->stage_busy[slot] = false;
     return TPLHIP_OK;
 }
@@ -1808,20 +1825,24 @@ int tplhip_dp_lon_reeval(tplhip_dp_lon* h, const TplLonState* traj, int len, con
     if (len != p.t_steps)                                     // lon_planner.cu:423-425
         return tplhip_fail(TPLHIP_ESTATE, "trajectory size does not match t_steps");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
-    rc = ensure_rollouts(h, 1);
-    if (rc) return rc;
-    if (h->n_rollouts < 1) h->n_rollouts = 1;
+    if (h->cap_reeval < len) {
+        hipFree(h->d_reeval); h->d_reeval = nullptr; h->cap_reeval = 0;
+        HIP_TRY(hipMalloc(&h->d_reeval, sizeof(TplLonState) * (size_t)len), "trajectory allocation failed");
+        h->cap_reeval = len;
+    }
+    // d_path now holds THIS path: a later plan_resident() plans on it, so the kernel choice follows it
+    h->path_bounded = path_is_bounded(path, p.path_steps);
     HIP_TRY(hipMemcpyAsync(h->d_path, path, sizeof(float) * 7 * (size_t)p.path_steps,
                            hipMemcpyHostToDevice, h->stream), "copying path failed");
-    HIP_TRY(hipMemcpyAsync(h->d_trajs, traj, sizeof(TplLonState) * (size_t)len,
+    HIP_TRY(hipMemcpyAsync(h->d_reeval, traj, sizeof(TplLonState) * (size_t)len,
                            hipMemcpyHostToDevice, h->stream), "copying trajectory to gpu failed");
     hipLaunchKernelGGL(k_dist_map_path, dim3(env->params.t_steps), dim3(256),
                        sizeof(float) * (size_t)env->params.s_steps, h->stream,
                        env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params);
     hipLaunchKernelGGL(k_reeval, dim3((len + 63) / 64), dim3(64), 0, h->stream,
-                       h->d_trajs, h->d_tables, h->table_cells, h->d_path, env->d_dist, p, env->params);
+                       h->d_reeval, h->d_tables, h->table_cells, h->d_path, env->d_dist, p, env->params);
     HIP_TRY(hipGetLastError(), "reeval launch failed");
-    HIP_TRY(hipMemcpyAsync(out_traj, h->d_trajs, sizeof(TplLonState) * (size_t)len,
+    HIP_TRY(hipMemcpyAsync(out_traj, h->d_reeval, sizeof(TplLonState) * (size_t)len,
                            hipMemcpyDeviceToHost, h->stream), "copying reevaluted trajectory to cpu failed");
     HIP_TRY(hipStreamSynchronize(h->stream), "reeval pass failed");
     return TPLHIP_OK;

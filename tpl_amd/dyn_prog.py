@@ -9,6 +9,7 @@ in ``libtplhip.so`` on the GPU; nothing here computes on the CPU.
 """
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -169,11 +170,13 @@ class RefLine:
     """tplcpp.RefLine as far as Python callers read it (bindings_dp_common.cu:21-36):
     the centred points, the step size and the offsets that were subtracted."""
 
-    def __init__(self, points=None, step_size=0.0, x_offset=0.0, y_offset=0.0):
+    def __init__(self, points=None, step_size=0.0, x_offset=0.0, y_offset=0.0, owner=None):
         self.points = np.zeros((0, 9)) if points is None else points
         self.step_size = step_size
         self.x_offset = x_offset
         self.y_offset = y_offset
+        # the environment that holds this line on the device (weak: the line must not keep it alive)
+        self._owner = weakref.ref(owner) if owner is not None else None
 
 
 class DynProgEnvironment:
@@ -238,7 +241,7 @@ class DynProgEnvironment:
         pts = ref_line.copy()
         pts[:, 0] -= xo.value
         pts[:, 1] -= yo.value
-        self.ref_line = RefLine(pts, np.float32(step_size), xo.value, yo.value)
+        self.ref_line = RefLine(pts, np.float32(step_size), xo.value, yo.value, owner=self)
 
     def insert_geometry(self, geom, stationary):
         geom = np.ascontiguousarray(geom, dtype=np.float64)

@@ -170,6 +170,15 @@ class LatLonCartTraj(_Traj):
         return self._one(fn, t) if np.ndim(t) == 0 else self._many(fn, t)
 
 
+class LatDistances:
+    """tplcpp.LatDistances (bindings_dp_lat_lon.cu:14-17, lat_lon_planner.cuh:123-126)."""
+    __slots__ = ("d_left", "d_right")
+
+    def __init__(self, d_left=0.0, d_right=0.0):
+        self.d_left = d_left
+        self.d_right = d_right
+
+
 def lat_lon_dynamics(x0, dds, dl, dt):
     out = TplLatLonState()
     _capi.load().tplhip_lat_lon_dynamics(C.byref(x0._c), float(dds), float(dl), float(dt), C.byref(out))
@@ -183,6 +192,7 @@ class DynProgLatLonPlanner:
         self._h = C.c_void_p()
         self._lib = _capi.load()
         check(self._lib.tplhip_lat_lon_create(int(device), C.byref(self._h)))
+        self._device = int(device)
         self.params = DynProgLatLonPlannerParams()
         self.traj_dp = LatLonTraj()
         self.traj_smooth = LatLonTraj()
@@ -223,10 +233,37 @@ class DynProgLatLonPlanner:
         out = (TplLatLonState * cap)()
         n = C.c_int()
         check(self._lib.tplhip_lat_lon_update_traj_smooth(self._h, dp, len(dp), C.byref(x0), out, cap, C.byref(n)))
+        # latDists: the reference resizes it to the length of the PREVIOUS smoothed trajectory and
+        # launches getLatDistances over it, a kernel whose body is empty (lat_lon_planner.cu:414-425,
+        # 729-747) -- the entries are the default-constructed zeros
+        self.lat_dists = [LatDistances() for _ in range(len(self.traj_smooth.states))]
         self.traj_smooth._take(out, n.value)
 
-    def frenet_to_cartesian(self, traj, env):
-        """(the reference takes the RefLine; here the environment that holds it)"""
+    def _ref_line_env(self, ref_line):
+        """The environment whose reference line the C-ABI converts on.  Accepts what the reference's
+        callers pass -- ``cpp_env.ref_line`` (dp_lat_lon_planner.py:148) -- the environment itself, or
+        a free-standing RefLine (a private environment is set up for it once and cached)."""
+        from .dyn_prog import DynProgEnvironment, RefLine
+        if isinstance(ref_line, DynProgEnvironment):
+            return ref_line
+        if not isinstance(ref_line, RefLine):
+            raise TypeError(f"expected a RefLine or a DynProgEnvironment, got {type(ref_line).__name__}")
+        owner = ref_line._owner() if getattr(ref_line, "_owner", None) is not None else None
+        if owner is not None and owner.ref_line is ref_line:
+            return owner
+        cached = getattr(self, "_own_env", None)
+        if cached is None or cached[0] is not ref_line:
+            env = DynProgEnvironment(self._device)
+            pts = np.array(ref_line.points, dtype=np.float64, copy=True)
+            pts[:, 0] += ref_line.x_offset
+            pts[:, 1] += ref_line.y_offset
+            env.set_ref_line(pts, ref_line.step_size)
+            cached = self._own_env = (ref_line, env)
+        return cached[1]
+
+    def frenet_to_cartesian(self, traj, ref_line):
+        """bindings_dp_lat_lon.cu:297-303: ``ref_line`` is the RefLine (or the environment holding it)."""
+        env = self._ref_line_env(ref_line)
         arr = traj._as_array()
         out = (TplLatLonCartState * len(arr))()
         check(self._lib.tplhip_lat_lon_frenet_to_cartesian(env._h, arr, len(arr), out))
@@ -234,9 +271,9 @@ class DynProgLatLonPlanner:
         res._take(out)
         return res
 
-    def update_traj_cart(self, env):
-        self.traj_dp_cart = self.frenet_to_cartesian(self.traj_dp, env)
-        self.traj_smooth_cart = self.frenet_to_cartesian(self.traj_smooth, env)
+    def update_traj_cart(self, ref_line):
+        self.traj_dp_cart = self.frenet_to_cartesian(self.traj_dp, ref_line)
+        self.traj_smooth_cart = self.frenet_to_cartesian(self.traj_smooth, ref_line)
 
     def reeval_traj(self, traj, env):
         arr = traj._as_array()

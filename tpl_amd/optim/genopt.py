@@ -78,13 +78,36 @@ class Config:
         return {}
 
     def fingerprint(self):
-        """sha1 over the problem text and the emitter revision (the reference hashes
-        the same parts plus its templates, genopt.py:493-505)."""
-        parts = [EMITTER_REVISION, self.states, self.actions, self.param_symbols, self.dynamics,
+        """sha1 over the problem text, the emitter revision and the solver template
+        (ilqr_model.hip, its headers, the C-ABI header) -- the reference hashes its
+        templates too (genopt.py:493-505).  A library whose exported fingerprint
+        matches was therefore compiled from exactly this problem AND this template."""
+        parts = [EMITTER_REVISION, template_hash(), self.states, self.actions, self.param_symbols, self.dynamics,
                  _as_matrix(self.costs), _as_matrix(self.end_costs), self.constraints]
         h = hashlib.sha1()
         h.update("|".join(str(p) for p in parts).encode("utf8"))
         return h.hexdigest()
+
+
+_TEMPLATE_HASH = None
+
+
+def template_files():
+    """Sources every libilqr_<problem>.so is compiled from besides its model header."""
+    files = [os.path.join(CSRC_ILQR, f) for f in sorted(os.listdir(CSRC_ILQR)) if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(_PKG, "..", "include", "tplhip_ilqr.h"))
+    return files
+
+
+def template_hash():
+    global _TEMPLATE_HASH
+    if _TEMPLATE_HASH is None:
+        h = hashlib.sha1()
+        for f in template_files():
+            with open(f, "rb") as fd:
+                h.update(os.path.basename(f).encode("utf8") + b"\0" + fd.read() + b"\0")
+        _TEMPLATE_HASH = h.hexdigest()
+    return _TEMPLATE_HASH
 
 
 # bump when the emitted text for an unchanged problem changes (invalidates cached models)
