@@ -4,7 +4,7 @@
 #   on the box:  gpurun -- 'bash tools/ab_dp.sh run [rounds] [grid]'
 set -eu
 cd "$(dirname "$0")/.."
-SRCS="common.hip dp_lon.hip dp_env.hip poly_lat.hip lat_lon.hip"
+SRCS="common.hip dp_lon.hip dp_sweep.hip dp_env.hip poly_lat.hip lat_lon.hip"
 case "${1:-}" in
 build)
     shift
@@ -14,7 +14,7 @@ build)
     for rev in "${revs[@]}"; do
         top=$(mktemp -d); d=$top/tpl_amd/csrc
         mkdir -p $d; ln -s "$PWD/include" $top/include           # the sources include ../../include/tplhip.h
-        for f in $SRCS dp_lon_math.h dp_env_internal.h tplhip_common.h; do
+        for f in $SRCS dp_lon_math.h dp_env_internal.h dp_lon_internal.h tplhip_common.h; do
             if [ "$rev" = WORK ]; then cp tpl_amd/csrc/$f $d/; else git show "$rev:tpl_amd/csrc/$f" > $d/$f; fi
         done
         (cd $d && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \

@@ -211,6 +211,9 @@ int main(int argc, char** argv)
     RUN(p_add_f64); RUN(p_mul_f64); RUN(p_fma_f64); RUN(p_max_f64); RUN(p_cvt_f64_f32); RUN(p_cvt_f32_f64);
     RUN(p_cmp_lt_u64); RUN(p_cmp_lt_f32); RUN(p_cndmask); RUN(p_floor_f32); RUN(p_rndne_f32); RUN(p_cvt_i32_f32);
     RUN(p_mul_f32); RUN(p_fmac_f32); RUN(p_cndmask_e64); RUN(p_cndmask_wr); RUN(p_cmp_cnd); RUN(p_cmp_cnd3); RUN(p_cmp64_cnd); RUN(p_bfi_b32); RUN(p_min_u32); RUN(p_sub_u32); RUN(p_ashrrev); RUN(p_med3_f32); RUN(p_fract_f32); RUN(p_add_f32_sgpr); RUN(p_max_f32_sgpr); RUN(p_pk_fma_sgpr); RUN(p_mix_fma_max); RUN(p_cmp_lt_u32); RUN(p_cmp_class);
+    RUN(p_mix_6fma_2max); RUN(p_mix_2fma_6max); RUN(p_mix_fma_f64); RUN(p_mix_fma_cvt); RUN(p_mix_fma_pk); RUN(p_mix_fma_cmpcnd); RUN(p_mix_3fma_1max);
+    run("p_mix_fma_lds", p_mix_fma_lds, 8192);
+    RUN(p_mul_f32_sgpr); RUN(p_fma_f32_sgpr); RUN(p_add_f32_const); RUN(p_add_f32_lit); RUN(p_mov_b32_sgpr); RUN(p_sub_f32); RUN(p_add_u32); RUN(p_lshlrev); RUN(p_and_b32); RUN(p_fma_f32_neg); RUN(p_add_f32_e64abs); RUN(p_cvt_f32_i32); RUN(p_max3_f32);
     RUN(p_mov_b32); RUN(p_mov_b64); RUN(p_pk_mov_b32); RUN(p_lshl_add); RUN(p_s_nop);
     run("p_ds_read_b128", p_ds_read_b128, 8192); run("p_ds_read_b96", p_ds_read_b96, 8192);
     run("p_ds_read2_b32", p_ds_read2_b32, 8192); run("p_ds_read_b64", p_ds_read_b64, 8192);

@@ -20,14 +20,16 @@ __global__ void __launch_bounds__(256) k_load(const float* __restrict__ src, flo
     // L1: every wave re-reads its own 8 x (64 x BYTES) window.  L2: the window start walks through span_bytes.
     unsigned base = L2WALK ? ((blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 * 64 * BYTES) % (span_bytes - 16 * 64 * BYTES) : 0u;   // L1: one 8-load window for all
     float acc = 0.0f;
+    unsigned lo = lane_off;
     for (int it = 0; it < ITERS; ++it) {
+        asm volatile("" : "+v"(lo));      // keeps the (L1-resident) loads inside the loop
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const unsigned so = base + j * 64 * BYTES;
-            if constexpr (BYTES == 4)  { acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, so, 0)); }
-            if constexpr (BYTES == 8)  { v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, so, 0)); acc += v.x; }
-            if constexpr (BYTES == 12) { v3f v = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(r, lane_off, so, 0)); acc += v.x; }
-            if constexpr (BYTES == 16) { v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, so, 0)); acc += v.x; }
+            if constexpr (BYTES == 4)  { acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lo, so, 0)); }
+            if constexpr (BYTES == 8)  { v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, lo, so, 0)); acc += v.x; }
+            if constexpr (BYTES == 12) { v3f v = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(r, lo, so, 0)); acc += v.x; }
+            if constexpr (BYTES == 16) { v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, lo, so, 0)); acc += v.x; }
         }
         if (L2WALK) base = (base + 1031u * 64 * BYTES) % (span_bytes - 16 * 64 * BYTES);
     }

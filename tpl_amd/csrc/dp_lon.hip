@@ -31,34 +31,13 @@
 #include <string>
 #include <vector>
 
-#include "dp_lon_math.h"
+#include "dp_lon_internal.h"
 #include "tplhip_common.h"
 #include "dp_env_internal.h"
 
 using namespace tplhip;
 
 namespace {
-
-constexpr int N_BWD = 9;    // evalNode<9>,  lon_planner.cu:201
-constexpr int N_FWD = 21;   // evalNode<21>, lon_planner.cu:220
-
-// Per-(row, action) constants of the backward sweep.  Everything here depends
-// only on (v, a, jerk_k, dt) -- never on the station or the stage.
-struct alignas(16) ActDesc {
-    double a_term;      // ((0.5*a)*dt)*dt             lon_planner.cu:244
-    double j_term;      // ((((1/6)*j)*dt)*dt)*dt      lon_planner.cu:244
-    float vdt;          // v*dt
-    float j;            // jerk of this action
-    float wj_cost;      // stateActionCost             lon_planner.cu:57-64
-    float a_viol;       // (a_min - a') or (a' - a_max) if violated, else 0 (at most one is non-zero)
-    float wa, wv;       // quantised blend weights along a and v (rule R2)
-    float iwa, iwv;     // 1 - wa, 1 - wv (exact: the weights are multiples of 1/256)
-    float tn_v;         // successor velocity          lon_planner.cu:245
-    int r00, r10, r01, r11;   // next-stage rows (a*V + v) of the corners (a0,v0) (a1,v0) (a0,v1) (a1,v1)
-    int pad;
-    double tn_v_d;      // (double)tn_v, for the double-precision speed-limit term (:114-118)
-};
-static_assert(sizeof(ActDesc) == 80, "ActDesc must be 80 bytes");
 
 // ------------------------------------------------------------------------
 // descriptor table: one thread per (row, action)
@@ -801,21 +780,42 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8)
 //    closer than 2^-49 (relative) to a rounding boundary of binary32 unless it is exactly
 //    representable, and it is never exactly a midpoint;
 //  * x*r + one fma residual correction in float is exact for many divisors (all powers of
-//    two) but not all (it fails for 200).
+//    two) but not all (it fails for 200);
+//  * fma(x, r_hi, x*r_lo) with r_hi + r_lo = 1/c to ~49 bits: the sum is within ~2^-47 of x/c before
+//    its one rounding, two plain fp32 instructions -- exact where no quotient of the range comes that
+//    close to a rounding boundary, which only the brute force can tell.
 // The proof is re-established by brute force anyway; a mode is only used if its flag stays 0.
 // ------------------------------------------------------------------------
-__global__ void k_verify_div(unsigned int* __restrict__ flags, float c, float r, double rd, unsigned int max_bits)
+// scale > 0 (the station-range divisor): the two k_backward3v forms are compared on what the sweep derives from
+// the quotient -- the filter coordinate ((q * scale + 0.5) - 0.5, lon_planner.cu:35 + arr_tex_surf.cuh:142-149) --
+// not on the quotient itself: for dividends below ~1e-34 their x * r_lo term underflows and the quotient's last bit
+// can differ, but every quotient below 2^-26 / scale yields the coordinate 0 either way.  scale == 0: raw quotients.
+__global__ void k_verify_div(unsigned int* __restrict__ flags, float c, float r, double rd, float r_lo, float scale,
+                             unsigned int max_bits)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    bool bad_f = false, bad_d = false;
+    bool bad_f = false, bad_d = false, bad_2 = false, bad_p = false;
     for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= max_bits; b += stride) {
         const float x = __uint_as_float((unsigned int)b);
-        const unsigned int q = __float_as_uint(x / c);
+        const float qf = x / c;
+        const unsigned int q = __float_as_uint(qf);
         bad_f |= (q != __float_as_uint(fast_div(x, c, r)));
         bad_d |= (q != __float_as_uint((float)((double)x * rd)));
+        const float q2 = fmaf(x, r, x * r_lo);                       // two-float reciprocal r + r_lo (k_backward3v)
+        const float qp = x * r;                                      // exact for a power-of-two divisor
+        if (scale > 0.0f) {
+            const unsigned int want = __float_as_uint((qf * scale + 0.5f) - 0.5f);
+            bad_2 |= (want != __float_as_uint((q2 * scale + 0.5f) - 0.5f));
+            bad_p |= (want != __float_as_uint((qp * scale + 0.5f) - 0.5f));
+        } else {
+            bad_2 |= (q != __float_as_uint(q2));
+            bad_p |= (q != __float_as_uint(qp));
+        }
     }
     if (bad_f) atomicOr(&flags[0], 1u);      // float reciprocal + residual correction is not exact here
     if (bad_d) atomicOr(&flags[1], 1u);      // double-product form is not exact here
+    if (bad_2) atomicOr(&flags[2], 1u);      // two-float reciprocal is not exact here
+    if (bad_p) atomicOr(&flags[3], 1u);      // a bare multiplication by the reciprocal is not exact here
 }
 
 // ------------------------------------------------------------------------
@@ -1060,10 +1060,15 @@ struct tplhip_dp_lon {
     int div_mode = 0;
     float rcp_path_step = 0.0f;
     double rcp_path_step_d = 0.0, rcp_s_range_d = 0.0;
+    float rcp_path_lo = 0.0f, rcp_range_hi = 0.0f, rcp_range_lo = 0.0f;   // two-float reciprocals (k_backward3v)
+    int path_div3 = 0, range_div3 = 0;        // k_backward3v's forms: 4 = one multiplication, 3 = two-float, 0 = not proven
+    int verified_path3 = 0, verified_range3 = 0;
+    bool weights_nonneg = false;              // every cost weight >= +0: (constraint, cost) compare as one integer key
     float verified_c[2] = {0.0f, 0.0f};      // divisors and range the proof covers
     float verified_xmax = 0.0f;
+    int verified_s_steps = 0;                 // the coordinate check of the range divisor depends on s_steps - 1
     int verified_mode = 0;
-    unsigned int* d_flag = nullptr;           // [4]: path {float, double}, range {float, double}
+    unsigned int* d_flag = nullptr;           // [8]: path {float, double, two-float, product}, range {the same}
 
     // two staged downloads in flight (pinned host buffers + completion events)
     TplLonState* h_stage[2] = {nullptr, nullptr};
@@ -1212,6 +1217,35 @@ void launch_backward2v(tplhip_dp_lon* h, int idx_t, int nx)
     else go(k_backward2v<DIVMODE, false>);
 }
 
+// k_backward3v (dp_sweep.hip): the two-rows-per-lane geometry with the plain-fp32 instruction stream.  Needs buffer
+// loads, both divisions proven in one of its cheap forms and non-negative weights (integer-key argmin).
+bool use_v3(const tplhip_dp_lon* h)
+{
+    static const bool off = std::getenv("TPLHIP_NO_V3") != nullptr;
+    return !off && h->use_buf && h->weights_nonneg && h->path_div3 >= 3 && h->range_div3 >= 3
+           && backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps) <= 64 * 1024;
+}
+
+void launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
+{
+    const size_t S = (size_t)h->params.s_steps;
+    SweepArgs a;
+    a.next = h->d_tables + (size_t)nx * h->table_cells;
+    a.out = h->d_tables + (size_t)idx_t * h->table_cells;
+    a.acts = h->d_acts;
+    a.path = h->d_path;
+    a.pre_vmax = h->d_pre_vmax + (size_t)idx_t * S;
+    a.pre_sdist = h->d_pre_sdist + (size_t)idx_t * S;
+    a.pre_prog = h->d_pre_prog;
+    a.p = h->params;
+    a.s_pad = h->vp_s_pad;
+    a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->rcp_path_lo;
+    a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
+    a.tile_v = h->tile_v; a.tile_a = h->tile_a;
+    a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
+    launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->vp_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
+}
+
 // the terminal stage of the two-station geometry: k_backward<true> with one station per lane
 void launch_terminal(tplhip_dp_lon* h, int idx_t)
 {
@@ -1254,7 +1288,8 @@ void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
     if (h->cells == 2) {
         if (terminal) launch_terminal(h, i);                         // rule R4
         else if (h->params_bounded && h->path_bounded && h->env_bounded) {
-            if (h->vpair) launch_backward2v<DIVMODE>(h, i, nx);
+            if (h->vpair && use_v3(h)) launch_backward3(h, i, nx);
+            else if (h->vpair) launch_backward2v<DIVMODE>(h, i, nx);
             else launch_backward2<DIVMODE>(h, i, nx);
         }
         else launch_exact<DIVMODE>(h, i, nx);
@@ -1629,6 +1664,10 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         // the two-station kernels also read the path's second tap as "the next slot": needs arclength >= 0
         ok = ok && p.s_min >= 0.0f && p.path_step_size > 0.0f;
         h->params_bounded = ok;
+        // k_backward3v orders (constraint, cost) by their bit patterns: needs both to be sums of terms >= +0
+        bool nn = true;
+        for (float w : {p.w_progress, p.w_a, p.w_j, p.w_snap, p.w_safety_dist}) nn = nn && !std::signbit(w);
+        h->weights_nonneg = nn;
     }
     // Large grids (one action per barrier) run two stations per lane, see k_backward2.
     h->cells = 1;
@@ -1679,33 +1718,43 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         h->rcp_path_step = 1.0f / p.path_step_size;
         h->rcp_path_step_d = 1.0 / (double)p.path_step_size;
         h->rcp_s_range_d = 1.0 / (double)s_range;
-        const bool cached = h->verified_c[0] == p.path_step_size && h->verified_c[1] == s_range && h->verified_xmax >= xmax;
+        h->rcp_path_lo = (float)(h->rcp_path_step_d - (double)h->rcp_path_step);
+        h->rcp_range_hi = 1.0f / s_range;
+        h->rcp_range_lo = (float)(h->rcp_s_range_d - (double)h->rcp_range_hi);
+        const bool cached = h->verified_c[0] == p.path_step_size && h->verified_c[1] == s_range && h->verified_xmax >= xmax
+                            && h->verified_s_steps == p.s_steps;
         if (!cached) {
             h->verified_mode = 0;
+            h->verified_path3 = h->verified_range3 = 0;
             if (std::isfinite(xmax) && xmax > 0.0f && s_range > 0.0f && p.path_step_size > 0.0f
                 && !std::getenv("TPLHIP_NO_FASTDIV")) {
-                if (!h->d_flag) HIP_TRY(hipMalloc(&h->d_flag, 4 * sizeof(unsigned int)), "flag allocation failed");
-                HIP_TRY(hipMemsetAsync(h->d_flag, 0, 4 * sizeof(unsigned int), h->stream), "flag clear failed");
+                if (!h->d_flag) HIP_TRY(hipMalloc(&h->d_flag, 8 * sizeof(unsigned int)), "flag allocation failed");
+                HIP_TRY(hipMemsetAsync(h->d_flag, 0, 8 * sizeof(unsigned int), h->stream), "flag clear failed");
                 unsigned int max_bits;
                 std::memcpy(&max_bits, &xmax, sizeof max_bits);
                 hipLaunchKernelGGL(k_verify_div, dim3(4096), dim3(256), 0, h->stream, h->d_flag,
-                                   p.path_step_size, h->rcp_path_step, h->rcp_path_step_d, max_bits);
-                hipLaunchKernelGGL(k_verify_div, dim3(4096), dim3(256), 0, h->stream, h->d_flag + 2,
-                                   s_range, 1.0f / s_range, h->rcp_s_range_d, max_bits);
+                                   p.path_step_size, h->rcp_path_step, h->rcp_path_step_d, h->rcp_path_lo, 0.0f, max_bits);
+                hipLaunchKernelGGL(k_verify_div, dim3(4096), dim3(256), 0, h->stream, h->d_flag + 4,
+                                   s_range, h->rcp_range_hi, h->rcp_s_range_d, h->rcp_range_lo, (float)(p.s_steps - 1), max_bits);
                 HIP_TRY(hipGetLastError(), "division check launch failed");
-                unsigned int flags[4] = {1, 1, 1, 1};
+                unsigned int flags[8] = {1, 1, 1, 1, 1, 1, 1, 1};
                 HIP_TRY(hipMemcpyAsync(flags, h->d_flag, sizeof flags, hipMemcpyDeviceToHost, h->stream), "flag copy failed");
                 HIP_TRY(hipStreamSynchronize(h->stream), "division check failed");
-                if (flags[3] == 0) {                     // station range through the double product
+                if (flags[5] == 0) {                     // station range through the double product
                     if (flags[0] == 0) h->verified_mode = 1;          // path step through float reciprocal
                     else if (flags[1] == 0) h->verified_mode = 2;     // path step through the double product
                 }
+                h->verified_path3 = flags[3] == 0 ? 4 : (flags[2] == 0 ? 3 : 0);
+                h->verified_range3 = flags[7] == 0 ? 4 : (flags[6] == 0 ? 3 : 0);
             }
             h->verified_c[0] = p.path_step_size;
             h->verified_c[1] = s_range;
             h->verified_xmax = xmax;
+            h->verified_s_steps = p.s_steps;
         }
         h->div_mode = h->verified_mode;
+        h->path_div3 = h->verified_path3;
+        h->range_div3 = h->verified_range3;
     }
     HIP_TRY(hipStreamSynchronize(h->stream), "building the action table failed");
     return TPLHIP_OK;
@@ -1871,10 +1920,12 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
     std::snprintf(buf, (size_t)n,
                   "{\"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
                   "\"div_mode\": %d, \"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"cells\": %d, "
-                  "\"bounded_inputs\": %d, \"vpair\": %d}",
+                  "\"bounded_inputs\": %d, \"vpair\": %d, \"v3\": %d, \"path_div3\": %d, \"range_div3\": %d}",
                   h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
                   h->div_mode, (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->cells,
-                  (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0, (h->cells == 2 && h->vpair) ? 1 : 0);
+                  (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0, (h->cells == 2 && h->vpair) ? 1 : 0,
+                  (h->cells == 2 && h->vpair && use_v3(h) && h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
+                  h->path_div3, h->range_div3);
     return TPLHIP_OK;
 }
 

@@ -1,0 +1,58 @@
+// dp_lon_internal.h -- types shared by the translation units of the DP (s,v,a) planner
+// (dp_lon.hip: host driver + the general kernels; dp_sweep.hip: the large-grid sweep kernel).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include "dp_lon_math.h"
+
+namespace tplhip {
+
+constexpr int N_BWD = 9;    // evalNode<9>,  lon_planner.cu:201
+constexpr int N_FWD = 21;   // evalNode<21>, lon_planner.cu:220
+
+// Per-(row, action) constants of the backward sweep.  Everything here depends
+// only on (v, a, jerk_k, dt) -- never on the station or the stage.
+// The first eight floats are the part a sweep needs in VECTOR registers (operands of plain fp32
+// multiply / add instructions, which only run at full rate on vector operands -- tools/micro/valu_tp.hip);
+// k_backward3v copies them to LDS once and reads them back as broadcasts.
+struct alignas(16) ActDesc {
+    float wa, iwa;      // quantised blend weight along a (rule R2) and 1 - wa (exact: multiples of 1/256)
+    float wv, iwv;      // the same along v
+    float j;            // jerk of this action
+    float wj_cost;      // stateActionCost             lon_planner.cu:57-64
+    float a_viol;       // (a_min - a') or (a' - a_max) if violated, else 0 (at most one is non-zero)
+    float tn_v;         // successor velocity          lon_planner.cu:245
+    double j_term;      // ((((1/6)*j)*dt)*dt)*dt      lon_planner.cu:244
+    double tn_v_d;      // (double)tn_v, for the double-precision speed-limit term (:114-118)
+    int r00, r10, r01, r11;   // next-stage rows (a*V + v) of the corners (a0,v0) (a1,v0) (a0,v1) (a1,v1)
+    double a_term;      // ((0.5*a)*dt)*dt             lon_planner.cu:244   (the same for the nine actions of a row)
+    float vdt;          // v*dt                                              (the same for the nine actions of a row)
+    int pad;
+};
+static_assert(sizeof(ActDesc) == 80, "ActDesc must be 80 bytes");
+
+// Everything a sweep launch needs besides the tables (filled by the host driver in dp_lon.hip).
+struct SweepArgs {
+    const Node* next;
+    Node* out;
+    const ActDesc* acts;
+    const float* path;
+    const float* pre_vmax;     // this stage, [s_steps]
+    const float* pre_sdist;    // this stage, [s_steps]
+    const double* pre_prog;    // [s_steps]
+    TplDpLonParams p;
+    int s_pad;
+    float rcp_path_hi, rcp_path_lo;      // 1/path_step_size as a two-float number
+    float rcp_range_hi, rcp_range_lo;    // 1/(s_max - s_min) likewise
+    int tile_v, tile_a;
+    // scenario batch (blockIdx.y): element strides between consecutive scenarios, 0 = shared
+    size_t stride_tables, stride_pre, stride_path;
+};
+
+// dp_sweep.hip.  path_div / range_div: 3 = two-float reciprocal (2 plain fp32 instructions), 4 = power-of-two
+// divisor (one multiplication); both only after k_verify_div proved them equal to IEEE division on the whole range.
+// Returns false when the combination is not built (the caller falls back to k_backward2v).
+bool launch_backward3v(int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
+size_t backward3v_lds_bytes(int s_pad, int path_steps);
+
+} // namespace tplhip
