@@ -30,7 +30,14 @@
 //     are sums of non-negative terms (the host checks that every weight is >= +0), and for
 //     non-negative floats the integer order of the bit patterns is the float order.
 // Results are bit-identical to k_backward / k_backward2v and to oracle/dp_lon_oracle.c.
+#include <cstdlib>
+
 #include "dp_lon_internal.h"
+
+// timing experiments only (tools/ab_dp.sh build WORK -- -DV3_ABLATE=n): 1 = phase 2 removed, 2 = row loads removed
+#ifndef V3_ABLATE
+#define V3_ABLATE 0
+#endif
 
 namespace tplhip {
 namespace {
@@ -65,8 +72,10 @@ __device__ __forceinline__ Node3 lerp3(Node3 p, Node3 q, float w, float iw)     
     return r;
 }
 
-template <int PATH_DIV, int RANGE_DIV>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8)))
+// PREFETCH: the six common row loads of action k+1 are issued before the barrier of action k, so they fly under
+// its phase 2 (a few more live registers).
+template <int PATH_DIV, int RANGE_DIV, bool PREFETCH>
+__global__ void __launch_bounds__(1024)
 k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, const ActDesc* __restrict__ acts,
              const float* __restrict__ path_all, const float* __restrict__ pre_vmax_all,
              const float* __restrict__ pre_sdist_all, const double* __restrict__ pre_prog, SweepArgs a)
@@ -166,6 +175,17 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     unsigned long long best0 = 0x7f8000007f800000ull, best1 = 0x7f8000007f800000ull;   // (+inf, +inf)
     int bk0 = 0, bk1 = 0;
 
+    Node3 ld[6];
+    auto issue_loads = [&](int k) {
+        const ActDesc* e0 = d0 + k;
+        const ActDesc* e1 = d1 + k;
+        ld[0] = load_row(e0->r00); ld[1] = load_row(e0->r10); ld[2] = load_row(e0->r01); ld[3] = load_row(e0->r11);
+        ld[4] = load_row(e1->r01); ld[5] = load_row(e1->r11);
+    };
+#if V3_ABLATE == 2       // timing experiment: no row loads at all (registers fed from lane ids), results are wrong
+    for (int i = 0; i < 6; ++i) ld[i] = Node3{(float)is, (float)(is + i), 1.0f};
+#endif
+
     __syncthreads();                     // descriptors and path limits are in LDS
 
     const v4f* dsc4 = reinterpret_cast<const v4f*>(dsc);
@@ -181,9 +201,10 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             // the upper half of row 0's window is the lower half of row 1's, blended with the same weight
             const bool shared = e0->r01 == e1->r00 && e0->r11 == e1->r10
                                 && __float_as_uint(e0->wa) == __float_as_uint(e1->wa);
-            const Node3 p00 = load_row(e0->r00), p10 = load_row(e0->r10);
-            const Node3 p01 = load_row(e0->r01), p11 = load_row(e0->r11);
-            const Node3 q01 = load_row(e1->r01), q11 = load_row(e1->r11);
+#if V3_ABLATE != 2
+            if (!PREFETCH || k == 0) issue_loads(k);
+#endif
+            const Node3 p00 = ld[0], p10 = ld[1], p01 = ld[2], p11 = ld[3], q01 = ld[4], q11 = ld[5];
             const Node3 a0 = lerp3(p00, p10, w0.x, w0.y);
             const Node3 a1 = lerp3(p01, p11, w0.x, w0.y);
             Node3 b0;
@@ -202,10 +223,18 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                 *reinterpret_cast<v3f*>(Rk0 + S) = (v3f){r0.c, r0.g, r0.j};
                 *reinterpret_cast<v3f*>(Rk1 + S) = (v3f){r1.c, r1.g, r1.j};
             }
+#if V3_ABLATE != 2
+            if (PREFETCH && k + 1 < N_BWD) {
+                issue_loads(k + 1);
+                __builtin_amdgcn_sched_barrier(0);            // keep the requests in front of phase 2
+            }
+#endif
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // ---- phase 2: successor station, 1-D blend along s, costs, argmin -- per cell
         const v4f u0 = dsc4[(0 * N_BWD + k) * 2 + 1], u1 = dsc4[(1 * N_BWD + k) * 2 + 1];   // j, wj_cost, a_viol, tn_v
+        int kv = k;
+        asm volatile("" : "+v"(kv));                       // k in a vector register: the select below takes it as it is
         auto cell = [&](double sd_base, const ActDesc* e, const v4f u, const v4f* Rk, float sc, float sg,
                         unsigned long long& best, int& bk) {
             // lonDynamics station part, lon_planner.cu:244
@@ -250,10 +279,14 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const unsigned long long key = ((unsigned long long)__float_as_uint(g) << 32) | __float_as_uint(c);
             const bool better = key < best;
             best = better ? key : best;
-            bk = better ? k : bk;
+            bk = better ? kv : bk;
         };
+#if V3_ABLATE != 1
         cell(sd_base0, e0, u0, Rk0, sc0, sg0, best0, bk0);
         cell(sd_base1, e1, u1, Rk1, sc1, sg1, best1, bk1);
+#else
+        best0 += __float_as_uint(Rk0[is].x + u0.x); best1 += __float_as_uint(Rk1[is].y + u1.x);
+#endif
         asm volatile("" : "+v"(best0), "+v"(bk0), "+v"(best1), "+v"(bk1));
     }
     if (active) {
@@ -277,10 +310,17 @@ bool launch_backward3v(int path_div, int range_div, const SweepArgs& a, dim3 gri
         hipLaunchKernelGGL(kernel, grid, dim3(a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
         return true;
     };
-    if (path_div == 4 && range_div == 3) return go(k_backward3v<4, 3>);
-    if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3>);
-    if (path_div == 4 && range_div == 4) return go(k_backward3v<4, 4>);
-    if (path_div == 3 && range_div == 4) return go(k_backward3v<3, 4>);
+    static const bool no_prefetch = std::getenv("TPLHIP_V3_NO_PREFETCH") != nullptr;
+    if (no_prefetch) {
+        if (path_div == 4 && range_div == 3) return go(k_backward3v<4, 3, false>);
+        if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3, false>);
+        if (path_div == 4 && range_div == 4) return go(k_backward3v<4, 4, false>);
+        if (path_div == 3 && range_div == 4) return go(k_backward3v<3, 4, false>);
+    }
+    if (path_div == 4 && range_div == 3) return go(k_backward3v<4, 3, true>);
+    if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3, true>);
+    if (path_div == 4 && range_div == 4) return go(k_backward3v<4, 4, true>);
+    if (path_div == 3 && range_div == 4) return go(k_backward3v<3, 4, true>);
     return false;
 }
 
