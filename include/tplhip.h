@@ -19,6 +19,7 @@
 #ifndef TPLHIP_H
 #define TPLHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -194,6 +195,45 @@ TPLHIP_API int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n);
  * returns the summed ms and the number of sweep launches since enable. */
 TPLHIP_API int tplhip_dp_lon_timing_enable(tplhip_dp_lon* h, int enable);
 TPLHIP_API int tplhip_dp_lon_timing_get(tplhip_dp_lon* h, double* sweep_ms, int64_t* sweep_launches);
+
+/* ---- scenario batches: Monte-Carlo rollouts of the planner (new; SURVEY 8e, BASELINE configs[4]) ----
+ *
+ * Nothing in the reference plans more than one scenario at a time (DynProgLonPlanner::update,
+ * lon_planner.cu:328-401, is one plan with a host sync per stage).  Here n independent scenarios --
+ * n occupancy maps and initial states, one path each or one shared path; planner parameters shared --
+ * stay resident in HBM, and `count` of them are swept per launch (the scenario is a grid dimension of
+ * every kernel: own value tables, distance map and stage prelude per scenario), which is what fills the
+ * chip on the small grids tpl really runs.  Every scenario's plan is bit-identical to
+ * tplhip_dp_lon_update on the same inputs.  After the rollouts of a launch the lexicographically
+ * smallest (constraint violation, cost, id) plan is reduced ON THE DEVICE into a fixed-size record:
+ * the message of the one all-gather a multi-GPU run needs. */
+
+/* header of the best-plan record; TplLonState[t_steps] follows (tplhip_dp_lon_record_bytes in all) */
+typedef struct TplDpPlanRecord {
+    float constr;       /* max of states[1..t_steps-2].constr: the validity measure of the Python caller
+                           (planning/dyn_prog/poly_lat_dp_lon_planner.py:99-101); all states when t_steps <= 2 */
+    float cost;         /* states[0].cost = value of the whole plan */
+    int32_t id;         /* id_base + index of the scenario; 0x7fffffff = no plan yet */
+    int32_t t_steps;
+} TplDpPlanRecord;
+
+TPLHIP_API size_t tplhip_dp_lon_record_bytes(int t_steps);
+/* occ_nlst: float[n][l_steps][s_steps][t_steps] (the layout of tplhip_dp_env_get_occ_map, per scenario);
+ * inits: TplLonState[n]; paths: float[n_paths][path_steps][7] with n_paths = 1 (shared) or n.
+ * chunk = scenarios swept per launch (value tables for that many are allocated: chunk x t_steps x cells x 12 B). */
+TPLHIP_API int tplhip_dp_lon_scenarios_upload(tplhip_dp_lon* h, int n, const float* occ_nlst, const TplDpEnvParams* ep,
+                                              const TplLonState* inits, const float* paths, int n_paths, int chunk);
+/* Enqueue the complete plans of scenarios [first, first + count), count <= chunk: distance maps, stage preludes,
+ * t_steps-1 batched sweeps, the forward rollouts and the reduction into the record (reset_best != 0 starts a new
+ * record, 0 keeps the better of the record and this launch).  Scenario i carries the id id_base + i. */
+TPLHIP_API int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_base, int reset_best);
+/* all n trajectories (TplLonState[n][t_steps]; scenarios never planned read as zeros); synchronises */
+TPLHIP_API int tplhip_dp_lon_scenarios_download(tplhip_dp_lon* h, TplLonState* out_trajs);
+/* the record on the host (record_bytes bytes), or its device address for a collective that sends it from HBM */
+TPLHIP_API int tplhip_dp_lon_scenarios_best(tplhip_dp_lon* h, void* record_out);
+TPLHIP_API int tplhip_dp_lon_scenarios_best_device(tplhip_dp_lon* h, void** dev_record, size_t* bytes);
+/* parity: stage t of the value table of a scenario of the most recent launch, layout of tplhip_dp_lon_copy_table */
+TPLHIP_API int tplhip_dp_lon_scenarios_copy_table(tplhip_dp_lon* h, int scenario, int t, float* out);
 
 /* ------------- lateral polynomial planner (poly_lat_planner.cu) -- */
 

@@ -196,6 +196,14 @@ SIGNATURES = {
     "tplhip_dp_lon_info": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "tplhip_dp_lon_timing_enable": (C.c_int, [_vp, C.c_int]),
     "tplhip_dp_lon_timing_get": (C.c_int, [_vp, _P(C.c_double), _P(C.c_int64)]),
+    "tplhip_dp_lon_record_bytes": (C.c_size_t, [C.c_int]),
+    "tplhip_dp_lon_scenarios_upload": (C.c_int, [_vp, C.c_int, _P(C.c_float), _P(TplDpEnvParams), _P(TplLonState),
+                                                 _P(C.c_float), C.c_int, C.c_int]),
+    "tplhip_dp_lon_scenarios_plan": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tplhip_dp_lon_scenarios_download": (C.c_int, [_vp, _P(TplLonState)]),
+    "tplhip_dp_lon_scenarios_best": (C.c_int, [_vp, C.c_void_p]),
+    "tplhip_dp_lon_scenarios_best_device": (C.c_int, [_vp, _P(C.c_void_p), _P(C.c_size_t)]),
+    "tplhip_dp_lon_scenarios_copy_table": (C.c_int, [_vp, C.c_int, C.c_int, _P(C.c_float)]),
 }
 
 _lib = None

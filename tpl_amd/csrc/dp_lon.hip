@@ -87,13 +87,19 @@ __global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p)
 // per-(stage, station) prelude: interpPath(tp.s), dist map lookup, progress
 // cost.  evalNode lon_planner.cu:80-86.  grid = t_steps blocks.
 // ------------------------------------------------------------------------
+// blockIdx.y = scenario of a batch (strides in elements between consecutive scenarios; 0 = shared).
 __global__ void k_stage_prelude(float* __restrict__ pre_vmax, float* __restrict__ pre_sdist,
                                 double* __restrict__ pre_prog,
                                 const float* __restrict__ path, const float* __restrict__ dist_ts,
-                                TplDpLonParams p, TplDpEnvParams ep)
+                                TplDpLonParams p, TplDpEnvParams ep,
+                                size_t stride_pre, size_t stride_path, size_t stride_dist)
 {
     const int idx_t = blockIdx.x;
     if (idx_t < 1) return;
+    pre_vmax += blockIdx.y * stride_pre;
+    pre_sdist += blockIdx.y * stride_pre;
+    path += blockIdx.y * stride_path;
+    dist_ts += blockIdx.y * stride_dist;
     const float t = p.dt_start + (float)(idx_t - 1) * p.dt;       // lon_planner.cu:196
     for (int is = threadIdx.x; is < p.s_steps; is += blockDim.x) {
         const float s = p.s_min + (float)is * p._s_step_size;     // lon_planner.cu:197
@@ -104,7 +110,7 @@ __global__ void k_stage_prelude(float* __restrict__ pre_vmax, float* __restrict_
                                      - (double)p.length_veh * 0.6);
         pre_vmax[(size_t)idx_t * p.s_steps + is] = v_max;
         pre_sdist[(size_t)idx_t * p.s_steps + is] = s_dist;
-        if (idx_t == 1) {
+        if (idx_t == 1 && blockIdx.y == 0) {
             pre_prog[is] = (double)p.w_progress * fabs(1000.0 - (double)s);
         }
     }
@@ -132,9 +138,16 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
                            const double* __restrict__ pre_prog,   // [s_steps]
                            TplDpLonParams p, int s_pad, int rows_per_block, int nblocks,
                            float rcp_path_step, double rcp_path_step_d, double rcp_s_range_d,
-                           int tile_v, int tile_a)
+                           int tile_v, int tile_a,
+                           size_t stride_tables, size_t stride_pre, size_t stride_path)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // scenario batch: blockIdx.y selects the scenario's tables, stage prelude and path (strides 0 = shared)
+    next += blockIdx.y * stride_tables;
+    out += blockIdx.y * stride_tables;
+    pre_vmax += blockIdx.y * stride_pre;
+    pre_sdist += blockIdx.y * stride_pre;
+    path += blockIdx.y * stride_path;
 
     // Traversal order (speed only; any order gives the same table).  Blocks b and b+8 share an
     // XCD and its 4 MiB L2 (round-robin dispatch).  Action k of row (v,a) reads next-stage rows
@@ -891,12 +904,18 @@ __device__ __forceinline__ void eval_node_wave(TplLonState& tp, const Node* __re
 // the distance map are copied to LDS once, so only the table reads of a step go to memory.
 constexpr int FWD_RING = 16;
 
+// Scenario batches: rollout r belongs to scenario r (one rollout each); its tables, path and distance map are
+// stride_* elements further on (0 = shared by all rollouts, the single-plan case).
 template <bool IN_LDS>
 __global__ void k_forward(TplLonState* __restrict__ trajs, const TplLonState* __restrict__ inits,
                           const Node* __restrict__ tables, size_t table_cells,
                           const float* __restrict__ path, const float* __restrict__ dist_ts,
-                          TplDpLonParams p, TplDpEnvParams ep)
+                          TplDpLonParams p, TplDpEnvParams ep,
+                          size_t stride_tables, size_t stride_path, size_t stride_dist)
 {
+    tables += blockIdx.x * stride_tables;
+    path += blockIdx.x * stride_path;
+    dist_ts += blockIdx.x * stride_dist;
     extern __shared__ __attribute__((aligned(16))) char fwd_smem[];
     float* ring = reinterpret_cast<float*>(fwd_smem);                       // FWD_RING x LonState (7 floats)
     float* l_path = ring + FWD_RING * 7;
@@ -979,9 +998,12 @@ __global__ void k_reeval(TplLonState* __restrict__ traj,
 // ------------------------------------------------------------------------
 __global__ void k_dist_map_path(float* __restrict__ dist_ts, const float* __restrict__ occ_lst,
                                 const float* __restrict__ path, int path_steps, float path_step_size,
-                                TplDpEnvParams ep)
+                                TplDpEnvParams ep, size_t stride_dist, size_t stride_occ, size_t stride_path)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    dist_ts += blockIdx.y * stride_dist;          // scenario batch, see k_stage_prelude
+    occ_lst += blockIdx.y * stride_occ;
+    path += blockIdx.y * stride_path;
     float* d_sh = reinterpret_cast<float*>(smem);      // [s_steps]: occupancy flag, then distance
     const int idx_t = blockIdx.x;
     const int S = ep.s_steps;
@@ -1010,6 +1032,58 @@ __global__ void k_dist_map_path(float* __restrict__ dist_ts, const float* __rest
     for (int idx_s = threadIdx.x; idx_s < S; idx_s += blockDim.x) {
         dist_ts[(size_t)idx_t * S + idx_s] = d_sh[idx_s];
     }
+}
+
+
+// ------------------------------------------------------------------------
+// Best plan of a batch of scenario rollouts (new): the lexicographically smallest
+// (constraint violation, cost, scenario id) -- the planner's own order (lon_planner.cu:153-170) applied to
+// whole plans, with the validity measure of the Python caller (max constr over states[1:-1],
+// planning/dyn_prog/poly_lat_dp_lon_planner.py:99-101) and the value of the plan (cost of the first node).
+// One workgroup; the winner's trajectory is written behind a 16-byte header {constr, cost, id, t_steps}
+// unless the record already holds a better one (reset == 0: running best over several chunks).
+// ------------------------------------------------------------------------
+__device__ __forceinline__ bool plan_better(float g, float c, int id, float bg, float bc, int bid)
+{
+    return g < bg || (g == bg && (c < bc || (c == bc && id < bid)));
+}
+
+__global__ void __launch_bounds__(256) k_best_plan(const TplLonState* __restrict__ trajs, int count, int id_first, int T,
+                                                   unsigned char* __restrict__ record, int reset)
+{
+    __shared__ float s_g[256], s_c[256];
+    __shared__ int s_id[256], s_take;
+    const int tid = threadIdx.x;
+    float bg = INFINITY, bc = INFINITY;
+    int bid = 0x7fffffff;
+    for (int j = tid; j < count; j += 256) {
+        const TplLonState* tr = trajs + (size_t)j * T;
+        float g;
+        if (T > 2) { g = tr[1].constr; for (int i = 2; i < T - 1; ++i) g = fmaxf(g, tr[i].constr); }
+        else { g = tr[0].constr; for (int i = 1; i < T; ++i) g = fmaxf(g, tr[i].constr); }
+        const float c = tr[0].cost;
+        if (plan_better(g, c, id_first + j, bg, bc, bid)) { bg = g; bc = c; bid = id_first + j; }
+    }
+    s_g[tid] = bg; s_c[tid] = bc; s_id[tid] = bid;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w && plan_better(s_g[tid + w], s_c[tid + w], s_id[tid + w], s_g[tid], s_c[tid], s_id[tid])) {
+            s_g[tid] = s_g[tid + w]; s_c[tid] = s_c[tid + w]; s_id[tid] = s_id[tid + w];
+        }
+        __syncthreads();
+    }
+    float* rf = reinterpret_cast<float*>(record);
+    int* ri = reinterpret_cast<int*>(record);
+    if (tid == 0) {
+        const bool have = s_id[0] != 0x7fffffff;
+        s_take = have && (reset || plan_better(s_g[0], s_c[0], s_id[0], rf[0], rf[1], ri[2]));
+        if (reset && !have) { rf[0] = INFINITY; rf[1] = INFINITY; ri[2] = 0x7fffffff; ri[3] = T; }
+    }
+    __syncthreads();
+    if (!s_take) return;
+    const float* src = reinterpret_cast<const float*>(trajs + (size_t)(s_id[0] - id_first) * T);
+    for (int e = tid; e < T * 7; e += 256) rf[4 + e] = src[e];
+    if (tid == 0) { rf[0] = s_g[0]; rf[1] = s_c[0]; ri[2] = s_id[0]; ri[3] = T; }
 }
 
 } // namespace
@@ -1076,6 +1150,22 @@ struct tplhip_dp_lon {
     size_t stage_n[2] = {0, 0};          // states staged in each slot (rollouts x t_steps at staging time)
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     bool stage_busy[2] = {false, false};
+
+    // scenario batches (tplhip_dp_lon_scenarios_*): n scenarios resident, `chunk` of them swept per launch
+    int sc_n = 0, sc_chunk = 0, sc_paths = 0;
+    TplDpEnvParams sc_ep;
+    float* d_sc_occ = nullptr;           // [n][l][s][t]
+    float* d_sc_path = nullptr;          // [sc_paths][path_steps][7]
+    float* d_sc_dist = nullptr;          // [chunk][env t][env s]
+    Node* d_sc_tables = nullptr;         // [chunk][t_steps][cells]
+    float* d_sc_pre_vmax = nullptr;      // [chunk][t_steps][s]
+    float* d_sc_pre_sdist = nullptr;
+    TplLonState* d_sc_inits = nullptr;   // [n]
+    TplLonState* d_sc_trajs = nullptr;   // [n][t_steps]
+    unsigned char* d_sc_best = nullptr;  // TplDpPlanRecord + TplLonState[t_steps]
+    bool sc_bounded = false;
+    int sc_last_first = 0, sc_last_count = 0;
+    bool vp_ok = false;                  // the two-rows-per-lane geometry fits this grid (any number of plans)
 
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1160,7 +1250,8 @@ void launch_backward_b(tplhip_dp_lon* h, int idx_t, int nx)
                        h->d_acts, h->d_path,
                        h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
                        h->d_pre_prog, h->params, h->s_pad, h->rows_per_block, h->nblocks,
-                       h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a);
+                       h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a,
+                       (size_t)0, (size_t)0, (size_t)0);
 }
 
 template <bool TERMINAL, int KCHUNK, int DIVMODE>
@@ -1262,7 +1353,8 @@ void launch_terminal(tplhip_dp_lon* h, int idx_t)
                        h->d_acts, h->d_path,
                        h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
                        h->d_pre_prog, h->params, s_pad1, rpb, 0,
-                       h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a);
+                       h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a,
+                       (size_t)0, (size_t)0, (size_t)0);
 }
 
 // two-pass argmin kernel on the fallback geometry (inputs outside the bounded range)
@@ -1276,7 +1368,8 @@ void launch_exact(tplhip_dp_lon* h, int idx_t, int nx)
                            h->d_tables + (size_t)nx * h->table_cells, h->d_tables + (size_t)idx_t * h->table_cells,
                            h->d_acts, h->d_path, h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
                            h->d_pre_prog, h->params, h->x_s_pad, h->x_rpb, h->x_nblocks,
-                           h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a);
+                           h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a,
+                           (size_t)0, (size_t)0, (size_t)0);
     };
     if (buf) go(k_backward<false, 1, DIVMODE, true>);
     else go(k_backward<false, 1, DIVMODE, false>);
@@ -1320,9 +1413,11 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env)
     // env.updateDistMapPath, lon_planner.cu:343
     hipLaunchKernelGGL(k_dist_map_path, dim3(env->params.t_steps), dim3(256),
                        sizeof(float) * (size_t)env->params.s_steps, h->stream,
-                       env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params);
+                       env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params,
+                       (size_t)0, (size_t)0, (size_t)0);
     hipLaunchKernelGGL(k_stage_prelude, dim3(T), dim3(256), 0, h->stream,
-                       h->d_pre_vmax, h->d_pre_sdist, h->d_pre_prog, h->d_path, env->d_dist, p, env->params);
+                       h->d_pre_vmax, h->d_pre_sdist, h->d_pre_prog, h->d_path, env->d_dist, p, env->params,
+                       (size_t)0, (size_t)0, (size_t)0);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
@@ -1349,11 +1444,11 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env)
         if (ring_b + maps_b <= 60 * 1024)
             hipLaunchKernelGGL(k_forward<true>, dim3(h->n_rollouts), dim3(64), ring_b + maps_b, h->stream,
                                h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
-                               h->d_path, env->d_dist, p, env->params);
+                               h->d_path, env->d_dist, p, env->params, (size_t)0, (size_t)0, (size_t)0);
         else
             hipLaunchKernelGGL(k_forward<false>, dim3(h->n_rollouts), dim3(64), ring_b, h->stream,
                                h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
-                               h->d_path, env->d_dist, p, env->params);
+                               h->d_path, env->d_dist, p, env->params, (size_t)0, (size_t)0, (size_t)0);
     }
     HIP_TRY(hipGetLastError(), "lon planner launch failed");
     h->tables_valid = true;
@@ -1361,6 +1456,8 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env)
 }
 
 } // namespace
+
+void free_scenarios_fwd(tplhip_dp_lon* h);
 
 extern "C" {
 
@@ -1548,6 +1645,7 @@ int tplhip_dp_lon_destroy(tplhip_dp_lon* h)
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& ev : h->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     free_planner_buffers(h);
+    free_scenarios_fwd(h);
     hipFree(h->d_inits);
     hipFree(h->d_trajs);
     hipFree(h->d_reeval);
@@ -1595,6 +1693,7 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         h->d_inits = nullptr; h->d_trajs = nullptr; h->cap_rollouts = 0;
         h->n_rollouts = 0; h->path_bounded = false;          // nothing uploaded any more
         h->stage_busy[0] = h->stage_busy[1] = false;
+        free_scenarios_fwd(h);                               // scenario tables are sized by the grid
         h->table_cells = S * p.v_steps * p.a_steps;
         HIP_TRY(hipMalloc(&h->d_tables, sizeof(Node) * h->table_cells * (size_t)p.t_steps), "value table allocation failed");
         HIP_TRY(hipMemsetAsync(h->d_tables, 0, sizeof(Node) * h->table_cells * (size_t)p.t_steps, h->stream), "value table clear failed");
@@ -1669,6 +1768,16 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         for (float w : {p.w_progress, p.w_a, p.w_j, p.w_snap, p.w_safety_dist}) nn = nn && !std::signbit(w);
         h->weights_nonneg = nn;
     }
+    // two rows per lane where every XCD's v range splits into pairs (k_backward2v / k_backward3v)
+    {
+        h->vp_s_pad = ((p.s_steps + 63) / 64) * 64;
+        h->vp_lds = (size_t)4 * (h->vp_s_pad + 1) * 16 + path_lds;
+        h->vp_grid = 8 * ((p.v_steps / 16) * p.a_steps);
+        const char* vo = std::getenv("TPLHIP_VPAIR");
+        h->vp_ok = (vo ? std::atoi(vo) != 0 : true) && p.v_steps % 16 == 0 && h->vp_s_pad <= 1024
+                   && (h->tile_v % 2 == 0) && h->vp_lds <= 64 * 1024;
+        h->vpair = false;
+    }
     // Large grids (one action per barrier) run two stations per lane, see k_backward2.
     h->cells = 1;
     {
@@ -1689,13 +1798,7 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
                 max_rows = std::max(max_rows, ((((x + 1) * p.v_steps) >> 3) - ((x * p.v_steps) >> 3)) * p.a_steps);
             h->grid = 8 * ((max_rows + h->rows_per_block - 1) / h->rows_per_block);
             h->lds_bytes = (size_t)2 * (h->s_pad + 1) * h->rows_per_block * 16 + path_lds;
-            // two rows per lane where every XCD's v range splits into pairs
-            h->vp_s_pad = ((p.s_steps + 63) / 64) * 64;
-            h->vp_lds = (size_t)4 * (h->vp_s_pad + 1) * 16 + path_lds;
-            h->vp_grid = 8 * ((p.v_steps / 16) * p.a_steps);
-            const char* vo = std::getenv("TPLHIP_VPAIR");
-            h->vpair = (vo ? std::atoi(vo) != 0 : true) && p.v_steps % 16 == 0 && h->vp_s_pad <= 1024
-                       && (h->tile_v % 2 == 0) && h->vp_lds <= 64 * 1024;
+            h->vpair = h->vp_ok;
         }
     }
     if (h->lds_bytes > 160 * 1024)
@@ -1887,7 +1990,8 @@ int tplhip_dp_lon_reeval(tplhip_dp_lon* h, const TplLonState* traj, int len, con
                            hipMemcpyHostToDevice, h->stream), "copying trajectory to gpu failed");
     hipLaunchKernelGGL(k_dist_map_path, dim3(env->params.t_steps), dim3(256),
                        sizeof(float) * (size_t)env->params.s_steps, h->stream,
-                       env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params);
+                       env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params,
+                       (size_t)0, (size_t)0, (size_t)0);
     hipLaunchKernelGGL(k_reeval, dim3((len + 63) / 64), dim3(64), 0, h->stream,
                        h->d_reeval, h->d_tables, h->table_cells, h->d_path, env->d_dist, p, env->params);
     HIP_TRY(hipGetLastError(), "reeval launch failed");
@@ -1957,6 +2061,222 @@ int tplhip_dp_lon_timing_get(tplhip_dp_lon* h, double* sweep_ms, int64_t* sweep_
     h->events.clear();
     *sweep_ms = h->sweep_ms;
     *sweep_launches = h->sweep_launches;
+    return TPLHIP_OK;
+}
+
+} // extern "C"
+
+// ---- scenario batches ----------------------------------------------------------
+
+namespace {
+
+void free_scenarios(tplhip_dp_lon* h)
+{
+    hipFree(h->d_sc_occ); hipFree(h->d_sc_path); hipFree(h->d_sc_dist); hipFree(h->d_sc_tables);
+    hipFree(h->d_sc_pre_vmax); hipFree(h->d_sc_pre_sdist); hipFree(h->d_sc_inits); hipFree(h->d_sc_trajs);
+    hipFree(h->d_sc_best);
+    h->d_sc_occ = h->d_sc_path = h->d_sc_dist = h->d_sc_pre_vmax = h->d_sc_pre_sdist = nullptr;
+    h->d_sc_tables = nullptr; h->d_sc_inits = h->d_sc_trajs = nullptr; h->d_sc_best = nullptr;
+    h->sc_n = h->sc_chunk = h->sc_paths = 0;
+}
+
+size_t record_bytes(int T) { return 16 + sizeof(TplLonState) * (size_t)T; }
+
+} // namespace
+
+void free_scenarios_fwd(tplhip_dp_lon* h) { free_scenarios(h); }
+
+extern "C" {
+
+size_t tplhip_dp_lon_record_bytes(int t_steps)
+{
+    return t_steps < 1 ? 0 : record_bytes(t_steps);
+}
+
+int tplhip_dp_lon_scenarios_upload(tplhip_dp_lon* h, int n, const float* occ_nlst, const TplDpEnvParams* ep_in,
+                                   const TplLonState* inits, const float* paths, int n_paths, int chunk)
+{
+    if (!h || !occ_nlst || !ep_in || !inits || !paths) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (!h->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the planner");
+    if (n < 1 || chunk < 1 || (n_paths != 1 && n_paths != n))
+        return tplhip_fail(TPLHIP_EINVAL, "need n >= 1, chunk >= 1 and one path or one per scenario (n = %d, chunk = %d, n_paths = %d)", n, chunk, n_paths);
+    if (ep_in->t_steps < 1 || ep_in->s_steps < 2 || ep_in->l_steps < 2)
+        return tplhip_fail(TPLHIP_EINVAL, "environment needs t_steps >= 1, s_steps >= 2, l_steps >= 2");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
+    chunk = std::min(chunk, n);
+    const TplDpLonParams& p = h->params;
+    TplDpEnvParams ep = *ep_in;
+    env_update_step_sizes(&ep);
+    const size_t occ_elems = (size_t)ep.l_steps * ep.s_steps * ep.t_steps;
+    const size_t dist_elems = (size_t)ep.t_steps * ep.s_steps;
+    const size_t path_elems = (size_t)p.path_steps * 7;
+    const size_t S = (size_t)p.s_steps, T = (size_t)p.t_steps;
+    free_scenarios(h);
+    HIP_TRY(hipMalloc(&h->d_sc_occ, sizeof(float) * occ_elems * n), "scenario occupancy allocation failed");
+    HIP_TRY(hipMalloc(&h->d_sc_path, sizeof(float) * path_elems * n_paths), "scenario path allocation failed");
+    HIP_TRY(hipMalloc(&h->d_sc_dist, sizeof(float) * dist_elems * chunk), "scenario distance map allocation failed");
+    HIP_TRY(hipMalloc(&h->d_sc_tables, sizeof(Node) * h->table_cells * T * chunk), "scenario value table allocation failed");
+    HIP_TRY(hipMalloc(&h->d_sc_pre_vmax, sizeof(float) * S * T * chunk), "scenario prelude allocation failed");
+    HIP_TRY(hipMalloc(&h->d_sc_pre_sdist, sizeof(float) * S * T * chunk), "scenario prelude allocation failed");
+    HIP_TRY(hipMalloc(&h->d_sc_inits, sizeof(TplLonState) * (size_t)n), "scenario state allocation failed");
+    HIP_TRY(hipMalloc(&h->d_sc_trajs, sizeof(TplLonState) * T * n), "scenario trajectory allocation failed");
+    HIP_TRY(hipMalloc(&h->d_sc_best, record_bytes(p.t_steps)), "plan record allocation failed");
+    HIP_TRY(hipMemsetAsync(h->d_sc_tables, 0, sizeof(Node) * h->table_cells * T * chunk, h->stream), "value table clear failed");
+    HIP_TRY(hipMemsetAsync(h->d_sc_trajs, 0, sizeof(TplLonState) * T * n, h->stream), "trajectory clear failed");
+    HIP_TRY(hipMemcpyAsync(h->d_sc_occ, occ_nlst, sizeof(float) * occ_elems * n, hipMemcpyHostToDevice, h->stream), "copying occupancy maps failed");
+    HIP_TRY(hipMemcpyAsync(h->d_sc_path, paths, sizeof(float) * path_elems * n_paths, hipMemcpyHostToDevice, h->stream), "copying paths failed");
+    HIP_TRY(hipMemcpyAsync(h->d_sc_inits, inits, sizeof(TplLonState) * (size_t)n, hipMemcpyHostToDevice, h->stream), "copying initial states failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "scenario upload failed");
+    h->sc_n = n; h->sc_chunk = chunk; h->sc_paths = n_paths; h->sc_ep = ep;
+    {
+        bool ok = true;
+        for (int i = 0; i < n_paths && ok; ++i) ok = path_is_bounded(paths + path_elems * i, p.path_steps);
+        const float vals[] = {ep.s_min, ep.s_max, ep.l_min, ep.l_max, ep.dt, ep.dt_start};
+        for (float v : vals) ok = ok && std::isfinite(v) && std::fabs(v) < 1e6f;
+        h->sc_bounded = ok && h->params_bounded;
+    }
+    h->sc_last_first = h->sc_last_count = 0;
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_base, int reset_best)
+{
+    if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
+    if (h->sc_n < 1) return tplhip_fail(TPLHIP_ESTATE, "no scenarios uploaded");
+    if (first < 0 || count < 1 || count > h->sc_chunk || first + count > h->sc_n)
+        return tplhip_fail(TPLHIP_EINVAL, "scenario range [%d, %d) does not fit (%d scenarios, %d per launch)", first, first + count, h->sc_n, h->sc_chunk);
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    const TplDpLonParams& p = h->params;
+    const TplDpEnvParams& ep = h->sc_ep;
+    const int T = p.t_steps;
+    const size_t S = (size_t)p.s_steps;
+    const size_t occ_elems = (size_t)ep.l_steps * ep.s_steps * ep.t_steps;
+    const size_t dist_elems = (size_t)ep.t_steps * ep.s_steps;
+    const size_t path_stride = h->sc_paths > 1 ? (size_t)p.path_steps * 7 : 0;
+    const float* paths = h->d_sc_path + path_stride * first;
+    const size_t tab_stride = h->table_cells * (size_t)T, pre_stride = S * (size_t)T;
+
+    hipLaunchKernelGGL(k_dist_map_path, dim3(ep.t_steps, count), dim3(256), sizeof(float) * (size_t)ep.s_steps, h->stream,
+                       h->d_sc_dist, h->d_sc_occ + occ_elems * first, paths, p.path_steps, p.path_step_size, ep,
+                       dist_elems, occ_elems, path_stride);
+    hipLaunchKernelGGL(k_stage_prelude, dim3(T, count), dim3(256), 0, h->stream,
+                       h->d_sc_pre_vmax, h->d_sc_pre_sdist, h->d_pre_prog, paths, h->d_sc_dist, p, ep,
+                       pre_stride, path_stride, dist_elems);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing) {
+        HIP_TRY(hipEventCreate(&e0), "event creation failed");
+        HIP_TRY(hipEventCreate(&e1), "event creation failed");
+        HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
+    }
+    const bool v3 = h->vp_ok && use_v3(h) && h->sc_bounded;
+    for (int i = T - 1; i > 0; --i) {
+        const int nx = std::min(T - 1, i + 1);
+        Node* out = h->d_sc_tables + (size_t)i * h->table_cells;
+        const Node* next = h->d_sc_tables + (size_t)nx * h->table_cells;
+        const float* pv = h->d_sc_pre_vmax + (size_t)i * S;
+        const float* ps = h->d_sc_pre_sdist + (size_t)i * S;
+        if (i == T - 1) {                                            // rule R4
+            hipLaunchKernelGGL((k_backward<true, 1, 0, false>), dim3(h->x_grid, count), dim3(h->x_s_pad * h->x_rpb), 0, h->stream,
+                               out, out, h->d_acts, paths, pv, ps, h->d_pre_prog, p, h->x_s_pad, h->x_rpb, h->x_nblocks,
+                               h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a,
+                               tab_stride, pre_stride, path_stride);
+        } else if (v3) {
+            SweepArgs a;
+            a.next = next; a.out = out; a.acts = h->d_acts; a.path = paths; a.pre_vmax = pv; a.pre_sdist = ps;
+            a.pre_prog = h->d_pre_prog; a.p = p; a.s_pad = h->vp_s_pad;
+            a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->rcp_path_lo;
+            a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
+            a.tile_v = h->tile_v; a.tile_a = h->tile_a;
+            a.stride_tables = tab_stride; a.stride_pre = pre_stride; a.stride_path = path_stride;
+            launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->vp_grid, count),
+                              backward3v_lds_bytes(h->vp_s_pad, p.path_steps), h->stream);
+        } else {
+            auto go = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3(h->x_grid, count), dim3(h->x_s_pad * h->x_rpb), h->x_lds, h->stream,
+                                   next, out, h->d_acts, paths, pv, ps, h->d_pre_prog, p, h->x_s_pad, h->x_rpb, h->x_nblocks,
+                                   h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a,
+                                   tab_stride, pre_stride, path_stride);
+            };
+            const bool buf = h->use_buf;
+            if (h->div_mode == 1) { if (buf) go(k_backward<false, 1, 1, true>); else go(k_backward<false, 1, 1, false>); }
+            else if (h->div_mode == 2) { if (buf) go(k_backward<false, 1, 2, true>); else go(k_backward<false, 1, 2, false>); }
+            else { if (buf) go(k_backward<false, 1, 0, true>); else go(k_backward<false, 1, 0, false>); }
+        }
+    }
+    if (h->timing) {
+        HIP_TRY(hipEventRecord(e1, h->stream), "event record failed");
+        h->events.emplace_back(e0, e1);
+        h->sweep_launches += (T - 1);
+    }
+    {
+        const size_t ring_b = sizeof(float) * 7 * FWD_RING;
+        const size_t maps_b = sizeof(float) * ((size_t)p.path_steps * 7 + dist_elems);
+        TplLonState* trajs = h->d_sc_trajs + (size_t)first * T;
+        if (ring_b + maps_b <= 60 * 1024)
+            hipLaunchKernelGGL(k_forward<true>, dim3(count), dim3(64), ring_b + maps_b, h->stream,
+                               trajs, h->d_sc_inits + first, h->d_sc_tables, h->table_cells, paths, h->d_sc_dist, p, ep,
+                               tab_stride, path_stride, dist_elems);
+        else
+            hipLaunchKernelGGL(k_forward<false>, dim3(count), dim3(64), ring_b, h->stream,
+                               trajs, h->d_sc_inits + first, h->d_sc_tables, h->table_cells, paths, h->d_sc_dist, p, ep,
+                               tab_stride, path_stride, dist_elems);
+        hipLaunchKernelGGL(k_best_plan, dim3(1), dim3(256), 0, h->stream, trajs, count, id_base + first, T, h->d_sc_best, reset_best ? 1 : 0);
+    }
+    HIP_TRY(hipGetLastError(), "scenario plan launch failed");
+    h->sc_last_first = first; h->sc_last_count = count;
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_scenarios_download(tplhip_dp_lon* h, TplLonState* out_trajs)
+{
+    if (!h || !out_trajs) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (h->sc_n < 1) return tplhip_fail(TPLHIP_ESTATE, "no scenarios uploaded");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipMemcpyAsync(out_trajs, h->d_sc_trajs, sizeof(TplLonState) * (size_t)h->sc_n * h->params.t_steps,
+                           hipMemcpyDeviceToHost, h->stream), "copying trajectories failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "scenario plans failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_scenarios_best(tplhip_dp_lon* h, void* record_out)
+{
+    if (!h || !record_out) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (h->sc_n < 1) return tplhip_fail(TPLHIP_ESTATE, "no scenarios uploaded");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipMemcpyAsync(record_out, h->d_sc_best, record_bytes(h->params.t_steps), hipMemcpyDeviceToHost, h->stream),
+            "copying the plan record failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "scenario plans failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_scenarios_best_device(tplhip_dp_lon* h, void** dev_record, size_t* bytes)
+{
+    if (!h || !dev_record || !bytes) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (h->sc_n < 1) return tplhip_fail(TPLHIP_ESTATE, "no scenarios uploaded");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "scenario plans failed");      // the record is final when this returns
+    *dev_record = h->d_sc_best;
+    *bytes = record_bytes(h->params.t_steps);
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_scenarios_copy_table(tplhip_dp_lon* h, int scenario, int t, float* out)
+{
+    if (!h || !out) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (scenario < h->sc_last_first || scenario >= h->sc_last_first + h->sc_last_count)
+        return tplhip_fail(TPLHIP_ESTATE, "scenario %d is not among those of the last launch [%d, %d)", scenario,
+                           h->sc_last_first, h->sc_last_first + h->sc_last_count);
+    if (t < 0 || t >= h->params.t_steps) return tplhip_fail(TPLHIP_EINVAL, "stage %d out of range", t);
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
+    std::vector<Node> tmp(h->table_cells);
+    const size_t slot = (size_t)(scenario - h->sc_last_first);
+    HIP_TRY(hipMemcpy(tmp.data(), h->d_sc_tables + (slot * h->params.t_steps + (size_t)t) * h->table_cells,
+                      sizeof(Node) * h->table_cells, hipMemcpyDeviceToHost), "copying value table failed");
+    for (size_t i = 0; i < h->table_cells; ++i) {
+        out[4 * i + 0] = tmp[i].c; out[4 * i + 1] = tmp[i].g; out[4 * i + 2] = tmp[i].j; out[4 * i + 3] = 0.0f;
+    }
     return TPLHIP_OK;
 }
 

@@ -369,6 +369,63 @@ class DynProgLonPlanner:
         check(self._lib.tplhip_dp_lon_collect_download(self._h, int(slot), out))
         return [LonTraj._from_array(out[i * T:(i + 1) * T]) for i in range(n)]
 
+    # ---- scenario batches (new) -----------------------------------
+
+    def upload_scenarios(self, occ_maps, env_params, initial_states, paths, chunk=32):
+        """n independent scenarios, resident on the device: ``occ_maps`` float32[n, l, s, t] (per scenario the
+        layout of ``DynProgEnvironment.get_occ_map``), ``initial_states`` n LonStates, ``paths`` one
+        float32[path_steps, 7] shared by all or float32[n, path_steps, 7].  ``chunk`` scenarios are swept per
+        launch (value tables are allocated for that many)."""
+        ep = env_params
+        occ = np.ascontiguousarray(occ_maps, dtype=np.float32)
+        n = len(initial_states)
+        want = (n, ep.l_steps, ep.s_steps, ep.t_steps)
+        if occ.shape != want:
+            raise ValueError(f"array has incorrect shape, expected: {want}, got: {occ.shape}")
+        paths = np.ascontiguousarray(paths, dtype=np.float32)
+        if paths.ndim == 2:
+            paths = paths[None]
+        if paths.shape[1:] != (self.params.path_steps, 7) or paths.shape[0] not in (1, n):
+            raise ValueError(f"array has incorrect shape, expected: (1 or {n}, {self.params.path_steps}, 7), got: {paths.shape}")
+        inits = (TplLonState * n)()
+        for i, s in enumerate(initial_states):
+            C.memmove(C.byref(inits[i]), C.byref(s._c), C.sizeof(TplLonState))
+        check(self._lib.tplhip_dp_lon_scenarios_upload(self._h, n, _fptr(occ), C.byref(ep._c), inits, _fptr(paths),
+                                                       paths.shape[0], int(chunk)))
+        self._sc_n = n
+
+    def plan_scenarios(self, first=0, count=None, id_base=0, reset_best=True):
+        """Enqueue the plans of scenarios [first, first + count) (one launch per stage for all of them) and fold
+        their best plan into the device-side record."""
+        count = self._sc_n - first if count is None else count
+        check(self._lib.tplhip_dp_lon_scenarios_plan(self._h, int(first), int(count), int(id_base), 1 if reset_best else 0))
+
+    def download_scenarios(self):
+        n, T = self._sc_n, self.params.t_steps
+        out = (TplLonState * (n * T))()
+        check(self._lib.tplhip_dp_lon_scenarios_download(self._h, out))
+        return [LonTraj._from_array(out[i * T:(i + 1) * T]) for i in range(n)]
+
+    def best_record(self):
+        """The reduced record as numpy: (constr, cost, id, float32[t_steps, 7] states)."""
+        T = self.params.t_steps
+        buf = np.zeros(self._lib.tplhip_dp_lon_record_bytes(T), dtype=np.uint8)
+        check(self._lib.tplhip_dp_lon_scenarios_best(self._h, buf.ctypes.data_as(C.c_void_p)))
+        return (float(buf[0:4].view(np.float32)[0]), float(buf[4:8].view(np.float32)[0]), int(buf[8:12].view(np.int32)[0]),
+                buf[16:].view(np.float32).reshape(T, 7).copy())
+
+    def best_record_device(self):
+        """(device address, bytes) of the record -- for a collective that sends it straight from HBM."""
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        check(self._lib.tplhip_dp_lon_scenarios_best_device(self._h, C.byref(ptr), C.byref(nbytes)))
+        return ptr.value, nbytes.value
+
+    def copy_scenario_table(self, scenario, t):
+        p = self.params
+        out = np.empty((p.a_steps, p.v_steps, p.s_steps, 4), dtype=np.float32)
+        check(self._lib.tplhip_dp_lon_scenarios_copy_table(self._h, int(scenario), int(t), _fptr(out)))
+        return out
+
     def info(self):
         import json
         buf = C.create_string_buffer(512)

@@ -111,7 +111,7 @@ def template_hash():
 
 
 # bump when the emitted text for an unchanged problem changes (invalidates cached models)
-EMITTER_REVISION = "emit-6: deterministic order of batch members"
+EMITTER_REVISION = "emit-7: per-routine operation counts next to the model header"
 
 
 def _as_matrix(e):
@@ -355,12 +355,37 @@ def _fuse_sincos(subs, reduced):
     return new_subs, fused
 
 
-def _emit_exprs(flat, printer, lines, dest):
+# fp64 operations of the statements as emitted (SURVEY 8d asks for F_deriv / F_roll "counted by the generator"):
+# sympy's operation count of every assignment after common-subexpression elimination, plus fixed prices for the
+# two library-like pieces -- a fused sincos (Cody-Waite reduction + two minimax polynomials, csrc/ilqr/builtins.h)
+# and a table look-up (one shared index computation per batch, one two-tap blend per member).
+SINCOS_FLOPS = 38
+LOOKUP_SHARED_FLOPS = 6
+LOOKUP_MEMBER_FLOPS = 4
+
+
+def _count_flops(subs, reduced, fused, batches):
+    n = 0
+    for sym, e in subs:
+        n += SINCOS_FLOPS if sym in fused else 0
+        n += int(sp.count_ops(e))
+    for e in reduced:
+        n += int(sp.count_ops(e))
+    for b in batches:
+        n += LOOKUP_SHARED_FLOPS + LOOKUP_MEMBER_FLOPS * len(b["members"])
+    return n
+
+
+def _emit_exprs(flat, printer, lines, dest, counts=None):
     """CSE + sincos fusion + look-up batching + scheduling of a list of expressions; appends the
     statements to ``lines``; ``dest(i)`` is the lvalue that receives expression i."""
     subs, reduced = sp.cse(flat, symbols=sp.numbered_symbols("w"))
     subs, fused = _fuse_sincos(subs, reduced)
     subs, reduced, batches = _batch_lookups(subs, reduced)
+    if counts is not None:
+        counts["flops"] = _count_flops(subs, reduced, fused, batches)
+        counts["sincos"] = len(fused)
+        counts["lookups"] = sum(len(b["members"]) for b in batches)
     # schedule: the original order, every look-up batch as soon as its abscissa exists
     items = [("assign", sym, e) for sym, e in subs] + [("batch", b) for b in batches]
 
@@ -413,7 +438,7 @@ def _emit_exprs(flat, printer, lines, dest):
         lines.append(f"    {dest(i)} = {printer.doprint(e)};")
 
 
-def _emit_routine(name, m, cfg, printer):
+def _emit_routine(name, m, cfg, printer, counts=None):
     lines = [f"TPL_HD inline void {name}({_signature(name)}) {{"]
     # keep every argument "used" so -Wall stays quiet for trivial routines
     lines.append("    (void)P; (void)x; (void)t; (void)dt; (void)os;")
@@ -424,7 +449,7 @@ def _emit_routine(name, m, cfg, printer):
     n = m.shape[0] * m.shape[1]
     if n:
         flat = [_vectorise(sp.sympify(e), cfg) for e in m]               # row-major
-        _emit_exprs(flat, printer, lines, lambda i: f"out[{i}*os]")
+        _emit_exprs(flat, printer, lines, lambda i: f"out[{i}*os]", counts)
     lines.append("}")
     return "\n".join(lines)
 
@@ -673,6 +698,16 @@ def _array_checks(cfg, routines):
     return sorted(ndim.items()), sorted(same)
 
 
+_LAST_FLOPS = {}
+
+
+def routine_flops(name, out_dir=None):
+    """{routine: {"flops", "sincos", "lookups"}} of a generated model (written next to <name>.inc by generate())."""
+    import json
+    with open(model_paths(name, out_dir)["inc"][:-4] + ".flops.json") as fd:
+        return json.load(fd)
+
+
 def emit_model(cfg, name):
     """Text of model.inc for ``cfg``."""
     printer = _Printer()
@@ -708,9 +743,12 @@ def emit_model(cfg, name):
     out.append("#define TPL_NDIM_CHECKS " + ("{" + ", ".join(f"{{{i}, {n}}}" for i, n in nd) + ", {-1, 0}}" if nd else "{{-1, 0}}"))
     out.append("#define TPL_SAME_LEN_CHECKS " + ("{" + ", ".join(f"{{{a}, {b}}}" for a, b in same) + ", {-1, -1}}" if same else "{{-1, -1}}"))
     out.append("")
+    flops = {}
     for rname, m in routines:
-        out.append(_emit_routine(rname, m, cfg, printer))
+        flops[rname] = {"flops": 0, "sincos": 0, "lookups": 0}
+        out.append(_emit_routine(rname, m, cfg, printer, flops[rname]))
         out.append("")
+    _LAST_FLOPS[name] = flops
     # quad-cooperative form of the dynamics for the line-search rollouts (device only; the template
     # defines TPL_QUAD_ROUTINES before it includes this file, the CPU oracle does not)
     quad = None
@@ -760,6 +798,9 @@ def generate(cfg, name=None, out_dir=None, force=False):
     with open(tmp, "w") as fd:
         fd.write(text)
     os.replace(tmp, paths["inc"])
+    import json
+    with open(paths["inc"][:-4] + ".flops.json", "w") as fd:
+        json.dump(_LAST_FLOPS.get(name, {}), fd, indent=1, sort_keys=True)
     return paths["inc"]
 
 

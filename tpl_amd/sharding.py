@@ -34,6 +34,13 @@ def plan_record(traj_np, scenario_id):
     return np.concatenate([head, traj_np.astype(np.float64).ravel()])
 
 
+def record_from_device(rec):
+    """The device-side record of ``DynProgLonPlanner.best_record()`` -- (constr, cost, id, float32[t_steps, 7]) --
+    in the layout of ``plan_record``."""
+    constr, cost, rid, states = rec
+    return np.concatenate([np.array([constr, cost, float(rid)], dtype=np.float64), np.asarray(states, dtype=np.float64).ravel()])
+
+
 def better(a, b):
     """Lexicographic order of the planner itself (lon_planner.cu:153-170):
     smaller constraint violation first, then smaller cost, then smaller id."""
