@@ -3,20 +3,27 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One "step" = one complete DP plan on device-resident inputs: distance map,
-t_steps-1 backward stage sweeps over the (s,v,a) grid, one forward rollout.
-value = stage sweeps per second over the whole job (all ranks), timed over
-exactly K steps between barrier + device synchronize on both sides, max over
-ranks.  For N > 1 the plans (independent scenarios) are sharded across ranks,
-no data-path collective: "scaling": "weak".
+One "step" = one batch of PLANS_PER_STEP complete DP plans on device-resident inputs (each: distance map,
+t_steps-1 backward stage sweeps over the (s,v,a) grid, one forward rollout).  value = stage sweeps per second
+over the whole job (all ranks), timed over exactly K steps between barrier + device synchronize on both sides,
+max over ranks.  For N > 1 the plans (independent scenarios) are sharded across ranks with no data-path
+collective ("scaling": "weak"); the only exchange is ONE all-gather of the best-plan record at the end of the
+timed region.
 
-Also on the line: "roofline" (HBM, algorithmic 32 B/cell/sweep over the sweep
-kernel's HIP-event time), "cpu_baseline" (the CPU oracle timed on a bounded
-sample on rank 0), and "secondary" (batched iLQR iterations/s etc.).
+Launching: under `torch.distributed.run` (RANK / WORLD_SIZE in the environment) this process is one rank.  A
+plain `python bench.py --gpus N` with N > 1 starts the N ranks ITSELF -- child processes spawned before this
+process touches a GPU -- and relays rank 0's JSON line; when the box has fewer than N GPUs the ranks share
+device 0 and talk over gloo ("rehearsal": true in the line: it exercises the N > 1 code path, not scaling).
+
+Also on the line: "roofline" (HBM, algorithmic 32 B/cell/sweep over the sweep kernel's HIP-event time),
+"cpu_baseline" (the CPU oracle, built -O3 -march=native on this host, timed on a bounded sample on rank 0),
+and "secondary": the 8192-rollout Monte-Carlo workload of BASELINE configs[4] (1024 scenarios per GPU,
+device-side reduction, one all-gather), batched iLQR iterations/s with its roofline block, plan latencies.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,11 +33,101 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_CELL = 32            # read next float4 + write this float4
+PLANS_PER_STEP = 24            # one step = one batch of plans (keeps the timed region of 20 steps above a second)
+MC_PER_GPU = 1024              # BASELINE configs[4]: 8192 Monte-Carlo rollouts on 8 GPUs
+MC_CHUNK = 64                  # scenarios swept per launch (value tables for that many: 64 x 157 MB)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines: the oracle (test infrastructure) timed as a baseline, never the product.  The DP and iLQR
+# restatements are rebuilt here, on the host that is timed, with -O3 -march=native (oracle/Makefile, `_native/`):
+# same source and results as the checker the tests use, compiler flags for speed.
+# ------------------------------------------------------------------------------------------------
+
+def _native_oracle(target):
+    """Build oracle/_native/<target> on this host; returns its path or None (then the -O2 checker is timed)."""
+    try:
+        subprocess.check_call(["make", "-B", "-C", os.path.join(ROOT, "oracle"), f"_native/{target}"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return os.path.join(ROOT, "oracle", "_native", target)
+    except (subprocess.CalledProcessError, OSError):
+        return None
+
+
+def dp_cpu_baseline(p, ep, path, occ, budget_s=12.0):
+    """Whole stage sweeps of the same grid on all host cores until ~budget_s of wall time is spent."""
+    import ctypes as C
+    import numpy as np
+    import oracle_dp as O
+    native = _native_oracle("libdp_lon_oracle.so")
+    O.use(native)
+    try:
+        cp, cep = O.cparams(p), O.cparams(ep)
+        dist = O.dist_map_path(cep, occ, path, cp.path_steps, cp.path_step_size)
+        tf = int(O.lib().dpo_table_floats(C.byref(cp)))
+        a = np.zeros(tf, dtype=np.float32)
+        b = np.zeros(tf, dtype=np.float32)
+        T = cp.t_steps
+        O.lib().dpo_backward_stage(C.byref(cp), C.byref(cep), T - 1, O.fptr(a), O.fptr(a), O.fptr(path), O.fptr(dist), 0)
+        n = 0
+        t0 = time.perf_counter()
+        while True:
+            O.lib().dpo_backward_stage(C.byref(cp), C.byref(cep), T - 2, O.fptr(a), O.fptr(b), O.fptr(path), O.fptr(dist), 0)
+            a, b = b, a
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 200:
+                break
+        cores = int(O.lib().dpo_max_threads())
+    finally:
+        O.use(None)
+    return {"value": n / el, "unit": "stage-sweeps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full stage sweeps of the same {cp.s_steps}x{cp.v_steps}x{cp.a_steps} grid "
+                      f"(oracle/dp_lon_oracle.c, OpenMP over rows, "
+                      f"{'-O3 -march=native build of this host' if native else '-O2 checker build'})"}
+
+
+def ilqr_cpu_baseline(x0, horizon, budget_s, workload="mpc"):
+    """The CPU oracle on a bounded sample of the same problems, all host cores (OpenMP over problems); reset +
+    solve are timed inside the C library."""
+    import ctypes as C
+    import numpy as np
+    import oracle_ilqr as OI
+    from tpl_amd.optim import bench_ilqr
+    problem = bench_ilqr.WORKLOADS[workload]["problem"]
+    native = _native_oracle(f"libilqr_oracle_{problem}.so")
+    lib = OI.load(problem, path=native) if native else OI.load(problem)
+    cores = int(lib.ilqo_max_threads())
+    n = len(x0)
+    opts = []
+    for b in range(n):
+        r = OI.OracleOptim(problem, t_cap=horizon, lib=lib)
+        r.horizon = horizon
+        if workload == "mpc":
+            bench_ilqr._configure(r, x0[b])
+        else:
+            bench_ilqr._configure_lateral(r, x0[b], horizon)
+        opts.append(r)
+    hs = (C.c_void_p * n)(*[r._h for r in opts])
+    x0c = np.ascontiguousarray(x0, dtype=np.float64)
+    px = x0c.ctypes.data_as(C.POINTER(C.c_double))
+    lib.ilqo_reset_and_update_many(hs, n, px, 1, 0)              # warm-up, also calibrates
+    t0 = time.perf_counter()
+    lib.ilqo_reset_and_update_many(hs, n, px, 1, 0)
+    one = time.perf_counter() - t0
+    reps = max(1, min(200, int(budget_s / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    lib.ilqo_reset_and_update_many(hs, n, px, reps, 0)
+    el = time.perf_counter() - t0
+    iters = opts[0].iterations
+    return {"value": reps * iters / el, "unit": f"batched iLQR iterations/s ({n}-problem batch)",
+            "problem_iterations_per_s": reps * n * iters / el, "cores": cores, "kind": "port",
+            "sample": f"{reps} x the same {n} problems x {iters} iterations (oracle/ilqr_oracle.cpp, OpenMP over "
+                      f"problems, {'-O3 -march=native build of this host' if native else '-O2 checker build'})"}
 
 
 def env_cpu_baseline(reps=20):
-    """The occupancy-pipeline oracle (oracle/dp_env_oracle.c, one thread) on the scene of
-    latency.env_update -- the checker timed as a baseline, never the product."""
+    """oracle/dp_env_oracle.c (one thread) on the scene of latency.env_update."""
     import numpy as np
     import oracle_env as oe
     from tpl_amd import scenarios
@@ -128,6 +225,10 @@ def mpc_cpu_baseline(ticks=300, horizon=20):
             "p99_ms": float(np.percentile(lat, 99)), "sample": f"{len(lat)} ticks of the same closed loop"}
 
 
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+
 def dp_setup(grid, device):
     import tpl_amd
     from tpl_amd import scenarios as sc
@@ -145,50 +246,143 @@ def dp_setup(grid, device):
     return dp, env, p, ep, path, occ
 
 
-def dp_cpu_baseline(p, ep, path, occ, budget_s=12.0):
-    """CPU oracle (port) on a bounded sample: whole stage sweeps of the same
-    grid, all host cores, until ~budget_s of wall time is spent."""
-    import ctypes as C
+def sweep_kernel_name(info):
+    if info.get("v3"):
+        return "k_backward3v"
+    if info.get("cells") == 2:
+        return "k_backward2v" if info.get("vpair") else "k_backward2"
+    return "k_backward"
+
+
+def mc_scenarios(ep, first, n):
+    """Monte-Carlo scenarios [first, first + n) of the 8192-rollout workload: perturbed initial state and an own
+    set of moving obstacles per scenario id (seeded by the id, so every rank count gives the same scenarios)."""
     import numpy as np
-    import oracle_dp as O
-    cp, cep = O.cparams(p), O.cparams(ep)
-    dist = O.dist_map_path(cep, occ, path, cp.path_steps, cp.path_step_size)
-    tf = int(O.lib().dpo_table_floats(C.byref(cp)))
-    a = np.zeros(tf, dtype=np.float32)
-    b = np.zeros(tf, dtype=np.float32)
-    T = cp.t_steps
-    O.lib().dpo_backward_stage(C.byref(cp), C.byref(cep), T - 1, O.fptr(a), O.fptr(a), O.fptr(path), O.fptr(dist), 0)
-    n = 0
+    from tpl_amd import scenarios as sc
+    occs = np.empty((n, ep.l_steps, ep.s_steps, ep.t_steps), dtype=np.float32)
+    inits = []
+    for i in range(n):
+        sid = first + i
+        rng = np.random.default_rng(77000 + sid)
+        k = int(rng.integers(2, 7))
+        obst = tuple((float(a), float(b), 4.0) for a, b in zip(rng.uniform(30.0, 180.0, k), rng.uniform(0.0, 10.0, k)))
+        occs[i] = sc.occ_map(ep, obst)
+        inits.append(sc.initial_state(0.0, float(rng.uniform(2.0, 14.0)), float(rng.uniform(-1.0, 1.0))))
+    return occs, inits
+
+
+class _DeviceBytes:
+    """Zero-copy view of device memory for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_chunks=2):
+    """BASELINE configs[4]: 1024 scenario rollouts per GPU on the 128x64x32x50 grid, swept MC_CHUNK scenarios per
+    launch; per-rank lexicographic (constr, cost, id) reduction on the device; ONE all-gather of the 1416-byte
+    record straight from HBM; identical argmin on every rank."""
+    import numpy as np
+    import torch
+    import tpl_amd
+    from tpl_amd import scenarios as sc, sharding
+    S, V, A, T = sc.GRIDS["config2"]
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    n_total = MC_PER_GPU * world
+    lo, hi = sharding.shard_range(n_total, rank, world)
+    occs, inits = mc_scenarios(ep, lo, hi - lo)
+    dp = tpl_amd.DynProgLonPlanner(device)
+    dp.reinit_buffers(p)
+    dp.upload_scenarios(occs, ep, inits, path, chunk=MC_CHUNK)
+    del occs
+    n = hi - lo
+
+    def one_pass():
+        for first in range(0, n, MC_CHUNK):
+            dp.plan_scenarios(first, min(MC_CHUNK, n - first), id_base=lo, reset_best=(first == 0))
+
+    for c in range(warmup_chunks):
+        dp.plan_scenarios(c * MC_CHUNK, min(MC_CHUNK, n - c * MC_CHUNK), id_base=lo, reset_best=True)
+    dp.sync()
+    dp.timing_enable(True)
+    barrier()
     t0 = time.perf_counter()
-    while True:
-        O.lib().dpo_backward_stage(C.byref(cp), C.byref(cep), T - 2, O.fptr(a), O.fptr(b), O.fptr(path), O.fptr(dist), 0)
-        a, b = b, a
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 200:
-            break
-    cores = int(O.lib().dpo_max_threads())
-    return {"value": n / el, "unit": "stage-sweeps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} full stage sweeps of the same {cp.s_steps}x{cp.v_steps}x{cp.a_steps} grid "
-                      f"(oracle/dp_lon_oracle.c, OpenMP over rows)"}
+    for _ in range(steps):
+        one_pass()
+    # the one exchange of the path: every rank's record -> all ranks, sent from device memory
+    ptr, nbytes = dp.best_record_device()                    # synchronises this rank's stream
+    if dist is not None:
+        mine = torch.as_tensor(_DeviceBytes(ptr, nbytes), device=torch.device("cuda", device))
+        if rehearsal:
+            mine = mine.cpu()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        recs = [g.cpu().numpy() for g in gathered]
+    else:
+        recs = [dp.best_record_bytes()]
+    barrier()
+    el = time.perf_counter() - t0
+    sweep_ms, launches = dp.timing_get()
+    dp.timing_enable(False)
+
+    def key(r):
+        return (float(r[0:4].view(np.float32)[0]), float(r[4:8].view(np.float32)[0]), int(r[8:12].view(np.int32)[0]))
+    best = min(recs, key=key)
+    bk = key(best)
+    identical = True
+    if dist is not None:
+        ids = torch.tensor([bk[2], -bk[2]], dtype=torch.int64, device="cpu" if rehearsal else torch.device("cuda", device))
+        dist.all_reduce(ids, op=dist.ReduceOp.MAX)
+        identical = int(ids[0].item()) == bk[2] and int(-ids[1].item()) == bk[2]
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else torch.device("cuda", device))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    cells = S * V * A
+    per_launch_s = (sweep_ms / 1e3) / max(1, launches)
+    achieved = MC_CHUNK * cells * BYTES_PER_CELL / per_launch_s / 1e9
+    return {
+        "metric": "dp_stage_sweeps_per_s", "unit": "stage-sweeps/s (one sweep = one stage of one scenario)",
+        "value": steps * n_total * (T - 1) / el, "n_gpus": world, "scaling": "weak",
+        "rollouts": n_total, "rollouts_per_gpu": MC_PER_GPU, "rollouts_per_s": steps * n_total / el,
+        "ms_per_pass": el / steps * 1e3, "passes": steps,
+        "config": {"workload": f"{n_total} Monte-Carlo scenario rollouts (perturbed initial state + own moving obstacles), "
+                               f"DP grid {S}x{V}x{A}, {T} stages, {MC_CHUNK} scenarios per launch, device-side "
+                               "(constr, cost, id) reduction, one all-gather of the best-plan record",
+                   "grid": [S, V, A], "t_steps": T},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": dp.info().get("scenario_kernel", "k_backward"),
+                     "launch_us": per_launch_s * 1e6, "scenarios_per_launch": MC_CHUNK,
+                     "algorithmic_bytes_per_launch": MC_CHUNK * cells * BYTES_PER_CELL, "rank": rank},
+        "best_plan": {"constr": bk[0], "cost": bk[1], "id": bk[2], "identical_on_all_ranks": bool(identical)},
+        "record_bytes": int(nbytes),
+    }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--grid", default="target", help="target (256x128x64, default) | config2 | config4 | default")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true")
-    args = ap.parse_args()
+def traffic_block(out, p, cells, per_launch_s):
+    """L2<->fabric bytes per sweep launch from the committed PMC pass of this kernel (rocprofv3 cannot run inside the
+    timed process; profiles/README.md has the command)."""
+    for f in ("r02_dp_traffic.json", "r01_dp_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f)) as fd:
+                tr = json.load(fd).get(f"{p.s_steps}x{p.v_steps}x{p.a_steps}")
+        except OSError:
+            continue
+        if tr and tr.get("kernel", out["roofline"]["kernel"]) == out["roofline"]["kernel"]:
+            out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = f"profiles/{f} (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+            return
 
+
+def worker(args):
+    import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # Rehearsal hook for a one-GPU box: TPL_BENCH_REHEARSAL=1 runs the N > 1 code path with every rank on
-    # device 0 and the all-gather over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
+    # Rehearsal: the N > 1 code path on a box with fewer GPUs than ranks -- every rank on device 0, collectives over
+    # gloo (RCCL refuses two ranks on one device).  Set by the launcher below, never by the driver's torchrun.
     rehearsal = world > 1 and os.environ.get("TPL_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
@@ -205,36 +399,20 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
 
+    from tpl_amd import sharding
     dp, env, p, ep, path, occ = dp_setup(args.grid, local_rank)
     cells = p.s_steps * p.v_steps * p.a_steps
-    sweeps_per_step = p.t_steps - 1
+    sweeps_per_plan = p.t_steps - 1
+    plans_per_step = 2 if args.grid == "config4" else PLANS_PER_STEP
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    from tpl_amd import sharding
-    import numpy as np
-
-    # N > 1: the path's only exchange is the best-plan record of every rank -> all ranks (RCCL
-    # all-gather of 1.4 KB).  It is pipelined one step deep: the plan of step k is copied
-    # out behind its kernels, and gathered while the GPU already runs step k+1.
-    def exchange(slot):
-        tr = np.array([[s.t, s.s, s.v, s.a, s.j, s.cost, s.constr] for s in dp.collect_download(slot)[0].states],
-                      dtype=np.float32)
-        sharding.allgather_best(sharding.plan_record(tr, rank), dist,
-                                torch.device("cpu") if rehearsal else torch.device("cuda", local_rank))
-
-    def run(n):
-        for k in range(n):
+    def run(n_steps):
+        for _ in range(n_steps * plans_per_step):
             dp.plan_resident(env)
-            if dist is not None:
-                dp.stage_download(k & 1)
-                if k > 0:
-                    exchange((k - 1) & 1)
-        if dist is not None and n > 0:
-            exchange((n - 1) & 1)
 
     run(args.warmup)
     dp.sync()
@@ -242,7 +420,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
-    dp.sync()
+    # N > 1: the path's only exchange -- ONE all-gather of every rank's best-plan record (1.4 KB),
+    # followed by the same lexicographic argmin on every rank
+    traj = dp.download()[0]
+    rec = sharding.plan_record(np.array([[s.t, s.s, s.v, s.a, s.j, s.cost, s.constr] for s in traj.states], dtype=np.float32), rank)
+    best = sharding.allgather_best(rec, dist, torch.device("cpu") if rehearsal else torch.device("cuda", local_rank))
     barrier()
     elapsed = time.perf_counter() - t0
     sweep_ms, sweep_launches = dp.timing_get()
@@ -253,16 +435,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    total_sweeps = sweeps_per_step * args.steps * world
-    value = total_sweeps / elapsed
-
+    total_sweeps = sweeps_per_plan * plans_per_step * args.steps * world
     out = None
     if rank == 0:
         per_launch_s = (sweep_ms / 1e3) / max(1, sweep_launches)
         achieved = cells * BYTES_PER_CELL / per_launch_s / 1e9
         out = {
             "metric": "dp_stage_sweeps_per_s",
-            "value": value,
+            "value": total_sweeps / elapsed,
             "unit": "stage-sweeps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -275,79 +455,118 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"DP (s,v,a) planner, {p.s_steps}x{p.v_steps}x{p.a_steps} grid, "
-                            f"{p.t_steps} stages, straight 200 m path, 5 moving obstacles; "
-                            f"one step = dist map + {sweeps_per_step} backward sweeps + forward rollout",
+                            f"{p.t_steps} stages, straight 200 m path, 5 moving obstacles; one step = {plans_per_step} plans, "
+                            f"each dist map + {sweeps_per_plan} backward sweeps + forward rollout",
                 "grid": [p.s_steps, p.v_steps, p.a_steps], "t_steps": p.t_steps,
-                "plans_per_step_per_gpu": 1,
-                "parallelism": f"independent plans x{world}" + (", all-gather of the best plan per step" if world > 1 else ""),
+                "plans_per_step_per_gpu": plans_per_step, "ms_per_plan": elapsed / args.steps / plans_per_step * 1e3,
+                "parallelism": f"independent plans x{world}" + (", one all-gather of the best plan" if world > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": ("k_backward2v" if dp.info().get("vpair") else "k_backward2") if dp.info().get("cells") == 2
-                          else "k_backward",
+                "kernel": sweep_kernel_name(dp.info()),
                 "launch_us": per_launch_s * 1e6,
                 "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
             },
         }
-        # L2<->fabric bytes per sweep launch from the committed PMC pass of this kernel (rocprofv3
-        # cannot run inside the timed process; see profiles/README.md for the command)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_dp_traffic.json")) as fd:
-                tr = json.load(fd).get(f"{p.s_steps}x{p.v_steps}x{p.a_steps}")
-            if tr:
-                out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r01_dp_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
-                # what actually binds the sweep: VALU issue.  Instructions per wave from the same PMC
-                # passes (SQ_INSTS_VALU / SQ_WAVES), 4 cycles per wave instruction, 1024 SIMDs, against the
-                # measured launch time at the 2.4 GHz peak clock (the real clock under this load is lower,
-                # so the true fraction is higher).  Informative; `frac` above stays the prescribed HBM one.
-                if out["roofline"]["kernel"] in ("k_backward2v", "k_backward2") and tr.get("valu_insts_per_wave"):
-                    waves = cells / 128.0
-                    busy = tr["valu_insts_per_wave"] * waves * 4.0 / 1024.0
-                    out["roofline"]["valu_issue"] = {
-                        "insts_per_wave": tr["valu_insts_per_wave"], "waves_per_launch": waves,
-                        "busy_cycles_per_simd": busy, "launch_cycles_at_2.4GHz": per_launch_s * 2.4e9,
-                        "frac": busy / (per_launch_s * 2.4e9)}
-        except OSError:
-            pass
+        if rehearsal:
+            out["rehearsal"] = True
+            out["note"] = f"{world} ranks share ONE device over gloo: exercises the N > 1 code path, says nothing about scaling"
+        if world > 1:
+            out["best_plan"] = {"constr": float(best[0]), "cost": float(best[1]), "rank": int(best[2])}
+        traffic_block(out, p, cells, per_launch_s)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = dp_cpu_baseline(p, ep, path, occ)
-        if not args.no_secondary and world == 1:
-            from tpl_amd import latency
-            from tpl_amd.optim import bench_ilqr
-            out["secondary"] = {"batched_ilqr": bench_ilqr.run(local_rank),
-                                "plan_latency": latency.run(local_rank)}
-            out["secondary"]["plan_latency"]["mpc_closed_loop"]["cpu_baseline"] = mpc_cpu_baseline()
-            out["secondary"]["plan_latency"]["env_update"]["cpu_baseline"] = env_cpu_baseline()
-            out["secondary"]["plan_latency"]["poly_lat_update"]["cpu_baseline"] = poly_lat_cpu_baseline()
-            out["secondary"]["plan_latency"]["lat_lon_update"]["cpu_baseline"] = lat_lon_cpu_baseline()
-            out["secondary"]["batched_ilqr"].pop("best_record", None)
+    del dp, env
 
-    # N > 1: the batched iLQR shards the same way -- every rank solves its own block of 1024 initial
-    # states (seed = rank), the timed region is barrier-bracketed and the MAX over ranks, and the only
-    # exchange is the all-gather of each rank's best {cost, id, x, u} record.
-    if not args.no_secondary and world > 1:
+    secondary = {}
+    if not args.no_secondary:
+        # BASELINE configs[4] at this job size: 1024 rollouts per GPU
+        mc = mc_rollouts(local_rank, rank, world, dist, rehearsal, barrier)
         from tpl_amd.optim import bench_ilqr
-        res = bench_ilqr.run(local_rank, cpu_budget_s=0, seed=rank, barrier=barrier, id_offset=rank * 1024)
-        dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
-        t = torch.tensor([res["elapsed_s"]], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        best = sharding.allgather_best(res.pop("best_record"), dist, dev)
-        if rank == 0:
-            el = float(t.item())
-            res["value"] = world * res["updates"] * res["iterations_per_update"] / el
-            res["problem_iterations_per_s"] = res["value"] * res["config"]["batch"]
-            res["ms_per_update"] = el / res["updates"] * 1e3
-            res["n_gpus"] = world
-            res["config"]["parallelism"] = f"{world} x 1024 independent problems, all-gather of the best plan"
-            res["best_plan"] = {"cost": float(best[1]), "id": int(best[2])}
-            out["secondary"] = {"batched_ilqr": res}
+        il = bench_ilqr.run(local_rank, seed=rank, barrier=barrier if world > 1 else None, id_offset=rank * 1024)
+        lat = bench_ilqr.run(local_rank, seed=rank, barrier=barrier if world > 1 else None, id_offset=rank * 1024,
+                             workload="lateral", updates=20)
+        x0_mpc, x0_lat = il.pop("x0"), lat.pop("x0")
+        if world > 1:
+            dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
+            for res in (il, lat):
+                t = torch.tensor([res["elapsed_s"]], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                bestp = sharding.allgather_best(res.pop("best_record"), dist, dev)
+                el = float(t.item())
+                res["value"] = world * res["updates"] * res["iterations_per_update"] / el
+                res["problem_iterations_per_s"] = res["value"] * res["config"]["batch"]
+                res["ms_per_update"] = el / res["updates"] * 1e3
+                res["n_gpus"] = world
+                res["config"]["parallelism"] = f"{world} x {res['config']['batch']} independent problems, one all-gather of the best plan"
+                res["best_plan"] = {"cost": float(bestp[1]), "id": int(bestp[2])}
+                res["roofline"]["rank"] = rank
+        il.pop("best_record", None)
+        lat.pop("best_record", None)
+        secondary = {"mc_rollouts": mc, "batched_ilqr": il, "batched_ilqr_lateral_profile": lat}
+        if rank == 0 and world == 1:
+            if not args.no_cpu_baseline:
+                il["cpu_baseline"] = ilqr_cpu_baseline(x0_mpc, 50, 10.0, "mpc")
+                lat["cpu_baseline"] = ilqr_cpu_baseline(x0_lat, 250, 6.0, "lateral")
+            from tpl_amd import latency
+            secondary["plan_latency"] = latency.run(local_rank)
+            if not args.no_cpu_baseline:
+                pl = secondary["plan_latency"]
+                pl["mpc_closed_loop"]["cpu_baseline"] = mpc_cpu_baseline()
+                pl["env_update"]["cpu_baseline"] = env_cpu_baseline()
+                pl["poly_lat_update"]["cpu_baseline"] = poly_lat_cpu_baseline()
+                pl["lat_lon_update"]["cpu_baseline"] = lat_lon_cpu_baseline()
     if rank == 0:
+        if secondary:
+            out["secondary"] = secondary
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launcher(args, argv):
+    """`python bench.py --gpus N` without torchrun: start the N ranks as CHILD processes (this process never
+    initialises the GPU: device_count() does not, and nothing else here touches HIP), wait, relay rank 0's line."""
+    import socket
+    import torch
+    n_dev = torch.cuda.device_count()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if n_dev < args.gpus:
+            env["TPL_BENCH_REHEARSAL"] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for pr in procs[1:]:
+        rc = max(rc, pr.wait())
+    # ONE JSON line on stdout: rank 0's (gloo announces its connections on stdout in the rehearsal set-up)
+    lines = [ln for ln in out.decode("utf8", "replace").splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    return rc if lines else max(rc, 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", default="target", help="target (256x128x64, default) | config2 | config4 | default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launcher(args, sys.argv[1:]))
+    worker(args)
 
 
 if __name__ == "__main__":

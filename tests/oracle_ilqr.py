@@ -26,12 +26,15 @@ ALIASES = {"step": "dt", "T": "horizon", "elapsed_update_time": "runtime"}
 _libs = {}
 
 
-def load(model):
-    if model in _libs:
-        return _libs[model]
-    path = os.path.join(ORACLE_DIR, f"libilqr_oracle_{model}.so")
-    if not os.path.exists(path):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, os.path.basename(path)])
+def load(model, path=None):
+    """``path``: another build of the same restatement (bench.py's -O3 -march=native baseline build)."""
+    key = (model, path)
+    if key in _libs:
+        return _libs[key]
+    if path is None:
+        path = os.path.join(ORACLE_DIR, f"libilqr_oracle_{model}.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, os.path.basename(path)])
     lib = C.CDLL(path)
     lib.ilqo_create.restype = C.c_void_p
     lib.ilqo_create.argtypes = [C.c_int]
@@ -53,7 +56,7 @@ def load(model):
     lib.ilqo_ct_dynamics.argtypes = [C.c_void_p, dptr, dptr, C.c_int, C.c_double, dptr]
     lib.ilqo_update_many.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
     lib.ilqo_reset_and_update_many.argtypes = [C.POINTER(C.c_void_p), C.c_int, dptr, C.c_int, C.c_int]
-    _libs[model] = lib
+    _libs[key] = lib
     return lib
 
 
@@ -90,8 +93,8 @@ _Params.__slots__ = property(lambda self: list(self._o._pnames))
 class OracleOptim:
     EULER, HEUN, RK4 = 0, 1, 2
 
-    def __init__(self, model, t_cap=299):
-        lib = load(model)
+    def __init__(self, model, t_cap=299, lib=None):
+        lib = lib or load(model)
         object.__setattr__(self, "_lib", lib)
         object.__setattr__(self, "_tcap", t_cap)
         object.__setattr__(self, "_h", lib.ilqo_create(t_cap))

@@ -1,6 +1,6 @@
-"""N > 1 path on CPU: world_size-2 gloo processes shard a set of scenarios, each
-rank reduces its block to a best-plan record, one all-gather, identical global
-argmin on every rank."""
+"""N > 1 path on CPU: world_size-2 gloo processes shard a set of scenarios, each rank plans its block (here with the
+CPU oracle -- the HIP planner needs a GPU; tests/test_dp_scenarios_gpu.py checks that its device-side record equals
+this host-side reduction), reduces it to a best-plan record, one all-gather, identical global argmin on every rank."""
 import os
 import socket
 import sys
@@ -13,15 +13,28 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+GRID = (33, 9, 7, 5)          # s, v, a, stages: an oracle plan takes milliseconds
 
-def _fake_plan(sid, t_steps=6):
-    """Stand-in for one planner result (the HIP planner needs a GPU): a
-    deterministic float32[t_steps, 7] trajectory whose cost/constr depend on the id."""
-    rng = np.random.default_rng(1000 + sid)
-    tr = rng.uniform(0, 1, size=(t_steps, 7)).astype(np.float32)
-    tr[:, 6] = 0.0 if sid % 3 else 0.5          # every third scenario violates a constraint
-    tr[0, 5] = 50.0 + ((sid * 37) % 17)          # plan cost
-    return tr
+
+def _scenario(sid):
+    """Scenario `sid` of a small Monte-Carlo set: own obstacles and initial state, seeded by the id."""
+    from tpl_amd import scenarios as sc
+    S, V, A, T = GRID
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=101, l_steps=21)
+    rng = np.random.default_rng(4000 + sid)
+    obst = () if sid % 5 == 0 else sc.random_obstacles(seed=sid, k=2 + sid % 3)
+    init = sc.initial_state(0.0, float(rng.uniform(2.0, 14.0)), float(rng.uniform(-1.0, 1.0)))
+    return p, ep, sc.straight_path(p.path_steps, p.path_step_size), sc.occ_map(ep, obst), init
+
+
+def _oracle_record(sid):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_dp as O
+    from tpl_amd import sharding
+    p, ep, path, occ, init = _scenario(sid)
+    _, trajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, [init], nthreads=1, keep_tables=False)
+    return sharding.plan_record(trajs[0], sid)
 
 
 def _worker(rank, world, port, n, q):
@@ -31,7 +44,7 @@ def _worker(rank, world, port, n, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = sharding.shard_range(n, rank, world)
-    best = sharding.local_best([sharding.plan_record(_fake_plan(i), i) for i in range(lo, hi)])
+    best = sharding.local_best([_oracle_record(i) for i in range(lo, hi)])
     glob = sharding.allgather_best(best, dist)
     q.put((rank, lo, hi, glob))
     dist.barrier()
@@ -55,31 +68,76 @@ def test_shard_range_partitions_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+    assert [sharding.shard_range(8192, r, 8) for r in (0, 7)] == [(0, 1024), (7168, 8192)]
 
 
-def test_two_rank_allgather_of_best_plan():
+def test_two_rank_allgather_of_the_best_oracle_plan():
     sys.path.insert(0, ROOT)
     from tpl_amd import sharding
-    n, world = 37, 2
+    n, world = 23, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in range(world)]
+    results = [q.get(timeout=180) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    serial = sharding.local_best([sharding.plan_record(_fake_plan(i), i) for i in range(n)])
+    records = [_oracle_record(i) for i in range(n)]
+    serial = sharding.local_best(records)
     for rank, lo, hi, glob in results:
         assert np.array_equal(glob, serial), rank
-    assert serial[0] == 0.0                      # a constraint-free plan wins over any cheaper violating one
+    # the record really is a plan: id, validity measure and value of the winning trajectory
+    T = GRID[3]
+    traj = serial[3:].reshape(T, 7)
+    assert serial[0] == np.max(traj[1:-1, 6]) and serial[1] == traj[0, 5] and 0 <= serial[2] < n
+    assert len({(r[0], r[1]) for r in records}) > n // 2          # the scenarios are really different plans
+    assert all(not sharding.better(r, serial) for r in records)
     spans = sorted((lo, hi) for _, lo, hi, _ in results)
     assert spans[0][0] == 0 and spans[-1][1] == n and spans[0][1] == spans[1][0]
 
 
+def test_order_is_constraint_then_cost_then_id():
+    from tpl_amd import sharding
+    T = 4
+    base = np.zeros((T, 7), dtype=np.float32)
+
+    def rec(constr, cost, sid):
+        tr = base.copy()
+        tr[1, 6] = constr
+        tr[0, 5] = cost
+        return sharding.plan_record(tr, sid)
+    assert sharding.better(rec(0.0, 9.0, 5), rec(0.1, 1.0, 0))          # a feasible plan beats any cheaper violating one
+    assert sharding.better(rec(0.0, 1.0, 5), rec(0.0, 2.0, 0))
+    assert sharding.better(rec(0.0, 1.0, 3), rec(0.0, 1.0, 4))          # ties: lowest id, like the planner's lowest action
+    assert not sharding.better(rec(0.0, 1.0, 3), rec(0.0, 1.0, 3))
+    # first and last state do not count towards the validity measure (poly_lat_dp_lon_planner.py:99-101)
+    tr = base.copy()
+    tr[0, 6] = 7.0
+    tr[-1, 6] = 7.0
+    assert sharding.plan_record(tr, 0)[0] == 0.0
+
+
+def test_device_record_layout_decodes_to_the_host_record():
+    """TplDpPlanRecord + TplLonState[t_steps] as the device writes it (include/tplhip.h) -> plan_record layout."""
+    from tpl_amd import sharding
+    T = GRID[3]
+    want = _oracle_record(3)
+    traj = want[3:].reshape(T, 7).astype(np.float32)
+    raw = np.zeros(16 + 28 * T, dtype=np.uint8)
+    raw[0:4] = np.array([want[0]], np.float32).view(np.uint8)
+    raw[4:8] = np.array([want[1]], np.float32).view(np.uint8)
+    raw[8:12] = np.array([3], np.int32).view(np.uint8)
+    raw[12:16] = np.array([T], np.int32).view(np.uint8)
+    raw[16:] = traj.view(np.uint8).ravel()
+    got = sharding.record_from_device((float(raw[0:4].view(np.float32)[0]), float(raw[4:8].view(np.float32)[0]),
+                                       int(raw[8:12].view(np.int32)[0]), raw[16:].view(np.float32).reshape(T, 7)))
+    assert np.array_equal(got, want)
+
+
 def test_single_process_skips_the_collective():
     from tpl_amd import sharding
-    rec = sharding.plan_record(_fake_plan(3), 3)
+    rec = _oracle_record(3)
     assert sharding.allgather_best(rec, None) is rec

@@ -2024,12 +2024,12 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
     std::snprintf(buf, (size_t)n,
                   "{\"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
                   "\"div_mode\": %d, \"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"cells\": %d, "
-                  "\"bounded_inputs\": %d, \"vpair\": %d, \"v3\": %d, \"path_div3\": %d, \"range_div3\": %d}",
+                  "\"bounded_inputs\": %d, \"vpair\": %d, \"v3\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\"}",
                   h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
                   h->div_mode, (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->cells,
                   (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0, (h->cells == 2 && h->vpair) ? 1 : 0,
                   (h->cells == 2 && h->vpair && use_v3(h) && h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
-                  h->path_div3, h->range_div3);
+                  h->path_div3, h->range_div3, (h->vp_ok && use_v3(h) && h->sc_bounded) ? "k_backward3v" : "k_backward");
     return TPLHIP_OK;
 }
 

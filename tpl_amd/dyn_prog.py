@@ -406,13 +406,17 @@ class DynProgLonPlanner:
         check(self._lib.tplhip_dp_lon_scenarios_download(self._h, out))
         return [LonTraj._from_array(out[i * T:(i + 1) * T]) for i in range(n)]
 
+    def best_record_bytes(self):
+        """The reduced record as it sits in device memory: TplDpPlanRecord + TplLonState[t_steps] (uint8 array)."""
+        buf = np.zeros(self._lib.tplhip_dp_lon_record_bytes(self.params.t_steps), dtype=np.uint8)
+        check(self._lib.tplhip_dp_lon_scenarios_best(self._h, buf.ctypes.data_as(C.c_void_p)))
+        return buf
+
     def best_record(self):
         """The reduced record as numpy: (constr, cost, id, float32[t_steps, 7] states)."""
-        T = self.params.t_steps
-        buf = np.zeros(self._lib.tplhip_dp_lon_record_bytes(T), dtype=np.uint8)
-        check(self._lib.tplhip_dp_lon_scenarios_best(self._h, buf.ctypes.data_as(C.c_void_p)))
+        buf = self.best_record_bytes()
         return (float(buf[0:4].view(np.float32)[0]), float(buf[4:8].view(np.float32)[0]), int(buf[8:12].view(np.int32)[0]),
-                buf[16:].view(np.float32).reshape(T, 7).copy())
+                buf[16:].view(np.float32).reshape(self.params.t_steps, 7).copy())
 
     def best_record_device(self):
         """(device address, bytes) of the record -- for a collective that sends it straight from HBM."""

@@ -1,9 +1,14 @@
-"""Batched iLQR measurement (BASELINE configs[2]): 1024 random initial states,
-kinematic single-track tracking MPC (trajectory_tracking_mpc, X=7 U=2 C=4),
-HEUN, N = 50, dt = 0.05, 20 iterations per update with min_rel_cost_change = 0
-(every problem runs every iteration), device-resident.  One "batched iteration"
-= one pass of the iLQR loop body (derivative refresh + backward pass + line
-search) for every problem of the batch."""
+"""Batched iLQR measurement, GPU leg only (the CPU-oracle baseline lives in bench.py: nothing under tpl_amd/
+touches oracle/ or tests/).
+
+* ``mpc`` (BASELINE configs[2]): 1024 random initial states, kinematic single-track tracking MPC
+  (trajectory_tracking_mpc, X=7 U=2 C=4), HEUN, N = 50, dt = 0.05, 20 iterations per update with
+  min_rel_cost_change = 0 (every problem runs every iteration), device-resident.
+* ``lateral`` (SURVEY 8d "spatial representative"): lateral_profile (X=2 U=1 C=2), EULER, T = 250,
+  ds = 0.5, 5 iterations per update, as PathOptim runs it (planning/path_vel_decomp/path_optim.py:292-299).
+
+One "batched iteration" = one pass of the iLQR loop body (derivative refresh + backward pass + line search)
+for every problem of the batch."""
 import os
 import sys
 import time
@@ -11,6 +16,11 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6          # MI355X_MICROARCH.md / SURVEY 8d: fp64 vector = fp64 MFMA peak
+
+# backward-pass operations per stage counted from optim.c:926-985
+F_BW = {(7, 2): 2427, (6, 2): 1718, (2, 1): 118, (3, 1): 261, (4, 1): 486}
 
 
 def _configure(opt, x0):
@@ -49,15 +59,75 @@ def initial_states(batch, seed=0):
     return x0
 
 
-def run(device=0, batch=1024, horizon=50, updates=10, warmup=2, cpu_budget_s=10.0, seed=0, barrier=None,
-        id_offset=0):
-    """One rank's share of the batched-iLQR workload.  `seed` picks this rank's block of initial states,
+def _configure_lateral(opt, x0, horizon):
+    """PathOptim's set-up of lateral_profile (path_optim.py:101-104, 125-133, 292-299): a corridor with an
+    obstacle bump on the right, min_rel_cost_change = 0 so that every problem runs all 5 iterations."""
+    opt.integrator_type = opt.EULER
+    opt.lg_mult_limit = 0.0
+    opt.barrier_weight[:] = 1000.0
+    opt.step = 0.5
+    opt.max_iterations = 5
+    opt.max_lg_iterations = 1
+    opt.min_rel_cost_change = 0.0
+    opt.lagrange_multiplier[:] = 0.0
+    opt.u_min[:] = -0.5
+    opt.u_max[:] = 0.5
+    s = np.arange(horizon) * 0.5
+    p = opt.params
+    p.ref_step, p.w_d, p.w_v_d, p.w_a_d, p.w_k = 0.5, 1.0, 10.0, 100.0, 50.0
+    p.k_ref = 0.01 * np.sin(s / 20.0)
+    p.d_offset = np.zeros(horizon)
+    p.d_lower_constr = -2.0 + 2.6 * np.exp(-((s - 30.0) / 6.0) ** 2)
+    p.d_upper_constr = np.full(horizon, 2.5)
+    opt.x[..., 0, :] = x0
+    opt.u[:] = 0.0
+
+
+def initial_states_lateral(batch, seed=0):
+    rng = np.random.default_rng(200 + seed)
+    x0 = np.zeros((batch, 2))
+    x0[:, 0] = rng.uniform(-0.5, 0.5, batch)
+    return x0
+
+
+WORKLOADS = {
+    "mpc": dict(problem="trajectory_tracking_mpc", config="config_trajectory_tracking_mpc", horizon=50, dyn_evals=2,
+                what="trajectory_tracking_mpc X=7 U=2 C=4, HEUN, N={T}, dt=0.05"),
+    "lateral": dict(problem="lateral_profile", config="config_lateral_profile", horizon=250, dyn_evals=1,
+                    what="lateral_profile X=2 U=1 C=2, EULER, T={T}, ds=0.5"),
+}
+
+
+def flops_per_stage(problem, dims, dyn_evals):
+    """(F_bw, F_deriv, F_roll) per stage: backward-pass count of SURVEY 8a, and the generator's own operation
+    counts of the routines one derivative refresh / one rollout stage evaluates (genopt.routine_flops)."""
+    from . import genopt
+    fl = genopt.routine_flops(problem)
+    X, U = dims
+    f = lambda name: fl.get(name, {}).get("flops", 0)
+    f_deriv = (f("jacobian") + f("stateJacobian") + f("actionJacobian") + f("stateGradient") + f("actionGradient")
+               + f("stateStateHessian") + f("actionActionHessian") + f("actionStateHessian"))
+    # one rollout stage: the integrator's ctDynamics calls (+ ~4X flops of combination per call), the feedback law
+    # u + alpha k + K (x' - x) with its clamp (2UX + 4U), the stage cost
+    f_roll = dyn_evals * (f("ctDynamics") + 4 * X) + 2 * U * X + 4 * U + f("costs")
+    return F_BW.get((X, U), 0), f_deriv, f_roll
+
+
+def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrier=None, id_offset=0, workload="mpc"):
+    """One rank's share of a batched-iLQR workload.  `seed` picks this rank's block of initial states,
     `barrier` (N > 1) brackets the timed region, `id_offset` is the global id of this rank's problem 0."""
     from . import genopt, optimizers as o
-    make = genopt.build(o.config_trajectory_tracking_mpc(), "trajectory_tracking_mpc")
+    w = WORKLOADS[workload]
+    horizon = horizon or w["horizon"]
+    make = genopt.build(getattr(o, w["config"])(), w["problem"])
     opt = make(batch=batch, horizon=horizon, device=device)
-    x0 = initial_states(batch, seed)
-    _configure(opt, x0)
+    if workload == "mpc":
+        x0 = initial_states(batch, seed)
+        _configure(opt, x0)
+    else:
+        x0 = initial_states_lateral(batch, seed)
+        opt.horizon = horizon
+        _configure_lateral(opt, x0, horizon)
     opt.upload()
     for _ in range(warmup):
         opt.restore()
@@ -76,66 +146,52 @@ def run(device=0, batch=1024, horizon=50, updates=10, warmup=2, cpu_budget_s=10.
     el = time.perf_counter() - t0
     kernel_ms, launches = opt.timing(reset=True)
     opt.download()
-    iters = int(opt.iterations[0])
+    iters = int(np.ravel(opt.iterations)[0])
+    X, U = opt.x.shape[-1], (opt.u.shape[-1] if opt.u.ndim == 3 else 1)
+    f_bw, f_deriv, f_roll = flops_per_stage(w["problem"], (X, U), w["dyn_evals"])
+    # line-search tries of the reference's accept-first search on the LAST iteration: alpha = 10^-(tries-1)
+    alpha = np.clip(np.ravel(np.asarray(opt.alpha, dtype=np.float64)), 1e-8, 1.0)
+    n_ls = float(np.mean(np.rint(-np.log10(alpha)) + 1.0))
+    per_iter = batch * horizon * (f_bw + f_deriv + n_ls * f_roll)
+    per_iter_exec = batch * horizon * (f_bw + f_deriv + 8 * f_roll)          # the kernel rolls all 8 candidates out
+    k_s = (kernel_ms / max(1, launches)) * 1e-3
     out = {
         "metric": "batched_ilqr_iters_per_s",
         "value": updates * iters / el,
         "unit": "batched iLQR iterations/s (1 iteration = all problems of the batch)",
         "problem_iterations_per_s": updates * iters * batch / el,
-        "config": {"workload": f"trajectory_tracking_mpc X=7 U=2 C=4, HEUN, N={horizon}, dt=0.05, batch={batch}, "
-                               f"{iters} iterations/update, min_rel_cost_change=0", "batch": batch, "N": horizon},
+        "config": {"workload": (w["what"].format(T=horizon) + f", batch={batch}, {iters} iterations/update, "
+                                "min_rel_cost_change=0"), "batch": batch, "N": horizon},
         "dtype": "f64",
         "ms_per_update": el / updates * 1e3,
         "kernel_ms_per_update": kernel_ms / max(1, launches),
         "all_finite": bool(np.all(np.isfinite(opt.traj_costs))),
         "elapsed_s": el, "updates": updates, "iterations_per_update": iters,
+        # algorithmic flops per batched iteration = batch x T x (F_bw + F_deriv + n_ls F_roll) over the
+        # kernel time of one iteration, against the fp64 vector peak.  The path is latency-bound by construction
+        # (50-250 dependent stages on one wavefront per problem); MFMA is not used.
+        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_VECTOR_PEAK_TFLOPS,
+                     "achieved": per_iter * iters / k_s / 1e12, "frac": per_iter * iters / k_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                     "traffic": None, "kernel": "k_ilqr_update",
+                     "flops_per_stage": {"F_bw": f_bw, "F_deriv": f_deriv, "F_roll": f_roll, "n_ls": n_ls},
+                     "algorithmic_flops_per_batched_iteration": per_iter,
+                     "executed_flops_per_batched_iteration": per_iter_exec,
+                     "executed_tflops": per_iter_exec * iters / k_s / 1e12,
+                     "mfma_busy": 0.0},
     }
     # this rank's best problem as the fixed-size record of SURVEY 8e: {constr, cost, id, x[T+1,X], u[T,U]}
     b = int(np.argmin(np.where(np.isfinite(opt.traj_costs), opt.traj_costs, np.inf)))
     out["best_record"] = np.concatenate([[0.0, float(opt.traj_costs[b]), float(id_offset + b)],
                                          np.asarray(opt.x[b], dtype=np.float64).ravel(),
                                          np.asarray(opt.u[b], dtype=np.float64).ravel()])
-    if cpu_budget_s > 0:
-        out["cpu_baseline"] = cpu_baseline(x0, horizon, cpu_budget_s)
+    out["x0"] = x0
     return out
-
-
-def cpu_baseline(x0, horizon, budget_s):
-    """The CPU oracle (port) on a bounded sample of the same problems, all host
-    cores (OpenMP over problems); reset + solve are timed inside the C library."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import ctypes as C
-    import oracle_ilqr as OI
-    lib = OI.load("trajectory_tracking_mpc")
-    cores = int(lib.ilqo_max_threads())
-    n = len(x0)
-    opts = []
-    for b in range(n):
-        r = OI.OracleOptim("trajectory_tracking_mpc", t_cap=horizon)
-        r.horizon = horizon
-        _configure(r, x0[b])
-        opts.append(r)
-    hs = (C.c_void_p * n)(*[r._h for r in opts])
-    x0c = np.ascontiguousarray(x0, dtype=np.float64)
-    px = x0c.ctypes.data_as(C.POINTER(C.c_double))
-    lib.ilqo_reset_and_update_many(hs, n, px, 1, 0)              # warm-up, also calibrates
-    t0 = time.perf_counter()
-    lib.ilqo_reset_and_update_many(hs, n, px, 1, 0)
-    one = time.perf_counter() - t0
-    reps = max(1, min(200, int(budget_s / max(one, 1e-3))))
-    t0 = time.perf_counter()
-    lib.ilqo_reset_and_update_many(hs, n, px, reps, 0)
-    el = time.perf_counter() - t0
-    iters = opts[0].iterations
-    return {"value": reps * iters / el, "unit": "batched iLQR iterations/s (1024-problem batch)",
-            "problem_iterations_per_s": reps * n * iters / el, "cores": cores, "kind": "port",
-            "sample": f"{reps} x the same {n} problems x {iters} iterations "
-                      f"(oracle/ilqr_oracle.cpp, OpenMP over problems)"}
 
 
 if __name__ == "__main__":
     import json
     sys.path.insert(0, ROOT)
-    res = run(cpu_budget_s=0.0 if "--no-cpu-baseline" in sys.argv else 10.0)
+    res = run(workload=sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "mpc")
     res.pop("best_record", None)
+    res.pop("x0", None)
     print(json.dumps(res))
