@@ -199,30 +199,20 @@ def lat_lon_cpu_baseline(reps=3):
             "sample": f"{reps} plans of the same scene (OpenMP over cells)"}
 
 
-def mpc_cpu_baseline(ticks=300, horizon=20):
-    """oracle/ilqr_oracle.cpp (one thread, one problem) in the closed loop of latency.mpc_closed_loop:
-    what the reference's CPU genopt solver costs per controller tick on this host."""
+def mpc_cpu_baseline(ticks=1000, horizon=20):
+    """oracle/ilqr_oracle.cpp (one thread, one problem) in the closed loop of latency.mpc_closed_loop
+    (tpl_amd/minisim.py): what the reference's CPU genopt solver costs per controller tick on this host."""
     import numpy as np
     import oracle_ilqr as OI
-    from tpl_amd.optim import bench_ilqr
-    opt = OI.OracleOptim("trajectory_tracking_mpc")
+    from tpl_amd import minisim
+    native = _native_oracle("libilqr_oracle_trajectory_tracking_mpc.so")
+    opt = OI.OracleOptim("trajectory_tracking_mpc", lib=OI.load("trajectory_tracking_mpc", path=native) if native else None)
     opt.horizon = horizon
-    x = np.array([0.0, 0.4, 0.05, 0.0, 6.0, 0.0, 0.0])
-    bench_ilqr._configure(opt, x)
-    opt.min_rel_cost_change = 1e-6
-    opt.horizon = horizon
-    lat = []
-    for _ in range(ticks):
-        opt.x[0] = x
-        t0 = time.perf_counter()
-        opt.update()
-        lat.append((time.perf_counter() - t0) * 1e3)
-        x = opt.dynamics(x, opt.u[0], 0, 0.01)
-        x[5] = max(0.0, x[0])
-        opt.shift(0)
-    lat = np.array(lat[10:])
+    _, trace, con = minisim.closed_loop(opt, ticks=ticks)
+    lat = np.array(con.solve_ms[10:])
     return {"value": float(np.percentile(lat, 50)), "unit": "ms per update (p50)", "cores": 1, "kind": "port",
-            "p99_ms": float(np.percentile(lat, 99)), "sample": f"{len(lat)} ticks of the same closed loop"}
+            "p99_ms": float(np.percentile(lat, 99)), "final_lateral_error_m": float(abs(trace[-1, 1])),
+            "sample": f"{len(lat)} ticks of the same closed loop"}
 
 
 # ------------------------------------------------------------------------------------------------

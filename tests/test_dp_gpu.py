@@ -164,9 +164,7 @@ def test_full_size_spot_checks(grid):
     (2) random cells of two stages re-evaluated by the oracle's evalNode on the
     GPU's own next-stage table (bit-exact), (3) the trajectory re-costed by
     reeval equals the forward pass, stations are monotone, t advances by dt."""
-    S, V, A, T = sc.GRIDS[grid]
-    if grid == "config4":
-        T = 6                       # full 512x256x128 grid, fewer stages: 1.5 GiB of tables
+    S, V, A, T = sc.GRIDS[grid]            # config4: 512x256x128 x 100 stages = 20 GB of value tables, as stated
     p = sc.lon_params(S, V, A, T)
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
     path = sc.straight_path(p.path_steps, p.path_step_size)
@@ -183,10 +181,10 @@ def test_full_size_spot_checks(grid):
     assert np.array_equal(env.get_dist_map_path().view(np.uint32), dist.view(np.uint32))
 
     rng = np.random.default_rng(11)
-    for t in (T - 1, T - 2, 1):
+    for t in (T - 1, T - 2, T // 2, 1):
         nxt = dp.copy_table(min(T - 1, t + 1))
         cur = dp.copy_table(t)
-        n = 1500
+        n = 1000
         ia = rng.integers(0, A, n); iv = rng.integers(0, V, n); i_s = rng.integers(0, S, n)
         for k in range(n):
             tp = TplLonState()

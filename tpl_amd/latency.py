@@ -2,10 +2,10 @@
 "p50 plan latency on default scenario"): host buffers in, host buffers out, one
 vehicle, exactly how tpl's planner / controller plugins would call the engines.
 
-* MPC: a closed loop of the kinematic single-track ego model (the generated
-  model's own ``dynamics``) under ``trajectory_tracking_mpc`` with N = 20
-  (the template's default horizon, optim.c:1900), tracking a straight 8 m/s plan,
-  one ``Optim.update()`` per 10 ms tick like tplsim's fixed_time_step.
+* MPC: the closed loop of tpl_amd/minisim.py -- the simulator's ego model (core.py:91-135, with
+  actuator dead time) under the controller's per-tick use of ``trajectory_tracking_mpc`` with N = 20
+  (the template's default horizon, optim.c:1900), tracking a straight 8 m/s plan, one ``Optim.update()``
+  per 10 ms tick like tplsim's fixed_time_step, 1 000 ticks.
 * DP: ``DynProgLonPlanner.update`` on the reference's default grid
   (201 x 37 x 20, 10 stages; data/params/planning/default/state.json).
 """
@@ -14,29 +14,21 @@ import time
 import numpy as np
 
 
-def mpc_closed_loop(device=0, ticks=300, horizon=20):
-    from .optim import bench_ilqr, genopt, optimizers as o
+def mpc_closed_loop(device=0, ticks=1000, horizon=20):
+    """BASELINE configs[0] reduced to the hot path (tpl_amd/minisim.py): the simulator's ego model with 0.1 s actuator
+    dead time under the model-predictive controller's per-tick solver use, N = 20, 1 000 ticks of 10 ms."""
+    from . import minisim
+    from .optim import genopt, optimizers as o
     make = genopt.build(o.config_trajectory_tracking_mpc(), "trajectory_tracking_mpc")
     opt = make(device=device)
     opt.horizon = horizon
-    x = np.array([0.0, 0.4, 0.05, 0.0, 6.0, 0.0, 0.0])
-    bench_ilqr._configure(opt, x)
-    opt.min_rel_cost_change = 1e-6
-    opt.horizon = horizon
-    lat = []
-    for k in range(ticks):
-        opt.x[0] = x
-        t0 = time.perf_counter()
-        opt.update()
-        lat.append((time.perf_counter() - t0) * 1e3)
-        # apply the first control for one tick of 10 ms, then warm-start like the controller does
-        x = opt.dynamics(x, opt.u[0], 0, 0.01)
-        x[5] = max(0.0, x[0])                      # arc length of the projection on the straight plan
-        opt.shift(0)
-    lat = np.array(lat[10:])
+    controls, trace, con = minisim.closed_loop(opt, ticks=ticks)
+    lat = np.array(con.solve_ms[10:])
     return {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
             "mean_iterations": float(np.mean(opt.iterations)), "ticks": int(len(lat)),
-            "what": f"Optim.update() of trajectory_tracking_mpc, batch 1, N={horizon}, HEUN, <=20 iterations, "
+            "final_lateral_error_m": float(abs(trace[-1, 1])), "final_speed_mps": float(trace[-1, 3]),
+            "what": f"Optim.update() of trajectory_tracking_mpc, batch 1, N={horizon}, HEUN, <=20 iterations, inside the "
+                    "closed loop of tpl_amd/minisim.py (ego model with 0.1 s dead time, controller shim, straight 8 m/s plan); "
                     "host mirrors in and out (H2D + kernel + D2H)"}
 
 
