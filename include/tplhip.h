@@ -361,6 +361,36 @@ TPLHIP_API int tplhip_lat_lon_reeval_traj(tplhip_lat_lon* h, tplhip_dp_env* env,
 TPLHIP_API int tplhip_lat_lon_copy_backward_pass_tex(tplhip_lat_lon* h, int idx_t, float* out);
 TPLHIP_API int tplhip_lat_lon_query_backward_pass_tex(tplhip_lat_lon* h, int idx_t, float s, float ds, float l, float* out4);
 
+/* --------- host helpers of the path/velocity-decomposition glue -- */
+
+/* Projection, library/include/tplcpp/utils.hpp:240-256 (what tplcpp.project returns) */
+typedef struct TplProjection {
+    int64_t start, end;
+    double alpha;
+    int64_t index;
+    double point[2];
+    double distance, arc_len, angle;
+    double tangent[2];
+    int32_t in_bounds;
+} TplProjection;
+
+/* tplcpp.project, utils.cpp:257-408: m positions (double[m][2]) on the line strip points (x, y in the first two
+ * of `stride` doubles per point); closed != 0 treats it as a loop */
+TPLHIP_API int tplhip_path_project(const double* points, int stride, int n, int closed, const double* positions, int m,
+                                   TplProjection* out);
+/* tplcpp.resample, utils.cpp:410-548: out = double[steps][5] = (x, y, alpha, prev index, next index); TPLHIP_ESTATE
+ * with the reference's messages where it throws */
+TPLHIP_API int tplhip_path_resample(const double* points, int stride, int n, double sampling_dist, int steps,
+                                    int start_index, int closed, double* out, int* n_out);
+/* rampify_profile, library/tpl/planning/utils.py:5-65: out = double[n][2] = (v, a) */
+TPLHIP_API int tplhip_rampify_velocity_profile(int has_v0, double v0, int has_a0, double a0, const double* lim_v, int n,
+                                               double a_min, double a_max, double j_min, double j_max, double v_min,
+                                               double step, double* out);
+/* rampify_profile, library/tpl/planning/path_vel_decomp/path_optim.py:11-59: out = double[n_path] */
+TPLHIP_API int tplhip_rampify_lateral_profile(double step, int horizon, double evasion_sharpness, double proj_distance,
+                                              const double* path_v, int path_stride, int n_path, double gap,
+                                              const double* lower, const double* upper, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,13 @@ class TplPolyQuintic(C.Structure):
 assert C.sizeof(TplPolyLatTrajPoint) == 72
 
 
+class TplProjection(C.Structure):
+    """Projection, library/include/tplcpp/utils.hpp:240-256."""
+    _fields_ = [("start", C.c_int64), ("end", C.c_int64), ("alpha", C.c_double), ("index", C.c_int64),
+                ("point", C.c_double * 2), ("distance", C.c_double), ("arc_len", C.c_double), ("angle", C.c_double),
+                ("tangent", C.c_double * 2), ("in_bounds", C.c_int32)]
+
+
 class TplLatLonParams(C.Structure):
     """DynProgLatLonPlannerParams, library/include/tplcpp/dyn_prog/lat_lon_planner.cuh:9-62."""
     _fields_ = (
@@ -196,6 +203,14 @@ SIGNATURES = {
     "tplhip_dp_lon_info": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "tplhip_dp_lon_timing_enable": (C.c_int, [_vp, C.c_int]),
     "tplhip_dp_lon_timing_get": (C.c_int, [_vp, _P(C.c_double), _P(C.c_int64)]),
+    "tplhip_path_project": (C.c_int, [_P(C.c_double), C.c_int, C.c_int, C.c_int, _P(C.c_double), C.c_int, _P(TplProjection)]),
+    "tplhip_path_resample": (C.c_int, [_P(C.c_double), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                       _P(C.c_double), _P(C.c_int)]),
+    "tplhip_rampify_velocity_profile": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_double, _P(C.c_double), C.c_int,
+                                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                                  _P(C.c_double)]),
+    "tplhip_rampify_lateral_profile": (C.c_int, [C.c_double, C.c_int, C.c_double, C.c_double, _P(C.c_double), C.c_int,
+                                                 C.c_int, C.c_double, _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "tplhip_dp_lon_record_bytes": (C.c_size_t, [C.c_int]),
     "tplhip_dp_lon_scenarios_upload": (C.c_int, [_vp, C.c_int, _P(C.c_float), _P(TplDpEnvParams), _P(TplLonState),
                                                  _P(C.c_float), C.c_int, C.c_int]),

@@ -1,0 +1,234 @@
+// planning.hip -- host-side geometry and profile helpers of the path/velocity-decomposition glue
+// (SURVEY 8 f-4).  Nothing here runs on the GPU: these are the small serial routines the reference keeps in its
+// C++ extension (tplcpp.project / resample, library/src/utils.cpp:257-548) or compiles with numba
+// (rampify_profile, library/tpl/planning/utils.py:5-65 and planning/path_vel_decomp/path_optim.py:11-59), which
+// the Python callers of the iLQR solvers run every planning cycle.  Restated from those sources; the order of the
+// floating-point operations follows them (the numba versions are fastmath, so they are only defined up to
+// reassociation; tests compare at 1e-9).
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "tplhip_common.h"
+
+namespace {
+
+inline long mod_floor(long a, long n) { long r = a % n; return r < 0 ? r + n : r; }
+
+// utils.cpp:257-408
+void project_one(const double* pts, long stride, long n, bool closed, double px, double py, TplProjection* out)
+{
+    TplProjection proj = {};
+    double best = INFINITY, off = 0.0, arc_len = 0.0;
+    const long end = closed ? n + 1 : n;
+    double prev_x = pts[0], prev_y = pts[1];
+    for (long i = 1; i < end; ++i) {
+        const long ii = mod_floor(i, n);
+        const double nx = pts[ii * stride], ny = pts[ii * stride + 1];
+        const double pvx = px - prev_x, pvy = py - prev_y;
+        const double vx = nx - prev_x, vy = ny - prev_y;
+        const double l = std::sqrt(vx * vx + vy * vy);
+        double q = (pvx * vx + pvy * vy) / (vx * vx + vy * vy);
+        double cx, cy;
+        bool in_bounds = true;
+        if (q < 0) { in_bounds = !closed && i != 1; q = 0.0; cx = prev_x; cy = prev_y; }
+        else if (q > 1) { in_bounds = !closed && i != end - 1; q = 1.0; cx = nx; cy = ny; }
+        else { cx = prev_x + vx * q; cy = prev_y + vy * q; }
+        const double dx = px - cx, dy = py - cy;
+        const double d = dx * dx + dy * dy;
+        if (d < best) {
+            proj.in_bounds = in_bounds ? 1 : 0;
+            best = d;
+            proj.point[0] = cx; proj.point[1] = cy;
+            proj.index = i;
+            proj.alpha = q;
+            off = arc_len;
+        }
+        arc_len += l;
+        prev_x = nx; prev_y = ny;
+    }
+    proj.distance = std::sqrt(best);
+    long idx_start, idx_end, idx_next;
+    if (closed) {
+        idx_start = mod_floor(proj.index - 1, n);
+        idx_end = mod_floor(proj.index, n);
+        idx_next = mod_floor(proj.index + 1, n);
+    } else {
+        idx_start = std::max(0L, (long)proj.index - 1);
+        idx_end = proj.index;
+        idx_next = std::min(n - 1, (long)proj.index + 1);
+    }
+    proj.start = idx_start;
+    proj.end = idx_end;
+    if (proj.alpha < 0.5) proj.index = idx_start;
+    const double ax = pts[idx_start * stride], ay = pts[idx_start * stride + 1];
+    const double bx = pts[idx_end * stride], by = pts[idx_end * stride + 1];
+    double vx = bx - ax, vy = by - ay;
+    const double l = std::sqrt(vx * vx + vy * vy);
+    vx /= l; vy /= l;
+    const double adx = ax - proj.point[0], ady = ay - proj.point[1];
+    proj.arc_len = off + std::sqrt(adx * adx + ady * ady) * ((proj.alpha < 0) ? -1.0 : 1.0);
+    if (proj.index < n - 2) {
+        double wx = pts[idx_next * stride] - bx, wy = pts[idx_next * stride + 1] - by;
+        const double wl = std::sqrt(wx * wx + wy * wy);
+        wx /= wl; wy /= wl;
+        proj.tangent[0] = proj.alpha * wx + (1.0 - proj.alpha) * vx;
+        proj.tangent[1] = proj.alpha * wy + (1.0 - proj.alpha) * vy;
+    } else {
+        proj.tangent[0] = vx; proj.tangent[1] = vy;
+    }
+    proj.angle = std::atan2(proj.tangent[1], proj.tangent[0]);
+    double ox = proj.point[0] - px, oy = proj.point[1] - py;
+    const double ol = std::sqrt(ox * ox + oy * oy);
+    ox /= ol; oy /= ol;                                   // a point ON the line gives NaN here, like the reference
+    const double rx = -oy, ry = ox;
+    if (vx * rx + vy * ry <= 0) proj.distance *= -1.0;
+    *out = proj;
+}
+
+} // namespace
+
+extern "C" {
+
+int tplhip_path_project(const double* points, int stride, int n, int closed, const double* positions, int m,
+                        TplProjection* out)
+{
+    if (!points || !positions || !out || stride < 2) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (n < 2) return tplhip_fail(TPLHIP_EINVAL, "a line strip needs at least two points (got %d)", n);
+    for (int k = 0; k < m; ++k) project_one(points, stride, n, closed != 0, positions[2 * k], positions[2 * k + 1], out + k);
+    return TPLHIP_OK;
+}
+
+// utils.cpp:410-548: out = double[steps][5] = (x, y, alpha, prev index, next index); *n_out rows are valid
+int tplhip_path_resample(const double* pts_in, int stride, int n, double sampling_dist, int steps, int start_index,
+                         int closed_i, double* out, int* n_out)
+{
+    if (!pts_in || !out || !n_out || stride < 2) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    const bool closed = closed_i != 0;
+    *n_out = 0;
+    if (n == 0 || steps == 0) return TPLHIP_OK;
+    std::vector<double> px(n), py(n);
+    px[0] = pts_in[0]; py[0] = pts_in[1];
+    long count_pts = 1;
+    for (long k = 1; k < n; ++k) {                       // drops duplicate points
+        px[count_pts] = pts_in[k * stride]; py[count_pts] = pts_in[k * stride + 1];
+        const double dx = px[count_pts] - px[count_pts - 1], dy = py[count_pts] - py[count_pts - 1];
+        if (std::sqrt(dx * dx + dy * dy) != 0) count_pts += 1;
+    }
+    if (count_pts == 1) {
+        out[0] = px[0]; out[1] = py[0]; out[2] = out[3] = out[4] = 0.0;
+        *n_out = 1;
+        return TPLHIP_OK;
+    }
+    long start = closed ? mod_floor(start_index, count_pts) : std::max(0L, std::min((long)start_index, count_pts - 1));
+    for (long i = 0; i < (long)steps * 5; ++i) out[i] = 0.0;
+    out[0] = px[start]; out[1] = py[start]; out[2] = 0.0; out[3] = (double)start;
+    out[4] = closed ? (double)mod_floor(start + 1, count_pts) : (double)std::max(0L, std::min(start + 1, count_pts - 1));
+    long count = 1, i = start;
+    while (count < steps) {
+        const long prev_count = count;
+        for (long k = 0; k < count_pts; ++k) {
+            long prev_idx = i + k, next_idx = i + k + 1;
+            if (closed) { prev_idx = mod_floor(prev_idx, count_pts); next_idx = mod_floor(next_idx, count_pts); }
+            else { prev_idx = std::max(0L, std::min(prev_idx, count_pts - 2)); next_idx = std::max(0L, std::min(next_idx, count_pts - 1)); }
+            const double ax = px[prev_idx], ay = py[prev_idx], bx = px[next_idx], by = py[next_idx];
+            const double vx = bx - ax, vy = by - ay;
+            const double l = std::sqrt(vx * vx + vy * vy), ls = l * l;
+            const double ux = vx / l, uy = vy / l;
+            const double cx = out[(count - 1) * 5], cy = out[(count - 1) * 5 + 1];
+            // intersection of the segment with the circle of radius sampling_dist around the last sample
+            const double D = (ax - cx) * (by - cy) - (bx - cx) * (ay - cy);
+            const double disc = sampling_dist * sampling_dist * ls - D * D;
+            if (disc < 0) return tplhip_fail(TPLHIP_ESTATE, "cannot solve for next sampling point");
+            const double sq = std::sqrt(disc);
+            const double sign_y = (vy < 0.0) ? -1.0 : 1.0;
+            const double xp0 = D * vy, yp0 = -D * vx, xp1 = sign_y * vx * sq, yp1 = std::fabs(vy) * sq;
+            double p0x = (xp0 + xp1) / ls + cx, p0y = (yp0 + yp1) / ls + cy;
+            const double p1x = (xp0 - xp1) / ls + cx, p1y = (yp0 - yp1) / ls + cy;
+            double q0 = (ux * (p0x - ax) + uy * (p0y - ay)) / l;
+            const double q1 = (ux * (p1x - ax) + uy * (p1y - ay)) / l;
+            const double tol = 1e-8;
+            if (q0 < q1) { q0 = q1; p0x = p1x; p0y = p1y; }
+            if ((!closed && next_idx == count_pts - 1) || (q0 > -tol && q0 - 1.0 < tol)) {
+                i = prev_idx;
+                double* s = out + count * 5;
+                s[0] = p0x; s[1] = p0y; s[2] = q0; s[3] = (double)prev_idx; s[4] = (double)next_idx;
+                count += 1;
+                break;
+            }
+        }
+        if (count == prev_count) return tplhip_fail(TPLHIP_ESTATE, "resampling failed");
+    }
+    *n_out = (int)count;
+    return TPLHIP_OK;
+}
+
+// planning/utils.py:5-65.  out = double[n][2] = (v, a) per station.
+int tplhip_rampify_velocity_profile(int has_v0, double v0, int has_a0, double a0, const double* lim_v_in, int n,
+                                    double a_min, double a_max, double j_min, double j_max, double v_min, double step,
+                                    double* out)
+{
+    if (!lim_v_in || !out || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
+    std::vector<double> lim_v(n);
+    for (int i = 0; i < n; ++i) lim_v[i] = std::max(lim_v_in[i], v_min);
+    for (int i = 0; i < 2 * n; ++i) out[i] = 0.0;
+    // backward pass: minimum jerk and acceleration
+    double cv = lim_v[n - 1], ca = 0.0;
+    for (int t = n - 1; t > 0; --t) {
+        out[2 * t] = cv; out[2 * t + 1] = ca;
+        const double lim_a = std::max(a_min, (cv - lim_v[t - 1]) / step * cv);
+        if (lim_a < 0.0) ca = std::max(ca + j_min / cv * step, lim_a);
+        else { ca = 0.0; cv = lim_v[t]; }
+        cv += std::min(-ca / cv * step, lim_v[t - 1] - cv);
+    }
+    // forward pass: maximum jerk and acceleration
+    if (!has_v0) out[0] = cv;
+    else { cv = std::max(v0, v_min); out[0] = std::max(v0, v_min); }
+    if (!has_a0) { ca = -ca; out[1] = ca; }
+    else { ca = a0; out[1] = a0; }
+    double lim_a = 0.0;
+    for (int t = 0; t < n; ++t) {
+        if (t < n - 1) lim_a = std::min(a_max, (out[2 * (t + 1)] - cv) / step * cv);
+        if (lim_a > 0.0) ca = std::min(ca + j_max / cv * step, lim_a);
+        else { ca = 0.0; cv = out[2 * t]; }
+        const double next_v = cv + std::min(ca / cv * step, lim_v[t] - cv);
+        cv = std::min(out[2 * t], next_v);
+        out[2 * t] = cv; out[2 * t + 1] = ca;
+    }
+    return TPLHIP_OK;
+}
+
+// planning/path_vel_decomp/path_optim.py:11-59.  path_v = the speed-limit column of the path (path[:, 5]) with its
+// stride in doubles; lower / upper: double[horizon]; out: double[n_path].
+int tplhip_rampify_lateral_profile(double step, int horizon, double evasion_sharpness, double proj_distance,
+                                   const double* path_v, int path_stride, int n_path, double gap,
+                                   const double* lower, const double* upper, double* out)
+{
+    if (!path_v || !lower || !upper || !out || horizon < 1 || n_path < horizon)
+        return tplhip_fail(TPLHIP_EINVAL, "bad argument");
+    std::vector<double> fwd(n_path, -10.0), bwd(n_path, -10.0);
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<double>& pd = pass == 0 ? fwd : bwd;
+        double d = pass == 0 ? lower[0] : lower[horizon - 1];
+        for (int c = 0; c < horizon; ++c) {
+            const int i = pass == 0 ? c : horizon - 1 - c;
+            d = std::max(lower[i], d);
+            pd[i] = d;
+            const double v = std::max(path_v[(long)i * path_stride], 1e-8);
+            double slope = -(evasion_sharpness / (v * v));
+            if (pass == 0) {
+                for (int k = i; k < horizon; ++k)
+                    slope = std::min(slope, (upper[k] - gap - d) / ((double)std::max(1, std::abs(k - i)) * step));
+            } else {
+                for (int k = i; k >= 0; --k)
+                    slope = std::min(slope, (upper[k] - gap - d) / ((double)std::max(1, std::abs(k - i)) * step));
+                slope = std::min(slope, (proj_distance - d) / std::max(1.0, (double)i * step));
+            }
+            d += step * slope;
+        }
+    }
+    for (int i = 0; i < n_path; ++i) out[i] = std::max(fwd[i], bwd[i]);
+    return TPLHIP_OK;
+}
+
+} // extern "C"

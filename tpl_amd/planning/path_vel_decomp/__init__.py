@@ -1,0 +1,7 @@
+"""``tpl.planning.path_vel_decomp``'s three solver users on the MI355X solvers: same class names, parameters,
+attributes and call signatures (``update(env, params)`` / ``update(path, env, params)``)."""
+from .path_optim import PathOptim
+from .path_smoothing import PathSmoothing
+from .velocity_optim import TimeConstr, VelocityOptim
+
+__all__ = ["PathOptim", "PathSmoothing", "VelocityOptim", "TimeConstr"]
