@@ -182,13 +182,18 @@ def test_long_horizon_and_per_problem_parameters():
         assert int(batch.iterations[b]) == one.iterations
 
 
-@pytest.mark.parametrize("horizon,t_cap", [(37, 37), (21, None), (60, 60), (13, 13)])
-def test_ragged_horizons_match_oracle(horizon, t_cap):
-    """Horizons that are not a multiple of the rollout ring (8 stages) and both homes of the
-    trajectory mirrors: t_cap = horizon puts them in LDS, the default capacity of 299 stages leaves
-    them in global memory.  60 stages no longer fit the cost block into the LDS ring."""
+@pytest.mark.parametrize("horizon,t_cap,lds_kb,want_lds", [(37, 37, None, 1), (21, None, None, 1), (21, None, 39, 0),
+                                                           (60, 60, None, 1), (13, 13, 8, 0)])
+def test_ragged_horizons_match_oracle(horizon, t_cap, lds_kb, want_lds, monkeypatch):
+    """Horizons that are not a multiple of the rollout ring (8 stages) and BOTH homes of the trajectory mirrors.
+    A single problem has a compute unit to itself, so its mirrors sit in LDS even at the default capacity of 299
+    stages (70 KB); TPLHIP_ILQR_LDS_KB forces the budget of a chip-filling batch (39 KB) or less, which leaves them
+    in global memory.  The residency is asserted, not assumed (tplhip_ilqr_info).  60 stages no longer fit the cost
+    block into the LDS ring."""
+    if lds_kb is not None:
+        monkeypatch.setenv("TPLHIP_ILQR_LDS_KB", str(lds_kb))
     make = _factory("trajectory_tracking_mpc")
-    opt = make(horizon=t_cap) if t_cap else make()
+    opt = make(horizon=horizon, t_cap=t_cap) if t_cap else make()
     ref = OI.OracleOptim("trajectory_tracking_mpc")
     for o in (opt, ref):
         cases.mpc(o, seed=2, curvature=0.01, min_rel=0.0)
@@ -202,6 +207,8 @@ def test_ragged_horizons_match_oracle(horizon, t_cap):
         assert cases.scaled_err(opt.x[:horizon + 1], ref.x[:horizon + 1]) < 1e-6
         assert cases.scaled_err(opt.u[:horizon], ref.u[:horizon]) < 1e-6
         assert abs(float(opt.traj_costs) - float(ref.traj_costs)) < 1e-8 * abs(float(ref.traj_costs))
+    info = opt.info()
+    assert info["lds_traj"] == want_lds and info["t_cap"] == (t_cap or 299), info
 
 
 def test_frozen_prefix_stays_frozen():

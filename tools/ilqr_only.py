@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""Profiling driver: the batched iLQR workload of bench.py and nothing else.  usage: python3 tools/ilqr_only.py [mpc|lateral]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tpl_amd.optim import bench_ilqr  # noqa: E402
+
+res = bench_ilqr.run(workload=sys.argv[1] if len(sys.argv) > 1 else "mpc", updates=3, warmup=1)
+print("done", res["value"], res["kernel_ms_per_update"])

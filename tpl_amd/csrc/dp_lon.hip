@@ -1098,8 +1098,17 @@ struct tplhip_dp_lon {
     TplDpLonParams params;
     bool have_params = false;
 
-    Node* d_tables = nullptr;           // [t_steps][a][v][s], 12-byte cells
+    Node* d_tables = nullptr;           // [t_steps][a][v][s], 12-byte cells: the table set of the most recent plan
+    Node* d_table_set[2] = {nullptr, nullptr};   // [0] = the planner's tables; [1] = second set, allocated on demand, so
+                                                 // that the rollout of plan k can run under the sweeps of plan k+1
     size_t table_cells = 0;
+    hipStream_t fwd_stream = nullptr;   // forward rollouts + their downloads in the back-to-back (plan_resident) mode
+    hipEvent_t ev_swept = nullptr, ev_fwd[2] = {nullptr, nullptr};
+    bool fwd_pending[2] = {false, false};
+    float* d_dist_fwd[2] = {nullptr, nullptr};   // the distance map a pending rollout reads (the environment's is rewritten)
+    size_t dist_fwd_cap = 0;
+    long plan_count = 0;
+    bool overlap = false;               // set by plan_resident once the second table set exists
     ActDesc* d_acts = nullptr;          // [a*v][9]
     float* d_path = nullptr;            // [path_steps][7]
     float* d_pre_vmax = nullptr;        // [t_steps][s]
@@ -1199,7 +1208,9 @@ int pick_device(int device)
 
 void free_planner_buffers(tplhip_dp_lon* h)
 {
-    hipFree(h->d_tables);    h->d_tables = nullptr;
+    hipFree(h->d_table_set[0]); hipFree(h->d_table_set[1]);
+    h->d_table_set[0] = h->d_table_set[1] = nullptr; h->d_tables = nullptr;
+    h->overlap = false; h->fwd_pending[0] = h->fwd_pending[1] = false;
     hipFree(h->d_acts);      h->d_acts = nullptr;
     hipFree(h->d_path);      h->d_path = nullptr;
     hipFree(h->d_pre_vmax);  h->d_pre_vmax = nullptr;
@@ -1398,10 +1409,32 @@ void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
 }
 
 // device part of DynProgLonPlanner::update (lon_planner.cu:341-388), all async on h->stream
-int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env)
+// overlap: back-to-back mode (plan_resident).  Plans alternate between two table sets; the forward rollout runs on
+// its own stream behind the last sweep, so the sweeps of the NEXT plan (main stream, other table set) do not wait
+// for its ~50 dependent steps.  Without overlap everything is enqueued on the main stream and uses table set 0.
+int wait_pending_forwards(tplhip_dp_lon* h)
+{
+    if (h->fwd_stream && (h->fwd_pending[0] || h->fwd_pending[1])) {
+        HIP_TRY(hipStreamSynchronize(h->fwd_stream), "lon planner forward pass failed");
+        h->fwd_pending[0] = h->fwd_pending[1] = false;
+    }
+    return TPLHIP_OK;
+}
+
+int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap)
 {
     const TplDpLonParams& p = h->params;
     const int T = p.t_steps;
+    const int par = overlap ? (int)(h->plan_count & 1) : 0;
+    if (!overlap) {
+        int rc = wait_pending_forwards(h);
+        if (rc) return rc;
+    } else if (h->fwd_pending[par]) {
+        // the rollout of the plan before last still reads this table set
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_fwd[par], 0), "stream wait failed");
+    }
+    h->d_tables = h->d_table_set[par];
+    h->plan_count += 1;
     {
         const TplDpEnvParams& e = env->params;
         const float vals[] = {e.s_min, e.s_max, e.l_min, e.l_max, e.dt, e.dt_start};
@@ -1439,20 +1472,62 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env)
     }
     // forward pass, lon_planner.cu:365-386 -- one launch
     {
+        hipStream_t fs = h->stream;
+        const float* dist = env->d_dist;
+        if (overlap) {
+            const size_t dist_b = sizeof(float) * (size_t)env->params.t_steps * env->params.s_steps;
+            HIP_TRY(hipMemcpyAsync(h->d_dist_fwd[par], env->d_dist, dist_b, hipMemcpyDeviceToDevice, h->stream), "distance map copy failed");
+            HIP_TRY(hipEventRecord(h->ev_swept, h->stream), "event record failed");
+            HIP_TRY(hipStreamWaitEvent(h->fwd_stream, h->ev_swept, 0), "stream wait failed");
+            fs = h->fwd_stream;
+            dist = h->d_dist_fwd[par];
+        }
         const size_t ring_b = sizeof(float) * 7 * FWD_RING;
         const size_t maps_b = sizeof(float) * ((size_t)p.path_steps * 7 + (size_t)env->params.t_steps * env->params.s_steps);
         if (ring_b + maps_b <= 60 * 1024)
-            hipLaunchKernelGGL(k_forward<true>, dim3(h->n_rollouts), dim3(64), ring_b + maps_b, h->stream,
+            hipLaunchKernelGGL(k_forward<true>, dim3(h->n_rollouts), dim3(64), ring_b + maps_b, fs,
                                h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
-                               h->d_path, env->d_dist, p, env->params, (size_t)0, (size_t)0, (size_t)0);
+                               h->d_path, dist, p, env->params, (size_t)0, (size_t)0, (size_t)0);
         else
-            hipLaunchKernelGGL(k_forward<false>, dim3(h->n_rollouts), dim3(64), ring_b, h->stream,
+            hipLaunchKernelGGL(k_forward<false>, dim3(h->n_rollouts), dim3(64), ring_b, fs,
                                h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
-                               h->d_path, env->d_dist, p, env->params, (size_t)0, (size_t)0, (size_t)0);
+                               h->d_path, dist, p, env->params, (size_t)0, (size_t)0, (size_t)0);
+        if (overlap) {
+            HIP_TRY(hipEventRecord(h->ev_fwd[par], h->fwd_stream), "event record failed");
+            h->fwd_pending[par] = true;
+        }
     }
     HIP_TRY(hipGetLastError(), "lon planner launch failed");
     h->tables_valid = true;
     return TPLHIP_OK;
+}
+
+// second table set + rollout stream of the back-to-back mode; any failure just leaves the mode off
+void try_enable_overlap(tplhip_dp_lon* h, tplhip_dp_env* env)
+{
+    static const bool off = std::getenv("TPLHIP_NO_FWD_OVERLAP") != nullptr;
+    const size_t dist_elems = (size_t)env->params.t_steps * env->params.s_steps;
+    if (off) { h->overlap = false; return; }
+    if (h->overlap && h->dist_fwd_cap >= dist_elems) return;
+    h->overlap = false;
+    const size_t bytes = sizeof(Node) * h->table_cells * (size_t)h->params.t_steps;
+    if (!h->d_table_set[1]) {
+        if (hipMalloc(&h->d_table_set[1], bytes) != hipSuccess) { (void)hipGetLastError(); h->d_table_set[1] = nullptr; return; }
+        if (hipMemsetAsync(h->d_table_set[1], 0, bytes, h->stream) != hipSuccess) return;
+    }
+    if (!h->fwd_stream && hipStreamCreate(&h->fwd_stream) != hipSuccess) { h->fwd_stream = nullptr; return; }
+    if (!h->ev_swept && hipEventCreateWithFlags(&h->ev_swept, hipEventDisableTiming) != hipSuccess) return;
+    for (int i = 0; i < 2; ++i)
+        if (!h->ev_fwd[i] && hipEventCreateWithFlags(&h->ev_fwd[i], hipEventDisableTiming) != hipSuccess) return;
+    if (h->dist_fwd_cap < dist_elems) {
+        if (hipStreamSynchronize(h->fwd_stream) != hipSuccess) return;
+        for (int i = 0; i < 2; ++i) {
+            hipFree(h->d_dist_fwd[i]); h->d_dist_fwd[i] = nullptr;
+            if (hipMalloc(&h->d_dist_fwd[i], sizeof(float) * dist_elems) != hipSuccess) { (void)hipGetLastError(); h->dist_fwd_cap = 0; return; }
+        }
+        h->dist_fwd_cap = dist_elems;
+    }
+    h->overlap = true;
 }
 
 } // namespace
@@ -1643,6 +1718,9 @@ int tplhip_dp_lon_destroy(tplhip_dp_lon* h)
     if (!h) return TPLHIP_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->fwd_stream) { hipStreamSynchronize(h->fwd_stream); hipStreamDestroy(h->fwd_stream); }
+    if (h->ev_swept) hipEventDestroy(h->ev_swept);
+    for (int i = 0; i < 2; ++i) { if (h->ev_fwd[i]) hipEventDestroy(h->ev_fwd[i]); hipFree(h->d_dist_fwd[i]); }
     for (auto& ev : h->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     free_planner_buffers(h);
     free_scenarios_fwd(h);
@@ -1680,6 +1758,10 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         || ps->path_steps != h->params.path_steps;
 
     HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
+    {
+        int rc = wait_pending_forwards(h);
+        if (rc) return rc;
+    }
     h->params = *ps;
     h->have_params = true;
     h->tables_valid = false;
@@ -1695,7 +1777,8 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         h->stage_busy[0] = h->stage_busy[1] = false;
         free_scenarios_fwd(h);                               // scenario tables are sized by the grid
         h->table_cells = S * p.v_steps * p.a_steps;
-        HIP_TRY(hipMalloc(&h->d_tables, sizeof(Node) * h->table_cells * (size_t)p.t_steps), "value table allocation failed");
+        HIP_TRY(hipMalloc(&h->d_table_set[0], sizeof(Node) * h->table_cells * (size_t)p.t_steps), "value table allocation failed");
+        h->d_tables = h->d_table_set[0];
         HIP_TRY(hipMemsetAsync(h->d_tables, 0, sizeof(Node) * h->table_cells * (size_t)p.t_steps, h->stream), "value table clear failed");
         HIP_TRY(hipMalloc(&h->d_acts, sizeof(ActDesc) * (size_t)nrows * N_BWD), "action table allocation failed");
         HIP_TRY(hipMalloc(&h->d_path, sizeof(float) * 7 * (size_t)p.path_steps), "path array allocation failed");
@@ -1868,7 +1951,9 @@ int tplhip_dp_lon_upload(tplhip_dp_lon* h, int n, const TplLonState* inits, cons
     if (!h || !inits || !path || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
     if (!h->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the planner");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
-    int rc = ensure_rollouts(h, n);
+    int rc = wait_pending_forwards(h);                      // they read the path and the initial states
+    if (rc) return rc;
+    rc = ensure_rollouts(h, n);
     if (rc) return rc;
     h->n_rollouts = n;
     h->path_bounded = path_is_bounded(path, h->params.path_steps);
@@ -1887,7 +1972,8 @@ int tplhip_dp_lon_plan_resident(tplhip_dp_lon* h, tplhip_dp_env* env)
     if (rc) return rc;
     if (h->n_rollouts < 1) return tplhip_fail(TPLHIP_ESTATE, "nothing uploaded");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
-    return enqueue_plan(h, env);
+    try_enable_overlap(h, env);
+    return enqueue_plan(h, env, h->overlap);
 }
 
 int tplhip_dp_lon_sync(tplhip_dp_lon* h)
@@ -1895,7 +1981,7 @@ int tplhip_dp_lon_sync(tplhip_dp_lon* h)
     if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     HIP_TRY(hipStreamSynchronize(h->stream), "lon planner pass failed");
-    return TPLHIP_OK;
+    return wait_pending_forwards(h);
 }
 
 int tplhip_dp_lon_download(tplhip_dp_lon* h, TplLonState* out_trajs)
@@ -1903,6 +1989,11 @@ int tplhip_dp_lon_download(tplhip_dp_lon* h, TplLonState* out_trajs)
     if (!h || !out_trajs) return tplhip_fail(TPLHIP_EINVAL, "null argument");
     if (h->n_rollouts < 1) return tplhip_fail(TPLHIP_ESTATE, "nothing to download");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "lon planner pass failed");
+    {
+        int rc = wait_pending_forwards(h);
+        if (rc) return rc;
+    }
     HIP_TRY(hipMemcpyAsync(out_trajs, h->d_trajs, sizeof(TplLonState) * (size_t)h->n_rollouts * h->params.t_steps,
                            hipMemcpyDeviceToHost, h->stream), "copying trajectory failed");
     HIP_TRY(hipStreamSynchronize(h->stream), "lon planner forward pass failed");
@@ -1922,9 +2013,11 @@ int tplhip_dp_lon_stage_download(tplhip_dp_lon* h, int slot)
         h->stage_cap[slot] = n;
     }
     if (!h->stage_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[slot], hipEventDisableTiming), "event creation failed");
-    HIP_TRY(hipMemcpyAsync(h->h_stage[slot], h->d_trajs, sizeof(TplLonState) * n, hipMemcpyDeviceToHost, h->stream),
+    // behind the rollout it copies: on the rollout stream in the back-to-back mode
+    hipStream_t cs = (h->overlap && (h->fwd_pending[0] || h->fwd_pending[1])) ? h->fwd_stream : h->stream;
+    HIP_TRY(hipMemcpyAsync(h->h_stage[slot], h->d_trajs, sizeof(TplLonState) * n, hipMemcpyDeviceToHost, cs),
             "copying trajectory failed");
-    HIP_TRY(hipEventRecord(h->stage_ev[slot], h->stream), "event record failed");
+    HIP_TRY(hipEventRecord(h->stage_ev[slot], cs), "event record failed");
     h->stage_busy[slot] = true;
     h->stage_n[slot] = n;
     return TPLHIP_OK;
@@ -1956,7 +2049,7 @@ int tplhip_dp_lon_update_batch(tplhip_dp_lon* h, int n, const TplLonState* inits
     if (!out_trajs) return tplhip_fail(TPLHIP_EINVAL, "null output");
     rc = tplhip_dp_lon_upload(h, n, inits, path);
     if (rc) return rc;
-    rc = enqueue_plan(h, env);
+    rc = enqueue_plan(h, env, false);
     if (rc) return rc;
     return tplhip_dp_lon_download(h, out_trajs);
 }
@@ -2024,12 +2117,12 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
     std::snprintf(buf, (size_t)n,
                   "{\"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
                   "\"div_mode\": %d, \"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"cells\": %d, "
-                  "\"bounded_inputs\": %d, \"vpair\": %d, \"v3\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\"}",
+                  "\"bounded_inputs\": %d, \"vpair\": %d, \"v3\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\", \"fwd_overlap\": %d}",
                   h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
                   h->div_mode, (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->cells,
                   (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0, (h->cells == 2 && h->vpair) ? 1 : 0,
                   (h->cells == 2 && h->vpair && use_v3(h) && h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
-                  h->path_div3, h->range_div3, (h->vp_ok && use_v3(h) && h->sc_bounded) ? "k_backward3v" : "k_backward");
+                  h->path_div3, h->range_div3, (h->vp_ok && use_v3(h) && h->sc_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0);
     return TPLHIP_OK;
 }
 

@@ -1301,6 +1301,8 @@ struct tplhip_ilqr {
     bool timing = false;
     double kernel_ms = 0.0;
     int64_t launches = 0;
+    int n_cu = 256;                              // compute units of the device
+    size_t lds_optin = 0;                        // dynamic LDS the kernel is currently allowed (hipFuncSetAttribute)
     unsigned long long lds_aperture = 0;         // flat address of LDS offset 0 (0: unknown, no LDS residency)
     size_t lds_static = 0;                       // static LDS of k_ilqr_update
     size_t lds_dyn_bytes = 0;                    // dynamic LDS of the next launch
@@ -1314,8 +1316,11 @@ size_t field_elems(const tplhip_ilqr* h, int f)
     return (size_t)h->batch * rows * field_width(f);
 }
 
-// Decide what lives in LDS for the next launch.  One workgroup per SIMD must stay resident
-// (4 per CU, 160 KB of LDS per CU), so a workgroup may use ~36 KB on top of its static block.
+// Decide what lives in LDS for the next launch.  Batches that fill the chip keep one workgroup per SIMD resident
+// (4 per CU, 160 KB of LDS per CU), so a workgroup may use ~36 KB on top of its static block; a SMALL batch -- the
+// one problem of an MPC tick or a planner call -- has a compute unit to itself and takes up to 150 KB: its
+// trajectory mirrors (x, u, k, K, uMin, uMax of all t_cap rows: 70 KB for X = 7, U = 2, 300 rows) then sit in LDS
+// too, instead of every stage of the dependent rollout and Riccati chains waiting on global memory.
 // Priority: array parameters (every ctDynamics waits on them), then the trajectory mirrors.
 void plan_lds(tplhip_ilqr* h)
 {
@@ -1325,7 +1330,11 @@ void plan_lds(tplhip_ilqr* h)
     d.lds_dyn_flat = 0;
     h->lds_dyn_bytes = 0;
     if (!h->lds_aperture || std::getenv("TPLHIP_ILQR_NO_LDS")) return;
-    const size_t budget = (39 * 1024 - sizeof(Lds)) / sizeof(double);
+    const int per_cu = (h->batch + h->n_cu - 1) / std::max(1, h->n_cu);          // workgroups sharing a compute unit
+    size_t wg_bytes = per_cu <= 1 ? (size_t)150 * 1024 : (per_cu == 2 ? (size_t)78 * 1024 : (size_t)39 * 1024);
+    if (const char* kb = std::getenv("TPLHIP_ILQR_LDS_KB"))                      // tests: force the other home of the mirrors
+        wg_bytes = std::min((size_t)150, std::max((size_t)8, (size_t)std::atoi(kb))) * 1024;
+    const size_t budget = (wg_bytes - sizeof(Lds)) / sizeof(double);
     const size_t traj = (size_t)h->rows * (NX + NU + NU + NU * NX + NU + NU);
     size_t off = 0;
     if (traj <= budget) { d.lds_traj = 1; off = traj; }
@@ -1439,6 +1448,11 @@ int launch(tplhip_ilqr* h)
         HIP_TRY(hipEventCreate(&e0), "event creation failed");
         HIP_TRY(hipEventCreate(&e1), "event creation failed");
         HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
+    }
+    if (h->lds_dyn_bytes > 48 * 1024 && h->lds_dyn_bytes > h->lds_optin) {       // more than the default allowance: opt in
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ilqr_update), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)h->lds_dyn_bytes), "raising the LDS limit failed");
+        h->lds_optin = h->lds_dyn_bytes;
     }
     hipLaunchKernelGGL(k_ilqr_update, dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes, h->stream, h->dev);
     HIP_TRY(hipGetLastError(), "solver launch failed");
@@ -1604,6 +1618,9 @@ int tplhip_ilqr_create(int device, int batch, int t_cap, tplhip_ilqr** out)
                 && hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(k_ilqr_update)) == hipSuccess) {
                 h->lds_aperture = ap;
                 h->lds_static = attr.sharedSizeBytes;
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
+                    h->n_cu = prop.multiProcessorCount;
             }
             hipFree(d_ap);
         }
@@ -1870,6 +1887,15 @@ int tplhip_ilqr_download(tplhip_ilqr* h)
     int rc = fetch_eager(h);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream), "solver update failed");
+    return TPLHIP_OK;
+}
+
+int tplhip_ilqr_info(tplhip_ilqr* h, char* buf, int n)
+{
+    if (!h || !buf || n < 1) return fail(TPLHIP_EINVAL, "bad argument");
+    std::snprintf(buf, (size_t)n, "{\"batch\": %d, \"t_cap\": %d, \"lds_traj\": %d, \"lds_arrays\": %d, \"lds_dyn_bytes\": %zu, "
+                  "\"lds_static_bytes\": %zu}", h->batch, h->rows - 1, h->dev.lds_traj, h->dev.n_lds_arrays, h->lds_dyn_bytes,
+                  h->lds_static);
     return TPLHIP_OK;
 }
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "tplhip_ilqr_param_is_array": (C.c_int, [C.c_int]),
     "tplhip_ilqr_last_error": (C.c_char_p, []),
     "tplhip_ilqr_fingerprint": (C.c_char_p, []),
+    "tplhip_ilqr_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "tplhip_ilqr_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "tplhip_ilqr_destroy": (C.c_int, [C.c_void_p]),
     "tplhip_ilqr_batch": (C.c_int, [C.c_void_p]),
@@ -350,6 +351,12 @@ class Optim:
 
     def download(self):
         _check(self._lib, self._lib.tplhip_ilqr_download(self._h))
+
+    def info(self):
+        import json
+        buf = C.create_string_buffer(512)
+        _check(self._lib, self._lib.tplhip_ilqr_info(self._h, buf, 512))
+        return json.loads(buf.value.decode())
 
     def timing(self, reset=False):
         ms, n = C.c_double(), C.c_int64()
