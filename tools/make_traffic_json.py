@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/<tag>_dp_traffic.json from the per-dispatch PMC averages of tools/pmc_dp.sh.
-usage: python3 tools/make_traffic_json.py <tag> <pmc_target.txt> <pmc_config4.txt>"""
+usage: python3 tools/make_traffic_json.py <tag> <pmc_target.txt> <pmc_config4.txt> [kernel name]"""
 import json
 import re
 import sys
@@ -20,11 +20,11 @@ def parse(path):
     return vals
 
 
-def entry(v):
+def entry(v, kernel):
     fetch = v["FETCH_SIZE"] * 1024.0
     write = v["WRITE_SIZE"] * 1024.0
     return {
-        "kernel": "k_backward2v",
+        "kernel": kernel,
         "fetch_size_bytes_raw": fetch,
         "write_size_bytes": write,
         "traffic_bytes_per_launch": 2.0 * fetch + write,
@@ -36,7 +36,8 @@ def entry(v):
 
 
 tag, tgt, c4 = sys.argv[1:4]
-out = {"256x128x64": entry(parse(tgt)), "512x256x128": entry(parse(c4))}
+kernel = sys.argv[4] if len(sys.argv) > 4 else "k_backward3v"
+out = {"256x128x64": entry(parse(tgt), kernel), "512x256x128": entry(parse(c4), kernel)}
 with open(f"profiles/{tag}_dp_traffic.json", "w") as f:
     json.dump(out, f, indent=1)
 print(json.dumps(out, indent=1))
