@@ -1,7 +1,7 @@
 // dp_sweep.hip -- the large-grid backward sweep of the DP (s,v,a) planner, third form (k_backward3v).
 //
 // Same data flow as k_backward2v in dp_lon.hip (two vertically adjacent rows (v, a), (v+1, a) per
-// lane, six coalesced row loads per action, blended rows parked in LDS, one barrier per action), with
+// lane, six coalesced row loads per action, blended rows parked in LDS), with
 // the instruction stream rebuilt around what gfx950's vector ALU actually charges
 // (tools/micro/valu_tp.hip, 8 waves per SIMD, nominal cycles per wave-instruction):
 //
@@ -72,23 +72,27 @@ __device__ __forceinline__ Node3 lerp3(Node3 p, Node3 q, float w, float iw)     
     return r;
 }
 
-// PREFETCH: the six common row loads of action k+1 are issued before the barrier of action k, so they fly under
-// its phase 2 (a few more live registers).
-template <int PATH_DIV, int RANGE_DIV, bool PREFETCH>
+// ------------------------------------------------------------------------
+// NV = 2 vertically adjacent rows (v, a), (v+1, a) per lane.  For action k the two rows blend the same a' pair one
+// v' row apart, so "upper a-blend of row 0" IS "lower a-blend of row 1" (checked per action on the descriptors:
+// rows and weight equal): 2 + 2 NV row loads per action for NV cells and NV + 1 a-blends.  The code is written for
+// general NV; NV = 4 (2.5 loads per cell instead of 3) was measured and lost, 54 us against 42: its 100 registers
+// leave four waves per SIMD.  ONE LDS row buffer per row and two barriers per action: the kernel fits 64 registers,
+// i.e. eight waves per SIMD, which beat the two-buffer / one-barrier / loads-in-flight-across-the-barrier form
+// (68-70 registers, seven waves) by 2 % -- 42.1 against 42.9 us per 256x128x64 sweep on the same box.
+// ------------------------------------------------------------------------
+template <int PATH_DIV, int RANGE_DIV>
 __global__ void __launch_bounds__(1024)
 k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, const ActDesc* __restrict__ acts,
-             const float* __restrict__ path_all, const float* __restrict__ pre_vmax_all,
-             const float* __restrict__ pre_sdist_all, const double* __restrict__ pre_prog, SweepArgs a)
-{   // (the pointers are separate restrict-qualified parameters, not members of `a`: only then are the uniform
-    // descriptor reads scalar loads -- a member pointer carries no noalias, and the barriers count as clobbers)
+              const float* __restrict__ path_all, const float* __restrict__ pre_vmax_all,
+              const float* __restrict__ pre_sdist_all, const double* __restrict__ pre_prog, SweepArgs a)
+{
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const TplDpLonParams& p = a.p;
     const int S = p.s_steps, V = p.v_steps, A = p.a_steps;
     const int nrows = V * A;
     const int is = threadIdx.x;
     const int s_pad = a.s_pad;
-
-    // scenario of this workgroup (blockIdx.y): own tables, stage prelude and path
     const size_t scn = blockIdx.y;
     const Node* __restrict__ next = next_all + scn * a.stride_tables;
     Node* __restrict__ out = out_all + scn * a.stride_tables;
@@ -96,12 +100,13 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     const float* __restrict__ pre_sdist = pre_sdist_all + scn * a.stride_pre;
     const float* __restrict__ path = path_all + scn * a.stride_path;
 
-    // traversal: as k_backward2v (XCD = blockIdx.x & 7 owns a v range, a-major tiles inside)
+    constexpr int NV = 2;
+    // traversal: as k_backward2v (XCD = blockIdx.x & 7 owns a v range, a-major tiles inside), in units of NV rows
     const int xcd = blockIdx.x & 7;
     const int v_lo = (xcd * V) >> 3, v_hi = ((xcd + 1) * V) >> 3;
-    const int vx = (v_hi - v_lo) >> 1, tv = max(1, a.tile_v >> 1);
+    const int vx = (v_hi - v_lo) / NV, tv = max(1, a.tile_v / NV);
     const int q = (int)(blockIdx.x >> 3);
-    if (q >= vx * A) return;                                   // whole workgroup, before any barrier
+    if (q >= vx * A) return;
     int ia, iv;
     {
         const int full = vx / tv;
@@ -110,50 +115,53 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         const int tile = rem / (a.tile_a * w);
         const int r = rem - tile * (a.tile_a * w);
         ia = tile * a.tile_a + r / w;
-        iv = v_lo + 2 * (strip * tv + (r - (r / w) * w));
+        iv = v_lo + NV * (strip * tv + (r - (r / w) * w));
     }
-    const int row0 = ia * V + iv, row1 = row0 + 1;
+    const int row0 = ia * V + iv;
     const bool active = is < S;
     const int js = min(is, S - 1);
 
-    // LDS: float4 R[2 rows][2 buffers][s_pad + 1] | float dsc[2 rows][9][8] | float pv[path_steps + 1]
+    // LDS: float4 R[NV rows][s_pad + 1] | float dsc[NV rows][9][8] | float pv[path_steps + 1]
     const int row_slots = s_pad + 1;
     v4f* R = reinterpret_cast<v4f*>(smem);
-    float* dsc = reinterpret_cast<float*>(smem + (size_t)4 * row_slots * sizeof(v4f));
-    float* pv = dsc + 2 * N_BWD * 8;
+    float* dsc = reinterpret_cast<float*>(smem + (size_t)NV * row_slots * sizeof(v4f));
+    float* pv = dsc + NV * N_BWD * 8;
     const ActDesc* __restrict__ d0 = acts + (size_t)row0 * N_BWD;
-    const ActDesc* __restrict__ d1 = acts + (size_t)row1 * N_BWD;
-    for (int i = is; i < 2 * N_BWD * 8; i += blockDim.x) {
-        const int r = i / (N_BWD * 8), rem = i - r * (N_BWD * 8);
-        const int k = rem >> 3, f = rem & 7;
-        dsc[i] = reinterpret_cast<const float*>((r ? d1 : d0) + k)[f];
-    }
-    for (int i = is; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];   // last sample twice
+    for (int i = is; i < NV * N_BWD * 8; i += blockDim.x)
+        dsc[i] = reinterpret_cast<const float*>(d0 + (i >> 3))[i & 7];
+    for (int i = is; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];
 
     const float s = p.s_min + (float)js * p._s_step_size;
-    const float v0 = p.v_min + (float)iv * p._v_step_size, v1 = p.v_min + (float)(iv + 1) * p._v_step_size;
     const float acc = p.a_min + (float)ia * p._a_step_size;
     const float v_max = pre_vmax[js];
     const float s_dist = pre_sdist[js];
     const double prog = pre_prog[js];
-
-    // stateCost lon_planner.cu:40-55
-    float sc0, sc1, sg0, sg1;
+    float sc[NV], sg[NV];
+    double sd_base[NV];
     {
         float c0 = 0.0f;
         c0 += p.w_a * (acc * acc);
         const float x = (float)((double)c0 + prog);
-        const float gap0 = (v0 * p.time_gap + p.gap_min) - s_dist;
-        const float gap1 = (v1 * p.time_gap + p.gap_min) - s_dist;
-        sc0 = (float)((double)x + (double)p.w_safety_dist * fmax(0.0, (double)gap0));
-        sc1 = (float)((double)x + (double)p.w_safety_dist * fmax(0.0, (double)gap1));
-        sg0 = 0.0f; if (v0 > v_max) sg0 += v0 - v_max;
-        sg1 = 0.0f; if (v1 > v_max) sg1 += v1 - v_max;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float v = p.v_min + (float)(iv + i) * p._v_step_size;
+            const float gap = (v * p.time_gap + p.gap_min) - s_dist;
+            sc[i] = (float)((double)x + (double)p.w_safety_dist * fmax(0.0, (double)gap));
+            sg[i] = 0.0f; if (v > v_max) sg[i] += v - v_max;
+            sd_base[i] = (double)(s + d0[i * N_BWD].vdt) + d0[i * N_BWD].a_term;
+        }
     }
-    // lonDynamics station part lon_planner.cu:244, the terms that do not depend on the action
-    const double sd_base0 = (double)(s + d0->vdt) + d0->a_term;
-    const double sd_base1 = (double)(s + d1->vdt) + d1->a_term;
-
+    unsigned shared_mask = 0;
+#pragma unroll
+    for (int i = 0; i + 1 < NV; ++i) {
+#pragma unroll
+        for (int k = 0; k < N_BWD; ++k) {
+            const ActDesc& x = d0[i * N_BWD + k];
+            const ActDesc& y = d0[(i + 1) * N_BWD + k];
+            const bool sh = x.r01 == y.r00 && x.r11 == y.r10 && __float_as_uint(x.wa) == __float_as_uint(y.wa);
+            shared_mask |= (sh ? 1u : 0u) << (i * N_BWD + k);
+        }
+    }
     const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<Node*>(next), 0, (int)((size_t)nrows * S * sizeof(Node)), 0x00020000);
     const unsigned voff = (unsigned)js * 12u, row_bytes = (unsigned)S * 12u;
@@ -161,8 +169,6 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         const v3f x = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(next_rsrc, (int)voff, (int)((unsigned)r * row_bytes), 0));
         return Node3{x.x, x.y, x.z};
     };
-
-    // launch constants of the fp32 arithmetic, in vector registers
     const float s_min_v = in_vgpr(p.s_min);
     const float s_scale = (float)(S - 1);
     const float s_scale_v = in_vgpr(s_scale);
@@ -171,92 +177,83 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     const float w_snap_v = in_vgpr(p.w_snap);
     const float path_top = (float)(p.path_steps - 1);
     const bool dup_last = is == S - 1;
-
-    unsigned long long best0 = 0x7f8000007f800000ull, best1 = 0x7f8000007f800000ull;   // (+inf, +inf)
-    int bk0 = 0, bk1 = 0;
-
-    Node3 ld[6];
+    unsigned long long best[NV];
+    int bk[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { best[i] = 0x7f8000007f800000ull; bk[i] = 0; }
+    Node3 lo[2], up[NV][2];
     auto issue_loads = [&](int k) {
-        const ActDesc* e0 = d0 + k;
-        const ActDesc* e1 = d1 + k;
-        ld[0] = load_row(e0->r00); ld[1] = load_row(e0->r10); ld[2] = load_row(e0->r01); ld[3] = load_row(e0->r11);
-        ld[4] = load_row(e1->r01); ld[5] = load_row(e1->r11);
+        lo[0] = load_row(d0[k].r00); lo[1] = load_row(d0[k].r10);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { up[i][0] = load_row(d0[i * N_BWD + k].r01); up[i][1] = load_row(d0[i * N_BWD + k].r11); }
     };
 #if V3_ABLATE == 2       // timing experiment: no row loads at all (registers fed from lane ids), results are wrong
-    for (int i = 0; i < 6; ++i) ld[i] = Node3{(float)is, (float)(is + i), 1.0f};
+    lo[0] = lo[1] = Node3{(float)is, 1.0f, 1.0f};
+    for (int i = 0; i < NV; ++i) up[i][0] = up[i][1] = Node3{(float)(is + i), 2.0f, 1.0f};
 #endif
-
     __syncthreads();                     // descriptors and path limits are in LDS
-
     const v4f* dsc4 = reinterpret_cast<const v4f*>(dsc);
 #pragma unroll
     for (int k = 0; k < N_BWD; ++k) {
-        const ActDesc* e0 = d0 + k;
-        const ActDesc* e1 = d1 + k;
-        v4f* Rk0 = R + (k & 1) * row_slots;
-        v4f* Rk1 = R + (2 + (k & 1)) * row_slots;
-        // ---- phase 1: blend the next-stage rows around (v', a') for both cells (a, then v)
+        // ---- phase 1: blend the next-stage rows around (v', a') for the NV cells (a, then v)
         {
-            const v4f w0 = dsc4[(0 * N_BWD + k) * 2], w1 = dsc4[(1 * N_BWD + k) * 2];      // wa, iwa, wv, iwv
-            // the upper half of row 0's window is the lower half of row 1's, blended with the same weight
-            const bool shared = e0->r01 == e1->r00 && e0->r11 == e1->r10
-                                && __float_as_uint(e0->wa) == __float_as_uint(e1->wa);
 #if V3_ABLATE != 2
-            if (!PREFETCH || k == 0) issue_loads(k);
+            issue_loads(k);
 #endif
-            const Node3 p00 = ld[0], p10 = ld[1], p01 = ld[2], p11 = ld[3], q01 = ld[4], q11 = ld[5];
-            const Node3 a0 = lerp3(p00, p10, w0.x, w0.y);
-            const Node3 a1 = lerp3(p01, p11, w0.x, w0.y);
-            Node3 b0;
-            if (shared) {
-                b0 = a1;
-            } else {
-                const Node3 q00 = load_row(e1->r00), q10 = load_row(e1->r10);
-                b0 = lerp3(q00, q10, w1.x, w1.y);
+            v4f w[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) w[i] = dsc4[(i * N_BWD + k) * 2];
+            Node3 bl = lerp3(lo[0], lo[1], w[0].x, w[0].y);
+            if (k > 0) asm volatile("s_barrier" ::: "memory");      // everyone is done reading the row buffers of action k-1
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const Node3 bu = lerp3(up[i][0], up[i][1], w[i].x, w[i].y);
+                const Node3 r = lerp3(bl, bu, w[i].z, w[i].w);
+                v4f* Rk = R + i * row_slots;
+                *reinterpret_cast<v3f*>(Rk + is) = (v3f){r.c, r.g, r.j};
+                if (dup_last) *reinterpret_cast<v3f*>(Rk + S) = (v3f){r.c, r.g, r.j};
+                if (i + 1 < NV) {
+                    if ((shared_mask >> (i * N_BWD + k)) & 1u) {
+                        bl = bu;
+                    } else {
+                        const ActDesc& y = d0[(i + 1) * N_BWD + k];
+                        const Node3 q00 = load_row(y.r00), q10 = load_row(y.r10);
+                        bl = lerp3(q00, q10, w[i + 1].x, w[i + 1].y);
+                    }
+                }
             }
-            const Node3 b1 = lerp3(q01, q11, w1.x, w1.y);
-            const Node3 r0 = lerp3(a0, a1, w0.z, w0.w);
-            const Node3 r1 = lerp3(b0, b1, w1.z, w1.w);
-            *reinterpret_cast<v3f*>(Rk0 + is) = (v3f){r0.c, r0.g, r0.j};
-            *reinterpret_cast<v3f*>(Rk1 + is) = (v3f){r1.c, r1.g, r1.j};
-            if (dup_last) {
-                *reinterpret_cast<v3f*>(Rk0 + S) = (v3f){r0.c, r0.g, r0.j};
-                *reinterpret_cast<v3f*>(Rk1 + S) = (v3f){r1.c, r1.g, r1.j};
-            }
-#if V3_ABLATE != 2
-            if (PREFETCH && k + 1 < N_BWD) {
-                issue_loads(k + 1);
-                __builtin_amdgcn_sched_barrier(0);            // keep the requests in front of phase 2
-            }
-#endif
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // ---- phase 2: successor station, 1-D blend along s, costs, argmin -- per cell
-        const v4f u0 = dsc4[(0 * N_BWD + k) * 2 + 1], u1 = dsc4[(1 * N_BWD + k) * 2 + 1];   // j, wj_cost, a_viol, tn_v
         int kv = k;
-        asm volatile("" : "+v"(kv));                       // k in a vector register: the select below takes it as it is
-        auto cell = [&](double sd_base, const ActDesc* e, const v4f u, const v4f* Rk, float sc, float sg,
-                        unsigned long long& best, int& bk) {
+        asm volatile("" : "+v"(kv));
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const ActDesc* e = d0 + i * N_BWD + k;
+            const v4f u = dsc4[(i * N_BWD + k) * 2 + 1];
+            const v4f* Rk = R + i * row_slots;
+#if V3_ABLATE == 1
+            best[i] += __float_as_uint(Rk[is].x + u.x);
+            continue;
+#endif
             // lonDynamics station part, lon_planner.cu:244
-            const double sd = sd_base + e->j_term;
+            const double sd = sd_base[i] + e->j_term;
             const float tn_s = fmaxf(s, (float)sd);
-            // readNode coordinate along s (lon_planner.cu:35); tn_s >= s >= s_min
             const float xs = tn_s - s_min_v;
             const float qs = div_const<RANGE_DIV>(xs, rr_hi, rr_lo);
             const float cs = qs * s_scale_v + 0.5f;
             const float xb = cs - 0.5f;
             const float fl = floorf(xb);
             const float fr = xb - fl;
-            const float ws = (fr + 32768.0f) - 32768.0f;          // rint(fr * 256) / 256
+            const float ws = (fr + 32768.0f) - 32768.0f;
             const float iws = 1.0f - ws;
-            const int off = (int)(fminf(fl, s_scale) * 16.0f);    // byte offset of the lower tap
+            const int off = (int)(fminf(fl, s_scale) * 16.0f);
             const v4f nl = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off);
             const v4f nh = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off + 16);
-            asm volatile("" :: "v"(nl.w), "v"(nh.w));             // whole 16-byte reads: ds_read_b128 is twice as fast as b96
+            asm volatile("" :: "v"(nl.w), "v"(nh.w));
             const float nc = fmaf(nh.x, ws, nl.x * iws);
             const float ng = fmaf(nh.y, ws, nl.y * iws);
             const float nj = fmaf(nh.z, ws, nl.z * iws);
-            // interpPath(tn.s).v_max, lon_planner.cu:114 (second tap = the next slot, see k_backward2)
             const float alpha = div_const<PATH_DIV>(tn_s, rp_hi, rp_lo);
             const float f0 = fminf(floorf(alpha), path_top);
             const float pa = alpha - f0;
@@ -265,35 +262,28 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const float pv0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4);
             const float pv1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4 + 4);
             const float vmn = pv0 * pia + pv1 * pa;
-
-            float c = sc + nc;
-            float g = sg + ng;
+            float c = sc[i] + nc;
+            float g = sg[i] + ng;
             const float dj = nj - u.x;
             c += w_snap_v * (dj * dj);
-            // lon_planner.cu:114-118 in double; max(d, 0) is the difference where the test holds, +0 otherwise
             g = (float)((double)g + fmax(e->tn_v_d - (double)vmn, 0.0));
             const float s_change = tn_s - s;
             g += fmaxf(s_change - s_dist, 0.0f);
             c += u.y;
             g += u.z;
             const unsigned long long key = ((unsigned long long)__float_as_uint(g) << 32) | __float_as_uint(c);
-            const bool better = key < best;
-            best = better ? key : best;
-            bk = better ? kv : bk;
-        };
-#if V3_ABLATE != 1
-        cell(sd_base0, e0, u0, Rk0, sc0, sg0, best0, bk0);
-        cell(sd_base1, e1, u1, Rk1, sc1, sg1, best1, bk1);
-#else
-        best0 += __float_as_uint(Rk0[is].x + u0.x); best1 += __float_as_uint(Rk1[is].y + u1.x);
-#endif
-        asm volatile("" : "+v"(best0), "+v"(bk0), "+v"(best1), "+v"(bk1));
+            const bool better = key < best[i];
+            best[i] = better ? key : best[i];
+            bk[i] = better ? kv : bk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(best[i]), "+v"(bk[i]));
     }
     if (active) {
-        st_node(out + (size_t)row0 * S + is, __uint_as_float((unsigned)best0), __uint_as_float((unsigned)(best0 >> 32)),
-                action_jerk(p, bk0, N_BWD));
-        st_node(out + (size_t)row1 * S + is, __uint_as_float((unsigned)best1), __uint_as_float((unsigned)(best1 >> 32)),
-                action_jerk(p, bk1, N_BWD));
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            st_node(out + (size_t)(row0 + i) * S + is, __uint_as_float((unsigned)best[i]), __uint_as_float((unsigned)(best[i] >> 32)),
+                    action_jerk(p, bk[i], N_BWD));
     }
 }
 
@@ -301,7 +291,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 
 size_t backward3v_lds_bytes(int s_pad, int path_steps)
 {
-    return (size_t)4 * (s_pad + 1) * 16 + (size_t)2 * N_BWD * 8 * sizeof(float) + sizeof(float) * ((size_t)path_steps + 1);
+    return (size_t)2 * (s_pad + 1) * 16 + (size_t)2 * N_BWD * 8 * sizeof(float) + sizeof(float) * ((size_t)path_steps + 1);
 }
 
 bool launch_backward3v(int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
@@ -310,17 +300,10 @@ bool launch_backward3v(int path_div, int range_div, const SweepArgs& a, dim3 gri
         hipLaunchKernelGGL(kernel, grid, dim3(a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
         return true;
     };
-    static const bool no_prefetch = std::getenv("TPLHIP_V3_NO_PREFETCH") != nullptr;
-    if (no_prefetch) {
-        if (path_div == 4 && range_div == 3) return go(k_backward3v<4, 3, false>);
-        if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3, false>);
-        if (path_div == 4 && range_div == 4) return go(k_backward3v<4, 4, false>);
-        if (path_div == 3 && range_div == 4) return go(k_backward3v<3, 4, false>);
-    }
-    if (path_div == 4 && range_div == 3) return go(k_backward3v<4, 3, true>);
-    if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3, true>);
-    if (path_div == 4 && range_div == 4) return go(k_backward3v<4, 4, true>);
-    if (path_div == 3 && range_div == 4) return go(k_backward3v<3, 4, true>);
+    if (path_div == 4 && range_div == 3) return go(k_backward3v<4, 3>);
+    if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3>);
+    if (path_div == 4 && range_div == 4) return go(k_backward3v<4, 4>);
+    if (path_div == 3 && range_div == 4) return go(k_backward3v<3, 4>);
     return false;
 }
 
