@@ -376,6 +376,8 @@ def worker(args):
     rehearsal = world > 1 and os.environ.get("TPL_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

@@ -141,3 +141,17 @@ def test_single_process_skips_the_collective():
     from tpl_amd import sharding
     rec = _oracle_record(3)
     assert sharding.allgather_best(rec, None) is rec
+
+
+def test_bench_launcher_starts_its_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` (no torchrun): the parent starts two child ranks before touching a GPU; on a box
+    without one every rank refuses to run (no CPU fallback) and the launcher reports failure instead of a line."""
+    import subprocess
+    if torch.cuda.device_count() > 0 and os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present: the launcher is exercised by the bench itself")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-secondary", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert b"needs a GPU" in p.stderr or b"No HIP GPUs are available" in p.stderr or b"no usable HIP device" in p.stderr

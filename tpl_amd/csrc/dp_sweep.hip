@@ -38,6 +38,9 @@
 #ifndef V3_ABLATE
 #define V3_ABLATE 0
 #endif
+#ifndef V3_SETPRIO
+#define V3_SETPRIO 0
+#endif
 
 namespace tplhip {
 namespace {
@@ -197,6 +200,9 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     for (int k = 0; k < N_BWD; ++k) {
         // ---- phase 1: blend the next-stage rows around (v', a') for the NV cells (a, then v)
         {
+#if V3_SETPRIO
+            __builtin_amdgcn_s_setprio(V3_SETPRIO);
+#endif
 #if V3_ABLATE != 2
             issue_loads(k);
 #endif
@@ -224,6 +230,9 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if V3_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- phase 2: successor station, 1-D blend along s, costs, argmin -- per cell
         int kv = k;
         asm volatile("" : "+v"(kv));
