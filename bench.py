@@ -268,15 +268,18 @@ class _DeviceBytes:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_chunks=2):
+def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_chunks=2, grid="config2",
+                per_gpu=MC_PER_GPU, chunk=MC_CHUNK):
     """BASELINE configs[4]: 1024 scenario rollouts per GPU on the 128x64x32x50 grid, swept MC_CHUNK scenarios per
     launch; per-rank lexicographic (constr, cost, id) reduction on the device; ONE all-gather of the 1416-byte
-    record straight from HBM; identical argmin on every rank."""
+    record straight from HBM; identical argmin on every rank.  (Also run on the reference's default grid, the size
+    tpl really plans on: `grid`, `per_gpu`, `chunk`.)"""
     import numpy as np
     import torch
     import tpl_amd
     from tpl_amd import scenarios as sc, sharding
-    S, V, A, T = sc.GRIDS["config2"]
+    MC_PER_GPU, MC_CHUNK = per_gpu, chunk
+    S, V, A, T = sc.GRIDS[grid]
     p = sc.lon_params(S, V, A, T)
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
     path = sc.straight_path(p.path_steps, p.path_step_size)
@@ -336,6 +339,7 @@ def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_c
         "metric": "dp_stage_sweeps_per_s", "unit": "stage-sweeps/s (one sweep = one stage of one scenario)",
         "value": steps * n_total * (T - 1) / el, "n_gpus": world, "scaling": "weak",
         "rollouts": n_total, "rollouts_per_gpu": MC_PER_GPU, "rollouts_per_s": steps * n_total / el,
+        "plans_per_s": steps * n_total / el,
         "ms_per_pass": el / steps * 1e3, "passes": steps,
         "config": {"workload": f"{n_total} Monte-Carlo scenario rollouts (perturbed initial state + own moving obstacles), "
                                f"DP grid {S}x{V}x{A}, {T} stages, {MC_CHUNK} scenarios per launch, device-side "
@@ -475,6 +479,8 @@ def worker(args):
     if not args.no_secondary:
         # BASELINE configs[4] at this job size: 1024 rollouts per GPU
         mc = mc_rollouts(local_rank, rank, world, dist, rehearsal, barrier)
+        # the grid tpl really plans on (reference default 201x37x20, 10 stages), 256 scenarios per GPU, 64 per launch
+        mc_default = mc_rollouts(local_rank, rank, world, dist, rehearsal, barrier, steps=4, grid="default", per_gpu=256)
         from tpl_amd.optim import bench_ilqr
         il = bench_ilqr.run(local_rank, seed=rank, barrier=barrier if world > 1 else None, id_offset=rank * 1024)
         lat = bench_ilqr.run(local_rank, seed=rank, barrier=barrier if world > 1 else None, id_offset=rank * 1024,
@@ -496,7 +502,8 @@ def worker(args):
                 res["roofline"]["rank"] = rank
         il.pop("best_record", None)
         lat.pop("best_record", None)
-        secondary = {"mc_rollouts": mc, "batched_ilqr": il, "batched_ilqr_lateral_profile": lat}
+        secondary = {"mc_rollouts": mc, "default_grid_batched": mc_default, "batched_ilqr": il,
+                     "batched_ilqr_lateral_profile": lat}
         if rank == 0 and world == 1:
             if not args.no_cpu_baseline:
                 il["cpu_baseline"] = ilqr_cpu_baseline(x0_mpc, 50, 10.0, "mpc")

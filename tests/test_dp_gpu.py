@@ -55,10 +55,13 @@ GRID_CASES = [
     pytest.param(201, 50, 42, 4, sc.random_obstacles(3, 6), 0.4, id="ragged-rows-two-stations-per-lane"),
     pytest.param(256, 40, 52, 4, sc.OBSTACLES_OVERTAKE, None, id="full-rows-two-stations-per-lane"),
     pytest.param(128, 64, 66, 3, sc.random_obstacles(9, 7), None, id="s128-two-rows-per-lane"),
+    # an odd number of velocity rows: the last row pair of k_backward3v is row V-1 twice
+    pytest.param(128, 37, 120, 3, sc.random_obstacles(5, 6), None, id="odd-v-steps-plain-fp32-sweep"),
 ]
 
 EXPECTED_KERNEL = {"ragged-rows-two-rows-per-lane": (2, 1), "ragged-rows-two-stations-per-lane": (2, 0),
-                   "full-rows-two-stations-per-lane": (2, 0), "s128-two-rows-per-lane": (2, 1)}
+                   "full-rows-two-stations-per-lane": (2, 0), "s128-two-rows-per-lane": (2, 1),
+                   "odd-v-steps-plain-fp32-sweep": (2, 0)}
 
 
 @pytest.mark.parametrize("S,V,A,T,obst,dt_start", GRID_CASES)
@@ -74,6 +77,7 @@ def test_tables_and_trajectories_bit_exact(S, V, A, T, obst, dt_start, request):
     if case in EXPECTED_KERNEL:
         info = dp.info()
         assert (info["cells"], info["vpair"]) == EXPECTED_KERNEL[case], info
+        assert info["v3"] == 1, info                          # bounded inputs, power-of-two path step: the plain-fp32 sweep
     _assert_tables_equal(dp, tables, T)
     for r, tr in enumerate(trajs):
         got = _traj_np(tr)

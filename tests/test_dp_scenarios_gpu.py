@@ -30,14 +30,18 @@ CASES = [
     pytest.param(64, 16, 9, 5, 1, 1, False, id="B1-two-rows-per-lane"),
     pytest.param(128, 32, 12, 5, 3, 3, False, id="B3-s128-v32"),
     pytest.param(128, 64, 32, 4, 8, 8, False, id="B8-config2-grid"),
-    pytest.param(201, 37, 20, 6, 8, 3, False, id="B8-in-chunks-of-3-reference-default-grid"),     # generic kernel (V % 16 != 0)
+    pytest.param(201, 37, 20, 6, 8, 3, False, id="B8-in-chunks-of-3-reference-default-grid"),     # odd v_steps, ragged rows
     pytest.param(96, 16, 10, 5, 4, 4, True, id="B4-own-path-per-scenario"),
+    pytest.param(96, 17, 10, 5, 3, 3, "step0.3", id="B3-generic-kernel-path-step-0.3"),      # no proven cheap division: k_backward
 ]
 
 
 @pytest.mark.parametrize("S,V,A,T,n,chunk,own_paths", CASES)
 def test_batched_scenarios_bit_exact(S, V, A, T, n, chunk, own_paths):
     p = sc.lon_params(S, V, A, T)
+    want_kernel = "k_backward3v"
+    if own_paths == "step0.3":
+        p.path_step_size, p.path_steps, own_paths, want_kernel = 0.3, 667, False, "k_backward"
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
     occs, inits = _scenarios(n, ep, seed=S + n)
     if own_paths:
@@ -49,6 +53,7 @@ def test_batched_scenarios_bit_exact(S, V, A, T, n, chunk, own_paths):
     dp = tpl_amd.DynProgLonPlanner()
     dp.reinit_buffers(p)
     dp.upload_scenarios(occs, ep, inits, paths, chunk=chunk)
+    assert dp.info()["scenario_kernel"] == want_kernel, dp.info()
     cp, cep = O.cparams(p), O.cparams(ep)
     want_trajs, records = [], []
     for first in range(0, n, chunk):

@@ -1174,7 +1174,9 @@ struct tplhip_dp_lon {
     unsigned char* d_sc_best = nullptr;  // TplDpPlanRecord + TplLonState[t_steps]
     bool sc_bounded = false;
     int sc_last_first = 0, sc_last_count = 0;
-    bool vp_ok = false;                  // the two-rows-per-lane geometry fits this grid (any number of plans)
+    bool vp_ok = false;                  // the two-rows-per-lane geometry of k_backward2v fits this grid (v_steps % 16 == 0)
+    bool v3_ok = false;                  // ... that of k_backward3v (any v_steps)
+    int v3_grid = 0;
 
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1345,7 +1347,7 @@ void launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
     a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
     a.tile_v = h->tile_v; a.tile_a = h->tile_a;
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
-    launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->vp_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
+    launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
 }
 
 // the terminal stage of the two-station geometry: k_backward<true> with one station per lane
@@ -1392,7 +1394,7 @@ void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
     if (h->cells == 2) {
         if (terminal) launch_terminal(h, i);                         // rule R4
         else if (h->params_bounded && h->path_bounded && h->env_bounded) {
-            if (h->vpair && use_v3(h)) launch_backward3(h, i, nx);
+            if (h->v3_ok && use_v3(h)) launch_backward3(h, i, nx);
             else if (h->vpair) launch_backward2v<DIVMODE>(h, i, nx);
             else launch_backward2<DIVMODE>(h, i, nx);
         }
@@ -1860,6 +1862,14 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         h->vp_ok = (vo ? std::atoi(vo) != 0 : true) && p.v_steps % 16 == 0 && h->vp_s_pad <= 1024
                    && (h->tile_v % 2 == 0) && h->vp_lds <= 64 * 1024;
         h->vpair = false;
+        // k_backward3v deals row PAIRS to the XCDs, so it takes any v_steps
+        {
+            const int np = (p.v_steps + 1) / 2;
+            int max_pairs = 0;
+            for (int x = 0; x < 8; ++x) max_pairs = std::max(max_pairs, (((x + 1) * np) >> 3) - ((x * np) >> 3));
+            h->v3_grid = 8 * max_pairs * p.a_steps;
+            h->v3_ok = (vo ? std::atoi(vo) != 0 : true) && h->vp_s_pad <= 1024 && (h->tile_v % 2 == 0);
+        }
     }
     // Large grids (one action per barrier) run two stations per lane, see k_backward2.
     h->cells = 1;
@@ -2121,8 +2131,8 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
                   h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
                   h->div_mode, (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->cells,
                   (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0, (h->cells == 2 && h->vpair) ? 1 : 0,
-                  (h->cells == 2 && h->vpair && use_v3(h) && h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
-                  h->path_div3, h->range_div3, (h->vp_ok && use_v3(h) && h->sc_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0);
+                  (h->cells == 2 && h->v3_ok && use_v3(h) && h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
+                  h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0);
     return TPLHIP_OK;
 }
 
@@ -2262,7 +2272,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
         HIP_TRY(hipEventCreate(&e1), "event creation failed");
         HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
     }
-    const bool v3 = h->vp_ok && use_v3(h) && h->sc_bounded;
+    const bool v3 = h->v3_ok && use_v3(h) && h->sc_bounded;
     for (int i = T - 1; i > 0; --i) {
         const int nx = std::min(T - 1, i + 1);
         Node* out = h->d_sc_tables + (size_t)i * h->table_cells;
@@ -2282,7 +2292,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
             a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
             a.tile_v = h->tile_v; a.tile_a = h->tile_a;
             a.stride_tables = tab_stride; a.stride_pre = pre_stride; a.stride_path = path_stride;
-            launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->vp_grid, count),
+            launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, count),
                               backward3v_lds_bytes(h->vp_s_pad, p.path_steps), h->stream);
         } else {
             auto go = [&](auto kernel) {

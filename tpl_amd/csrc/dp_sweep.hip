@@ -38,8 +38,10 @@
 #ifndef V3_ABLATE
 #define V3_ABLATE 0
 #endif
+// wave priority while a wave requests and blends its rows (phase 1); phase 2 runs at priority 0.  Getting the loads out
+// and the block to its barrier first is worth 0.9 % (42.6 vs 43.0 us, same box); 0 switches it off
 #ifndef V3_SETPRIO
-#define V3_SETPRIO 0
+#define V3_SETPRIO 1
 #endif
 
 namespace tplhip {
@@ -104,10 +106,13 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     const float* __restrict__ path = path_all + scn * a.stride_path;
 
     constexpr int NV = 2;
-    // traversal: as k_backward2v (XCD = blockIdx.x & 7 owns a v range, a-major tiles inside), in units of NV rows
+    // traversal: as k_backward2v (XCD = blockIdx.x & 7 owns a v range, a-major tiles inside), in units of row PAIRS,
+    // so that any v_steps works: the pairs (0,1), (2,3), ... of an a-slice are dealt to the XCDs in contiguous runs;
+    // with an odd v_steps the last "pair" is row V-1 twice (second copy computed, not stored)
     const int xcd = blockIdx.x & 7;
-    const int v_lo = (xcd * V) >> 3, v_hi = ((xcd + 1) * V) >> 3;
-    const int vx = (v_hi - v_lo) / NV, tv = max(1, a.tile_v / NV);
+    const int NP = (V + NV - 1) / NV;
+    const int p_lo = (xcd * NP) >> 3, p_hi = ((xcd + 1) * NP) >> 3;
+    const int vx = p_hi - p_lo, tv = max(1, a.tile_v / NV);
     const int q = (int)(blockIdx.x >> 3);
     if (q >= vx * A) return;
     int ia, iv;
@@ -118,9 +123,10 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         const int tile = rem / (a.tile_a * w);
         const int r = rem - tile * (a.tile_a * w);
         ia = tile * a.tile_a + r / w;
-        iv = v_lo + NV * (strip * tv + (r - (r / w) * w));
+        iv = NV * (p_lo + strip * tv + (r - (r / w) * w));
     }
     const int row0 = ia * V + iv;
+    const int rs = (iv + 1 < V) ? N_BWD : 0;            // descriptor stride to the lane's second row (0: the row twice)
     const bool active = is < S;
     const int js = min(is, S - 1);
 
@@ -131,7 +137,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     float* pv = dsc + NV * N_BWD * 8;
     const ActDesc* __restrict__ d0 = acts + (size_t)row0 * N_BWD;
     for (int i = is; i < NV * N_BWD * 8; i += blockDim.x)
-        dsc[i] = reinterpret_cast<const float*>(d0 + (i >> 3))[i & 7];
+        dsc[i] = reinterpret_cast<const float*>(d0 + (i / (N_BWD * 8)) * rs + ((i >> 3) % N_BWD))[i & 7];
     for (int i = is; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];
 
     const float s = p.s_min + (float)js * p._s_step_size;
@@ -147,11 +153,11 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         const float x = (float)((double)c0 + prog);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const float v = p.v_min + (float)(iv + i) * p._v_step_size;
+            const float v = p.v_min + (float)(iv + (rs ? i : 0)) * p._v_step_size;
             const float gap = (v * p.time_gap + p.gap_min) - s_dist;
             sc[i] = (float)((double)x + (double)p.w_safety_dist * fmax(0.0, (double)gap));
             sg[i] = 0.0f; if (v > v_max) sg[i] += v - v_max;
-            sd_base[i] = (double)(s + d0[i * N_BWD].vdt) + d0[i * N_BWD].a_term;
+            sd_base[i] = (double)(s + d0[i * rs].vdt) + d0[i * rs].a_term;
         }
     }
     unsigned shared_mask = 0;
@@ -159,8 +165,8 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     for (int i = 0; i + 1 < NV; ++i) {
 #pragma unroll
         for (int k = 0; k < N_BWD; ++k) {
-            const ActDesc& x = d0[i * N_BWD + k];
-            const ActDesc& y = d0[(i + 1) * N_BWD + k];
+            const ActDesc& x = d0[i * rs + k];
+            const ActDesc& y = d0[(i + 1) * rs + k];
             const bool sh = x.r01 == y.r00 && x.r11 == y.r10 && __float_as_uint(x.wa) == __float_as_uint(y.wa);
             shared_mask |= (sh ? 1u : 0u) << (i * N_BWD + k);
         }
@@ -188,7 +194,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     auto issue_loads = [&](int k) {
         lo[0] = load_row(d0[k].r00); lo[1] = load_row(d0[k].r10);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) { up[i][0] = load_row(d0[i * N_BWD + k].r01); up[i][1] = load_row(d0[i * N_BWD + k].r11); }
+        for (int i = 0; i < NV; ++i) { up[i][0] = load_row(d0[i * rs + k].r01); up[i][1] = load_row(d0[i * rs + k].r11); }
     };
 #if V3_ABLATE == 2       // timing experiment: no row loads at all (registers fed from lane ids), results are wrong
     lo[0] = lo[1] = Node3{(float)is, 1.0f, 1.0f};
@@ -222,7 +228,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                     if ((shared_mask >> (i * N_BWD + k)) & 1u) {
                         bl = bu;
                     } else {
-                        const ActDesc& y = d0[(i + 1) * N_BWD + k];
+                        const ActDesc& y = d0[(i + 1) * rs + k];
                         const Node3 q00 = load_row(y.r00), q10 = load_row(y.r10);
                         bl = lerp3(q00, q10, w[i + 1].x, w[i + 1].y);
                     }
@@ -238,7 +244,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         asm volatile("" : "+v"(kv));
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const ActDesc* e = d0 + i * N_BWD + k;
+            const ActDesc* e = d0 + i * rs + k;
             const v4f u = dsc4[(i * N_BWD + k) * 2 + 1];
             const v4f* Rk = R + i * row_slots;
 #if V3_ABLATE == 1
@@ -291,7 +297,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     if (active) {
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-            st_node(out + (size_t)(row0 + i) * S + is, __uint_as_float((unsigned)best[i]), __uint_as_float((unsigned)(best[i] >> 32)),
+            if (i == 0 || rs) st_node(out + (size_t)(row0 + i) * S + is, __uint_as_float((unsigned)best[i]), __uint_as_float((unsigned)(best[i] >> 32)),
                     action_jerk(p, bk[i], N_BWD));
     }
 }
