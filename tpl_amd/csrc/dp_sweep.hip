@@ -40,6 +40,11 @@
 #endif
 // wave priority while a wave requests and blends its rows (phase 1); phase 2 runs at priority 0.  Getting the loads out
 // and the block to its barrier first is worth 0.9 % (42.6 vs 43.0 us, same box); 0 switches it off
+// 1: the scalar descriptor words of action k+1 (row ids, j_term, tn_v) are requested at the start of phase 2 of action
+// k, so that neither the row loads nor the first instruction of a phase 2 wait for a scalar-memory round trip
+#ifndef V3_EARLY_SMEM
+#define V3_EARLY_SMEM 1
+#endif
 #ifndef V3_SETPRIO
 #define V3_SETPRIO 1
 #endif
@@ -191,10 +196,22 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 #pragma unroll
     for (int i = 0; i < NV; ++i) { best[i] = 0x7f8000007f800000ull; bk[i] = 0; }
     Node3 lo[2], up[NV][2];
-    auto issue_loads = [&](int k) {
-        lo[0] = load_row(d0[k].r00); lo[1] = load_row(d0[k].r10);
+    // scalar descriptor words of ONE action: the rows (lower pair of row 0, upper pair of every row) and the two doubles
+    struct ActScalars { int r00, r10, r01[NV], r11[NV]; double j_term[NV], tn_v_d[NV]; };
+    auto fetch_scalars = [&](int k) {
+        ActScalars x;
+        x.r00 = d0[k].r00; x.r10 = d0[k].r10;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) { up[i][0] = load_row(d0[i * rs + k].r01); up[i][1] = load_row(d0[i * rs + k].r11); }
+        for (int i = 0; i < NV; ++i) {
+            const ActDesc& e = d0[i * rs + k];
+            x.r01[i] = e.r01; x.r11[i] = e.r11; x.j_term[i] = e.j_term; x.tn_v_d[i] = e.tn_v_d;
+        }
+        return x;
+    };
+    auto issue_loads = [&](const ActScalars& x) {
+        lo[0] = load_row(x.r00); lo[1] = load_row(x.r10);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { up[i][0] = load_row(x.r01[i]); up[i][1] = load_row(x.r11[i]); }
     };
 #if V3_ABLATE == 2       // timing experiment: no row loads at all (registers fed from lane ids), results are wrong
     lo[0] = lo[1] = Node3{(float)is, 1.0f, 1.0f};
@@ -202,15 +219,19 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 #endif
     __syncthreads();                     // descriptors and path limits are in LDS
     const v4f* dsc4 = reinterpret_cast<const v4f*>(dsc);
+    ActScalars cur = fetch_scalars(0);
 #pragma unroll
     for (int k = 0; k < N_BWD; ++k) {
+#if !V3_EARLY_SMEM
+        if (k > 0) cur = fetch_scalars(k);
+#endif
         // ---- phase 1: blend the next-stage rows around (v', a') for the NV cells (a, then v)
         {
 #if V3_SETPRIO
             __builtin_amdgcn_s_setprio(V3_SETPRIO);
 #endif
 #if V3_ABLATE != 2
-            issue_loads(k);
+            issue_loads(cur);
 #endif
             v4f w[NV];
 #pragma unroll
@@ -242,9 +263,17 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         // ---- phase 2: successor station, 1-D blend along s, costs, argmin -- per cell
         int kv = k;
         asm volatile("" : "+v"(kv));
+#if V3_EARLY_SMEM
+        const ActScalars now = cur;
+        if (k + 1 < N_BWD) {
+            cur = fetch_scalars(k + 1);
+            __builtin_amdgcn_sched_barrier(0);                 // the requests go out before this phase's arithmetic
+        }
+#else
+        const ActScalars& now = cur;
+#endif
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const ActDesc* e = d0 + i * rs + k;
             const v4f u = dsc4[(i * N_BWD + k) * 2 + 1];
             const v4f* Rk = R + i * row_slots;
 #if V3_ABLATE == 1
@@ -252,7 +281,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             continue;
 #endif
             // lonDynamics station part, lon_planner.cu:244
-            const double sd = sd_base[i] + e->j_term;
+            const double sd = sd_base[i] + now.j_term[i];
             const float tn_s = fmaxf(s, (float)sd);
             const float xs = tn_s - s_min_v;
             const float qs = div_const<RANGE_DIV>(xs, rr_hi, rr_lo);
@@ -281,7 +310,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             float g = sg[i] + ng;
             const float dj = nj - u.x;
             c += w_snap_v * (dj * dj);
-            g = (float)((double)g + fmax(e->tn_v_d - (double)vmn, 0.0));
+            g = (float)((double)g + fmax(now.tn_v_d[i] - (double)vmn, 0.0));
             const float s_change = tn_s - s;
             g += fmaxf(s_change - s_dist, 0.0f);
             c += u.y;
