@@ -375,6 +375,11 @@ def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE line, the result.  Libraries write there too (RCCL prints its version banner through C stdio,
+    # gloo announces connections): from here on file descriptor 1 is stderr, and the line goes to the saved descriptor
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     # Rehearsal: the N > 1 code path on a box with fewer GPUs than ranks -- every rank on device 0, collectives over
     # gloo (RCCL refuses two ranks on one device).  Set by the launcher below, never by the driver's torchrun.
     rehearsal = world > 1 and os.environ.get("TPL_BENCH_REHEARSAL") == "1"
@@ -382,8 +387,15 @@ def worker(args):
         local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    if world > 1:
+    # TPL_BENCH_FORCE_DIST=1 (tests/test_bench_gpu.py): a world of ONE rank still goes through RCCL -- process group,
+    # barrier, the device-memory all-gather of the record -- so that the N > 1 code path runs on the real backend
+    # on a one-GPU box
+    if world > 1 or os.environ.get("TPL_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         if rehearsal:
             dist.init_process_group("gloo")
@@ -468,7 +480,7 @@ def worker(args):
         if rehearsal:
             out["rehearsal"] = True
             out["note"] = f"{world} ranks share ONE device over gloo: exercises the N > 1 code path, says nothing about scaling"
-        if world > 1:
+        if dist is not None:
             out["best_plan"] = {"constr": float(best[0]), "cost": float(best[1]), "rank": int(best[2])}
         traffic_block(out, p, cells, per_launch_s)
         if not args.no_cpu_baseline and world == 1:
@@ -482,11 +494,11 @@ def worker(args):
         # the grid tpl really plans on (reference default 201x37x20, 10 stages), 256 scenarios per GPU, 64 per launch
         mc_default = mc_rollouts(local_rank, rank, world, dist, rehearsal, barrier, steps=4, grid="default", per_gpu=256)
         from tpl_amd.optim import bench_ilqr
-        il = bench_ilqr.run(local_rank, seed=rank, barrier=barrier if world > 1 else None, id_offset=rank * 1024)
-        lat = bench_ilqr.run(local_rank, seed=rank, barrier=barrier if world > 1 else None, id_offset=rank * 1024,
+        il = bench_ilqr.run(local_rank, seed=rank, barrier=barrier if dist is not None else None, id_offset=rank * 1024)
+        lat = bench_ilqr.run(local_rank, seed=rank, barrier=barrier if dist is not None else None, id_offset=rank * 1024,
                              workload="lateral", updates=20)
         x0_mpc, x0_lat = il.pop("x0"), lat.pop("x0")
-        if world > 1:
+        if dist is not None:
             dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
             for res in (il, lat):
                 t = torch.tensor([res["elapsed_s"]], dtype=torch.float64, device=dev)
@@ -519,10 +531,12 @@ def worker(args):
     if rank == 0:
         if secondary:
             out["secondary"] = secondary
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
 
 
 def launcher(args, argv):

@@ -1,0 +1,48 @@
+"""bench.py's contract on a GPU box: ONE JSON line with the fields the driver reads, and the N > 1 code path run
+through RCCL itself.  A one-GPU box cannot hold two RCCL ranks, so the second test forces a process group of one
+rank (TPL_BENCH_FORCE_DIST=1): init_process_group("nccl"), the barriers, the all-gather of the device-resident record
+(`DynProgLonPlanner.best_record_device` -> __cuda_array_interface__ -> torch, no host copy) and the reductions are the
+calls ranks 0..N-1 make at N > 1."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(extra_env, *flags):
+    env = dict(os.environ, **extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", *flags], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                       # exactly one line on stdout
+    return json.loads(lines[0])
+
+
+def test_one_line_with_the_contract_fields():
+    d = _bench({}, "--no-secondary")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert 0.05 < rf["frac"] < 1.0
+    assert rf["kernel"].startswith("k_backward3v")       # the large-grid sweep is the one that ran
+
+
+def test_collectives_run_through_rccl_with_one_rank():
+    d = _bench({"TPL_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29547", "RANK": "0",
+                "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert d["n_gpus"] == 1 and "best_plan" in d and d["best_plan"]["rank"] == 0
+    mc = d["secondary"]["mc_rollouts"]
+    assert mc["best_plan"]["identical_on_all_ranks"] and mc["value"] > 0
+    for name in ("batched_ilqr", "batched_ilqr_lateral_profile"):
+        assert d["secondary"][name]["all_finite"] and "best_plan" in d["secondary"][name]

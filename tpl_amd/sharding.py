@@ -59,7 +59,7 @@ def allgather_best(record, dist=None, device=None):
     """All ranks contribute their best record; every rank returns the global
     best (identical on all ranks).  dist: torch.distributed or None (single
     process: no collective at all)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return record
     import torch
     world = dist.get_world_size()
