@@ -57,7 +57,7 @@ def main():
     ll.traj_smooth[0] = s0
     ll.update_traj_dp(env)
     ll.update_traj_smooth(env)
-    ll.update_traj_cart(env)
+    ll.update_traj_cart(env.ref_line)
     b = ll.traj_dp.as_numpy()
     print("(s,ds,l) plan s:", np.round(b[:, 1], 1), " l:", np.round(b[:, 5], 2))
 

@@ -132,6 +132,11 @@ TPLHIP_API int tplhip_dp_env_insert_geometry(tplhip_dp_env* env, const double* g
  * updateDistMapLon.  TPLHIP_ESTATE with the reference's message when the reference
  * line is shorter than s_max. */
 TPLHIP_API int tplhip_dp_env_update(tplhip_dp_env* env);
+/* Only the last stage of update(), updateDistMapLon (env.cu:95-129), on the Frenet occupancy the
+ * environment holds (from update() or tplhip_dp_env_set_occ_map).  Not in the reference's bindings:
+ * it lets a table dumped with get_occ_map() from the CUDA build drive the planners that read the
+ * longitudinal distance map, independent of the rasterisation stages (tests/cycle_golden_format.py). */
+TPLHIP_API int tplhip_dp_env_update_dist_maps(tplhip_dp_env* env);
 /* get_occ_map_cartesian (bindings_dp_env.cu:76-83): uint32[size][size], size from
  * tplhip_dp_env_cart_size (1 before the first update, like the reference's 1x1 frame buffer) */
 TPLHIP_API int tplhip_dp_env_cart_size(tplhip_dp_env* env, int* size_pixels);

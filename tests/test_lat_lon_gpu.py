@@ -117,7 +117,11 @@ def test_reeval_smooth_and_cartesian():
     out = (TplLatLonState * 256)()
     n = oll.lib().llo_update_traj_smooth(C.byref(p._c), otraj, len(otraj), C.byref(_start()._c), out, 256)
     assert n == len(pl.traj_smooth.states) and n > 10
-    assert np.allclose(pl.traj_smooth.as_numpy(), oll.states_np(out[:n]), rtol=1e-9, atol=1e-9)
+    assert np.allclose(pl.traj_smooth.as_numpy_full(), oll.states_np(out[:n]), rtol=1e-9, atol=1e-9)
+    # the reference's array conversions (bindings_dp_lat_lon.cu:56-70, 132-184, 32-44, 83-116): column subsets
+    assert pl.traj_smooth.as_numpy().shape == (n, 9) and pl.traj_smooth[0].as_numpy().shape == (7,)
+    assert np.array_equal(pl.traj_smooth.as_numpy(), pl.traj_smooth.as_numpy_full()[:, :9])
+    assert pl.traj_smooth.state(np.array([0.1, 0.2])).shape == (2, 7) and pl.traj_smooth.lerp(np.array([0.1])).shape == (1, 7)
     assert len(pl.lat_dists) == 1 and pl.lat_dists[0].d_left == 0.0          # lat_lon_planner.cu:729-747
     # Frenet -> Cartesian (host arithmetic on both sides: identical), called the way
     # dp_lat_lon_planner.py:148 calls it: with the environment's RefLine
@@ -128,6 +132,8 @@ def test_reeval_smooth_and_cartesian():
     assert bytes(pl.traj_dp_cart._as_array()) == bytes(ocart)
     assert len(pl.traj_smooth_cart.states) == n
     c = pl.traj_smooth_cart.lerp(0.55)
+    assert pl.traj_smooth_cart.as_numpy().shape == (n, 8) and c.as_numpy().shape == (8,)
+    assert pl.traj_smooth_cart.lerp(np.array([0.5, 1.0])).shape == (2, 7)
     assert np.isfinite(c.x) and np.isfinite(c.heading)
     # the environment itself and a free-standing RefLine with the same points give the same conversion
     via_env = pl.frenet_to_cartesian(pl.traj_dp, env)
@@ -152,7 +158,7 @@ def test_free_road_plan_cruises_in_lane_and_flags():
     pl.reinit_buffers(p)
     pl.traj_dp[0] = _start(0.0, 8.0, 0.0)
     pl.update_traj_dp(env)
-    a = pl.traj_dp.as_numpy()
+    a = pl.traj_dp.as_numpy_full()
     assert np.all(a[:, 10] == 0.0) and np.all(a[:, 11] == 0)               # no constraint violated
     assert np.all(np.abs(a[:, 5]) < 1.0) and np.all(a[:, 2] <= 10.0 + 1e-6)   # stays near l_trg, below v_max
 

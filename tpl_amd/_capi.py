@@ -151,6 +151,7 @@ SIGNATURES = {
     "tplhip_dp_env_destroy": (C.c_int, [_vp]),
     "tplhip_dp_env_reinit": (C.c_int, [_vp, _P(TplDpEnvParams)]),
     "tplhip_dp_env_set_occ_map": (C.c_int, [_vp, _fp]),
+    "tplhip_dp_env_update_dist_maps": (C.c_int, [_vp]),
     "tplhip_dp_env_get_occ_map": (C.c_int, [_vp, _fp]),
     "tplhip_dp_env_get_dist_map_path": (C.c_int, [_vp, _fp]),
     "tplhip_dp_env_set_ref_line": (C.c_int, [_vp, _P(C.c_double), C.c_int, C.c_float]),

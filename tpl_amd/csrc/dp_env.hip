@@ -346,6 +346,34 @@ int tplhip_dp_env_insert_geometry(tplhip_dp_env* env, const double* geom, int n,
     return TPLHIP_OK;
 }
 
+// updateDistMapLon (env.cu:95-129) on the Frenet occupancy currently in d_occ
+static int launch_dist_map_lon(tplhip_dp_env* env, hipStream_t st)
+{
+    const TplDpEnvParams& ep = env->params;
+    // LDS per workgroup: 12 bytes per (station, slice); at most 60 KB
+    const int tc_cap = std::max(1, std::min(DML_TC, (int)(60 * 1024 / (12 * (size_t)ep.s_steps))));
+    if (12 * (size_t)ep.s_steps * tc_cap > 64 * 1024)
+        return tplhip_fail(TPLHIP_EINVAL, "s_steps = %d is too large for the distance-map kernel", ep.s_steps);
+    hipLaunchKernelGGL(k_dist_map_lon, dim3(ep.l_steps, (ep.t_steps + tc_cap - 1) / tc_cap), dim3(256),
+                       sizeof(float) * 3 * (size_t)ep.s_steps * tc_cap, st, env->d_dist_lon, env->d_occ, ep, tc_cap);
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_env_update_dist_maps(tplhip_dp_env* env)
+{
+    if (!env) return tplhip_fail(TPLHIP_EINVAL, "null handle");
+    if (!env->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the environment");
+    if (!env->have_occ) return tplhip_fail(TPLHIP_ESTATE, "no occupancy map: call set_occ_map or update first");
+    if (env->params.l_steps > 1024) return tplhip_fail(TPLHIP_EINVAL, "l_steps = %d exceeds one workgroup", env->params.l_steps);
+    HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
+    hipStream_t st = nullptr;
+    int rc;
+    if ((rc = launch_dist_map_lon(env, st))) return rc;
+    HIP_TRY(hipGetLastError(), "distance-map launch failed");
+    HIP_TRY(hipStreamSynchronize(st), "updating the distance maps failed");
+    return TPLHIP_OK;
+}
+
 int tplhip_dp_env_update(tplhip_dp_env* env)
 {
     if (!env) return tplhip_fail(TPLHIP_EINVAL, "null handle");
@@ -398,14 +426,7 @@ int tplhip_dp_env_update(tplhip_dp_env* env)
                        env->d_occ, env->d_cart, W, env->d_frames, ep);
     hipLaunchKernelGGL(k_close_intersections, dim3((ep.t_steps * ep.s_steps + 255) / 256), dim3(256), 0, st,
                        env->d_occ, env->d_semantic, (int)n_ref, env->ref_step, ep);
-    {
-        // LDS per workgroup: 12 bytes per (station, slice); at most 60 KB
-        const int tc_cap = std::max(1, std::min(DML_TC, (int)(60 * 1024 / (12 * (size_t)ep.s_steps))));
-        if (12 * (size_t)ep.s_steps * tc_cap > 64 * 1024)
-            return tplhip_fail(TPLHIP_EINVAL, "s_steps = %d is too large for the distance-map kernel", ep.s_steps);
-        hipLaunchKernelGGL(k_dist_map_lon, dim3(ep.l_steps, (ep.t_steps + tc_cap - 1) / tc_cap), dim3(256),
-                           sizeof(float) * 3 * (size_t)ep.s_steps * tc_cap, st, env->d_dist_lon, env->d_occ, ep, tc_cap);
-    }
+    if ((rc = launch_dist_map_lon(env, st))) return rc;
     HIP_TRY(hipGetLastError(), "occupancy pipeline launch failed");
     HIP_TRY(hipStreamSynchronize(st), "updating the environment failed");
     env->vertices.clear();            // occupancy_renderer.cu:311

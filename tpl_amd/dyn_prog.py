@@ -217,6 +217,10 @@ class DynProgEnvironment:
             raise ValueError(f"array has incorrect shape, expected: {self._shape()}, got: {occ.shape}")
         check(self._lib.tplhip_dp_env_set_occ_map(self._h, _fptr(occ)))
 
+    def update_dist_maps(self):
+        """updateDistMapLon (env.cu:95-129) alone, on the occupancy set by set_occ_map / the last update()."""
+        check(self._lib.tplhip_dp_env_update_dist_maps(self._h))
+
     def get_occ_map(self):
         occ = np.empty(self._shape(), dtype=np.float32)
         check(self._lib.tplhip_dp_env_get_occ_map(self._h, _fptr(occ)))

@@ -13,6 +13,13 @@ LAT_LON_CONSTR_OCCUPANCY, LAT_LON_CONSTR_VELOCITY, LAT_LON_CONSTR_ANGLE = 1, 2, 
 
 _STATE_F = ("t", "s", "ds", "dds", "ddds", "l", "dl", "ddl", "dddl", "cost", "constr", "flags_constr")
 _CART_F = ("t", "distance", "x", "y", "v", "a", "heading", "k", "cost", "constr", "flags_constr")
+# column subsets of the reference's array conversions (bindings_dp_lat_lon.cu): a state / a state(ts) or lerp(ts)
+# row has 7 columns, a trajectory's as_numpy() prepends t and appends dddl (:56-70, :132-165, :166-184); a
+# Cartesian state has 8 columns, a Cartesian lerp(distances) row drops t (:32-44, :83-116)
+_STATE_ROW = ("s", "ds", "dds", "ddds", "l", "dl", "ddl")
+_STATE_TRAJ_ROW = ("t", "s", "ds", "dds", "ddds", "l", "dl", "ddl", "dddl")
+_CART_ROW = ("t", "distance", "x", "y", "v", "a", "heading", "k")
+_CART_LERP_ROW = ("distance", "x", "y", "v", "a", "heading", "k")
 
 
 class DynProgLatLonPlannerParams(_StructView):
@@ -39,7 +46,7 @@ class LatLonState(_StructView):
         return st
 
     def as_numpy(self):
-        return np.array([getattr(self._c, f) for f in _STATE_F], dtype=np.float64)
+        return np.array([getattr(self._c, f) for f in _STATE_ROW], dtype=np.float64)
 
 
 class LatLonCartState(_StructView):
@@ -58,7 +65,7 @@ class LatLonCartState(_StructView):
         return st
 
     def as_numpy(self):
-        return np.array([getattr(self._c, f) for f in _CART_F], dtype=np.float64)
+        return np.array([getattr(self._c, f) for f in _CART_ROW], dtype=np.float64)
 
 
 class _Traj:
@@ -112,10 +119,15 @@ class _Traj:
 
     def as_numpy(self):
         arr = self._as_array()
-        res = np.empty((len(arr), len(self._fields)), dtype=np.float64)
+        res = np.empty((len(arr), len(self._traj_row)), dtype=np.float64)
         for i, c in enumerate(arr):
-            res[i] = [getattr(c, f) for f in self._fields]
+            res[i] = [getattr(c, f) for f in self._traj_row]
         return res
+
+    def as_numpy_full(self):
+        """Every member of every state (not in the reference: its as_numpy() drops cost / constr / flags)."""
+        arr = self._as_array()
+        return np.array([[getattr(c, f) for f in self._fields] for c in arr], dtype=np.float64).reshape(len(arr), len(self._fields))
 
     def copy(self):
         other = type(self)()
@@ -131,10 +143,10 @@ class _Traj:
             raise ValueError(f"array has incorrect shape, expected: (-1,), got: {ts.shape}")
         arr = self._as_array()
         out = self._ctype()
-        res = np.empty((len(ts), len(self._fields)), dtype=np.float64)
+        res = np.empty((len(ts), len(self._many_row)), dtype=np.float64)
         for i, t in enumerate(ts):
             check(fn(arr, len(arr), float(t), C.byref(out)))
-            res[i] = [getattr(out, f) for f in self._fields]
+            res[i] = [getattr(out, f) for f in self._many_row]
         return res
 
     def _one(self, fn, t):
@@ -149,6 +161,8 @@ class LatLonTraj(_Traj):
     _state_cls = LatLonState
     _ctype = TplLatLonState
     _fields = _STATE_F
+    _traj_row = _STATE_TRAJ_ROW
+    _many_row = _STATE_ROW
 
     def state(self, t):
         fn = _capi.load().tplhip_lat_lon_traj_state
@@ -164,6 +178,8 @@ class LatLonCartTraj(_Traj):
     _state_cls = LatLonCartState
     _ctype = TplLatLonCartState
     _fields = _CART_F
+    _traj_row = _CART_ROW
+    _many_row = _CART_LERP_ROW
 
     def lerp(self, t):
         fn = _capi.load().tplhip_lat_lon_cart_lerp
