@@ -84,6 +84,9 @@ typedef struct tplhip_dp_lon tplhip_dp_lon;   /* replaces DynProgLonPlanner */
 TPLHIP_API const char* tplhip_last_error(void);
 /* tplcpp.cuda_get_device_count, bindings_dp_common.cu:38-45 (0 on error) */
 TPLHIP_API int tplhip_device_count(void);
+/* tplcpp.cuda_set_device, bindings_dp_common.cu:47-49: handles created with device < 0 use this device
+ * (default: the last one, as tpl/planning/__init__.py:2-7 selects) */
+TPLHIP_API int tplhip_set_device(int idx);
 TPLHIP_API const char* tplhip_version(void);
 
 TPLHIP_API void tplhip_dp_lon_params_default(TplDpLonParams* p);   /* lon_planner.cuh:9-43 defaults */
@@ -378,6 +381,13 @@ typedef struct TplProjection {
     double tangent[2];
     int32_t in_bounds;
 } TplProjection;
+
+/* RefLine(data, len, step_size, no_offset), utils.hpp:184-214: copies double[n][9] reference-line points into `out`
+ * with the bounding-box centre subtracted (unless no_offset) and returns that centre */
+TPLHIP_API int tplhip_ref_line_center(const double* points, int n, int no_offset, double* out, double* x_offset,
+                                      double* y_offset);
+/* RefLine::lerp = interpRefLine, utils.hpp:148-173: the point at station s, out = double[9] */
+TPLHIP_API int tplhip_ref_line_lerp(const double* points, int n, float step_size, float s, double* out);
 
 /* tplcpp.project, utils.cpp:257-408: m positions (double[m][2]) on the line strip points (x, y in the first two
  * of `stride` doubles per point); closed != 0 treats it as a loop */

@@ -138,7 +138,7 @@ def test_reeval_smooth_and_cartesian():
     # the environment itself and a free-standing RefLine with the same points give the same conversion
     via_env = pl.frenet_to_cartesian(pl.traj_dp, env)
     rl = env.ref_line
-    free = tpl_amd.RefLine(rl.points.copy(), rl.step_size, rl.x_offset, rl.y_offset)
+    free = tpl_amd.RefLine(rl.as_array().copy(), rl.step_size, rl.x_offset, rl.y_offset)
     via_free = pl.frenet_to_cartesian(pl.traj_dp, free)
     assert bytes(via_env._as_array()) == bytes(ocart)
     assert np.allclose(via_free.as_numpy(), pl.traj_dp_cart.as_numpy(), rtol=0, atol=1e-9)

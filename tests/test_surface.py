@@ -1,0 +1,94 @@
+"""tpl_amd answers to every name tplcpp's bindings expose for the DP family.  The list of names is a fixture
+(tests/golden/tplcpp_surface.json, written by tests/golden/make_surface_fixture.py from the reference's binding
+sources: class / method / attribute / function names, nothing else).  No GPU: objects whose constructor creates a
+device handle are checked on the class."""
+import json
+import os
+
+import pytest
+
+import tpl_amd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SURFACE = json.load(open(os.path.join(HERE, "golden", "tplcpp_surface.json")))
+# constructing these opens a device handle; their surface is checked on the class object
+NEEDS_DEVICE = {"DynProgEnvironment", "DynProgLonPlanner", "PolyLatPlanner", "DynProgLatLonPlanner"}
+# instance attributes set in __init__ of device-owning classes (def_readwrite members in the reference)
+INSTANCE_ATTRS = {"DynProgEnvironment": {"ref_line"},
+                  "DynProgLatLonPlanner": {"traj_dp", "traj_smooth", "traj_dp_cart", "traj_smooth_cart", "lat_dists"}}
+
+
+def test_module_functions():
+    for f in SURFACE["functions"]:
+        assert callable(getattr(tpl_amd, f, None)), f"tpl_amd.{f} is missing"
+
+
+@pytest.mark.parametrize("name", sorted(SURFACE["classes"]))
+def test_class_surface(name):
+    want = SURFACE["classes"][name]
+    cls = getattr(tpl_amd, name, None)
+    assert cls is not None, f"tpl_amd.{name} is missing"
+    if name in NEEDS_DEVICE:
+        obj, probe = None, cls
+    else:
+        obj = cls() if want["init"] or name == "RefLine" else None
+        probe = obj if obj is not None else cls
+    for m in want["methods"]:
+        assert callable(getattr(probe, m, None)), f"{name}.{m}() is missing"
+    for a in want["attributes"]:
+        if name in NEEDS_DEVICE:
+            assert a in INSTANCE_ATTRS.get(name, ()), f"{name}.{a} is not known to be set by __init__"
+            continue
+        assert hasattr(obj, a), f"{name}.{a} is missing"
+        if name not in ("RefLine",):
+            setattr(obj, a, getattr(obj, a))                    # read-write like def_readwrite
+    if "slots" in want:
+        assert list(obj.__slots__) == want["slots"], f"{name}.__slots__ differs"
+    if "__deepcopy__" in want["methods"]:
+        import copy
+        other = copy.deepcopy(obj)
+        assert other is not obj and other == obj
+
+
+def test_device_classes_set_their_members(monkeypatch):
+    """The def_readwrite members of the device-owning classes are assigned in __init__ (checked on the source of
+    __init__, no handle is created)."""
+    import inspect
+    for name, attrs in INSTANCE_ATTRS.items():
+        src = inspect.getsource(getattr(tpl_amd, name).__init__)
+        for a in attrs:
+            assert f"self.{a} =" in src, f"{name}.__init__ does not set {a}"
+
+
+def test_ref_line_fromarray_and_lerp():
+    """RefLine (utils.hpp:176-220): bounding-box centring, interpRefLine with its float weights, the short way
+    round for the heading, the nearer sample's semantic flag (as the source writes it), clamping at both ends."""
+    import numpy as np
+    rl = np.zeros((4, 9))
+    rl[:, 0] = [10.0, 12.0, 14.0, 16.0]
+    rl[:, 1] = [-2.0, 0.0, 2.0, 8.0]
+    rl[:, 2] = [3.1, -3.1, -3.0, -2.9]          # crosses +-pi between samples 0 and 1
+    rl[:, 3] = [0.0, 2.0, 4.0, 6.0]
+    rl[:, 5] = [5.0, 7.0, 9.0, 11.0]
+    rl[:, 8] = [0.0, 1.0, 0.0, 1.0]
+    line = tpl_amd.RefLine.fromarray(rl, 2.0)
+    assert line.x_offset == 13.0 and line.y_offset == 3.0 and float(line.step_size) == 2.0
+    pts = line.points
+    assert len(pts) == 4 and pts[0].x == -3.0 and pts[3].y == 5.0 and pts[1].semantic == 1.0
+    raw = tpl_amd.RefLine.fromarray(rl, 2.0, True)
+    assert raw.x_offset == 0.0 and raw.points[0].x == 10.0
+    p = raw.lerp(1.0)                              # halfway between samples 0 and 1
+    assert p.x == 11.0 and p.y == -1.0 and p.s == 1.0 and p.v_max == 6.0
+    want = 3.1 + (2 * np.pi - 6.2) * 0.5           # the short way round, not the mean (0.0)
+    assert abs(p.heading - want) < 1e-12
+    a = np.float32(0.5) / np.float32(2.0)          # s = 0.5: a = 0.25, ia = 0.75 -> ia < 0.5 is false -> sample i1
+    q = raw.lerp(0.5)
+    assert q.semantic == 1.0 and q.x == 10.0 * float(np.float32(1.0) - a) + 12.0 * float(a)
+    assert raw.lerp(1.5).semantic == 0.0           # ia = 0.25 < 0.5 -> sample i0
+    assert raw.lerp(-5.0).x == 10.0                # both indices clamp to sample 0: 10 * 3.5 + 10 * -2.5
+    end = raw.lerp(100.0)                          # both indices clamp to the last sample; a = 50 - 3 = 47 extrapolates nothing
+    assert end.x == 16.0 * (1.0 - 47.0) + 16.0 * 47.0
+    with pytest.raises(ValueError, match="expected: \\(-1, 9\\)"):
+        tpl_amd.RefLine.fromarray(np.zeros((3, 8)), 1.0)
+    line.points = pts[:2]
+    assert line.as_array().shape == (2, 9)

@@ -18,10 +18,11 @@ from .dyn_prog import (  # noqa: E402
     LonState,
     LonTraj,
     cuda_get_device_count,
+    cuda_set_device,
     lon_dynamics,
 )
 
-from .dyn_prog import RefLine  # noqa: E402
+from .dyn_prog import RefLine, RefLinePoint  # noqa: E402
 from .lat_lon import (  # noqa: E402
     DynProgLatLonPlanner,
     DynProgLatLonPlannerParams,
@@ -44,5 +45,5 @@ __all__ = [
     "LatLonTraj",
     "PolyLatPlanner", "PolyLatPlannerParams", "PolyLatTraj", "PolyLatTrajPoint", "PolyQuintic",
     "DynProgEnvParams", "DynProgEnvironment", "DynProgLonPlanner", "DynProgLonPlannerParams",
-    "LonState", "LonTraj", "RefLine", "LatDistances", "cuda_get_device_count", "lon_dynamics",
+    "LonState", "LonTraj", "RefLine", "RefLinePoint", "LatDistances", "cuda_get_device_count", "cuda_set_device", "lon_dynamics",
 ]

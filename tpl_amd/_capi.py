@@ -134,14 +134,23 @@ class TplLatLonCartState(C.Structure):
 
 assert C.sizeof(TplLatLonState) == 48 and C.sizeof(TplLatLonCartState) == 88
 
+class TplRefLinePoint(C.Structure):
+    """RefLinePoint, utils.hpp:129-140."""
+    _fields_ = [(n, C.c_double) for n in ("x", "y", "heading", "s", "k", "v_max", "d_left", "d_right", "semantic")]
+
+
 _P = C.POINTER
 _vp = C.c_void_p
 _fp = _P(C.c_float)
+_dp = _P(C.c_double)
 
 # name -> (restype, argtypes); mirrors include/tplhip.h declaration by declaration
 SIGNATURES = {
     "tplhip_last_error": (C.c_char_p, []),
     "tplhip_device_count": (C.c_int, []),
+    "tplhip_set_device": (C.c_int, [C.c_int]),
+    "tplhip_ref_line_center": (C.c_int, [_dp, C.c_int, C.c_int, _dp, _dp, _dp]),
+    "tplhip_ref_line_lerp": (C.c_int, [_dp, C.c_int, C.c_float, C.c_float, _dp]),
     "tplhip_version": (C.c_char_p, []),
     "tplhip_dp_lon_params_default": (None, [_P(TplDpLonParams)]),
     "tplhip_dp_env_params_default": (None, [_P(TplDpEnvParams)]),

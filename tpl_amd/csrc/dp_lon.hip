@@ -1203,7 +1203,7 @@ int pick_device(int device)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -1;
-    if (device < 0) device = n - 1;        // tpl/planning/__init__.py:2-7 picks the last device
+    if (device < 0) device = tplhip_default_device(n);
     if (device >= n) return -1;
     return device;
 }

@@ -790,7 +790,7 @@ int tplhip_lat_lon_create(int device, tplhip_lat_lon** out)
     if (!out) return tplhip_fail(TPLHIP_EINVAL, "null out pointer");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return tplhip_fail(TPLHIP_EDEVICE, "no usable HIP device");
-    if (device < 0) device = n - 1;
+    if (device < 0) device = tplhip_default_device(n);
     if (device >= n) return tplhip_fail(TPLHIP_EDEVICE, "no usable HIP device (requested %d)", device);
     tplhip_lat_lon* h = new (std::nothrow) tplhip_lat_lon();
     if (!h) return tplhip_fail(TPLHIP_EDEVICE, "out of host memory");

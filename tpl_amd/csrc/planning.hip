@@ -7,9 +7,11 @@
 // reassociation; tests compare at 1e-9).
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "tplhip_common.h"
+#include "dp_env_internal.h"      // short_angle_dist (utils.hpp:21-53)
 
 namespace {
 
@@ -228,6 +230,43 @@ int tplhip_rampify_lateral_profile(double step, int horizon, double evasion_shar
         }
     }
     for (int i = 0; i < n_path; ++i) out[i] = std::max(fwd[i], bwd[i]);
+    return TPLHIP_OK;
+}
+
+// RefLine(RefLinePoint*, len, step_size, no_offset), utils.hpp:184-214: the bounding-box centre is subtracted
+int tplhip_ref_line_center(const double* points, int n, int no_offset, double* out, double* x_offset, double* y_offset)
+{
+    if (!points || !out || !x_offset || !y_offset || n < 0) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
+    std::memcpy(out, points, sizeof(double) * 9 * (size_t)n);
+    *x_offset = 0.0;
+    *y_offset = 0.0;
+    if (no_offset) return TPLHIP_OK;
+    double x_min = INFINITY, x_max = -INFINITY, y_min = INFINITY, y_max = -INFINITY;
+    for (int i = 0; i < n; ++i) {
+        x_min = std::min(x_min, out[9 * i]);     x_max = std::max(x_max, out[9 * i]);
+        y_min = std::min(y_min, out[9 * i + 1]); y_max = std::max(y_max, out[9 * i + 1]);
+    }
+    *x_offset = x_min + (x_max - x_min) / 2.0;
+    *y_offset = y_min + (y_max - y_min) / 2.0;
+    for (int i = 0; i < n; ++i) { out[9 * i] -= *x_offset; out[9 * i + 1] -= *y_offset; }
+    return TPLHIP_OK;
+}
+
+// RefLine::lerp = interpRefLine, utils.hpp:148-173 (float weights promoted per product; the semantic channel is
+// the nearer sample's)
+int tplhip_ref_line_lerp(const double* points, int n, float step_size, float s, double* out)
+{
+    if (!points || !out || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
+    float a = s / step_size;
+    const int i0 = std::max(0, std::min(n - 1, (int)std::floor(a)));
+    const int i1 = std::max(0, std::min(n - 1, (int)std::ceil(a)));
+    a -= (float)i0;
+    const float ia = (float)(1.0 - (double)a);
+    const double* p0 = points + 9 * (size_t)i0;
+    const double* p1 = points + 9 * (size_t)i1;
+    for (int c = 0; c < 8; ++c) out[c] = p0[c] * (double)ia + p1[c] * (double)a;
+    out[2] = p0[2] + tplhip::short_angle_dist(p0[2], p1[2]) * (double)a;
+    out[8] = (ia < 0.5f) ? p0[8] : p1[8];
     return TPLHIP_OK;
 }
 

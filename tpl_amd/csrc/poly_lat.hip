@@ -354,7 +354,7 @@ int tplhip_poly_lat_create(int device, tplhip_poly_lat** out)
     if (!out) return tplhip_fail(TPLHIP_EINVAL, "null out pointer");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return tplhip_fail(TPLHIP_EDEVICE, "no usable HIP device");
-    if (device < 0) device = n - 1;
+    if (device < 0) device = tplhip_default_device(n);
     if (device >= n) return tplhip_fail(TPLHIP_EDEVICE, "no usable HIP device (requested %d)", device);
     tplhip_poly_lat* h = new (std::nothrow) tplhip_poly_lat();
     if (!h) return tplhip_fail(TPLHIP_EDEVICE, "out of host memory");

@@ -9,6 +9,8 @@
 // msg>: <context>") (library/src/dyn_prog/common.cu:3-10); HIP_TRY builds the
 // same "<hip msg>: <context>" text.
 int tplhip_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// device of a handle created with device < 0: the one tplhip_set_device chose, else the last one
+int tplhip_default_device(int n_devices);
 
 #define HIP_TRY(expr, context)                                                        \
     do {                                                                              \

@@ -14,7 +14,7 @@ import weakref
 import numpy as np
 
 from . import _capi
-from ._capi import TplDpEnvParams, TplDpLonParams, TplLonState, check
+from ._capi import TplDpEnvParams, TplDpLonParams, TplLonState, TplRefLinePoint, check
 
 
 def _fptr(arr):
@@ -166,17 +166,65 @@ class LonTraj:
         return res
 
 
+class RefLinePoint(_StructView):
+    """tplcpp.RefLinePoint (bindings_dp_common.cu:9-19)."""
+    _ctype = TplRefLinePoint
+    _slot_names = tuple(f[0] for f in TplRefLinePoint._fields_)
+
+
 class RefLine:
-    """tplcpp.RefLine as far as Python callers read it (bindings_dp_common.cu:21-36):
-    the centred points, the step size and the offsets that were subtracted."""
+    """tplcpp.RefLine (bindings_dp_common.cu:21-36; utils.hpp:176-220): the centred points, the step size and the
+    offsets that were subtracted.  ``points`` reads as a list of RefLinePoint like the reference's vector; the
+    float64[n, 9] array behind it is ``as_array()``."""
 
     def __init__(self, points=None, step_size=0.0, x_offset=0.0, y_offset=0.0, owner=None):
-        self.points = np.zeros((0, 9)) if points is None else points
+        self._array = np.zeros((0, 9)) if points is None else np.ascontiguousarray(points, dtype=np.float64)
         self.step_size = step_size
         self.x_offset = x_offset
         self.y_offset = y_offset
         # the environment that holds this line on the device (weak: the line must not keep it alive)
         self._owner = weakref.ref(owner) if owner is not None else None
+
+    @staticmethod
+    def fromarray(arr, step_size, no_offset=False):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if arr.ndim != 2 or arr.shape[1] != 9:
+            raise ValueError(f"array has incorrect shape, expected: (-1, 9), got: {arr.shape}")
+        out = np.empty_like(arr)
+        xo, yo = C.c_double(), C.c_double()
+        dp = C.POINTER(C.c_double)
+        check(_capi.load().tplhip_ref_line_center(arr.ctypes.data_as(dp), len(arr), 1 if no_offset else 0,
+                                                  out.ctypes.data_as(dp), C.byref(xo), C.byref(yo)))
+        return RefLine(out, np.float32(step_size), xo.value, yo.value)
+
+    def as_array(self):
+        return self._array
+
+    @property
+    def points(self):
+        pts = []
+        for row in self._array:
+            p = RefLinePoint()
+            C.memmove(C.byref(p._c), row.ctypes.data, C.sizeof(TplRefLinePoint))
+            pts.append(p)
+        return pts
+
+    @points.setter
+    def points(self, value):
+        if isinstance(value, np.ndarray):
+            self._array = np.ascontiguousarray(value, dtype=np.float64).reshape(-1, 9)
+        else:
+            self._array = np.array([[getattr(p, f) for f in RefLinePoint._slot_names] for p in value],
+                                   dtype=np.float64).reshape(-1, 9)
+        self._owner = None                      # no longer the line its environment holds
+
+    def lerp(self, s):
+        """RefLine::lerp (utils.hpp:217-219) -> RefLinePoint at station s."""
+        out = RefLinePoint()
+        dp = C.POINTER(C.c_double)
+        check(_capi.load().tplhip_ref_line_lerp(self._array.ctypes.data_as(dp), len(self._array), float(self.step_size),
+                                                float(s), C.cast(C.byref(out._c), dp)))
+        return out
 
 
 class DynProgEnvironment:
@@ -453,3 +501,9 @@ class DynProgLonPlanner:
 def cuda_get_device_count():
     """tplcpp.cuda_get_device_count (bindings_dp_common.cu:38-45)."""
     return _capi.load().tplhip_device_count()
+
+
+def cuda_set_device(idx):
+    """tplcpp.cuda_set_device (bindings_dp_common.cu:47-49): the device of every planner / environment created
+    afterwards without an explicit ``device=``.  Unlike cudaSetDevice's ignored status, a bad index raises."""
+    check(_capi.load().tplhip_set_device(int(idx)))

@@ -25,7 +25,13 @@ _CART_LERP_ROW = ("distance", "x", "y", "v", "a", "heading", "k")
 class DynProgLatLonPlannerParams(_StructView):
     """tplcpp.DynProgLatLonPlannerParams (bindings_dp_lat_lon.cu:188-278)."""
     _ctype = TplLatLonParams
-    _slot_names = tuple(f[0] for f in TplLatLonParams._fields_)
+    # the order of the reference's __slots__ list (bindings_dp_lat_lon.cu:233-277), which is not the struct's
+    _slot_names = (
+        "s_min", "s_max", "ds_min", "ds_max", "l_min", "l_max", "dds_min", "dds_max", "dl_min", "dl_max",
+        "t_steps", "s_steps", "ds_steps", "l_steps", "dt", "dt_smooth_traj", "dt_start", "dds_start", "w_dds_start",
+        "angle_start", "w_angle_start", "l_trg", "w_progress", "w_dds", "w_ddds", "w_l", "w_dl", "w_ddl",
+        "w_xing_slow", "w_safety_dist", "w_lat_dist", "d_lat_comf", "slope_abs_max", "time_gap", "gap_min",
+        "t_st_min", "t_st_max", "s_st", "w_spatio_temporal", "width_veh", "length_veh")
 
     def _set_defaults(self):
         _capi.load().tplhip_lat_lon_params_default(C.byref(self._c))
@@ -270,7 +276,7 @@ class DynProgLatLonPlanner:
         cached = getattr(self, "_own_env", None)
         if cached is None or cached[0] is not ref_line:
             env = DynProgEnvironment(self._device)
-            pts = np.array(ref_line.points, dtype=np.float64, copy=True)
+            pts = np.array(ref_line.as_array(), dtype=np.float64, copy=True)
             pts[:, 0] += ref_line.x_offset
             pts[:, 1] += ref_line.y_offset
             env.set_ref_line(pts, ref_line.step_size)
