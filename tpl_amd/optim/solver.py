@@ -34,13 +34,15 @@ _BOOL = {"trajectory_changed", "improved", "use_quadratic_terms"}
 _ALIASES = {"step": "dt", "T": "horizon", "elapsed_update_time": "runtime"}
 H_MAX = 300
 
-# the reference's Optim.__slots__ (optim.c:1736-1782)
+# the reference's Optim.__slots__ as Python sees it (optim.c:1736-1782): the format string holds 41 "s" for 42 names,
+# so the list ends at max_lg_iterations -- min_rel_cost_change is an attribute but not a slot
+# (tests/golden/genopt_surface.json, read off the imported reference)
 OPTIM_SLOTS = ["step", "opt_start", "horizon", "int_step", "x", "u", "next_int_step", "next_x", "next_u",
                "prev_x", "prev_u", "prev_k", "fx", "fu", "lx", "lu", "lxx", "luu", "lux", "g", "k", "K",
                "lagrange_multiplier", "barrier_weight", "lg_mult_limit", "u_max", "u_min", "params",
                "traj_costs", "iterations", "lg_iterations", "runtime", "alpha", "mu", "mu_step",
                "trajectory_changed", "improved", "termination_condition", "use_quadratic_terms",
-               "max_iterations", "max_lg_iterations", "min_rel_cost_change"]
+               "max_iterations", "max_lg_iterations"]
 
 SIGNATURES = {
     "tplhip_ilqr_model_name": (C.c_char_p, []),
