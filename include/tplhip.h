@@ -389,6 +389,14 @@ TPLHIP_API int tplhip_ref_line_center(const double* points, int n, int no_offset
 /* RefLine::lerp = interpRefLine, utils.hpp:148-173: the point at station s, out = double[9] */
 TPLHIP_API int tplhip_ref_line_lerp(const double* points, int n, float step_size, float s, double* out);
 
+/* tplcpp.gen_prediction_geometry, utils.cpp:576-693 (binding :1007-1048): pred = double[n_pred][5] (t, x, y, heading,
+ * v), hull = double[n_hull][2], path = double[n_path][2], ts = double[n_ts]; writes the triangle-soup vertices
+ * double[*n_out][3] = (x, y, t) that insert_geometry takes.  out == NULL only counts; TPLHIP_EINVAL when cap is too
+ * small (then *n_out still holds the count). */
+TPLHIP_API int tplhip_gen_prediction_geometry(const double* pred, int n_pred, const double* hull, int n_hull,
+                                              const double* path, int n_path, const double* ts, int n_ts,
+                                              double station_step_size, double expansion_rate, double sweep_length,
+                                              double* out, int cap, int* n_out);
 /* tplcpp.project, utils.cpp:257-408: m positions (double[m][2]) on the line strip points (x, y in the first two
  * of `stride` doubles per point); closed != 0 treats it as a loop */
 TPLHIP_API int tplhip_path_project(const double* points, int stride, int n, int closed, const double* positions, int m,

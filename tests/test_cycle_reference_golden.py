@@ -104,6 +104,23 @@ def test_oracle_stage_runner_feeds_every_stage_from_the_dump():
         F.check(sc, bad, got, who="oracle/")
 
 
+def test_dump_script_drives_a_cpu_module_with_the_tplcpp_surface(tmp_path):
+    """The maintainer's script against tests/oracle_tplcpp.py (tplcpp's surface over the CPU restatements): the calls
+    it makes exist with those signatures, and its file passes loader and checker."""
+    import importlib.util
+    import oracle_tplcpp
+    spec = importlib.util.spec_from_file_location("dump_cycle_goldens", os.path.join(ROOT, "tools", "dump_cycle_goldens.py"))
+    dump = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dump)
+    res = dump.run_scene(oracle_tplcpp.module(), np.load(F.SCENES), "arc")
+    res["scene"] = np.array("arc")
+    f = str(tmp_path / "ref_cycle_arc.npz")
+    np.savez_compressed(f, **res)
+    sc, d = F.load(f)
+    rep = F.check(sc, d, F.run_oracle(sc, d), who="oracle/")
+    assert rep["occ"] == 0 and rep["dist_lon"] == 0 and np.count_nonzero(d["occ"]) > 0
+
+
 @pytest.mark.gpu
 def test_dump_script_drives_tpl_amd_and_its_files_pass_both_checkers(tmp_path):
     """The maintainer's command with --module tpl_amd: proves the script speaks the tplcpp surface this package mirrors,

@@ -1,0 +1,125 @@
+"""tplcpp.gen_prediction_geometry (utils.cpp:576-693), the producer of the triangle soups the occupancy pipeline
+rasterises: the host routine of libtplhip.so against the numpy restatement (oracle/planning_oracle.py) and against
+hand-derived cases.  Host arithmetic only -- no GPU needed."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import tpl_amd
+from tpl_amd import scenarios as sc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_spec = importlib.util.spec_from_file_location("planning_oracle", os.path.join(ROOT, "oracle", "planning_oracle.py"))
+po = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(po)
+
+
+def _straight(n=120, step=1.0):
+    return np.stack([np.arange(n) * step, np.zeros(n)], axis=1)
+
+
+def _box(x0, x1, y0, y1):
+    return np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]], dtype=np.float64)
+
+
+def test_straight_road_closed_form():
+    """A 4 m box at s = 8..12 moving at 5 m/s, slices of 1 s (> sweep 0.5 s): slice k covers s = 8+5k .. 17+5k in
+    chunks of 5 m, as two triangles per chunk joined to the previous chunk's far edge."""
+    pred = np.array([[0.0, 10.0, 0.5, 0.0, 5.0], [1.0, 15.0, 0.5, 0.0, 5.0], [2.0, 20.0, 0.5, 0.0, 5.0]])
+    g = tpl_amd.gen_prediction_geometry(pred, _box(8, 12, -0.5, 1.5), _straight(), np.array([0.0, 1.0, 2.0]), 5.0, 0.0, 0.5)
+    assert g.shape == (24, 3)
+    for k, t in enumerate((0.0, 1.0)):
+        s0 = 8.0 + 5.0 * k
+        first = g[12 * k:12 * k + 6]
+        want = np.array([[s0, -0.5, t], [s0 + 5, -0.5, t], [s0, 1.5, t], [s0, 1.5, t], [s0 + 5, -0.5, t], [s0 + 5, 1.5, t]])
+        assert np.allclose(first, want, atol=1e-12)
+        second = g[12 * k + 6:12 * k + 12]
+        want = np.array([[s0 + 5, -0.5, t], [s0 + 9, -0.5, t], [s0 + 5, 1.5, t], [s0 + 5, 1.5, t], [s0 + 9, -0.5, t],
+                         [s0 + 9, 1.5, t]])
+        assert np.allclose(second, want, atol=1e-12)
+
+
+def test_sweep_length_expansion_and_reverse():
+    path = _straight()
+    hull = _box(48, 52, -1.0, 1.0)
+    fwd = np.array([[0.0, 50.0, 0.0, 0.0, 2.0], [4.0, 58.0, 0.0, 0.0, 2.0]])
+    # sweep 3 s > dt 1 s: every slice reaches 3 s * v ahead; the box grows 10 % per slice
+    g = tpl_amd.gen_prediction_geometry(fwd, hull, path, np.array([0.0, 1.0, 2.0, 3.0]), 5.0, 0.1, 3.0)
+    ref = po.gen_prediction_geometry(fwd, hull, path, np.array([0.0, 1.0, 2.0, 3.0]), 5.0, 0.1, 3.0)
+    assert np.array_equal(g, ref)
+    for k, t in enumerate((0.0, 1.0, 2.0)):
+        sl = g[g[:, 2] == t]
+        length = 4.0 * 1.1 ** k
+        mid = 50.0 + 2.0 * k
+        assert sl[:, 0].min() == pytest.approx(mid - length / 2) and sl[:, 0].max() == pytest.approx(mid + 6.0 + length / 2)
+    # a reversing object sweeps backwards from its front edge
+    back = np.array([[0.0, 50.0, 0.0, 0.0, -2.0], [4.0, 42.0, 0.0, 0.0, -2.0]])
+    g = tpl_amd.gen_prediction_geometry(back, hull, path, np.array([0.0, 1.0]), 5.0, 0.0, 0.0)
+    assert np.array_equal(g, po.gen_prediction_geometry(back, hull, path, np.array([0.0, 1.0]), 5.0, 0.0, 0.0))
+    assert g[0, 0] == pytest.approx(52.0) and g[:, 0].min() == pytest.approx(46.0)
+    # a standing object: only its own box, one chunk
+    still = np.array([[0.0, 50.0, 0.0, 0.0, 0.0], [4.0, 50.0, 0.0, 0.0, 0.0]])
+    g = tpl_amd.gen_prediction_geometry(still, hull, path, np.array([0.0, 1.0, 2.0]), 5.0, 0.0, 0.5)
+    assert g.shape == (12, 3) and g[:, 0].min() == pytest.approx(48.0) and g[:, 0].max() == pytest.approx(52.0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_curved_paths_match_the_restatement(seed):
+    rng = np.random.default_rng(seed)
+    rl = sc.ref_line_arc(n=300, step=0.5, radius=float(rng.uniform(40, 200)), heading0=float(rng.uniform(-3, 3)))
+    path = np.ascontiguousarray(rl[:, :2])
+    s0, d0 = float(rng.uniform(10, 100)), float(rng.uniform(-3, 3))
+    c = sc.frenet_to_cart(rl, 0.5, s0, d0)
+    h = float(rng.uniform(-np.pi, np.pi))
+    ca, sa = np.cos(h), np.sin(h)
+    hull = np.array([[c[0] + ca * a - sa * b, c[1] + sa * a + ca * b] for a, b in ((-2.2, -0.9), (2.2, -0.9), (2.2, 0.9), (-2.2, 0.9))])
+    v = float(rng.uniform(-3, 12))
+    n = 8
+    pred = np.zeros((n, 5))
+    pred[:, 0] = np.arange(n) * 0.7
+    for i in range(n):
+        pred[i, 1:3] = sc.frenet_to_cart(rl, 0.5, s0 + v * pred[i, 0], d0)
+    pred[:, 3] = rng.uniform(-np.pi, np.pi, n)
+    pred[:, 4] = v + rng.uniform(-0.5, 0.5, n)
+    ts = np.array([0.0, *(0.3 + pred[:-1, 0])]) + 0.05
+    args = (pred, hull, path, ts, float(rng.choice([2.0, 5.0])), float(rng.choice([0.0, 0.05])), float(rng.choice([0.0, 0.5, 2.0])))
+    got = tpl_amd.gen_prediction_geometry(*args)
+    ref = po.gen_prediction_geometry(*args)
+    assert got.shape == ref.shape and len(got) % 6 == 0 and len(got) > 0
+    assert np.allclose(got, ref, rtol=0, atol=1e-12)
+    assert np.array_equal(got[:, 2], ref[:, 2])
+
+
+def test_interpolation_and_projection_pieces():
+    pred = np.array([[0.0, 0.0, 0.0, 3.1, 1.0], [1.0, 2.0, 4.0, -3.1, 3.0], [2.0, 4.0, 4.0, -3.0, 3.0]])
+    p = po.interp_prediction(pred, 0.5)
+    assert p[1] == 1.0 and p[2] == 2.0 and p[4] == 2.0 and abs(p[3] - (3.1 + (2 * np.pi - 6.2) * 0.5)) < 1e-12
+    assert np.array_equal(po.interp_prediction(pred, -1.0)[1:3], [0.0, 0.0])          # alpha clipped below
+    assert np.array_equal(po.interp_prediction(pred, 9.0)[1:3], [4.0, 4.0])           # and above
+    path = _straight(10)
+    for pos in ([3.3, 2.0], [3.3, -2.0], [-1.0, 0.5], [20.0, 0.5]):
+        a = po.project(path, pos)
+        b = tpl_amd.project(path, pos)
+        assert a["in_bounds"] == b.in_bounds and a["arc_len"] == b.arc_len and a["distance"] == b.distance
+    assert po.project(path, [3.3, 2.0])["distance"] == 2.0 and po.project(path, [3.3, -2.0])["distance"] == -2.0
+    assert not po.project(path, [-1.0, 0.5])["in_bounds"] and not po.project(path, [20.0, 0.5])["in_bounds"]
+
+
+def test_feeds_the_occupancy_pipeline_shapes_and_errors():
+    path = _straight()
+    pred = np.array([[0.0, 10.0, 0.0, 0.0, 5.0], [1.0, 15.0, 0.0, 0.0, 5.0]])
+    hull = _box(8, 12, -1, 1)
+    g = tpl_amd.gen_prediction_geometry(pred, hull, path, np.array([0.0, 1.0]))
+    assert g.dtype == np.float64 and g.shape[1] == 3 and g.flags.c_contiguous
+    assert tpl_amd.gen_prediction_geometry(pred, hull, path, np.array([0.0])).shape == (0, 3)      # one time: no slice
+    # a hull entirely off the ends of the path: no vertex is in bounds, the box is empty (inf - inf), nothing is drawn
+    far = tpl_amd.gen_prediction_geometry(pred, _box(-50, -40, -1, 1), path, np.array([0.0, 1.0]))
+    assert far.shape[0] == po.gen_prediction_geometry(pred, _box(-50, -40, -1, 1), path, np.array([0.0, 1.0])).shape[0]
+    with pytest.raises(ValueError, match="expected: \\(-1, 5\\)"):
+        tpl_amd.gen_prediction_geometry(pred[:, :4], hull, path, np.array([0.0, 1.0]))
+    with pytest.raises(ValueError, match="expected: \\(-1, 2\\)"):
+        tpl_amd.gen_prediction_geometry(pred, hull, np.zeros((5, 3)), np.array([0.0, 1.0]))
+    with pytest.raises(ValueError, match="at least two"):
+        tpl_amd.gen_prediction_geometry(pred[:1], hull, path, np.array([0.0, 1.0]))

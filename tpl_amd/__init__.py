@@ -40,7 +40,10 @@ from .poly_lat import (  # noqa: E402
     PolyQuintic,
 )
 
+from .planning.geometry import Projection, gen_prediction_geometry, project, resample  # noqa: E402
+
 __all__ = [
+    "Projection", "gen_prediction_geometry", "project", "resample",
     "DynProgLatLonPlanner", "DynProgLatLonPlannerParams", "LatLonCartState", "LatLonCartTraj", "LatLonState",
     "LatLonTraj",
     "PolyLatPlanner", "PolyLatPlannerParams", "PolyLatTraj", "PolyLatTrajPoint", "PolyQuintic",

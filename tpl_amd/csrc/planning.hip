@@ -88,6 +88,36 @@ void project_one(const double* pts, long stride, long n, bool closed, double px,
     *out = proj;
 }
 
+// InterpVars(vals, &PredictionPoint::t, v), utils.hpp:58-86, on rows of 5 doubles (t first)
+struct PredInterp { long i_prev, i_next; double a; };
+PredInterp pred_interp(const double* pred, long n, double v)
+{
+    PredInterp r = {0, 0, 0.0};
+    if (v < pred[0]) { r.i_prev = 0; r.i_next = 1; }
+    else if (v >= pred[(n - 1) * 5]) { r.i_prev = n - 2; r.i_next = n - 1; }
+    else {
+        for (long i = 1; i < n; ++i) {
+            if (pred[(i - 1) * 5] <= v && v < pred[i * 5]) { r.i_prev = i - 1; r.i_next = i; break; }
+        }
+    }
+    const double t_prev = pred[r.i_prev * 5], t_next = pred[r.i_next * 5];
+    r.a = std::max(0.0, std::min(1.0, (v - t_prev) / (t_next - t_prev)));
+    return r;
+}
+
+// interpPrediction, utils.cpp:560-574: out = (t, x, y, heading, v)
+void interp_prediction(const double* pred, long n, double t, double* out)
+{
+    const PredInterp i = pred_interp(pred, n, t);
+    const double* p = pred + i.i_prev * 5;
+    const double* q = pred + i.i_next * 5;
+    out[0] = t;
+    out[1] = p[1] * (1.0 - i.a) + q[1] * i.a;
+    out[2] = p[2] * (1.0 - i.a) + q[2] * i.a;
+    out[3] = p[3] + tplhip::short_angle_dist(p[3], q[3]) * i.a;
+    out[4] = p[4] * (1.0 - i.a) + q[4] * i.a;
+}
+
 } // namespace
 
 extern "C" {
@@ -267,6 +297,101 @@ int tplhip_ref_line_lerp(const double* points, int n, float step_size, float s, 
     for (int c = 0; c < 8; ++c) out[c] = p0[c] * (double)ia + p1[c] * (double)a;
     out[2] = p0[2] + tplhip::short_angle_dist(p0[2], p1[2]) * (double)a;
     out[8] = (ia < 0.5f) ? p0[8] : p1[8];
+    return TPLHIP_OK;
+}
+
+// genPredictionGeometry, utils.cpp:576-693: the Frenet box of an object's hull on its map path, swept along the path
+// for every prediction step, as triangle-soup vertices (x, y, t).  Two passes: out == nullptr (or cap too small)
+// only counts; *n_out is always the number of vertices the call produces.
+int tplhip_gen_prediction_geometry(const double* pred, int n_pred, const double* hull, int n_hull, const double* path,
+                                   int n_path, const double* ts, int n_ts, double station_step_size,
+                                   double expansion_rate, double sweep_length, double* out, int cap, int* n_out)
+{
+    if (!pred || !hull || !path || !ts || !n_out) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (n_pred < 2) return tplhip_fail(TPLHIP_EINVAL, "a prediction needs at least two states (got %d)", n_pred);
+    if (n_path < 2) return tplhip_fail(TPLHIP_EINVAL, "a line strip needs at least two points (got %d)", n_path);
+    if (n_ts < 1) return tplhip_fail(TPLHIP_EINVAL, "ts is empty");
+    const double pdx = path[2] - path[0], pdy = path[3] - path[1];
+    const double path_step = std::sqrt(pdx * pdx + pdy * pdy);
+    auto get_path = [&](double s, double* xy) {
+        double a = s / path_step;
+        const int i_prev = std::max(0, std::min(n_path - 2, (int)std::floor(a)));
+        const int i_next = std::max(1, std::min(n_path - 1, (int)std::ceil(a)));
+        a = std::max(0.0, std::min(1.0, a - i_prev));
+        xy[0] = path[2 * i_prev] * (1.0 - a) + path[2 * i_next] * a;
+        xy[1] = path[2 * i_prev + 1] * (1.0 - a) + path[2 * i_next + 1] * a;
+    };
+    // the hull as a box in Frenet coordinates of the path
+    double s_min = INFINITY, s_max = -INFINITY, d_min = INFINITY, d_max = -INFINITY;
+    for (int i = 0; i < n_hull; ++i) {
+        TplProjection pr;
+        project_one(path, 2, n_path, false, hull[2 * i], hull[2 * i + 1], &pr);
+        if (pr.in_bounds) {
+            s_min = std::min(pr.arc_len, s_min); s_max = std::max(pr.arc_len, s_max);
+            d_min = std::min(pr.distance, d_min); d_max = std::max(pr.distance, d_max);
+        }
+    }
+    double pp0[5];
+    interp_prediction(pred, n_pred, ts[0], pp0);
+    TplProjection proj0;
+    project_one(path, 2, n_path, false, pp0[1], pp0[2], &proj0);
+    double l = s_max - s_min;
+    double s_mid = proj0.arc_len;
+    long n = 0;
+    double prev_min[3] = {0, 0, 0}, prev_max[3] = {0, 0, 0};       // the last two vertices pushed
+    auto push = [&](double x, double y, double t) {
+        if (out && n < cap) { out[3 * n] = x; out[3 * n + 1] = y; out[3 * n + 2] = t; }
+        prev_min[0] = prev_max[0]; prev_min[1] = prev_max[1]; prev_min[2] = prev_max[2];
+        prev_max[0] = x; prev_max[1] = y; prev_max[2] = t;
+        ++n;
+    };
+    for (int t_idx = 0; t_idx < n_ts - 1; ++t_idx) {
+        const double t = ts[t_idx], dt = ts[t_idx + 1] - t;
+        double pp[5];
+        interp_prediction(pred, n_pred, t, pp);
+        const double sg = pp[4] < 0.0 ? -1.0 : 1.0;
+        const double s_start = s_mid - sg * l * 0.5;
+        const double s_stop = s_mid + std::max(sweep_length, dt) * pp[4] + sg * l * 0.5;
+        // a hull with no vertex in bounds leaves the box at inf - inf: the reference's (int) of a non-finite double is
+        // INT_MIN on x86-64 and nothing is drawn; made explicit here
+        const double n_steps = std::abs(s_stop - s_start) / station_step_size + 1;
+        const int steps = (std::isfinite(n_steps) && n_steps < 2147483648.0) ? (int)n_steps : 0;
+        for (int i = 0; i < steps; ++i) {
+            const double s = s_start + i * station_step_size * sg;
+            const double ds = sg * std::min(std::abs(s_stop - s), station_step_size);
+            if (std::abs(ds) < 1e-3) break;
+            double p0[2], p1[2];
+            get_path(s, p0);
+            get_path(s + ds, p1);
+            const double vx = (p1[0] - p0[0]) * sg, vy = (p1[1] - p0[1]) * sg;
+            const double vl = std::sqrt(vx * vx + vy * vy);
+            if (vl < 1e-3) break;
+            const double ox = -vy / vl, oy = vx / vl;
+            if (i == 0) {
+                push(p0[0] + ox * d_min, p0[1] + oy * d_min, t);
+                push(p1[0] + ox * d_min, p1[1] + oy * d_min, t);
+                push(p0[0] + ox * d_max, p0[1] + oy * d_max, t);
+                push(p0[0] + ox * d_max, p0[1] + oy * d_max, t);
+                push(p1[0] + ox * d_min, p1[1] + oy * d_min, t);
+                push(p1[0] + ox * d_max, p1[1] + oy * d_max, t);
+            } else {
+                // joined to the previous segment: its last two vertices (the t they carry included)
+                const double a[3] = {prev_min[0], prev_min[1], prev_min[2]};
+                const double b[3] = {prev_max[0], prev_max[1], prev_max[2]};
+                const double cx = p1[0] + ox * d_min, cy = p1[1] + oy * d_min;
+                push(a[0], a[1], a[2]);
+                push(cx, cy, t);
+                push(b[0], b[1], b[2]);
+                push(b[0], b[1], b[2]);
+                push(cx, cy, t);
+                push(p1[0] + ox * d_max, p1[1] + oy * d_max, t);
+            }
+        }
+        l *= 1.0 + expansion_rate;
+        s_mid += dt * pp[4];
+    }
+    *n_out = (int)n;
+    if (out && n > cap) return tplhip_fail(TPLHIP_EINVAL, "vertex buffer holds %d vertices, the geometry has %ld", cap, n);
     return TPLHIP_OK;
 }
 

@@ -53,6 +53,28 @@ def resample(points, sampling_dist, steps, start_index=0, closed=False):
     return out[:n.value]
 
 
+def gen_prediction_geometry(pred, hull, path, ts=0, station_step_size=5.0, expansion_rate=0.0, sweep_length=0.0):
+    """tplcpp.gen_prediction_geometry (utils.cpp:576-693, binding :1007-1048): the triangle soup float64[n, 3] =
+    (x, y, t) that DpEnv.update hands to DynProgEnvironment.insert_geometry (dp_env.py:157-168).  ``pred`` is
+    float64[k, 5] = (t, x, y, heading, v), ``hull`` float64[m, 2], ``path`` float64[p, 2], ``ts`` the slice times."""
+    arrs = []
+    for a, shape, name in ((pred, (-1, 5), "pred"), (hull, (-1, 2), "hull"), (path, (-1, 2), "path"), (ts, (-1,), "ts")):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.ndim != len(shape) or (len(shape) == 2 and a.shape[1] != shape[1]):
+            raise ValueError(f"array has incorrect shape, expected: {shape}, got: {a.shape}")
+        arrs.append(a)
+    pred, hull, path, ts = arrs
+    lib = _capi.load()
+    n = C.c_int()
+    args = (pred.ctypes.data_as(_dp), len(pred), hull.ctypes.data_as(_dp), len(hull), path.ctypes.data_as(_dp), len(path),
+            ts.ctypes.data_as(_dp), len(ts), float(station_step_size), float(expansion_rate), float(sweep_length))
+    _capi.check(lib.tplhip_gen_prediction_geometry(*args, None, 0, C.byref(n)))
+    out = np.empty((n.value, 3))
+    if n.value:
+        _capi.check(lib.tplhip_gen_prediction_geometry(*args, out.ctypes.data_as(_dp), n.value, C.byref(n)))
+    return out
+
+
 def normalize_angle(a):
     """tpl.util.normalize_angle (util.py:92-100): into (-pi, pi]."""
     a = a % (np.pi * 2)
