@@ -397,6 +397,10 @@ TPLHIP_API int tplhip_gen_prediction_geometry(const double* pred, int n_pred, co
                                               const double* path, int n_path, const double* ts, int n_ts,
                                               double station_step_size, double expansion_rate, double sweep_length,
                                               double* out, int cap, int* n_out);
+/* tplcpp.lerp, utils.cpp:931-990: ys = double[m][d] sampled at the sorted xs[m], evaluated at vals[n] into
+ * out = double[n][d]; angle: short-way-round interpolation; clip_alpha: hold the end values outside [xs[0], xs[m-1]] */
+TPLHIP_API int tplhip_lerp(const double* vals, int n, const double* xs, int m, const double* ys, int d, int angle,
+                           int clip_alpha, double* out);
 /* tplcpp.project, utils.cpp:257-408: m positions (double[m][2]) on the line strip points (x, y in the first two
  * of `stride` doubles per point); closed != 0 treats it as a loop */
 TPLHIP_API int tplhip_path_project(const double* points, int stride, int n, int closed, const double* positions, int m,

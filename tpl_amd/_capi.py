@@ -152,6 +152,7 @@ SIGNATURES = {
     "tplhip_ref_line_center": (C.c_int, [_dp, C.c_int, C.c_int, _dp, _dp, _dp]),
     "tplhip_gen_prediction_geometry": (C.c_int, [_dp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_double,
                                                  C.c_double, C.c_double, _dp, C.c_int, _P(C.c_int)]),
+    "tplhip_lerp": (C.c_int, [_dp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp]),
     "tplhip_ref_line_lerp": (C.c_int, [_dp, C.c_int, C.c_float, C.c_float, _dp]),
     "tplhip_version": (C.c_char_p, []),
     "tplhip_dp_lon_params_default": (None, [_P(TplDpLonParams)]),

@@ -395,4 +395,38 @@ int tplhip_gen_prediction_geometry(const double* pred, int n_pred, const double*
     return TPLHIP_OK;
 }
 
+// tplcpp.lerp (binding utils.cpp:931-990; InterpVars(array, v, clipAlpha) utils.hpp:88-133): values ys[m][d] given at
+// the sorted abscissae xs[m], evaluated at vals[n]; angle != 0 interpolates the short way round
+int tplhip_lerp(const double* vals, int n, const double* xs, int m, const double* ys, int d, int angle, int clip_alpha,
+                double* out)
+{
+    if (!vals || !xs || !ys || !out || d < 1) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (m < 2) return tplhip_fail(TPLHIP_EINVAL, "interpolation needs at least two samples (got %d)", m);
+    for (int k = 0; k < n; ++k) {
+        const double v = vals[k];
+        long i_prev = 0, i_next = 0;
+        if (v < xs[0]) { i_prev = 0; i_next = 1; }
+        else if (v >= xs[m - 1]) { i_prev = m - 2; i_next = m - 1; }
+        else if (m < 100) {
+            for (long i = 1; i < m; ++i)
+                if (xs[i - 1] <= v && v < xs[i]) { i_prev = i - 1; i_next = i; break; }
+        } else {
+            i_prev = 0; i_next = m - 1;
+            while (i_next - i_prev >= 2) {
+                const long mid = (i_next + i_prev) / 2;
+                if (xs[mid] <= v) i_prev = mid;
+                else if (xs[mid] > v) i_next = mid;
+                else break;
+            }
+        }
+        double a = (v - xs[i_prev]) / (xs[i_next] - xs[i_prev]);
+        if (clip_alpha) a = std::max(0.0, std::min(1.0, a));
+        for (int j = 0; j < d; ++j) {
+            const double y0 = ys[i_prev * d + j], y1 = ys[i_next * d + j];
+            out[(long)k * d + j] = angle ? y0 + a * tplhip::short_angle_dist(y0, y1) : (1.0 - a) * y0 + a * y1;
+        }
+    }
+    return TPLHIP_OK;
+}
+
 } // extern "C"

@@ -75,6 +75,41 @@ def gen_prediction_geometry(pred, hull, path, ts=0, station_step_size=5.0, expan
     return out
 
 
+def lerp_cpp(vals, xs, ys, angle=False, clip_alpha=True):
+    """tplcpp.lerp (utils.cpp:931-990): ``ys`` (1-D or [m, d]) sampled at the sorted ``xs``, evaluated at the 1-D
+    ``vals`` -> float64[n] or float64[n, d]."""
+    v = np.ascontiguousarray(vals, dtype=np.float64)
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    ys = np.ascontiguousarray(ys, dtype=np.float64)
+    if v.ndim != 1 or xs.ndim != 1:
+        raise ValueError(f"array has incorrect shape, expected: (-1,), got: {v.shape if v.ndim != 1 else xs.shape}")
+    if len(v) == 0:
+        return np.zeros((0,))
+    d = 1 if ys.ndim == 1 else ys.shape[1]
+    out = np.empty((len(v), d) if ys.ndim > 1 else (len(v),))
+    _capi.check(_capi.load().tplhip_lerp(v.ctypes.data_as(_dp), len(v), xs.ctypes.data_as(_dp), len(xs),
+                                         ys.ctypes.data_as(_dp), d, 1 if angle else 0, 1 if clip_alpha else 0,
+                                         out.ctypes.data_as(_dp)))
+    return out
+
+
+def lerp(vals, xs, ys, angle=False, clip_alpha=True):
+    """tpl.util.lerp (util.py:103-108): a number -> one row, an array -> the squeezed result."""
+    if np.ndim(vals) == 0:
+        return lerp_cpp([vals], xs, ys, angle, clip_alpha)[0]
+    return lerp_cpp(vals, xs, ys, angle, clip_alpha).squeeze()
+
+
+def curv_to_vel_profile(k, lim_v, a_lat_max, k_eps=1e-6):
+    """tpl.environment.map_module.curv_to_vel_profile (map_module.py:534-545): the speed limit capped by the lateral
+    acceleration bound, sqrt(a_lat_max / |k|), wherever the curvature is not negligible."""
+    abs_k = np.abs(np.asarray(k, dtype=np.float64))
+    lim_v = np.asarray(lim_v, dtype=np.float64)
+    with np.errstate(divide="ignore"):
+        capped = np.minimum(lim_v, np.sqrt(a_lat_max / abs_k))
+    return np.where(abs_k > k_eps, capped, lim_v)
+
+
 def normalize_angle(a):
     """tpl.util.normalize_angle (util.py:92-100): into (-pi, pi]."""
     a = a % (np.pi * 2)
