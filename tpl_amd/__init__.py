@@ -41,9 +41,10 @@ from .poly_lat import (  # noqa: E402
 )
 
 from .planning.geometry import Projection, gen_prediction_geometry, project, resample  # noqa: E402
+from .planning.geometry import lerp_cpp as lerp  # noqa: E402  (tplcpp.lerp, utils.cpp:931-990)
 
 __all__ = [
-    "Projection", "gen_prediction_geometry", "project", "resample",
+    "Projection", "gen_prediction_geometry", "lerp", "project", "resample",
     "DynProgLatLonPlanner", "DynProgLatLonPlannerParams", "LatLonCartState", "LatLonCartTraj", "LatLonState",
     "LatLonTraj",
     "PolyLatPlanner", "PolyLatPlannerParams", "PolyLatTraj", "PolyLatTrajPoint", "PolyQuintic",
