@@ -66,7 +66,7 @@ class Drive:
     def _nolock(self):
         yield
 
-    def cycle(self, k, follow=None):
+    def cycle(self, k, follow=None, man_time=False):
         """Shared environment state of cycle k.  `follow`: trajectory of the previous cycle to place the vehicle on
         (closed loop); None keeps the nominal constant-speed drive."""
         t = self.t + k * DT
@@ -98,7 +98,8 @@ class Drive:
                            predictions=[NS(uuid_assoc_map="map-behind", states=prediction(path, s_obj, d, v)),
                                         NS(uuid_assoc_map="map-unknown", states=prediction(path, s_obj, d, v))]))
         sh = NS(t=t, reset_counter=1, vehicle_state=veh, local_map=local_map, local_map_behind=behind, selected_map=None,
-                tracks=[], predicted=objs, man_time_cons=[])
+                tracks=[], predicted=objs,
+                man_time_cons=[(frenet(path, s_loc + 60.0, 0.0)[0], t + 6.0, t + 30.0)] if man_time else [])
         sh.lock = self._nolock
         return sh
 

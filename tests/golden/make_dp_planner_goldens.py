@@ -114,6 +114,20 @@ def run_drive(make_planner, drive, cycles, closed_loop):
     return rows, np.array(meta), pl
 
 
+def run_drive_ll(make_planner, drive, cycles):
+    import dp_planner_cases as cases
+    pl = make_planner()
+    rows, meta = [], []
+    for k in range(cycles):
+        traj = pl.update(drive.cycle(k, man_time=(k >= 4)))
+        r = cases.trajectory_row(traj)
+        rows.append(np.zeros((0, 8)) if r is None else r)
+        s0 = pl.dp_planner.traj_smooth[0]
+        meta.append([float(traj.emergency), pl.last_replan_time, s0.s, s0.ds, s0.l, pl.dp_env.ref_line_shift,
+                     pl.dt_start, float(pl.emergency_counter), len(pl.traj_dp.states)])
+    return rows, np.array(meta), pl
+
+
 def main():
     install_shims()
     sys.path.insert(0, "/root/reference/library")
@@ -129,6 +143,14 @@ def main():
         out[f"{name}.ref_line"] = pl.dp_env.ref_line
         out[f"{name}.path"] = pl.path
         out[f"{name}.occ"] = pl.dp_env.cpp_env.get_occ_map()
+        print(name, [len(r) for r in rows], "replans at", sorted(set(np.round(meta[:, 1], 2))))
+    from tpl.planning.dyn_prog.dp_lat_lon_planner import DpLatLonPlanner
+    for name, kw, cycles in (("ll_nominal", dict(v_ego=9.0), 12), ("ll_manual", dict(v_ego=6.0, automated=False), 14)):
+        rows, meta, pl = run_drive_ll(lambda: DpLatLonPlanner(_Store(), _lock), cases.Drive(**kw), cycles)
+        for k, r in enumerate(rows):
+            out[f"{name}.traj_{k}"] = r
+        out[f"{name}.meta"] = meta
+        out[f"{name}.traj_dp"] = pl.dp_planner.traj_dp.as_numpy()
         print(name, [len(r) for r in rows], "replans at", sorted(set(np.round(meta[:, 1], 2))))
     path = os.path.join(HERE, "dp_planner.npz")
     np.savez_compressed(path, **out)

@@ -153,13 +153,18 @@ class DynProgLatLonPlanner:
         self.traj_smooth = tpl_amd.LatLonTraj()
         self.traj_dp_cart = tpl_amd.LatLonCartTraj()
         self.traj_smooth_cart = tpl_amd.LatLonCartTraj()
-        self.lat_dists = [tpl_amd.LatDistances()]
-        self.traj_dp.states = [tpl_amd.LatLonState()]
-        self.traj_smooth.states = [tpl_amd.LatLonState()]
+        self.lat_dists = []
         self._tables = None
+        self.reinit_buffers(self.params, True)
 
     def reinit_buffers(self, params, force=False):
+        full = force or any(getattr(params, f) != getattr(self.params, f) for f in ("t_steps", "s_steps", "ds_steps", "l_steps"))
         self.params = params.__deepcopy__({})
+        if full:                                            # lat_lon_planner.cu:539-541
+            T = self.params.t_steps
+            self.traj_dp.states = (self.traj_dp.states + [tpl_amd.LatLonState() for _ in range(T)])[:T]
+            self.traj_smooth.states = self.traj_smooth.states[:1]
+            self.traj_smooth_cart.states = self.traj_smooth_cart.states[:1]
 
     def update_traj_dp(self, env):
         o = env._o
@@ -167,9 +172,11 @@ class DynProgLatLonPlanner:
         self.traj_dp._take(otraj)
 
     def update_traj_smooth(self, env):
-        out = (TplLatLonState * 512)()
         dp = self.traj_dp._as_array()
-        n = oll.lib().llo_update_traj_smooth(C.byref(self.params._c), dp, len(dp), C.byref(self.traj_smooth[0]._c), out, 512)
+        cap = max(2, int(dp[len(dp) - 1].t / self.params.dt_smooth_traj) + 2)
+        out = (TplLatLonState * cap)()
+        n = oll.lib().llo_update_traj_smooth(C.byref(self.params._c), dp, len(dp), C.byref(self.traj_smooth[0]._c), out, cap)
+        self.lat_dists = [tpl_amd.LatDistances() for _ in range(len(self.traj_smooth.states))]
         self.traj_smooth._take(out, n)
 
     def frenet_to_cartesian(self, traj, ref_line):

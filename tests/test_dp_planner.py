@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import dp_planner_cases as cases
-from tpl_amd.planning.dyn_prog import PolyLatDpLonPlanner
+from tpl_amd.planning.dyn_prog import DpLatLonPlanner, PolyLatDpLonPlanner
 from tpl_amd.store import Bundle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -74,6 +74,46 @@ def test_hip_engines_under_the_plugin(name):
     pl = _run(name, None, rtol=1e-5, atol=1e-5)
     assert isinstance(pl.dp_lon, tpl_amd.DynProgLonPlanner) and isinstance(pl.dp_env.cpp_env, tpl_amd.DynProgEnvironment)
     assert np.array_equal(pl.dp_env.cpp_env.get_occ_map(), GOLD[f"{name}.occ"])
+
+
+LL_DRIVES = {"ll_nominal": (dict(v_ego=9.0), 12), "ll_manual": (dict(v_ego=6.0, automated=False), 14)}
+
+
+def _run_ll(name, engines, rtol, atol):
+    kw, cycles = LL_DRIVES[name]
+    pl = DpLatLonPlanner(Bundle(), _lock, engines=engines)
+    drive = cases.Drive(**kw)
+    want_meta = GOLD[f"{name}.meta"]
+    for k in range(cycles):
+        traj = pl.update(drive.cycle(k, man_time=(k >= 4)))
+        r = cases.trajectory_row(traj)
+        want = GOLD[f"{name}.traj_{k}"]
+        assert (r is None) == (len(want) == 0), f"cycle {k}: emergency flag differs"
+        if r is not None:
+            assert r.shape == want.shape, f"{name} cycle {k}: {r.shape} vs {want.shape}"
+            assert np.allclose(r, want, rtol=rtol, atol=atol), f"{name} cycle {k}: differs by {np.max(np.abs(r - want)):.3e}"
+        s0 = pl.dp_planner.traj_smooth[0]
+        meta = np.array([float(traj.emergency), pl.last_replan_time, s0.s, s0.ds, s0.l, pl.dp_env.ref_line_shift, pl.dt_start,
+                         float(pl.emergency_counter), len(pl.traj_dp.states)])
+        assert np.allclose(meta, want_meta[k], rtol=rtol, atol=atol), f"{name} cycle {k}: planner state {meta} vs {want_meta[k]}"
+    assert np.allclose(pl.dp_planner.traj_dp.as_numpy(), GOLD[f"{name}.traj_dp"], rtol=rtol, atol=atol)
+    return pl
+
+
+@pytest.mark.parametrize("name", sorted(LL_DRIVES))
+def test_lat_lon_plugin_logic_matches_the_reference_class(name):
+    import oracle_tplcpp
+    pl = _run_ll(name, oracle_tplcpp.module(), rtol=0.0, atol=1e-9)
+    dbg = pl.shared.debug.planner
+    assert dbg.traj_dp.shape[1] == 9 and dbg.traj_smooth_cart.shape[1] == 8 and dbg.reinit_msg == ""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(LL_DRIVES))
+def test_hip_lat_lon_engine_under_the_plugin(name):
+    import tpl_amd
+    pl = _run_ll(name, None, rtol=1e-6, atol=1e-6)
+    assert isinstance(pl.dp_planner, tpl_amd.DynProgLatLonPlanner)
 
 
 def test_skips_when_time_stands_still_and_handles_missing_map():
