@@ -34,18 +34,25 @@ class _Shared:
 def main():
     import make_pvd_goldens as shims
     shims.install_shims()
+    # objtoolbox.merge writes the attributes the DESTINATION has (the time-indexed problem has no p_phi_ref_dot_diff)
+    sys.modules["objtoolbox"].merge = lambda dst, src: [setattr(dst, k, getattr(src, k)) for k in
+                                                        (getattr(dst, "__slots__", None) or vars(dst)) if hasattr(src, k)] and None
     sys.path.insert(0, "/root/reference/library")
     from make_ilqr_goldens import reference_factory
     import mpc_cases as cases
     from tpl.optim import optimizers as ref_opts
     ref_opts.trajectory_tracking_mpc = reference_factory("trajectory_tracking_mpc")
     from tpl.control.model_predictive_controller import ModelPredictiveController
+    ref_opts.trajectory_tracking_mpc_time = reference_factory("trajectory_tracking_mpc_time")
+    from tpl.control.model_predictive_controller_time import ModelPredictiveControllerTime
     out = {}
-    for name in cases.CASES:
+    for name in list(cases.CASES) + list(cases.TIME_CASES):
+        Controller = ModelPredictiveController if name in cases.CASES else ModelPredictiveControllerTime
+
         def factory(shared, lock):
             # cases.run sets its overrides on shared.params: hand it the controller's own parameter object
             st = _Shared()
-            con = ModelPredictiveController(st, lock)
+            con = Controller(st, lock)
             shared.params = st.params
             return con
         controls, trace, extra, con = cases.run(factory, name)
@@ -53,8 +60,8 @@ def main():
         for i, e in enumerate(extra):
             out[f"{name}.con_traj_{i}"] = e
         out[f"{name}.dead_time_trajectory"] = con.dead_time_trajectory
-        out[f"{name}.state"] = np.array([con.lat_dist_to_traj, con.jerk, con.cycle_time_estimate, con.idle_comp_acc,
-                                         con.idle_comp_steer, len(con.ctrl_vars_history)])
+        out[f"{name}.state"] = np.array([con.lat_dist_to_traj, con.jerk, getattr(con, "cycle_time_estimate", 0.0),
+                                         con.idle_comp_acc, con.idle_comp_steer, len(con.ctrl_vars_history)])
         print(name, controls[[0, 1, -1]].round(4).tolist(), trace[-1].round(3).tolist())
     path = os.path.join(HERE, "mpc_controller.npz")
     np.savez_compressed(path, **out)

@@ -23,6 +23,19 @@ def planner_trajectory(v=8.0, n=160, step=0.6, curvature=0.01):
     return NS(time=t, s=s, x=x, y=y, orientation=phi, curvature=k, velocity=vel, acceleration=np.zeros(n), emergency=False)
 
 
+def planner_trajectory_time(v=8.0, n=120, dt=0.1, curvature=0.008):
+    """The same road sampled every `dt` seconds (what the time-indexed controller takes as it is)."""
+    vel = v + 1.0 * np.tanh((np.arange(n) * dt - 3.0) / 2.0)
+    s = np.concatenate([[0.0], np.cumsum(vel[:-1] * dt)])
+    k = curvature * np.exp(-s / 60.0)
+    ds = np.diff(s, append=s[-1] + vel[-1] * dt)
+    phi = 0.03 + np.concatenate([[0.0], np.cumsum(k[:-1] * ds[:-1])])
+    x = np.concatenate([[0.0], np.cumsum(np.cos(phi[:-1]) * ds[:-1])])
+    y = np.concatenate([[0.0], np.cumsum(np.sin(phi[:-1]) * ds[:-1])])
+    return NS(time=np.arange(n) * dt, s=s, x=x, y=y, orientation=phi, curvature=k, velocity=vel, acceleration=np.zeros(n),
+              emergency=False)
+
+
 @contextmanager
 def nolock():
     yield
@@ -43,9 +56,16 @@ CASES = {
 }
 
 
+TIME_CASES = {
+    "time_default": (dict(x=-1.5, y=0.4, yaw=0.06, v=7.0), {}, 100),
+    "time_no_dead_time": (dict(x=-1.0, y=-0.3, yaw=0.0, v=8.5, steer_dead_time=0.0, acc_dead_time=0.0),
+                          dict(horizon=25, max_iterations=10, cog_pos=0.3), 100),
+}
+
+
 def run(controller_factory, name, on_tick=None):
     """-> controls float64[ticks, 2], ego trace float64[ticks, 4], the controller."""
-    ego_kw, over, ticks = CASES[name]
+    ego_kw, over, ticks = CASES[name] if name in CASES else TIME_CASES[name]
     ego = EgoSim(**ego_kw)
     shared = NS()
     con = controller_factory(shared, nolock)
@@ -55,7 +75,7 @@ def run(controller_factory, name, on_tick=None):
             p.idle_comp.active = True
         else:
             setattr(p, k, v)
-    traj = planner_trajectory(v=0.05 if over.get("idle") else 8.0)
+    traj = planner_trajectory_time() if name in TIME_CASES else planner_trajectory(v=0.05 if over.get("idle") else 8.0)
     controls, trace, extra = np.zeros((ticks, 2)), np.zeros((ticks, 4)), []
     t = 0.0
     for k in range(ticks):
@@ -67,8 +87,10 @@ def run(controller_factory, name, on_tick=None):
         controls[k] = (acc, steer)
         trace[k] = (ego.x, ego.y, ego.yaw, ego.v)
         if k in (0, ticks // 2, ticks - 1):
-            extra.append(np.stack([con_traj.time, con_traj.x, con_traj.y, con_traj.orientation, con_traj.velocity,
-                                   con_traj.curvature, con_traj.s, con_traj.acceleration], axis=1))
+            cols = [con_traj.time, con_traj.x, con_traj.y, con_traj.orientation, con_traj.velocity, con_traj.curvature]
+            if name in CASES:
+                cols += [con_traj.s, con_traj.acceleration]
+            extra.append(np.stack(cols, axis=1))
         if on_tick:
             on_tick(k, con)
     return controls, trace, extra, con

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import mpc_cases as cases
-from tpl_amd.control import ModelPredictiveController
+from tpl_amd.control import ModelPredictiveController, ModelPredictiveControllerTime
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = np.load(os.path.join(HERE, "golden", "mpc_controller.npz"))
@@ -27,8 +27,8 @@ def _check(name, factory):
         want = GOLD[f"{name}.con_traj_{i}"]
         assert e.shape == want.shape and np.allclose(e, want, rtol=0, atol=10 * TOL), f"{name}: predicted trajectory {i}"
     assert np.allclose(con.dead_time_trajectory, GOLD[f"{name}.dead_time_trajectory"], rtol=0, atol=TOL)
-    state = np.array([con.lat_dist_to_traj, con.jerk, con.cycle_time_estimate, con.idle_comp_acc, con.idle_comp_steer,
-                      len(con.ctrl_vars_history)])
+    state = np.array([con.lat_dist_to_traj, con.jerk, getattr(con, "cycle_time_estimate", 0.0), con.idle_comp_acc,
+                      con.idle_comp_steer, len(con.ctrl_vars_history)])
     assert np.allclose(state, GOLD[f"{name}.state"], rtol=0, atol=10 * TOL)
     return con
 
@@ -47,6 +47,19 @@ def test_controller_on_the_hip_solver_matches_the_reference_loop(name):
     from tpl_amd.optim.solver import Optim
     con = _check(name, lambda shared, lock: ModelPredictiveController(shared, lock))
     assert isinstance(con.opt, Optim)
+
+
+@pytest.mark.parametrize("name", sorted(cases.TIME_CASES))
+def test_time_indexed_controller_on_the_cpu_solver(name):
+    import oracle_ilqr
+    _check(name, lambda shared, lock: ModelPredictiveControllerTime(shared, lock, solver=oracle_ilqr.OracleOptim(
+        "trajectory_tracking_mpc_time")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(cases.TIME_CASES))
+def test_time_indexed_controller_on_the_hip_solver(name):
+    _check(name, lambda shared, lock: ModelPredictiveControllerTime(shared, lock))
 
 
 def test_short_trajectory_and_failed_resampling_keep_the_last_controls():
