@@ -63,6 +63,7 @@ def install_shims():
     otb = types.ModuleType("objtoolbox")
     otb.merge = lambda dst, src: [setattr(dst, k, getattr(src, k)) for k in vars(src) if not k.startswith("_")] and None
     otb.bundle = lambda: types.SimpleNamespace()
+    otb.get_obj_dict = lambda o: {k: v for k, v in vars(o).items() if not k.startswith("_")}
     sys.modules["objtoolbox"] = otb
     sys.modules["structstore"] = types.ModuleType("structstore")
     tplcpp = types.ModuleType("tplcpp")
@@ -139,6 +140,43 @@ def main():
         # the smoothed path through the velocity optimisation too (the planner's smooth_only branch)
         vo_s.update(ps.opt_path, cases.environment(cyc, with_objects=False), cases.default_params("velocity_optim"))
         out[f"c{cyc}.vel_smooth.v_opt"] = np.array(vo_s.v_opt)
+    # ---- the planner plugin on top: three cycles with obstacle avoidance, three smoothing only
+    import copy as _copy
+    from tpl.planning.path_vel_decomp.path_vel_decomp_planner import PathVelDecompPlanner
+
+    class _Shared:
+        def __setattr__(self, k, v):
+            if k == "params" and not hasattr(v, "deepcopy"):
+                v.deepcopy = lambda v=v: _copy.deepcopy(v)
+            object.__setattr__(self, k, v)
+
+    from contextlib import contextmanager
+
+    @contextmanager
+    def _lock():
+        yield
+    for tag, smooth_only in (("plan", False), ("plan_smooth", True)):
+        sh = _Shared()
+        pl = PathVelDecompPlanner(sh, _lock)
+        sh.params.smooth_only = smooth_only
+        sh.params.write_debug_data = not smooth_only       # the debug block reads path-optimisation results
+        for k, v in vars(cases.default_params("path_optim")).items():
+            setattr(sh.params.path_optim, k, v)
+        for k, v in vars(cases.default_params("velocity_optim")).items():
+            setattr(sh.params.velocity_optim, k, v)
+        for k, v in vars(cases.default_params("path_smoothing")).items():
+            setattr(sh.params.path_smoothing, k, v)
+        for cyc in range(3):
+            sh_env = cases.shared_environment(cyc)
+            tr = pl.update(sh_env)
+            out[f"{tag}.c{cyc}.traj"] = np.stack([tr.time, tr.s, tr.x, tr.y, tr.orientation, tr.curvature, tr.velocity,
+                                                  np.ravel(tr.acceleration)], axis=1)
+            out[f"{tag}.c{cyc}.requests"] = np.array([float(sh_env.local_map.update_inters_paths),
+                                                      sh_env.local_map.step_shift_idx, sh_env.local_map.shift_vel_lim])
+            out[f"{tag}.c{cyc}.leader"] = np.array([sh.debug.s_leader, sh.debug.v_leader])
+            if not smooth_only:
+                out[f"{tag}.c{cyc}.dbg_v_ref"] = np.array(sh.debug.v_ref)
+                out[f"{tag}.c{cyc}.dbg_path_lower_constr"] = np.array(sh.debug.path_lower_constr)
     dst = os.path.join(HERE, "pvd_glue.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, len(out), "arrays,", os.path.getsize(dst), "bytes")

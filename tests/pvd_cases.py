@@ -65,6 +65,23 @@ def environment(cycle=0, with_objects=True):
               get_all_tracks=lambda: tracks)
 
 
+def shared_environment(cycle=0, with_objects=True):
+    """The same cycle as the planner plugin sees it: tpl's shared environment state (lock(), tracks by source)."""
+    from contextlib import contextmanager
+    env = environment(cycle, with_objects)
+    tracks = env.get_all_tracks()
+    del env.get_all_tracks
+    env.tracks = NS(lidar=tracks)
+    env.selected_map = None
+    env.local_map.intersection_paths = []
+
+    @contextmanager
+    def lock():
+        yield
+    env.lock = lock
+    return env
+
+
 def default_params(kind):
     """The `path_vel_decomp_planner.params` blocks of data/params/planning/default/state.json (numbers committed
     here as data), as attribute objects."""

@@ -149,6 +149,54 @@ def test_glue_on_the_cpu_oracle_solvers_matches_the_reference_glue():
     assert max(worst.values()) < 1e-6
 
 
+def _run_planner(make):
+    """The planner plugin over the same three cycles, with and without obstacle avoidance (fixture: the reference's
+    PathVelDecompPlanner on the reference's solvers)."""
+    from contextlib import contextmanager
+    from tpl_amd.planning.path_vel_decomp import PathVelDecompPlanner
+    from tpl_amd.store import Bundle
+
+    @contextmanager
+    def lock():
+        yield
+    res = {}
+    for tag, smooth_only in (("plan", False), ("plan_smooth", True)):
+        sh = Bundle()
+        pl = PathVelDecompPlanner(sh, lock, solvers={k: make(k) for k in ("ref_line_smoother_k", "lateral_profile",
+                                                                          "velocity_profile_space")})
+        sh.params.smooth_only = smooth_only
+        sh.params.write_debug_data = not smooth_only
+        for kind in ("path_optim", "velocity_optim", "path_smoothing"):
+            for k, v in vars(cases.default_params(kind)).items():
+                setattr(getattr(sh.params, kind), k, v)
+        for cyc in range(3):
+            sh_env = cases.shared_environment(cyc)
+            tr = pl.update(sh_env)
+            res[f"{tag}.c{cyc}.traj"] = np.stack([tr.time, tr.s, tr.x, tr.y, tr.orientation, tr.curvature, tr.velocity,
+                                                  np.ravel(tr.acceleration)], axis=1)
+            res[f"{tag}.c{cyc}.requests"] = np.array([float(sh_env.local_map.update_inters_paths),
+                                                      sh_env.local_map.step_shift_idx, sh_env.local_map.shift_vel_lim])
+            res[f"{tag}.c{cyc}.leader"] = np.array([sh.debug.s_leader, sh.debug.v_leader])
+            if not smooth_only:
+                res[f"{tag}.c{cyc}.dbg_v_ref"] = np.array(sh.debug.v_ref)
+                res[f"{tag}.c{cyc}.dbg_path_lower_constr"] = np.array(sh.debug.path_lower_constr)
+        assert pl.update.runtime > 0.0
+    return res
+
+
+def test_planner_plugin_on_the_cpu_oracle_solvers_matches_the_reference_planner():
+    res = _run_planner(lambda problem: OI.OracleOptim(problem))
+    _compare(res, 1e-6)
+    assert res["plan.c0.traj"].shape == (250, 8) and res["plan.c0.leader"][1] > 4.0
+
+
+@pytest.mark.gpu
+def test_planner_plugin_on_the_hip_solvers_matches_the_reference_planner():
+    from tpl_amd.optim import optimizers as opts
+    opts.build_optimizers()
+    _compare(_run_planner(lambda problem: getattr(opts, problem)()), 1e-5)
+
+
 @pytest.mark.gpu
 def test_glue_on_the_hip_solvers_matches_the_reference_glue():
     from tpl_amd.optim import optimizers as opts

@@ -43,9 +43,22 @@ class EnvironmentState:
         self.local_map = None
         self.local_map_behind = None
         self.selected_map = None
-        self.tracks = []
+        self.tracks = Bundle()              # sensor name -> list of tracked objects
+        self.cpms = []
         self.predicted = []
         self.man_time_cons = []
+        self.man_vel_cons = []
+
+    def get_all_tracks(self):
+        """env_state.py:141-148: every tracked object of every source, plus the infrastructure's."""
+        groups = self.tracks.values() if isinstance(self.tracks, dict) else (
+            [self.tracks] if isinstance(self.tracks, list) else
+            [v for k, v in vars(self.tracks).items() if not k.startswith("_")])
+        objs = []
+        for g in groups:
+            objs += copy.deepcopy(g)
+        objs += copy.deepcopy(self.cpms)
+        return objs
 
     def get_relevant_maps(self):
         """env_state.py:125-139: the map behind/around the vehicle and the intersecting paths whose stop point lies

@@ -3,5 +3,6 @@ attributes and call signatures (``update(env, params)`` / ``update(path, env, pa
 from .path_optim import PathOptim
 from .path_smoothing import PathSmoothing
 from .velocity_optim import TimeConstr, VelocityOptim
+from .path_vel_decomp_planner import Params as PathVelDecompParams, PathVelDecompPlanner  # noqa: E402
 
-__all__ = ["PathOptim", "PathSmoothing", "VelocityOptim", "TimeConstr"]
+__all__ = ["PathOptim", "PathSmoothing", "VelocityOptim", "TimeConstr", "PathVelDecompPlanner", "PathVelDecompParams"]
