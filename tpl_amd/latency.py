@@ -151,7 +151,41 @@ def lat_lon_update(device=0, updates=40):
                     "rollout of 441 actions per stage) + update_traj_smooth + update_traj_cart; host states in and out"}
 
 
+def planner_cycles(device=0, cycles=80):
+    """Whole planner-plugin cycles (what tplsim times as a planner's update): PolyLatDpLonPlanner.update and
+    DpLatLonPlanner.update on the synthetic drive of tpl_amd/drive.py -- environment update with prediction geometry
+    for three objects, previous-plan shift, replan decision, lattice + (s,v,a) plan or (s,ds,l) plan + smoothing,
+    trajectory assembly.  Host Python around the engine calls is inside the time, as it is in the reference."""
+    from contextlib import contextmanager
+    from . import drive
+    from .planning.dyn_prog import DpLatLonPlanner, PolyLatDpLonPlanner
+    from .store import Bundle
+
+    @contextmanager
+    def lock():
+        yield
+    out = {}
+    for name, cls in (("poly_lat_dp_lon_planner", PolyLatDpLonPlanner), ("dp_lat_lon_planner", DpLatLonPlanner)):
+        pl = cls(Bundle(), lock)
+        d = drive.Drive(v_ego=9.0)
+        lat, engine = [], []
+        for k in range(cycles):
+            sh = d.cycle(k)
+            t0 = time.perf_counter()
+            tr = pl.update(sh)
+            lat.append((time.perf_counter() - t0) * 1e3)
+            engine.append(pl.dp_env.runtime_environment)
+        lat = np.array(lat[5:])
+        out[name] = {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "cycles": int(len(lat)),
+                     "env_update_p50_ms": float(np.percentile(engine[5:], 50)), "emergency": bool(tr.emergency),
+                     "what": f"{cls.__name__}.update on the drive of tpl_amd/drive.py (10 Hz, 230 m local map, 3 predicted "
+                             "objects), default parameters of the plugin, HIP engines; Python glue included"}
+    return out
+
+
 def run(device=0):
-    return {"mpc_closed_loop": mpc_closed_loop(device), "dp_default_plan": dp_default_plan(device),
-            "env_update": env_update(device), "poly_lat_update": poly_lat_update(device),
-            "lat_lon_update": lat_lon_update(device)}
+    res = {"mpc_closed_loop": mpc_closed_loop(device), "dp_default_plan": dp_default_plan(device),
+           "env_update": env_update(device), "poly_lat_update": poly_lat_update(device),
+           "lat_lon_update": lat_lon_update(device)}
+    res.update(planner_cycles(device))
+    return res
