@@ -98,6 +98,8 @@ TPLHIP_API void tplhip_dp_env_params_default(TplDpEnvParams* p);   /* env.cuh:13
 TPLHIP_API void tplhip_lon_dynamics(const TplLonState* x0, float j, float dt, TplLonState* out);
 /* LonTraj::state(t), lon_planner.cu:252-260 with InterpVars utils.hpp:53-86 */
 TPLHIP_API int tplhip_lon_traj_state(const TplLonState* states, int n, float t, TplLonState* out);
+/* the array overload of LonTraj.state (bindings_dp_lon.cu:93-108): out = double[m][4] = (s, v, a, j) at ts[m] */
+TPLHIP_API int tplhip_lon_traj_state_rows(const TplLonState* states, int n, const double* ts, int m, double* out);
 
 /* -------------------------------------------- DP environment (HP-1 a11) -- */
 
@@ -303,6 +305,11 @@ TPLHIP_API int tplhip_poly_lat_copy_nodes(tplhip_poly_lat* h, float* out);
 TPLHIP_API int tplhip_poly_lat_traj_update(TplPolyLatTrajPoint* points, int n);
 TPLHIP_API int tplhip_poly_lat_traj_lerp(const TplPolyLatTrajPoint* points, int n, double distance,
                                          TplPolyLatTrajPoint* out);
+/* the array overload of PolyLatTraj.lerp and PolyLatTraj.as_numpy (bindings_dp_poly_lat.cu:55-97): rows of 12 doubles
+ * (t, l, dl, ddl, dddl, s, v, x, y, heading, distance, k) */
+TPLHIP_API int tplhip_poly_lat_traj_lerp_rows(const TplPolyLatTrajPoint* points, int n, const double* distances, int m,
+                                              double* out);
+TPLHIP_API int tplhip_poly_lat_traj_rows(const TplPolyLatTrajPoint* points, int n, double* out);
 
 /* --------- lateral/longitudinal DP planner (lat_lon_planner.cu) -- */
 

@@ -159,6 +159,7 @@ SIGNATURES = {
     "tplhip_dp_env_params_default": (None, [_P(TplDpEnvParams)]),
     "tplhip_lon_dynamics": (None, [_P(TplLonState), C.c_float, C.c_float, _P(TplLonState)]),
     "tplhip_lon_traj_state": (C.c_int, [_P(TplLonState), C.c_int, C.c_float, _P(TplLonState)]),
+    "tplhip_lon_traj_state_rows": (C.c_int, [_P(TplLonState), C.c_int, _dp, C.c_int, _dp]),
     "tplhip_dp_env_create": (C.c_int, [C.c_int, _P(_vp)]),
     "tplhip_dp_env_destroy": (C.c_int, [_vp]),
     "tplhip_dp_env_reinit": (C.c_int, [_vp, _P(TplDpEnvParams)]),
@@ -200,6 +201,8 @@ SIGNATURES = {
     "tplhip_poly_lat_copy_nodes": (C.c_int, [_vp, _fp]),
     "tplhip_poly_lat_traj_update": (C.c_int, [_P(TplPolyLatTrajPoint), C.c_int]),
     "tplhip_poly_lat_traj_lerp": (C.c_int, [_P(TplPolyLatTrajPoint), C.c_int, C.c_double, _P(TplPolyLatTrajPoint)]),
+    "tplhip_poly_lat_traj_lerp_rows": (C.c_int, [_P(TplPolyLatTrajPoint), C.c_int, _dp, C.c_int, _dp]),
+    "tplhip_poly_lat_traj_rows": (C.c_int, [_P(TplPolyLatTrajPoint), C.c_int, _dp]),
     "tplhip_dp_lon_create": (C.c_int, [C.c_int, _P(_vp)]),
     "tplhip_dp_lon_destroy": (C.c_int, [_vp]),
     "tplhip_dp_lon_reinit": (C.c_int, [_vp, _P(TplDpLonParams)]),

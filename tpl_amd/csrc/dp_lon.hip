@@ -1605,6 +1605,19 @@ int tplhip_lon_traj_state(const TplLonState* states, int n, float t, TplLonState
     return TPLHIP_OK;
 }
 
+// LonTraj::state over an array of times (bindings_dp_lon.cu:93-108): rows (s, v, a, j)
+int tplhip_lon_traj_state_rows(const TplLonState* states, int n, const double* ts, int m, double* out)
+{
+    if (!ts || !out) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    for (int k = 0; k < m; ++k) {
+        TplLonState r;
+        const int rc = tplhip_lon_traj_state(states, n, (float)ts[k], &r);
+        if (rc) return rc;
+        out[4 * (size_t)k] = r.s; out[4 * (size_t)k + 1] = r.v; out[4 * (size_t)k + 2] = r.a; out[4 * (size_t)k + 3] = r.j;
+    }
+    return TPLHIP_OK;
+}
+
 // ---- environment -------------------------------------------------------------
 
 int tplhip_dp_env_create(int device, tplhip_dp_env** out)

@@ -527,4 +527,31 @@ int tplhip_poly_lat_traj_lerp(const TplPolyLatTrajPoint* pts, int n, double dist
     return TPLHIP_OK;
 }
 
+// PolyLatTraj::lerp over an array of distances and PolyLatTraj::as_numpy (bindings_dp_poly_lat.cu:55-97): rows of
+// 12 doubles (t, l, dl, ddl, dddl, s, v, x, y, heading, distance, k)
+static void poly_lat_row(const TplPolyLatTrajPoint& p, double* r)
+{
+    r[0] = p.t; r[1] = p.l; r[2] = p.dl; r[3] = p.ddl; r[4] = p.dddl; r[5] = p.s; r[6] = p.v; r[7] = p.x; r[8] = p.y;
+    r[9] = p.heading; r[10] = p.distance; r[11] = p.k;
+}
+
+int tplhip_poly_lat_traj_lerp_rows(const TplPolyLatTrajPoint* pts, int n, const double* distances, int m, double* out)
+{
+    if (!distances || !out) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    for (int k = 0; k < m; ++k) {
+        TplPolyLatTrajPoint r;
+        const int rc = tplhip_poly_lat_traj_lerp(pts, n, distances[k], &r);
+        if (rc) return rc;
+        poly_lat_row(r, out + 12 * (size_t)k);
+    }
+    return TPLHIP_OK;
+}
+
+int tplhip_poly_lat_traj_rows(const TplPolyLatTrajPoint* pts, int n, double* out)
+{
+    if ((!pts && n > 0) || !out) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    for (int k = 0; k < n; ++k) poly_lat_row(pts[k], out + 12 * (size_t)k);
+    return TPLHIP_OK;
+}
+
 } // extern "C"

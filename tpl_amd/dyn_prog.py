@@ -50,7 +50,11 @@ class _StructView:
 
     @classmethod
     def _all_fields(cls):
-        return {f[0] for f in cls._ctype._fields_}
+        names = cls.__dict__.get("_field_names")
+        if names is None:
+            names = frozenset(f[0] for f in cls._ctype._fields_)
+            cls._field_names = names
+        return names
 
     def __deepcopy__(self, memo):
         other = type(self)()
@@ -152,11 +156,10 @@ class LonTraj:
         ts = np.asarray(t, dtype=np.float64)
         if ts.ndim != 1:
             raise ValueError(f"array has incorrect shape, expected: (-1,), got: {ts.shape}")
+        ts = np.ascontiguousarray(ts)
         res = np.empty((ts.shape[0], 4), dtype=np.float64)
-        out = TplLonState()
-        for i, ti in enumerate(ts):
-            check(lib.tplhip_lon_traj_state(arr, len(self.states), float(ti), C.byref(out)))
-            res[i] = (out.s, out.v, out.a, out.j)
+        dp = C.POINTER(C.c_double)
+        check(lib.tplhip_lon_traj_state_rows(arr, len(self.states), ts.ctypes.data_as(dp), len(ts), res.ctypes.data_as(dp)))
         return res
 
     def as_numpy(self):

@@ -124,16 +124,19 @@ class _Traj:
         self._states = None
 
     def as_numpy(self):
+        return self._columns(self._traj_row)
+
+    def _columns(self, names):
+        """The named members of every state as float64[n, len(names)], read through a record view of the C array."""
         arr = self._as_array()
-        res = np.empty((len(arr), len(self._traj_row)), dtype=np.float64)
-        for i, c in enumerate(arr):
-            res[i] = [getattr(c, f) for f in self._traj_row]
-        return res
+        if not len(arr):
+            return np.empty((0, len(names)), dtype=np.float64)
+        rec = np.frombuffer(arr, dtype=np.dtype(self._ctype), count=len(arr))
+        return np.stack([rec[f].astype(np.float64) for f in names], axis=1)
 
     def as_numpy_full(self):
         """Every member of every state (not in the reference: its as_numpy() drops cost / constr / flags)."""
-        arr = self._as_array()
-        return np.array([[getattr(c, f) for f in self._fields] for c in arr], dtype=np.float64).reshape(len(arr), len(self._fields))
+        return self._columns(self._fields)
 
     def copy(self):
         other = type(self)()

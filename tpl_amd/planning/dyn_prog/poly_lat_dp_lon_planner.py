@@ -234,10 +234,13 @@ class PolyLatDpLonPlanner(BasePlanner):
         if self.traj_lon is None:
             return
         shift = env.local_map.shift_idx_start_ref * env.local_map.step_size_ref                        # :303-312
-        pts = self.traj_lat.points
-        for p in pts:
-            p.s -= shift
-        self.traj_lat.points = [p for p in pts if p.s >= 0.0]
+        if hasattr(self.traj_lat, "shift_stations"):
+            self.traj_lat.shift_stations(shift)             # the two statements below on the C array
+        else:
+            pts = self.traj_lat.points
+            for p in pts:
+                p.s -= shift
+            self.traj_lat.points = [p for p in pts if p.s >= 0.0]
         self.poly_lat_start = self.traj_lat.lerp(params.dist_path_fix_min + params.dist_path_fix * env.vehicle_state.v)
         self.poly_lat_start.v = env.vehicle_state.v
         self.trajectory_np[:, 1] -= shift                                                              # :316

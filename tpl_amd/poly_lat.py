@@ -76,6 +76,10 @@ class PolyQuintic:
         return self._eval(3, x)
 
 
+_POINT_DTYPE = np.dtype(TplPolyLatTrajPoint)
+assert _POINT_DTYPE.itemsize == C.sizeof(TplPolyLatTrajPoint)
+
+
 class PolyLatTraj:
     """tplcpp.PolyLatTraj (bindings_dp_poly_lat.cu:47-100)."""
 
@@ -122,14 +126,41 @@ class PolyLatTraj:
         check(_capi.load().tplhip_poly_lat_traj_update(arr, len(arr)))
         self._take(arr)
 
+    @staticmethod
+    def _view(arr):
+        """The C array as a numpy record array (same memory)."""
+        return np.frombuffer(arr, dtype=_POINT_DTYPE, count=len(arr))
+
+    def _stations(self, arr):
+        return self._view(arr)["s"] if len(arr) else np.zeros(0, np.float32)
+
     def insert_after_station(self, s, other):
-        # PolyLatTraj::insertAfterStation, poly_lat_planner.cu:283-298
-        for i, p in enumerate(self.points):
-            if p.s >= s:
-                self.points = self.points[:i]
-                break
-        self.points = self.points + [q.copy() for q in other.points]
-        self.update_time_dist_curv()
+        # PolyLatTraj::insertAfterStation, poly_lat_planner.cu:283-298: everything from the first point with
+        # station >= s on is replaced by the other trajectory's points; done on the C arrays (no per-point objects)
+        mine, theirs = self._as_array(), other._as_array()
+        hit = np.flatnonzero(self._stations(mine) >= s)
+        keep = int(hit[0]) if len(hit) else len(mine)
+        arr = (TplPolyLatTrajPoint * (keep + len(theirs)))()
+        sz = C.sizeof(TplPolyLatTrajPoint)
+        C.memmove(arr, mine, keep * sz)
+        if len(theirs):
+            C.memmove(C.byref(arr, keep * sz), theirs, len(theirs) * sz)
+        check(_capi.load().tplhip_poly_lat_traj_update(arr, len(arr)))
+        self._take(arr)
+
+    def shift_stations(self, shift):
+        """``for p in traj.points: p.s -= shift`` followed by dropping the points with p.s < 0 -- what
+        PolyLatDpLonPlanner.shift_trajectory does through the point list (poly_lat_dp_lon_planner.py:305-307) -- on
+        the C array."""
+        arr = self._as_array()
+        if not len(arr):
+            return
+        a = self._view(arr)
+        a["s"] = (a["s"].astype(np.float64) - shift).astype(np.float32)
+        kept = np.ascontiguousarray(a[a["s"] >= 0.0])
+        out = (TplPolyLatTrajPoint * len(kept))()
+        C.memmove(out, kept.ctypes.data, len(kept) * C.sizeof(TplPolyLatTrajPoint))
+        self._take(out)
 
     def lerp(self, distance):
         arr = self._as_array()
@@ -142,17 +173,15 @@ class PolyLatTraj:
         if distance.ndim != 1:
             raise ValueError(f"array has incorrect shape, expected: (-1,), got: {distance.shape}")
         res = np.empty((len(distance), 12), dtype=np.float64)
-        out = TplPolyLatTrajPoint()
-        for i, d in enumerate(distance):
-            check(lib.tplhip_poly_lat_traj_lerp(arr, len(arr), float(d), C.byref(out)))
-            res[i] = [getattr(out, f) for f in _FIELDS12]
+        dp = C.POINTER(C.c_double)
+        check(lib.tplhip_poly_lat_traj_lerp_rows(arr, len(arr), distance.ctypes.data_as(dp), len(distance),
+                                                 res.ctypes.data_as(dp)))
         return res
 
     def as_numpy(self):
         arr = self._as_array()
         res = np.empty((len(arr), 12), dtype=np.float64)
-        for i, c in enumerate(arr):
-            res[i] = [getattr(c, f) for f in _FIELDS12]
+        check(_capi.load().tplhip_poly_lat_traj_rows(arr, len(arr), res.ctypes.data_as(C.POINTER(C.c_double))))
         return res
 
     def copy(self):
