@@ -44,6 +44,9 @@ OPTIM_SLOTS = ["step", "opt_start", "horizon", "int_step", "x", "u", "next_int_s
                "trajectory_changed", "improved", "termination_condition", "use_quadratic_terms",
                "max_iterations", "max_lg_iterations"]
 
+_FIELD_ID = {f: i for i, f in enumerate(FIELDS)}
+_S_HORIZON = SCALARS.index("horizon")
+
 SIGNATURES = {
     "tplhip_ilqr_model_name": (C.c_char_p, []),
     "tplhip_ilqr_dims": (None, [C.POINTER(C.c_int)] * 4),
@@ -202,11 +205,25 @@ class Optim:
         }[f]
 
     def _view(self, f):
-        rows, trail, width = self._spec(f)
+        # the call itself matters: it brings the host mirror up to date when the device holds newer values.  The numpy
+        # view over the (fixed) mirror is built once per (field, horizon).
         stride = C.c_int64()
-        ptr = self._lib.tplhip_ilqr_ptr(self._h, FIELDS.index(f), C.byref(stride))
+        ptr = self._lib.tplhip_ilqr_ptr(self._h, _FIELD_ID[f], C.byref(stride))
         if not ptr:
             _check(self._lib, -2)
+        T = int(self._sc[0, _S_HORIZON])
+        cache = self.__dict__.setdefault("_views", {})
+        hit = cache.get((f, T))
+        addr = C.cast(ptr, C.c_void_p).value
+        if hit is not None and hit[0] == addr:
+            return hit[1]
+        v = self._build_view(f, ptr, stride.value)
+        cache[(f, T)] = (addr, v)
+        return v
+
+    def _build_view(self, f, ptr, stride_value):
+        rows, trail, width = self._spec(f)
+        stride = C.c_int64(stride_value)
         B = self._batch
         cap_rows = stride.value // width
         shape = (B,) + ((rows,) if rows is not None else ()) + tuple(trail)
