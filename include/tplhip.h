@@ -404,6 +404,16 @@ TPLHIP_API int tplhip_gen_prediction_geometry(const double* pred, int n_pred, co
                                               const double* path, int n_path, const double* ts, int n_ts,
                                               double station_step_size, double expansion_rate, double sweep_length,
                                               double* out, int cap, int* n_out);
+/* tplcpp.point_in_polygon, utils.cpp:25-65 (binding :780-804): out[k] = 1 where points[k] lies inside the polygon
+ * double[n][2] */
+TPLHIP_API int tplhip_point_in_polygon(const double* points, int m, const double* polygon, int n, uint8_t* out);
+/* tplcpp.intersect_polygons, utils.cpp:67-158: separating-axis test of two convex polygons; *out = 1 when they overlap */
+TPLHIP_API int tplhip_intersect_polygons(const double* poly0, int l0, const double* poly1, int l1, int* out);
+/* tplcpp.convex_hull, utils.cpp:160-255: counter-clockwise hull from the lowest point; out = double[<= n][2] */
+TPLHIP_API int tplhip_convex_hull(const double* points, int n, double* out, int* n_out);
+/* tplcpp.smooth_path, utils.cpp:693-776: LQR smoothing of a line strip sampled every ds; out = double[n][2] */
+TPLHIP_API int tplhip_smooth_path(const double* path, int n, double ds, double w_v, double w_a, double w_j, int closed,
+                                  double* out);
 /* tplcpp.lerp, utils.cpp:931-990: ys = double[m][d] sampled at the sorted xs[m], evaluated at vals[n] into
  * out = double[n][d]; angle: short-way-round interpolation; clip_alpha: hold the end values outside [xs[0], xs[m-1]] */
 TPLHIP_API int tplhip_lerp(const double* vals, int n, const double* xs, int m, const double* ys, int d, int angle,

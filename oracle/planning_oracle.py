@@ -149,3 +149,80 @@ def gen_prediction_geometry(pred, hull, path, ts, station_step_size=5.0, expansi
         length *= 1.0 + expansion_rate
         s_mid += dt * pp[4]
     return np.array(vtxs, dtype=np.float64).reshape(-1, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# polygon helpers and the path smoother of the same source file (utils.cpp:25-255, 693-776; lqrSmoother utils.hpp:278-326)
+
+def point_in_polygon(x, y, polygon):
+    poly = np.asarray(polygon, dtype=np.float64)
+    n = len(poly)
+    p1x, p1y = poly[0]
+    xints, inside = 0.0, False
+    for i in range(n + 1):
+        p2x, p2y = poly[i % n]
+        if min(p1y, p2y) <= y <= max(p1y, p2y) and x <= max(p1x, p2x):
+            if p1y != p2y:
+                xints = (y - p1y) * (p2x - p1x) / (p2y - p1y) + p1x
+            if p1x == p2x or x <= xints:
+                inside = not inside
+        p1x, p1y = p2x, p2y
+    return inside
+
+
+def intersect_polygons(poly0, poly1):
+    a, b = np.asarray(poly0, dtype=np.float64), np.asarray(poly1, dtype=np.float64)
+    if len(a) == 0 or len(b) == 0:
+        return False
+    for p in (a, b):
+        for i in range(len(p)):
+            e = p[(i + 1) % len(p)] - p[i]
+            e = e / math.sqrt(e[0] * e[0] + e[1] * e[1])
+            o = np.array([-e[1], e[0]])
+            q0, q1 = (a - p[i]) @ o, (b - p[i]) @ o
+            if (q0.max() < q1.min() and q0.max() < q1.max()) or (q0.min() > q1.min() and q0.min() > q1.max()):
+                return False
+    return True
+
+
+def smooth_path(path, ds, w_v=1.0, w_a=1.0, w_j=1.0, closed=False):
+    path = np.asarray(path, dtype=np.float64)
+    H = len(path)
+    x_ref = np.zeros((H, 6))
+    x_ref[:, 0], x_ref[:, 3] = path[:, 0], path[:, 1]
+    d = path[1] - path[0]
+    d = d / math.sqrt(d[0] * d[0] + d[1] * d[1]) * ds
+    x_ref[0, 1], x_ref[0, 4] = d
+    if closed:
+        x_ref[-1] = x_ref[0]
+    A = np.eye(6)
+    A[0, 1] = A[1, 2] = A[3, 4] = A[4, 5] = ds
+    B = np.zeros((6, 2))
+    B[2, 0] = B[5, 1] = ds
+    Q = np.diag([1.0, w_v, w_a, 1.0, w_v, w_a])
+    R = np.eye(2) * w_j
+    Qs = [Q.copy() for _ in range(H)]
+    Qs[0] = np.eye(6) * 1.0e6
+    Qs[-1] = np.eye(6) * 1.0e6
+    k, K = [None] * H, [None] * H
+    Vxx = Qs[-1].copy()
+    Vx = -Qs[-1] @ x_ref[-1]
+    for i in range(H - 2, -1, -1):
+        lx = -Qs[i] @ x_ref[i]
+        Qx = lx + A.T @ Vx
+        Qu = B.T @ Vx
+        Qxx = Qs[i] + A.T @ Vxx @ A
+        Quu = R + B.T @ Vxx @ B
+        Qux = B.T @ Vxx @ A
+        W = -np.linalg.inv(Quu)
+        k[i], K[i] = W @ Qu, W @ Qux
+        Vx = Qx + K[i].T @ Quu @ k[i] + K[i].T @ Qu + Qux.T @ k[i]
+        Vxx = Qxx + K[i].T @ Quu @ K[i]
+        tmp = K[i].T @ Qux
+        Vxx = Vxx + tmp + tmp.T
+    xs = np.zeros((H, 6))
+    xs[0] = x_ref[0]
+    for i in range(H - 1):
+        u = K[i] @ xs[i] + k[i]
+        xs[i + 1] = A @ xs[i] + B @ u
+    return xs[:, [0, 3]]

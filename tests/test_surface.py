@@ -92,3 +92,41 @@ def test_ref_line_fromarray_and_lerp():
         tpl_amd.RefLine.fromarray(np.zeros((3, 8)), 1.0)
     line.points = pts[:2]
     assert line.as_array().shape == (2, 9)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/library/tpl"), reason="the reference checkout exists in the build container only")
+def test_the_references_own_util_module_runs_on_tpl_amd_as_tplcpp():
+    """`import tpl_amd as tplcpp`: tpl/util.py (which imports nine names from tplcpp) imports and its wrappers work.
+    numba / structstore / objtoolbox are absent from this image and stubbed; nothing of the reference is copied."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, types
+import numpy as np
+import tpl_amd
+sys.modules["tplcpp"] = tpl_amd
+numba = types.ModuleType("numba"); numba.njit = lambda *a, **k: (a[0] if len(a) == 1 and callable(a[0]) and not k else (lambda f: f))
+sys.modules["numba"] = numba
+sys.modules["structstore"] = types.ModuleType("structstore")
+otb = types.ModuleType("objtoolbox"); otb.bundle = lambda: types.SimpleNamespace(); sys.modules["objtoolbox"] = otb
+sys.path.insert(0, "/root/reference/library")
+import importlib.util
+spec = importlib.util.spec_from_file_location("ref_util", "/root/reference/library/tpl/util.py")
+tpl_pkg = types.ModuleType("tpl"); tpl_pkg.__path__ = ["/root/reference/library/tpl"]; sys.modules["tpl"] = tpl_pkg
+optim = types.ModuleType("tpl.optim"); optim.__path__ = []; sys.modules["tpl.optim"] = optim
+sys.modules["tpl.optim.optimizers"] = types.ModuleType("tpl.optim.optimizers"); optim.optimizers = sys.modules["tpl.optim.optimizers"]
+util = importlib.util.module_from_spec(spec); spec.loader.exec_module(util)
+path = np.stack([np.arange(40) * 0.5, np.zeros(40), np.zeros(40), np.arange(40) * 0.5, np.zeros(40), np.full(40, 5.0)], axis=1)
+p = util.project(path[:, :2], [3.2, 1.0])
+assert abs(p.arc_len - 3.2) < 1e-12 and abs(p.distance - 1.0) < 1e-12
+rs = util.resample_path(path, 1.0, 10)
+assert rs.shape == (10, 6) and abs(rs[3, 0] - 3.0) < 1e-12
+assert abs(util.lerp(0.25, np.array([0.0, 1.0]), np.array([2.0, 4.0])) - 2.5) < 1e-12
+assert util.lerp(np.array([0.25, 0.75]), np.array([0.0, 1.0]), np.array([[2.0, 0.0], [4.0, 1.0]])).shape == (2, 2)
+assert util.point_in_polygon([0.5, 0.5], np.array([[0.0, 0], [1, 0], [1, 1], [0, 1]]))
+print("ok")
+'''
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]

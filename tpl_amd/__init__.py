@@ -42,9 +42,11 @@ from .poly_lat import (  # noqa: E402
 
 from .planning.geometry import Projection, gen_prediction_geometry, project, resample  # noqa: E402
 from .planning.geometry import lerp_cpp as lerp  # noqa: E402  (tplcpp.lerp, utils.cpp:931-990)
+from .planning.geometry import convex_hull, intersect_polygons, point_in_polygon, smooth_path  # noqa: E402
 
 __all__ = [
-    "Projection", "gen_prediction_geometry", "lerp", "project", "resample",
+    "Projection", "gen_prediction_geometry", "lerp", "project", "resample", "convex_hull", "intersect_polygons",
+    "point_in_polygon", "smooth_path",
     "DynProgLatLonPlanner", "DynProgLatLonPlannerParams", "LatLonCartState", "LatLonCartTraj", "LatLonState",
     "LatLonTraj",
     "PolyLatPlanner", "PolyLatPlannerParams", "PolyLatTraj", "PolyLatTrajPoint", "PolyQuintic",

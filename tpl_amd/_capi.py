@@ -152,6 +152,10 @@ SIGNATURES = {
     "tplhip_ref_line_center": (C.c_int, [_dp, C.c_int, C.c_int, _dp, _dp, _dp]),
     "tplhip_gen_prediction_geometry": (C.c_int, [_dp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_double,
                                                  C.c_double, C.c_double, _dp, C.c_int, _P(C.c_int)]),
+    "tplhip_point_in_polygon": (C.c_int, [_dp, C.c_int, _dp, C.c_int, _P(C.c_uint8)]),
+    "tplhip_intersect_polygons": (C.c_int, [_dp, C.c_int, _dp, C.c_int, _P(C.c_int)]),
+    "tplhip_convex_hull": (C.c_int, [_dp, C.c_int, _dp, _P(C.c_int)]),
+    "tplhip_smooth_path": (C.c_int, [_dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _dp]),
     "tplhip_lerp": (C.c_int, [_dp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp]),
     "tplhip_ref_line_lerp": (C.c_int, [_dp, C.c_int, C.c_float, C.c_float, _dp]),
     "tplhip_version": (C.c_char_p, []),

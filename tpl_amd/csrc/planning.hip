@@ -7,6 +7,7 @@
 // reassociation; tests compare at 1e-9).
 #include <cmath>
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -425,6 +426,191 @@ int tplhip_lerp(const double* vals, int n, const double* xs, int m, const double
             const double y0 = ys[i_prev * d + j], y1 = ys[i_next * d + j];
             out[(long)k * d + j] = angle ? y0 + a * tplhip::short_angle_dist(y0, y1) : (1.0 - a) * y0 + a * y1;
         }
+    }
+    return TPLHIP_OK;
+}
+
+// pointInPolygon, utils.cpp:25-65: the reference's edge-crossing count (its own handling of points on edges kept)
+int tplhip_point_in_polygon(const double* points, int m, const double* polygon, int n, uint8_t* out)
+{
+    if (!points || !polygon || !out) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (n < 1) return tplhip_fail(TPLHIP_EINVAL, "empty polygon");
+    for (int k = 0; k < m; ++k) {
+        const double x = points[2 * k], y = points[2 * k + 1];
+        double p1x = polygon[0], p1y = polygon[1], xints = 0.0;
+        bool inside = false;
+        for (int i = 0; i < n + 1; ++i) {
+            const double p2x = polygon[2 * (i % n)], p2y = polygon[2 * (i % n) + 1];
+            if (std::min(p1y, p2y) <= y && y <= std::max(p1y, p2y) && x <= std::max(p1x, p2x)) {
+                if (p1y != p2y) xints = (y - p1y) * (p2x - p1x) / (p2y - p1y) + p1x;
+                if (p1x == p2x || x <= xints) inside = !inside;
+            }
+            p1x = p2x; p1y = p2y;
+        }
+        out[k] = inside ? 1 : 0;
+    }
+    return TPLHIP_OK;
+}
+
+// intersectPolygons, utils.cpp:87-158: separating-axis test over the edge normals of both (convex) polygons
+int tplhip_intersect_polygons(const double* poly0, int l0, const double* poly1, int l1, int* out)
+{
+    if (!out || (!poly0 && l0 > 0) || (!poly1 && l1 > 0)) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    *out = 0;
+    if (l0 <= 0 || l1 <= 0) return TPLHIP_OK;                 // an empty polygon intersects nothing
+    for (int pass = 0; pass < 2; ++pass) {
+        const double* p = pass == 0 ? poly0 : poly1;
+        const int l = pass == 0 ? l0 : l1;
+        for (int i = 0; i < l; ++i) {
+            const double ax = p[2 * i], ay = p[2 * i + 1];
+            double ex = p[2 * ((i + 1) % l)] - ax, ey = p[2 * ((i + 1) % l) + 1] - ay;
+            const double en = std::sqrt(ex * ex + ey * ey);
+            ex /= en; ey /= en;
+            const double ox = -ey, oy = ex;
+            double min0 = INFINITY, max0 = -INFINITY, min1 = INFINITY, max1 = -INFINITY;
+            for (int j = 0; j < l0; ++j) {
+                const double q = ox * (poly0[2 * j] - ax) + oy * (poly0[2 * j + 1] - ay);
+                min0 = std::min(q, min0); max0 = std::max(q, max0);
+            }
+            for (int j = 0; j < l1; ++j) {
+                const double q = ox * (poly1[2 * j] - ax) + oy * (poly1[2 * j + 1] - ay);
+                min1 = std::min(q, min1); max1 = std::max(q, max1);
+            }
+            if ((max0 < min1 && max0 < max1) || (min0 > min1 && min0 > max1)) return TPLHIP_OK;   // separating axis
+        }
+    }
+    *out = 1;
+    return TPLHIP_OK;
+}
+
+// convexHull, utils.cpp:160-255: Graham scan from the lowest (then leftmost) point; out holds at most n points
+int tplhip_convex_hull(const double* points, int n, double* out, int* n_out)
+{
+    if (!out || !n_out || (!points && n > 0)) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    struct P { double x, y; };
+    std::vector<P> ps((size_t)std::max(n, 0));
+    for (int i = 0; i < n; ++i) ps[(size_t)i] = {points[2 * i], points[2 * i + 1]};
+    auto emit = [&](const std::vector<P>& v) {
+        for (size_t i = 0; i < v.size(); ++i) { out[2 * i] = v[i].x; out[2 * i + 1] = v[i].y; }
+        *n_out = (int)v.size();
+        return TPLHIP_OK;
+    };
+    size_t len = ps.size();
+    if (len < 4) return emit(ps);
+    for (size_t i = 1; i < len; ++i) {
+        if (ps[i].y > ps[0].y) continue;
+        if (ps[i].y == ps[0].y && ps[i].x >= ps[0].x) continue;
+        std::swap(ps[0], ps[i]);
+    }
+    auto orientation = [](const P& p, const P& q, const P& r) {
+        const double res = (q.y - p.y) * (r.x - q.x) - (q.x - p.x) * (r.y - q.y);
+        return res == 0 ? 0 : (res > 0 ? 1 : 2);              // colinear / clockwise / counter-clockwise
+    };
+    const P p0 = ps[0];
+    std::sort(ps.begin() + 1, ps.end(), [&](const P& a, const P& b) {
+        const int o = orientation(p0, a, b);
+        if (o == 0) {
+            const double d1 = (p0.x - a.x) * (p0.x - a.x) + (p0.y - a.y) * (p0.y - a.y);
+            const double d2 = (p0.x - b.x) * (p0.x - b.x) + (p0.y - b.y) * (p0.y - b.y);
+            return d1 < d2;
+        }
+        return o == 2;
+    });
+    size_t unique = 1;                                          // of colinear points keep the farthest
+    for (size_t i = 1; i < len; i++) {
+        while (i < len - 1 && orientation(p0, ps[i], ps[i + 1]) == 0) i++;
+        ps[unique++] = ps[i];
+    }
+    ps.resize(unique);
+    len = ps.size();
+    if (len < 4) return emit(ps);
+    std::vector<P> stack;
+    stack.push_back(ps[0]);
+    for (size_t i = 1; i < len; i++) {
+        while (stack.size() > 1 && orientation(stack[stack.size() - 2], stack.back(), ps[i]) != 2) stack.pop_back();
+        stack.push_back(ps[i]);
+    }
+    return emit(stack);
+}
+
+// smoothPath, utils.cpp:693-776: the path as the reference of an LQR over (x, x', x'', y, y', y'') with jerk inputs
+// (lqrSmoother<6, 2>, utils.hpp:278-326, in plain loops); the end states are pinned with weight 1e6
+int tplhip_smooth_path(const double* path, int n, double ds, double w_v, double w_a, double w_j, int closed, double* out)
+{
+    if (!path || !out) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (n < 2) return tplhip_fail(TPLHIP_EINVAL, "a line strip needs at least two points (got %d)", n);
+    constexpr int X = 6, U = 2;
+    const size_t H = (size_t)n;
+    std::vector<double> xref(H * X, 0.0);
+    for (size_t i = 0; i < H; ++i) { xref[i * X + 0] = path[2 * i]; xref[i * X + 3] = path[2 * i + 1]; }
+    {
+        double dx = path[2] - path[0], dy = path[3] - path[1];
+        const double dn = std::sqrt(dx * dx + dy * dy);
+        dx = dx / dn * ds; dy = dy / dn * ds;
+        xref[1] = dx; xref[4] = dy;
+    }
+    if (closed) for (int c = 0; c < X; ++c) xref[(H - 1) * X + c] = xref[c];
+    double A[X][X] = {}, B[X][U] = {};
+    for (int i = 0; i < X; ++i) A[i][i] = 1.0;
+    A[0][1] = ds; A[1][2] = ds; A[3][4] = ds; A[4][5] = ds;
+    B[2][0] = ds; B[5][1] = ds;
+    const double qd[X] = {1.0, w_v, w_a, 1.0, w_v, w_a};
+    auto q_at = [&](size_t i, int c) { return (i == 0 || i == H - 1) ? 1.0e6 : qd[c]; };     // Qs are diagonal
+    std::vector<double> kf(H * U, 0.0), Kf(H * U * X, 0.0);
+    double Vxx[X][X] = {}, Vx[X];
+    for (int c = 0; c < X; ++c) { Vxx[c][c] = q_at(H - 1, c); Vx[c] = -q_at(H - 1, c) * xref[(H - 1) * X + c]; }
+    for (long i = (long)H - 2; i >= 0; --i) {
+        double lx[X], Qx[X], Qu[U], Qxx[X][X], Quu[U][U], Qux[U][X], VA[X][X], VB[X][U];
+        for (int c = 0; c < X; ++c) lx[c] = -q_at((size_t)i, c) * xref[(size_t)i * X + c];
+        for (int r = 0; r < X; ++r) {                          // Vxx * fx, Vxx * fu
+            for (int c = 0; c < X; ++c) { double a = 0; for (int k = 0; k < X; ++k) a += Vxx[r][k] * A[k][c]; VA[r][c] = a; }
+            for (int c = 0; c < U; ++c) { double a = 0; for (int k = 0; k < X; ++k) a += Vxx[r][k] * B[k][c]; VB[r][c] = a; }
+        }
+        for (int r = 0; r < X; ++r) { double a = 0; for (int k = 0; k < X; ++k) a += A[k][r] * Vx[k]; Qx[r] = lx[r] + a; }
+        for (int r = 0; r < U; ++r) { double a = 0; for (int k = 0; k < X; ++k) a += B[k][r] * Vx[k]; Qu[r] = a; }
+        for (int r = 0; r < X; ++r)
+            for (int c = 0; c < X; ++c) {
+                double a = 0; for (int k = 0; k < X; ++k) a += A[k][r] * VA[k][c];
+                Qxx[r][c] = (r == c ? q_at((size_t)i, r) : 0.0) + a;
+            }
+        for (int r = 0; r < U; ++r) {
+            for (int c = 0; c < U; ++c) { double a = 0; for (int k = 0; k < X; ++k) a += B[k][r] * VB[k][c]; Quu[r][c] = (r == c ? w_j : 0.0) + a; }
+            for (int c = 0; c < X; ++c) { double a = 0; for (int k = 0; k < X; ++k) a += B[k][r] * VA[k][c]; Qux[r][c] = a; }
+        }
+        const double det = Quu[0][0] * Quu[1][1] - Quu[0][1] * Quu[1][0];
+        const double W[U][U] = {{-Quu[1][1] / det, Quu[0][1] / det}, {Quu[1][0] / det, -Quu[0][0] / det}};   // -Quu^-1
+        double* k = &kf[(size_t)i * U];
+        double* K = &Kf[(size_t)i * U * X];
+        for (int r = 0; r < U; ++r) {
+            k[r] = W[r][0] * Qu[0] + W[r][1] * Qu[1];
+            for (int c = 0; c < X; ++c) K[r * X + c] = W[r][0] * Qux[0][c] + W[r][1] * Qux[1][c];
+        }
+        double Quuk[U], QuuK[U][X];
+        for (int r = 0; r < U; ++r) {
+            Quuk[r] = Quu[r][0] * k[0] + Quu[r][1] * k[1];
+            for (int c = 0; c < X; ++c) QuuK[r][c] = Quu[r][0] * K[c] + Quu[r][1] * K[X + c];
+        }
+        for (int r = 0; r < X; ++r)
+            Vx[r] = Qx[r] + (K[r] * Quuk[0] + K[X + r] * Quuk[1]) + (K[r] * Qu[0] + K[X + r] * Qu[1])
+                    + (Qux[0][r] * k[0] + Qux[1][r] * k[1]);
+        for (int r = 0; r < X; ++r)
+            for (int c = 0; c < X; ++c) {
+                const double t1 = K[r] * Qux[0][c] + K[X + r] * Qux[1][c];
+                const double t2 = K[c] * Qux[0][r] + K[X + c] * Qux[1][r];
+                Vxx[r][c] = Qxx[r][c] + (K[r] * QuuK[0][c] + K[X + r] * QuuK[1][c]) + t1 + t2;
+            }
+    }
+    double x[X];
+    for (int c = 0; c < X; ++c) x[c] = xref[c];
+    out[0] = x[0]; out[1] = x[3];
+    for (size_t i = 0; i + 1 < H; ++i) {
+        const double* k = &kf[i * U];
+        const double* K = &Kf[i * U * X];
+        double u[U], xn[X];
+        for (int r = 0; r < U; ++r) { double a = 0; for (int c = 0; c < X; ++c) a += K[r * X + c] * x[c]; u[r] = a + k[r]; }
+        for (int r = 0; r < X; ++r) { double a = 0; for (int c = 0; c < X; ++c) a += A[r][c] * x[c]; xn[r] = a + B[r][0] * u[0] + B[r][1] * u[1]; }
+        for (int c = 0; c < X; ++c) x[c] = xn[c];
+        out[2 * (i + 1)] = x[0]; out[2 * (i + 1) + 1] = x[3];
     }
     return TPLHIP_OK;
 }

@@ -75,6 +75,52 @@ def gen_prediction_geometry(pred, hull, path, ts=0, station_step_size=5.0, expan
     return out
 
 
+def _xy(a, name):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] != 2:
+        raise ValueError(f"array has incorrect shape, expected: (-1, 2), got: {a.shape}")
+    return a
+
+
+def point_in_polygon(points, polygon):
+    """tplcpp.point_in_polygon (utils.cpp:25-65, binding :780-804): one point -> bool, an array of points -> bool array."""
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    if not ((pts.ndim == 1 and pts.shape == (2,)) or (pts.ndim == 2 and pts.shape[1] == 2)):
+        raise ValueError(f"array has incorrect shape, expected: (2,) or (-1, 2), got: {pts.shape}")
+    poly = _xy(polygon, "polygon")
+    p2 = pts.reshape(-1, 2)
+    out = np.zeros(len(p2), dtype=np.uint8)
+    _capi.check(_capi.load().tplhip_point_in_polygon(p2.ctypes.data_as(_dp), len(p2), poly.ctypes.data_as(_dp), len(poly),
+                                                      out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return bool(out[0]) if pts.ndim == 1 else out.astype(bool)
+
+
+def intersect_polygons(poly0, poly1):
+    """tplcpp.intersect_polygons (utils.cpp:67-158): do two convex polygons overlap."""
+    a, b = _xy(poly0, "poly0"), _xy(poly1, "poly1")
+    out = C.c_int()
+    _capi.check(_capi.load().tplhip_intersect_polygons(a.ctypes.data_as(_dp), len(a), b.ctypes.data_as(_dp), len(b), C.byref(out)))
+    return bool(out.value)
+
+
+def convex_hull(points):
+    """tplcpp.convex_hull (utils.cpp:160-255): float64[k, 2], counter-clockwise from the lowest point."""
+    pts = _xy(points, "points")
+    out = np.empty((max(len(pts), 1), 2))
+    n = C.c_int()
+    _capi.check(_capi.load().tplhip_convex_hull(pts.ctypes.data_as(_dp), len(pts), out.ctypes.data_as(_dp), C.byref(n)))
+    return out[:n.value].copy()
+
+
+def smooth_path(path, ds, w_v=1.0, w_a=1.0, w_j=1.0, closed=False):
+    """tplcpp.smooth_path (utils.cpp:693-776): the path through an LQR smoother with jerk inputs."""
+    pts = _xy(path, "path")
+    out = np.empty_like(pts)
+    _capi.check(_capi.load().tplhip_smooth_path(pts.ctypes.data_as(_dp), len(pts), float(ds), float(w_v), float(w_a),
+                                                 float(w_j), 1 if closed else 0, out.ctypes.data_as(_dp)))
+    return out
+
+
 def lerp_cpp(vals, xs, ys, angle=False, clip_alpha=True):
     """tplcpp.lerp (utils.cpp:931-990): ``ys`` (1-D or [m, d]) sampled at the sorted ``xs``, evaluated at the 1-D
     ``vals`` -> float64[n] or float64[n, d]."""
