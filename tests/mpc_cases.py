@@ -56,9 +56,18 @@ CASES = {
 }
 
 
+def rebased(plan, t, n=80, dt=0.1):
+    """The plan as a planner would hand it over at time t: sampled every `dt` from NOW on (the time-indexed controller
+    reads sample k as "where to be k * dt from now")."""
+    ts = t + np.arange(n) * dt
+    f = lambda a: np.interp(ts, plan.time, a)
+    return NS(time=ts, s=f(plan.s), x=f(plan.x), y=f(plan.y), orientation=f(plan.orientation), curvature=f(plan.curvature),
+              velocity=f(plan.velocity), acceleration=np.zeros(n), emergency=False)
+
+
 TIME_CASES = {
-    "time_default": (dict(x=-1.5, y=0.4, yaw=0.06, v=7.0), {}, 100),
-    "time_no_dead_time": (dict(x=-1.0, y=-0.3, yaw=0.0, v=8.5, steer_dead_time=0.0, acc_dead_time=0.0),
+    "time_default": (dict(x=-1.58, y=0.3, yaw=0.05, v=7.1), {}, 100),
+    "time_no_dead_time": (dict(x=-0.95, y=-0.2, yaw=0.03, v=7.6, steer_dead_time=0.0, acc_dead_time=0.0),
                           dict(horizon=25, max_iterations=10, cog_pos=0.3), 100),
 }
 
@@ -79,7 +88,8 @@ def run(controller_factory, name, on_tick=None):
     controls, trace, extra = np.zeros((ticks, 2)), np.zeros((ticks, 4)), []
     t = 0.0
     for k in range(ticks):
-        (acc, steer), con_traj = con.update(NS(t=t, vehicle=vehicle_of(ego), trajectory=traj))
+        now = rebased(traj, t) if name in TIME_CASES else traj
+        (acc, steer), con_traj = con.update(NS(t=t, vehicle=vehicle_of(ego), trajectory=now))
         ego.control_acc, ego.control_steer = acc, steer
         for _ in range(2):
             ego.step(t, DT / 2)

@@ -12,7 +12,7 @@ import pytest
 import oracle_ilqr as OI
 import pvd_cases as cases
 from tpl_amd.planning import geometry as geo, utils as putils
-from tpl_amd.planning.path_vel_decomp import PathOptim, PathSmoothing, VelocityOptim, path_optim
+from tpl_amd.planning.path_vel_decomp import PathOptim, PathSmoothing, VelocityOptim, rampify_lateral_profile
 
 GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pvd_glue.npz"))
 
@@ -64,7 +64,7 @@ def test_ramp_functions_match_the_reference():
                                      c["v_min"], c["step"])
         assert np.allclose(got, GOLD[f"ramp_v{i}"], rtol=1e-12, atol=1e-12), i
     for i, c in enumerate(cases.rampify_lateral_cases()):
-        got = path_optim.rampify_profile(c["step"], c["horizon"], c["evasion_sharpness"], c["proj_distance"], c["path"],
+        got = rampify_lateral_profile(c["step"], c["horizon"], c["evasion_sharpness"], c["proj_distance"], c["path"],
                                          c["gap"], c["lower"], c["upper"])
         assert np.allclose(got, GOLD[f"ramp_l{i}"], rtol=1e-12, atol=1e-12), i
         assert np.all(got[:c["horizon"]] >= c["lower"] - 1e-12) and np.all(got[c["horizon"]:] == -10.0)

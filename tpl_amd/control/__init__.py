@@ -1,3 +1,3 @@
-"""The controller plugin that drives the batched iLQR solver (library/tpl/control/): HP-2's caller in tplsim."""
-from .model_predictive_controller import BaseController, ModelPredictiveController, Params  # noqa: F401
-from .model_predictive_controller_time import ModelPredictiveControllerTime  # noqa: F401
+"""The controller plugins that drive the batched iLQR solver (tpl.control's two tracking MPCs): HP-2's callers."""
+from .tracking_mpc import (BaseController, ModelPredictiveController, ModelPredictiveControllerTime, Params,  # noqa: F401
+                           TimeParams)

@@ -1,24 +1,19 @@
-"""``tpl.planning.Trajectory`` / ``BasePlanner`` (library/tpl/planning/trajectory.py, base_planner.py): what a planner
-plugin returns and the interface it implements."""
+"""What a planner plugin returns and the interface it implements (tpl.planning.Trajectory / BasePlanner)."""
 import numpy as np
+
+_SERIES = ("time", "s", "x", "y", "orientation", "curvature", "velocity", "acceleration")
 
 
 class Trajectory:
+    """Eight equally long series plus the emergency flag; a fresh one holds a single zero sample."""
 
     def __init__(self):
-        self.time = np.zeros((1,))
-        self.s = np.zeros((1,))
-        self.x = np.zeros((1,))
-        self.y = np.zeros((1,))
-        self.orientation = np.zeros((1,))
-        self.curvature = np.zeros((1,))
-        self.velocity = np.zeros((1,))
-        self.acceleration = np.zeros((1,))
+        for name in _SERIES:
+            setattr(self, name, np.zeros((1,)))
         self.emergency = False
 
 
 class BasePlanner:
-
     def __init__(self, state, params):
         pass
 
