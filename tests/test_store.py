@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 from tpl_amd import store
-from tpl_amd.planning.path_vel_decomp import path_optim
+from tpl_amd.planning.path_vel_decomp import OptimParams
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -22,7 +22,7 @@ def test_state_json_reader():
     assert st["cars"][0].uuid == "u1" and st["plain"] == {"a": 1}
     # the json file itself works too, and parameter objects of the glue take the file's values (otb.merge)
     again = store.load_state(os.path.join(HERE, "golden", "state", "state.json"))
-    p = path_optim.Params()
+    p = OptimParams()
     store.merge(p, again["path_vel_decomp_planner"].params.path_optim)
     assert p.cost_func.w_a_d == 200.0 and p.evasion_sharpness == 20.0 and p.lateral_min_gap == 2.0    # untouched default
 
