@@ -84,6 +84,31 @@ def test_tables_and_trajectories_bit_exact(S, V, A, T, obst, dt_start, request):
         assert np.array_equal(got.view(np.uint32), otrajs[r].view(np.uint32)), (r, got, otrajs[r])
 
 
+def test_single_row_axes_are_refused():
+    """One sample on an axis makes the reference's step size (max - min) / (steps - 1) a division by zero; here the
+    planner says so instead of planning on NaNs."""
+    dp = tpl_amd.DynProgLonPlanner()
+    for S, V, A in ((3, 17, 1), (9, 1, 5), (1, 4, 4)):
+        with pytest.raises(ValueError, match="s/v/a_steps >= 2"):
+            dp.reinit_buffers(sc.lon_params(S, V, A, 4))
+
+
+@pytest.mark.parametrize("S,V,A,T", [(2, 2, 2, 2), (5, 2, 3, 2), (64, 2, 2, 3), (70, 3, 2, 2)])
+def test_degenerate_grids_still_match(S, V, A, T):
+    """The smallest grids the parameters allow (two stations, two stages, two speeds, two accelerations): same
+    arithmetic, same answers -- and no launch geometry that divides by zero or reads past a row."""
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
+    inits = [sc.initial_state(0.0, 8.0, 0.0), sc.initial_state(20.0, 2.0, -1.0)]
+    dp, env, trajs, tables, otrajs, dist = _run_both(p, ep, path, occ, inits)
+    _assert_tables_equal(dp, tables, T)
+    for r, tr in enumerate(trajs):
+        got = _traj_np(tr)
+        assert np.array_equal(got.view(np.uint32), otrajs[r].view(np.uint32)), (r, got, otrajs[r])
+
+
 def test_config2_full_plan_bit_exact():
     # BASELINE configs[1]: 128x64x32 grid, 50 stages (oracle: ~1e8 action evaluations)
     S, V, A, T = sc.GRIDS["config2"]
