@@ -84,6 +84,13 @@ def test_tables_and_trajectories_bit_exact(S, V, A, T, obst, dt_start, request):
         assert np.array_equal(got.view(np.uint32), otrajs[r].view(np.uint32)), (r, got, otrajs[r])
 
 
+def test_fuzz_sample():
+    """A short sample of the randomised soak (tests/fuzz_dp.py; the long run is a tool, not a test)."""
+    import fuzz_dp
+    for seed in range(12):
+        fuzz_dp.run_case(seed)
+
+
 def test_single_row_axes_are_refused():
     """One sample on an axis makes the reference's step size (max - min) / (steps - 1) a division by zero; here the
     planner says so instead of planning on NaNs."""
