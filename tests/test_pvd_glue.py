@@ -207,3 +207,55 @@ def test_glue_on_the_hip_solvers_matches_the_reference_glue():
     po = PathOptim()
     po.update(cases.environment(0), cases.default_params("path_optim"))
     assert np.allclose(po.opt_path, GOLD["c0.optim.opt_path"], atol=1e-5)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/library/tpl"), reason="the reference checkout exists in the build container only")
+def test_the_references_own_planner_file_runs_on_these_stage_classes():
+    """INTEGRATION.md's claim, executed: tpl's path_vel_decomp_planner.py UNCHANGED, with PathSmoothing / PathOptim /
+    VelocityOptim swapped for tpl_amd's (on the CPU restatement of the solvers), reproduces the fixture its own
+    classes produced.  Runs in a subprocess with the import shims of the fixture generator."""
+    import subprocess
+    import sys
+    code = r'''
+import copy, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, ROOT)
+import make_pvd_goldens as shims
+shims.install_shims()
+sys.modules["objtoolbox"].get_obj_dict = lambda o: {k: v for k, v in vars(o).items() if not k.startswith("_")}
+sys.path.insert(0, "/root/reference/library")
+import pvd_cases as cases
+import oracle_ilqr as OI
+import tpl.planning.path_vel_decomp.path_vel_decomp_planner as rp
+from tpl_amd.planning.path_vel_decomp import PathOptim, PathSmoothing, VelocityOptim
+rp.PathSmoothing = lambda: PathSmoothing(OI.OracleOptim("ref_line_smoother_k"))
+rp.PathOptim = lambda: PathOptim(OI.OracleOptim("lateral_profile"))
+rp.VelocityOptim = lambda: VelocityOptim(OI.OracleOptim("velocity_profile_space"))
+from contextlib import contextmanager
+@contextmanager
+def lock():
+    yield
+class Shared:
+    def __setattr__(self, k, v):
+        if k == "params" and not hasattr(v, "deepcopy"):
+            v.deepcopy = lambda v=v: copy.deepcopy(v)
+        object.__setattr__(self, k, v)
+gold = np.load(os.path.join(ROOT, "tests", "golden", "pvd_glue.npz"))
+sh = Shared()
+pl = rp.PathVelDecompPlanner(sh, lock)
+sh.params.write_debug_data = True
+for kind in ("path_optim", "velocity_optim", "path_smoothing"):
+    for k, v in vars(cases.default_params(kind)).items():
+        setattr(getattr(sh.params, kind), k, v)
+for cyc in range(3):
+    tr = pl.update(cases.shared_environment(cyc))
+    rows = np.stack([tr.time, tr.s, tr.x, tr.y, tr.orientation, tr.curvature, tr.velocity, np.ravel(tr.acceleration)], axis=1)
+    want = gold[f"plan.c{cyc}.traj"]
+    err = np.max(np.abs(rows - want)) / max(1.0, np.max(np.abs(want)))
+    assert err < 1e-6, (cyc, err)
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + code], cwd=root, capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, PYTHONPATH=root, CFLAGS="-DPyArray_MoveInto=PyArray_CopyInto"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
