@@ -555,6 +555,181 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
 #endif
 }
 
+// ---- the same pass for problems with two or three states and one input (tpl's lateral and speed profile problems: what
+// its default planner solves, one problem per call, twice per cycle).  With matrices this small the lane-parallel form
+// above is all exchange and no work: three LDS round trips per stage for a dozen multiplications.  Here every lane
+// carries the whole recursion in registers -- Vxx, Vx, the stage's derivatives one stage ahead -- and a stage is one
+// straight dependent chain without a wait in it; lane 0 stores the gains.  Same operations in the same order as the
+// lane-parallel form (the dots accumulate from zero in index order, only the lower triangle of Qxx is formed and
+// mirrored), so both give the same bits.
+#ifndef TPL_ILQR_ABLATE
+#define TPL_ILQR_ABLATE 0
+#endif
+#ifndef TPL_ILQR_SMALL_NX
+#define TPL_ILQR_SMALL_NX 2
+#endif
+constexpr bool SMALL_BACKWARD = (NU == 1 && NX <= TPL_ILQR_SMALL_NX);
+
+struct SmallStage {
+    double fx[NX][NX], fu[NX], lxx[NX][NX], lux[NX], luu, lx[NX], lu, u, umax, umin;
+};
+
+__device__ __attribute__((noinline)) void riccati_backward_small(const RiccatiArgs A, LdsAS* s)
+{
+    const GlbCD FX = uni_g(A.FX), LXX = uni_g(A.LXX), FU = uni_g(A.FU), LUX = uni_g(A.LUX), LX = uni_g(A.LX),
+                LU = uni_g(A.LU), LUU = uni_g(A.LUU), U_ = uni_g(A.U_), UMAX = uni_g(A.UMAX), UMIN = uni_g(A.UMIN);
+    const GlbD KFF = uni_g(A.KFF), KFB = uni_g(A.KFB);
+    const LdsD KL = uni_l(A.KL), KBL = uni_l(A.KBL);
+    const double mu = uni_d(A.mu);
+    const int T = uni_i(A.T);
+    const bool lt = uni_i(A.lt) != 0;
+    const bool writer = threadIdx.x == 0;
+
+    double Vxx[NX][NX], Vx[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        Vx[i] = s->Vx[i];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) Vxx[i][j] = s->Vxx[i * NX + j];
+    }
+    auto fetch = [&](int t, SmallStage& g) {
+        const GlbCD fx = FX + (int64_t)t * NX * NX, lxx = LXX + (int64_t)t * NX * NX;
+        const GlbCD fu = FU + (int64_t)t * NX, lux = LUX + (int64_t)t * NX, lx = LX + (int64_t)t * NX;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            g.fu[i] = fu[i]; g.lux[i] = lux[i]; g.lx[i] = lx[i];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) { g.fx[i][j] = fx[i * NX + j]; g.lxx[i][j] = lxx[i * NX + j]; }
+        }
+        g.luu = LUU[t]; g.lu = LU[t]; g.u = U_[t]; g.umax = UMAX[t]; g.umin = UMIN[t];
+    };
+    // One stage of the recursion on the derivatives in `cur`.
+    auto stage = [&](int t, const SmallStage& cur) {
+        auto F = [&](int m, int j) { return j < NX ? cur.fx[m][j < NX ? j : 0] : cur.fu[m]; };
+        // W = Vxx [fx fu]
+        double W[NX][NXU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int j = 0; j < NXU; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < NX; ++m) acc = fma(Vxx[i][m], F(m, j), acc);
+                W[i][j] = acc;
+            }
+        // Q = L + F^T W (lower triangle of Qxx, mirrored), q = l + F^T Vx
+        double Qxx[NX][NX], Qux[NX], qx[NX];
+#pragma unroll
+        for (int hi = 0; hi < NX; ++hi)
+#pragma unroll
+            for (int lo = 0; lo <= hi; ++lo) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < NX; ++m) acc = fma(cur.fx[m][hi], W[m][lo], acc);
+                Qxx[hi][lo] = cur.lxx[hi][lo] + acc;
+                Qxx[lo][hi] = cur.lxx[lo][hi] + acc;
+            }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < NX; ++m) acc = fma(cur.fu[m], W[m][j], acc);
+            Qux[j] = cur.lux[j] + acc;
+        }
+        double quu, qu;
+        {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < NX; ++m) acc = fma(cur.fu[m], W[m][NX], acc);
+            quu = cur.luu + acc;
+        }
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < NX; ++m) acc = fma(cur.fx[m][c], Vx[m], acc);
+            qx[c] = cur.lx[c] + acc;
+        }
+        {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < NX; ++m) acc = fma(cur.fu[m], Vx[m], acc);
+            qu = cur.lu + acc;
+        }
+        // gains (solve_action optim.c:243-291) and the control-box projection (:950-963)
+        // (selects, no branches: the stage stays one basic block, so the loads of later stages can be scheduled across it)
+        double quotient = -1.0 / (quu + mu), room_up = cur.umax - cur.u, room_down = cur.umin - cur.u;
+        asm volatile("" : "+v"(quotient), "+v"(room_up), "+v"(room_down));
+        const double inv = (quu > 0.0) ? quotient : 0.0;
+        const double kd = fma(inv, qu, 0.0);
+        double K[NX];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) K[c] = fma(inv, Qux[c], 0.0);
+        const double cd = cur.u + kd;
+        const bool over = cd > cur.umax, under = cd < cur.umin;
+        const double kk = under ? room_down : (over ? room_up : kd);
+#pragma unroll
+        for (int c = 0; c < NX; ++c) K[c] = (over || under) ? 0.0 : K[c];
+        if (writer) {
+            KFF[t] = kk;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) KFB[(int64_t)t * NX + c] = K[c];
+            if (lt) {
+                KL[t] = kk;
+#pragma unroll
+                for (int c = 0; c < NX; ++c) KBL[t * NX + c] = K[c];
+            }
+        }
+        // value function (:965-984, same order of additions)
+        double nVxx[NX][NX], nVx[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double kq = fma(K[i], quu, 0.0);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const double mij = fma(K[i], Qux[j], 0.0), mji = fma(K[j], Qux[i], 0.0);
+                double v1 = mji + mij;
+                v1 = fma(kq, K[j], v1);
+                nVxx[i][j] = v1 + Qxx[i][j];
+            }
+            double v2 = fma(kq, kk, 0.0);
+            v2 = fma(K[i], qu, v2);
+            v2 = fma(Qux[i], kk, v2);
+            nVx[i] = v2 + qx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            Vx[i] = nVx[i];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) Vxx[i][j] = nVxx[i][j];
+        }
+    };
+    // The derivatives come from global memory (L2: several hundred cycles), a stage's chain is shorter than that: four
+    // stage records are kept in flight, each refilled for stage t-4 as soon as stage t has consumed it.  The main loop
+    // is one basic block (four stages, unconditional refills with the stage index clamped at 0), so the compiler
+    // counts the outstanding loads exactly; the T % 4 stages before it run one at a time.
+    SmallStage b0, b1, b2, b3;
+    int t = T - 1;
+    for (; t >= 0 && ((t + 1) & 3) != 0; --t) {
+        fetch(t, b0);
+        stage(t, b0);
+    }
+    if (t >= 3) {
+        fetch(t, b0); fetch(t - 1, b1); fetch(t - 2, b2); fetch(t - 3, b3);
+        for (; t >= 3; t -= 4) {
+            stage(t, b0);
+            fetch(max(t - 4, 0), b0);
+            stage(t - 1, b1);
+            fetch(max(t - 5, 0), b1);
+            stage(t - 2, b2);
+            fetch(max(t - 6, 0), b2);
+            stage(t - 3, b3);
+            fetch(max(t - 7, 0), b3);
+        }
+    }
+    lds_sync();
+}
+
 // The parameter record through the constant address space, field by field (typed, so the copy
 // ends up in registers and not in a stack slot).
 __device__ __forceinline__ void load_params_uniform(Params& dst, const Params* src_generic)
@@ -977,7 +1152,10 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
 #else
                 ra.stamp_acc = nullptr;
 #endif
-                riccati_backward(ra, (LdsAS*)(unsigned)(unsigned long long)&s);
+#if TPL_ILQR_ABLATE != 1                    /* diagnostic builds: 1 = no backward pass, 2 = no rollouts */
+                if constexpr (SMALL_BACKWARD) riccati_backward_small(ra, (LdsAS*)(unsigned)(unsigned long long)&s);
+                else riccati_backward(ra, (LdsAS*)(unsigned)(unsigned long long)&s);
+#endif
             } else {
                 // ---- first-order backward pass, optim.c:1044-1073
                 for (int t = T - 1; t >= 0; --t) {
@@ -1029,8 +1207,10 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                     else if (int_type == HEUN) line_search_rollouts<L, S2, HEUN>(ra, sl);
                     else line_search_rollouts<L, S2, RK4>(ra, sl);
                 };
+#if TPL_ILQR_ABLATE != 2
                 if (lt) { if (second_order) roll(std::true_type{}, std::true_type{}); else roll(std::true_type{}, std::false_type{}); }
                 else { if (second_order) roll(std::false_type{}, std::true_type{}); else roll(std::false_type{}, std::false_type{}); }
+#endif
             }
             __syncthreads();
             STAMP(11);
