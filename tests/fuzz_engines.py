@@ -2,7 +2,7 @@
 """Randomised parity soak of the three other DP-family engines against their CPU restatements: N random scenes
 (straight / arc reference lines with random radius and heading, 0..14 predicted objects, grid sizes, dilation, stage
 length) -> occupancy image, Frenet occupancy and distance map bit for bit; the lateral lattice (values 1e-5, discrete
-outcomes and the final trajectory identical); the (s,ds,l) tables and trajectory bit for bit.
+outcomes identical, the final trajectory to 1e-12); the (s,ds,l) tables and trajectory bit for bit.
 
     python tests/fuzz_engines.py [scenes] [first seed]"""
 import os
@@ -72,7 +72,9 @@ def run_scene(seed):
     got = pl.nodes()
     assert np.allclose(got[..., 1:, :2], nodes[..., 1:, :2], rtol=1e-5, atol=1e-6), f"seed {seed}: lattice values"
     assert np.array_equal(got[..., 2], nodes[..., 2]), f"seed {seed}: collision stations"
-    assert pl.best == best and np.array_equal(traj.as_numpy(), pts), f"seed {seed}: selected lattice path"
+    assert pl.best == best, f"seed {seed}: selected lattice path"
+    # the final trajectory is host arithmetic on both sides, but of two compilers (sin / cos vs sincos): last-bit differences
+    assert np.allclose(traj.as_numpy(), pts, rtol=0, atol=1e-12), f"seed {seed}: lattice trajectory"
 
     # (s, ds, l) planner
     qp = tpl_amd.DynProgLatLonPlannerParams()

@@ -592,16 +592,23 @@ __device__ __attribute__((noinline)) void riccati_backward_small(const RiccatiAr
 #pragma unroll
         for (int j = 0; j < NX; ++j) Vxx[i][j] = s->Vxx[i * NX + j];
     }
+    // Addresses: a lone wavefront pays four cycles for a scalar add as for a vector one, and ten arrays walked by
+    // 64-bit scalar pointers cost two dozen of them per stage.  Three byte offsets in vector registers (one per row
+    // width), added to the arrays' scalar bases by the load instruction itself, cost three.
+    typedef const __attribute__((address_space(1))) char* GlbCC;
+    unsigned lane_zero = 0;
+    asm volatile("" : "+v"(lane_zero));                      // a vector register the compiler cannot fold away
+    auto at = [&](GlbCD base, unsigned byte_off, int k) { return *(GlbCD)((GlbCC)base + byte_off + 8u * (unsigned)k); };
     auto fetch = [&](int t, SmallStage& g) {
-        const GlbCD fx = FX + (int64_t)t * NX * NX, lxx = LXX + (int64_t)t * NX * NX;
-        const GlbCD fu = FU + (int64_t)t * NX, lux = LUX + (int64_t)t * NX, lx = LX + (int64_t)t * NX;
+        const unsigned o1 = lane_zero + (unsigned)t * 8u, o2 = lane_zero + (unsigned)t * (8u * NX),
+                       o4 = lane_zero + (unsigned)t * (8u * NX * NX);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            g.fu[i] = fu[i]; g.lux[i] = lux[i]; g.lx[i] = lx[i];
+            g.fu[i] = at(FU, o2, i); g.lux[i] = at(LUX, o2, i); g.lx[i] = at(LX, o2, i);
 #pragma unroll
-            for (int j = 0; j < NX; ++j) { g.fx[i][j] = fx[i * NX + j]; g.lxx[i][j] = lxx[i * NX + j]; }
+            for (int j = 0; j < NX; ++j) { g.fx[i][j] = at(FX, o4, i * NX + j); g.lxx[i][j] = at(LXX, o4, i * NX + j); }
         }
-        g.luu = LUU[t]; g.lu = LU[t]; g.u = U_[t]; g.umax = UMAX[t]; g.umin = UMIN[t];
+        g.luu = at(LUU, o1, 0); g.lu = at(LU, o1, 0); g.u = at(U_, o1, 0); g.umax = at(UMAX, o1, 0); g.umin = at(UMIN, o1, 0);
     };
     // One stage of the recursion on the derivatives in `cur`.
     auto stage = [&](int t, const SmallStage& cur) {
