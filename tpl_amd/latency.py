@@ -28,7 +28,7 @@ def mpc_closed_loop(device=0, ticks=1000, horizon=20):
             "mean_iterations": float(np.mean(opt.iterations)), "ticks": int(len(lat)),
             "final_lateral_error_m": float(abs(trace[-1, 1])), "final_speed_mps": float(trace[-1, 3]),
             "what": f"Optim.update() of trajectory_tracking_mpc, batch 1, N={horizon}, HEUN, <=20 iterations, inside the "
-                    "closed loop of tpl_amd/minisim.py (ego model with 0.1 s dead time, controller shim, straight 8 m/s plan); "
+                    "closed loop of tpl_amd/minisim.py (ego model with 0.1 s dead time under the ModelPredictiveController plugin, straight 8 m/s plan); "
                     "host mirrors in and out (H2D + kernel + D2H)"}
 
 
