@@ -120,8 +120,15 @@ def ilqr_cpu_baseline(x0, horizon, budget_s, workload="mpc"):
     lib.ilqo_reset_and_update_many(hs, n, px, reps, 0)
     el = time.perf_counter() - t0
     iters = opts[0].iterations
+    # and on ONE core (SURVEY 8d asks for both): the first 32 problems, one thread
+    m = min(32, n)
+    hs1 = (C.c_void_p * m)(*[r._h for r in opts[:m]])
+    t0 = time.perf_counter()
+    lib.ilqo_reset_and_update_many(hs1, m, px, 1, 1)
+    el1 = time.perf_counter() - t0
     return {"value": reps * iters / el, "unit": f"batched iLQR iterations/s ({n}-problem batch)",
             "problem_iterations_per_s": reps * n * iters / el, "cores": cores, "kind": "port",
+            "one_core_problem_iterations_per_s": m * iters / el1,
             "sample": f"{reps} x the same {n} problems x {iters} iterations (oracle/ilqr_oracle.cpp, OpenMP over "
                       f"problems, {'-O3 -march=native build of this host' if native else '-O2 checker build'})"}
 
