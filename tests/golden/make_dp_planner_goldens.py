@@ -96,9 +96,17 @@ def _lock():
     yield
 
 
-def run_drive(make_planner, drive, cycles, closed_loop):
+def set_dead_time(pl, seconds):
+    """What a user does in tpl's GUI: the planner plans from `seconds` ahead, the environment shifts its slices."""
+    pl.shared.params.planner.dead_time = seconds
+    pl.shared.params.env.dead_time = seconds
+
+
+def run_drive(make_planner, drive, cycles, closed_loop, dead_time=0.0):
     import dp_planner_cases as cases
     pl = make_planner()
+    if dead_time:
+        set_dead_time(pl, dead_time)
     rows, meta = [], []
     follow = None
     for k in range(cycles):
@@ -114,9 +122,11 @@ def run_drive(make_planner, drive, cycles, closed_loop):
     return rows, np.array(meta), pl
 
 
-def run_drive_ll(make_planner, drive, cycles):
+def run_drive_ll(make_planner, drive, cycles, dead_time=0.0):
     import dp_planner_cases as cases
     pl = make_planner()
+    if dead_time:
+        set_dead_time(pl, dead_time)
     rows, meta = [], []
     for k in range(cycles):
         traj = pl.update(drive.cycle(k, man_time=(k >= 4)))
@@ -134,9 +144,10 @@ def main():
     import dp_planner_cases as cases
     from tpl.planning.dyn_prog.poly_lat_dp_lon_planner import PolyLatDpLonPlanner
     out = {}
-    for name, kw, cycles, closed in (("nominal", dict(v_ego=9.0), 14, False), ("closed_loop", dict(v_ego=7.0), 14, True),
-                                     ("manual", dict(v_ego=11.0, automated=False), 12, False)):
-        rows, meta, pl = run_drive(lambda: PolyLatDpLonPlanner(_Store(), _lock), cases.Drive(**kw), cycles, closed)
+    for name, kw, cycles, closed, dead in (("nominal", dict(v_ego=9.0), 14, False, 0.0), ("closed_loop", dict(v_ego=7.0), 14, True, 0.0),
+                                           ("manual", dict(v_ego=11.0, automated=False), 12, False, 0.0),
+                                           ("dead_time", dict(v_ego=8.0), 12, False, 0.25)):
+        rows, meta, pl = run_drive(lambda: PolyLatDpLonPlanner(_Store(), _lock), cases.Drive(**kw), cycles, closed, dead)
         for k, r in enumerate(rows):
             out[f"{name}.traj_{k}"] = r
         out[f"{name}.meta"] = meta
@@ -145,8 +156,9 @@ def main():
         out[f"{name}.occ"] = pl.dp_env.cpp_env.get_occ_map()
         print(name, [len(r) for r in rows], "replans at", sorted(set(np.round(meta[:, 1], 2))))
     from tpl.planning.dyn_prog.dp_lat_lon_planner import DpLatLonPlanner
-    for name, kw, cycles in (("ll_nominal", dict(v_ego=9.0), 12), ("ll_manual", dict(v_ego=6.0, automated=False), 14)):
-        rows, meta, pl = run_drive_ll(lambda: DpLatLonPlanner(_Store(), _lock), cases.Drive(**kw), cycles)
+    for name, kw, cycles, dead in (("ll_nominal", dict(v_ego=9.0), 12, 0.0), ("ll_manual", dict(v_ego=6.0, automated=False), 14, 0.0),
+                                   ("ll_dead_time", dict(v_ego=8.0), 12, 0.25)):
+        rows, meta, pl = run_drive_ll(lambda: DpLatLonPlanner(_Store(), _lock), cases.Drive(**kw), cycles, dead)
         for k, r in enumerate(rows):
             out[f"{name}.traj_{k}"] = r
         out[f"{name}.meta"] = meta
