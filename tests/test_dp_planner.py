@@ -19,7 +19,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = np.load(os.path.join(HERE, "golden", "dp_planner.npz"))
 DRIVES = {"nominal": (dict(v_ego=9.0), 14, False, 0.0), "closed_loop": (dict(v_ego=7.0), 14, True, 0.0),
           "manual": (dict(v_ego=11.0, automated=False), 12, False, 0.0),
-          "dead_time": (dict(v_ego=8.0), 12, False, 0.25)}      # plans start 0.25 s ahead, bridged by the previous trajectory
+          "dead_time": (dict(v_ego=8.0), 12, False, 0.25),      # plans start 0.25 s ahead, bridged by the previous trajectory
+          # an intersecting road with traffic (stop line flags, crossing-traffic sweep by ego speed and object
+          # acceleration), a reset request at cycle 5, the vehicle found 3 m off its plan at cycle 9
+          "crossing_reset_jump": (dict(v_ego=12.0, crossing=True, reset_at=5, jump_at=9), 13, False, 0.0)}
 
 
 @contextmanager
@@ -80,7 +83,8 @@ def test_hip_engines_under_the_plugin(name):
 
 
 LL_DRIVES = {"ll_nominal": (dict(v_ego=9.0), 12, 0.0), "ll_manual": (dict(v_ego=6.0, automated=False), 14, 0.0),
-             "ll_dead_time": (dict(v_ego=8.0), 12, 0.25)}
+             "ll_dead_time": (dict(v_ego=8.0), 12, 0.25),
+             "ll_crossing_reset_jump": (dict(v_ego=12.0, crossing=True, reset_at=5, jump_at=9), 13, 0.0)}
 
 
 def _run_ll(name, engines, rtol, atol):
@@ -111,7 +115,9 @@ def test_lat_lon_plugin_logic_matches_the_reference_class(name):
     import oracle_tplcpp
     pl = _run_ll(name, oracle_tplcpp.module(), rtol=0.0, atol=1e-9)
     dbg = pl.shared.debug.planner
-    assert dbg.traj_dp.shape[1] == 9 and dbg.traj_smooth_cart.shape[1] == 8 and dbg.reinit_msg == ""
+    assert dbg.traj_dp.shape[1] == 9 and dbg.traj_smooth_cart.shape[1] == 8
+    # the drive with the localisation jump went through the "too far from the plan" restart and says so
+    assert dbg.reinit_msg.startswith("Warning: Planner reinit") == ("jump" in name)
 
 
 @pytest.mark.gpu

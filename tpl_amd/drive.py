@@ -55,9 +55,13 @@ class Drive:
     """A vehicle following the road at `v_ego`; the local map window starts `behind` metres behind it and moves in
     whole reference steps.  Objects: a slow car ahead on the right edge, a leader on the lane centre, a parked car."""
 
-    def __init__(self, v_ego=9.0, automated=True):
+    def __init__(self, v_ego=9.0, automated=True, crossing=False, reset_at=None, jump_at=None):
+        """crossing: an intersecting road 70 m ahead with two cars on it (one accelerating) and its stop line on the
+        map; reset_at: cycle from which the environment's reset counter is one higher; jump_at: cycle at which the
+        vehicle is found 3 m beside where it should be (a localisation jump)."""
         self.v_ego = v_ego
         self.automated = automated
+        self.crossing, self.reset_at, self.jump_at = crossing, reset_at, jump_at
         self.s_ego = 30.0
         self.idx_prev = None
         self.t = 100.0
@@ -85,10 +89,31 @@ class Drive:
                  width=1.9, wheel_base=3.16, rear_axis_to_front=3.9, rear_axis_to_rear=1.0, automated=self.automated)
         if follow is not None:
             veh.x, veh.y, veh.phi, veh.v, veh.a = follow
+        if self.jump_at is not None and k == self.jump_at:
+            veh.x -= np.sin(h) * 3.0
+            veh.y += np.cos(h) * 3.0
         local_map = NS(uuid="map-local", name="local_map", path=path, steps_ref=n, step_size_ref=STEP, d_left=d_left,
                        d_right=d_right, shift_idx_start_ref=shift, intersection_paths=[])
         behind = NS(uuid="map-behind", name="local_map_behind", path=path.copy())
         objs = []
+        if self.crossing:
+            # a road crossing ours at right angles 100 m (absolute) along it; its stop line 8 m before the crossing
+            s_x = 100.0 - idx0 * STEP
+            if 12.0 < s_x < n * STEP - 30.0:
+                centre, hx = frenet(path, s_x, 0.0)
+                along = np.array([-np.sin(hx), np.cos(hx)])
+                d = np.arange(-60.0, 60.0, STEP)
+                cross = np.zeros((len(d), 6))
+                cross[:, :2] = centre + d[:, None] * along
+                cross[:, 2], cross[:, 3], cross[:, 5] = hx + np.pi / 2, d + 60.0, 13.9
+                seg = NS(uuid="map-cross", name="crossing", path=cross)
+                stop_pos = frenet(path, s_x - 8.0, 0.0)[0]
+                from .planning.geometry import project
+                local_map.intersection_paths = [NS(stop_pos=stop_pos, stop_proj=project(path[:, :2], stop_pos), map_segment=seg)]
+                for (d0, v, acc) in ((-40.0 + 0.0, 6.0, 0.0), (-25.0, 3.0, 1.5)):
+                    sc = 60.0 + d0 + v * k * DT
+                    objs.append(NS(hull=box(cross, sc, 0.0), stationary=False, a=acc, v=v,
+                                   predictions=[NS(uuid_assoc_map="map-cross", states=prediction(cross, sc, 0.0, v))]))
         for (s_abs0, d, v, stationary, acc) in ((95.0, -2.2, 2.0, False, 0.0), (130.0, 0.1, 6.0, False, None),
                                                (70.0, 2.9, 0.0, True, 0.0)):
             s_obj = s_abs0 + v * k * DT - idx0 * STEP
@@ -97,7 +122,7 @@ class Drive:
             objs.append(NS(hull=box(path, s_obj, d), stationary=stationary, a=acc, v=v,
                            predictions=[NS(uuid_assoc_map="map-behind", states=prediction(path, s_obj, d, v)),
                                         NS(uuid_assoc_map="map-unknown", states=prediction(path, s_obj, d, v))]))
-        sh = NS(t=t, reset_counter=1, vehicle_state=veh, local_map=local_map, local_map_behind=behind, selected_map=None,
+        sh = NS(t=t, reset_counter=2 if (self.reset_at is not None and k >= self.reset_at) else 1, vehicle_state=veh, local_map=local_map, local_map_behind=behind, selected_map=None,
                 tracks=[], predicted=objs,
                 man_time_cons=[(frenet(path, s_loc + 60.0, 0.0)[0], t + 6.0, t + 30.0)] if man_time else [])
         sh.lock = self._nolock
