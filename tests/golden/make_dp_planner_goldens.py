@@ -147,7 +147,8 @@ def main():
     for name, kw, cycles, closed, dead in (("nominal", dict(v_ego=9.0), 14, False, 0.0), ("closed_loop", dict(v_ego=7.0), 14, True, 0.0),
                                            ("manual", dict(v_ego=11.0, automated=False), 12, False, 0.0),
                                            ("dead_time", dict(v_ego=8.0), 12, False, 0.25),
-                                           ("crossing_reset_jump", dict(v_ego=12.0, crossing=True, reset_at=5, jump_at=9), 13, False, 0.0)):
+                                           ("crossing_reset_jump", dict(v_ego=12.0, crossing=True, reset_at=5, jump_at=9), 13, False, 0.0),
+                                           ("blocked", dict(v_ego=9.0, blocked=True), 16, False, 0.0)):
         rows, meta, pl = run_drive(lambda: PolyLatDpLonPlanner(_Store(), _lock), cases.Drive(**kw), cycles, closed, dead)
         for k, r in enumerate(rows):
             out[f"{name}.traj_{k}"] = r
@@ -159,7 +160,8 @@ def main():
     from tpl.planning.dyn_prog.dp_lat_lon_planner import DpLatLonPlanner
     for name, kw, cycles, dead in (("ll_nominal", dict(v_ego=9.0), 12, 0.0), ("ll_manual", dict(v_ego=6.0, automated=False), 14, 0.0),
                                    ("ll_dead_time", dict(v_ego=8.0), 12, 0.25),
-                                   ("ll_crossing_reset_jump", dict(v_ego=12.0, crossing=True, reset_at=5, jump_at=9), 13, 0.0)):
+                                   ("ll_crossing_reset_jump", dict(v_ego=12.0, crossing=True, reset_at=5, jump_at=9), 13, 0.0),
+                                   ("ll_blocked", dict(v_ego=9.0, blocked=True), 6, 0.0)):
         rows, meta, pl = run_drive_ll(lambda: DpLatLonPlanner(_Store(), _lock), cases.Drive(**kw), cycles, dead)
         for k, r in enumerate(rows):
             out[f"{name}.traj_{k}"] = r

@@ -22,7 +22,9 @@ DRIVES = {"nominal": (dict(v_ego=9.0), 14, False, 0.0), "closed_loop": (dict(v_e
           "dead_time": (dict(v_ego=8.0), 12, False, 0.25),      # plans start 0.25 s ahead, bridged by the previous trajectory
           # an intersecting road with traffic (stop line flags, crossing-traffic sweep by ego speed and object
           # acceleration), a reset request at cycle 5, the vehicle found 3 m off its plan at cycle 9
-          "crossing_reset_jump": (dict(v_ego=12.0, crossing=True, reset_at=5, jump_at=9), 13, False, 0.0)}
+          "crossing_reset_jump": (dict(v_ego=12.0, crossing=True, reset_at=5, jump_at=9), 13, False, 0.0),
+          # no valid plan for more than ten cycles: the planner declares an emergency (no trajectory) and restarts
+          "blocked": (dict(v_ego=9.0, blocked=True), 16, False, 0.0)}
 
 
 @contextmanager
@@ -84,7 +86,8 @@ def test_hip_engines_under_the_plugin(name):
 
 LL_DRIVES = {"ll_nominal": (dict(v_ego=9.0), 12, 0.0), "ll_manual": (dict(v_ego=6.0, automated=False), 14, 0.0),
              "ll_dead_time": (dict(v_ego=8.0), 12, 0.25),
-             "ll_crossing_reset_jump": (dict(v_ego=12.0, crossing=True, reset_at=5, jump_at=9), 13, 0.0)}
+             "ll_crossing_reset_jump": (dict(v_ego=12.0, crossing=True, reset_at=5, jump_at=9), 13, 0.0),
+             "ll_blocked": (dict(v_ego=9.0, blocked=True), 6, 0.0)}
 
 
 def _run_ll(name, engines, rtol, atol):

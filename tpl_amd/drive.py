@@ -55,13 +55,14 @@ class Drive:
     """A vehicle following the road at `v_ego`; the local map window starts `behind` metres behind it and moves in
     whole reference steps.  Objects: a slow car ahead on the right edge, a leader on the lane centre, a parked car."""
 
-    def __init__(self, v_ego=9.0, automated=True, crossing=False, reset_at=None, jump_at=None):
+    def __init__(self, v_ego=9.0, automated=True, crossing=False, reset_at=None, jump_at=None, blocked=False):
         """crossing: an intersecting road 70 m ahead with two cars on it (one accelerating) and its stop line on the
         map; reset_at: cycle from which the environment's reset counter is one higher; jump_at: cycle at which the
         vehicle is found 3 m beside where it should be (a localisation jump)."""
         self.v_ego = v_ego
         self.automated = automated
         self.crossing, self.reset_at, self.jump_at = crossing, reset_at, jump_at
+        self.blocked = blocked              # a standing obstacle across the whole lane 22 m ahead: no valid plan exists
         self.s_ego = 30.0
         self.idx_prev = None
         self.t = 100.0
@@ -96,6 +97,10 @@ class Drive:
                        d_right=d_right, shift_idx_start_ref=shift, intersection_paths=[])
         behind = NS(uuid="map-behind", name="local_map_behind", path=path.copy())
         objs = []
+        if self.blocked:
+            wall = box(path, s_loc + 22.0, 0.0, length=3.0, width=9.0)
+            objs.append(NS(hull=wall, stationary=True, a=0.0, v=0.0,
+                           predictions=[NS(uuid_assoc_map="map-behind", states=prediction(path, s_loc + 22.0, 0.0, 0.0))]))
         if self.crossing:
             # a road crossing ours at right angles 100 m (absolute) along it; its stop line 8 m before the crossing
             s_x = 100.0 - idx0 * STEP
