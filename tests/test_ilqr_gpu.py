@@ -230,3 +230,37 @@ def test_frozen_prefix_stays_frozen():
     assert np.array_equal(np.asarray(opt.x[:5]), x_before[:5]) and np.array_equal(np.asarray(opt.u[:4]), u_before[:4])
     assert np.isfinite(float(opt.traj_costs)) and float(opt.traj_costs) <= j_before * (1 + 1e-12)
     assert not np.array_equal(np.asarray(opt.x[6:]), x_before[6:])
+
+
+@pytest.mark.parametrize("name", ["lateral", "velocity_space"])
+def test_both_backward_pass_forms_pass_the_goldens_and_agree_bit_for_bit(name, tmp_path):
+    """Two-state problems ship with the register-resident backward pass (riccati_backward_small); the lane-parallel
+    form every other problem uses is built here for the same problem (-DTPL_ILQR_SMALL_NX=0, hipcc on the box):
+    both pass the reference's golden sequence, and their results are the same bits."""
+    import shutil
+    import subprocess
+    from tpl_amd.optim import optimizers as o, solver
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not shutil.which(hipcc) and not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    model, _, kw, _ = cases.CASES[name]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "tpl_amd", "models", f"{model}.inc")
+    if not os.path.exists(inc):
+        pytest.skip("generated model header not in this tree")
+    so = str(tmp_path / f"libilqr_{model}_lane_parallel.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+                           "-fno-fast-math", "-ffp-contract=off", "-DTPL_ILQR_SMALL_NX=0", f'-DTPL_MODEL_INC="{inc}"',
+                           "-I", os.path.join(root, "include"), "-o", so,
+                           os.path.join(root, "tpl_amd", "csrc", "ilqr", "ilqr_model.hip")], timeout=600)
+    cfg = getattr(o, "config_" + model)()
+    g = np.load(os.path.join(GOLDEN, f"ilqr_{name}.npz"))
+    results = []
+    for make in (_factory(model), solver.factory(so, cfg.param_defaults)):
+        opt = make()
+        cases.apply_inputs(opt, g)
+        snaps = cases.run_sequence(opt, int(g["in.shift"]))
+        assert not cases.compare(snaps, g), "golden sequence"
+        results.append([np.array(getattr(opt, f)) for f in ("x", "u", "k", "K", "lagrange_multiplier")])
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
