@@ -283,7 +283,7 @@ template <typename T>
 int ensure_capacity(T** ptr, size_t* cap, size_t need, const char* what)
 {
     if (need <= *cap && *ptr) return TPLHIP_OK;
-    hipFree(*ptr);
+    (void)hipFree(*ptr);
     *ptr = nullptr; *cap = 0;
     const size_t n = std::max<size_t>(need, 1);
     HIP_TRY(hipMalloc(ptr, n * sizeof(T)), what);
@@ -473,7 +473,7 @@ int tplhip_dp_env_get_dist(tplhip_dp_env* env, float t, float s, float l, float*
     HIP_TRY(hipMalloc(&d, sizeof(float)), "allocation failed");
     hipLaunchKernelGGL(k_get_dist, dim3(1), dim3(1), 0, nullptr, d, env->d_occ, t, s, l, env->params);
     hipError_t e = hipMemcpy(out, d, sizeof(float), hipMemcpyDeviceToHost);
-    hipFree(d);
+    (void)hipFree(d);
     HIP_TRY(e, "reading the distance field failed");
     return TPLHIP_OK;
 }

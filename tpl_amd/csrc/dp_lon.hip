@@ -1210,14 +1210,14 @@ int pick_device(int device)
 
 void free_planner_buffers(tplhip_dp_lon* h)
 {
-    hipFree(h->d_table_set[0]); hipFree(h->d_table_set[1]);
+    (void)hipFree(h->d_table_set[0]); (void)hipFree(h->d_table_set[1]);
     h->d_table_set[0] = h->d_table_set[1] = nullptr; h->d_tables = nullptr;
     h->overlap = false; h->fwd_pending[0] = h->fwd_pending[1] = false;
-    hipFree(h->d_acts);      h->d_acts = nullptr;
-    hipFree(h->d_path);      h->d_path = nullptr;
-    hipFree(h->d_pre_vmax);  h->d_pre_vmax = nullptr;
-    hipFree(h->d_pre_sdist); h->d_pre_sdist = nullptr;
-    hipFree(h->d_pre_prog);  h->d_pre_prog = nullptr;
+    (void)hipFree(h->d_acts);      h->d_acts = nullptr;
+    (void)hipFree(h->d_path);      h->d_path = nullptr;
+    (void)hipFree(h->d_pre_vmax);  h->d_pre_vmax = nullptr;
+    (void)hipFree(h->d_pre_sdist); h->d_pre_sdist = nullptr;
+    (void)hipFree(h->d_pre_prog);  h->d_pre_prog = nullptr;
     h->tables_valid = false;
 }
 
@@ -1233,7 +1233,7 @@ int ensure_rollouts(tplhip_dp_lon* h, int n)
 {
     const int T = h->params.t_steps;
     if (n <= h->cap_rollouts && h->d_trajs) return TPLHIP_OK;
-    hipFree(h->d_inits); hipFree(h->d_trajs);
+    (void)hipFree(h->d_inits); (void)hipFree(h->d_trajs);
     h->d_inits = nullptr; h->d_trajs = nullptr; h->cap_rollouts = 0;
     HIP_TRY(hipMalloc(&h->d_inits, sizeof(TplLonState) * (size_t)n), "rollout init allocation failed");
     HIP_TRY(hipMalloc(&h->d_trajs, sizeof(TplLonState) * (size_t)n * T), "trajectory allocation failed");
@@ -1524,7 +1524,7 @@ void try_enable_overlap(tplhip_dp_lon* h, tplhip_dp_env* env)
     if (h->dist_fwd_cap < dist_elems) {
         if (hipStreamSynchronize(h->fwd_stream) != hipSuccess) return;
         for (int i = 0; i < 2; ++i) {
-            hipFree(h->d_dist_fwd[i]); h->d_dist_fwd[i] = nullptr;
+            (void)hipFree(h->d_dist_fwd[i]); h->d_dist_fwd[i] = nullptr;
             if (hipMalloc(&h->d_dist_fwd[i], sizeof(float) * dist_elems) != hipSuccess) { (void)hipGetLastError(); h->dist_fwd_cap = 0; return; }
         }
         h->dist_fwd_cap = dist_elems;
@@ -1636,14 +1636,14 @@ int tplhip_dp_env_create(int device, tplhip_dp_env** out)
 int tplhip_dp_env_destroy(tplhip_dp_env* env)
 {
     if (!env) return TPLHIP_OK;
-    hipSetDevice(env->device);
-    hipFree(env->d_occ);
-    hipFree(env->d_dist);
-    hipFree(env->d_cart);
-    hipFree(env->d_vtx);
-    hipFree(env->d_frames);
-    hipFree(env->d_semantic);
-    hipFree(env->d_dist_lon);
+    (void)hipSetDevice(env->device);
+    (void)hipFree(env->d_occ);
+    (void)hipFree(env->d_dist);
+    (void)hipFree(env->d_cart);
+    (void)hipFree(env->d_vtx);
+    (void)hipFree(env->d_frames);
+    (void)hipFree(env->d_semantic);
+    (void)hipFree(env->d_dist_lon);
     delete env;
     return TPLHIP_OK;
 }
@@ -1660,7 +1660,7 @@ int tplhip_dp_env_reinit(tplhip_dp_env* env, TplDpEnvParams* ps)
     env->params = *ps;
     env->have_params = true;
     if (!full) return TPLHIP_OK;
-    hipFree(env->d_occ); hipFree(env->d_dist); hipFree(env->d_dist_lon); hipFree(env->d_frames);
+    (void)hipFree(env->d_occ); (void)hipFree(env->d_dist); (void)hipFree(env->d_dist_lon); (void)hipFree(env->d_frames);
     env->d_occ = nullptr; env->d_dist = nullptr; env->d_dist_lon = nullptr; env->d_frames = nullptr;
     const size_t n_occ = (size_t)ps->l_steps * ps->s_steps * ps->t_steps;
     const size_t n_dist = (size_t)ps->t_steps * ps->s_steps;
@@ -1731,23 +1731,23 @@ int tplhip_dp_lon_create(int device, tplhip_dp_lon** out)
 int tplhip_dp_lon_destroy(tplhip_dp_lon* h)
 {
     if (!h) return TPLHIP_OK;
-    hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->fwd_stream) { hipStreamSynchronize(h->fwd_stream); hipStreamDestroy(h->fwd_stream); }
-    if (h->ev_swept) hipEventDestroy(h->ev_swept);
-    for (int i = 0; i < 2; ++i) { if (h->ev_fwd[i]) hipEventDestroy(h->ev_fwd[i]); hipFree(h->d_dist_fwd[i]); }
-    for (auto& ev : h->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->fwd_stream) { (void)hipStreamSynchronize(h->fwd_stream); (void)hipStreamDestroy(h->fwd_stream); }
+    if (h->ev_swept) (void)hipEventDestroy(h->ev_swept);
+    for (int i = 0; i < 2; ++i) { if (h->ev_fwd[i]) (void)hipEventDestroy(h->ev_fwd[i]); (void)hipFree(h->d_dist_fwd[i]); }
+    for (auto& ev : h->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     free_planner_buffers(h);
     free_scenarios_fwd(h);
-    hipFree(h->d_inits);
-    hipFree(h->d_trajs);
-    hipFree(h->d_reeval);
-    hipFree(h->d_flag);
+    (void)hipFree(h->d_inits);
+    (void)hipFree(h->d_trajs);
+    (void)hipFree(h->d_reeval);
+    (void)hipFree(h->d_flag);
     for (int i = 0; i < 2; ++i) {
-        if (h->h_stage[i]) hipHostFree(h->h_stage[i]);
-        if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]);
+        if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
+        if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
     }
-    if (h->stream) hipStreamDestroy(h->stream);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return TPLHIP_OK;
 }
@@ -1786,7 +1786,7 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
 
     if (resize) {
         free_planner_buffers(h);
-        hipFree(h->d_inits); hipFree(h->d_trajs);
+        (void)hipFree(h->d_inits); (void)hipFree(h->d_trajs);
         h->d_inits = nullptr; h->d_trajs = nullptr; h->cap_rollouts = 0;
         h->n_rollouts = 0; h->path_bounded = false;          // nothing uploaded any more
         h->stage_busy[0] = h->stage_busy[1] = false;
@@ -2030,7 +2030,7 @@ int tplhip_dp_lon_stage_download(tplhip_dp_lon* h, int slot)
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     const size_t n = (size_t)h->n_rollouts * h->params.t_steps;
     if (n > h->stage_cap[slot]) {
-        if (h->h_stage[slot]) hipHostFree(h->h_stage[slot]);
+        if (h->h_stage[slot]) (void)hipHostFree(h->h_stage[slot]);
         h->h_stage[slot] = nullptr; h->stage_cap[slot] = 0;
         HIP_TRY(hipHostMalloc(&h->h_stage[slot], sizeof(TplLonState) * n, hipHostMallocDefault), "pinned buffer allocation failed");
         h->stage_cap[slot] = n;
@@ -2094,7 +2094,7 @@ int tplhip_dp_lon_reeval(tplhip_dp_lon* h, const TplLonState* traj, int len, con
         return tplhip_fail(TPLHIP_ESTATE, "trajectory size does not match t_steps");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     if (h->cap_reeval < len) {
-        hipFree(h->d_reeval); h->d_reeval = nullptr; h->cap_reeval = 0;
+        (void)hipFree(h->d_reeval); h->d_reeval = nullptr; h->cap_reeval = 0;
         HIP_TRY(hipMalloc(&h->d_reeval, sizeof(TplLonState) * (size_t)len), "trajectory allocation failed");
         h->cap_reeval = len;
     }
@@ -2154,7 +2154,7 @@ int tplhip_dp_lon_timing_enable(tplhip_dp_lon* h, int enable)
     if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
-    for (auto& ev : h->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    for (auto& ev : h->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     h->events.clear();
     h->sweep_ms = 0.0;
     h->sweep_launches = 0;
@@ -2171,8 +2171,8 @@ int tplhip_dp_lon_timing_get(tplhip_dp_lon* h, double* sweep_ms, int64_t* sweep_
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second), "event query failed");
         h->sweep_ms += (double)ms;
-        hipEventDestroy(ev.first);
-        hipEventDestroy(ev.second);
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
     }
     h->events.clear();
     *sweep_ms = h->sweep_ms;
@@ -2188,9 +2188,9 @@ namespace {
 
 void free_scenarios(tplhip_dp_lon* h)
 {
-    hipFree(h->d_sc_occ); hipFree(h->d_sc_path); hipFree(h->d_sc_dist); hipFree(h->d_sc_tables);
-    hipFree(h->d_sc_pre_vmax); hipFree(h->d_sc_pre_sdist); hipFree(h->d_sc_inits); hipFree(h->d_sc_trajs);
-    hipFree(h->d_sc_best);
+    (void)hipFree(h->d_sc_occ); (void)hipFree(h->d_sc_path); (void)hipFree(h->d_sc_dist); (void)hipFree(h->d_sc_tables);
+    (void)hipFree(h->d_sc_pre_vmax); (void)hipFree(h->d_sc_pre_sdist); (void)hipFree(h->d_sc_inits); (void)hipFree(h->d_sc_trajs);
+    (void)hipFree(h->d_sc_best);
     h->d_sc_occ = h->d_sc_path = h->d_sc_dist = h->d_sc_pre_vmax = h->d_sc_pre_sdist = nullptr;
     h->d_sc_tables = nullptr; h->d_sc_inits = h->d_sc_trajs = nullptr; h->d_sc_best = nullptr;
     h->sc_n = h->sc_chunk = h->sc_paths = 0;

@@ -277,8 +277,8 @@ __device__ __forceinline__ GlbD uni_g(double* p) { return (GlbD)uni_u64((unsigne
 // a generic pointer into LDS -> LDS pointer: the low half of the flat address IS the LDS offset.  (A
 // plain address-space cast also emits a null test against the shared aperture, which this hipcc
 // mis-selects in some kernels: "Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base".)
-__device__ __forceinline__ LdsCD uni_l(const double* p) { return (LdsCD)(unsigned)uni_i((int)(unsigned)(unsigned long long)p); }
-__device__ __forceinline__ LdsD uni_l(double* p) { return (LdsD)(unsigned)uni_i((int)(unsigned)(unsigned long long)p); }
+__device__ __forceinline__ LdsCD uni_l(const double* p) { return (LdsCD)(unsigned long long)(unsigned)uni_i((int)(unsigned)(unsigned long long)p); }
+__device__ __forceinline__ LdsD uni_l(double* p) { return (LdsD)(unsigned long long)(unsigned)uni_i((int)(unsigned)(unsigned long long)p); }
 __device__ __forceinline__ double uni_d(double d)
 {
     return __longlong_as_double((long long)uni_u64((unsigned long long)__double_as_longlong(d)));
@@ -1160,8 +1160,8 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                 ra.stamp_acc = nullptr;
 #endif
 #if TPL_ILQR_ABLATE != 1                    /* diagnostic builds: 1 = no backward pass, 2 = no rollouts */
-                if constexpr (SMALL_BACKWARD) riccati_backward_small(ra, (LdsAS*)(unsigned)(unsigned long long)&s);
-                else riccati_backward(ra, (LdsAS*)(unsigned)(unsigned long long)&s);
+                if constexpr (SMALL_BACKWARD) riccati_backward_small(ra, (LdsAS*)(unsigned long long)(unsigned)(unsigned long long)&s);
+                else riccati_backward(ra, (LdsAS*)(unsigned long long)(unsigned)(unsigned long long)&s);
 #endif
             } else {
                 // ---- first-order backward pass, optim.c:1044-1073
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
 #else
                 ra.stamp_acc = nullptr;
 #endif
-                LdsAS* const sl = (LdsAS*)(unsigned)(unsigned long long)&s;
+                LdsAS* const sl = (LdsAS*)(unsigned long long)(unsigned)(unsigned long long)&s;
                 auto roll = [&](auto lt_c, auto so_c) {
                     constexpr bool L = decltype(lt_c)::value, S2 = decltype(so_c)::value;
                     if (int_type == EULER) line_search_rollouts<L, S2, EULER>(ra, sl);
@@ -1551,8 +1551,8 @@ int upload_params(tplhip_ilqr* h)
         if (g_params[i].is_array) need += pad(h->parray[i].host.size() * sizeof(double));
     if (need > h->parena_cap) {
         HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
-        if (h->h_parena) hipHostFree(h->h_parena);
-        hipFree(h->d_parena);
+        if (h->h_parena) (void)hipHostFree(h->h_parena);
+        (void)hipFree(h->d_parena);
         h->h_parena = nullptr; h->d_parena = nullptr; h->parena_cap = 0;
         const size_t cap = need + need / 2;
         HIP_TRY(hipHostMalloc((void**)&h->h_parena, cap, hipHostMallocDefault), "parameter staging allocation failed");
@@ -1809,7 +1809,7 @@ int tplhip_ilqr_create(int device, int batch, int t_cap, tplhip_ilqr** out)
                 if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
                     h->n_cu = prop.multiProcessorCount;
             }
-            hipFree(d_ap);
+            (void)hipFree(d_ap);
         }
     }
 #ifdef TPL_ILQR_STAMP
@@ -1843,19 +1843,19 @@ int tplhip_ilqr_create(int device, int batch, int t_cap, tplhip_ilqr** out)
 int tplhip_ilqr_destroy(tplhip_ilqr* h)
 {
     if (!h) return TPLHIP_OK;
-    hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
-    for (auto& ev : h->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-    hipFree(h->d_arena);
-    if (h->h_arena) hipHostFree(h->h_arena);
-    hipFree(h->d_parena);
-    if (h->h_parena) hipHostFree(h->h_parena);
-    hipFree(h->dev.cand_x);
-    hipFree(h->dev.cand_u);
-    hipFree(h->dev.cand_c);
-    for (double* p : h->d_snapshot) hipFree(p);
-    hipFree(h->d_snapshot_scalars);
-    if (h->stream) hipStreamDestroy(h->stream);
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& ev : h->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    (void)hipFree(h->d_arena);
+    if (h->h_arena) (void)hipHostFree(h->h_arena);
+    (void)hipFree(h->d_parena);
+    if (h->h_parena) (void)hipHostFree(h->h_parena);
+    (void)hipFree(h->dev.cand_x);
+    (void)hipFree(h->dev.cand_u);
+    (void)hipFree(h->dev.cand_c);
+    for (double* p : h->d_snapshot) (void)hipFree(p);
+    (void)hipFree(h->d_snapshot_scalars);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return TPLHIP_OK;
 }
@@ -1867,7 +1867,7 @@ double* tplhip_ilqr_ptr(tplhip_ilqr* h, int field, int64_t* problem_stride)
 {
     if (!h || field < 0 || field >= TPL_F_COUNT) { fail(TPLHIP_EINVAL, "bad field id %d", field); return nullptr; }
     if (h->device_newer[field]) {
-        hipSetDevice(h->device);
+        (void)hipSetDevice(h->device);
         if (fetch_field(h, field) != TPLHIP_OK) return nullptr;
         if (hipStreamSynchronize(h->stream) != hipSuccess) { fail(TPLHIP_EDEVICE, "copying solver results failed"); return nullptr; }
     }
@@ -2095,8 +2095,8 @@ int tplhip_ilqr_timing(tplhip_ilqr* h, int reset, double* kernel_ms, int64_t* la
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second), "event query failed");
         h->kernel_ms += (double)ms;
-        hipEventDestroy(ev.first);
-        hipEventDestroy(ev.second);
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
     }
     h->events.clear();
     if (kernel_ms) *kernel_ms = h->kernel_ms;

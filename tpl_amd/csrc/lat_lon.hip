@@ -675,7 +675,7 @@ int ll_upload_ref(tplhip_lat_lon* h, tplhip_dp_env* env)
     // RefLineGpu::upload, common.cuh:59-78: (v_max, d_left, d_right, semantic) as floats
     const size_t n = env->ref_line.size();
     if (n > h->ref_cap) {
-        hipFree(h->d_ref); h->d_ref = nullptr; h->ref_cap = 0;
+        (void)hipFree(h->d_ref); h->d_ref = nullptr; h->ref_cap = 0;
         HIP_TRY(hipMalloc(&h->d_ref, sizeof(float4) * n), "ref line texture allocation failed");
         h->ref_cap = n;
     }
@@ -692,7 +692,7 @@ int ll_upload_ref(tplhip_lat_lon* h, tplhip_dp_env* env)
 int ll_ensure_traj(tplhip_lat_lon* h, size_t n)
 {
     if (n <= h->traj_cap && h->d_traj) return TPLHIP_OK;
-    hipFree(h->d_traj); hipFree(h->d_traj2);
+    (void)hipFree(h->d_traj); (void)hipFree(h->d_traj2);
     h->d_traj = nullptr; h->d_traj2 = nullptr; h->traj_cap = 0;
     HIP_TRY(hipMalloc(&h->d_traj, sizeof(TplLatLonState) * n), "forward nodes allocation failed");
     HIP_TRY(hipMalloc(&h->d_traj2, sizeof(TplLatLonState) * n), "reeval nodes allocation failed");
@@ -807,10 +807,10 @@ int tplhip_lat_lon_create(int device, tplhip_lat_lon** out)
 int tplhip_lat_lon_destroy(tplhip_lat_lon* h)
 {
     if (!h) return TPLHIP_OK;
-    hipSetDevice(h->device);
-    if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
-    hipFree(h->d_tables); hipFree(h->d_ref_s); hipFree(h->d_profile); hipFree(h->d_ref);
-    hipFree(h->d_traj); hipFree(h->d_traj2); hipFree(h->d_q);
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    (void)hipFree(h->d_tables); (void)hipFree(h->d_ref_s); (void)hipFree(h->d_profile); (void)hipFree(h->d_ref);
+    (void)hipFree(h->d_traj); (void)hipFree(h->d_traj2); (void)hipFree(h->d_q);
     delete h;
     return TPLHIP_OK;
 }
@@ -827,7 +827,7 @@ int tplhip_lat_lon_reinit(tplhip_lat_lon* h, const TplLatLonParams* ps, int forc
     h->have_params = true;
     if (!full) return TPLHIP_OK;
     HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
-    hipFree(h->d_tables); hipFree(h->d_ref_s); hipFree(h->d_q);
+    (void)hipFree(h->d_tables); (void)hipFree(h->d_ref_s); (void)hipFree(h->d_q);
     h->d_tables = nullptr; h->d_ref_s = nullptr; h->d_q = nullptr;
     h->tables_valid = false;
     h->table_cells = (size_t)ps->s_steps * ps->ds_steps * ps->l_steps;
@@ -850,7 +850,7 @@ int tplhip_lat_lon_update_traj_dp(tplhip_lat_lon* h, tplhip_dp_env* env, TplLatL
     if ((rc = ll_upload_ref(h, env))) return rc;
     const size_t n_prof = (size_t)p.t_steps * p.s_steps * ep.l_steps;
     if (n_prof > h->profile_cap) {
-        hipFree(h->d_profile); h->d_profile = nullptr; h->profile_cap = 0;
+        (void)hipFree(h->d_profile); h->d_profile = nullptr; h->profile_cap = 0;
         HIP_TRY(hipMalloc(&h->d_profile, sizeof(float) * n_prof), "prelude allocation failed");
         h->profile_cap = n_prof;
     }

@@ -367,8 +367,8 @@ int tplhip_poly_lat_create(int device, tplhip_poly_lat** out)
 int tplhip_poly_lat_destroy(tplhip_poly_lat* h)
 {
     if (!h) return TPLHIP_OK;
-    hipSetDevice(h->device);
-    hipFree(h->d_nodes); hipFree(h->d_path_res); hipFree(h->d_frames); hipFree(h->d_best);
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->d_nodes); (void)hipFree(h->d_path_res); (void)hipFree(h->d_frames); (void)hipFree(h->d_best);
     delete h;
     return TPLHIP_OK;
 }
@@ -386,7 +386,7 @@ int tplhip_poly_lat_reinit(tplhip_poly_lat* h, TplPolyLatParams* ps)
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     h->params = *ps;
     h->have_params = true;
-    hipFree(h->d_nodes); hipFree(h->d_path_res); hipFree(h->d_frames); hipFree(h->d_best);
+    (void)hipFree(h->d_nodes); (void)hipFree(h->d_path_res); (void)hipFree(h->d_frames); (void)hipFree(h->d_best);
     h->d_nodes = nullptr; h->d_path_res = nullptr; h->d_frames = nullptr; h->d_best = nullptr;
     h->have_nodes = false;
     const size_t n_paths = (size_t)ps->l_dst_steps * ps->s_dst_steps;

@@ -815,7 +815,7 @@ def compile_model(name, out_dir=None, force=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = paths["so"] + f".tmp{os.getpid()}"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-fno-fast-math", "-ffp-contract=off", "-Wall", "-Wno-unused-value", "-Wno-unused-function",
+           "-fvisibility=hidden", "-fno-fast-math", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
            f"-DTPL_MODEL_INC=\"{paths['inc']}\"", "-I", os.path.join(_PKG, "..", "include"),
            "-o", tmp, src]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
