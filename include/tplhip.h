@@ -149,6 +149,11 @@ TPLHIP_API int tplhip_dp_env_get_occ_map_cartesian(tplhip_dp_env* env, uint32_t*
 /* getDistMapLon (env.cu:474-489): float[l_steps][s_steps][t_steps][2] =
  * (distance to the next occupied cell ahead, behind) */
 TPLHIP_API int tplhip_dp_env_get_dist_map_lon(tplhip_dp_env* env, float* out);
+/* The same two tables with their time slices below each other -- float[t_steps * l_steps][s_steps] and
+ * float[t_steps * l_steps][s_steps][2] -- which is how the environment plugin publishes them every cycle
+ * (dp_env.py:185-188 does np.vstack(np.moveaxis(get_occ_map(), 2, 0))): transposed on the device, one copy out. */
+TPLHIP_API int tplhip_dp_env_get_occ_map_slices(tplhip_dp_env* env, float* out);
+TPLHIP_API int tplhip_dp_env_get_dist_map_lon_slices(tplhip_dp_env* env, float* out);
 /* DynProgEnvironment::getDist (env.cu:439-450): filtered occupancy at (t, s, l) */
 TPLHIP_API int tplhip_dp_env_get_dist(tplhip_dp_env* env, float t, float s, float l, float* out);
 

@@ -30,6 +30,9 @@ def _assert_same(env, ref):
     assert np.array_equal(got_img, img), f"{np.count_nonzero(got_img != img)} pixels differ"
     assert np.array_equal(env.get_occ_map(), occ)
     assert np.array_equal(env.get_dist_map_lon(), dl)
+    # the published form of the two tables (dp_env.py:185-188), transposed on the device
+    assert np.array_equal(env.get_occ_map_slices(), np.vstack(np.moveaxis(occ, 2, 0)))
+    assert np.array_equal(env.get_dist_map_lon_slices(), np.vstack(np.moveaxis(dl, 2, 0)))
 
 
 @pytest.mark.parametrize("kind,seed", [("straight", 0), ("straight", 3), ("arc", 1), ("arc", 7)])

@@ -178,6 +178,8 @@ SIGNATURES = {
     "tplhip_dp_env_cart_size": (C.c_int, [_vp, _P(C.c_int)]),
     "tplhip_dp_env_get_occ_map_cartesian": (C.c_int, [_vp, _P(C.c_uint32)]),
     "tplhip_dp_env_get_dist_map_lon": (C.c_int, [_vp, _fp]),
+    "tplhip_dp_env_get_occ_map_slices": (C.c_int, [_vp, _fp]),
+    "tplhip_dp_env_get_dist_map_lon_slices": (C.c_int, [_vp, _fp]),
     "tplhip_dp_env_get_dist": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, _fp]),
     "tplhip_lat_lon_params_default": (None, [_P(TplLatLonParams)]),
     "tplhip_lat_lon_dynamics": (None, [_P(TplLatLonState), C.c_float, C.c_float, C.c_float, _P(TplLatLonState)]),

@@ -2,6 +2,8 @@
 #include <cstdarg>
 #include <cstdio>
 
+#include <cstring>
+
 #include "tplhip_common.h"
 
 namespace {
@@ -23,6 +25,35 @@ int tplhip_default_device(int n_devices)
 {
     // tpl/planning/__init__.py:2-7 picks the last device unless cuda_set_device chose one
     return (g_default_device >= 0 && g_default_device < n_devices) ? g_default_device : n_devices - 1;
+}
+
+int tplhip_copy_to_host(void* dst, const void* src, size_t bytes, hipStream_t stream, const char* context)
+{
+    static thread_local void* bounce = nullptr;             // lives as long as the thread (page-locked memory is per process)
+    static thread_local size_t cap = 0;
+    if (bytes == 0) return TPLHIP_OK;
+    if (bytes > ((size_t)64 << 20)) {                       // whole value tables of the largest grids: no 64 MB+ of page-locked memory for a debug read
+        HIP_TRY(hipStreamSynchronize(stream), context);
+        HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), context);
+        return TPLHIP_OK;
+    }
+    if (bytes > cap) {
+        if (bounce) (void)hipHostFree(bounce);
+        bounce = nullptr; cap = 0;
+        const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        if (hipHostMalloc(&bounce, want, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            bounce = nullptr;                               // no page-locked memory to be had: the plain copy still works
+            HIP_TRY(hipStreamSynchronize(stream), context);
+            HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), context);
+            return TPLHIP_OK;
+        }
+        cap = want;
+    }
+    HIP_TRY(hipMemcpyAsync(bounce, src, bytes, hipMemcpyDeviceToHost, stream), context);
+    HIP_TRY(hipStreamSynchronize(stream), context);
+    std::memcpy(dst, bounce, bytes);
+    return TPLHIP_OK;
 }
 
 extern "C" {

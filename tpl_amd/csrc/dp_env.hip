@@ -366,6 +366,9 @@ int tplhip_dp_env_update_dist_maps(tplhip_dp_env* env)
     if (!env->have_occ) return tplhip_fail(TPLHIP_ESTATE, "no occupancy map: call set_occ_map or update first");
     if (env->params.l_steps > 1024) return tplhip_fail(TPLHIP_EINVAL, "l_steps = %d exceeds one workgroup", env->params.l_steps);
     HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
+    // planners work on their own non-blocking streams and may still read the tables of this environment (plan_resident):
+    // nothing here is ordered against them implicitly
+    HIP_TRY(hipDeviceSynchronize(), "waiting for the device failed");
     hipStream_t st = nullptr;
     int rc;
     if ((rc = launch_dist_map_lon(env, st))) return rc;
@@ -387,6 +390,9 @@ int tplhip_dp_env_update(tplhip_dp_env* env)
     }
     if (ep.l_steps > 1024) return tplhip_fail(TPLHIP_EINVAL, "l_steps = %d exceeds one workgroup", ep.l_steps);
     HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
+    // planners work on their own non-blocking streams and may still read the tables of this environment (plan_resident):
+    // nothing here is ordered against them implicitly
+    HIP_TRY(hipDeviceSynchronize(), "waiting for the device failed");
 
     // occupancy_renderer.cu:277-279
     const float size = ep.s_max + ep.l_max * 2.0f;
@@ -411,6 +417,10 @@ int tplhip_dp_env_update(tplhip_dp_env* env)
     for (size_t i = 0; i < n_ref; ++i) semantic[i] = (float)env->ref_line[i].semantic;
 
     hipStream_t st = nullptr;
+    if (env->cart_staged) {                                 // the last image may still be on its way out of d_cart
+        HIP_TRY(hipEventSynchronize(env->ev_cart), "copying the occupancy image failed");
+        env->cart_staged = false;
+    }
     HIP_TRY(hipMemcpyAsync(env->d_frames, frames.data(), sizeof(StationFrame) * frames.size(), hipMemcpyHostToDevice, st),
             "copying station frames failed");
     HIP_TRY(hipMemcpyAsync(env->d_semantic, semantic.data(), sizeof(float) * n_ref, hipMemcpyHostToDevice, st),
@@ -421,6 +431,29 @@ int tplhip_dp_env_update(tplhip_dp_env* env)
                 "copying occupancy vertex data failed");
         hipLaunchKernelGGL(k_raster_or, dim3((unsigned)(n_vtx / 3)), dim3(64), 0, st,
                            env->d_cart, W, env->d_vtx, (int)(n_vtx / 3), scale);
+    }
+    // image -> page-locked host copy, beside the Frenet stages
+    env->cart_staged = false;
+    {
+        const size_t px = (size_t)W * W;
+        bool ok = true;
+        if (px > env->h_cart_cap) {
+            if (env->h_cart) (void)hipHostFree(env->h_cart);
+            env->h_cart = nullptr; env->h_cart_cap = 0;
+            ok = hipHostMalloc(&env->h_cart, sizeof(uint32_t) * px, hipHostMallocDefault) == hipSuccess;
+            if (ok) env->h_cart_cap = px; else (void)hipGetLastError();
+        }
+        ok = ok && (env->copy_stream || hipStreamCreateWithFlags(&env->copy_stream, hipStreamNonBlocking) == hipSuccess);
+        ok = ok && (env->ev_raster || hipEventCreateWithFlags(&env->ev_raster, hipEventDisableTiming) == hipSuccess);
+        ok = ok && (env->ev_cart || hipEventCreateWithFlags(&env->ev_cart, hipEventDisableTiming) == hipSuccess);
+        if (ok) {
+            HIP_TRY(hipEventRecord(env->ev_raster, st), "event record failed");
+            HIP_TRY(hipStreamWaitEvent(env->copy_stream, env->ev_raster, 0), "stream wait failed");
+            HIP_TRY(hipMemcpyAsync(env->h_cart, env->d_cart, sizeof(uint32_t) * px, hipMemcpyDeviceToHost, env->copy_stream),
+                    "copying the occupancy image failed");
+            HIP_TRY(hipEventRecord(env->ev_cart, env->copy_stream), "event record failed");
+            env->cart_staged = true;
+        }
     }
     hipLaunchKernelGGL(k_occ_to_frenet, dim3(ep.s_steps), dim3(256), 0, st,
                        env->d_occ, env->d_cart, W, env->d_frames, ep);
@@ -448,9 +481,13 @@ int tplhip_dp_env_get_occ_map_cartesian(tplhip_dp_env* env, uint32_t* out)
     if (!env || !out) return tplhip_fail(TPLHIP_EINVAL, "null argument");
     if (!env->rendered) { out[0] = 0u; return TPLHIP_OK; }
     HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
-    HIP_TRY(hipMemcpy(out, env->d_cart, sizeof(uint32_t) * (size_t)env->cart_px * env->cart_px, hipMemcpyDeviceToHost),
-            "copying the occupancy image failed");
-    return TPLHIP_OK;
+    if (env->cart_staged) {                                 // update() already has it on the way to the host
+        HIP_TRY(hipEventSynchronize(env->ev_cart), "copying the occupancy image failed");
+        std::memcpy(out, env->h_cart, sizeof(uint32_t) * (size_t)env->cart_px * env->cart_px);
+        return TPLHIP_OK;
+    }
+    return tplhip_copy_to_host(out, env->d_cart, sizeof(uint32_t) * (size_t)env->cart_px * env->cart_px, nullptr,
+                               "copying the occupancy image failed");
 }
 
 int tplhip_dp_env_get_dist_map_lon(tplhip_dp_env* env, float* out)
@@ -459,9 +496,49 @@ int tplhip_dp_env_get_dist_map_lon(tplhip_dp_env* env, float* out)
     if (!env->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the environment");
     HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
     const size_t n = (size_t)env->params.l_steps * env->params.s_steps * env->params.t_steps * 2;
-    HIP_TRY(hipMemcpy(out, env->d_dist_lon, n * sizeof(float), hipMemcpyDeviceToHost),
-            "copying longitudinal distance map from gpu to cpu failed");
-    return TPLHIP_OK;
+    return tplhip_copy_to_host(out, env->d_dist_lon, n * sizeof(float), nullptr,
+                               "copying longitudinal distance map from gpu to cpu failed");
+}
+
+namespace {
+// [l][s][t][c] -> [t][l][s][c]: the time slices of a Frenet table below each other
+__global__ void k_time_slices(float* __restrict__ out, const float* __restrict__ in, int L, int S, int T, int C)
+{
+    const size_t n = (size_t)L * S * T * C;
+    for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < n; o += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(o % C);
+        size_t r = o / C;
+        const int s = (int)(r % S); r /= S;
+        const int l = (int)(r % L);
+        const int t = (int)(r / L);
+        out[o] = in[(((size_t)l * S + s) * T + t) * C + c];
+    }
+}
+
+int time_slices(tplhip_dp_env* env, const float* table, int channels, float* out, const char* what)
+{
+    if (!env || !out) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (!env->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the environment");
+    HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
+    const TplDpEnvParams& ep = env->params;
+    const size_t n = (size_t)ep.l_steps * ep.s_steps * ep.t_steps * channels;
+    int rc;
+    if ((rc = ensure_capacity(&env->d_slices, &env->slices_cap, n, "time slice buffer allocation failed"))) return rc;
+    hipLaunchKernelGGL(k_time_slices, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, nullptr,
+                       env->d_slices, table, ep.l_steps, ep.s_steps, ep.t_steps, channels);
+    HIP_TRY(hipGetLastError(), what);
+    return tplhip_copy_to_host(out, env->d_slices, n * sizeof(float), nullptr, what);
+}
+} // namespace
+
+int tplhip_dp_env_get_occ_map_slices(tplhip_dp_env* env, float* out)
+{
+    return time_slices(env, env ? env->d_occ : nullptr, 1, out, "copying occupancy map failed");
+}
+
+int tplhip_dp_env_get_dist_map_lon_slices(tplhip_dp_env* env, float* out)
+{
+    return time_slices(env, env ? env->d_dist_lon : nullptr, 2, out, "copying longitudinal distance map from gpu to cpu failed");
 }
 
 int tplhip_dp_env_get_dist(tplhip_dp_env* env, float t, float s, float l, float* out)

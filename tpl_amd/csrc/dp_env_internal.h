@@ -92,5 +92,15 @@ struct tplhip_dp_env {
     float* d_semantic = nullptr;                 // [ref steps], float as in the reference's texture copy
     size_t sem_cap = 0;
     float* d_dist_lon = nullptr;                 // [l][s][t][2]
+    // the occupancy image is copied to page-locked host memory behind the rasteriser, on a side stream, while the
+    // Frenet stages run: the environment plugin fetches it every cycle (dp_env.py:183), and a 2.8 MB hipMemcpy into
+    // fresh pageable memory pins and unpins the pages each time -- sporadic 20-30 ms waits in the NEXT device call
+    uint32_t* h_cart = nullptr;
+    size_t h_cart_cap = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_raster = nullptr, ev_cart = nullptr;
+    bool cart_staged = false;
+    float* d_slices = nullptr;                   // scratch of the time-slice getters, [t][l][s][1 or 2]
+    size_t slices_cap = 0;
     bool rendered = false;
 };

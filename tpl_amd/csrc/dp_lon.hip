@@ -1094,6 +1094,7 @@ __global__ void __launch_bounds__(256) k_best_plan(const TplLonState* __restrict
 
 struct tplhip_dp_lon {
     int device = 0;
+    int n_cu = 0;                       // compute units of the device (0: not asked yet)
     hipStream_t stream = nullptr;
     TplDpLonParams params;
     bool have_params = false;
@@ -1159,6 +1160,15 @@ struct tplhip_dp_lon {
     size_t stage_n[2] = {0, 0};          // states staged in each slot (rollouts x t_steps at staging time)
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     bool stage_busy[2] = {false, false};
+
+    // page-locked staging of update()'s own transfers: path + initial states in (the copies are enqueued without a
+    // host sync; `ev_up` guards the buffer against the next upload), trajectories out (one sync per plan)
+    unsigned char* h_up = nullptr;
+    size_t up_cap = 0;
+    hipEvent_t ev_up = nullptr;
+    bool up_inflight = false;
+    TplLonState* h_dl = nullptr;
+    size_t dl_cap = 0;
 
     // scenario batches (tplhip_dp_lon_scenarios_*): n scenarios resident, `chunk` of them swept per launch
     int sc_n = 0, sc_chunk = 0, sc_paths = 0;
@@ -1517,7 +1527,7 @@ void try_enable_overlap(tplhip_dp_lon* h, tplhip_dp_env* env)
         if (hipMalloc(&h->d_table_set[1], bytes) != hipSuccess) { (void)hipGetLastError(); h->d_table_set[1] = nullptr; return; }
         if (hipMemsetAsync(h->d_table_set[1], 0, bytes, h->stream) != hipSuccess) return;
     }
-    if (!h->fwd_stream && hipStreamCreate(&h->fwd_stream) != hipSuccess) { h->fwd_stream = nullptr; return; }
+    if (!h->fwd_stream && hipStreamCreateWithFlags(&h->fwd_stream, hipStreamNonBlocking) != hipSuccess) { h->fwd_stream = nullptr; return; }
     if (!h->ev_swept && hipEventCreateWithFlags(&h->ev_swept, hipEventDisableTiming) != hipSuccess) return;
     for (int i = 0; i < 2; ++i)
         if (!h->ev_fwd[i] && hipEventCreateWithFlags(&h->ev_fwd[i], hipEventDisableTiming) != hipSuccess) return;
@@ -1640,10 +1650,15 @@ int tplhip_dp_env_destroy(tplhip_dp_env* env)
     (void)hipFree(env->d_occ);
     (void)hipFree(env->d_dist);
     (void)hipFree(env->d_cart);
+    if (env->copy_stream) { (void)hipStreamSynchronize(env->copy_stream); (void)hipStreamDestroy(env->copy_stream); }
+    if (env->h_cart) (void)hipHostFree(env->h_cart);
+    if (env->ev_raster) (void)hipEventDestroy(env->ev_raster);
+    if (env->ev_cart) (void)hipEventDestroy(env->ev_cart);
     (void)hipFree(env->d_vtx);
     (void)hipFree(env->d_frames);
     (void)hipFree(env->d_semantic);
     (void)hipFree(env->d_dist_lon);
+    (void)hipFree(env->d_slices);
     delete env;
     return TPLHIP_OK;
 }
@@ -1681,6 +1696,9 @@ int tplhip_dp_env_set_occ_map(tplhip_dp_env* env, const float* occ_lst)
     if (!env || !occ_lst) return tplhip_fail(TPLHIP_EINVAL, "null argument");
     if (!env->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the environment");
     HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
+    // planners work on their own non-blocking streams and may still read the tables of this environment (plan_resident):
+    // nothing here is ordered against them implicitly
+    HIP_TRY(hipDeviceSynchronize(), "waiting for the device failed");
     const size_t n = (size_t)env->params.l_steps * env->params.s_steps * env->params.t_steps;
     HIP_TRY(hipMemcpy(env->d_occ, occ_lst, n * sizeof(float), hipMemcpyHostToDevice), "copying occupancy map failed");
     env->have_occ = true;
@@ -1693,8 +1711,7 @@ int tplhip_dp_env_get_occ_map(tplhip_dp_env* env, float* occ_lst)
     if (!env->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the environment");
     HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
     const size_t n = (size_t)env->params.l_steps * env->params.s_steps * env->params.t_steps;
-    HIP_TRY(hipMemcpy(occ_lst, env->d_occ, n * sizeof(float), hipMemcpyDeviceToHost), "copying occupancy map failed");
-    return TPLHIP_OK;
+    return tplhip_copy_to_host(occ_lst, env->d_occ, n * sizeof(float), nullptr, "copying occupancy map failed");
 }
 
 int tplhip_dp_env_get_dist_map_path(tplhip_dp_env* env, float* dist_ts)
@@ -1702,9 +1719,11 @@ int tplhip_dp_env_get_dist_map_path(tplhip_dp_env* env, float* dist_ts)
     if (!env || !dist_ts) return tplhip_fail(TPLHIP_EINVAL, "null argument");
     if (!env->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the environment");
     HIP_TRY(hipSetDevice(env->device), "hipSetDevice failed");
+    // planners work on their own non-blocking streams and may still read the tables of this environment (plan_resident):
+    // nothing here is ordered against them implicitly
+    HIP_TRY(hipDeviceSynchronize(), "waiting for the device failed");
     const size_t n = (size_t)env->params.t_steps * env->params.s_steps;
-    HIP_TRY(hipMemcpy(dist_ts, env->d_dist, n * sizeof(float), hipMemcpyDeviceToHost), "copying distance map failed");
-    return TPLHIP_OK;
+    return tplhip_copy_to_host(dist_ts, env->d_dist, n * sizeof(float), nullptr, "copying distance map failed");
 }
 
 // ---- planner -----------------------------------------------------------------
@@ -1719,7 +1738,9 @@ int tplhip_dp_lon_create(int device, tplhip_dp_lon** out)
     if (!h) return tplhip_fail(TPLHIP_EDEVICE, "out of host memory");
     h->device = dev;
     tplhip_dp_lon_params_default(&h->params);
-    hipError_t err = hipStreamCreate(&h->stream);
+    // non-blocking: nothing here is ordered against the null stream implicitly (the environment works on it and ends
+    // every update with a host wait); implicit null-stream coupling costs sporadic 30 ms waits on this runtime
+    hipError_t err = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (err != hipSuccess) {
         delete h;
         return tplhip_fail(TPLHIP_EDEVICE, "%s: stream creation failed", hipGetErrorString(err));
@@ -1747,6 +1768,9 @@ int tplhip_dp_lon_destroy(tplhip_dp_lon* h)
         if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
         if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
     }
+    if (h->h_up) (void)hipHostFree(h->h_up);
+    if (h->h_dl) (void)hipHostFree(h->h_dl);
+    if (h->ev_up) (void)hipEventDestroy(h->ev_up);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return TPLHIP_OK;
@@ -1832,9 +1856,12 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     // A grid that fits the chip in one residency round (config 2, the reference default grid)
     // has nothing to overlap with and prefers fewer barriers: 3 per pass (10.7 vs 12.0 us).
     {
-        int n_cu = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        if (h->n_cu <= 0) {                                 // asked once per planner: the query takes tens of microseconds
+            h->n_cu = 256;
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && n > 0) h->n_cu = n;
+        }
+        const int n_cu = h->n_cu;
         const size_t waves = (size_t)h->nblocks * (threads / 64);
         h->kchunk = (waves <= (size_t)n_cu * 4 * 8) ? 3 : 1;
     }
@@ -1965,7 +1992,9 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         h->path_div3 = h->verified_path3;
         h->range_div3 = h->verified_range3;
     }
-    HIP_TRY(hipStreamSynchronize(h->stream), "building the action table failed");
+    // a re-parameterisation of an existing planner (tpl changes dt_start every cycle) only rebuilds the action table:
+    // the launch is ordered before every later kernel of the stream, nothing here is read by the host
+    if (resize) HIP_TRY(hipStreamSynchronize(h->stream), "building the action table failed");
     return TPLHIP_OK;
 }
 
@@ -1980,12 +2009,27 @@ int tplhip_dp_lon_upload(tplhip_dp_lon* h, int n, const TplLonState* inits, cons
     if (rc) return rc;
     h->n_rollouts = n;
     h->path_bounded = path_is_bounded(path, h->params.path_steps);
-    // lon_planner.cu:334-338 and :365-368
-    HIP_TRY(hipMemcpyAsync(h->d_path, path, sizeof(float) * 7 * (size_t)h->params.path_steps,
-                           hipMemcpyHostToDevice, h->stream), "copying path failed");
-    HIP_TRY(hipMemcpyAsync(h->d_inits, inits, sizeof(TplLonState) * (size_t)n,
-                           hipMemcpyHostToDevice, h->stream), "copying initial states failed");
-    HIP_TRY(hipStreamSynchronize(h->stream), "upload failed");
+    // lon_planner.cu:334-338 and :365-368.  Through a page-locked staging buffer, so that the copies are true
+    // asynchronous DMA requests and the host does not wait for them: the kernels that read them follow on the stream.
+    const size_t path_b = sizeof(float) * 7 * (size_t)h->params.path_steps;
+    const size_t init_b = sizeof(TplLonState) * (size_t)n;
+    if (h->up_inflight) {
+        HIP_TRY(hipEventSynchronize(h->ev_up), "upload failed");
+        h->up_inflight = false;
+    }
+    if (path_b + init_b > h->up_cap) {
+        if (h->h_up) (void)hipHostFree(h->h_up);
+        h->h_up = nullptr; h->up_cap = 0;
+        HIP_TRY(hipHostMalloc(&h->h_up, path_b + init_b, hipHostMallocDefault), "pinned buffer allocation failed");
+        h->up_cap = path_b + init_b;
+    }
+    if (!h->ev_up) HIP_TRY(hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming), "event creation failed");
+    std::memcpy(h->h_up, path, path_b);
+    std::memcpy(h->h_up + path_b, inits, init_b);
+    HIP_TRY(hipMemcpyAsync(h->d_path, h->h_up, path_b, hipMemcpyHostToDevice, h->stream), "copying path failed");
+    HIP_TRY(hipMemcpyAsync(h->d_inits, h->h_up + path_b, init_b, hipMemcpyHostToDevice, h->stream), "copying initial states failed");
+    HIP_TRY(hipEventRecord(h->ev_up, h->stream), "event record failed");
+    h->up_inflight = true;
     return TPLHIP_OK;
 }
 
@@ -2012,14 +2056,22 @@ int tplhip_dp_lon_download(tplhip_dp_lon* h, TplLonState* out_trajs)
     if (!h || !out_trajs) return tplhip_fail(TPLHIP_EINVAL, "null argument");
     if (h->n_rollouts < 1) return tplhip_fail(TPLHIP_ESTATE, "nothing to download");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
-    HIP_TRY(hipStreamSynchronize(h->stream), "lon planner pass failed");
-    {
-        int rc = wait_pending_forwards(h);
-        if (rc) return rc;
+    // the copy queues behind the rollout it reads (its own stream in the back-to-back mode, and that stream waited
+    // for the sweeps), into a page-locked buffer: ONE host wait per plan
+    const size_t n = (size_t)h->n_rollouts * h->params.t_steps;
+    if (n > h->dl_cap) {
+        if (h->h_dl) (void)hipHostFree(h->h_dl);
+        h->h_dl = nullptr; h->dl_cap = 0;
+        HIP_TRY(hipHostMalloc(&h->h_dl, sizeof(TplLonState) * n, hipHostMallocDefault), "pinned buffer allocation failed");
+        h->dl_cap = n;
     }
-    HIP_TRY(hipMemcpyAsync(out_trajs, h->d_trajs, sizeof(TplLonState) * (size_t)h->n_rollouts * h->params.t_steps,
-                           hipMemcpyDeviceToHost, h->stream), "copying trajectory failed");
-    HIP_TRY(hipStreamSynchronize(h->stream), "lon planner forward pass failed");
+    const bool on_fwd = h->fwd_stream && (h->fwd_pending[0] || h->fwd_pending[1]);
+    hipStream_t cs = on_fwd ? h->fwd_stream : h->stream;
+    HIP_TRY(hipMemcpyAsync(h->h_dl, h->d_trajs, sizeof(TplLonState) * n, hipMemcpyDeviceToHost, cs), "copying trajectory failed");
+    HIP_TRY(hipStreamSynchronize(cs), "lon planner forward pass failed");
+    if (on_fwd) h->fwd_pending[0] = h->fwd_pending[1] = false;
+    h->up_inflight = false;                                  // the uploads were ordered before what just finished
+    std::memcpy(out_trajs, h->h_dl, sizeof(TplLonState) * n);
     return TPLHIP_OK;
 }
 

@@ -795,7 +795,7 @@ int tplhip_lat_lon_create(int device, tplhip_lat_lon** out)
     tplhip_lat_lon* h = new (std::nothrow) tplhip_lat_lon();
     if (!h) return tplhip_fail(TPLHIP_EDEVICE, "out of host memory");
     h->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return tplhip_fail(TPLHIP_EDEVICE, "stream creation failed");
     }
@@ -987,10 +987,8 @@ int tplhip_lat_lon_copy_backward_pass_tex(tplhip_lat_lon* h, int idx_t, float* o
     if (!h->have_params || !h->d_tables) return tplhip_fail(TPLHIP_ESTATE, "no value tables allocated");
     if (idx_t < 0 || idx_t >= h->params.t_steps) return tplhip_fail(TPLHIP_EINVAL, "stage %d out of range", idx_t);
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
-    HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
-    HIP_TRY(hipMemcpy(out, h->d_tables + (size_t)idx_t * h->table_cells, sizeof(float4) * h->table_cells,
-                      hipMemcpyDeviceToHost), "copying backward pass texture gpu to cpu failed");
-    return TPLHIP_OK;
+    return tplhip_copy_to_host(out, h->d_tables + (size_t)idx_t * h->table_cells, sizeof(float4) * h->table_cells, h->stream,
+                               "copying backward pass texture gpu to cpu failed");
 }
 
 int tplhip_lat_lon_query_backward_pass_tex(tplhip_lat_lon* h, int idx_t, float s, float ds, float l, float* out4)

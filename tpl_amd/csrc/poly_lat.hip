@@ -466,8 +466,7 @@ int tplhip_poly_lat_copy_nodes(tplhip_poly_lat* h, float* out)
     if (!h->have_nodes) return tplhip_fail(TPLHIP_ESTATE, "no lattice evaluated yet");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     const size_t n = (size_t)h->params.l_dst_steps * h->params.s_dst_steps * h->params.s_steps;
-    HIP_TRY(hipMemcpy(out, h->d_nodes, sizeof(float4) * n, hipMemcpyDeviceToHost), "copying path nodes failed");
-    return TPLHIP_OK;
+    return tplhip_copy_to_host(out, h->d_nodes, sizeof(float4) * n, nullptr, "copying path nodes failed");
 }
 
 int tplhip_poly_lat_traj_update(TplPolyLatTrajPoint* points, int n)

@@ -320,6 +320,21 @@ class DynProgEnvironment:
         check(self._lib.tplhip_dp_env_get_dist_map_lon(self._h, _fptr(out)))
         return out
 
+    def get_occ_map_slices(self):
+        """np.vstack(np.moveaxis(get_occ_map(), 2, 0)) -- the time slices below each other, [t_steps * l_steps, s_steps]
+        -- transposed on the device (what dp_env.py:185-186 publishes every cycle)."""
+        p = self.params
+        out = np.empty((p.t_steps * p.l_steps, p.s_steps), dtype=np.float32)
+        check(self._lib.tplhip_dp_env_get_occ_map_slices(self._h, _fptr(out)))
+        return out
+
+    def get_dist_map_lon_slices(self):
+        """np.vstack(np.moveaxis(get_dist_map_lon(), 2, 0)): [t_steps * l_steps, s_steps, 2] (dp_env.py:187-188)."""
+        p = self.params
+        out = np.empty((p.t_steps * p.l_steps, p.s_steps, 2), dtype=np.float32)
+        check(self._lib.tplhip_dp_env_get_dist_map_lon_slices(self._h, _fptr(out)))
+        return out
+
     def get_dist_map_dir(self, idx_t):
         # the reference never launches updateDirDistMap (env.cu:160-217 has no caller), so the
         # array it hands out is the zero-initialised allocation

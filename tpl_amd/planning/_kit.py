@@ -17,6 +17,9 @@ from .base import Trajectory
 from .geometry import project
 
 
+_ATOMS = frozenset((int, float, bool, str, type(None)))
+
+
 class ParamBlock:
     """Subclasses set ``DEFAULTS = {name: value | ParamBlock subclass | callable(engines) -> value}``."""
     DEFAULTS = {}
@@ -33,6 +36,16 @@ class ParamBlock:
 
     def deepcopy(self):
         return copy.deepcopy(self)
+
+    def __deepcopy__(self, memo):
+        """Attribute by attribute, without the pickle protocol copy.deepcopy falls back to for plain objects (a
+        plugin copies its parameter tree twice per cycle)."""
+        twin = object.__new__(type(self))
+        memo[id(self)] = twin
+        fill = twin.__dict__
+        for name, value in self.__dict__.items():
+            fill[name] = value if type(value) in _ATOMS else copy.deepcopy(value, memo)
+        return twin
 
 
 def snapshot(lock, shared_block, cls, engines=None, before_copy=None):

@@ -127,12 +127,17 @@ class DpEnv:
 
     def write_debug_data(self):
         cpp = self.cpp_env
-        slices_stacked = lambda table: np.vstack(np.moveaxis(table, 2, 0))          # [l, s, t(, k)] -> time slices on top of each other
+        # the Frenet tables are published with their time slices below each other ([l, s, t(, k)] -> [t * l, s(, k)])
+        if hasattr(cpp, "get_occ_map_slices"):
+            occ_slices, dist_slices = cpp.get_occ_map_slices, cpp.get_dist_map_lon_slices      # transposed on the device
+        else:
+            occ_slices = lambda: np.vstack(np.moveaxis(cpp.get_occ_map(), 2, 0))
+            dist_slices = lambda: np.vstack(np.moveaxis(cpp.get_dist_map_lon(), 2, 0))
         with self.lock_shared():
             dbg = self.shared.debug.env
             dbg.runtime_environment = self.runtime_environment
             dbg.ref_line = self.ref_line
             dbg.occ_map_cart = cpp.get_occ_map_cartesian()
-            dbg.occ_map = slices_stacked(cpp.get_occ_map())
-            dbg.dist_map_lon = slices_stacked(cpp.get_dist_map_lon())
+            dbg.occ_map = occ_slices()
+            dbg.dist_map_lon = dist_slices()
             dbg.dir_dist_map = cpp.get_dist_map_dir(0)

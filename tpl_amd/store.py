@@ -80,6 +80,12 @@ class Bundle(SimpleNamespace):
         super().__init__(**kw)
         object.__setattr__(self, "__class_tag__", _class)
 
+    def __deepcopy__(self, memo):
+        twin = type(self).__new__(type(self))
+        memo[id(self)] = twin
+        twin.__dict__.update((k, copy.deepcopy(v, memo)) for k, v in self.__dict__.items())
+        return twin
+
 
 def _decode(obj, base_dir):
     if isinstance(obj, list):
