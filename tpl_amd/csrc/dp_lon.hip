@@ -1687,6 +1687,7 @@ int tplhip_dp_env_reinit(tplhip_dp_env* env, TplDpEnvParams* ps)
     // a freshly allocated cudaArray is read as all-free road until update() ran
     HIP_TRY(hipMemset(env->d_occ, 0, n_occ * sizeof(float)), "occupancy map clear failed");
     HIP_TRY(hipMemset(env->d_dist, 0, n_dist * sizeof(float)), "distance map clear failed");
+    HIP_TRY(hipDeviceSynchronize(), "clearing the environment tables failed");   // planners read them from their own (non-blocking) streams
     env->have_occ = true;
     return TPLHIP_OK;
 }

@@ -1748,7 +1748,7 @@ int tplhip_ilqr_create(int device, int batch, int t_cap, tplhip_ilqr** out)
     h->t_cap = t_cap;
     h->rows = t_cap + 1;
     h->dev.rows = h->rows;
-    hipError_t err = hipStreamCreate(&h->stream);
+    hipError_t err = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);      // nothing of a solver runs on the null stream
     if (err != hipSuccess) { delete h; return fail(TPLHIP_EDEVICE, "%s: stream creation failed", hipGetErrorString(err)); }
 
     {
