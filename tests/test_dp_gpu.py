@@ -315,6 +315,43 @@ def test_pipelined_downloads_match_the_blocking_one():
         dp.collect_download(0)
 
 
+def test_one_wait_per_plan_keeps_every_plan_exact():
+    """update() waits for the device once per plan: a re-parameterisation (dt_start moves every cycle in tpl) only
+    enqueues the new action table, path and start state go through a page-locked staging buffer without a wait.
+    Ten cycles with a changing dt_start, path and start state, each against the oracle; then the staging buffer
+    reused before anything waited (upload twice), and a download repeated."""
+    S, V, A, T = 201, 37, 20, 6
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
+    env = tpl_amd.DynProgEnvironment()
+    dp = tpl_amd.DynProgLonPlanner()
+    p = sc.lon_params(S, V, A, T)
+    base = sc.straight_path(p.path_steps, p.path_step_size)
+    for k in range(10):
+        p.dt_start = 1.0 - 0.07 * k
+        ep.dt_start = p.dt_start
+        path = base.copy()
+        path[:, 5] = 13.9 - 0.3 * k                          # speed limit of the cycle
+        init = sc.initial_state(0.5 * k, 6.0 + 0.4 * k, 0.1 * (k % 3))
+        env.reinit_buffers(ep)
+        env.set_occ_map(occ)
+        dp.reinit_buffers(p)
+        got = _traj_np(dp.update(init, path, env))
+        tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, [init])
+        assert np.array_equal(got.view(np.uint32), otrajs[0].view(np.uint32)), k
+        if k in (0, 9):
+            _assert_tables_equal(dp, tables, T)
+    other = sc.initial_state(3.0, 11.0, -0.5)
+    dp.upload([init], path)
+    dp.upload([other], path)                                 # the staging buffer of the first upload is still in flight
+    dp.plan_resident(env)
+    first = _traj_np(dp.download()[0])
+    again = _traj_np(dp.download()[0])
+    _, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, [other])
+    assert np.array_equal(first.view(np.uint32), otrajs[0].view(np.uint32))
+    assert np.array_equal(again.view(np.uint32), first.view(np.uint32))
+
+
 def test_unbounded_inputs_take_the_two_pass_kernel_and_still_match():
     """The two-stations-per-lane sweep keeps a running lexicographic argmin, which the host only
     selects for finite inputs below 1e6 (no NaN can arise); anything else runs the two-pass kernel.
