@@ -117,26 +117,23 @@ class Params:
 
     def __getattr__(self, name):
         o = object.__getattribute__(self, "_o")
-        try:
-            i = o._pnames.index(name)
-        except ValueError:
-            raise AttributeError(name) from None
+        i = o._pindex.get(name)
+        if i is None:
+            raise AttributeError(name)
         if o._pis_array[i]:
             return o._get_param_array(i)
-        v = np.ctypeslib.as_array(o._lib.tplhip_ilqr_param_scalar_ptr(o._h, i), shape=(o._batch,))
+        v = o._pscalar_view(i)
         return float(v[0]) if o._batch == 1 else v
 
     def __setattr__(self, name, value):
         o = self._o
-        try:
-            i = o._pnames.index(name)
-        except ValueError:
-            raise AttributeError(f"Params has no attribute {name!r}") from None
+        i = o._pindex.get(name)
+        if i is None:
+            raise AttributeError(f"Params has no attribute {name!r}")
         if o._pis_array[i]:
             o._set_param_array(i, value)
         else:
-            v = np.ctypeslib.as_array(o._lib.tplhip_ilqr_param_scalar_ptr(o._h, i), shape=(o._batch,))
-            v[...] = value
+            o._pscalar_view(i)[...] = value
 
     def __getstate__(self):
         return {n: (np.array(getattr(self, n)) if self._o._pis_array[i] else getattr(self, n))
@@ -172,6 +169,9 @@ class Optim:
         d(self, "_dims", (x.value, u.value, c.value))
         d(self, "_pnames", [lib.tplhip_ilqr_param_name(i).decode() for i in range(n.value)])
         d(self, "_pis_array", [bool(lib.tplhip_ilqr_param_is_array(i)) for i in range(n.value)])
+        d(self, "_pindex", {name: i for i, name in enumerate(self._pnames)})
+        d(self, "_dyn_buf", None)
+        d(self, "_pscalars", {})             # views of the scalar parameters' host mirrors ([batch] doubles, fixed for the solver's life)
         d(self, "_params", Params(self))
         d(self, "_defaults", dict(defaults or {}))
         d(self, "_sc", np.ctypeslib.as_array(lib.tplhip_ilqr_scalars(h), shape=(int(batch), len(SCALARS))))
@@ -311,18 +311,29 @@ class Optim:
     def shift(self, amount):
         _check(self._lib, self._lib.tplhip_ilqr_shift(self._h, int(amount)))
 
+    def _pscalar_view(self, i):
+        v = self._pscalars.get(i)
+        if v is None:
+            v = np.ctypeslib.as_array(self._lib.tplhip_ilqr_param_scalar_ptr(self._h, i), shape=(self._batch,))
+            self._pscalars[i] = v
+        return v
+
     def _dyn(self, fn, x, u, t, dt, problem=0):
         X, U, _ = self._dims
-        x = np.ascontiguousarray(x, dtype=np.float64)
-        u = np.ascontiguousarray(u, dtype=np.float64)
-        if x.shape != (X,):
-            raise ValueError(f'Expected "x_arr" with shape ({X}), but found {x.shape}')
-        if u.shape != (U,):
-            raise ValueError(f'Expected "u_arr" with shape ({U}), but found {u.shape}')
-        out = np.empty(X, dtype=np.float64)
-        _check(self._lib, fn(self._h, int(problem), x.ctypes.data_as(_dp), u.ctypes.data_as(_dp),
-                             int(t), float(dt), out.ctypes.data_as(_dp)))
-        return out
+        buf = self._dyn_buf
+        if buf is None:                     # argument buffers with their pointers made once (a controller calls this ten times a tick)
+            bx, bu, bo = np.empty(X), np.empty(U), np.empty(X)
+            buf = (bx, bu, bo, bx.ctypes.data_as(_dp), bu.ctypes.data_as(_dp), bo.ctypes.data_as(_dp))
+            object.__setattr__(self, "_dyn_buf", buf)
+        shape_x, shape_u = np.shape(x), np.shape(u)
+        if shape_x != (X,):
+            raise ValueError(f'Expected "x_arr" with shape ({X}), but found {shape_x}')
+        if shape_u != (U,):
+            raise ValueError(f'Expected "u_arr" with shape ({U}), but found {shape_u}')
+        buf[0][:] = x
+        buf[1][:] = u
+        _check(self._lib, fn(self._h, int(problem), buf[3], buf[4], int(t), float(dt), buf[5]))
+        return buf[2].copy()
 
     def dynamics(self, x, u, t, dt, problem=0):
         return self._dyn(self._lib.tplhip_ilqr_dynamics, x, u, t, dt, problem)
