@@ -352,6 +352,54 @@ def test_one_wait_per_plan_keeps_every_plan_exact():
     assert np.array_equal(again.view(np.uint32), first.view(np.uint32))
 
 
+def test_two_threads_with_their_own_engines():
+    """Different engine objects may be driven from different threads (own non-blocking streams, thread-local error
+    slot and bounce buffer; ctypes releases the GIL during the calls): two threads, each with its own environment
+    and planner on a different grid, 12 plans each, concurrently -- every plan equals the oracle's."""
+    import threading
+    cases = [(201, 37, 20, 6, sc.OBSTACLES_OVERTAKE_TRAFFIC, 7.0), (128, 24, 16, 5, sc.OBSTACLES_OVERTAKE, 10.0)]
+    want, jobs = [], []
+    for S, V, A, T, obst, v0 in cases:
+        p = sc.lon_params(S, V, A, T)
+        ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+        path = sc.straight_path(p.path_steps, p.path_step_size)
+        occ = sc.occ_map(ep, obst)
+        inits = [sc.initial_state(1.0 * k, v0 + 0.25 * k, 0.0) for k in range(12)]
+        _, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, inits)
+        want.append(otrajs)
+        jobs.append((p, ep, path, occ, inits))
+    got, errors = [None, None], []
+    start = threading.Barrier(2)
+
+    def work(i):
+        try:
+            p, ep, path, occ, inits = jobs[i]
+            env = tpl_amd.DynProgEnvironment()
+            env.reinit_buffers(ep)
+            env.set_occ_map(occ)
+            dp = tpl_amd.DynProgLonPlanner()
+            dp.reinit_buffers(p)
+            start.wait()
+            out = []
+            for ini in inits:
+                out.append(_traj_np(dp.update(ini, path, env)))
+                env.get_occ_map()                            # a staged device-to-host copy between the plans
+            got[i] = out
+        except Exception as e:                               # noqa: BLE001 -- reported by the main thread
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    for i in range(2):
+        assert got[i] is not None, f"thread {i} did not finish"
+        for k, tr in enumerate(got[i]):
+            assert np.array_equal(tr.view(np.uint32), want[i][k].view(np.uint32)), (i, k)
+
+
 def test_unbounded_inputs_take_the_two_pass_kernel_and_still_match():
     """The two-stations-per-lane sweep keeps a running lexicographic argmin, which the host only
     selects for finite inputs below 1e6 (no NaN can arise); anything else runs the two-pass kernel.
