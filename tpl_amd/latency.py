@@ -24,7 +24,9 @@ def mpc_closed_loop(device=0, ticks=1000, horizon=20):
     opt.horizon = horizon
     controls, trace, con = minisim.closed_loop(opt, ticks=ticks)
     lat = np.array(con.solve_ms[10:])
+    tick = np.array(con.tick_ms[10:])
     return {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+            "controller_tick_p50_ms": float(np.percentile(tick, 50)), "controller_tick_p99_ms": float(np.percentile(tick, 99)),
             "mean_iterations": float(np.mean(opt.iterations)), "ticks": int(len(lat)),
             "final_lateral_error_m": float(abs(trace[-1, 1])), "final_speed_mps": float(trace[-1, 3]),
             "what": f"Optim.update() of trajectory_tracking_mpc, batch 1, N={horizon}, HEUN, <=20 iterations, inside the "

@@ -83,7 +83,9 @@ def _no_lock():
 def closed_loop(opt, ticks=1000, dt=0.01, int_step=0.005, horizon=None, **ego_kw):
     """``ticks`` controller cycles of ``dt`` (the default scenario's fixed_time_step 0.01 s, integration sub-step
     0.005 s) of the MPC plugin on solver ``opt``: returns the per-tick controls, the ego trace (x, y, yaw, v) and the
-    controller, whose ``solve_ms`` lists the wall time of every ``Optim.update()``."""
+    controller, whose ``solve_ms`` lists the wall time of every ``Optim.update()`` and ``tick_ms`` that of every whole
+    ``ModelPredictiveController.update`` (reference look-up, dead-time prediction, bounds and weights, the solve, the
+    read-out)."""
     from .control import ModelPredictiveController
     ego = EgoSim(**ego_kw)
     shared = SimpleNamespace()
@@ -91,7 +93,7 @@ def closed_loop(opt, ticks=1000, dt=0.01, int_step=0.005, horizon=None, **ego_kw
     shared.params.horizon = int(horizon if horizon is not None else opt.horizon)
     for name, weight in DEFAULT_VEHICLE_WEIGHTS.items():
         setattr(shared.params.cost_function, name, weight)
-    con.solve_ms = []
+    con.solve_ms, con.tick_ms = [], []
     solve = opt.update
 
     def timed_update():
@@ -106,7 +108,9 @@ def closed_loop(opt, ticks=1000, dt=0.01, int_step=0.005, horizon=None, **ego_kw
     for k in range(ticks):
         veh = SimpleNamespace(x=ego.x, y=ego.y, phi=ego.yaw, delta=ego.steer_angle, v=ego.v, a=ego.a, pitch=0.0,
                               wheel_base=ego.wheel_base, delta_max=ego.max_steer_angle, dead_time_steer=ego.steer_dead_time)
+        t_tick = time.perf_counter()
         (acc, steer), _ = con.update(SimpleNamespace(t=t, vehicle=veh, trajectory=plan))
+        con.tick_ms.append((time.perf_counter() - t_tick) * 1e3)
         ego.control_acc, ego.control_steer = acc, steer
         for _ in range(sub):
             ego.step(t, dt / sub)
