@@ -1864,7 +1864,9 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         }
         const int n_cu = h->n_cu;
         const size_t waves = (size_t)h->nblocks * (threads / 64);
-        h->kchunk = (waves <= (size_t)n_cu * 4 * 8) ? 3 : 1;
+        // (measured per grid with tools/plan_time_grid.py: at 4096 waves the three-per-pass kernel wins by 10 %, at 8192
+        // the two-rows-per-lane sweep by 7 %)
+        h->kchunk = (waves <= (size_t)n_cu * 4 * 6) ? 3 : 1;
     }
     if (threads * 16 * 3 + path_lds > lds_max) h->kchunk = 1;
     if (const char* ov = std::getenv("TPLHIP_KCHUNK")) {       // tuning override: 9, 3 or 1
