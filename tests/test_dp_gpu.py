@@ -84,6 +84,27 @@ def test_tables_and_trajectories_bit_exact(S, V, A, T, obst, dt_start, request):
         assert np.array_equal(got.view(np.uint32), otrajs[r].view(np.uint32)), (r, got, otrajs[r])
 
 
+@pytest.mark.parametrize("S,V,A,T,dt_start", [(201, 37, 20, 10, None), (201, 37, 20, 6, 0.6), (128, 64, 32, 5, None),
+                                              (70, 9, 7, 4, 0.3), (256, 12, 6, 3, None), (33, 3, 2, 3, None)])
+def test_small_grid_forms_agree_bit_for_bit(S, V, A, T, dt_start, monkeypatch):
+    """Grids that leave the chip mostly empty have two sweeps: k_backward (scalar-operand instruction stream, two-pass
+    argmin; TPLHIP_S3=0) and k_backward3s (plain-fp32 stream, integer-key argmin; the default).  Each against the
+    oracle, tables and trajectories as raw bits."""
+    p = sc.lon_params(S, V, A, T, dt_start=dt_start)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31, dt_start=dt_start)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
+    inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(3, seed=11)
+    for form in ("3", "0"):
+        monkeypatch.setenv("TPLHIP_S3", form)
+        dp, env, trajs, tables, otrajs, dist = _run_both(p, ep, path, occ, inits)
+        info = dp.info()
+        assert info["cells"] == 1 and info["s3"] == int(form), info
+        _assert_tables_equal(dp, tables, T)
+        for r, tr in enumerate(trajs):
+            assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (form, r)
+
+
 def test_fuzz_sample():
     """A short sample of the randomised soak (tests/fuzz_dp.py; the long run is a tool, not a test)."""
     import fuzz_dp

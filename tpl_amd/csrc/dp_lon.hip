@@ -1187,6 +1187,8 @@ struct tplhip_dp_lon {
     bool vp_ok = false;                  // the two-rows-per-lane geometry of k_backward2v fits this grid (v_steps % 16 == 0)
     bool v3_ok = false;                  // ... that of k_backward3v (any v_steps)
     int v3_grid = 0;
+    int s3_kc = 0, s3_grid = 0;          // k_backward3s (grids that leave the chip mostly empty): actions per round (0 = not used), grid
+    size_t s3_lds = 0;
 
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1360,6 +1362,26 @@ void launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
     launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
 }
 
+bool launch_backward3s_(tplhip_dp_lon* h, int idx_t, int nx)
+{
+    const size_t S = (size_t)h->params.s_steps;
+    SweepArgs a;
+    a.next = h->d_tables + (size_t)nx * h->table_cells;
+    a.out = h->d_tables + (size_t)idx_t * h->table_cells;
+    a.acts = h->d_acts;
+    a.path = h->d_path;
+    a.pre_vmax = h->d_pre_vmax + (size_t)idx_t * S;
+    a.pre_sdist = h->d_pre_sdist + (size_t)idx_t * S;
+    a.pre_prog = h->d_pre_prog;
+    a.p = h->params;
+    a.s_pad = h->vp_s_pad;
+    a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->rcp_path_lo;
+    a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
+    a.tile_v = h->tile_v; a.tile_a = h->tile_a;
+    a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
+    return launch_backward3s(h->path_div3, h->range_div3, h->s3_kc, a, dim3(h->s3_grid, 1), h->s3_lds, h->stream);
+}
+
 // the terminal stage of the two-station geometry: k_backward<true> with one station per lane
 void launch_terminal(tplhip_dp_lon* h, int idx_t)
 {
@@ -1411,6 +1433,8 @@ void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
         else launch_exact<DIVMODE>(h, i, nx);
     } else if (terminal) {
         launch_backward<true, 1, 0>(h, i, nx);                       // rule R4 (no division in it)
+    } else if (h->s3_kc && h->params_bounded && h->path_bounded && h->env_bounded && use_v3(h) && launch_backward3s_(h, i, nx)) {
+        // the plain-fp32 stream, one cell per lane
     } else if (h->kchunk == 9) {
         launch_backward<false, 9, DIVMODE>(h, i, nx);
     } else if (h->kchunk == 3) {
@@ -1914,6 +1938,21 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
             h->v3_ok = (vo ? std::atoi(vo) != 0 : true) && h->vp_s_pad <= 1024 && (h->tile_v % 2 == 0);
         }
     }
+    // Grids that leave the chip mostly empty (the kchunk = 3 class above) with rows of at most 256 lanes: k_backward3s,
+    // one cell per lane on the plain-fp32 instruction stream, three actions per barrier round (TPLHIP_S3=0: k_backward)
+    {
+        h->s3_kc = 0;
+        int want = 3;
+        if (const char* ov = std::getenv("TPLHIP_S3")) want = std::atoi(ov);
+        if (h->kchunk == 3 && h->vp_s_pad <= 256 && want == 3) {
+            h->s3_lds = backward3s_lds_bytes(want, h->vp_s_pad, p.path_steps);
+            int max_rows = 0;
+            for (int x = 0; x < 8; ++x)
+                max_rows = std::max(max_rows, ((((x + 1) * p.v_steps) >> 3) - ((x * p.v_steps) >> 3)) * p.a_steps);
+            h->s3_grid = 8 * max_rows;
+            if (h->s3_lds <= (size_t)64 * 1024) h->s3_kc = want;
+        }
+    }
     // Large grids (one action per barrier) run two stations per lane, see k_backward2.
     h->cells = 1;
     {
@@ -2195,12 +2234,13 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
     std::snprintf(buf, (size_t)n,
                   "{\"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
                   "\"div_mode\": %d, \"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"cells\": %d, "
-                  "\"bounded_inputs\": %d, \"vpair\": %d, \"v3\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\", \"fwd_overlap\": %d}",
+                  "\"bounded_inputs\": %d, \"vpair\": %d, \"v3\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\", \"fwd_overlap\": %d, \"s3\": %d}",
                   h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
                   h->div_mode, (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->cells,
                   (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0, (h->cells == 2 && h->vpair) ? 1 : 0,
                   (h->cells == 2 && h->v3_ok && use_v3(h) && h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
-                  h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0);
+                  h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0,
+                  (h->cells == 1 && h->s3_kc && use_v3(h) && h->params_bounded && h->path_bounded && h->env_bounded) ? h->s3_kc : 0);
     return TPLHIP_OK;
 }
 

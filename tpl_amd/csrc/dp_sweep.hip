@@ -331,6 +331,177 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     }
 }
 
+// ------------------------------------------------------------------------
+// k_backward3s: the plain-fp32 instruction stream of k_backward3v for grids that do NOT fill the chip (tpl's default
+// 201x37x20, 128x64x32): there a sweep is bound by how many instructions ONE SIMD has to issue for its two to four
+// wavefronts and by one workgroup's latency, not by loads.  One cell per lane (a row per workgroup: the shortest
+// chain per wavefront), KC = 3 actions per barrier round (their row loads requested together), the same arithmetic in
+// the same order and the same integer-key argmin as k_backward3v -- k_backward's work at ~2.5 instead of ~4.5 cycles
+// per instruction.
+// ------------------------------------------------------------------------
+template <int PATH_DIV, int RANGE_DIV, int KC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, const ActDesc* __restrict__ acts,
+              const float* __restrict__ path_all, const float* __restrict__ pre_vmax_all,
+              const float* __restrict__ pre_sdist_all, const double* __restrict__ pre_prog, SweepArgs a)
+{
+    static_assert(N_BWD % KC == 0, "the chunks cover the actions exactly");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const TplDpLonParams& p = a.p;
+    const int S = p.s_steps, V = p.v_steps, A = p.a_steps;
+    const int nrows = V * A;
+    const int is = threadIdx.x;
+    const int s_pad = a.s_pad;
+    const size_t scn = blockIdx.y;
+    const Node* __restrict__ next = next_all + scn * a.stride_tables;
+    Node* __restrict__ out = out_all + scn * a.stride_tables;
+    const float* __restrict__ pre_vmax = pre_vmax_all + scn * a.stride_pre;
+    const float* __restrict__ pre_sdist = pre_sdist_all + scn * a.stride_pre;
+    const float* __restrict__ path = path_all + scn * a.stride_path;
+
+    // traversal: k_backward's (XCD = blockIdx.x & 7 owns a v range, strips of tile_v rows walked a-major)
+    const int xcd = blockIdx.x & 7;
+    const int v_lo = (xcd * V) >> 3, v_hi = ((xcd + 1) * V) >> 3;
+    const int vx = v_hi - v_lo, tv = max(1, a.tile_v);
+    const int q = (int)(blockIdx.x >> 3);
+    if (q >= vx * A) return;
+    int ia, iv;
+    {
+        const int full = vx / tv;
+        int strip = q / (A * tv), w = tv, rem = q - strip * (A * tv);
+        if (strip >= full) { strip = full; w = vx - full * tv; rem = q - full * (A * tv); }
+        const int tile = rem / (a.tile_a * w);
+        const int r = rem - tile * (a.tile_a * w);
+        ia = tile * a.tile_a + r / w;
+        iv = v_lo + strip * tv + (r - (r / w) * w);
+    }
+    const int row0 = ia * V + iv;
+    const bool active = is < S;
+    const int js = min(is, S - 1);
+
+    // LDS: float4 R[KC actions][s_pad + 1] | float dsc[9][8] | float pv[path_steps + 1]
+    const int row_slots = s_pad + 1;
+    v4f* R = reinterpret_cast<v4f*>(smem);
+    float* dsc = reinterpret_cast<float*>(smem + (size_t)KC * row_slots * sizeof(v4f));
+    float* pv = dsc + N_BWD * 8;
+    const ActDesc* __restrict__ d0 = acts + (size_t)row0 * N_BWD;
+    for (int i = is; i < N_BWD * 8; i += blockDim.x) dsc[i] = reinterpret_cast<const float*>(d0 + (i >> 3))[i & 7];
+    for (int i = is; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];
+
+    const float s = p.s_min + (float)js * p._s_step_size;
+    const float acc = p.a_min + (float)ia * p._a_step_size;
+    const float v_max = pre_vmax[js];
+    const float s_dist = pre_sdist[js];
+    const double prog = pre_prog[js];
+    float sc, sg;
+    double sd_base;
+    {
+        float c0 = 0.0f;
+        c0 += p.w_a * (acc * acc);
+        const float x = (float)((double)c0 + prog);
+        const float v = p.v_min + (float)iv * p._v_step_size;
+        const float gap = (v * p.time_gap + p.gap_min) - s_dist;
+        sc = (float)((double)x + (double)p.w_safety_dist * fmax(0.0, (double)gap));
+        sg = 0.0f; if (v > v_max) sg += v - v_max;
+        sd_base = (double)(s + d0[0].vdt) + d0[0].a_term;
+    }
+    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<Node*>(next), 0, (int)((size_t)nrows * S * sizeof(Node)), 0x00020000);
+    const unsigned voff = (unsigned)js * 12u, row_bytes = (unsigned)S * 12u;
+    auto load_row = [&](int r) -> Node3 {
+        const v3f x = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(next_rsrc, (int)voff, (int)((unsigned)r * row_bytes), 0));
+        return Node3{x.x, x.y, x.z};
+    };
+    const float s_min_v = in_vgpr(p.s_min);
+    const float s_scale = (float)(S - 1);
+    const float s_scale_v = in_vgpr(s_scale);
+    const float rr_hi = in_vgpr(a.rcp_range_hi), rr_lo = in_vgpr(a.rcp_range_lo);
+    const float rp_hi = in_vgpr(a.rcp_path_hi), rp_lo = in_vgpr(a.rcp_path_lo);
+    const float w_snap_v = in_vgpr(p.w_snap);
+    const float path_top = (float)(p.path_steps - 1);
+    const bool dup_last = is == S - 1;
+    unsigned long long best = 0x7f8000007f800000ull;
+    int bk = 0;
+    const v4f* dsc4 = reinterpret_cast<const v4f*>(dsc);
+
+#pragma unroll
+    for (int k0 = 0; k0 < N_BWD; k0 += KC) {
+        // ---- phase 1: the four rows of each of the KC actions, requested together; then a-blend, v-blend
+        Node3 r00[KC], r10[KC], r01[KC], r11[KC];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const ActDesc& x = d0[k0 + kk];
+            r00[kk] = load_row(x.r00); r10[kk] = load_row(x.r10);
+            r01[kk] = load_row(x.r01); r11[kk] = load_row(x.r11);
+        }
+        if (k0 > 0) asm volatile("s_barrier" ::: "memory");          // the row buffers of the last chunk are read
+        else __syncthreads();                                         // descriptors and path limits are in LDS
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const v4f w = dsc4[(k0 + kk) * 2];
+            const Node3 b0 = lerp3(r00[kk], r10[kk], w.x, w.y);
+            const Node3 b1 = lerp3(r01[kk], r11[kk], w.x, w.y);
+            const Node3 r = lerp3(b0, b1, w.z, w.w);
+            v4f* Rk = R + kk * row_slots;
+            *reinterpret_cast<v3f*>(Rk + is) = (v3f){r.c, r.g, r.j};
+            if (dup_last) *reinterpret_cast<v3f*>(Rk + S) = (v3f){r.c, r.g, r.j};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ---- phase 2: successor station, 1-D blend along s, costs, argmin (k_backward3v's, one cell)
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const int k = k0 + kk;
+            int kv = k;
+            asm volatile("" : "+v"(kv));
+            const ActDesc& e = d0[k];
+            const v4f u = dsc4[k * 2 + 1];
+            const v4f* Rk = R + kk * row_slots;
+            const double sd = sd_base + e.j_term;                    // lonDynamics station part, lon_planner.cu:244
+            const float tn_s = fmaxf(s, (float)sd);
+            const float xs = tn_s - s_min_v;
+            const float qs = div_const<RANGE_DIV>(xs, rr_hi, rr_lo);
+            const float cs = qs * s_scale_v + 0.5f;
+            const float xb = cs - 0.5f;
+            const float fl = floorf(xb);
+            const float fr = xb - fl;
+            const float ws = (fr + 32768.0f) - 32768.0f;
+            const float iws = 1.0f - ws;
+            const int off = (int)(fminf(fl, s_scale) * 16.0f);
+            const v4f nl = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off);
+            const v4f nh = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off + 16);
+            asm volatile("" :: "v"(nl.w), "v"(nh.w));
+            const float nc = fmaf(nh.x, ws, nl.x * iws);
+            const float ng = fmaf(nh.y, ws, nl.y * iws);
+            const float nj = fmaf(nh.z, ws, nl.z * iws);
+            const float alpha = div_const<PATH_DIV>(tn_s, rp_hi, rp_lo);
+            const float f0 = fminf(floorf(alpha), path_top);
+            const float pa = alpha - f0;
+            const float pia = 1.0f - pa;
+            const int t4 = (int)(f0 * 4.0f);
+            const float pv0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4);
+            const float pv1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4 + 4);
+            const float vmn = pv0 * pia + pv1 * pa;
+            float c = sc + nc;
+            float g = sg + ng;
+            const float dj = nj - u.x;
+            c += w_snap_v * (dj * dj);
+            g = (float)((double)g + fmax(e.tn_v_d - (double)vmn, 0.0));
+            const float s_change = tn_s - s;
+            g += fmaxf(s_change - s_dist, 0.0f);
+            c += u.y;
+            g += u.z;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(g) << 32) | __float_as_uint(c);
+            const bool better = key < best;
+            best = better ? key : best;
+            bk = better ? kv : bk;
+            asm volatile("" : "+v"(best), "+v"(bk));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (active)
+        st_node(out + (size_t)row0 * S + is, __uint_as_float((unsigned)best), __uint_as_float((unsigned)(best >> 32)), action_jerk(p, bk, N_BWD));
+}
+
 } // namespace
 
 size_t backward3v_lds_bytes(int s_pad, int path_steps)
@@ -348,6 +519,29 @@ bool launch_backward3v(int path_div, int range_div, const SweepArgs& a, dim3 gri
     if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3>);
     if (path_div == 4 && range_div == 4) return go(k_backward3v<4, 4>);
     if (path_div == 3 && range_div == 4) return go(k_backward3v<3, 4>);
+    return false;
+}
+
+size_t backward3s_lds_bytes(int kc, int s_pad, int path_steps)
+{
+    return (size_t)kc * (s_pad + 1) * 16 + (size_t)N_BWD * 8 * sizeof(float) + sizeof(float) * ((size_t)path_steps + 1);
+}
+
+// one row per workgroup of a.s_pad <= 256 lanes, grid = 8 * (rows of the widest XCD share); kc = 3 (all nine actions per round
+// was built too: 128 registers with spills, 0.22 against 0.16 ms per default-grid plan)
+bool launch_backward3s(int path_div, int range_div, int kc, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
+{
+    if (a.s_pad > 256 || lds_bytes > 64 * 1024) return false;
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, dim3(a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
+        return true;
+    };
+    if (kc == 3) {
+        if (path_div == 4 && range_div == 3) return go(k_backward3s<4, 3, 3>);
+        if (path_div == 3 && range_div == 3) return go(k_backward3s<3, 3, 3>);
+        if (path_div == 4 && range_div == 4) return go(k_backward3s<4, 4, 3>);
+        if (path_div == 3 && range_div == 4) return go(k_backward3s<3, 4, 3>);
+    }
     return false;
 }
 
