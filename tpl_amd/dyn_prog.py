@@ -9,6 +9,7 @@ in ``libtplhip.so`` on the GPU; nothing here computes on the CPU.
 """
 
 import ctypes as C
+import sys
 import weakref
 
 import numpy as np
@@ -230,6 +231,28 @@ class RefLine:
         return out
 
 
+class _ResultPool:
+    """Result arrays whose memory is recycled once every holder has dropped them.  The environment plugin fetches a
+    2.8 MB image and two tables of 0.25 / 0.5 MB every cycle; a fresh numpy array of that size is fresh pages, ~700
+    page faults while it is filled.  An array is handed out again only when nothing but the pool refers to it (views
+    keep their base alive and count), so a caller cannot tell it from a new one."""
+
+    def __init__(self, depth=8):                 # three kinds of result per cycle, each alternating between two buffers
+        self._depth = depth
+        self._arrays = []
+
+    def take(self, shape, dtype):
+        for k in range(len(self._arrays)):
+            a = self._arrays[k]
+            if a.shape == shape and a.dtype == dtype and sys.getrefcount(a) == 3:     # the list, `a`, the argument
+                return a
+            del a
+        a = np.empty(shape, dtype=dtype)
+        self._arrays.append(a)
+        del self._arrays[:-self._depth]
+        return a
+
+
 class DynProgEnvironment:
     """tplcpp.DynProgEnvironment (bindings_dp_env.cu:53-105).
 
@@ -244,6 +267,7 @@ class DynProgEnvironment:
         self._h = C.c_void_p()
         self._lib = _capi.load()
         check(self._lib.tplhip_dp_env_create(int(device), C.byref(self._h)))
+        self._results = _ResultPool()
         self.params = DynProgEnvParams()
         self.ref_line = RefLine()
         self.reinit_buffers(self.params, True)          # env.cu:282-285
@@ -311,7 +335,7 @@ class DynProgEnvironment:
     def get_occ_map_cartesian(self):
         n = C.c_int()
         check(self._lib.tplhip_dp_env_cart_size(self._h, C.byref(n)))
-        img = np.zeros((n.value, n.value), dtype=np.uint32)
+        img = self._results.take((n.value, n.value), np.dtype(np.uint32))
         check(self._lib.tplhip_dp_env_get_occ_map_cartesian(self._h, img.ctypes.data_as(C.POINTER(C.c_uint32))))
         return img
 
@@ -324,14 +348,14 @@ class DynProgEnvironment:
         """np.vstack(np.moveaxis(get_occ_map(), 2, 0)) -- the time slices below each other, [t_steps * l_steps, s_steps]
         -- transposed on the device (what dp_env.py:185-186 publishes every cycle)."""
         p = self.params
-        out = np.empty((p.t_steps * p.l_steps, p.s_steps), dtype=np.float32)
+        out = self._results.take((p.t_steps * p.l_steps, p.s_steps), np.dtype(np.float32))
         check(self._lib.tplhip_dp_env_get_occ_map_slices(self._h, _fptr(out)))
         return out
 
     def get_dist_map_lon_slices(self):
         """np.vstack(np.moveaxis(get_dist_map_lon(), 2, 0)): [t_steps * l_steps, s_steps, 2] (dp_env.py:187-188)."""
         p = self.params
-        out = np.empty((p.t_steps * p.l_steps, p.s_steps, 2), dtype=np.float32)
+        out = self._results.take((p.t_steps * p.l_steps, p.s_steps, 2), np.dtype(np.float32))
         check(self._lib.tplhip_dp_env_get_dist_map_lon_slices(self._h, _fptr(out)))
         return out
 
