@@ -130,3 +130,28 @@ print("ok")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
+
+
+def test_result_pool_never_hands_out_an_array_somebody_holds():
+    """DynProgEnvironment's big getters recycle result arrays (tpl_amd/dyn_prog.py:_ResultPool): only arrays nobody
+    refers to any more -- directly or through a view -- come back."""
+    import numpy as np
+    from tpl_amd.dyn_prog import _ResultPool
+    pool = _ResultPool()
+    f32 = np.dtype(np.float32)
+    a = pool.take((4, 4), f32)
+    a[:] = 7.0
+    ida = id(a)
+    b = pool.take((4, 4), f32)
+    assert b is not a                                   # `a` is held by this test
+    view = a[1:]
+    del a
+    c = pool.take((4, 4), f32)
+    assert id(c) != ida and c is not b                  # a view keeps its base busy
+    assert float(view[0, 0]) == 7.0
+    del view
+    d = pool.take((4, 4), f32)
+    assert id(d) == ida                                 # released: recycled
+    assert pool.take((4, 5), f32).shape == (4, 5)       # other shapes get their own arrays
+    held = [pool.take((2, 2), f32) for _ in range(20)]  # more live results than the pool remembers: still all distinct
+    assert len({id(x) for x in held}) == 20
