@@ -248,6 +248,8 @@ def sweep_kernel_name(info):
         return "k_backward3v"
     if info.get("cells") == 2:
         return "k_backward2v" if info.get("vpair") else "k_backward2"
+    if info.get("s3"):
+        return "k_backward3s"
     return "k_backward"
 
 
