@@ -1131,6 +1131,7 @@ struct tplhip_dp_lon {
     // and below 1e6 in magnitude (see reinit).  Otherwise the plan runs k_backward<.., 1, ..> with
     // the geometry below.
     bool params_bounded = false, path_bounded = false, env_bounded = false;
+    bool bounded_but_dt_start = false;   // params_bounded without its test of dt_start (the one field tpl moves every cycle)
     bool use_buf = false;                // buffer loads: one stage table addressable with 32-bit byte offsets
     bool vpair = false;                  // k_backward2v (two rows per lane) instead of k_backward2
     int vp_s_pad = 0, vp_grid = 0;
@@ -1816,6 +1817,18 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     if (h->have_params && std::memcmp(ps, &h->params, sizeof(TplDpLonParams)) == 0) {
         return TPLHIP_OK;                                   // lon_planner.cu:288-290
     }
+    // tpl moves dt_start every cycle and nothing else: the action table, the launch geometry and the division proofs do
+    // not depend on it (k_build_actions integrates over params.dt; dt_start reaches the kernels as an argument)
+    if (h->have_params && h->d_tables) {
+        TplDpLonParams a = *ps, b = h->params;
+        a.dt_start = 0.0f; b.dt_start = 0.0f;
+        if (std::memcmp(&a, &b, sizeof a) == 0) {
+            h->params.dt_start = ps->dt_start;
+            h->params_bounded = h->bounded_but_dt_start && std::isfinite(ps->dt_start) && std::fabs(ps->dt_start) < 1e6f;
+            h->tables_valid = false;
+            return TPLHIP_OK;
+        }
+    }
     const bool resize = !h->have_params || !h->d_tables
         || ps->t_steps != h->params.t_steps || ps->s_steps != h->params.s_steps
         || ps->v_steps != h->params.v_steps || ps->a_steps != h->params.a_steps
@@ -1907,14 +1920,15 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     // most 1e5 of them), no infinity and hence no NaN can appear, and a running lexicographic argmin
     // is identical to the two-pass argmin of lon_planner.cu:153-170.
     {
-        const float vals[] = {p.s_min, p.s_max, p.v_min, p.v_max, p.a_min, p.a_max, p.j_min, p.j_max, p.dt_start, p.dt,
+        const float vals[] = {p.s_min, p.s_max, p.v_min, p.v_max, p.a_min, p.a_max, p.j_min, p.j_max, p.dt,
                               p.time_gap, p.gap_min, p.w_progress, p.w_a, p.w_j, p.w_snap, p.w_safety_dist,
                               p.path_step_size, p.width_veh, p.length_veh};
         bool ok = p.t_steps <= 100000;
         for (float v : vals) ok = ok && std::isfinite(v) && std::fabs(v) < 1e6f;
         // the two-station kernels also read the path's second tap as "the next slot": needs arclength >= 0
         ok = ok && p.s_min >= 0.0f && p.path_step_size > 0.0f;
-        h->params_bounded = ok;
+        h->bounded_but_dt_start = ok;
+        h->params_bounded = ok && std::isfinite(p.dt_start) && std::fabs(p.dt_start) < 1e6f;
         // k_backward3v orders (constraint, cost) by their bit patterns: needs both to be sums of terms >= +0
         bool nn = true;
         for (float w : {p.w_progress, p.w_a, p.w_j, p.w_snap, p.w_safety_dist}) nn = nn && !std::signbit(w);
