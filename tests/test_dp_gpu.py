@@ -336,19 +336,20 @@ def test_pipelined_downloads_match_the_blocking_one():
         dp.collect_download(0)
 
 
-def test_one_wait_per_plan_keeps_every_plan_exact():
+@pytest.mark.parametrize("S,V,A,T,cycles", [(201, 37, 20, 6, 10), (128, 64, 66, 4, 4)], ids=["small-grid-sweep", "two-rows-per-lane-sweep"])
+def test_one_wait_per_plan_keeps_every_plan_exact(S, V, A, T, cycles):
     """update() waits for the device once per plan: a re-parameterisation (dt_start moves every cycle in tpl) only
     enqueues the new action table, path and start state go through a page-locked staging buffer without a wait.
-    Ten cycles with a changing dt_start, path and start state, each against the oracle; then the staging buffer
+    Cycles with a changing dt_start (alone among the parameters: the action table is kept), path and start state, each
+    against the oracle, on a grid of each sweep family; then the staging buffer
     reused before anything waited (upload twice), and a download repeated."""
-    S, V, A, T = 201, 37, 20, 6
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
     occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
     env = tpl_amd.DynProgEnvironment()
     dp = tpl_amd.DynProgLonPlanner()
     p = sc.lon_params(S, V, A, T)
     base = sc.straight_path(p.path_steps, p.path_step_size)
-    for k in range(10):
+    for k in range(cycles):
         p.dt_start = 1.0 - 0.07 * k
         ep.dt_start = p.dt_start
         path = base.copy()
@@ -360,7 +361,7 @@ def test_one_wait_per_plan_keeps_every_plan_exact():
         got = _traj_np(dp.update(init, path, env))
         tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, [init])
         assert np.array_equal(got.view(np.uint32), otrajs[0].view(np.uint32)), k
-        if k in (0, 9):
+        if k in (0, cycles - 1):
             _assert_tables_equal(dp, tables, T)
     other = sc.initial_state(3.0, 11.0, -0.5)
     dp.upload([init], path)
