@@ -1188,6 +1188,7 @@ struct tplhip_dp_lon {
     bool vp_ok = false;                  // the two-rows-per-lane geometry of k_backward2v fits this grid (v_steps % 16 == 0)
     bool v3_ok = false;                  // ... that of k_backward3v (any v_steps)
     int v3_grid = 0;
+    int v4_ng = 1, v4_grid = 0;          // k_backward4: row pairs per workgroup (1 = k_backward3v), grid
     int s3_kc = 0, s3_grid = 0;          // k_backward3s (grids that leave the chip mostly empty): actions per round (0 = not used), grid
     size_t s3_lds = 0;
 
@@ -1360,7 +1361,10 @@ void launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
     a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
     a.tile_v = h->tile_v; a.tile_a = h->tile_a;
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
-    launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
+    if (h->v4_ng > 1)
+        launch_backward4(h->path_div3, h->range_div3, h->v4_ng, a, dim3(h->v4_grid, 1), backward4_lds_bytes(h->v4_ng, h->vp_s_pad, h->params.path_steps), h->stream);
+    else
+        launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
 }
 
 bool launch_backward3s_(tplhip_dp_lon* h, int idx_t, int nx)
@@ -1950,6 +1954,17 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
             for (int x = 0; x < 8; ++x) max_pairs = std::max(max_pairs, (((x + 1) * np) >> 3) - ((x * np) >> 3));
             h->v3_grid = 8 * max_pairs * p.a_steps;
             h->v3_ok = (vo ? std::atoi(vo) != 0 : true) && h->vp_s_pad <= 1024 && (h->tile_v % 2 == 0);
+            // k_backward4: ng pairs per workgroup
+            h->v4_ng = 1;
+            if (const char* ov = std::getenv("TPLHIP_NG")) h->v4_ng = std::atoi(ov);
+            while (h->v4_ng > 1 && (h->v4_ng * h->vp_s_pad > 1024 || backward4_lds_bytes(h->v4_ng, h->vp_s_pad, p.path_steps) > 64 * 1024)) h->v4_ng /= 2;
+            if (h->v4_ng != 2 && h->v4_ng != 4) h->v4_ng = 1;
+            if (h->v4_ng > 1) {
+                const int nvg = 2 * h->v4_ng, nu = (p.v_steps + nvg - 1) / nvg;
+                int max_units = 0;
+                for (int x = 0; x < 8; ++x) max_units = std::max(max_units, (((x + 1) * nu) >> 3) - ((x * nu) >> 3));
+                h->v4_grid = 8 * max_units * p.a_steps;
+            }
         }
     }
     // Grids that leave the chip mostly empty (the kchunk = 3 class above) with rows of at most 256 lanes: k_backward3s,
@@ -2414,8 +2429,12 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
             a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
             a.tile_v = h->tile_v; a.tile_a = h->tile_a;
             a.stride_tables = tab_stride; a.stride_pre = pre_stride; a.stride_path = path_stride;
-            launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, count),
-                              backward3v_lds_bytes(h->vp_s_pad, p.path_steps), h->stream);
+            if (h->v4_ng > 1)
+                launch_backward4(h->path_div3, h->range_div3, h->v4_ng, a, dim3(h->v4_grid, count),
+                                 backward4_lds_bytes(h->v4_ng, h->vp_s_pad, p.path_steps), h->stream);
+            else
+                launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, count),
+                                  backward3v_lds_bytes(h->vp_s_pad, p.path_steps), h->stream);
         } else {
             auto go = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(h->x_grid, count), dim3(h->x_s_pad * h->x_rpb), h->x_lds, h->stream,
