@@ -244,13 +244,7 @@ def dp_setup(grid, device):
 
 
 def sweep_kernel_name(info):
-    if info.get("v3"):
-        return "k_backward3v"
-    if info.get("cells") == 2:
-        return "k_backward2v" if info.get("vpair") else "k_backward2"
-    if info.get("s3"):
-        return "k_backward3s"
-    return "k_backward"
+    return info["sweep"]
 
 
 def mc_scenarios(ep, first, n):

@@ -50,18 +50,19 @@ GRID_CASES = [
     pytest.param(96, 10, 8, 6, (), 0.3, id="dt_start-0.3-rule-R4"),
     pytest.param(512, 8, 6, 4, sc.random_obstacles(7, 5), None, id="s512-kchunk3"),
     pytest.param(1000, 6, 5, 3, sc.random_obstacles(8, 5), None, id="s1000-kchunk1"),
-    # grids several residency rounds deep select the two-cells-per-lane kernels:
-    pytest.param(201, 48, 44, 4, sc.OBSTACLES_OVERTAKE_TRAFFIC, None, id="ragged-rows-two-rows-per-lane"),
-    pytest.param(201, 50, 42, 4, sc.random_obstacles(3, 6), 0.4, id="ragged-rows-two-stations-per-lane"),
-    pytest.param(256, 40, 52, 4, sc.OBSTACLES_OVERTAKE, None, id="full-rows-two-stations-per-lane"),
-    pytest.param(128, 64, 66, 3, sc.random_obstacles(9, 7), None, id="s128-two-rows-per-lane"),
+    # grids several residency rounds deep select the two-rows-per-lane sweep (k_backward3v):
+    pytest.param(201, 48, 44, 4, sc.OBSTACLES_OVERTAKE_TRAFFIC, None, id="ragged-rows-v48"),
+    pytest.param(201, 50, 42, 4, sc.random_obstacles(3, 6), 0.4, id="ragged-rows-v50-dt_start"),
+    pytest.param(256, 40, 52, 4, sc.OBSTACLES_OVERTAKE, None, id="full-rows-v40"),
+    pytest.param(128, 64, 66, 3, sc.random_obstacles(9, 7), None, id="s128-v64"),
     # an odd number of velocity rows: the last row pair of k_backward3v is row V-1 twice
     pytest.param(128, 37, 120, 3, sc.random_obstacles(5, 6), None, id="odd-v-steps-plain-fp32-sweep"),
 ]
 
-EXPECTED_KERNEL = {"ragged-rows-two-rows-per-lane": (2, 1), "ragged-rows-two-stations-per-lane": (2, 0),
-                   "full-rows-two-stations-per-lane": (2, 0), "s128-two-rows-per-lane": (2, 1),
-                   "odd-v-steps-plain-fp32-sweep": (2, 0)}
+EXPECTED_KERNEL = {"ragged-rows-v48": "k_backward3v", "ragged-rows-v50-dt_start": "k_backward3v", "full-rows-v40": "k_backward3v",
+                   "s128-v64": "k_backward3v", "odd-v-steps-plain-fp32-sweep": "k_backward3v",
+                   "reference-default-201x37x20": "k_backward3s", "tiny-33x9x7": "k_backward3s",
+                   "s512-kchunk3": "k_backward", "s1000-kchunk1": "k_backward"}
 
 
 @pytest.mark.parametrize("S,V,A,T,obst,dt_start", GRID_CASES)
@@ -76,8 +77,7 @@ def test_tables_and_trajectories_bit_exact(S, V, A, T, obst, dt_start, request):
     case = request.node.callspec.id
     if case in EXPECTED_KERNEL:
         info = dp.info()
-        assert (info["cells"], info["vpair"]) == EXPECTED_KERNEL[case], info
-        assert info["v3"] == 1, info                          # bounded inputs, power-of-two path step: the plain-fp32 sweep
+        assert info["sweep"] == EXPECTED_KERNEL[case], info    # bounded inputs, power-of-two path step: the plain-fp32 sweeps
     _assert_tables_equal(dp, tables, T)
     for r, tr in enumerate(trajs):
         got = _traj_np(tr)
@@ -88,18 +88,18 @@ def test_tables_and_trajectories_bit_exact(S, V, A, T, obst, dt_start, request):
                                               (70, 9, 7, 4, 0.3), (256, 12, 6, 3, None), (33, 3, 2, 3, None)])
 def test_small_grid_forms_agree_bit_for_bit(S, V, A, T, dt_start, monkeypatch):
     """Grids that leave the chip mostly empty have two sweeps: k_backward (scalar-operand instruction stream, two-pass
-    argmin; TPLHIP_S3=0) and k_backward3s (plain-fp32 stream, integer-key argmin; the default).  Each against the
+    argmin; TPLHIP_DEBUG=no_s3) and k_backward3s (plain-fp32 stream, integer-key argmin; the default).  Each against the
     oracle, tables and trajectories as raw bits."""
     p = sc.lon_params(S, V, A, T, dt_start=dt_start)
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31, dt_start=dt_start)
     path = sc.straight_path(p.path_steps, p.path_step_size)
     occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
     inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(3, seed=11)
-    for form in ("3", "0"):
-        monkeypatch.setenv("TPLHIP_S3", form)
+    for form in ("k_backward3s", "k_backward"):
+        monkeypatch.setenv("TPLHIP_DEBUG", "no_s3" if form == "k_backward" else "")
         dp, env, trajs, tables, otrajs, dist = _run_both(p, ep, path, occ, inits)
         info = dp.info()
-        assert info["cells"] == 1 and info["s3"] == int(form), info
+        assert info["big"] == 0 and info["sweep"] == form, info
         _assert_tables_equal(dp, tables, T)
         for r, tr in enumerate(trajs):
             assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (form, r)
@@ -274,15 +274,16 @@ def test_division_modes_agree(monkeypatch):
     tabs = {}
     for mode in ("fast", "ieee"):
         if mode == "ieee":
-            monkeypatch.setenv("TPLHIP_NO_FASTDIV", "1")
+            monkeypatch.setenv("TPLHIP_DEBUG", "no_fastdiv")
         env = tpl_amd.DynProgEnvironment()
         env.reinit_buffers(ep)
         env.set_occ_map(occ)
         dp = tpl_amd.DynProgLonPlanner()
         dp.reinit_buffers(p)
-        info = dp.info()
-        assert (info["div_mode"] == 0) == (mode == "ieee"), info
         dp.update(sc.initial_state(0.0, 8.0, 0.0), path, env)
+        info = dp.info()
+        assert info["sweep"] == ("k_backward" if mode == "ieee" else "k_backward3s"), info
+        assert (info["range_div3"] == 0) == (mode == "ieee"), info
         tabs[mode] = [dp.copy_table(t) for t in range(1, T)]
     for a, b in zip(tabs["fast"], tabs["ieee"]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
@@ -292,7 +293,7 @@ def test_division_modes_agree(monkeypatch):
     p2.path_steps = 667
     dp = tpl_amd.DynProgLonPlanner()
     dp.reinit_buffers(p2)
-    assert dp.info()["div_mode"] in (0, 1, 2)
+    assert dp.info()["path_div3"] in (0, 3, 4)
     path2 = sc.straight_path(p2.path_steps, p2.path_step_size)
     env = tpl_amd.DynProgEnvironment()
     env.reinit_buffers(ep)
@@ -444,7 +445,8 @@ def test_unbounded_inputs_take_the_two_pass_kernel_and_still_match():
         dp.reinit_buffers(p)
         trajs = dp.update_batch(init, path, env)
         info = dp.info()
-        assert info["cells"] == 2 and info["bounded_inputs"] == bounded, info
+        assert info["big"] == 1 and info["bounded_inputs"] == bounded, info
+        assert info["sweep"] == ("k_backward3v" if bounded else "k_backward"), info
         tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, init)
         _assert_tables_equal(dp, tables, T)
         assert np.array_equal(_traj_np(trajs[0]).view(np.uint32), otrajs[0].view(np.uint32))

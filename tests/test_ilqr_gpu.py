@@ -187,11 +187,11 @@ def test_long_horizon_and_per_problem_parameters():
 def test_ragged_horizons_match_oracle(horizon, t_cap, lds_kb, want_lds, monkeypatch):
     """Horizons that are not a multiple of the rollout ring (8 stages) and BOTH homes of the trajectory mirrors.
     A single problem has a compute unit to itself, so its mirrors sit in LDS even at the default capacity of 299
-    stages (70 KB); TPLHIP_ILQR_LDS_KB forces the budget of a chip-filling batch (39 KB) or less, which leaves them
+    stages (70 KB); TPLHIP_DEBUG=ilqr_lds_kb=N forces the budget of a chip-filling batch (39 KB) or less, which leaves them
     in global memory.  The residency is asserted, not assumed (tplhip_ilqr_info).  60 stages no longer fit the cost
     block into the LDS ring."""
     if lds_kb is not None:
-        monkeypatch.setenv("TPLHIP_ILQR_LDS_KB", str(lds_kb))
+        monkeypatch.setenv("TPLHIP_DEBUG", f"ilqr_lds_kb={lds_kb}")
     make = _factory("trajectory_tracking_mpc")
     opt = make(horizon=horizon, t_cap=t_cap) if t_cap else make()
     ref = OI.OracleOptim("trajectory_tracking_mpc")

@@ -31,4 +31,4 @@ for k in range(plans):
     dp.update(init, path, env)
     lat.append((time.perf_counter() - t0) * 1e3)
 info = dp.info()
-print(f"{S}x{V}x{A} x {T}: p50 {np.percentile(lat[5:], 50):.3f} ms  = {np.percentile(lat[5:], 50) * 1e3 / (T - 1):.2f} us per stage incl. everything; kchunk {info['kchunk']} cells {info['cells']} v3 {info['v3']}")
+print(f"{S}x{V}x{A} x {T}: p50 {np.percentile(lat[5:], 50):.3f} ms  = {np.percentile(lat[5:], 50) * 1e3 / (T - 1):.2f} us per stage incl. everything; kchunk {info['kchunk']} sweep {info['sweep']}")

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "dp_lon_internal.h"
+#include "tplhip_debug.h"
 #include "tplhip_common.h"
 #include "dp_env_internal.h"
 
@@ -124,12 +125,9 @@ __global__ void k_stage_prelude(float* __restrict__ pre_vmax, float* __restrict_
 // KCHUNK actions are blended into LDS per barrier.
 // LDS: float4 R[KCHUNK][blockDim] | float path_vmax[path_steps]
 // ------------------------------------------------------------------------
-// DIVMODE selects how the two divisions by run-time constants are formed; every mode is
-// bit-identical to IEEE division (modes 1/2 only after k_verify_div proved it, see reinit):
-//   0  IEEE division for both
-//   1  station range: (float)((double)x * rcp_d);  path step: x*r with one residual correction
-//   2  both through the double product
-template <bool TERMINAL, int KCHUNK, int DIVMODE, bool USE_BUF>
+// This is the GENERAL sweep (any input: two-pass argmin, IEEE divisions); the plain-fp32 sweeps of dp_sweep.hip take
+// over wherever their preconditions hold.
+template <bool TERMINAL, int KCHUNK, bool USE_BUF>
 __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out,
                            const ActDesc* __restrict__ acts,
                            const float* __restrict__ path,
@@ -137,7 +135,6 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
                            const float* __restrict__ pre_sdist,   // this stage, [s_steps]
                            const double* __restrict__ pre_prog,   // [s_steps]
                            TplDpLonParams p, int s_pad, int rows_per_block, int nblocks,
-                           float rcp_path_step, double rcp_path_step_d, double rcp_s_range_d,
                            int tile_v, int tile_a,
                            size_t stride_tables, size_t stride_pre, size_t stride_path)
 {
@@ -275,7 +272,7 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
                 // readNode coordinate along s (lon_planner.cu:35).  tn_s >= s >= s_min, so the
                 // coordinate is never negative and only the upper clamp can bite.
                 const float xs = tn_s - p.s_min;
-                const float qs = (DIVMODE == 0) ? xs / s_range : (float)((double)xs * rcp_s_range_d);
+                const float qs = xs / s_range;
                 const float cs = qs * s_scale + 0.5f;         // == (float)((double)c + 0.5), see node_coord
                 const float xb = cs - 0.5f;
                 const float fl = floorf(xb);
@@ -285,9 +282,7 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
                 const float4* Rk = R + kk * blockDim.x + rib * s_pad;
                 const float4 node = lerp4(Rk[i_lo], Rk[i_hi], ws);
                 // interpPath(tn.s).v_max, lon_planner.cu:114
-                const float alpha = (DIVMODE == 0) ? tn_s / p.path_step_size
-                                  : (DIVMODE == 1) ? fast_div(tn_s, p.path_step_size, rcp_path_step)
-                                                   : (float)((double)tn_s * rcp_path_step_d);
+                const float alpha = tn_s / p.path_step_size;
                 const PathTap pt = path_tap_q(alpha, p.path_steps);
                 const float vmn = path_lerp(pt, pv[pt.i0], pv[pt.i1]);
 
@@ -334,501 +329,38 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
 }
 
 // ------------------------------------------------------------------------
-// Two stations per lane (the large-grid form of k_backward, one action per barrier).
-//
-// The sweep is bound by VALU issue, and about half of a cell's instructions are plain fp32
-// add / mul / fma.  gfx950 issues those two-wide (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32)
-// at the cost of one: a lane that owns the stations is and is + half of its row carries both
-// through the same instruction stream as a float2, and everything that is per (row, action)
-// -- descriptor scalars, row offsets, broadcast moves -- is paid once for two cells.  Each
-// component still sees exactly the operations of k_backward (no contraction, same order).
-// blockDim.x = half * rows_per_block with half = s_pad2 / 2, s_pad2 = s_steps rounded up to 128.
-// LDS: float4 R[2 buffers][rows_per_block][2*half + 1] | float path_vmax[path_steps]
+// Exhaustive check of the two cheap division forms of the plain-fp32 sweeps against the IEEE quotient for EVERY float
+// in [0, x_max] (all are odd-symmetric, so the sign is covered): ~1e9 candidates, about a millisecond, once per divisor.
+//  * fma(x, r_hi, x*r_lo) with r_hi + r_lo = 1/c to ~49 bits: the sum is within ~2^-47 of x/c before its one rounding,
+//    two plain fp32 instructions -- exact where no quotient of the range comes that close to a rounding boundary,
+//    which only the brute force can tell;
+//  * x * r_hi alone: exact for a power-of-two divisor.
+// A form is only used if its flag stays 0.
+// scale > 0 (the station-range divisor): the forms are compared on what the sweep derives from the quotient -- the
+// filter coordinate ((q * scale + 0.5) - 0.5, lon_planner.cu:35 + arr_tex_surf.cuh:142-149) -- not on the quotient
+// itself: for dividends below ~1e-34 their x * r_lo term underflows and the quotient's last bit can differ, but every
+// quotient below 2^-26 / scale yields the coordinate 0 either way.  scale == 0: raw quotients.
 // ------------------------------------------------------------------------
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f2 f2_floor(f2 x) { return (f2){floorf(x.x), floorf(x.y)}; }
-__device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-// HALF_CT > 0: rows are full (s_steps == 2 * HALF_CT), so the second station of a lane sits at a
-// compile-time distance from the first: its table and LDS addresses become immediate offsets of
-// the first station's (two registers and their arithmetic less -- the difference between 7 and 8
-// resident waves per SIMD, i.e. between 2.3 and exactly 2 residency rounds on 256x128x64).
-// HALF_CT == 0: ragged rows, distances and clamps at run time.
-template <int DIVMODE, bool USE_BUF, int HALF_CT>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) k_backward2(const Node* __restrict__ next, Node* __restrict__ out,
-                            const ActDesc* __restrict__ acts,
-                            const float* __restrict__ path,
-                            const float* __restrict__ pre_vmax,    // this stage, [s_steps]
-                            const float* __restrict__ pre_sdist,   // this stage, [s_steps]
-                            const double* __restrict__ pre_prog,   // [s_steps]
-                            TplDpLonParams p, int half_rt, int rows_per_block,
-                            float rcp_path_step, double rcp_path_step_d, double rcp_s_range_d,
-                            int tile_v, int tile_a)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    // traversal order: as k_backward
-    const int S = p.s_steps, V = p.v_steps, A = p.a_steps;
-    const int nrows = V * A;
-    const int tid = threadIdx.x;
-    const int half = HALF_CT ? HALF_CT : half_rt;
-    const int rib = tid / half;
-    const int il = tid - rib * half;
-    const int xcd = blockIdx.x & 7;
-    const int v_lo = (xcd * V) >> 3, v_hi = ((xcd + 1) * V) >> 3;
-    const int vx = v_hi - v_lo;
-    const int q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * rows_per_block + rib);
-    const bool row_ok = q < vx * A;
-    int ia = 0, iv = 0;
-    if (row_ok) {
-        const int full = vx / tile_v;
-        int strip = q / (A * tile_v), w = tile_v, rem = q - strip * (A * tile_v);
-        if (strip >= full) { strip = full; w = vx - full * tile_v; rem = q - full * (A * tile_v); }
-        const int tile = rem / (tile_a * w);
-        const int r = rem - tile * (tile_a * w);
-        ia = tile * tile_a + r / w;
-        iv = v_lo + strip * tile_v + (r - (r / w) * w);
-    }
-    const int row = ia * V + iv;
-
-    // the two stations of this lane; a station past the row end computes on the last one and
-    // is never stored (keeps the loads unconditional and the barriers uniform)
-    const int is0 = il, is1 = il + half;
-    const bool act0 = row_ok && (HALF_CT ? true : is0 < S), act1 = row_ok && (HALF_CT ? true : is1 < S);
-    const int js0 = HALF_CT ? is0 : min(is0, S - 1), js1 = HALF_CT ? is1 : min(is1, S - 1);
-
-    const f2 s = {p.s_min + (float)js0 * p._s_step_size, p.s_min + (float)js1 * p._s_step_size};
-    const float v = p.v_min + (float)iv * p._v_step_size;
-    const float a = p.a_min + (float)ia * p._a_step_size;
-
-    const f2 v_max = {pre_vmax[js0], pre_vmax[js1]};
-    const f2 s_dist = {pre_sdist[js0], pre_sdist[js1]};
-    const double prog0 = pre_prog[js0], prog1 = pre_prog[js1];
-
-    // stateCost lon_planner.cu:40-55
-    f2 sc;
-    {
-        float c0 = 0.0f;
-        c0 += p.w_a * (a * a);
-        const f2 gap = (v * p.time_gap + p.gap_min) - s_dist;
-        float x0 = (float)((double)c0 + prog0), x1 = (float)((double)c0 + prog1);
-        x0 = (float)((double)x0 + (double)p.w_safety_dist * fmax(0.0, (double)gap.x));
-        x1 = (float)((double)x1 + (double)p.w_safety_dist * fmax(0.0, (double)gap.y));
-        sc = (f2){x0, x1};
-    }
-    f2 sg;
-    sg.x = 0.0f; if (v > v_max.x) sg.x += v - v_max.x;
-    sg.y = 0.0f; if (v > v_max.y) sg.y += v - v_max.y;
-
-    float4* R = reinterpret_cast<float4*>(smem);
-    float* pv = reinterpret_cast<float*>(smem + (size_t)2 * (2 * half + 1) * rows_per_block * sizeof(float4));
-    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<Node*>(next), 0, USE_BUF ? (int)((size_t)nrows * S * sizeof(Node)) : 0, 0x00020000);
-    for (int i = tid; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];   // last sample twice
-
-    const float s_range = p.s_max - p.s_min;
-    const float s_scale = (float)(S - 1);
-    const float path_top = (float)(p.path_steps - 1);
-    // row buffer: stations 0..S-1 plus ONE duplicate of station S-1 at slot S, so the upper tap of
-    // the 1-D lerp, min(i_lo + 1, S - 1), is always the slot after the lower one and both come
-    // from one ds_read2.  Lanes past the row end recompute station S-1 into their own slots
-    // (slot S included when S < 2*half); when the row is full the lane of S-1 writes slot S too.
-    const int row_slots = 2 * half + 1;
-    const int buf_slots = row_slots * rows_per_block;      // one of the two alternating buffers
-    float4* Rrow = R + rib * row_slots;
-    const bool dup_last = HALF_CT ? (il == HALF_CT - 1) : ((is1 == S - 1) && (S == 2 * half));
-    // Running lexicographic argmin per station, (constr, cost, action), instead of keeping all nine
-    // results for the two passes of lon_planner.cu:153-170: 6 registers instead of 36, i.e. one more
-    // resident wave per SIMD.  A lower constraint value opens a new class (cost reset to +inf, action
-    // to 0, exactly the second pass' start values); inside the class the first strictly lower cost
-    // wins.  Identical to the two passes unless a constraint value is NaN -- excluded by the host for
-    // this kernel (tplhip_dp_lon::params_bounded / path_bounded).
-    float bg0 = INFINITY, bc0 = INFINITY, bg1 = INFINITY, bc1 = INFINITY;
-    int bk0 = 0, bk1 = 0;
-
-    // One barrier per action: two LDS row buffers alternate, and whoever writes buffer (k+1)&1 has
-    // passed barrier k, which every lane reaches only after its phase 2 of action k-1 -- the last
-    // reader of that buffer.  The barrier is a bare s_barrier behind an LDS-only wait.
-    // (Issuing the eight row loads of action k+1 before phase 2 of action k -- a software pipeline
-    // -- was measured and dropped: the 24 registers it holds cost two resident waves per SIMD,
-    // 51.4 vs 49.2 us per 256x128x64 sweep.)
-    float4 ld[8];
-    auto issue_loads = [&](int k) {
-        const ActDesc* d = acts + (size_t)row * N_BWD + k;
-        if (USE_BUF) {
-            const unsigned row_bytes = (unsigned)S * 12u;
-            const unsigned o0 = (unsigned)js0 * 12u, o1 = (unsigned)js1 * 12u;
-            const unsigned b00 = (unsigned)d->r00 * row_bytes, b10 = (unsigned)d->r10 * row_bytes;
-            const unsigned b01 = (unsigned)d->r01 * row_bytes, b11 = (unsigned)d->r11 * row_bytes;
-            ld[0] = buf_load_node(next_rsrc, o0, b00); ld[4] = buf_load_node(next_rsrc, o1, b00);
-            ld[1] = buf_load_node(next_rsrc, o0, b10); ld[5] = buf_load_node(next_rsrc, o1, b10);
-            ld[2] = buf_load_node(next_rsrc, o0, b01); ld[6] = buf_load_node(next_rsrc, o1, b01);
-            ld[3] = buf_load_node(next_rsrc, o0, b11); ld[7] = buf_load_node(next_rsrc, o1, b11);
-        } else {
-            const Node* r00 = next + (size_t)d->r00 * S; const Node* r10 = next + (size_t)d->r10 * S;
-            const Node* r01 = next + (size_t)d->r01 * S; const Node* r11 = next + (size_t)d->r11 * S;
-            ld[0] = ld_node(r00 + js0); ld[4] = ld_node(r00 + js1); ld[1] = ld_node(r10 + js0); ld[5] = ld_node(r10 + js1);
-            ld[2] = ld_node(r01 + js0); ld[6] = ld_node(r01 + js1); ld[3] = ld_node(r11 + js0); ld[7] = ld_node(r11 + js1);
-        }
-    };
-
-#pragma unroll
-    for (int k = 0; k < N_BWD; ++k) {
-        const ActDesc* d = acts + (size_t)row * N_BWD + k;
-        float4* Rk = Rrow + (k & 1) * buf_slots;
-        issue_loads(k);
-        // ---- phase 1: blend the four neighbouring next-stage rows (a, then v), both stations
-        {
-            const float wa = d->wa, iwa = d->iwa, wv = d->wv, iwv = d->iwv;
-            const float4 r0 = lerp4w(lerp4w(ld[0], ld[1], wa, iwa), lerp4w(ld[2], ld[3], wa, iwa), wv, iwv);
-            const float4 r1 = lerp4w(lerp4w(ld[4], ld[5], wa, iwa), lerp4w(ld[6], ld[7], wa, iwa), wv, iwv);
-            Rk[is0] = r0;
-            Rk[is1] = r1;
-            if (dup_last) Rk[S] = r1;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // ---- phase 2: successor station, 1-D lerp, costs -- the two stations as one float2
-        {
-            // lonDynamics station part, lon_planner.cu:244
-            const f2 sf = s + d->vdt;
-            double sd0 = (double)sf.x + d->a_term, sd1 = (double)sf.y + d->a_term;
-            sd0 = sd0 + d->j_term; sd1 = sd1 + d->j_term;
-            const f2 tn_s = {fmaxf(s.x, (float)sd0), fmaxf(s.y, (float)sd1)};
-            // readNode coordinate along s (lon_planner.cu:35); tn_s >= s >= s_min
-            const f2 xs = tn_s - p.s_min;
-            f2 qs;
-            if (DIVMODE == 0) qs = (f2){xs.x / s_range, xs.y / s_range};
-            else qs = (f2){(float)((double)xs.x * rcp_s_range_d), (float)((double)xs.y * rcp_s_range_d)};
-            const f2 cs = qs * s_scale + 0.5f;
-            const f2 xb = cs - 0.5f;
-            const f2 fl = f2_floor(xb);
-            const f2 w256 = (xb - fl) * 256.0f;
-            const f2 ws = (f2){rintf(w256.x), rintf(w256.y)} * (1.0f / 256.0f);
-            const f2 iws = 1.0f - ws;
-            const int lo0 = (int)fminf(fl.x, s_scale), lo1 = (int)fminf(fl.y, s_scale);
-            const float4 nl0 = Rk[lo0], nh0 = Rk[lo0 + 1], nl1 = Rk[lo1], nh1 = Rk[lo1 + 1];
-            // lerp (rule R3).  (cost, constr) of one station sit in adjacent registers of its LDS
-            // read, so that pair is blended as a float2 per station; the jerk components are
-            // blended one by one and travel on as the pair across stations.
-            const f2 cg0 = f2_fma((f2){nh0.x, nh0.y}, (f2){ws.x, ws.x}, (f2){nl0.x, nl0.y} * iws.x);
-            const f2 cg1 = f2_fma((f2){nh1.x, nh1.y}, (f2){ws.y, ws.y}, (f2){nl1.x, nl1.y} * iws.y);
-            float nj0 = fmaf(nh0.z, ws.x, nl0.z * iws.x), nj1 = fmaf(nh1.z, ws.y, nl1.z * iws.y);
-            // (keeps the two blends above scalar: pairing them across stations would need four
-            // register moves to line up the LDS results)
-            asm volatile("" : "+v"(nj0), "+v"(nj1));
-            const f2 node_j = {nj0, nj1};
-            // interpPath(tn.s).v_max, lon_planner.cu:114
-            f2 alpha;
-            if (DIVMODE == 0) alpha = (f2){tn_s.x / p.path_step_size, tn_s.y / p.path_step_size};
-            else if (DIVMODE == 1) {
-                const f2 q0 = tn_s * rcp_path_step;
-                const f2 e = f2_fma(-q0, (f2){p.path_step_size, p.path_step_size}, tn_s);
-                alpha = f2_fma(e, (f2){rcp_path_step, rcp_path_step}, q0);
-            } else alpha = (f2){(float)((double)tn_s.x * rcp_path_step_d), (float)((double)tn_s.y * rcp_path_step_d)};
-            // alpha >= 0 here (tn_s >= s >= s_min >= 0, the host checks it), so i0 = min(floor, n-1)
-            // and the second tap is ALWAYS the next slot: ceil = floor + 1 unless alpha is integral,
-            // where the weight of the second tap is 0 and any finite value there gives the same sum
-            // (its product is a zero, and the sign of a zero v_max is invisible downstream); past the
-            // end both taps are the last sample, which the path buffer carries twice.
-            const f2 afl = f2_floor(alpha);
-            const f2 f0 = {fminf(afl.x, path_top), fminf(afl.y, path_top)};
-            const f2 pa = alpha - f0;
-            const f2 pia = 1.0f - pa;
-            const int t0 = (int)f0.x, t1 = (int)f0.y;
-            const f2 pv0 = {pv[t0], pv[t1]};
-            const f2 pv1 = {pv[t0 + 1], pv[t1 + 1]};
-            const f2 vmn = pv0 * pia + pv1 * pa;
-
-            // (cost, constr) per station as a pair
-            f2 r0 = (f2){sc.x, sg.x} + cg0;
-            f2 r1 = (f2){sc.y, sg.y} + cg1;
-            const f2 dj = node_j - d->j;
-            const f2 snap = p.w_snap * (dj * dj);
-            r0.x += snap.x;
-            r1.x += snap.y;
-            // lon_planner.cu:114-118 (double compare == float compare, double subtraction)
-            // lon_planner.cu:114-118: if (tn.v > v_max) constr += tn.v - v_max, in double.  The
-            // addend max(tn.v - v_max, 0) is that difference exactly when the test holds and +0.0
-            // otherwise, and g + 0.0 == g (g is a sum of non-negative terms, never -0): one
-            // v_max_f64 instead of compare + select.  Same for the station-change term in float.
-            r0.y = (float)((double)r0.y + fmax(d->tn_v_d - (double)vmn.x, 0.0));
-            r1.y = (float)((double)r1.y + fmax(d->tn_v_d - (double)vmn.y, 0.0));
-            const f2 s_change = tn_s - s;
-            const f2 over = s_change - s_dist;
-            const f2 over_pos = {fmaxf(over.x, 0.0f), fmaxf(over.y, 0.0f)};
-            {
-                const f2 gg = (f2){r0.y, r1.y} + over_pos;
-                r0.y = gg.x;
-                r1.y = gg.y;
-            }
-            // c += wj_cost and g += a_viol are the last addends of their sums in k_backward too
-            const f2 tail = {d->wj_cost, d->a_viol};
-            f2 o0 = r0 + tail, o1 = r1 + tail;
-            // pin the results here: with nothing but the final argmin using them, the compiler
-            // otherwise sinks the tail of this action below the next barrier and spills its inputs
-            {
-                const bool lower0 = o0.y < bg0, lower1 = o1.y < bg1;
-                bg0 = lower0 ? o0.y : bg0; bc0 = lower0 ? INFINITY : bc0; bk0 = lower0 ? 0 : bk0;
-                bg1 = lower1 ? o1.y : bg1; bc1 = lower1 ? INFINITY : bc1; bk1 = lower1 ? 0 : bk1;
-                const bool take0 = !(o0.y > bg0) && (o0.x < bc0), take1 = !(o1.y > bg1) && (o1.x < bc1);
-                bc0 = take0 ? o0.x : bc0; bk0 = take0 ? k : bk0;
-                bc1 = take1 ? o1.x : bc1; bk1 = take1 ? k : bk1;
-                asm volatile("" : "+v"(bg0), "+v"(bc0), "+v"(bk0), "+v"(bg1), "+v"(bc1), "+v"(bk1));
-            }
-        }
-    }
-
-    if (act0) st_node(out + (size_t)row * S + is0, bc0, bg0, action_jerk(p, bk0, N_BWD));
-    if (act1) st_node(out + (size_t)row * S + is1, bc1, bg1, action_jerk(p, bk1, N_BWD));
-}
-
-// ------------------------------------------------------------------------
-// Two vertically adjacent ROWS per lane: cells (v, a, s) and (v+1, a, s).
-//
-// What bounds k_backward2 next to VALU issue is the number of vector-memory lane-loads: 36 per
-// cell whatever their width.  Action k of row (v+1, a) lands exactly one v' row above
-// action k of row (v, a), so the two rows' 2x2 source windows overlap in two of their four rows:
-// a lane that owns the same station in both rows needs 6 row loads per action instead of 8, and
-// one of the three a-blends is shared as well.  Whether the windows really overlap (they do not
-// where a successor speed is clamped at the grid edge) is read off the two action descriptors
-// -- a wave-uniform test -- and the lane falls back to 8 loads there.  The station, and with it
-// the stage prelude, is shared by the two cells; everything per (row, action) is per cell.
-// blockDim.x = s_pad (stations, multiple of 64); one workgroup per row pair; needs V % 16 == 0
-// so that every XCD's v range splits into pairs.
-// LDS: float4 R[2 rows][2 buffers][s_pad + 1] | float path_vmax[path_steps]
-// ------------------------------------------------------------------------
-template <int DIVMODE, bool USE_BUF>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8))) k_backward2v(
-                            const Node* __restrict__ next, Node* __restrict__ out,
-                            const ActDesc* __restrict__ acts,
-                            const float* __restrict__ path,
-                            const float* __restrict__ pre_vmax, const float* __restrict__ pre_sdist,
-                            const double* __restrict__ pre_prog,
-                            TplDpLonParams p, int s_pad,
-                            float rcp_path_step, double rcp_path_step_d, double rcp_s_range_d,
-                            int tile_v, int tile_a)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int S = p.s_steps, V = p.v_steps, A = p.a_steps;
-    const int nrows = V * A;
-    const int is = threadIdx.x;
-    // traversal: as k_backward, in units of row pairs (strips of tile_v rows = tile_v/2 pairs)
-    const int xcd = blockIdx.x & 7;
-    const int v_lo = (xcd * V) >> 3, v_hi = ((xcd + 1) * V) >> 3;
-    const int vx = (v_hi - v_lo) >> 1, tv = max(1, tile_v >> 1);
-    const int q = (int)(blockIdx.x >> 3);
-    if (q >= vx * A) return;                                   // whole workgroup, before any barrier
-    int ia, iv;
-    {
-        const int full = vx / tv;
-        int strip = q / (A * tv), w = tv, rem = q - strip * (A * tv);
-        if (strip >= full) { strip = full; w = vx - full * tv; rem = q - full * (A * tv); }
-        const int tile = rem / (tile_a * w);
-        const int r = rem - tile * (tile_a * w);
-        ia = tile * tile_a + r / w;
-        iv = v_lo + 2 * (strip * tv + (r - (r / w) * w));
-    }
-    const int row0 = ia * V + iv, row1 = row0 + 1;
-    const bool active = is < S;
-    const int js = min(is, S - 1);
-
-    const float s = p.s_min + (float)js * p._s_step_size;
-    const f2 v = {p.v_min + (float)iv * p._v_step_size, p.v_min + (float)(iv + 1) * p._v_step_size};
-    const float a = p.a_min + (float)ia * p._a_step_size;
-    const float v_max = pre_vmax[js];
-    const float s_dist = pre_sdist[js];
-    const double prog = pre_prog[js];
-
-    // stateCost lon_planner.cu:40-55
-    f2 sc, sg;
-    {
-        float c0 = 0.0f;
-        c0 += p.w_a * (a * a);
-        const float x = (float)((double)c0 + prog);
-        const f2 gap = (v * p.time_gap + p.gap_min) - s_dist;
-        sc.x = (float)((double)x + (double)p.w_safety_dist * fmax(0.0, (double)gap.x));
-        sc.y = (float)((double)x + (double)p.w_safety_dist * fmax(0.0, (double)gap.y));
-        sg.x = 0.0f; if (v.x > v_max) sg.x += v.x - v_max;
-        sg.y = 0.0f; if (v.y > v_max) sg.y += v.y - v_max;
-    }
-
-    const int row_slots = s_pad + 1;
-    float4* R = reinterpret_cast<float4*>(smem);               // [row c][buffer b][slot]
-    float* pv = reinterpret_cast<float*>(smem + (size_t)4 * row_slots * sizeof(float4));
-    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<Node*>(next), 0, USE_BUF ? (int)((size_t)nrows * S * sizeof(Node)) : 0, 0x00020000);
-    for (int i = is; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];     // last sample twice
-
-    const float s_range = p.s_max - p.s_min;
-    const float s_scale = (float)(S - 1);
-    const float path_top = (float)(p.path_steps - 1);
-    const bool dup_last = is == S - 1;
-    float bg0 = INFINITY, bc0 = INFINITY, bg1 = INFINITY, bc1 = INFINITY;     // running argmin, see k_backward2
-    int bk0 = 0, bk1 = 0;
-
-    auto load_row = [&](int r) -> float4 {
-        if (USE_BUF) return buf_load_node(next_rsrc, (unsigned)js * 12u, (unsigned)r * ((unsigned)S * 12u));
-        return ld_node(next + (size_t)r * S + js);
-    };
-
-#pragma unroll
-    for (int k = 0; k < N_BWD; ++k) {
-        const ActDesc* d0 = acts + (size_t)row0 * N_BWD + k;
-        const ActDesc* d1 = acts + (size_t)row1 * N_BWD + k;
-        float4* Rk0 = R + (k & 1) * row_slots;
-        float4* Rk1 = R + (2 + (k & 1)) * row_slots;
-        // ---- phase 1
-        {
-            const float wa0 = d0->wa, iwa0 = d0->iwa, wv0 = d0->wv, iwv0 = d0->iwv;
-            const float wa1 = d1->wa, iwa1 = d1->iwa, wv1 = d1->wv, iwv1 = d1->iwv;
-            // the upper half of row 0's window is the lower half of row 1's, blended with the same weight
-            const bool shared = d0->r01 == d1->r00 && d0->r11 == d1->r10
-                                && __float_as_uint(wa0) == __float_as_uint(wa1);
-            const float4 p00 = load_row(d0->r00), p10 = load_row(d0->r10);
-            const float4 p01 = load_row(d0->r01), p11 = load_row(d0->r11);
-            const float4 q01 = load_row(d1->r01), q11 = load_row(d1->r11);
-            const float4 a0 = lerp4w(p00, p10, wa0, iwa0);
-            const float4 a1 = lerp4w(p01, p11, wa0, iwa0);
-            float4 b0;
-            if (shared) {
-                b0 = a1;
-            } else {
-                const float4 q00 = load_row(d1->r00), q10 = load_row(d1->r10);
-                b0 = lerp4w(q00, q10, wa1, iwa1);
-            }
-            const float4 b1 = lerp4w(q01, q11, wa1, iwa1);
-            const float4 r0 = lerp4w(a0, a1, wv0, iwv0);
-            const float4 r1 = lerp4w(b0, b1, wv1, iwv1);
-            Rk0[is] = r0;
-            Rk1[is] = r1;
-            if (dup_last) { Rk0[S] = r0; Rk1[S] = r1; }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // ---- phase 2: the two rows as one float2
-        {
-            const f2 sf = s + (f2){d0->vdt, d1->vdt};
-            double sd0 = (double)sf.x + d0->a_term, sd1 = (double)sf.y + d1->a_term;
-            sd0 = sd0 + d0->j_term; sd1 = sd1 + d1->j_term;
-            const f2 tn_s = {fmaxf(s, (float)sd0), fmaxf(s, (float)sd1)};
-            const f2 xs = tn_s - p.s_min;
-            f2 qs;
-            if (DIVMODE == 0) qs = (f2){xs.x / s_range, xs.y / s_range};
-            else qs = (f2){(float)((double)xs.x * rcp_s_range_d), (float)((double)xs.y * rcp_s_range_d)};
-            const f2 cs = qs * s_scale + 0.5f;
-            const f2 xb = cs - 0.5f;
-            const f2 fl = f2_floor(xb);
-            const f2 w256 = (xb - fl) * 256.0f;
-            const f2 ws = (f2){rintf(w256.x), rintf(w256.y)} * (1.0f / 256.0f);
-            const f2 iws = 1.0f - ws;
-            const int lo0 = (int)fminf(fl.x, s_scale), lo1 = (int)fminf(fl.y, s_scale);
-            const float4 nl0 = Rk0[lo0], nh0 = Rk0[lo0 + 1], nl1 = Rk1[lo1], nh1 = Rk1[lo1 + 1];
-            const f2 cg0 = f2_fma((f2){nh0.x, nh0.y}, (f2){ws.x, ws.x}, (f2){nl0.x, nl0.y} * iws.x);
-            const f2 cg1 = f2_fma((f2){nh1.x, nh1.y}, (f2){ws.y, ws.y}, (f2){nl1.x, nl1.y} * iws.y);
-            float nj0 = fmaf(nh0.z, ws.x, nl0.z * iws.x), nj1 = fmaf(nh1.z, ws.y, nl1.z * iws.y);
-            asm volatile("" : "+v"(nj0), "+v"(nj1));
-            const f2 node_j = {nj0, nj1};
-            f2 alpha;
-            if (DIVMODE == 0) alpha = (f2){tn_s.x / p.path_step_size, tn_s.y / p.path_step_size};
-            else if (DIVMODE == 1) {
-                const f2 q0 = tn_s * rcp_path_step;
-                const f2 e = f2_fma(-q0, (f2){p.path_step_size, p.path_step_size}, tn_s);
-                alpha = f2_fma(e, (f2){rcp_path_step, rcp_path_step}, q0);
-            } else alpha = (f2){(float)((double)tn_s.x * rcp_path_step_d), (float)((double)tn_s.y * rcp_path_step_d)};
-            // alpha >= 0 here (tn_s >= s >= s_min >= 0, the host checks it), so i0 = min(floor, n-1)
-            // and the second tap is ALWAYS the next slot: ceil = floor + 1 unless alpha is integral,
-            // where the weight of the second tap is 0 and any finite value there gives the same sum
-            // (its product is a zero, and the sign of a zero v_max is invisible downstream); past the
-            // end both taps are the last sample, which the path buffer carries twice.
-            const f2 afl = f2_floor(alpha);
-            const f2 f0 = {fminf(afl.x, path_top), fminf(afl.y, path_top)};
-            const f2 pa = alpha - f0;
-            const f2 pia = 1.0f - pa;
-            const int t0 = (int)f0.x, t1 = (int)f0.y;
-            const f2 pv0 = {pv[t0], pv[t1]};
-            const f2 pv1 = {pv[t0 + 1], pv[t1 + 1]};
-            const f2 vmn = pv0 * pia + pv1 * pa;
-
-            f2 r0 = (f2){sc.x, sg.x} + cg0;
-            f2 r1 = (f2){sc.y, sg.y} + cg1;
-            const f2 dj = node_j - (f2){d0->j, d1->j};
-            const f2 snap = p.w_snap * (dj * dj);
-            r0.x += snap.x;
-            r1.x += snap.y;
-            r0.y = (float)((double)r0.y + fmax(d0->tn_v_d - (double)vmn.x, 0.0));      // see k_backward2
-            r1.y = (float)((double)r1.y + fmax(d1->tn_v_d - (double)vmn.y, 0.0));
-            const f2 s_change = tn_s - s;
-            const f2 over = s_change - s_dist;
-            const f2 over_pos = {fmaxf(over.x, 0.0f), fmaxf(over.y, 0.0f)};
-            {
-                const f2 gg = (f2){r0.y, r1.y} + over_pos;
-                r0.y = gg.x;
-                r1.y = gg.y;
-            }
-            const f2 o0 = r0 + (f2){d0->wj_cost, d0->a_viol};
-            const f2 o1 = r1 + (f2){d1->wj_cost, d1->a_viol};
-            {
-                const bool lower0 = o0.y < bg0, lower1 = o1.y < bg1;
-                bg0 = lower0 ? o0.y : bg0; bc0 = lower0 ? INFINITY : bc0; bk0 = lower0 ? 0 : bk0;
-                bg1 = lower1 ? o1.y : bg1; bc1 = lower1 ? INFINITY : bc1; bk1 = lower1 ? 0 : bk1;
-                const bool take0 = !(o0.y > bg0) && (o0.x < bc0), take1 = !(o1.y > bg1) && (o1.x < bc1);
-                bc0 = take0 ? o0.x : bc0; bk0 = take0 ? k : bk0;
-                bc1 = take1 ? o1.x : bc1; bk1 = take1 ? k : bk1;
-                asm volatile("" : "+v"(bg0), "+v"(bc0), "+v"(bk0), "+v"(bg1), "+v"(bc1), "+v"(bk1));
-            }
-        }
-    }
-    if (active) {
-        st_node(out + (size_t)row0 * S + is, bc0, bg0, action_jerk(p, bk0, N_BWD));
-        st_node(out + (size_t)row1 * S + is, bc1, bg1, action_jerk(p, bk1, N_BWD));
-    }
-}
-
-// ------------------------------------------------------------------------
-// Exhaustive check of the two cheap division forms against the IEEE quotient for EVERY
-// float in [0, x_max] (all three are odd-symmetric, so the sign is covered): ~1e9
-// candidates, about a millisecond, run once per divisor.
-//  * (float)((double)x * RN_d(1/c)) is provably the IEEE float quotient for normal results:
-//    the double product is within 2^-52 of x/c, a quotient of two 24-bit floats is never
-//    closer than 2^-49 (relative) to a rounding boundary of binary32 unless it is exactly
-//    representable, and it is never exactly a midpoint;
-//  * x*r + one fma residual correction in float is exact for many divisors (all powers of
-//    two) but not all (it fails for 200);
-//  * fma(x, r_hi, x*r_lo) with r_hi + r_lo = 1/c to ~49 bits: the sum is within ~2^-47 of x/c before
-//    its one rounding, two plain fp32 instructions -- exact where no quotient of the range comes that
-//    close to a rounding boundary, which only the brute force can tell.
-// The proof is re-established by brute force anyway; a mode is only used if its flag stays 0.
-// ------------------------------------------------------------------------
-// scale > 0 (the station-range divisor): the two k_backward3v forms are compared on what the sweep derives from
-// the quotient -- the filter coordinate ((q * scale + 0.5) - 0.5, lon_planner.cu:35 + arr_tex_surf.cuh:142-149) --
-// not on the quotient itself: for dividends below ~1e-34 their x * r_lo term underflows and the quotient's last bit
-// can differ, but every quotient below 2^-26 / scale yields the coordinate 0 either way.  scale == 0: raw quotients.
-__global__ void k_verify_div(unsigned int* __restrict__ flags, float c, float r, double rd, float r_lo, float scale,
-                             unsigned int max_bits)
+__global__ void k_verify_div(unsigned int* __restrict__ flags, float c, float r, float r_lo, float scale, unsigned int max_bits)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    bool bad_f = false, bad_d = false, bad_2 = false, bad_p = false;
+    bool bad_2 = false, bad_p = false;
     for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= max_bits; b += stride) {
         const float x = __uint_as_float((unsigned int)b);
         const float qf = x / c;
-        const unsigned int q = __float_as_uint(qf);
-        bad_f |= (q != __float_as_uint(fast_div(x, c, r)));
-        bad_d |= (q != __float_as_uint((float)((double)x * rd)));
-        const float q2 = fmaf(x, r, x * r_lo);                       // two-float reciprocal r + r_lo (k_backward3v)
+        const float q2 = fmaf(x, r, x * r_lo);                       // two-float reciprocal r + r_lo
         const float qp = x * r;                                      // exact for a power-of-two divisor
         if (scale > 0.0f) {
             const unsigned int want = __float_as_uint((qf * scale + 0.5f) - 0.5f);
             bad_2 |= (want != __float_as_uint((q2 * scale + 0.5f) - 0.5f));
             bad_p |= (want != __float_as_uint((qp * scale + 0.5f) - 0.5f));
         } else {
-            bad_2 |= (q != __float_as_uint(q2));
-            bad_p |= (q != __float_as_uint(qp));
+            bad_2 |= (__float_as_uint(qf) != __float_as_uint(q2));
+            bad_p |= (__float_as_uint(qf) != __float_as_uint(qp));
         }
     }
-    if (bad_f) atomicOr(&flags[0], 1u);      // float reciprocal + residual correction is not exact here
-    if (bad_d) atomicOr(&flags[1], 1u);      // double-product form is not exact here
-    if (bad_2) atomicOr(&flags[2], 1u);      // two-float reciprocal is not exact here
-    if (bad_p) atomicOr(&flags[3], 1u);      // a bare multiplication by the reciprocal is not exact here
+    if (bad_2) atomicOr(&flags[0], 1u);      // two-float reciprocal is not exact here
+    if (bad_p) atomicOr(&flags[1], 1u);      // a bare multiplication by the reciprocal is not exact here
 }
 
 // ------------------------------------------------------------------------
@@ -1125,26 +657,20 @@ struct tplhip_dp_lon {
 
     // launch geometry of k_backward
     int s_pad = 0, rows_per_block = 0, nblocks = 0, grid = 0, kchunk = 0;
-    int cells = 1;                       // stations per lane: 2 selects k_backward2 (s_pad = 2 * half)
-    // k_backward2 keeps a RUNNING lexicographic argmin, which equals the reference's two-pass argmin
+    bool big = false;                    // the grid is several residency rounds deep: k_backward3v (else k_backward3s)
+    // k_backward3v / 3s keep a RUNNING lexicographic argmin, which equals the reference's two-pass argmin
     // whenever no NaN can occur; that is guaranteed when every parameter and path value is finite
     // and below 1e6 in magnitude (see reinit).  Otherwise the plan runs k_backward<.., 1, ..> with
     // the geometry below.
     bool params_bounded = false, path_bounded = false, env_bounded = false;
     bool bounded_but_dt_start = false;   // params_bounded without its test of dt_start (the one field tpl moves every cycle)
     bool use_buf = false;                // buffer loads: one stage table addressable with 32-bit byte offsets
-    bool vpair = false;                  // k_backward2v (two rows per lane) instead of k_backward2
-    int vp_s_pad = 0, vp_grid = 0;
-    size_t vp_lds = 0;
-    int x_s_pad = 0, x_rpb = 0, x_nblocks = 0, x_grid = 0;
-    size_t x_lds = 0;
+    int vp_s_pad = 0;                    // s_steps rounded up to whole wavefronts (k_backward3v / 3s)
     int tile_v = 8, tile_a = 8;          // traversal tiles, see k_backward
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, lds1_bytes = 0;     // k_backward's LDS block at kchunk actions per round / at one
 
     // cheap division forms, only used when k_verify_div proved them exact (see k_backward)
-    int div_mode = 0;
     float rcp_path_step = 0.0f;
-    double rcp_path_step_d = 0.0, rcp_s_range_d = 0.0;
     float rcp_path_lo = 0.0f, rcp_range_hi = 0.0f, rcp_range_lo = 0.0f;   // two-float reciprocals (k_backward3v)
     int path_div3 = 0, range_div3 = 0;        // k_backward3v's forms: 4 = one multiplication, 3 = two-float, 0 = not proven
     int verified_path3 = 0, verified_range3 = 0;
@@ -1152,7 +678,6 @@ struct tplhip_dp_lon {
     float verified_c[2] = {0.0f, 0.0f};      // divisors and range the proof covers
     float verified_xmax = 0.0f;
     int verified_s_steps = 0;                 // the coordinate check of the range divisor depends on s_steps - 1
-    int verified_mode = 0;
     unsigned int* d_flag = nullptr;           // [8]: path {float, double, two-float, product}, range {the same}
 
     // two staged downloads in flight (pinned host buffers + completion events)
@@ -1185,10 +710,9 @@ struct tplhip_dp_lon {
     unsigned char* d_sc_best = nullptr;  // TplDpPlanRecord + TplLonState[t_steps]
     bool sc_bounded = false;
     int sc_last_first = 0, sc_last_count = 0;
-    bool vp_ok = false;                  // the two-rows-per-lane geometry of k_backward2v fits this grid (v_steps % 16 == 0)
-    bool v3_ok = false;                  // ... that of k_backward3v (any v_steps)
+    bool v3_ok = false;                  // the two-rows-per-lane geometry of k_backward3v fits this grid
     int v3_grid = 0;
-    int v4_ng = 1, v4_grid = 0;          // k_backward4: row pairs per workgroup (1 = k_backward3v), grid
+    bool no_v3 = false, no_fwd_overlap = false;   // TPLHIP_DEBUG overrides, read by reinit
     int s3_kc = 0, s3_grid = 0;          // k_backward3s (grids that leave the chip mostly empty): actions per round (0 = not used), grid
     size_t s3_lds = 0;
 
@@ -1265,82 +789,36 @@ int check_env(tplhip_dp_lon* h, tplhip_dp_env* env)
     return TPLHIP_OK;
 }
 
-template <bool TERMINAL, int KCHUNK, int DIVMODE, bool USE_BUF>
+template <bool TERMINAL, int KCHUNK, bool USE_BUF>
 void launch_backward_b(tplhip_dp_lon* h, int idx_t, int nx)
 {
     const size_t S = (size_t)h->params.s_steps;
     const size_t lds = TERMINAL ? 0 : h->lds_bytes;
-    hipLaunchKernelGGL((k_backward<TERMINAL, KCHUNK, DIVMODE, USE_BUF>), dim3(h->grid), dim3(h->s_pad * h->rows_per_block),
+    hipLaunchKernelGGL((k_backward<TERMINAL, KCHUNK, USE_BUF>), dim3(h->grid), dim3(h->s_pad * h->rows_per_block),
                        lds, h->stream,
                        h->d_tables + (size_t)nx * h->table_cells,
                        h->d_tables + (size_t)idx_t * h->table_cells,
                        h->d_acts, h->d_path,
                        h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
                        h->d_pre_prog, h->params, h->s_pad, h->rows_per_block, h->nblocks,
-                       h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a,
-                       (size_t)0, (size_t)0, (size_t)0);
+                       h->tile_v, h->tile_a, (size_t)0, (size_t)0, (size_t)0);
 }
 
-template <bool TERMINAL, int KCHUNK, int DIVMODE>
+template <bool TERMINAL, int KCHUNK>
 void launch_backward(tplhip_dp_lon* h, int idx_t, int nx)
 {
     // buffer loads need 32-bit byte offsets inside one stage table
     if (!TERMINAL && h->use_buf)
-        launch_backward_b<TERMINAL, KCHUNK, DIVMODE, true>(h, idx_t, nx);
+        launch_backward_b<TERMINAL, KCHUNK, true>(h, idx_t, nx);
     else
-        launch_backward_b<TERMINAL, KCHUNK, DIVMODE, false>(h, idx_t, nx);
-}
-
-template <int DIVMODE, bool USE_BUF>
-void launch_backward2_b(tplhip_dp_lon* h, int idx_t, int nx)
-{
-    const size_t S = (size_t)h->params.s_steps;
-    const int half = h->s_pad / 2;
-    const bool full = h->params.s_steps == 2 * half;
-    auto kern = (full && half == 64) ? k_backward2<DIVMODE, USE_BUF, 64>
-              : (full && half == 128) ? k_backward2<DIVMODE, USE_BUF, 128>
-              : (full && half == 256) ? k_backward2<DIVMODE, USE_BUF, 256>
-                                      : k_backward2<DIVMODE, USE_BUF, 0>;
-    hipLaunchKernelGGL(kern, dim3(h->grid), dim3(half * h->rows_per_block),
-                       h->lds_bytes, h->stream,
-                       h->d_tables + (size_t)nx * h->table_cells,
-                       h->d_tables + (size_t)idx_t * h->table_cells,
-                       h->d_acts, h->d_path,
-                       h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
-                       h->d_pre_prog, h->params, half, h->rows_per_block,
-                       h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a);
-}
-
-template <int DIVMODE>
-void launch_backward2(tplhip_dp_lon* h, int idx_t, int nx)
-{
-    if (h->use_buf)
-        launch_backward2_b<DIVMODE, true>(h, idx_t, nx);
-    else
-        launch_backward2_b<DIVMODE, false>(h, idx_t, nx);
-}
-
-template <int DIVMODE>
-void launch_backward2v(tplhip_dp_lon* h, int idx_t, int nx)
-{
-    const size_t S = (size_t)h->params.s_steps;
-    auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(h->vp_grid), dim3(h->vp_s_pad), h->vp_lds, h->stream,
-                           h->d_tables + (size_t)nx * h->table_cells, h->d_tables + (size_t)idx_t * h->table_cells,
-                           h->d_acts, h->d_path, h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
-                           h->d_pre_prog, h->params, h->vp_s_pad,
-                           h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a);
-    };
-    if (h->use_buf) go(k_backward2v<DIVMODE, true>);
-    else go(k_backward2v<DIVMODE, false>);
+        launch_backward_b<TERMINAL, KCHUNK, false>(h, idx_t, nx);
 }
 
 // k_backward3v (dp_sweep.hip): the two-rows-per-lane geometry with the plain-fp32 instruction stream.  Needs buffer
 // loads, both divisions proven in one of its cheap forms and non-negative weights (integer-key argmin).
 bool use_v3(const tplhip_dp_lon* h)
 {
-    static const bool off = std::getenv("TPLHIP_NO_V3") != nullptr;
-    return !off && h->use_buf && h->weights_nonneg && h->path_div3 >= 3 && h->range_div3 >= 3
+    return !h->no_v3 && h->use_buf && h->weights_nonneg && h->path_div3 >= 3 && h->range_div3 >= 3
            && backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps) <= 64 * 1024;
 }
 
@@ -1361,10 +839,7 @@ void launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
     a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
     a.tile_v = h->tile_v; a.tile_a = h->tile_a;
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
-    if (h->v4_ng > 1)
-        launch_backward4(h->path_div3, h->range_div3, h->v4_ng, a, dim3(h->v4_grid, 1), backward4_lds_bytes(h->v4_ng, h->vp_s_pad, h->params.path_steps), h->stream);
-    else
-        launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
+    launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
 }
 
 bool launch_backward3s_(tplhip_dp_lon* h, int idx_t, int nx)
@@ -1387,65 +862,19 @@ bool launch_backward3s_(tplhip_dp_lon* h, int idx_t, int nx)
     return launch_backward3s(h->path_div3, h->range_div3, h->s3_kc, a, dim3(h->s3_grid, 1), h->s3_lds, h->stream);
 }
 
-// the terminal stage of the two-station geometry: k_backward<true> with one station per lane
-void launch_terminal(tplhip_dp_lon* h, int idx_t)
-{
-    const size_t S = (size_t)h->params.s_steps;
-    const int s_pad1 = ((h->params.s_steps + 63) / 64) * 64;
-    const int rpb = std::max(1, 256 / s_pad1);
-    int max_rows = 0;
-    for (int x = 0; x < 8; ++x)
-        max_rows = std::max(max_rows, ((((x + 1) * h->params.v_steps) >> 3) - ((x * h->params.v_steps) >> 3)) * h->params.a_steps);
-    const int grid = 8 * ((max_rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL((k_backward<true, 1, 0, false>), dim3(grid), dim3(s_pad1 * rpb), 0, h->stream,
-                       h->d_tables + (size_t)idx_t * h->table_cells,
-                       h->d_tables + (size_t)idx_t * h->table_cells,
-                       h->d_acts, h->d_path,
-                       h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
-                       h->d_pre_prog, h->params, s_pad1, rpb, 0,
-                       h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a,
-                       (size_t)0, (size_t)0, (size_t)0);
-}
-
-// two-pass argmin kernel on the fallback geometry (inputs outside the bounded range)
-template <int DIVMODE>
-void launch_exact(tplhip_dp_lon* h, int idx_t, int nx)
-{
-    const size_t S = (size_t)h->params.s_steps;
-    const bool buf = h->use_buf;
-    auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(h->x_grid), dim3(h->x_s_pad * h->x_rpb), h->x_lds, h->stream,
-                           h->d_tables + (size_t)nx * h->table_cells, h->d_tables + (size_t)idx_t * h->table_cells,
-                           h->d_acts, h->d_path, h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
-                           h->d_pre_prog, h->params, h->x_s_pad, h->x_rpb, h->x_nblocks,
-                           h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a,
-                           (size_t)0, (size_t)0, (size_t)0);
-    };
-    if (buf) go(k_backward<false, 1, DIVMODE, true>);
-    else go(k_backward<false, 1, DIVMODE, false>);
-}
-
-template <int DIVMODE>
 void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
 {
-    if (h->cells == 2) {
-        if (terminal) launch_terminal(h, i);                         // rule R4
-        else if (h->params_bounded && h->path_bounded && h->env_bounded) {
-            if (h->v3_ok && use_v3(h)) launch_backward3(h, i, nx);
-            else if (h->vpair) launch_backward2v<DIVMODE>(h, i, nx);
-            else launch_backward2<DIVMODE>(h, i, nx);
-        }
-        else launch_exact<DIVMODE>(h, i, nx);
-    } else if (terminal) {
-        launch_backward<true, 1, 0>(h, i, nx);                       // rule R4 (no division in it)
-    } else if (h->s3_kc && h->params_bounded && h->path_bounded && h->env_bounded && use_v3(h) && launch_backward3s_(h, i, nx)) {
+    const bool running_argmin_ok = h->params_bounded && h->path_bounded && h->env_bounded && use_v3(h);
+    if (terminal) {
+        launch_backward<true, 1>(h, i, nx);                       // rule R4 (no division in it)
+    } else if (running_argmin_ok && h->big && h->v3_ok) {
+        launch_backward3(h, i, nx);                                   // two rows per lane, plain-fp32 stream
+    } else if (running_argmin_ok && !h->big && h->s3_kc && launch_backward3s_(h, i, nx)) {
         // the plain-fp32 stream, one cell per lane
-    } else if (h->kchunk == 9) {
-        launch_backward<false, 9, DIVMODE>(h, i, nx);
     } else if (h->kchunk == 3) {
-        launch_backward<false, 3, DIVMODE>(h, i, nx);
+        launch_backward<false, 3>(h, i, nx);                 // the general sweep: two-pass argmin, any input
     } else {
-        launch_backward<false, 1, DIVMODE>(h, i, nx);
+        launch_backward<false, 1>(h, i, nx);
     }
 }
 
@@ -1502,9 +931,7 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap)
     // backward pass, lon_planner.cu:347-361 -- no host sync between stages
     for (int i = T - 1; i > 0; --i) {
         const int nx = std::min(T - 1, i + 1);
-        if (h->div_mode == 1) launch_stage<1>(h, i, nx, i == T - 1);
-        else if (h->div_mode == 2) launch_stage<2>(h, i, nx, i == T - 1);
-        else launch_stage<0>(h, i, nx, i == T - 1);
+        launch_stage(h, i, nx, i == T - 1);
     }
     if (h->timing) {
         HIP_TRY(hipEventRecord(e1, h->stream), "event record failed");
@@ -1546,9 +973,8 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap)
 // second table set + rollout stream of the back-to-back mode; any failure just leaves the mode off
 void try_enable_overlap(tplhip_dp_lon* h, tplhip_dp_env* env)
 {
-    static const bool off = std::getenv("TPLHIP_NO_FWD_OVERLAP") != nullptr;
     const size_t dist_elems = (size_t)env->params.t_steps * env->params.s_steps;
-    if (off) { h->overlap = false; return; }
+    if (h->no_fwd_overlap) { h->overlap = false; return; }
     if (h->overlap && h->dist_fwd_cap >= dist_elems) return;
     h->overlap = false;
     const size_t bytes = sizeof(Node) * h->table_cells * (size_t)h->params.t_steps;
@@ -1885,8 +1311,9 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         h->tile_v = 8;
         while (h->tile_v > 2 && (size_t)9 * (h->tile_a + 1) * (h->tile_v + 3) * p.s_steps * sizeof(Node) > (size_t)3584 * 1024)
             h->tile_v -= 2;
-        if (const char* ov = std::getenv("TPLHIP_TILE_V")) h->tile_v = std::max(1, std::atoi(ov));
-        if (const char* ov = std::getenv("TPLHIP_TILE_A")) h->tile_a = std::max(1, std::atoi(ov));
+        int ov = 0;
+        if (debug_opt("tile_v", &ov)) h->tile_v = std::max(1, ov);
+        if (debug_opt("tile_a", &ov)) h->tile_a = std::max(1, ov);
     }
     const size_t threads = (size_t)h->s_pad * h->rows_per_block;
     const size_t path_lds = sizeof(float) * ((size_t)p.path_steps + 1);       // + the duplicate of the last sample
@@ -1910,15 +1337,16 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         h->kchunk = (waves <= (size_t)n_cu * 4 * 6) ? 3 : 1;
     }
     if (threads * 16 * 3 + path_lds > lds_max) h->kchunk = 1;
-    if (const char* ov = std::getenv("TPLHIP_KCHUNK")) {       // tuning override: 9, 3 or 1
-        const int k = std::atoi(ov);
-        if ((k == 9 || k == 3 || k == 1) && threads * 16 * (size_t)k + path_lds <= 160 * 1024) h->kchunk = k;
+    h->big = h->kchunk == 1;                                // decided on the grid, before any override
+    {
+        int k = 0;                                          // tuning override: 3 or 1
+        if (debug_opt("kchunk", &k) && (k == 3 || k == 1) && threads * 16 * (size_t)k + path_lds <= lds_max) h->kchunk = k;
     }
     h->lds_bytes = threads * 16 * (size_t)h->kchunk + path_lds;
-    h->use_buf = h->table_cells * sizeof(Node) < 0xffffffffull && !std::getenv("TPLHIP_NO_BUFLOAD");
-    // fallback geometry of the two-pass kernel (one station per lane, one action per barrier)
-    h->x_s_pad = h->s_pad; h->x_rpb = h->rows_per_block; h->x_nblocks = h->nblocks; h->x_grid = h->grid;
-    h->x_lds = threads * 16 + path_lds;
+    h->lds1_bytes = threads * 16 + path_lds;
+    h->use_buf = h->table_cells * sizeof(Node) < 0xffffffffull && !debug_opt("no_bufload");
+    h->no_v3 = debug_opt("no_v3");
+    h->no_fwd_overlap = debug_opt("no_fwd_overlap");
     // "bounded": every float parameter finite and < 1e6 in magnitude, at most 1e5 stages.  Then no
     // cost or constraint sum of the sweep can overflow (largest single term ~ w * (1e6)^2 = 1e18, at
     // most 1e5 of them), no infinity and hence no NaN can appear, and a running lexicographic argmin
@@ -1929,7 +1357,7 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
                               p.path_step_size, p.width_veh, p.length_veh};
         bool ok = p.t_steps <= 100000;
         for (float v : vals) ok = ok && std::isfinite(v) && std::fabs(v) < 1e6f;
-        // the two-station kernels also read the path's second tap as "the next slot": needs arclength >= 0
+        // the plain-fp32 sweeps read the path's second tap as "the next slot": needs arclength >= 0
         ok = ok && p.s_min >= 0.0f && p.path_step_size > 0.0f;
         h->bounded_but_dt_start = ok;
         h->params_bounded = ok && std::isfinite(p.dt_start) && std::fabs(p.dt_start) < 1e6f;
@@ -1938,42 +1366,21 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         for (float w : {p.w_progress, p.w_a, p.w_j, p.w_snap, p.w_safety_dist}) nn = nn && !std::signbit(w);
         h->weights_nonneg = nn;
     }
-    // two rows per lane where every XCD's v range splits into pairs (k_backward2v / k_backward3v)
+    // k_backward3v: two rows per lane; row PAIRS are dealt to the XCDs, so it takes any v_steps
     {
         h->vp_s_pad = ((p.s_steps + 63) / 64) * 64;
-        h->vp_lds = (size_t)4 * (h->vp_s_pad + 1) * 16 + path_lds;
-        h->vp_grid = 8 * ((p.v_steps / 16) * p.a_steps);
-        const char* vo = std::getenv("TPLHIP_VPAIR");
-        h->vp_ok = (vo ? std::atoi(vo) != 0 : true) && p.v_steps % 16 == 0 && h->vp_s_pad <= 1024
-                   && (h->tile_v % 2 == 0) && h->vp_lds <= 64 * 1024;
-        h->vpair = false;
-        // k_backward3v deals row PAIRS to the XCDs, so it takes any v_steps
-        {
-            const int np = (p.v_steps + 1) / 2;
-            int max_pairs = 0;
-            for (int x = 0; x < 8; ++x) max_pairs = std::max(max_pairs, (((x + 1) * np) >> 3) - ((x * np) >> 3));
-            h->v3_grid = 8 * max_pairs * p.a_steps;
-            h->v3_ok = (vo ? std::atoi(vo) != 0 : true) && h->vp_s_pad <= 1024 && (h->tile_v % 2 == 0);
-            // k_backward4: ng pairs per workgroup
-            h->v4_ng = 1;
-            if (const char* ov = std::getenv("TPLHIP_NG")) h->v4_ng = std::atoi(ov);
-            while (h->v4_ng > 1 && (h->v4_ng * h->vp_s_pad > 1024 || backward4_lds_bytes(h->v4_ng, h->vp_s_pad, p.path_steps) > 64 * 1024)) h->v4_ng /= 2;
-            if (h->v4_ng != 2 && h->v4_ng != 4) h->v4_ng = 1;
-            if (h->v4_ng > 1) {
-                const int nvg = 2 * h->v4_ng, nu = (p.v_steps + nvg - 1) / nvg;
-                int max_units = 0;
-                for (int x = 0; x < 8; ++x) max_units = std::max(max_units, (((x + 1) * nu) >> 3) - ((x * nu) >> 3));
-                h->v4_grid = 8 * max_units * p.a_steps;
-            }
-        }
+        const int np = (p.v_steps + 1) / 2;
+        int max_pairs = 0;
+        for (int x = 0; x < 8; ++x) max_pairs = std::max(max_pairs, (((x + 1) * np) >> 3) - ((x * np) >> 3));
+        h->v3_grid = 8 * max_pairs * p.a_steps;
+        h->v3_ok = h->vp_s_pad <= 1024 && (h->tile_v % 2 == 0);
     }
     // Grids that leave the chip mostly empty (the kchunk = 3 class above) with rows of at most 256 lanes: k_backward3s,
-    // one cell per lane on the plain-fp32 instruction stream, three actions per barrier round (TPLHIP_S3=0: k_backward)
+    // one cell per lane on the plain-fp32 instruction stream, three actions per barrier round (TPLHIP_DEBUG=no_s3: k_backward)
     {
         h->s3_kc = 0;
-        int want = 3;
-        if (const char* ov = std::getenv("TPLHIP_S3")) want = std::atoi(ov);
-        if (h->kchunk == 3 && h->vp_s_pad <= 256 && want == 3) {
+        const int want = 3;
+        if (!h->big && h->vp_s_pad <= 256 && !debug_opt("no_s3")) {
             h->s3_lds = backward3s_lds_bytes(want, h->vp_s_pad, p.path_steps);
             int max_rows = 0;
             for (int x = 0; x < 8; ++x)
@@ -1982,39 +1389,15 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
             if (h->s3_lds <= (size_t)64 * 1024) h->s3_kc = want;
         }
     }
-    // Large grids (one action per barrier) run two stations per lane, see k_backward2.
-    h->cells = 1;
-    {
-        const char* ov = std::getenv("TPLHIP_CELLS");
-        const int want = ov ? std::atoi(ov) : 2;
-        if (h->kchunk == 1 && want == 2) {
-            h->cells = 2;
-            h->s_pad = ((p.s_steps + 127) / 128) * 128;
-            const int half = h->s_pad / 2;
-            h->rows_per_block = std::max(1, 128 / half);
-            if (const char* ov = std::getenv("TPLHIP_RPB")) {
-                const int r = std::atoi(ov);
-                if (r >= 1 && half * r <= 512) h->rows_per_block = r;
-            }
-            h->nblocks = (nrows + h->rows_per_block - 1) / h->rows_per_block;
-            int max_rows = 0;
-            for (int x = 0; x < 8; ++x)
-                max_rows = std::max(max_rows, ((((x + 1) * p.v_steps) >> 3) - ((x * p.v_steps) >> 3)) * p.a_steps);
-            h->grid = 8 * ((max_rows + h->rows_per_block - 1) / h->rows_per_block);
-            h->lds_bytes = (size_t)2 * (h->s_pad + 1) * h->rows_per_block * 16 + path_lds;
-            h->vpair = h->vp_ok;
-        }
-    }
     if (h->lds_bytes > 160 * 1024)
         return tplhip_fail(TPLHIP_EINVAL, "path_steps = %d does not fit in LDS next to the row buffers", p.path_steps);
 
     hipLaunchKernelGGL(k_build_actions, dim3((nrows * N_BWD + 255) / 256), dim3(256), 0, h->stream, h->d_acts, p);
     HIP_TRY(hipGetLastError(), "action table launch failed");
 
-    // Division by the two run-time constants of the sweep (path step, station range): use the
-    // 3-instruction reciprocal form only if it is proven bit-identical to IEEE division for
-    // every float the sweep can feed it.  Largest dividend: s_max + the longest constant-jerk
-    // step, and |s_min|; the proof covers twice that.
+    // Division by the two run-time constants of the sweep (path step, station range): the plain-fp32 sweeps use a
+    // cheap form only if it is proven bit-identical to IEEE division for every float the sweep can feed it.
+    // Largest dividend: s_max + the longest constant-jerk step, and |s_min|; the proof covers twice that.
     {
         const float s_range = p.s_max - p.s_min;
         const double dt = (double)p.dt;
@@ -2023,43 +1406,36 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
                              + std::max(std::fabs((double)p.j_min), std::fabs((double)p.j_max)) * dt * dt * dt / 6.0;
         const float xmax = (float)(2.0 * (std::max(std::fabs((double)p.s_min), std::fabs((double)p.s_max)) + (double)s_range + reach));
         h->rcp_path_step = 1.0f / p.path_step_size;
-        h->rcp_path_step_d = 1.0 / (double)p.path_step_size;
-        h->rcp_s_range_d = 1.0 / (double)s_range;
-        h->rcp_path_lo = (float)(h->rcp_path_step_d - (double)h->rcp_path_step);
+        h->rcp_path_lo = (float)(1.0 / (double)p.path_step_size - (double)h->rcp_path_step);
         h->rcp_range_hi = 1.0f / s_range;
-        h->rcp_range_lo = (float)(h->rcp_s_range_d - (double)h->rcp_range_hi);
-        const bool cached = h->verified_c[0] == p.path_step_size && h->verified_c[1] == s_range && h->verified_xmax >= xmax
+        h->rcp_range_lo = (float)(1.0 / (double)s_range - (double)h->rcp_range_hi);
+        const bool off = debug_opt("no_fastdiv");
+        const bool cached = !off && h->verified_c[0] == p.path_step_size && h->verified_c[1] == s_range && h->verified_xmax >= xmax
                             && h->verified_s_steps == p.s_steps;
         if (!cached) {
-            h->verified_mode = 0;
             h->verified_path3 = h->verified_range3 = 0;
-            if (std::isfinite(xmax) && xmax > 0.0f && s_range > 0.0f && p.path_step_size > 0.0f
-                && !std::getenv("TPLHIP_NO_FASTDIV")) {
-                if (!h->d_flag) HIP_TRY(hipMalloc(&h->d_flag, 8 * sizeof(unsigned int)), "flag allocation failed");
-                HIP_TRY(hipMemsetAsync(h->d_flag, 0, 8 * sizeof(unsigned int), h->stream), "flag clear failed");
+            h->verified_c[0] = h->verified_c[1] = 0.0f;
+            if (!off && std::isfinite(xmax) && xmax > 0.0f && s_range > 0.0f && p.path_step_size > 0.0f) {
+                if (!h->d_flag) HIP_TRY(hipMalloc(&h->d_flag, 4 * sizeof(unsigned int)), "flag allocation failed");
+                HIP_TRY(hipMemsetAsync(h->d_flag, 0, 4 * sizeof(unsigned int), h->stream), "flag clear failed");
                 unsigned int max_bits;
                 std::memcpy(&max_bits, &xmax, sizeof max_bits);
                 hipLaunchKernelGGL(k_verify_div, dim3(4096), dim3(256), 0, h->stream, h->d_flag,
-                                   p.path_step_size, h->rcp_path_step, h->rcp_path_step_d, h->rcp_path_lo, 0.0f, max_bits);
-                hipLaunchKernelGGL(k_verify_div, dim3(4096), dim3(256), 0, h->stream, h->d_flag + 4,
-                                   s_range, h->rcp_range_hi, h->rcp_s_range_d, h->rcp_range_lo, (float)(p.s_steps - 1), max_bits);
+                                   p.path_step_size, h->rcp_path_step, h->rcp_path_lo, 0.0f, max_bits);
+                hipLaunchKernelGGL(k_verify_div, dim3(4096), dim3(256), 0, h->stream, h->d_flag + 2,
+                                   s_range, h->rcp_range_hi, h->rcp_range_lo, (float)(p.s_steps - 1), max_bits);
                 HIP_TRY(hipGetLastError(), "division check launch failed");
-                unsigned int flags[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+                unsigned int flags[4] = {1, 1, 1, 1};
                 HIP_TRY(hipMemcpyAsync(flags, h->d_flag, sizeof flags, hipMemcpyDeviceToHost, h->stream), "flag copy failed");
                 HIP_TRY(hipStreamSynchronize(h->stream), "division check failed");
-                if (flags[5] == 0) {                     // station range through the double product
-                    if (flags[0] == 0) h->verified_mode = 1;          // path step through float reciprocal
-                    else if (flags[1] == 0) h->verified_mode = 2;     // path step through the double product
-                }
-                h->verified_path3 = flags[3] == 0 ? 4 : (flags[2] == 0 ? 3 : 0);
-                h->verified_range3 = flags[7] == 0 ? 4 : (flags[6] == 0 ? 3 : 0);
+                h->verified_path3 = flags[1] == 0 ? 4 : (flags[0] == 0 ? 3 : 0);
+                h->verified_range3 = flags[3] == 0 ? 4 : (flags[2] == 0 ? 3 : 0);
+                h->verified_c[0] = p.path_step_size;
+                h->verified_c[1] = s_range;
+                h->verified_xmax = xmax;
+                h->verified_s_steps = p.s_steps;
             }
-            h->verified_c[0] = p.path_step_size;
-            h->verified_c[1] = s_range;
-            h->verified_xmax = xmax;
-            h->verified_s_steps = p.s_steps;
         }
-        h->div_mode = h->verified_mode;
         h->path_div3 = h->verified_path3;
         h->range_div3 = h->verified_range3;
     }
@@ -2221,6 +1597,9 @@ int tplhip_dp_lon_reeval(tplhip_dp_lon* h, const TplLonState* traj, int len, con
         HIP_TRY(hipMalloc(&h->d_reeval, sizeof(TplLonState) * (size_t)len), "trajectory allocation failed");
         h->cap_reeval = len;
     }
+    // a rollout of the back-to-back mode may still read d_path (and the environment's distance map) on its own stream
+    rc = wait_pending_forwards(h);
+    if (rc) return rc;
     // d_path now holds THIS path: a later plan_resident() plans on it, so the kernel choice follows it
     h->path_bounded = path_is_bounded(path, p.path_steps);
     HIP_TRY(hipMemcpyAsync(h->d_path, path, sizeof(float) * 7 * (size_t)p.path_steps,
@@ -2260,16 +1639,16 @@ int tplhip_dp_lon_copy_table(tplhip_dp_lon* h, int t, float* out)
 int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
 {
     if (!h || !buf || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
+    const bool running_ok = h->params_bounded && h->path_bounded && h->env_bounded && use_v3(h);
+    const char* sweep = (running_ok && h->big && h->v3_ok) ? "k_backward3v" : ((running_ok && !h->big && h->s3_kc) ? "k_backward3s" : "k_backward");
     std::snprintf(buf, (size_t)n,
-                  "{\"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
-                  "\"div_mode\": %d, \"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"cells\": %d, "
-                  "\"bounded_inputs\": %d, \"vpair\": %d, \"v3\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\", \"fwd_overlap\": %d, \"s3\": %d}",
-                  h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
-                  h->div_mode, (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->cells,
-                  (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0, (h->cells == 2 && h->vpair) ? 1 : 0,
-                  (h->cells == 2 && h->v3_ok && use_v3(h) && h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
-                  h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0,
-                  (h->cells == 1 && h->s3_kc && use_v3(h) && h->params_bounded && h->path_bounded && h->env_bounded) ? h->s3_kc : 0);
+                  "{\"sweep\": \"%s\", \"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
+                  "\"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"big\": %d, "
+                  "\"bounded_inputs\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\", \"fwd_overlap\": %d}",
+                  sweep, h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
+                  (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->big ? 1 : 0,
+                  (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
+                  h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded && h->params_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0);
     return TPLHIP_OK;
 }
 
@@ -2409,7 +1788,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
         HIP_TRY(hipEventCreate(&e1), "event creation failed");
         HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
     }
-    const bool v3 = h->v3_ok && use_v3(h) && h->sc_bounded;
+    const bool v3 = h->v3_ok && use_v3(h) && h->sc_bounded && h->params_bounded;
     for (int i = T - 1; i > 0; --i) {
         const int nx = std::min(T - 1, i + 1);
         Node* out = h->d_sc_tables + (size_t)i * h->table_cells;
@@ -2417,10 +1796,9 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
         const float* pv = h->d_sc_pre_vmax + (size_t)i * S;
         const float* ps = h->d_sc_pre_sdist + (size_t)i * S;
         if (i == T - 1) {                                            // rule R4
-            hipLaunchKernelGGL((k_backward<true, 1, 0, false>), dim3(h->x_grid, count), dim3(h->x_s_pad * h->x_rpb), 0, h->stream,
-                               out, out, h->d_acts, paths, pv, ps, h->d_pre_prog, p, h->x_s_pad, h->x_rpb, h->x_nblocks,
-                               h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a,
-                               tab_stride, pre_stride, path_stride);
+            hipLaunchKernelGGL((k_backward<true, 1, false>), dim3(h->grid, count), dim3(h->s_pad * h->rows_per_block), 0, h->stream,
+                               out, out, h->d_acts, paths, pv, ps, h->d_pre_prog, p, h->s_pad, h->rows_per_block, h->nblocks,
+                               h->tile_v, h->tile_a, tab_stride, pre_stride, path_stride);
         } else if (v3) {
             SweepArgs a;
             a.next = next; a.out = out; a.acts = h->d_acts; a.path = paths; a.pre_vmax = pv; a.pre_sdist = ps;
@@ -2429,23 +1807,15 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
             a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
             a.tile_v = h->tile_v; a.tile_a = h->tile_a;
             a.stride_tables = tab_stride; a.stride_pre = pre_stride; a.stride_path = path_stride;
-            if (h->v4_ng > 1)
-                launch_backward4(h->path_div3, h->range_div3, h->v4_ng, a, dim3(h->v4_grid, count),
-                                 backward4_lds_bytes(h->v4_ng, h->vp_s_pad, p.path_steps), h->stream);
-            else
-                launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, count),
-                                  backward3v_lds_bytes(h->vp_s_pad, p.path_steps), h->stream);
+            launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, count),
+                              backward3v_lds_bytes(h->vp_s_pad, p.path_steps), h->stream);
         } else {
             auto go = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, dim3(h->x_grid, count), dim3(h->x_s_pad * h->x_rpb), h->x_lds, h->stream,
-                                   next, out, h->d_acts, paths, pv, ps, h->d_pre_prog, p, h->x_s_pad, h->x_rpb, h->x_nblocks,
-                                   h->rcp_path_step, h->rcp_path_step_d, h->rcp_s_range_d, h->tile_v, h->tile_a,
-                                   tab_stride, pre_stride, path_stride);
+                hipLaunchKernelGGL(kernel, dim3(h->grid, count), dim3(h->s_pad * h->rows_per_block), h->lds1_bytes, h->stream,
+                                   next, out, h->d_acts, paths, pv, ps, h->d_pre_prog, p, h->s_pad, h->rows_per_block, h->nblocks,
+                                   h->tile_v, h->tile_a, tab_stride, pre_stride, path_stride);
             };
-            const bool buf = h->use_buf;
-            if (h->div_mode == 1) { if (buf) go(k_backward<false, 1, 1, true>); else go(k_backward<false, 1, 1, false>); }
-            else if (h->div_mode == 2) { if (buf) go(k_backward<false, 1, 2, true>); else go(k_backward<false, 1, 2, false>); }
-            else { if (buf) go(k_backward<false, 1, 0, true>); else go(k_backward<false, 1, 0, false>); }
+            if (h->use_buf) go(k_backward<false, 1, true>); else go(k_backward<false, 1, false>);
         }
     }
     if (h->timing) {

@@ -51,12 +51,9 @@ struct SweepArgs {
 
 // dp_sweep.hip.  path_div / range_div: 3 = two-float reciprocal (2 plain fp32 instructions), 4 = power-of-two
 // divisor (one multiplication); both only after k_verify_div proved them equal to IEEE division on the whole range.
-// Returns false when the combination is not built (the caller falls back to k_backward2v).
+// Returns false when the combination is not built.
 bool launch_backward3v(int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
 size_t backward3v_lds_bytes(int s_pad, int path_steps);
-// k_backward4: ng row pairs per workgroup that hand a-blended rows to each other through LDS (fewer row loads)
-size_t backward4_lds_bytes(int ng, int s_pad, int path_steps);
-bool launch_backward4(int path_div, int range_div, int ng, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
 // k_backward3s: the same instruction stream, one cell per lane and kc (= 3) actions per barrier round, for grids
 // that leave the chip mostly empty (s_pad <= 256; grid = 8 * rows of the widest XCD share, as k_backward's)
 size_t backward3s_lds_bytes(int kc, int s_pad, int path_steps);

@@ -134,16 +134,6 @@ __device__ __forceinline__ float path_lerp(const PathTap& t, float p0, float p1)
     return p0 * t.ia + p1 * t.a;
 }
 
-// x / c with a precomputed r = RN(1/c): q0 = x*r, one exact residual, one correction.
-// NOT trusted by itself: the planner only uses it after k_verify_fast_div has compared it
-// with the IEEE quotient for every float of the range it will see (dp_lon.hip).
-__device__ __forceinline__ float fast_div(float x, float c, float r)
-{
-    const float q0 = x * r;
-    const float e = fmaf(-q0, c, x);
-    return fmaf(e, r, q0);
-}
-
 // path_tap with the quotient distance / path_step_size already formed.
 // i0 = clamp((int)floor(a), 0, n-1), i1 = clamp((int)ceil(a), 0, n-1) (common.cuh:124-125), with
 // ceil(a) = floor(a) + (a > floor(a)).  The clamps are done on the (integral) floats -- exact

@@ -1,7 +1,7 @@
 // dp_sweep.hip -- the large-grid backward sweep of the DP (s,v,a) planner, third form (k_backward3v).
 //
-// Same data flow as k_backward2v in dp_lon.hip (two vertically adjacent rows (v, a), (v+1, a) per
-// lane, six coalesced row loads per action, blended rows parked in LDS), with
+// Two vertically adjacent rows (v, a), (v+1, a) per lane, six coalesced row loads per action (action k of row v+1
+// lands exactly one v' row above action k of row v, so the two 2x2 source windows share two rows), blended rows parked in LDS, with
 // the instruction stream rebuilt around what gfx950's vector ALU actually charges
 // (tools/micro/valu_tp.hip, 8 waves per SIMD, nominal cycles per wave-instruction):
 //
@@ -12,8 +12,8 @@
 //     second unit for ~4.5 cycles, so a stream of them runs at 4.5 per instruction, and packed fp32
 //     does not overlap with plain fp32 at all.
 //
-// k_backward2v was 1276 instructions per wave of which ~1100 were of the second kind (its weights and
-// per-action constants are scalar operands, its arithmetic is packed).  Here:
+// Round 1's sweep (packed fp32, per-action constants as scalar operands; removed in round 3) was 1276 instructions
+// per wave of which ~1100 were of the second kind.  Here:
 //   * per-(row, action) constants that feed fp32 arithmetic are read from an LDS copy of the action
 //     descriptors as broadcasts, launch constants are moved to vector registers once: the blends and
 //     the coordinate / cost arithmetic are plain VGPR-operand fp32 instructions;
@@ -29,7 +29,7 @@
 //   * the running lexicographic argmin compares (constraint, cost) as ONE unsigned 64-bit key: both
 //     are sums of non-negative terms (the host checks that every weight is >= +0), and for
 //     non-negative floats the integer order of the bit patterns is the float order.
-// Results are bit-identical to k_backward / k_backward2v and to oracle/dp_lon_oracle.c.
+// Results are bit-identical to k_backward and to oracle/dp_lon_oracle.c.
 #include <cstdlib>
 
 #include "dp_lon_internal.h"
@@ -113,7 +113,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     const float* __restrict__ path = path_all + scn * a.stride_path;
 
     constexpr int NV = 2;
-    // traversal: as k_backward2v (XCD = blockIdx.x & 7 owns a v range, a-major tiles inside), in units of row PAIRS,
+    // traversal: as k_backward (XCD = blockIdx.x & 7 owns a v range, a-major tiles inside), in units of row PAIRS,
     // so that any v_steps works: the pairs (0,1), (2,3), ... of an a-slice are dealt to the XCDs in contiguous runs;
     // with an odd v_steps the last "pair" is row V-1 twice (second copy computed, not stored)
     const int xcd = blockIdx.x & 7;
@@ -351,257 +351,6 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 }
 
 // ------------------------------------------------------------------------
-// k_backward4: k_backward3v's stream with NG row PAIRS (2 NG vertically adjacent rows) per workgroup, one pair per
-// group of s_pad lanes.  The pairs are vertical neighbours too: the LOWER a-blend of group g's first row is the UPPER
-// a-blend of group g-1's second row (same test on the descriptors as inside a pair), so group g-1 parks that
-// a-blended row in LDS ("X") and group g reads its own station from it instead of loading two more rows:
-// 6 + 4 (NG - 1) row loads per 2 NG cells -- 2.5 per cell and action at NG = 2, 2.25 at NG = 4, against 3.
-// The texture-address path, which a 12-byte row load occupies for 16 cycles per wavefront, is what the sweep sits on
-// (ablation: row loads + blends alone 36 us of 41), so this is the term to cut.  The exchange rides on the barrier
-// that already separates the phase-2 reads of action k-1 from the row writes of action k.
-// ------------------------------------------------------------------------
-template <int PATH_DIV, int RANGE_DIV, int NG, int SP>
-__global__ void __launch_bounds__(1024)
-k_backward4(const Node* __restrict__ next_all, Node* __restrict__ out_all, const ActDesc* __restrict__ acts,
-            const float* __restrict__ path_all, const float* __restrict__ pre_vmax_all,
-            const float* __restrict__ pre_sdist_all, const double* __restrict__ pre_prog, SweepArgs a)
-{
-    static_assert(NG >= 2, "NG = 1 is k_backward3v");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const TplDpLonParams& p = a.p;
-    const int S = SP ? SP : p.s_steps, V = p.v_steps, A = p.a_steps;       // SP: s_steps == s_pad == SP (LDS addresses become immediates)
-    const int nrows = V * A;
-    const int s_pad = SP ? SP : a.s_pad;
-    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / s_pad);      // wave-uniform: s_pad is a multiple of 64
-    const int is = (int)threadIdx.x - grp * s_pad;
-    const size_t scn = blockIdx.y;
-    const Node* __restrict__ next = next_all + scn * a.stride_tables;
-    Node* __restrict__ out = out_all + scn * a.stride_tables;
-    const float* __restrict__ pre_vmax = pre_vmax_all + scn * a.stride_pre;
-    const float* __restrict__ pre_sdist = pre_sdist_all + scn * a.stride_pre;
-    const float* __restrict__ path = path_all + scn * a.stride_path;
-
-    constexpr int NV = 2;
-    constexpr int NVG = NV * NG;                 // rows per workgroup
-    // traversal: k_backward3v's, in units of NVG rows (XCD = blockIdx.x & 7 owns a contiguous run of units, a-major tiles)
-    const int xcd = blockIdx.x & 7;
-    const int NU = (V + NVG - 1) / NVG;
-    const int u_lo = (xcd * NU) >> 3, u_hi = ((xcd + 1) * NU) >> 3;
-    const int vx = u_hi - u_lo, tv = max(1, a.tile_v / NVG);
-    const int q = (int)(blockIdx.x >> 3);
-    if (q >= vx * A) return;
-    int ia, iv;
-    {
-        const int full = vx / tv;
-        int strip = q / (A * tv), w = tv, rem = q - strip * (A * tv);
-        if (strip >= full) { strip = full; w = vx - full * tv; rem = q - full * (A * tv); }
-        const int tile = rem / (a.tile_a * w);
-        const int r = rem - tile * (a.tile_a * w);
-        ia = tile * a.tile_a + r / w;
-        iv = NVG * (u_lo + strip * tv + (r - (r / w) * w)) + NV * grp;
-    }
-    // rows past the top of the grid are computed as copies of row V-1 and not stored
-    const int rv0 = min(iv, V - 1), rv1 = min(iv + 1, V - 1);
-    const int row0 = ia * V + rv0;
-    const int rs = (rv1 - rv0) * N_BWD;                 // descriptor stride to the lane's second row (0: the row twice)
-    const bool store0 = iv < V, store1 = iv + 1 < V;
-    const bool active = is < S;
-    const int js = min(is, S - 1);
-
-    // LDS: float4 R[NVG rows][s_pad + 1] | float4 X[NG - 1][s_pad] | float dsc[NVG rows][9][8] | float pv[path_steps + 1]
-    const int row_slots = s_pad + 1;
-    v4f* R = reinterpret_cast<v4f*>(smem) + (size_t)grp * NV * row_slots;
-    v4f* Xall = reinterpret_cast<v4f*>(smem) + (size_t)NVG * row_slots;
-    float* dsc_all = reinterpret_cast<float*>(Xall + (size_t)(NG - 1) * s_pad);
-    float* dsc = dsc_all + grp * NV * N_BWD * 8;
-    float* pv = dsc_all + NVG * N_BWD * 8;
-    const ActDesc* __restrict__ d0 = acts + (size_t)row0 * N_BWD;
-    for (int i = is; i < NV * N_BWD * 8; i += s_pad)
-        dsc[i] = reinterpret_cast<const float*>(d0 + (i / (N_BWD * 8)) * rs + ((i >> 3) % N_BWD))[i & 7];
-    for (int i = threadIdx.x; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];
-
-    const float s = p.s_min + (float)js * p._s_step_size;
-    const float acc = p.a_min + (float)ia * p._a_step_size;
-    const float v_max = pre_vmax[js];
-    const float s_dist = pre_sdist[js];
-    const double prog = pre_prog[js];
-    float sc[NV], sg[NV];
-    double sd_base[NV];
-    {
-        float c0 = 0.0f;
-        c0 += p.w_a * (acc * acc);
-        const float x = (float)((double)c0 + prog);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const float v = p.v_min + (float)(i ? rv1 : rv0) * p._v_step_size;
-            const float gap = (v * p.time_gap + p.gap_min) - s_dist;
-            sc[i] = (float)((double)x + (double)p.w_safety_dist * fmax(0.0, (double)gap));
-            sg[i] = 0.0f; if (v > v_max) sg[i] += v - v_max;
-            sd_base[i] = (double)(s + d0[i * rs].vdt) + d0[i * rs].a_term;
-        }
-    }
-    // bit k: the two a-blends meet (rows and weight equal) -- inside the pair, with the group below, with the group above
-    auto meets = [](const ActDesc& x, const ActDesc& y) {
-        return x.r01 == y.r00 && x.r11 == y.r10 && __float_as_uint(x.wa) == __float_as_uint(y.wa);
-    };
-    unsigned shared_mask = 0, from_x = 0, to_x = 0;
-    {
-        const ActDesc* __restrict__ below = acts + (size_t)(ia * V + min(max(iv - 1, 0), V - 1)) * N_BWD;
-        const ActDesc* __restrict__ above = acts + (size_t)(ia * V + min(iv + 2, V - 1)) * N_BWD;
-#pragma unroll
-        for (int k = 0; k < N_BWD; ++k) {
-            shared_mask |= (meets(d0[k], d0[rs + k]) ? 1u : 0u) << k;
-            if (grp > 0) from_x |= (meets(below[k], d0[k]) ? 1u : 0u) << k;
-            if (grp + 1 < NG) to_x |= (meets(d0[rs + k], above[k]) ? 1u : 0u) << k;
-        }
-    }
-    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<Node*>(next), 0, (int)((size_t)nrows * S * sizeof(Node)), 0x00020000);
-    const unsigned voff = (unsigned)js * 12u, row_bytes = (unsigned)S * 12u;
-    auto load_row = [&](int r) -> Node3 {
-        const v3f x = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(next_rsrc, (int)voff, (int)((unsigned)r * row_bytes), 0));
-        return Node3{x.x, x.y, x.z};
-    };
-    const float s_min_v = in_vgpr(p.s_min);
-    const float s_scale = (float)(S - 1);
-    const float s_scale_v = in_vgpr(s_scale);
-    const float rr_hi = in_vgpr(a.rcp_range_hi), rr_lo = in_vgpr(a.rcp_range_lo);
-    const float rp_hi = in_vgpr(a.rcp_path_hi), rp_lo = in_vgpr(a.rcp_path_lo);
-    const float w_snap_v = in_vgpr(p.w_snap);
-    const float path_top = (float)(p.path_steps - 1);
-    const bool dup_last = is == S - 1;
-    unsigned long long best[NV];
-    int bk[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) { best[i] = 0x7f8000007f800000ull; bk[i] = 0; }
-    struct ActScalars { int r00, r10, r01[NV], r11[NV]; double j_term[NV], tn_v_d[NV]; };
-    auto fetch_scalars = [&](int k) {
-        ActScalars x;
-        x.r00 = d0[k].r00; x.r10 = d0[k].r10;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const ActDesc& e = d0[i * rs + k];
-            x.r01[i] = e.r01; x.r11[i] = e.r11; x.j_term[i] = e.j_term; x.tn_v_d[i] = e.tn_v_d;
-        }
-        return x;
-    };
-    v4f* Xw = Xall + (size_t)grp * s_pad;                       // the row this group leaves for the one above
-    const v4f* Xr = Xall + (size_t)max(grp - 1, 0) * s_pad;     // the row the group below leaves for this one
-    __syncthreads();                     // descriptors and path limits are in LDS
-    const v4f* dsc4 = reinterpret_cast<const v4f*>(dsc);
-    ActScalars cur = fetch_scalars(0);
-#pragma unroll
-    for (int k = 0; k < N_BWD; ++k) {
-        // ---- phase 1: a-blends of this pair's rows; the lowest one comes from the group below where the two meet
-        {
-#if V3_SETPRIO
-            __builtin_amdgcn_s_setprio(V3_SETPRIO);
-#endif
-            const bool take = (from_x >> k) & 1u;                // wave-uniform
-            Node3 lo[2], up[NV][2];
-            if (!take) { lo[0] = load_row(cur.r00); lo[1] = load_row(cur.r10); }
-#pragma unroll
-            for (int i = 0; i < NV; ++i) { up[i][0] = load_row(cur.r01[i]); up[i][1] = load_row(cur.r11[i]); }
-            v4f w[NV];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) w[i] = dsc4[(i * N_BWD + k) * 2];
-            Node3 bl, bu[NV];
-            if (!take) bl = lerp3(lo[0], lo[1], w[0].x, w[0].y);
-#pragma unroll
-            for (int i = NV - 1; i >= 0; --i) {
-                bu[i] = lerp3(up[i][0], up[i][1], w[i].x, w[i].y);
-                if (i == NV - 1 && ((to_x >> k) & 1u)) *reinterpret_cast<v3f*>(Xw + is) = (v3f){bu[i].c, bu[i].g, bu[i].j};
-            }
-            // everyone is done reading the row buffers of action k-1, and the exchanged rows are in LDS
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (take) {
-                const v4f x = Xr[is];
-                bl = Node3{x.x, x.y, x.z};
-            }
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const Node3 r = lerp3(bl, bu[i], w[i].z, w[i].w);
-                v4f* Rk = R + i * row_slots;
-                *reinterpret_cast<v3f*>(Rk + is) = (v3f){r.c, r.g, r.j};
-                if (dup_last) *reinterpret_cast<v3f*>(Rk + S) = (v3f){r.c, r.g, r.j};
-                if (i + 1 < NV) {
-                    if ((shared_mask >> k) & 1u) {
-                        bl = bu[i];
-                    } else {
-                        const ActDesc& y = d0[(i + 1) * rs + k];
-                        const Node3 q00 = load_row(y.r00), q10 = load_row(y.r10);
-                        bl = lerp3(q00, q10, w[i + 1].x, w[i + 1].y);
-                    }
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#if V3_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        // ---- phase 2: k_backward3v's, per cell
-        int kv = k;
-        asm volatile("" : "+v"(kv));
-        const ActScalars now = cur;
-        if (k + 1 < N_BWD) {
-            cur = fetch_scalars(k + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const v4f u = dsc4[(i * N_BWD + k) * 2 + 1];
-            const v4f* Rk = R + i * row_slots;
-            const double sd = sd_base[i] + now.j_term[i];
-            const float tn_s = fmaxf(s, (float)sd);
-            const float xs = tn_s - s_min_v;
-            const float qs = div_const<RANGE_DIV>(xs, rr_hi, rr_lo);
-            const float cs = qs * s_scale_v + 0.5f;
-            const float xb = cs - 0.5f;
-            const float fl = floorf(xb);
-            const float fr = xb - fl;
-            const float ws = (fr + 32768.0f) - 32768.0f;
-            const float iws = 1.0f - ws;
-            const int off = (int)(fminf(fl, s_scale) * 16.0f);
-            const v4f nl = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off);
-            const v4f nh = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off + 16);
-            asm volatile("" :: "v"(nl.w), "v"(nh.w));
-            const float nc = fmaf(nh.x, ws, nl.x * iws);
-            const float ng = fmaf(nh.y, ws, nl.y * iws);
-            const float nj = fmaf(nh.z, ws, nl.z * iws);
-            const float alpha = div_const<PATH_DIV>(tn_s, rp_hi, rp_lo);
-            const float f0 = fminf(floorf(alpha), path_top);
-            const float pa = alpha - f0;
-            const float pia = 1.0f - pa;
-            const int t4 = (int)(f0 * 4.0f);
-            const float pv0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4);
-            const float pv1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4 + 4);
-            const float vmn = pv0 * pia + pv1 * pa;
-            float c = sc[i] + nc;
-            float g = sg[i] + ng;
-            const float dj = nj - u.x;
-            c += w_snap_v * (dj * dj);
-            g = (float)((double)g + fmax(now.tn_v_d[i] - (double)vmn, 0.0));
-            const float s_change = tn_s - s;
-            g += fmaxf(s_change - s_dist, 0.0f);
-            c += u.y;
-            g += u.z;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(g) << 32) | __float_as_uint(c);
-            const bool better = key < best[i];
-            best[i] = better ? key : best[i];
-            bk[i] = better ? kv : bk[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(best[i]), "+v"(bk[i]));
-    }
-    if (active) {
-        if (store0) st_node(out + (size_t)(ia * V + iv) * S + is, __uint_as_float((unsigned)best[0]), __uint_as_float((unsigned)(best[0] >> 32)),
-                            action_jerk(p, bk[0], N_BWD));
-        if (store1) st_node(out + (size_t)(ia * V + iv + 1) * S + is, __uint_as_float((unsigned)best[1]), __uint_as_float((unsigned)(best[1] >> 32)),
-                            action_jerk(p, bk[1], N_BWD));
-    }
-}
-
-// ------------------------------------------------------------------------
 // k_backward3s: the plain-fp32 instruction stream of k_backward3v for grids that do NOT fill the chip (tpl's default
 // 201x37x20, 128x64x32): there a sweep is bound by how many instructions ONE SIMD has to issue for its two to four
 // wavefronts and by one workgroup's latency, not by loads.  One cell per lane (a row per workgroup: the shortest
@@ -789,34 +538,6 @@ bool launch_backward3v(int path_div, int range_div, const SweepArgs& a, dim3 gri
     if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3>);
     if (path_div == 4 && range_div == 4) return go(k_backward3v<4, 4>);
     if (path_div == 3 && range_div == 4) return go(k_backward3v<3, 4>);
-    return false;
-}
-
-size_t backward4_lds_bytes(int ng, int s_pad, int path_steps)
-{
-    return (size_t)2 * ng * (s_pad + 1) * 16 + (size_t)(ng - 1) * s_pad * 16 + (size_t)2 * ng * N_BWD * 8 * sizeof(float)
-           + sizeof(float) * ((size_t)path_steps + 1);
-}
-
-// ng row pairs per workgroup of ng * a.s_pad <= 1024 lanes; grid.x = 8 * (units of 2 ng rows of the widest XCD share) * a_steps
-bool launch_backward4(int path_div, int range_div, int ng, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
-{
-    if (ng * a.s_pad > 1024) return false;
-    auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, dim3(ng * a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
-        return true;
-    };
-    const bool full256 = a.s_pad == 256 && a.p.s_steps == 256;
-#define TPLHIP_V4_CASES(NG_, SP_) \
-        if (path_div == 4 && range_div == 3) return go(k_backward4<4, 3, NG_, SP_>); \
-        if (path_div == 3 && range_div == 3) return go(k_backward4<3, 3, NG_, SP_>); \
-        if (path_div == 4 && range_div == 4) return go(k_backward4<4, 4, NG_, SP_>); \
-        if (path_div == 3 && range_div == 4) return go(k_backward4<3, 4, NG_, SP_>);
-    if (ng == 2 && full256) { TPLHIP_V4_CASES(2, 256) }
-    if (ng == 4 && full256) { TPLHIP_V4_CASES(4, 256) }
-    if (ng == 2) { TPLHIP_V4_CASES(2, 0) }
-    if (ng == 4) { TPLHIP_V4_CASES(4, 0) }
-#undef TPLHIP_V4_CASES
     return false;
 }
 

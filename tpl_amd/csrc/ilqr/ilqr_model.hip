@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "builtins.h"
+#include "../tplhip_debug.h"
 #define TPL_QUAD_ROUTINES 1       /* the model file also emits the quad-cooperative ctDynamicsQ */
 #include TPL_MODEL_INC
 #include "tplhip_ilqr.h"
@@ -1516,11 +1517,12 @@ void plan_lds(tplhip_ilqr* h)
     d.n_lds_arrays = 0;
     d.lds_dyn_flat = 0;
     h->lds_dyn_bytes = 0;
-    if (!h->lds_aperture || std::getenv("TPLHIP_ILQR_NO_LDS")) return;
+    if (!h->lds_aperture || tplhip::debug_opt("ilqr_no_lds")) return;
     const int per_cu = (h->batch + h->n_cu - 1) / std::max(1, h->n_cu);          // workgroups sharing a compute unit
     size_t wg_bytes = per_cu <= 1 ? (size_t)150 * 1024 : (per_cu == 2 ? (size_t)78 * 1024 : (size_t)39 * 1024);
-    if (const char* kb = std::getenv("TPLHIP_ILQR_LDS_KB"))                      // tests: force the other home of the mirrors
-        wg_bytes = std::min((size_t)150, std::max((size_t)8, (size_t)std::atoi(kb))) * 1024;
+    int kb = 0;
+    if (tplhip::debug_opt("ilqr_lds_kb", &kb))                                   // tests: force the other home of the mirrors
+        wg_bytes = std::min((size_t)150, std::max((size_t)8, (size_t)kb)) * 1024;
     const size_t budget = (wg_bytes - sizeof(Lds)) / sizeof(double);
     const size_t traj = (size_t)h->rows * (NX + NU + NU + NU * NX + NU + NU);
     size_t off = 0;

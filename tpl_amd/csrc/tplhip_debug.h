@@ -1,0 +1,38 @@
+// tplhip_debug.h -- the ONE environment switch of the library.
+//   TPLHIP_DEBUG="token[=int],token[=int],..."     tuning and test overrides, read when a handle is (re)initialised:
+//     no_v3          large grids: the general two-pass sweep (k_backward) instead of k_backward3v
+//     no_s3          small grids: k_backward instead of k_backward3s
+//     no_fastdiv     IEEE division in the sweeps (skips the brute-force proof of the reciprocal forms)
+//     no_bufload     plain global loads instead of buffer loads in k_backward
+//     no_fwd_overlap plan_resident: the forward rollout stays on the main stream
+//     kchunk=N       actions per barrier round of k_backward (1 or 3)
+//     tile_v=N, tile_a=N   traversal tile of the sweeps
+//     ilqr_no_lds, ilqr_lds_kb=N   iLQR: where the solver mirrors live (tests force both homes)
+// Nothing else in the library reads the environment (tpl_amd/_capi.py reads TPLHIP_LIB to locate the .so).
+#pragma once
+
+#include <cstdlib>
+#include <cstring>
+
+namespace tplhip {
+
+// true if `name` is among the tokens; *value receives the integer behind '=' (left alone if there is none)
+inline bool debug_opt(const char* name, int* value = nullptr)
+{
+    const char* s = std::getenv("TPLHIP_DEBUG");
+    if (!s) return false;
+    const size_t n = std::strlen(name);
+    while (*s) {
+        const char* e = std::strchr(s, ',');
+        const size_t len = e ? (size_t)(e - s) : std::strlen(s);
+        if (len >= n && std::strncmp(s, name, n) == 0 && (len == n || s[n] == '=')) {
+            if (value && len > n) *value = std::atoi(s + n + 1);
+            return true;
+        }
+        s += len;
+        if (*s == ',') ++s;
+    }
+    return false;
+}
+
+} // namespace tplhip

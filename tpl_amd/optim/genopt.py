@@ -95,6 +95,7 @@ _TEMPLATE_HASH = None
 def template_files():
     """Sources every libilqr_<problem>.so is compiled from besides its model header."""
     files = [os.path.join(CSRC_ILQR, f) for f in sorted(os.listdir(CSRC_ILQR)) if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(CSRC_ILQR, "..", "tplhip_debug.h"))
     files.append(os.path.join(_PKG, "..", "include", "tplhip_ilqr.h"))
     return files
 
@@ -808,7 +809,8 @@ def compile_model(name, out_dir=None, force=False):
     """hipcc the solver template against ``<name>.inc`` -> libilqr_<name>.so."""
     paths = model_paths(name, out_dir)
     src = os.path.join(CSRC_ILQR, "ilqr_model.hip")
-    deps = [paths["inc"], src] + [os.path.join(CSRC_ILQR, f) for f in os.listdir(CSRC_ILQR) if f.endswith(".h")]
+    deps = [paths["inc"], src, os.path.join(CSRC_ILQR, "..", "tplhip_debug.h")] \
+        + [os.path.join(CSRC_ILQR, f) for f in os.listdir(CSRC_ILQR) if f.endswith(".h")]
     if not force and os.path.exists(paths["so"]):
         if all(os.path.getmtime(paths["so"]) >= os.path.getmtime(d) for d in deps):
             return paths["so"]
