@@ -93,7 +93,7 @@ def ilqr_cpu_baseline(x0, horizon, budget_s, workload="mpc"):
     import ctypes as C
     import numpy as np
     import oracle_ilqr as OI
-    from tpl_amd.optim import bench_ilqr
+    from benchkit import ilqr as bench_ilqr
     problem = bench_ilqr.WORKLOADS[workload]["problem"]
     native = _native_oracle(f"libilqr_oracle_{problem}.so")
     lib = OI.load(problem, path=native) if native else OI.load(problem)
@@ -137,7 +137,7 @@ def env_cpu_baseline(reps=20):
     """oracle/dp_env_oracle.c (one thread) on the scene of latency.env_update."""
     import numpy as np
     import oracle_env as oe
-    from tpl_amd import scenarios
+    from benchkit import scenarios
     ep = scenarios.env_params(t_steps=10, s_steps=201, l_steps=31)
     rl, step, objs = scenarios.env_scene("arc", seed=1, n_objects=10)
     t = []
@@ -159,7 +159,7 @@ def poly_lat_cpu_baseline(reps=10):
     import oracle_env as oe
     import oracle_poly_lat as opl
     import tpl_amd
-    from tpl_amd import scenarios
+    from benchkit import scenarios
     ep = scenarios.env_params(t_steps=10, s_steps=201, l_steps=31)
     rl, step, objs = scenarios.env_scene("arc", seed=1, n_objects=10)
     o = oe.OracleEnv(ep)
@@ -185,7 +185,7 @@ def lat_lon_cpu_baseline(reps=3):
     import oracle_env as oe
     import oracle_lat_lon as oll
     import tpl_amd
-    from tpl_amd import scenarios
+    from benchkit import scenarios
     ep = scenarios.env_params(t_steps=10, s_steps=201, l_steps=31)
     rl, step, objs = scenarios.env_scene("arc", seed=1, n_objects=10)
     o = oe.OracleEnv(ep)
@@ -208,10 +208,10 @@ def lat_lon_cpu_baseline(reps=3):
 
 def mpc_cpu_baseline(ticks=1000, horizon=20):
     """oracle/ilqr_oracle.cpp (one thread, one problem) in the closed loop of latency.mpc_closed_loop
-    (tpl_amd/minisim.py): what the reference's CPU genopt solver costs per controller tick on this host."""
+    (benchkit/minisim.py): what the reference's CPU genopt solver costs per controller tick on this host."""
     import numpy as np
     import oracle_ilqr as OI
-    from tpl_amd import minisim
+    from benchkit import minisim
     native = _native_oracle("libilqr_oracle_trajectory_tracking_mpc.so")
     opt = OI.OracleOptim("trajectory_tracking_mpc", lib=OI.load("trajectory_tracking_mpc", path=native) if native else None)
     opt.horizon = horizon
@@ -228,7 +228,7 @@ def mpc_cpu_baseline(ticks=1000, horizon=20):
 
 def dp_setup(grid, device):
     import tpl_amd
-    from tpl_amd import scenarios as sc
+    from benchkit import scenarios as sc
     S, V, A, T = sc.GRIDS[grid]
     p = sc.lon_params(S, V, A, T)
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
@@ -251,7 +251,7 @@ def mc_scenarios(ep, first, n):
     """Monte-Carlo scenarios [first, first + n) of the 8192-rollout workload: perturbed initial state and an own
     set of moving obstacles per scenario id (seeded by the id, so every rank count gives the same scenarios)."""
     import numpy as np
-    from tpl_amd import scenarios as sc
+    from benchkit import scenarios as sc
     occs = np.empty((n, ep.l_steps, ep.s_steps, ep.t_steps), dtype=np.float32)
     inits = []
     for i in range(n):
@@ -280,7 +280,8 @@ def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_c
     import numpy as np
     import torch
     import tpl_amd
-    from tpl_amd import scenarios as sc, sharding
+    from benchkit import scenarios as sc
+    from tpl_amd import sharding
     MC_PER_GPU, MC_CHUNK = per_gpu, chunk
     S, V, A, T = sc.GRIDS[grid]
     p = sc.lon_params(S, V, A, T)
@@ -406,9 +407,21 @@ def worker(args):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    collective = None
+    if dist is not None:
+        # what the driver cannot see from n_gpus = WORLD_SIZE alone: how many ranks the process group really holds (an
+        # all-reduce of ones through the backend) and that every rank sits on a device of its own
+        assert dist.get_world_size() == world and dist.get_rank() == rank, (dist.get_world_size(), world, dist.get_rank(), rank)
+        if not rehearsal:
+            assert local_rank < torch.cuda.device_count(), f"LOCAL_RANK {local_rank} but {torch.cuda.device_count()} devices"
+        cdev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
+        ones = torch.ones(1, dtype=torch.int64, device=cdev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        devs = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(devs, torch.tensor([local_rank], dtype=torch.int64, device=cdev))
+        collective = {"backend": dist.get_backend(), "ranks_seen": int(ones.item()), "devices": [int(d.item()) for d in devs]}
+        assert collective["ranks_seen"] == world, collective
 
     from tpl_amd import sharding
     dp, env, p, ep, path, occ = dp_setup(args.grid, local_rank)
@@ -441,8 +454,15 @@ def worker(args):
     sweep_ms, sweep_launches = dp.timing_get()
     dp.timing_enable(False)
 
+    rank_values = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        cdev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        every = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(every, mine)
+        own_sweeps = sweeps_per_plan * plans_per_step * args.steps
+        rank_values = [own_sweeps / float(e.item()) for e in every]           # each rank's own sweeps/s over ITS clock
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -485,6 +505,7 @@ def worker(args):
             out["note"] = f"{world} ranks share ONE device over gloo: exercises the N > 1 code path, says nothing about scaling"
         if dist is not None:
             out["best_plan"] = {"constr": float(best[0]), "cost": float(best[1]), "rank": int(best[2])}
+            out["collective"] = dict(collective, per_rank_value=rank_values)
         traffic_block(out, p, cells, per_launch_s)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = dp_cpu_baseline(p, ep, path, occ)
@@ -496,7 +517,7 @@ def worker(args):
         mc = mc_rollouts(local_rank, rank, world, dist, rehearsal, barrier)
         # the grid tpl really plans on (reference default 201x37x20, 10 stages), 256 scenarios per GPU, 64 per launch
         mc_default = mc_rollouts(local_rank, rank, world, dist, rehearsal, barrier, steps=4, grid="default", per_gpu=256)
-        from tpl_amd.optim import bench_ilqr
+        from benchkit import ilqr as bench_ilqr
         il = bench_ilqr.run(local_rank, seed=rank, barrier=barrier if dist is not None else None, id_offset=rank * 1024)
         lat = bench_ilqr.run(local_rank, seed=rank, barrier=barrier if dist is not None else None, id_offset=rank * 1024,
                              workload="lateral", updates=20)
@@ -523,7 +544,8 @@ def worker(args):
             if not args.no_cpu_baseline:
                 il["cpu_baseline"] = ilqr_cpu_baseline(x0_mpc, 50, 10.0, "mpc")
                 lat["cpu_baseline"] = ilqr_cpu_baseline(x0_lat, 250, 6.0, "lateral")
-            from tpl_amd import latency
+            il["batch_sweep"] = bench_ilqr.batch_sweep(local_rank)
+            from benchkit import latency
             secondary["plan_latency"] = latency.run(local_rank)
             if not args.no_cpu_baseline:
                 pl = secondary["plan_latency"]
@@ -561,9 +583,9 @@ def launcher(args, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
-    rc = procs[0].returncode
+    rc = 1 if procs[0].returncode != 0 else 0          # a rank killed by a signal has a NEGATIVE code: any non-zero is failure
     for pr in procs[1:]:
-        rc = max(rc, pr.wait())
+        rc = rc or (1 if pr.wait() != 0 else 0)
     # ONE JSON line on stdout: rank 0's (gloo announces its connections on stdout in the rehearsal set-up)
     lines = [ln for ln in out.decode("utf8", "replace").splitlines() if ln.startswith("{")]
     if lines:

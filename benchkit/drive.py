@@ -113,7 +113,7 @@ class Drive:
                 cross[:, 2], cross[:, 3], cross[:, 5] = hx + np.pi / 2, d + 60.0, 13.9
                 seg = NS(uuid="map-cross", name="crossing", path=cross)
                 stop_pos = frenet(path, s_x - 8.0, 0.0)[0]
-                from .planning.geometry import project
+                from tpl_amd.planning.geometry import project
                 local_map.intersection_paths = [NS(stop_pos=stop_pos, stop_proj=project(path[:, :2], stop_pos), map_segment=seg)]
                 for (d0, v, acc) in ((-40.0 + 0.0, 6.0, 0.0), (-25.0, 3.0, 1.5)):
                     sc = 60.0 + d0 + v * k * DT

@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6          # MI355X_MICROARCH.md / SURVEY 8d: fp64 vector = fp64 MFMA peak
 
@@ -101,7 +101,7 @@ WORKLOADS = {
 def flops_per_stage(problem, dims, dyn_evals):
     """(F_bw, F_deriv, F_roll) per stage: backward-pass count of SURVEY 8a, and the generator's own operation
     counts of the routines one derivative refresh / one rollout stage evaluates (genopt.routine_flops)."""
-    from . import genopt
+    from tpl_amd.optim import genopt
     fl = genopt.routine_flops(problem)
     X, U = dims
     f = lambda name: fl.get(name, {}).get("flops", 0)
@@ -116,7 +116,7 @@ def flops_per_stage(problem, dims, dyn_evals):
 def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrier=None, id_offset=0, workload="mpc"):
     """One rank's share of a batched-iLQR workload.  `seed` picks this rank's block of initial states,
     `barrier` (N > 1) brackets the timed region, `id_offset` is the global id of this rank's problem 0."""
-    from . import genopt, optimizers as o
+    from tpl_amd.optim import genopt, optimizers as o
     w = WORKLOADS[workload]
     horizon = horizon or w["horizon"]
     make = genopt.build(getattr(o, w["config"])(), w["problem"])
@@ -170,7 +170,7 @@ def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrie
         # algorithmic flops per batched iteration = batch x T x (F_bw + F_deriv + n_ls F_roll) over the
         # kernel time of one iteration, against the fp64 vector peak.  The path is latency-bound by construction
         # (50-250 dependent stages on one wavefront per problem); MFMA is not used.
-        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_VECTOR_PEAK_TFLOPS,
+        "roofline": {"bound": "valu_fp64", "unit": "TFLOP/s", "peak": FP64_VECTOR_PEAK_TFLOPS,
                      "achieved": per_iter * iters / k_s / 1e12, "frac": per_iter * iters / k_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                      "traffic": None, "kernel": "k_ilqr_update",
                      "flops_per_stage": {"F_bw": f_bw, "F_deriv": f_deriv, "F_roll": f_roll, "n_ls": n_ls},
@@ -188,9 +188,23 @@ def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrie
     return out
 
 
+def batch_sweep(device=0, batches=(256, 512, 1024, 2048, 4096), updates=3, warmup=1, workload="mpc"):
+    """Problem-iterations/s against the batch size: 1024 problems are one wavefront per SIMD of the chip, so 2048 / 4096
+    show what a second / fourth wavefront per SIMD hides of the dependent chains."""
+    out = []
+    for b in batches:
+        r = run(device=device, batch=b, updates=updates, warmup=warmup, workload=workload)
+        out.append({"batch": b, "batched_iters_per_s": r["value"], "problem_iterations_per_s": r["problem_iterations_per_s"],
+                    "kernel_ms_per_update": r["kernel_ms_per_update"]})
+    return out
+
+
 if __name__ == "__main__":
     import json
     sys.path.insert(0, ROOT)
+    if "--batch-sweep" in sys.argv:
+        print(json.dumps(batch_sweep()))
+        sys.exit(0)
     res = run(workload=sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "mpc")
     res.pop("best_record", None)
     res.pop("x0", None)

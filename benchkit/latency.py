@@ -2,7 +2,7 @@
 "p50 plan latency on default scenario"): host buffers in, host buffers out, one
 vehicle, exactly how tpl's planner / controller plugins would call the engines.
 
-* MPC: the closed loop of tpl_amd/minisim.py -- the simulator's ego model (core.py:91-135, with
+* MPC: the closed loop of benchkit/minisim.py -- the simulator's ego model (core.py:91-135, with
   actuator dead time) under the controller's per-tick use of ``trajectory_tracking_mpc`` with N = 20
   (the template's default horizon, optim.c:1900), tracking a straight 8 m/s plan, one ``Optim.update()``
   per 10 ms tick like tplsim's fixed_time_step, 1 000 ticks.
@@ -15,10 +15,10 @@ import numpy as np
 
 
 def mpc_closed_loop(device=0, ticks=1000, horizon=20):
-    """BASELINE configs[0] reduced to the hot path (tpl_amd/minisim.py): the simulator's ego model with 0.1 s actuator
+    """BASELINE configs[0] reduced to the hot path (benchkit/minisim.py): the simulator's ego model with 0.1 s actuator
     dead time under the model-predictive controller's per-tick solver use, N = 20, 1 000 ticks of 10 ms."""
     from . import minisim
-    from .optim import genopt, optimizers as o
+    from tpl_amd.optim import genopt, optimizers as o
     make = genopt.build(o.config_trajectory_tracking_mpc(), "trajectory_tracking_mpc")
     opt = make(device=device)
     opt.horizon = horizon
@@ -30,7 +30,7 @@ def mpc_closed_loop(device=0, ticks=1000, horizon=20):
             "mean_iterations": float(np.mean(opt.iterations)), "ticks": int(len(lat)),
             "final_lateral_error_m": float(abs(trace[-1, 1])), "final_speed_mps": float(trace[-1, 3]),
             "what": f"Optim.update() of trajectory_tracking_mpc, batch 1, N={horizon}, HEUN, <=20 iterations, inside the "
-                    "closed loop of tpl_amd/minisim.py (ego model with 0.1 s dead time under the ModelPredictiveController plugin, straight 8 m/s plan); "
+                    "closed loop of benchkit/minisim.py (ego model with 0.1 s dead time under the ModelPredictiveController plugin, straight 8 m/s plan); "
                     "host mirrors in and out (H2D + kernel + D2H)"}
 
 
@@ -155,13 +155,13 @@ def lat_lon_update(device=0, updates=40):
 
 def planner_cycles(device=0, cycles=80):
     """Whole planner-plugin cycles (what tplsim times as a planner's update): PolyLatDpLonPlanner.update and
-    DpLatLonPlanner.update on the synthetic drive of tpl_amd/drive.py -- environment update with prediction geometry
+    DpLatLonPlanner.update on the synthetic drive of benchkit/drive.py -- environment update with prediction geometry
     for three objects, previous-plan shift, replan decision, lattice + (s,v,a) plan or (s,ds,l) plan + smoothing,
     trajectory assembly.  Host Python around the engine calls is inside the time, as it is in the reference."""
     from contextlib import contextmanager
     from . import drive
-    from .planning.dyn_prog import DpLatLonPlanner, PolyLatDpLonPlanner
-    from .store import Bundle
+    from tpl_amd.planning.dyn_prog import DpLatLonPlanner, PolyLatDpLonPlanner
+    from tpl_amd.store import Bundle
 
     @contextmanager
     def lock():
@@ -180,7 +180,7 @@ def planner_cycles(device=0, cycles=80):
         lat = np.array(lat[5:])
         out[name] = {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "cycles": int(len(lat)),
                      "env_update_p50_ms": float(np.percentile(engine[5:], 50)), "emergency": bool(tr.emergency),
-                     "what": f"{cls.__name__}.update on the drive of tpl_amd/drive.py (10 Hz, 230 m local map, 3 predicted "
+                     "what": f"{cls.__name__}.update on the drive of benchkit/drive.py (10 Hz, 230 m local map, 3 predicted "
                              "objects), default parameters of the plugin, HIP engines; Python glue included"}
     return out
 

@@ -86,7 +86,7 @@ def closed_loop(opt, ticks=1000, dt=0.01, int_step=0.005, horizon=None, **ego_kw
     controller, whose ``solve_ms`` lists the wall time of every ``Optim.update()`` and ``tick_ms`` that of every whole
     ``ModelPredictiveController.update`` (reference look-up, dead-time prediction, bounds and weights, the solve, the
     read-out)."""
-    from .control import ModelPredictiveController
+    from tpl_amd.control import ModelPredictiveController
     ego = EgoSim(**ego_kw)
     shared = SimpleNamespace()
     con = ModelPredictiveController(shared, _no_lock, solver=opt)

@@ -9,7 +9,7 @@ here as plain constants.
 
 import numpy as np
 
-from .dyn_prog import DynProgEnvParams, DynProgLonPlannerParams, LonState
+from tpl_amd.dyn_prog import DynProgEnvParams, DynProgLonPlannerParams, LonState
 
 # (s0 [m], v [m/s], length [m]) of the cars ahead of the ego vehicle in
 # data/scenarios/test/overtake_multiple_dynamic_obstacles/state.json

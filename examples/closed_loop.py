@@ -4,7 +4,7 @@
     python examples/closed_loop.py [poly_lat_dp_lon | dp_lat_lon] [seconds]
 
 The planner (tpl_amd.planning.dyn_prog: occupancy pipeline + lattice + DP (s,v,a), or DP (s,ds,l)) runs at 10 Hz on the
-synthetic road of tpl_amd/drive.py with three predicted objects; the trajectory-tracking MPC
+synthetic road of benchkit/drive.py with three predicted objects; the trajectory-tracking MPC
 (tpl_amd.control.ModelPredictiveController on the HIP iLQR solver) runs at 100 Hz; the ego vehicle is the kinematic
 single-track model with actuator dead time of tpl's simulator (tpl_amd/minisim.EgoSim).  Needs an MI355X."""
 import os
@@ -16,9 +16,9 @@ from types import SimpleNamespace as NS
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tpl_amd import drive                                                   # noqa: E402
+from benchkit import drive                                                   # noqa: E402
 from tpl_amd.control import ModelPredictiveController                       # noqa: E402
-from tpl_amd.minisim import EgoSim                                          # noqa: E402
+from benchkit.minisim import EgoSim                                          # noqa: E402
 from tpl_amd.planning.dyn_prog import DpLatLonPlanner, PolyLatDpLonPlanner  # noqa: E402
 from tpl_amd.store import Bundle                                            # noqa: E402
 

@@ -11,7 +11,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tpl_amd                                      # noqa: E402
-from tpl_amd import scenarios as sc                 # noqa: E402
+from benchkit import scenarios as sc                 # noqa: E402
 
 
 def main():
@@ -62,7 +62,8 @@ def main():
     print("(s,ds,l) plan s:", np.round(b[:, 1], 1), " l:", np.round(b[:, 5], 2))
 
     # --- MPC tracking of the speed plan start (batch of 1)
-    from tpl_amd.optim import bench_ilqr, genopt, optimizers as o
+    from tpl_amd.optim import genopt, optimizers as o
+    from benchkit import ilqr as bench_ilqr
     make = genopt.build(o.config_trajectory_tracking_mpc(), "trajectory_tracking_mpc")
     mpc = make(device=0)
     mpc.horizon = 20

@@ -1,4 +1,4 @@
-"""The synthetic drives of the planner-plugin tests live in the package (tpl_amd/drive.py: bench.py and the examples use
+"""The synthetic drives of the planner-plugin tests live in the package (benchkit/drive.py: bench.py and the examples use
 them too); this name is what the tests and the fixture generator import."""
-from tpl_amd.drive import *  # noqa: F401,F403
-from tpl_amd.drive import DT, Drive, trajectory_row  # noqa: F401
+from benchkit.drive import *  # noqa: F401,F403
+from benchkit.drive import DT, Drive, trajectory_row  # noqa: F401

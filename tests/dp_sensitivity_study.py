@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle_dp as O                      # noqa: E402
-from tpl_amd import scenarios as sc        # noqa: E402
+from benchkit import scenarios as sc        # noqa: E402
 
 VARIANTS = [
     ("fma", "FMA contraction like nvcc -fmad=true (gcc -ffp-contract=fast -mfma)"),

@@ -15,7 +15,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 import oracle_dp as O                       # noqa: E402
 import tpl_amd                              # noqa: E402
-from tpl_amd import scenarios as sc         # noqa: E402
+from benchkit import scenarios as sc         # noqa: E402
 
 
 def random_case(seed):

@@ -17,7 +17,7 @@ import oracle_env as oe                         # noqa: E402
 import oracle_lat_lon as oll                    # noqa: E402
 import oracle_poly_lat as opl                   # noqa: E402
 import tpl_amd                                  # noqa: E402
-from tpl_amd import scenarios as sc             # noqa: E402
+from benchkit import scenarios as sc             # noqa: E402
 
 
 def run_scene(seed):

@@ -7,7 +7,7 @@ from /root/reference in the build container) through the closed loops of tests/m
 
 Shims as in tests/golden/make_pvd_goldens.py (numba identity, objtoolbox merge/bundle, structstore unused, tplcpp's
 project / resample = this repository's host routines); the shared-parameter object answers ``deepcopy()`` like a
-structstore struct.  The ego model is tpl_amd.minisim.EgoSim on both sides."""
+structstore struct.  The ego model is benchkit.minisim.EgoSim on both sides."""
 import copy
 import os
 import sys

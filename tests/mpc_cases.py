@@ -1,4 +1,4 @@
-"""Closed loops for the trajectory-tracking controller plugin: tplsim's ego model (tpl_amd.minisim.EgoSim, a restatement
+"""Closed loops for the trajectory-tracking controller plugin: tplsim's ego model (benchkit.minisim.EgoSim, a restatement
 of simulation/core.py:91-135 used on BOTH sides) under a controller object, tracking a fixed planner trajectory along
 a curved road.  Shared by tests/golden/make_mpc_goldens.py (reference controller + reference solver) and the tests."""
 from contextlib import contextmanager
@@ -6,7 +6,7 @@ from types import SimpleNamespace as NS
 
 import numpy as np
 
-from tpl_amd.minisim import EgoSim
+from benchkit.minisim import EgoSim
 
 DT = 0.01
 

@@ -81,7 +81,7 @@ def test_loader_rejects_incomplete_and_misshapen_dumps(tmp_path):
 def test_oracle_stage_runner_feeds_every_stage_from_the_dump():
     """run_oracle on a dump assembled from its own results: exercises the stage chaining and the checker without a GPU."""
     import oracle_env as oe
-    from tpl_amd import scenarios as scn
+    from benchkit import scenarios as scn
     sc = F.Scene("straight")
     o = oe.OracleEnv(sc.ep)
     o.set_ref_line(sc.ref_line, sc.ref_step)

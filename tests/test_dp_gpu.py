@@ -9,7 +9,7 @@ import pytest
 
 import oracle_dp as O
 import tpl_amd
-from tpl_amd import scenarios as sc
+from benchkit import scenarios as sc
 from tpl_amd._capi import TplLonState
 
 pytestmark = pytest.mark.gpu

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_dp as O
-from tpl_amd import scenarios as sc
+from benchkit import scenarios as sc
 from tpl_amd._capi import TplLonState, TplPathState
 
 

@@ -14,7 +14,7 @@ import pytest
 
 import dp_golden_format as G
 import oracle_dp as O
-from tpl_amd import scenarios as sc
+from benchkit import scenarios as sc
 from tpl_amd._capi import TplLonState
 
 UNPINNED = ("HP-1 parity unpinned: no tests/golden/dp_lon_*.npz dumped from the reference's CUDA build "

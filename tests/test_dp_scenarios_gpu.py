@@ -6,7 +6,8 @@ import pytest
 
 import oracle_dp as O
 import tpl_amd
-from tpl_amd import scenarios as sc, sharding
+from benchkit import scenarios as sc
+from tpl_amd import sharding
 
 pytestmark = pytest.mark.gpu
 

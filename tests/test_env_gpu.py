@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 import oracle_env as oe
-from tpl_amd import DynProgEnvironment, DynProgLonPlanner, scenarios as sc
+from tpl_amd import DynProgEnvironment, DynProgLonPlanner
+from benchkit import scenarios as sc
 
 pytestmark = pytest.mark.gpu
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle_env as oe
-from tpl_amd import scenarios as sc
+from benchkit import scenarios as sc
 
 
 def _env(t_steps=4, s_steps=201, l_steps=31, **kw):

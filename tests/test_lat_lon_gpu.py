@@ -11,7 +11,7 @@ import pytest
 import oracle_env as oe
 import oracle_lat_lon as oll
 import tpl_amd
-from tpl_amd import scenarios as sc
+from benchkit import scenarios as sc
 from tpl_amd._capi import TplLatLonCartState, TplLatLonState
 
 pytestmark = pytest.mark.gpu

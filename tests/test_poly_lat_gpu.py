@@ -16,7 +16,7 @@ import pytest
 import oracle_env as oe
 import oracle_poly_lat as opl
 import tpl_amd
-from tpl_amd import scenarios as sc
+from benchkit import scenarios as sc
 
 pytestmark = pytest.mark.gpu
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import tpl_amd
-from tpl_amd import scenarios as sc
+from benchkit import scenarios as sc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _spec = importlib.util.spec_from_file_location("planning_oracle", os.path.join(ROOT, "oracle", "planning_oracle.py"))

@@ -18,7 +18,7 @@ GRID = (33, 9, 7, 5)          # s, v, a, stages: an oracle plan takes millisecon
 
 def _scenario(sid):
     """Scenario `sid` of a small Monte-Carlo set: own obstacles and initial state, seeded by the id."""
-    from tpl_amd import scenarios as sc
+    from benchkit import scenarios as sc
     S, V, A, T = GRID
     p = sc.lon_params(S, V, A, T)
     ep = sc.env_params(t_steps=T, s_steps=101, l_steps=21)

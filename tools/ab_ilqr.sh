@@ -27,7 +27,7 @@ run)
         for so in tools/ab_tmp/*.so; do
             cp "$so" $LIB
             printf "%-14s " "$(basename "$so" .so)"
-            python3 -m tpl_amd.optim.bench_ilqr --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; print(round(json.loads(sys.stdin.read())['value'], 1))"
+            python3 -m benchkit.ilqr --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; print(round(json.loads(sys.stdin.read())['value'], 1))"
         done
     done
     cp tools/ab_tmp/.shipped.so $LIB ;;

@@ -8,6 +8,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tpl_amd import latency                         # noqa: E402
+from benchkit import latency                         # noqa: E402
 r = latency.dp_default_plan(0, plans=60)
 print(r["p50_ms"], r["p99_ms"])

@@ -5,7 +5,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tpl_amd.optim import bench_ilqr  # noqa: E402
+from benchkit import ilqr as bench_ilqr  # noqa: E402
 
 res = bench_ilqr.run(workload=sys.argv[1] if len(sys.argv) > 1 else "mpc", updates=3, warmup=1)
 print("done", res["value"], res["kernel_ms_per_update"])

@@ -5,7 +5,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from tpl_amd.optim import solver, bench_ilqr
+from tpl_amd.optim import solver
+from benchkit import ilqr as bench_ilqr
 so = sys.argv[1]; batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 opt = solver.Optim(so, batch=batch, horizon=50, device=0)
 bench_ilqr._configure(opt, bench_ilqr.initial_states(batch))

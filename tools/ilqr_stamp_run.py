@@ -4,14 +4,15 @@ With ticks > 0 (batch 1) the stamps are those of the LAST tick of the mini-tplsi
 few iterations), i.e. what one controller cycle really costs."""
 import sys, os, numpy as np
 sys.path.insert(0, ".")
-from tpl_amd.optim import bench_ilqr, genopt, optimizers as o, solver
+from tpl_amd.optim import genopt, optimizers as o, solver
+from benchkit import ilqr as bench_ilqr
 cfg = o.config_trajectory_tracking_mpc()
 make = solver.factory(os.path.abspath("gpurun_out/libilqr_stamp.so"), cfg.param_defaults)
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 horizon = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 ticks = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 if ticks > 0:
-    from tpl_amd import minisim
+    from benchkit import minisim
     opt = make(device=0)
     opt.horizon = horizon
     os.environ["TPL_ILQR_STAMP_QUIET"] = "1"

@@ -5,6 +5,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tpl_amd import latency                         # noqa: E402
+from benchkit import latency                         # noqa: E402
 r = latency.lat_lon_update(0)
 print(r["p50_ms"], r["p99_ms"], r["update_traj_dp_p50_ms"])

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench  # noqa: E402
 import tpl_amd  # noqa: E402
-from tpl_amd import scenarios as sc  # noqa: E402
+from benchkit import scenarios as sc  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 S, V, A, T = sc.GRIDS["config2"]

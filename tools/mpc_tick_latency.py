@@ -1,7 +1,8 @@
-"""p50 wall time of Optim.update() in the closed MPC loop of tpl_amd/latency.py, with the kernel share."""
+"""p50 wall time of Optim.update() in the closed MPC loop of benchkit/latency.py, with the kernel share."""
 import sys, time, numpy as np
 sys.path.insert(0, ".")
-from tpl_amd.optim import bench_ilqr, genopt, optimizers as o
+from tpl_amd.optim import genopt, optimizers as o
+from benchkit import ilqr as bench_ilqr
 make = genopt.build(o.config_trajectory_tracking_mpc(), "trajectory_tracking_mpc")
 opt = make(device=0)
 opt.horizon = 20

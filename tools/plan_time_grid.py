@@ -9,7 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import tpl_amd                                       # noqa: E402
-from tpl_amd import scenarios as sc                  # noqa: E402
+from benchkit import scenarios as sc                  # noqa: E402
 
 S, V, A, T = (int(x) for x in sys.argv[1:5])
 plans = int(sys.argv[5]) if len(sys.argv) > 5 else 40

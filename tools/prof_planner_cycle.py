@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a planner plugin's cycle goes on the host: cProfile over 200 cycles of PolyLatDpLonPlanner.update /
-DpLatLonPlanner.update on the drive of tpl_amd/drive.py (engines on the GPU).  usage: prof_planner_cycle.py [poly|latlon]"""
+DpLatLonPlanner.update on the drive of benchkit/drive.py (engines on the GPU).  usage: prof_planner_cycle.py [poly|latlon]"""
 import cProfile
 import os
 import pstats
@@ -9,7 +9,7 @@ from contextlib import contextmanager
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tpl_amd import drive                                   # noqa: E402
+from benchkit import drive                                   # noqa: E402
 from tpl_amd.planning.dyn_prog import DpLatLonPlanner, PolyLatDpLonPlanner   # noqa: E402
 from tpl_amd.store import Bundle                            # noqa: E402
 

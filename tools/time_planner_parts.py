@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import tpl_amd                                              # noqa: E402
-from tpl_amd import drive                                   # noqa: E402
+from benchkit import drive                                   # noqa: E402
 from tpl_amd.planning import _kit                           # noqa: E402
 from tpl_amd.planning.dyn_prog import DpLatLonPlanner, PolyLatDpLonPlanner, env_feed, plugins   # noqa: E402
 from tpl_amd.store import Bundle                            # noqa: E402
