@@ -206,6 +206,36 @@ def lat_lon_cpu_baseline(reps=3):
             "sample": f"{reps} plans of the same scene (OpenMP over cells)"}
 
 
+def ilqr_crossover(device):
+    """Single-problem callers (tpl's default planner and controller): update() wall time of the HIP solver against the
+    batch size next to ONE core of the CPU restatement on the same problem and settings, and the batch from which the
+    HIP solver wins (SURVEY 8b callers)."""
+    import numpy as np
+    import oracle_ilqr as OI
+    from benchkit import ilqr as bench_ilqr
+    out = {}
+    for workload in ("mpc", "lateral"):
+        problem = bench_ilqr.WORKLOADS[workload]["problem"]
+        native = _native_oracle(f"libilqr_oracle_{problem}.so")
+        ref = OI.OracleOptim(problem, lib=OI.load(problem, path=native) if native else None)
+        x0 = (bench_ilqr.initial_states(1) if workload == "mpc" else bench_ilqr.initial_states_lateral(1))[0]
+        lat = []
+        for r in range(33):
+            bench_ilqr.configure_crossover(ref, workload, x0)
+            t0 = time.perf_counter()
+            ref.update()
+            lat.append((time.perf_counter() - t0) * 1e3)
+        cpu_ms = float(np.percentile(lat[3:], 50))
+        rows = bench_ilqr.crossover_gpu(device, workload)
+        cross = next((r["batch"] for r in rows if r["ms_per_problem"] < cpu_ms), None)
+        out[workload] = {"problem": problem, "horizon": bench_ilqr.CROSSOVER[workload]["horizon"],
+                         "iterations_per_update": bench_ilqr.CROSSOVER[workload]["iterations"],
+                         "cpu_one_core_ms_per_problem": cpu_ms, "cpu_kind": "port (oracle/ilqr_oracle.cpp, 1 thread)",
+                         "gpu": rows, "crossover_batch": cross,
+                         "reading": "below crossover_batch problems per call a caller is faster on the CPU solver"}
+    return out
+
+
 def mpc_cpu_baseline(ticks=1000, horizon=20):
     """oracle/ilqr_oracle.cpp (one thread, one problem) in the closed loop of latency.mpc_closed_loop
     (benchkit/minisim.py): what the reference's CPU genopt solver costs per controller tick on this host."""
@@ -545,6 +575,8 @@ def worker(args):
                 il["cpu_baseline"] = ilqr_cpu_baseline(x0_mpc, 50, 10.0, "mpc")
                 lat["cpu_baseline"] = ilqr_cpu_baseline(x0_lat, 250, 6.0, "lateral")
             il["batch_sweep"] = bench_ilqr.batch_sweep(local_rank)
+            if not args.no_cpu_baseline:
+                secondary["ilqr_single_problem_crossover"] = ilqr_crossover(local_rank)
             from benchkit import latency
             secondary["plan_latency"] = latency.run(local_rank)
             if not args.no_cpu_baseline:

@@ -199,6 +199,48 @@ def batch_sweep(device=0, batches=(256, 512, 1024, 2048, 4096), updates=3, warmu
     return out
 
 
+CROSSOVER = {"mpc": dict(horizon=20, iterations=5), "lateral": dict(horizon=250, iterations=5)}
+
+
+def configure_crossover(opt, workload, x0):
+    """The problem of the crossover table: the caller's shape (ModelPredictiveController plans N = 20 stages,
+    PathOptim T = 250 stations), 5 iterations per update() -- the template's default, min_rel_cost_change = 0 so that
+    the CPU and the GPU leg do exactly the same work -- from a cold start."""
+    c = CROSSOVER[workload]
+    if workload == "mpc":
+        opt.horizon = c["horizon"]
+        _configure(opt, x0)
+    else:
+        opt.horizon = c["horizon"]
+        _configure_lateral(opt, x0, c["horizon"])
+    opt.max_iterations = c["iterations"]
+    opt.min_rel_cost_change = 0.0
+
+
+def crossover_gpu(device=0, workload="mpc", batches=(1, 2, 4, 8, 16, 32, 64), reps=30):
+    """Wall time of ONE synchronous update() -- mirrors up, kernel, mirrors down: what a caller of the plugin surface
+    waits for -- against the batch size.  With bench.py's one-core CPU figure for the same problem this gives the batch
+    from which the HIP solver is the faster way to solve a set of problems."""
+    from tpl_amd.optim import genopt, optimizers as o
+    w = WORKLOADS[workload]
+    make = genopt.build(getattr(o, w["config"])(), w["problem"])
+    rows = []
+    for b in batches:
+        opt = make(batch=b, horizon=CROSSOVER[workload]["horizon"], device=device) if b > 1 else make(device=device)
+        x0 = initial_states(b) if workload == "mpc" else initial_states_lateral(b)
+        lat = []
+        for r in range(reps + 3):
+            configure_crossover(opt, workload, x0 if b > 1 else x0[0])
+            t0 = time.perf_counter()
+            opt.update()
+            lat.append((time.perf_counter() - t0) * 1e3)
+        lat = np.array(lat[3:])
+        rows.append({"batch": b, "update_ms_p50": float(np.percentile(lat, 50)), "ms_per_problem": float(np.percentile(lat, 50)) / b,
+                     "iterations": int(np.ravel(opt.iterations)[0])})
+        del opt
+    return rows
+
+
 if __name__ == "__main__":
     import json
     sys.path.insert(0, ROOT)

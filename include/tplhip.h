@@ -205,6 +205,14 @@ TPLHIP_API int tplhip_dp_lon_stage_download(tplhip_dp_lon* h, int slot);
 TPLHIP_API int tplhip_dp_lon_collect_download(tplhip_dp_lon* h, int slot, TplLonState* out_trajs);
 /* Launch geometry and code path of the sweep kernel as a small JSON object (diagnostics). */
 TPLHIP_API int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n);
+/* The two choices of the HP-1 arithmetic contract that stand in for the reference's TEXTURE UNIT -- undocumented
+ * hardware arithmetic behind tex3D (library/include/tplcpp/dyn_prog/arr_tex_surf.cuh:142-149), frozen here by reading,
+ * not by running -- as a run-time parameter of the planner, so that a dump of the CUDA build
+ * which disagrees (tests/test_dp_reference_golden.py names the variant) is answered by this call:
+ *   weight_quant  1 = filter weight rint(a * 256) / 256 (default), 2 = floor(a * 256) / 256, 0 = not quantised
+ *   lerp_form     0 = fma(q, w, p * (1 - w)) (default), 1 = p * (1 - w) + q * w (every operation rounded), 2 = p + w * (q - p)
+ * A non-default rule plans with the general sweep kernel (the plain-fp32 sweeps implement the default only). */
+TPLHIP_API int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_form);
 /* HIP-event timing of the backward sweeps (events recorded on the planner's
  * stream around the loop of launches).  enable=1 starts accumulating; get
  * returns the summed ms and the number of sweep launches since enable. */

@@ -97,6 +97,23 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-12))) if a.size else 0.0
 
 
+def score_against(g, trajs, tables=None):
+    """How far a plan is from the dump, as numbers instead of a verdict: trajectory nodes / table cells with another
+    action and the largest relative value differences (what tests/test_dp_reference_golden.py tabulates per variant)."""
+    p = g["p"]
+    want = g["trajs"]
+    ka, kb = action_index(trajs[..., 4], p, 21), action_index(want[..., 4], p, 21)
+    out = {"traj_nodes": int(ka[:, :-1].size), "traj_nodes_other_action": int(np.count_nonzero(ka[:, :-1] != kb[:, :-1])),
+           "traj_value_rel": max(rel_err(trajs[..., c], want[..., c]) for c in (1, 2, 3, 5, 6)),
+           "table_cells": 0, "table_cells_other_action": 0, "table_value_rel": 0.0}
+    for t, ref in g["tables"].items():
+        got = tables[t]
+        out["table_cells"] += int(ref[..., 2].size)
+        out["table_cells_other_action"] += int(np.count_nonzero(action_index(got[..., 2], p, 9) != action_index(ref[..., 2], p, 9)))
+        out["table_value_rel"] = max(out["table_value_rel"], rel_err(got[..., 0], ref[..., 0]), rel_err(got[..., 1], ref[..., 1]))
+    return out
+
+
 def check_against(g, trajs, tables=None, who=""):
     """trajs: float32[n, T, 7] computed on g's inputs; tables: {t: float32[a, v, s, 4]} or None.
     Raises AssertionError naming the first thing outside the bar."""

@@ -450,3 +450,50 @@ def test_unbounded_inputs_take_the_two_pass_kernel_and_still_match():
         tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, init)
         _assert_tables_equal(dp, tables, T)
         assert np.array_equal(_traj_np(trajs[0]).view(np.uint32), otrajs[0].view(np.uint32))
+
+
+@pytest.mark.parametrize("name,quant,lerp", [("wfloor", 2, 0), ("wnone", 0, 0), ("lerp1", 1, 1), ("lerp2", 1, 2)])
+def test_filter_rule_variants_match_their_oracle_builds(name, quant, lerp):
+    """R2 (weight quantisation) and R3 (blend form) stand in for the reference's texture unit; they are run-time
+    parameters of the HIP planner (tplhip_dp_lon_set_filter_rule).  Each non-default rule must reproduce the
+    sensitivity build of the CPU restatement that makes the same choice (oracle/Makefile, _sens/) bit for bit --
+    tables, trajectories, re-evaluation -- on a small and on a several-rounds-deep grid, and setting the default again
+    must bring back the default result and the plain-fp32 sweep."""
+    import os
+    import subprocess
+    odir = os.path.join(O.ROOT, "oracle")
+    lib = os.path.join(odir, f"_sens/libdp_lon_oracle_{name}.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", odir, f"_sens/libdp_lon_oracle_{name}.so"])
+    for (S, V, A, T), want_default in (((201, 37, 20, 6), "k_backward3s"), ((128, 64, 66, 3), "k_backward3v")):
+        p = sc.lon_params(S, V, A, T)
+        ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+        path = sc.straight_path(p.path_steps, p.path_step_size)
+        occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
+        inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(4, seed=3)
+        env = tpl_amd.DynProgEnvironment()
+        env.reinit_buffers(ep)
+        env.set_occ_map(occ)
+        dp = tpl_amd.DynProgLonPlanner()
+        dp.reinit_buffers(p)
+        dp.set_filter_rule(quant, lerp)
+        trajs = dp.update_batch(inits, path, env)
+        assert dp.info()["sweep"] == "k_backward", dp.info()
+        cp, cep = O.cparams(p), O.cparams(ep)
+        O.use(lib)
+        try:
+            tables, otrajs, _ = O.update(cp, cep, path, occ, inits)
+        finally:
+            O.use(None)
+        _assert_tables_equal(dp, tables, T)
+        for r, tr in enumerate(trajs):
+            assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (name, r)
+        # the default rule again: default tables, default kernel
+        dp.set_filter_rule(1, 0)
+        trajs = dp.update_batch(inits, path, env)
+        assert dp.info()["sweep"] == want_default, dp.info()
+        tables0, otrajs0, _ = O.update(cp, cep, path, occ, inits)
+        _assert_tables_equal(dp, tables0, T)
+        assert any(not np.array_equal(tables0[t].view(np.uint32), tables[t].view(np.uint32)) for t in range(1, T)), "the variant changes nothing here"
+    with pytest.raises(ValueError):
+        dp.set_filter_rule(3, 0)

@@ -38,6 +38,49 @@ def _oracle_plan(g):
     return O.states_to_np(out).reshape(n, p.t_steps, 7), {t: tables[t] for t in g["tables"]}
 
 
+# The binary-level choices the restatement freezes (R1 no contraction, R2 rint quantisation, R3 blend
+# form) and the sensitivity builds of oracle/dp_lon_oracle.c that make each one differently (oracle/Makefile).
+VARIANTS = [("contract", None, "the checker: no contraction, weight rint(a*256)/256, blend fma(q, w, p*(1-w))"),
+            ("fma", "_sens/libdp_lon_oracle_fma.so", "R1: multiply-adds contracted like nvcc -fmad=true"),
+            ("wfloor", "_sens/libdp_lon_oracle_wfloor.so", "R2: weight truncated to 8 fractional bits"),
+            ("wnone", "_sens/libdp_lon_oracle_wnone.so", "R2: weight not quantised"),
+            ("lerp1", "_sens/libdp_lon_oracle_lerp1.so", "R3: blend p*(1-w) + q*w, every operation rounded"),
+            ("lerp2", "_sens/libdp_lon_oracle_lerp2.so", "R3: blend p + w*(q-p)"),
+            ("fma_wfloor", "_sens/libdp_lon_oracle_fma_wfloor.so", "R1 + R2: contracted AND truncated weights")]
+
+
+def variant_table(g):
+    """Which rule to flip: every sensitivity build of the restatement against the dump, best match first.  A maintainer
+    who drops a dump of the CUDA build into tests/golden/ and sees the checker fail reads the row with zero (or the
+    fewest) other actions: that is what the reference binary does."""
+    import os
+    import subprocess
+    odir = os.path.join(O.ROOT, "oracle")
+    rows = []
+    for name, rel, what in VARIANTS:
+        if rel is not None:
+            path = os.path.join(odir, rel)
+            if not os.path.exists(path) and subprocess.call(["make", "-s", "-C", odir, rel], stdout=subprocess.DEVNULL,
+                                                            stderr=subprocess.DEVNULL) != 0:
+                continue                                   # e.g. -mfma on a host without FMA3
+            O.use(path)
+        try:
+            trajs, tables = _oracle_plan(g)
+        finally:
+            O.use(None)
+        rows.append(dict(G.score_against(g, trajs, tables), variant=name, what=what))
+    rows.sort(key=lambda r: (r["table_cells_other_action"] + r["traj_nodes_other_action"], r["table_value_rel"], r["traj_value_rel"]))
+    return rows
+
+
+def format_variant_table(rows):
+    lines = ["variant      traj nodes w/ other action   table cells w/ other action   max rel (traj / tables)   rule"]
+    for r in rows:
+        lines.append(f"{r['variant']:12s} {r['traj_nodes_other_action']:6d} of {r['traj_nodes']:<8d}          "
+                     f"{r['table_cells_other_action']:8d} of {r['table_cells']:<10d}   {r['traj_value_rel']:.1e} / {r['table_value_rel']:.1e}   {r['what']}")
+    return "\n".join(lines)
+
+
 def _hip_plan(g):
     import tpl_amd
     p = tpl_amd.DynProgLonPlannerParams()
@@ -67,9 +110,7 @@ def _params():
 
 @pytest.mark.parametrize("path", _params())
 def test_cpu_restatement_matches_reference_dump(path):
-    g = G.load(path)
-    trajs, tables = _oracle_plan(g)
-    G.check_against(g, trajs, tables, who="oracle/dp_lon_oracle.c")
+    _check_cpu(path)
 
 
 @pytest.mark.gpu
@@ -124,6 +165,51 @@ def test_loader_round_trip_and_bar(tmp_path):
     np.savez(str(tmp_path / "dp_lon_broken.npz"), **z)
     with pytest.raises(ValueError, match="occ has shape"):
         G.load(str(tmp_path / "dp_lon_broken.npz"))
+
+
+def test_variant_table_names_the_rule(tmp_path, capsys):
+    """Day-one use of a dump: the table ranks the sensitivity builds against it.  Here the "dump" is written by ONE of
+    the variants (truncated filter weights) standing in for the CUDA build: the checker fails on it, and the table puts
+    exactly that variant first with zero other actions."""
+    import os
+    import subprocess
+    odir = os.path.join(O.ROOT, "oracle")
+    stand_in = os.path.join(odir, "_sens/libdp_lon_oracle_wfloor.so")
+    if not os.path.exists(stand_in):
+        subprocess.check_call(["make", "-s", "-C", odir, "_sens/libdp_lon_oracle_wfloor.so"])
+    S, V, A, T = 65, 12, 9, 6
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=101, l_steps=21)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
+    inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(15, seed=2)
+    cp, cep = O.cparams(p), O.cparams(ep)
+    O.use(stand_in)
+    try:
+        tables, trajs, _ = O.update(cp, cep, path, occ, inits)
+    finally:
+        O.use(None)
+    f = str(tmp_path / "dp_lon_standin.npz")
+    G.save(f, cp, cep, path, occ, O.states_to_np([s._c for s in inits]), trajs, {t: tables[t] for t in range(1, T)})
+    g = G.load(f)
+    rows = variant_table(g)
+    print(format_variant_table(rows))
+    assert rows[0]["variant"] == "wfloor", rows[0]
+    assert rows[0]["table_cells_other_action"] == 0 and rows[0]["traj_nodes_other_action"] == 0 and rows[0]["table_value_rel"] == 0.0
+    by = {r["variant"]: r for r in rows}
+    assert by["contract"]["table_cells_other_action"] > 0          # the checker itself is NOT what wrote this dump ...
+    with pytest.raises(AssertionError, match="best first"):          # ... and its failure carries the table
+        _check_cpu(f)
+
+
+def _check_cpu(path):
+    g = G.load(path)
+    trajs, tables = _oracle_plan(g)
+    try:
+        G.check_against(g, trajs, tables, who="oracle/dp_lon_oracle.c")
+    except AssertionError as e:
+        raise AssertionError(f"{e}\n\nsensitivity variants of the restatement against this dump, best first:\n"
+                             + format_variant_table(variant_table(g))) from None
 
 
 @pytest.mark.gpu

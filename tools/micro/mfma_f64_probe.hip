@@ -48,9 +48,11 @@ __global__ void __launch_bounds__(64) k_fma(const double* __restrict__ Fall, dou
     for (int e = lane; e < PA * PA; e += 64) s.Vxx[e] = ((e >> 3) == (e & 7) && (e >> 3) < NX) ? 1.0 : 0.0;
     lds_sync();
     const long long t0 = __builtin_amdgcn_s_memtime();
+    double f0 = Fall[lane], f1 = Fall[min(lane + 64, PA * PB - 1)];          // stage 0; the next stage is requested a stage ahead, as in the solver
     for (int t = 0; t < T; ++t) {
-        const double* F = Fall + (size_t)t * PA * PB;
-        for (int e = lane; e < PA * PB; e += 64) s.F[e] = F[e];
+        s.F[lane] = f0; if (lane + 64 < PA * PB) s.F[lane + 64] = f1;
+        const double* Fn = Fall + (size_t)min(t + 1, T - 1) * PA * PB;
+        f0 = Fn[lane]; f1 = Fn[min(lane + 64, PA * PB - 1)];
         lds_sync();
         {   // phase A: lane = (i, j) of W, 63 entries
             const int e = min(lane, NX * NXU - 1), i = e / NXU, j = e - i * NXU;
@@ -85,46 +87,53 @@ __global__ void __launch_bounds__(64) k_fma(const double* __restrict__ Fall, dou
     if (blockIdx.x == 0) out[lane] = s.Vxx[lane];
 }
 
-// v_mfma_f64_4x4x4_4b: lane l = 16 b + 4 k + i holds A_b[i][k]; lane l = 16 b + 4 k + j holds B_b[k][j]; lane l = 16 b + 4 i + j
-// holds D_b[i][j]  (verified at run time against the FMA form: a wrong layout shows as a mismatch, not as a timing)
-__global__ void __launch_bounds__(64) k_mfma(const double* __restrict__ Fall, double* __restrict__ out, long long* __restrict__ cyc)
+// v_mfma_f64_4x4x4_4b: lane l = 16 b + 4 hi + lo; which of (hi, lo) is the row / column / k index of the A, B and D
+// fragments is found at run time: main() tries the eight assignments and keeps the one that reproduces the FMA form
+// la / lb / ld = 1 swap the roles of the two 2-bit lane fields of the A / B / D fragment
+__global__ void __launch_bounds__(64) k_mfma(const double* __restrict__ Fall, double* __restrict__ out, long long* __restrict__ cyc,
+                                             int la, int lb, int ld)
 {
     __shared__ Lds s;
     const int lane = threadIdx.x;
     const int b = lane >> 4, hi = (lane >> 2) & 3, lo = lane & 3;
+    const int ai = la ? hi : lo, ak = la ? lo : hi;      // A_b[i][k] of this lane
+    const int bk = lb ? lo : hi, bj = lb ? hi : lo;      // B_b[k][j]
+    const int di = ld ? lo : hi, dj = ld ? hi : lo;      // D_b[i][j]
     for (int e = lane; e < PA * PA; e += 64) s.Vxx[e] = ((e >> 3) == (e & 7) && (e >> 3) < NX) ? 1.0 : 0.0;
     lds_sync();
     const long long t0 = __builtin_amdgcn_s_memtime();
+    double f0 = Fall[lane], f1 = Fall[min(lane + 64, PA * PB - 1)];
     for (int t = 0; t < T; ++t) {
-        const double* F = Fall + (size_t)t * PA * PB;
-        for (int e = lane; e < PA * PB; e += 64) s.F[e] = F[e];
+        s.F[lane] = f0; if (lane + 64 < PA * PB) s.F[lane + 64] = f1;
+        const double* Fn = Fall + (size_t)min(t + 1, T - 1) * PA * PB;
+        f0 = Fn[lane]; f1 = Fn[min(lane + 64, PA * PB - 1)];
         lds_sync();
         // phase A: W (8 x 12) = Vxx (8 x 8) F (8 x 12): output blocks (bi, bj), bi < 2, bj < 3; instruction 0 = blocks 0..3, 1 = blocks 4, 5
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const int blk = min(g * 4 + b, 5), bi = blk / 3, bj = blk - bi * 3;
+            const int blk = min(g * 4 + b, 5), bi = blk / 3, bj_ = blk - bi * 3;
             double acc = 0.0;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const double a = s.Vxx[(bi * 4 + lo) * PA + kk * 4 + hi];          // A_b[i = lo][k = hi]
-                const double bb = s.F[(kk * 4 + hi) * PB + bj * 4 + lo];            // B_b[k = hi][j = lo]
+                const double a = s.Vxx[(bi * 4 + ai) * PA + kk * 4 + ak];
+                const double bb = s.F[(kk * 4 + bk) * PB + bj_ * 4 + bj];
                 acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, acc, 0, 0, 0);
             }
-            if (g * 4 + b < 6) s.W[(bi * 4 + hi) * PB + bj * 4 + lo] = acc;        // D_b[i = hi][j = lo]
+            if (g * 4 + b < 6) s.W[(bi * 4 + di) * PB + bj_ * 4 + dj] = acc;
         }
         lds_sync();
         // phase B: Q (12 x 12) = F^T (12 x 8) W (8 x 12): nine output blocks, three instructions of four (the last holds one)
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-            const int blk = min(g * 4 + b, 8), bi = blk / 3, bj = blk - bi * 3;
+            const int blk = min(g * 4 + b, 8), bi = blk / 3, bj_ = blk - bi * 3;
             double acc = 0.0;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const double a = s.F[(kk * 4 + hi) * PB + bi * 4 + lo];            // A = F^T: A_b[i = lo][k = hi] = F[k][c = 4 bi + lo]
-                const double bb = s.W[(kk * 4 + hi) * PB + bj * 4 + lo];
+                const double a = s.F[(kk * 4 + ak) * PB + bi * 4 + ai];            // A = F^T: A_b[i][k] = F[k][c = 4 bi + i]
+                const double bb = s.W[(kk * 4 + bk) * PB + bj_ * 4 + bj];
                 acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, acc, 0, 0, 0);
             }
-            if (g * 4 + b < 9) s.Q[(bi * 4 + hi) * PB + bj * 4 + lo] = acc;
+            if (g * 4 + b < 9) s.Q[(bi * 4 + di) * PB + bj_ * 4 + dj] = acc;
         }
         lds_sync();
         next_vxx(&s, lane);
@@ -149,21 +158,33 @@ int main()
     CK(hipMemcpy(dF, F.data(), F.size() * 8, hipMemcpyHostToDevice));
     std::vector<double> res[2];
     const char* names[2] = {"fma (dot_lds form)", "mfma_f64_4x4x4_4b"};
-    for (int form = 0; form < 2; ++form) {
+    auto run = [&](int form, int la, int lb, int ld, bool print) {
         std::vector<long long> cyc(blocks);
         for (int rep = 0; rep < 3; ++rep) {
             if (form == 0) hipLaunchKernelGGL(k_fma, dim3(blocks), dim3(64), 0, 0, dF, dout, dcyc);
-            else hipLaunchKernelGGL(k_mfma, dim3(blocks), dim3(64), 0, 0, dF, dout, dcyc);
+            else hipLaunchKernelGGL(k_mfma, dim3(blocks), dim3(64), 0, 0, dF, dout, dcyc, la, lb, ld);
             CK(hipDeviceSynchronize());
         }
         CK(hipMemcpy(cyc.data(), dcyc, blocks * 8, hipMemcpyDeviceToHost));
         res[form].resize(64);
         CK(hipMemcpy(res[form].data(), dout, 64 * 8, hipMemcpyDeviceToHost));
         double sum = 0; for (long long c : cyc) sum += (double)c;
-        printf("%-22s %8.1f shader cycles per stage (s_memtime, mean over %d wavefronts, %d stages)\n", names[form], sum / blocks / T, blocks, T);
+        if (print) printf("%-22s %8.1f shader cycles per stage (s_memtime, mean over %d wavefronts, %d stages)\n", names[form], sum / blocks / T, blocks, T);
+    };
+    auto diff = [&]() {
+        double w = 0.0;
+        for (int i = 0; i < 64; ++i) w = std::fmax(w, std::fabs(res[0][i] - res[1][i]) / std::fmax(1.0, std::fabs(res[0][i])));
+        return w;
+    };
+    run(0, 0, 0, 0, true);
+    int best = -1;
+    for (int m = 0; m < 8 && best < 0; ++m) {
+        run(1, m & 1, (m >> 1) & 1, (m >> 2) & 1, false);
+        if (diff() < 1e-9) best = m;
     }
-    double worst = 0.0;
-    for (int i = 0; i < 64; ++i) worst = std::fmax(worst, std::fabs(res[0][i] - res[1][i]) / std::fmax(1.0, std::fabs(res[0][i])));
-    printf("largest relative difference between the two forms' final Vxx: %.3e %s\n", worst, worst < 1e-9 ? "(same product)" : "(LAYOUT WRONG)");
+    if (best < 0) { printf("no fragment layout reproduces the FMA form\n"); return 1; }
+    printf("fragment layout: A %s, B %s, D %s\n", (best & 1) ? "i=hi k=lo" : "i=lo k=hi", (best & 2) ? "k=lo j=hi" : "k=hi j=lo", (best & 4) ? "i=lo j=hi" : "i=hi j=lo");
+    run(1, best & 1, (best >> 1) & 1, (best >> 2) & 1, true);
+    printf("largest relative difference between the two forms' final Vxx: %.3e (same product, sums in a different order)\n", diff());
     return 0;
 }

@@ -43,7 +43,7 @@ namespace {
 // ------------------------------------------------------------------------
 // descriptor table: one thread per (row, action)
 // ------------------------------------------------------------------------
-__global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p)
+__global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p, FilterRule rule)
 {
     const int nrows = p.v_steps * p.a_steps;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,8 +70,8 @@ __global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p)
     // lon_planner.cu:125-130: a' < a_min and a' > a_max exclude each other, and adding the
     // +0 of the branch not taken leaves a float unchanged, so one addend carries both tests
     d.a_viol = (tn.a < p.a_min) ? (p.a_min - tn.a) : ((tn.a > p.a_max) ? (tn.a - p.a_max) : 0.0f);
-    const Tap tv = make_tap(node_coord(tn.v, p.v_min, p.v_max, p.v_steps), p.v_steps);
-    const Tap ta = make_tap(node_coord(tn.a, p.a_min, p.a_max, p.a_steps), p.a_steps);
+    const Tap tv = make_tap(node_coord(tn.v, p.v_min, p.v_max, p.v_steps), p.v_steps, rule);
+    const Tap ta = make_tap(node_coord(tn.a, p.a_min, p.a_max, p.a_steps), p.a_steps, rule);
     d.wa = ta.w; d.wv = tv.w;
     d.iwa = 1.0f - ta.w; d.iwv = 1.0f - tv.w;
     d.tn_v = tn.v;
@@ -93,7 +93,7 @@ __global__ void k_stage_prelude(float* __restrict__ pre_vmax, float* __restrict_
                                 double* __restrict__ pre_prog,
                                 const float* __restrict__ path, const float* __restrict__ dist_ts,
                                 TplDpLonParams p, TplDpEnvParams ep,
-                                size_t stride_pre, size_t stride_path, size_t stride_dist)
+                                size_t stride_pre, size_t stride_path, size_t stride_dist, FilterRule rule)
 {
     const int idx_t = blockIdx.x;
     if (idx_t < 1) return;
@@ -107,7 +107,7 @@ __global__ void k_stage_prelude(float* __restrict__ pre_vmax, float* __restrict_
         const PathTap pt = path_tap(s, p.path_step_size, p.path_steps);
         const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
         const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
-        const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, t, cps_s)
+        const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, t, cps_s, rule)
                                      - (double)p.length_veh * 0.6);
         pre_vmax[(size_t)idx_t * p.s_steps + is] = v_max;
         pre_sdist[(size_t)idx_t * p.s_steps + is] = s_dist;
@@ -136,7 +136,7 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
                            const double* __restrict__ pre_prog,   // [s_steps]
                            TplDpLonParams p, int s_pad, int rows_per_block, int nblocks,
                            int tile_v, int tile_a,
-                           size_t stride_tables, size_t stride_pre, size_t stride_path)
+                           size_t stride_tables, size_t stride_pre, size_t stride_path, FilterRule rule)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // scenario batch: blockIdx.y selects the scenario's tables, stage prelude and path (strides 0 = shared)
@@ -251,9 +251,17 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
                     p11 = ld_node(next + (size_t)d->r11 * S + is);
                 }
                 const float wa = d->wa, iwa = d->iwa, wv = d->wv, iwv = d->iwv;
-                const float4 b0 = lerp4w(p00, p10, wa, iwa);
-                const float4 b1 = lerp4w(p01, p11, wa, iwa);
-                R[kk * blockDim.x + tid] = lerp4w(b0, b1, wv, iwv);
+                float4 b0, b1, bb;
+                if (rule.lerp == 0) {                  // (the complements 1 - w come with the descriptor)
+                    b0 = lerp4w(p00, p10, wa, iwa);
+                    b1 = lerp4w(p01, p11, wa, iwa);
+                    bb = lerp4w(b0, b1, wv, iwv);
+                } else {
+                    b0 = lerp4(p00, p10, wa, rule);
+                    b1 = lerp4(p01, p11, wa, rule);
+                    bb = lerp4(b0, b1, wv, rule);
+                }
+                R[kk * blockDim.x + tid] = bb;
             }
         }
         __syncthreads();
@@ -276,11 +284,11 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
                 const float cs = qs * s_scale + 0.5f;         // == (float)((double)c + 0.5), see node_coord
                 const float xb = cs - 0.5f;
                 const float fl = floorf(xb);
-                const float ws = rintf((xb - fl) * 256.0f) * (1.0f / 256.0f);
+                const float ws = quant_weight(xb - fl, rule);
                 const int i_lo = (int)fminf(fl, s_scale);
                 const int i_hi = min(i_lo + 1, S - 1);
                 const float4* Rk = R + kk * blockDim.x + rib * s_pad;
-                const float4 node = lerp4(Rk[i_lo], Rk[i_hi], ws);
+                const float4 node = lerp4(Rk[i_lo], Rk[i_hi], ws, rule);
                 // interpPath(tn.s).v_max, lon_planner.cu:114
                 const float alpha = tn_s / p.path_step_size;
                 const PathTap pt = path_tap_q(alpha, p.path_steps);
@@ -379,14 +387,14 @@ __device__ __forceinline__ void eval_node_wave(TplLonState& tp, const Node* __re
                                                const float* __restrict__ path,
                                                const float* __restrict__ dist_ts,
                                                const TplDpLonParams& p, const TplDpEnvParams& ep,
-                                               float dt, bool choose_action)
+                                               float dt, bool choose_action, FilterRule rule = kDefaultRule)
 {
     const int lane = threadIdx.x & 63;
 
     const PathTap pt = path_tap(tp.s, p.path_step_size, p.path_steps);
     const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
     const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
-    const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, tp.t, cps_s)
+    const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, tp.t, cps_s, rule)
                                  - (double)p.length_veh * 0.6);
     const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist);
     float sg = 0.0f;
@@ -400,7 +408,7 @@ __device__ __forceinline__ void eval_node_wave(TplLonState& tp, const Node* __re
     const int k = choose_action ? lane : 0;
     const float j = choose_action ? action_jerk(p, k < N ? k : N - 1, N) : tp.j;
     const TplLonState tn = lon_dynamics(tp, j, dt);
-    const float4 node = read_node(p, table_next, tn.s, tn.v, tn.a);
+    const float4 node = read_node(p, table_next, tn.s, tn.v, tn.a, rule);
     const PathTap pn = path_tap(tn.s, p.path_step_size, p.path_steps);
     const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5]);
     const ActionResult r = eval_action_tail(p, sc, sg, node, j, state_action_cost(p, j, dt),
@@ -438,13 +446,15 @@ constexpr int FWD_RING = 16;
 
 // Scenario batches: rollout r belongs to scenario r (one rollout each); its tables, path and distance map are
 // stride_* elements further on (0 = shared by all rollouts, the single-plan case).
-template <bool IN_LDS>
+// RULE_RT: the filter rule is the kernel argument (a non-default rule was set); otherwise the default folds away.
+template <bool IN_LDS, bool RULE_RT>
 __global__ void k_forward(TplLonState* __restrict__ trajs, const TplLonState* __restrict__ inits,
                           const Node* __restrict__ tables, size_t table_cells,
                           const float* __restrict__ path, const float* __restrict__ dist_ts,
                           TplDpLonParams p, TplDpEnvParams ep,
-                          size_t stride_tables, size_t stride_path, size_t stride_dist)
+                          size_t stride_tables, size_t stride_path, size_t stride_dist, FilterRule rule_arg)
 {
+    const FilterRule rule = RULE_RT ? rule_arg : kDefaultRule;
     tables += blockIdx.x * stride_tables;
     path += blockIdx.x * stride_path;
     dist_ts += blockIdx.x * stride_dist;
@@ -468,7 +478,7 @@ __global__ void k_forward(TplLonState* __restrict__ trajs, const TplLonState* __
     for (int i = 0; i < T; ++i) {
         const float dt = (i == 0) ? p.dt_start : p.dt;
         const int nx = min(T - 1, i + 1);
-        eval_node_wave<N_FWD>(tp, tables + (size_t)nx * table_cells, pth, dst, p, ep, dt, true);
+        eval_node_wave<N_FWD>(tp, tables + (size_t)nx * table_cells, pth, dst, p, ep, dt, true, rule);
         const int slot = i % FWD_RING;
         if (lane == 0) {
             float* q = ring + slot * 7;
@@ -488,7 +498,7 @@ __global__ void k_forward(TplLonState* __restrict__ trajs, const TplLonState* __
 __global__ void k_reeval(TplLonState* __restrict__ traj,
                          const Node* __restrict__ tables, size_t table_cells,
                          const float* __restrict__ path, const float* __restrict__ dist_ts,
-                         TplDpLonParams p, TplDpEnvParams ep)
+                         TplDpLonParams p, TplDpEnvParams ep, FilterRule rule)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int T = p.t_steps;
@@ -501,7 +511,7 @@ __global__ void k_reeval(TplLonState* __restrict__ traj,
     const PathTap pt = path_tap(tp.s, p.path_step_size, p.path_steps);
     const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
     const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
-    const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, tp.t, cps_s)
+    const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, tp.t, cps_s, rule)
                                  - (double)p.length_veh * 0.6);
     const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist);
     float sg = 0.0f;
@@ -511,7 +521,7 @@ __global__ void k_reeval(TplLonState* __restrict__ traj,
     } else {
         const float j = tp.j;
         const TplLonState tn = lon_dynamics(tp, j, dt);
-        const float4 node = read_node(p, table_next, tn.s, tn.v, tn.a);
+        const float4 node = read_node(p, table_next, tn.s, tn.v, tn.a, rule);
         const PathTap pn = path_tap(tn.s, p.path_step_size, p.path_steps);
         const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5]);
         const ActionResult r = eval_action_tail(p, sc, sg, node, j, state_action_cost(p, j, dt),
@@ -713,6 +723,8 @@ struct tplhip_dp_lon {
     bool v3_ok = false;                  // the two-rows-per-lane geometry of k_backward3v fits this grid
     int v3_grid = 0;
     bool no_v3 = false, no_fwd_overlap = false;   // TPLHIP_DEBUG overrides, read by reinit
+    FilterRule rule = kDefaultRule;      // R2 / R3 of the arithmetic contract (tplhip_dp_lon_set_filter_rule)
+    bool rule_set = false;               // a non-default rule: only the general kernels implement it
     int s3_kc = 0, s3_grid = 0;          // k_backward3s (grids that leave the chip mostly empty): actions per round (0 = not used), grid
     size_t s3_lds = 0;
 
@@ -801,7 +813,7 @@ void launch_backward_b(tplhip_dp_lon* h, int idx_t, int nx)
                        h->d_acts, h->d_path,
                        h->d_pre_vmax + (size_t)idx_t * S, h->d_pre_sdist + (size_t)idx_t * S,
                        h->d_pre_prog, h->params, h->s_pad, h->rows_per_block, h->nblocks,
-                       h->tile_v, h->tile_a, (size_t)0, (size_t)0, (size_t)0);
+                       h->tile_v, h->tile_a, (size_t)0, (size_t)0, (size_t)0, h->rule);
 }
 
 template <bool TERMINAL, int KCHUNK>
@@ -818,7 +830,7 @@ void launch_backward(tplhip_dp_lon* h, int idx_t, int nx)
 // loads, both divisions proven in one of its cheap forms and non-negative weights (integer-key argmin).
 bool use_v3(const tplhip_dp_lon* h)
 {
-    return !h->no_v3 && h->use_buf && h->weights_nonneg && h->path_div3 >= 3 && h->range_div3 >= 3
+    return !h->no_v3 && !h->rule_set && h->use_buf && h->weights_nonneg && h->path_div3 >= 3 && h->range_div3 >= 3
            && backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps) <= 64 * 1024;
 }
 
@@ -920,7 +932,7 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap)
                        (size_t)0, (size_t)0, (size_t)0);
     hipLaunchKernelGGL(k_stage_prelude, dim3(T), dim3(256), 0, h->stream,
                        h->d_pre_vmax, h->d_pre_sdist, h->d_pre_prog, h->d_path, env->d_dist, p, env->params,
-                       (size_t)0, (size_t)0, (size_t)0);
+                       (size_t)0, (size_t)0, (size_t)0, h->rule);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
@@ -952,14 +964,16 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap)
         }
         const size_t ring_b = sizeof(float) * 7 * FWD_RING;
         const size_t maps_b = sizeof(float) * ((size_t)p.path_steps * 7 + (size_t)env->params.t_steps * env->params.s_steps);
-        if (ring_b + maps_b <= 60 * 1024)
-            hipLaunchKernelGGL(k_forward<true>, dim3(h->n_rollouts), dim3(64), ring_b + maps_b, fs,
-                               h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
-                               h->d_path, dist, p, env->params, (size_t)0, (size_t)0, (size_t)0);
-        else
-            hipLaunchKernelGGL(k_forward<false>, dim3(h->n_rollouts), dim3(64), ring_b, fs,
-                               h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
-                               h->d_path, dist, p, env->params, (size_t)0, (size_t)0, (size_t)0);
+        {
+            const bool in_lds = ring_b + maps_b <= 60 * 1024, rt = h->rule_set;
+            auto go = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3(h->n_rollouts), dim3(64), in_lds ? ring_b + maps_b : ring_b, fs,
+                                   h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
+                                   h->d_path, dist, p, env->params, (size_t)0, (size_t)0, (size_t)0, h->rule);
+            };
+            if (in_lds) { if (rt) go(k_forward<true, true>); else go(k_forward<true, false>); }
+            else { if (rt) go(k_forward<false, true>); else go(k_forward<false, false>); }
+        }
         if (overlap) {
             HIP_TRY(hipEventRecord(h->ev_fwd[par], h->fwd_stream), "event record failed");
             h->fwd_pending[par] = true;
@@ -1392,7 +1406,7 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     if (h->lds_bytes > 160 * 1024)
         return tplhip_fail(TPLHIP_EINVAL, "path_steps = %d does not fit in LDS next to the row buffers", p.path_steps);
 
-    hipLaunchKernelGGL(k_build_actions, dim3((nrows * N_BWD + 255) / 256), dim3(256), 0, h->stream, h->d_acts, p);
+    hipLaunchKernelGGL(k_build_actions, dim3((nrows * N_BWD + 255) / 256), dim3(256), 0, h->stream, h->d_acts, p, h->rule);
     HIP_TRY(hipGetLastError(), "action table launch failed");
 
     // Division by the two run-time constants of the sweep (path step, station range): the plain-fp32 sweeps use a
@@ -1611,7 +1625,7 @@ int tplhip_dp_lon_reeval(tplhip_dp_lon* h, const TplLonState* traj, int len, con
                        env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params,
                        (size_t)0, (size_t)0, (size_t)0);
     hipLaunchKernelGGL(k_reeval, dim3((len + 63) / 64), dim3(64), 0, h->stream,
-                       h->d_reeval, h->d_tables, h->table_cells, h->d_path, env->d_dist, p, env->params);
+                       h->d_reeval, h->d_tables, h->table_cells, h->d_path, env->d_dist, p, env->params, h->rule);
     HIP_TRY(hipGetLastError(), "reeval launch failed");
     HIP_TRY(hipMemcpyAsync(out_traj, h->d_reeval, sizeof(TplLonState) * (size_t)len,
                            hipMemcpyDeviceToHost, h->stream), "copying reevaluted trajectory to cpu failed");
@@ -1649,6 +1663,27 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
                   (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->big ? 1 : 0,
                   (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
                   h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded && h->params_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0);
+    return TPLHIP_OK;
+}
+
+// R2 / R3 of the HP-1 arithmetic contract as a run-time choice (see FilterRule in dp_lon_math.h).  Rebuilds the action
+// table; every later plan uses the general kernels unless the default (1, 0) is set again.
+int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_form)
+{
+    if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
+    if (weight_quant < 0 || weight_quant > 2 || lerp_form < 0 || lerp_form > 2)
+        return tplhip_fail(TPLHIP_EINVAL, "filter rule: weight_quant in {0 none, 1 rint, 2 floor}, lerp_form in {0, 1, 2}");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    int rc = wait_pending_forwards(h);
+    if (rc) return rc;
+    h->rule = FilterRule{weight_quant, lerp_form};
+    h->rule_set = !(weight_quant == kDefaultRule.quant && lerp_form == kDefaultRule.lerp);
+    h->tables_valid = false;
+    if (h->have_params && h->d_acts) {
+        const int nrows = h->params.v_steps * h->params.a_steps;
+        hipLaunchKernelGGL(k_build_actions, dim3((nrows * N_BWD + 255) / 256), dim3(256), 0, h->stream, h->d_acts, h->params, h->rule);
+        HIP_TRY(hipGetLastError(), "action table launch failed");
+    }
     return TPLHIP_OK;
 }
 
@@ -1781,7 +1816,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
                        dist_elems, occ_elems, path_stride);
     hipLaunchKernelGGL(k_stage_prelude, dim3(T, count), dim3(256), 0, h->stream,
                        h->d_sc_pre_vmax, h->d_sc_pre_sdist, h->d_pre_prog, paths, h->d_sc_dist, p, ep,
-                       pre_stride, path_stride, dist_elems);
+                       pre_stride, path_stride, dist_elems, h->rule);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         HIP_TRY(hipEventCreate(&e0), "event creation failed");
@@ -1798,7 +1833,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
         if (i == T - 1) {                                            // rule R4
             hipLaunchKernelGGL((k_backward<true, 1, false>), dim3(h->grid, count), dim3(h->s_pad * h->rows_per_block), 0, h->stream,
                                out, out, h->d_acts, paths, pv, ps, h->d_pre_prog, p, h->s_pad, h->rows_per_block, h->nblocks,
-                               h->tile_v, h->tile_a, tab_stride, pre_stride, path_stride);
+                               h->tile_v, h->tile_a, tab_stride, pre_stride, path_stride, h->rule);
         } else if (v3) {
             SweepArgs a;
             a.next = next; a.out = out; a.acts = h->d_acts; a.path = paths; a.pre_vmax = pv; a.pre_sdist = ps;
@@ -1813,7 +1848,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
             auto go = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(h->grid, count), dim3(h->s_pad * h->rows_per_block), h->lds1_bytes, h->stream,
                                    next, out, h->d_acts, paths, pv, ps, h->d_pre_prog, p, h->s_pad, h->rows_per_block, h->nblocks,
-                                   h->tile_v, h->tile_a, tab_stride, pre_stride, path_stride);
+                                   h->tile_v, h->tile_a, tab_stride, pre_stride, path_stride, h->rule);
             };
             if (h->use_buf) go(k_backward<false, 1, true>); else go(k_backward<false, 1, false>);
         }
@@ -1827,14 +1862,16 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
         const size_t ring_b = sizeof(float) * 7 * FWD_RING;
         const size_t maps_b = sizeof(float) * ((size_t)p.path_steps * 7 + dist_elems);
         TplLonState* trajs = h->d_sc_trajs + (size_t)first * T;
-        if (ring_b + maps_b <= 60 * 1024)
-            hipLaunchKernelGGL(k_forward<true>, dim3(count), dim3(64), ring_b + maps_b, h->stream,
-                               trajs, h->d_sc_inits + first, h->d_sc_tables, h->table_cells, paths, h->d_sc_dist, p, ep,
-                               tab_stride, path_stride, dist_elems);
-        else
-            hipLaunchKernelGGL(k_forward<false>, dim3(count), dim3(64), ring_b, h->stream,
-                               trajs, h->d_sc_inits + first, h->d_sc_tables, h->table_cells, paths, h->d_sc_dist, p, ep,
-                               tab_stride, path_stride, dist_elems);
+        {
+            const bool in_lds = ring_b + maps_b <= 60 * 1024, rt = h->rule_set;
+            auto go = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3(count), dim3(64), in_lds ? ring_b + maps_b : ring_b, h->stream,
+                                   trajs, h->d_sc_inits + first, h->d_sc_tables, h->table_cells, paths, h->d_sc_dist, p, ep,
+                                   tab_stride, path_stride, dist_elems, h->rule);
+            };
+            if (in_lds) { if (rt) go(k_forward<true, true>); else go(k_forward<true, false>); }
+            else { if (rt) go(k_forward<false, true>); else go(k_forward<false, false>); }
+        }
         hipLaunchKernelGGL(k_best_plan, dim3(1), dim3(256), 0, h->stream, trajs, count, id_base + first, T, h->d_sc_best, reset_best ? 1 : 0);
     }
     HIP_TRY(hipGetLastError(), "scenario plan launch failed");

@@ -19,14 +19,31 @@ struct Tap { int i0, i1; float w; };
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
 
+// R2 and R3 are what the reference's TEXTURE UNIT does (arr_tex_surf.cuh:142-149) -- undocumented arithmetic that
+// this repository could only freeze, not observe.  For HP-1 they are therefore parameters:
+// the general kernels of dp_lon.hip take the rule as an argument (tplhip_dp_lon_set_filter_rule), so that a dump of
+// the CUDA build that disagrees with the frozen choice is answered by a call, not by a rewrite.  Everything else in the
+// library (and the plain-fp32 sweeps of dp_sweep.hip) is built for the default rule: a default argument folds away.
+//   quant: 1 = weight rint(a * 256) / 256 (default), 2 = floor(a * 256) / 256, 0 = not quantised
+//   lerp : 0 = fma(q, w, p * (1 - w)) (default), 1 = p * (1 - w) + q * w with every operation rounded, 2 = p + w * (q - p)
+struct FilterRule { int quant, lerp; };
+constexpr FilterRule kDefaultRule{1, 0};
+
+__device__ __forceinline__ float quant_weight(float alpha, FilterRule r)
+{
+    if (r.quant == 1) return rintf(alpha * 256.0f) / 256.0f;          // power-of-two scaling: exact
+    if (r.quant == 2) return floorf(alpha * 256.0f) / 256.0f;
+    return alpha;
+}
+
 // R2.  x_plus_half is the coordinate as handed to tex3D (arr_tex_surf.cuh:142-149).
-__device__ __forceinline__ Tap make_tap(float x_plus_half, int n)
+__device__ __forceinline__ Tap make_tap(float x_plus_half, int n, FilterRule rule = kDefaultRule)
 {
     Tap t;
     float xb = x_plus_half - 0.5f;
     float fl = floorf(xb);
     float alpha = xb - fl;
-    t.w = rintf(alpha * 256.0f) / 256.0f;          // power-of-two scaling: exact
+    t.w = quant_weight(alpha, rule);
     float lo = fminf(fmaxf(fl, -1.0f), (float)n);
     int i = (int)lo;
     t.i0 = clampi(i, 0, n - 1);
@@ -34,21 +51,17 @@ __device__ __forceinline__ Tap make_tap(float x_plus_half, int n)
     return t;
 }
 
-// R3
-__device__ __forceinline__ float lerp1(float p, float q, float w)
+// R3 (this translation unit is built -ffp-contract=off: the forms below keep their roundings)
+__device__ __forceinline__ float lerp1(float p, float q, float w, FilterRule rule = kDefaultRule)
 {
+    if (rule.lerp == 1) { const float a = p * (1.0f - w), b = q * w; return a + b; }
+    if (rule.lerp == 2) { const float d = q - p; const float e = w * d; return p + e; }
     return fmaf(q, w, p * (1.0f - w));
 }
 
-__device__ __forceinline__ float4 lerp4(float4 p, float4 q, float w)
+__device__ __forceinline__ float4 lerp4(float4 p, float4 q, float w, FilterRule rule = kDefaultRule)
 {
-    float iw = 1.0f - w;
-    float4 r;
-    r.x = fmaf(q.x, w, p.x * iw);
-    r.y = fmaf(q.y, w, p.y * iw);
-    r.z = fmaf(q.z, w, p.z * iw);
-    r.w = 0.0f;
-    return r;
+    return make_float4(lerp1(p.x, q.x, w, rule), lerp1(p.y, q.y, w, rule), lerp1(p.z, q.z, w, rule), 0.0f);
 }
 
 // One cell of a value table in HBM: 12 bytes.  The reference keeps float4 texels whose fourth
@@ -163,17 +176,17 @@ __device__ __forceinline__ float env_t_idx(const TplDpEnvParams& ep, float t)
 // interpDistMapPath, env.cu:254-264; dist is [t_steps][s_steps]
 template <typename PtrT>
 __device__ __forceinline__ float interp_dist_map_path(const TplDpEnvParams& ep, PtrT dist_ts,
-                                                      float t, float s)
+                                                      float t, float s, FilterRule rule = kDefaultRule)
 {
     float t_idx = env_t_idx(ep, t);
     float sc = (s - ep.s_min) / (ep.s_max - ep.s_min) * (float)(ep.s_steps - 1);
-    Tap tt = make_tap(t_idx + 0.5f, ep.t_steps);
-    Tap ts = make_tap(sc + 0.5f, ep.s_steps);
+    Tap tt = make_tap(t_idx + 0.5f, ep.t_steps, rule);
+    Tap ts = make_tap(sc + 0.5f, ep.s_steps, rule);
     PtrT r0 = dist_ts + (size_t)tt.i0 * ep.s_steps;
     PtrT r1 = dist_ts + (size_t)tt.i1 * ep.s_steps;
-    float a = lerp1(r0[ts.i0], r1[ts.i0], tt.w);
-    float b = lerp1(r0[ts.i1], r1[ts.i1], tt.w);
-    return lerp1(a, b, ts.w);
+    float a = lerp1(r0[ts.i0], r1[ts.i0], tt.w, rule);
+    float b = lerp1(r0[ts.i1], r1[ts.i1], tt.w, rule);
+    return lerp1(a, b, ts.w, rule);
 }
 
 // coordinate of readNode, lon_planner.cu:34-37: float expression + double 0.5 -> float.
@@ -187,21 +200,21 @@ __device__ __forceinline__ float node_coord(float x, float x_min, float x_max, i
 
 // readNode with all eight taps from global memory (forward / reeval kernels).
 __device__ __forceinline__ float4 read_node(const TplDpLonParams& p, const Node* __restrict__ table,
-                                            float s, float v, float a)
+                                            float s, float v, float a, FilterRule rule = kDefaultRule)
 {
-    Tap ts = make_tap(node_coord(s, p.s_min, p.s_max, p.s_steps), p.s_steps);
-    Tap tv = make_tap(node_coord(v, p.v_min, p.v_max, p.v_steps), p.v_steps);
-    Tap ta = make_tap(node_coord(a, p.a_min, p.a_max, p.a_steps), p.a_steps);
+    Tap ts = make_tap(node_coord(s, p.s_min, p.s_max, p.s_steps), p.s_steps, rule);
+    Tap tv = make_tap(node_coord(v, p.v_min, p.v_max, p.v_steps), p.v_steps, rule);
+    Tap ta = make_tap(node_coord(a, p.a_min, p.a_max, p.a_steps), p.a_steps, rule);
     const size_t S = (size_t)p.s_steps, V = (size_t)p.v_steps;
     const Node* r00 = table + ((size_t)ta.i0 * V + tv.i0) * S;
     const Node* r10 = table + ((size_t)ta.i1 * V + tv.i0) * S;
     const Node* r01 = table + ((size_t)ta.i0 * V + tv.i1) * S;
     const Node* r11 = table + ((size_t)ta.i1 * V + tv.i1) * S;
-    float4 lo = lerp4(lerp4(ld_node(r00 + ts.i0), ld_node(r10 + ts.i0), ta.w),
-                      lerp4(ld_node(r01 + ts.i0), ld_node(r11 + ts.i0), ta.w), tv.w);
-    float4 hi = lerp4(lerp4(ld_node(r00 + ts.i1), ld_node(r10 + ts.i1), ta.w),
-                      lerp4(ld_node(r01 + ts.i1), ld_node(r11 + ts.i1), ta.w), tv.w);
-    return lerp4(lo, hi, ts.w);
+    float4 lo = lerp4(lerp4(ld_node(r00 + ts.i0), ld_node(r10 + ts.i0), ta.w, rule),
+                      lerp4(ld_node(r01 + ts.i0), ld_node(r11 + ts.i0), ta.w, rule), tv.w, rule);
+    float4 hi = lerp4(lerp4(ld_node(r00 + ts.i1), ld_node(r10 + ts.i1), ta.w, rule),
+                      lerp4(ld_node(r01 + ts.i1), ld_node(r11 + ts.i1), ta.w, rule), tv.w, rule);
+    return lerp4(lo, hi, ts.w, rule);
 }
 
 // stateCost, lon_planner.cu:40-55

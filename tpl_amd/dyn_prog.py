@@ -530,6 +530,11 @@ class DynProgLonPlanner:
         check(self._lib.tplhip_dp_lon_info(self._h, buf, 512))
         return json.loads(buf.value.decode())
 
+    def set_filter_rule(self, weight_quant=1, lerp_form=0):
+        """R2 / R3 of the HP-1 arithmetic contract (the stand-ins for the reference's texture unit) as a run-time
+        choice; ``(1, 0)`` is the default.  See ``tplhip_dp_lon_set_filter_rule`` in include/tplhip.h."""
+        check(self._lib.tplhip_dp_lon_set_filter_rule(self._h, int(weight_quant), int(lerp_form)))
+
     def timing_enable(self, enable=True):
         check(self._lib.tplhip_dp_lon_timing_enable(self._h, 1 if enable else 0))
 
