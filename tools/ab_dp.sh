@@ -14,7 +14,7 @@ build)
     for rev in "${revs[@]}"; do
         top=$(mktemp -d); d=$top/tpl_amd/csrc
         mkdir -p $d; ln -s "$PWD/include" $top/include           # the sources include ../../include/tplhip.h
-        for f in $SRCS dp_lon_math.h dp_env_internal.h dp_lon_internal.h tplhip_common.h; do
+        for f in $SRCS dp_lon_math.h dp_env_internal.h dp_lon_internal.h dp_lon_kernels.h tplhip_common.h tplhip_debug.h; do
             if [ "$rev" = WORK ]; then cp tpl_amd/csrc/$f $d/; else git show "$rev:tpl_amd/csrc/$f" > $d/$f; fi
         done
         (cd $d && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \

@@ -18,8 +18,10 @@
 //  * stages are enqueued back to back on one HIP stream -- no host sync
 //    between sweeps (the reference synchronises after every stage,
 //    lon_planner.cu:358);
-//  * the forward rollout is ONE launch: one wavefront per rollout, the 21
-//    candidate jerks across lanes, lexicographic wave-level argmin.
+//  * the forward rollout is ONE launch: eight wavefronts per rollout, the 21 candidate jerks of a step across the lanes
+//    of one and the 21 x 21 of the speculated next step across the other seven, lexicographic wave-level argmin.
+// This file is the host driver; the kernels of the general path are in dp_lon_kernels.h, the plain-fp32 sweeps in
+// dp_sweep.hip.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -38,597 +40,8 @@
 
 using namespace tplhip;
 
-namespace {
+#include "dp_lon_kernels.h"
 
-// ------------------------------------------------------------------------
-// descriptor table: one thread per (row, action)
-// ------------------------------------------------------------------------
-__global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p, FilterRule rule)
-{
-    const int nrows = p.v_steps * p.a_steps;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nrows * N_BWD) return;
-    const int row = idx / N_BWD;
-    const int k = idx - row * N_BWD;
-    const int ia = row / p.v_steps;
-    const int iv = row - ia * p.v_steps;
-
-    TplLonState tp;
-    tp.t = 0.0f; tp.s = 0.0f; tp.j = 0.0f; tp.cost = 0.0f; tp.constr = 0.0f;
-    tp.v = p.v_min + (float)iv * p._v_step_size;      // lon_planner.cu:198
-    tp.a = p.a_min + (float)ia * p._a_step_size;      // lon_planner.cu:199
-    const float dt = p.dt;
-    const float j = action_jerk(p, k, N_BWD);
-    const TplLonState tn = lon_dynamics(tp, j, dt);
-
-    ActDesc d;
-    d.a_term = ((0.5 * (double)tp.a) * (double)dt) * (double)dt;
-    d.j_term = ((((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt) * (double)dt;
-    d.vdt = tp.v * dt;
-    d.j = j;
-    d.wj_cost = state_action_cost(p, j, dt);
-    // lon_planner.cu:125-130: a' < a_min and a' > a_max exclude each other, and adding the
-    // +0 of the branch not taken leaves a float unchanged, so one addend carries both tests
-    d.a_viol = (tn.a < p.a_min) ? (p.a_min - tn.a) : ((tn.a > p.a_max) ? (tn.a - p.a_max) : 0.0f);
-    const Tap tv = make_tap(node_coord(tn.v, p.v_min, p.v_max, p.v_steps), p.v_steps, rule);
-    const Tap ta = make_tap(node_coord(tn.a, p.a_min, p.a_max, p.a_steps), p.a_steps, rule);
-    d.wa = ta.w; d.wv = tv.w;
-    d.iwa = 1.0f - ta.w; d.iwv = 1.0f - tv.w;
-    d.tn_v = tn.v;
-    d.r00 = ta.i0 * p.v_steps + tv.i0;
-    d.r10 = ta.i1 * p.v_steps + tv.i0;
-    d.r01 = ta.i0 * p.v_steps + tv.i1;
-    d.r11 = ta.i1 * p.v_steps + tv.i1;
-    d.pad = 0;
-    d.tn_v_d = (double)tn.v;
-    acts[idx] = d;
-}
-
-// ------------------------------------------------------------------------
-// per-(stage, station) prelude: interpPath(tp.s), dist map lookup, progress
-// cost.  evalNode lon_planner.cu:80-86.  grid = t_steps blocks.
-// ------------------------------------------------------------------------
-// blockIdx.y = scenario of a batch (strides in elements between consecutive scenarios; 0 = shared).
-__global__ void k_stage_prelude(float* __restrict__ pre_vmax, float* __restrict__ pre_sdist,
-                                double* __restrict__ pre_prog,
-                                const float* __restrict__ path, const float* __restrict__ dist_ts,
-                                TplDpLonParams p, TplDpEnvParams ep,
-                                size_t stride_pre, size_t stride_path, size_t stride_dist, FilterRule rule)
-{
-    const int idx_t = blockIdx.x;
-    if (idx_t < 1) return;
-    pre_vmax += blockIdx.y * stride_pre;
-    pre_sdist += blockIdx.y * stride_pre;
-    path += blockIdx.y * stride_path;
-    dist_ts += blockIdx.y * stride_dist;
-    const float t = p.dt_start + (float)(idx_t - 1) * p.dt;       // lon_planner.cu:196
-    for (int is = threadIdx.x; is < p.s_steps; is += blockDim.x) {
-        const float s = p.s_min + (float)is * p._s_step_size;     // lon_planner.cu:197
-        const PathTap pt = path_tap(s, p.path_step_size, p.path_steps);
-        const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
-        const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
-        const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, t, cps_s, rule)
-                                     - (double)p.length_veh * 0.6);
-        pre_vmax[(size_t)idx_t * p.s_steps + is] = v_max;
-        pre_sdist[(size_t)idx_t * p.s_steps + is] = s_dist;
-        if (idx_t == 1 && blockIdx.y == 0) {
-            pre_prog[is] = (double)p.w_progress * fabs(1000.0 - (double)s);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------
-// backward stage sweep (lonBackwardStep, lon_planner.cu:180-209)
-//
-// blockDim.x = s_pad * rows_per_block, s_pad = s_steps rounded up to 64, so a
-// wavefront never straddles two rows and the row index is wave-uniform.
-// KCHUNK actions are blended into LDS per barrier.
-// LDS: float4 R[KCHUNK][blockDim] | float path_vmax[path_steps]
-// ------------------------------------------------------------------------
-// This is the GENERAL sweep (any input: two-pass argmin, IEEE divisions); the plain-fp32 sweeps of dp_sweep.hip take
-// over wherever their preconditions hold.
-template <bool TERMINAL, int KCHUNK, bool USE_BUF>
-__global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out,
-                           const ActDesc* __restrict__ acts,
-                           const float* __restrict__ path,
-                           const float* __restrict__ pre_vmax,    // this stage, [s_steps]
-                           const float* __restrict__ pre_sdist,   // this stage, [s_steps]
-                           const double* __restrict__ pre_prog,   // [s_steps]
-                           TplDpLonParams p, int s_pad, int rows_per_block, int nblocks,
-                           int tile_v, int tile_a,
-                           size_t stride_tables, size_t stride_pre, size_t stride_path, FilterRule rule)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // scenario batch: blockIdx.y selects the scenario's tables, stage prelude and path (strides 0 = shared)
-    next += blockIdx.y * stride_tables;
-    out += blockIdx.y * stride_tables;
-    pre_vmax += blockIdx.y * stride_pre;
-    pre_sdist += blockIdx.y * stride_pre;
-    path += blockIdx.y * stride_path;
-
-    // Traversal order (speed only; any order gives the same table).  Blocks b and b+8 share an
-    // XCD and its 4 MiB L2 (round-robin dispatch).  Action k of row (v,a) reads next-stage rows
-    // around (v + a dt + j_k dt^2/2, a + j_k dt): the a' windows of the nine actions are ~A/7 rows
-    // apart and slide by ONE row per a-step, the v' window by a fraction of a row.  So
-    //  * each XCD owns a contiguous range of v indices,
-    //  * inside it, strips of `tile_v` v-indices are walked from a = 0 upwards, a-tiles of
-    //    `tile_a` rows at a time (v fastest inside a tile):
-    // the rows one a-tile fetched for action k+1 are the rows the next a-tile needs for action
-    // k, and a strip's working set (9 windows x (tile_a+1) a-rows x (tile_v+3) v-rows) stays
-    // inside the L2.  The first version walked v fastest across the whole v axis: 440 MB of L2
-    // misses per 256x128x64 sweep against 33.5 MB of table.
-    const int S = p.s_steps, V = p.v_steps, A = p.a_steps;
-    const int nrows = V * A;
-    const int tid = threadIdx.x;
-    const int rib = tid / s_pad;
-    const int is = tid - rib * s_pad;
-    const int xcd = blockIdx.x & 7;
-    const int v_lo = (xcd * V) >> 3, v_hi = ((xcd + 1) * V) >> 3;      // this XCD's v range
-    const int vx = v_hi - v_lo;
-    const int q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * rows_per_block + rib);   // position in the XCD's order
-    const bool row_ok = q < vx * A;
-    int ia = 0, iv = 0;
-    if (row_ok) {
-        const int full = vx / tile_v;                                   // strips of full width
-        int strip = q / (A * tile_v), w = tile_v, rem = q - strip * (A * tile_v);
-        if (strip >= full) { strip = full; w = vx - full * tile_v; rem = q - full * (A * tile_v); }
-        const int tile = rem / (tile_a * w);
-        const int r = rem - tile * (tile_a * w);
-        ia = tile * tile_a + r / w;
-        iv = v_lo + strip * tile_v + (r - (r / w) * w);
-    }
-    const int row = ia * V + iv;
-    const bool active = row_ok && is < S;
-    (void)nblocks;
-
-    const float s = p.s_min + (float)is * p._s_step_size;
-    const float v = p.v_min + (float)iv * p._v_step_size;
-    const float a = p.a_min + (float)ia * p._a_step_size;
-
-    float v_max = 0.0f, s_dist = 0.0f;
-    double prog = 0.0;
-    if (active) {
-        v_max = pre_vmax[is];
-        s_dist = pre_sdist[is];
-        prog = pre_prog[is];
-    }
-
-    // stateCost lon_planner.cu:40-55 (progress term precomputed per station)
-    float sc = 0.0f;
-    sc += p.w_a * (a * a);
-    sc = (float)((double)sc + prog);
-    {
-        const float gap = v * p.time_gap + p.gap_min - s_dist;
-        const double m = fmax(0.0, (double)gap);
-        sc = (float)((double)sc + (double)p.w_safety_dist * m);
-    }
-    float sg = 0.0f;
-    if (v > v_max) sg += v - v_max;
-
-    if (TERMINAL) {
-        // lon_planner.cu:93-97: cost only; constr and j keep their zero init
-        if (active) st_node(out + (size_t)row * S + is, sc, 0.0f, 0.0f);
-        return;
-    }
-
-    float4* R = reinterpret_cast<float4*>(smem);
-    float* pv = reinterpret_cast<float*>(smem + (size_t)KCHUNK * blockDim.x * sizeof(float4));
-    // (USE_BUF: the host checked that one stage table is addressable with 32-bit byte offsets)
-    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<Node*>(next), 0, USE_BUF ? (int)((size_t)nrows * S * sizeof(Node)) : 0, 0x00020000);
-    for (int i = tid; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];   // last sample twice
-
-    const float s_range = p.s_max - p.s_min;
-    const float s_scale = (float)(S - 1);
-    float res_c[N_BWD], res_g[N_BWD];
-
-#pragma unroll
-    for (int k0 = 0; k0 < N_BWD; k0 += KCHUNK) {
-        if (k0 > 0) __syncthreads();       // everyone is done reading R of the last chunk
-        // ---- phase 1: blend the four neighbouring next-stage rows (a, then v)
-#pragma unroll
-        for (int kk = 0; kk < KCHUNK; ++kk) {
-            const int k = k0 + kk;
-            if (active) {
-                const ActDesc* d = acts + (size_t)row * N_BWD + k;
-                // (clamped successors name the same row twice; those repeats hit L1 -- branching
-                // around them serialises the loads and more than doubles the sweep time)
-                float4 p00, p10, p01, p11;
-                if (USE_BUF) {
-                    // buffer loads: 128-bit descriptor of the whole next-stage table, row base as
-                    // SCALAR offset, station as one 32-bit lane offset shared by all 36 loads of the
-                    // cell -- no per-load 64-bit address arithmetic on the VALU
-                    const unsigned voff = (unsigned)is * 12u;
-                    const unsigned row_bytes = (unsigned)S * 12u;
-                    p00 = buf_load_node(next_rsrc, voff, (unsigned)d->r00 * row_bytes);
-                    p10 = buf_load_node(next_rsrc, voff, (unsigned)d->r10 * row_bytes);
-                    p01 = buf_load_node(next_rsrc, voff, (unsigned)d->r01 * row_bytes);
-                    p11 = buf_load_node(next_rsrc, voff, (unsigned)d->r11 * row_bytes);
-                } else {
-                    p00 = ld_node(next + (size_t)d->r00 * S + is);
-                    p10 = ld_node(next + (size_t)d->r10 * S + is);
-                    p01 = ld_node(next + (size_t)d->r01 * S + is);
-                    p11 = ld_node(next + (size_t)d->r11 * S + is);
-                }
-                const float wa = d->wa, iwa = d->iwa, wv = d->wv, iwv = d->iwv;
-                float4 b0, b1, bb;
-                if (rule.lerp == 0) {                  // (the complements 1 - w come with the descriptor)
-                    b0 = lerp4w(p00, p10, wa, iwa);
-                    b1 = lerp4w(p01, p11, wa, iwa);
-                    bb = lerp4w(b0, b1, wv, iwv);
-                } else {
-                    b0 = lerp4(p00, p10, wa, rule);
-                    b1 = lerp4(p01, p11, wa, rule);
-                    bb = lerp4(b0, b1, wv, rule);
-                }
-                R[kk * blockDim.x + tid] = bb;
-            }
-        }
-        __syncthreads();
-        // ---- phase 2: per-cell successor station, 1-D lerp, costs
-#pragma unroll
-        for (int kk = 0; kk < KCHUNK; ++kk) {
-            const int k = k0 + kk;
-            float c = 0.0f, g = 0.0f;
-            if (active) {
-                const ActDesc* d = acts + (size_t)row * N_BWD + k;
-                // lonDynamics station part, lon_planner.cu:244
-                const float sf = s + d->vdt;
-                double sd = (double)sf + d->a_term;
-                sd = sd + d->j_term;
-                const float tn_s = fmaxf(s, (float)sd);
-                // readNode coordinate along s (lon_planner.cu:35).  tn_s >= s >= s_min, so the
-                // coordinate is never negative and only the upper clamp can bite.
-                const float xs = tn_s - p.s_min;
-                const float qs = xs / s_range;
-                const float cs = qs * s_scale + 0.5f;         // == (float)((double)c + 0.5), see node_coord
-                const float xb = cs - 0.5f;
-                const float fl = floorf(xb);
-                const float ws = quant_weight(xb - fl, rule);
-                const int i_lo = (int)fminf(fl, s_scale);
-                const int i_hi = min(i_lo + 1, S - 1);
-                const float4* Rk = R + kk * blockDim.x + rib * s_pad;
-                const float4 node = lerp4(Rk[i_lo], Rk[i_hi], ws, rule);
-                // interpPath(tn.s).v_max, lon_planner.cu:114
-                const float alpha = tn_s / p.path_step_size;
-                const PathTap pt = path_tap_q(alpha, p.path_steps);
-                const float vmn = path_lerp(pt, pv[pt.i0], pv[pt.i1]);
-
-                c = sc;
-                g = sg;
-                c += node.x;
-                g += node.y;
-                c += p.w_snap * ((node.z - d->j) * (node.z - d->j));
-                c += d->wj_cost;
-                // lon_planner.cu:114-118 compares and subtracts in double; float -> double is
-                // exact and order preserving, so the test itself can stay in float
-                if (d->tn_v > vmn) g = (float)((double)g + (d->tn_v_d - (double)vmn));
-                const float s_change = tn_s - s;
-                if (s_change > s_dist) {
-                    g += s_change - s_dist;
-                }
-                g += d->a_viol;
-            }
-            res_c[k] = c;
-            res_g[k] = g;
-        }
-    }
-
-    if (!active) return;
-
-    // lexicographic argmin, lon_planner.cu:153-170
-    float constr_min = INFINITY;
-#pragma unroll
-    for (int k = 0; k < N_BWD; ++k) {
-        if (res_g[k] < constr_min) constr_min = res_g[k];
-    }
-    float cost_min = INFINITY;
-    int idx_min = 0;
-#pragma unroll
-    for (int k = 0; k < N_BWD; ++k) {
-        if (res_g[k] > constr_min) continue;
-        if (res_c[k] < cost_min) {
-            cost_min = res_c[k];
-            idx_min = k;
-        }
-    }
-    const float j_best = action_jerk(p, idx_min, N_BWD);
-    st_node(out + (size_t)row * S + is, cost_min, constr_min, j_best);
-}
-
-// ------------------------------------------------------------------------
-// Exhaustive check of the two cheap division forms of the plain-fp32 sweeps against the IEEE quotient for EVERY float
-// in [0, x_max] (all are odd-symmetric, so the sign is covered): ~1e9 candidates, about a millisecond, once per divisor.
-//  * fma(x, r_hi, x*r_lo) with r_hi + r_lo = 1/c to ~49 bits: the sum is within ~2^-47 of x/c before its one rounding,
-//    two plain fp32 instructions -- exact where no quotient of the range comes that close to a rounding boundary,
-//    which only the brute force can tell;
-//  * x * r_hi alone: exact for a power-of-two divisor.
-// A form is only used if its flag stays 0.
-// scale > 0 (the station-range divisor): the forms are compared on what the sweep derives from the quotient -- the
-// filter coordinate ((q * scale + 0.5) - 0.5, lon_planner.cu:35 + arr_tex_surf.cuh:142-149) -- not on the quotient
-// itself: for dividends below ~1e-34 their x * r_lo term underflows and the quotient's last bit can differ, but every
-// quotient below 2^-26 / scale yields the coordinate 0 either way.  scale == 0: raw quotients.
-// ------------------------------------------------------------------------
-__global__ void k_verify_div(unsigned int* __restrict__ flags, float c, float r, float r_lo, float scale, unsigned int max_bits)
-{
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    bool bad_2 = false, bad_p = false;
-    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= max_bits; b += stride) {
-        const float x = __uint_as_float((unsigned int)b);
-        const float qf = x / c;
-        const float q2 = fmaf(x, r, x * r_lo);                       // two-float reciprocal r + r_lo
-        const float qp = x * r;                                      // exact for a power-of-two divisor
-        if (scale > 0.0f) {
-            const unsigned int want = __float_as_uint((qf * scale + 0.5f) - 0.5f);
-            bad_2 |= (want != __float_as_uint((q2 * scale + 0.5f) - 0.5f));
-            bad_p |= (want != __float_as_uint((qp * scale + 0.5f) - 0.5f));
-        } else {
-            bad_2 |= (__float_as_uint(qf) != __float_as_uint(q2));
-            bad_p |= (__float_as_uint(qf) != __float_as_uint(qp));
-        }
-    }
-    if (bad_2) atomicOr(&flags[0], 1u);      // two-float reciprocal is not exact here
-    if (bad_p) atomicOr(&flags[1], 1u);      // a bare multiplication by the reciprocal is not exact here
-}
-
-// ------------------------------------------------------------------------
-// evalNode at an arbitrary trajectory point, one wavefront, action k on lane k.
-// All lanes hold the same tp.  lon_planner.cu:72-178
-// ------------------------------------------------------------------------
-__device__ __forceinline__ float wave_min(float x)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x = fminf(x, __shfl_xor(x, off, 64));
-    return x;
-}
-
-template <int N>
-__device__ __forceinline__ void eval_node_wave(TplLonState& tp, const Node* __restrict__ table_next,
-                                               const float* __restrict__ path,
-                                               const float* __restrict__ dist_ts,
-                                               const TplDpLonParams& p, const TplDpEnvParams& ep,
-                                               float dt, bool choose_action, FilterRule rule = kDefaultRule)
-{
-    const int lane = threadIdx.x & 63;
-
-    const PathTap pt = path_tap(tp.s, p.path_step_size, p.path_steps);
-    const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
-    const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
-    const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, tp.t, cps_s, rule)
-                                 - (double)p.length_veh * 0.6);
-    const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist);
-    float sg = 0.0f;
-    if (tp.v > v_max) sg += tp.v - v_max;
-
-    if (roundf(tp.t / p.dt) == (float)(p.t_steps - 1)) {    // lon_planner.cu:93-97
-        tp.cost = sc;
-        return;
-    }
-
-    const int k = choose_action ? lane : 0;
-    const float j = choose_action ? action_jerk(p, k < N ? k : N - 1, N) : tp.j;
-    const TplLonState tn = lon_dynamics(tp, j, dt);
-    const float4 node = read_node(p, table_next, tn.s, tn.v, tn.a, rule);
-    const PathTap pn = path_tap(tn.s, p.path_step_size, p.path_steps);
-    const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5]);
-    const ActionResult r = eval_action_tail(p, sc, sg, node, j, state_action_cost(p, j, dt),
-                                            tn.s, tn.v, tn.a, tp.s, s_dist, vmn);
-    if (!choose_action) {
-        tp.cost = r.cost;
-        tp.constr = r.constr;
-        return;
-    }
-
-    const bool valid = lane < N;
-    // constr_min: NaN never lowers the minimum (lon_planner.cu:155)
-    const float g_in = (valid && !(r.constr != r.constr)) ? r.constr : INFINITY;
-    const float constr_min = wave_min(g_in);
-    // candidates: not (constr > constr_min)  -- NaN constr stays a candidate (:163)
-    const bool cand = valid && !(r.constr > constr_min);
-    // first strictly smallest cost among candidates (:166); NaN / +inf cost never selected
-    const float c_in = (cand && r.cost < INFINITY) ? r.cost : INFINITY;
-    const float cost_min = wave_min(c_in);
-    const unsigned long long hit = __ballot(cand && c_in == cost_min && cost_min < INFINITY);
-    const int idx_min = hit ? (int)__builtin_ctzll(hit) : 0;
-
-    tp.j = action_jerk(p, idx_min, N);
-    tp.cost = cost_min;
-    tp.constr = constr_min;
-}
-
-// lonForwardStep chain, lon_planner.cu:211-225 + :365-386.  One wave per rollout.
-// A step is a chain of dependent look-ups (path -> distance map -> next-stage table), and loads and
-// stores of a wavefront complete in order: the trajectory therefore collects in an LDS ring that
-// leaves in one coalesced write every FWD_RING steps (a store per step would put a write
-// acknowledgement in front of the next step's first load), and where they fit (IN_LDS) the path and
-// the distance map are copied to LDS once, so only the table reads of a step go to memory.
-constexpr int FWD_RING = 16;
-
-// Scenario batches: rollout r belongs to scenario r (one rollout each); its tables, path and distance map are
-// stride_* elements further on (0 = shared by all rollouts, the single-plan case).
-// RULE_RT: the filter rule is the kernel argument (a non-default rule was set); otherwise the default folds away.
-template <bool IN_LDS, bool RULE_RT>
-__global__ void k_forward(TplLonState* __restrict__ trajs, const TplLonState* __restrict__ inits,
-                          const Node* __restrict__ tables, size_t table_cells,
-                          const float* __restrict__ path, const float* __restrict__ dist_ts,
-                          TplDpLonParams p, TplDpEnvParams ep,
-                          size_t stride_tables, size_t stride_path, size_t stride_dist, FilterRule rule_arg)
-{
-    const FilterRule rule = RULE_RT ? rule_arg : kDefaultRule;
-    tables += blockIdx.x * stride_tables;
-    path += blockIdx.x * stride_path;
-    dist_ts += blockIdx.x * stride_dist;
-    extern __shared__ __attribute__((aligned(16))) char fwd_smem[];
-    float* ring = reinterpret_cast<float*>(fwd_smem);                       // FWD_RING x LonState (7 floats)
-    float* l_path = ring + FWD_RING * 7;
-    float* l_dist = l_path + p.path_steps * 7;
-    const int lane = threadIdx.x;
-    if constexpr (IN_LDS) {
-        for (int e = lane; e < p.path_steps * 7; e += 64) l_path[e] = path[e];
-        for (int e = lane; e < ep.t_steps * ep.s_steps; e += 64) l_dist[e] = dist_ts[e];
-        __syncthreads();
-    }
-    const float* pth = IN_LDS ? l_path : path;
-    const float* dst = IN_LDS ? l_dist : dist_ts;
-    const int r = blockIdx.x;
-    const int T = p.t_steps;
-    static_assert(sizeof(TplLonState) == 7 * sizeof(float), "LonState is seven floats");
-    float* out = reinterpret_cast<float*>(trajs + (size_t)r * T);
-    TplLonState tp = inits[r];
-    for (int i = 0; i < T; ++i) {
-        const float dt = (i == 0) ? p.dt_start : p.dt;
-        const int nx = min(T - 1, i + 1);
-        eval_node_wave<N_FWD>(tp, tables + (size_t)nx * table_cells, pth, dst, p, ep, dt, true, rule);
-        const int slot = i % FWD_RING;
-        if (lane == 0) {
-            float* q = ring + slot * 7;
-            q[0] = tp.t; q[1] = tp.s; q[2] = tp.v; q[3] = tp.a; q[4] = tp.j; q[5] = tp.cost; q[6] = tp.constr;
-        }
-        if (slot == FWD_RING - 1 || i == T - 1) {
-            __syncthreads();
-            const int n = (slot + 1) * 7, base = (i - slot) * 7;
-            for (int e = lane; e < n; e += 64) out[base + e] = ring[e];
-            __syncthreads();
-        }
-        if (i < T - 1) tp = lon_dynamics(tp, tp.j, dt);
-    }
-}
-
-// lonReevalNode, lon_planner.cu:227-236 + :439-455: nodes are independent, one thread each
-__global__ void k_reeval(TplLonState* __restrict__ traj,
-                         const Node* __restrict__ tables, size_t table_cells,
-                         const float* __restrict__ path, const float* __restrict__ dist_ts,
-                         TplDpLonParams p, TplDpEnvParams ep, FilterRule rule)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int T = p.t_steps;
-    if (i >= T) return;
-    TplLonState tp = traj[i];
-    const float dt = (i == 0) ? p.dt_start : p.dt;
-    const int nx = min(T - 1, i + 1);
-    const Node* table_next = tables + (size_t)nx * table_cells;
-
-    const PathTap pt = path_tap(tp.s, p.path_step_size, p.path_steps);
-    const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
-    const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
-    const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, tp.t, cps_s, rule)
-                                 - (double)p.length_veh * 0.6);
-    const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist);
-    float sg = 0.0f;
-    if (tp.v > v_max) sg += tp.v - v_max;
-    if (roundf(tp.t / p.dt) == (float)(p.t_steps - 1)) {
-        tp.cost = sc;
-    } else {
-        const float j = tp.j;
-        const TplLonState tn = lon_dynamics(tp, j, dt);
-        const float4 node = read_node(p, table_next, tn.s, tn.v, tn.a, rule);
-        const PathTap pn = path_tap(tn.s, p.path_step_size, p.path_steps);
-        const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5]);
-        const ActionResult r = eval_action_tail(p, sc, sg, node, j, state_action_cost(p, j, dt),
-                                                tn.s, tn.v, tn.a, tp.s, s_dist, vmn);
-        tp.cost = r.cost;
-        tp.constr = r.constr;
-    }
-    traj[i] = tp;
-}
-
-// ------------------------------------------------------------------------
-// updateDistMapPath, env.cu:131-158.  One block per time slice: the occupancy
-// lookups run in parallel into LDS, then one lane does the (order-dependent,
-// float-accumulating) backward scan, then the slice is written coalesced.
-// occ: [l][s][t] (t fastest).  dist: [t][s].
-// ------------------------------------------------------------------------
-__global__ void k_dist_map_path(float* __restrict__ dist_ts, const float* __restrict__ occ_lst,
-                                const float* __restrict__ path, int path_steps, float path_step_size,
-                                TplDpEnvParams ep, size_t stride_dist, size_t stride_occ, size_t stride_path)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    dist_ts += blockIdx.y * stride_dist;          // scenario batch, see k_stage_prelude
-    occ_lst += blockIdx.y * stride_occ;
-    path += blockIdx.y * stride_path;
-    float* d_sh = reinterpret_cast<float*>(smem);      // [s_steps]: occupancy flag, then distance
-    const int idx_t = blockIdx.x;
-    const int S = ep.s_steps;
-    for (int idx_s = threadIdx.x; idx_s < S; idx_s += blockDim.x) {
-        const float s = ep.s_min + (float)idx_s * ep._s_step_size;
-        const PathTap pt = path_tap(s, path_step_size, path_steps);
-        const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
-        const float cps_l = path_lerp(pt, path[pt.i0 * 7 + 3], path[pt.i1 * 7 + 3]);
-        float fs = (cps_s - ep.s_min) / ep._s_step_size;
-        float fl = (cps_l - ep.l_min) / ep._l_step_size;
-        fs = fminf(fmaxf(fs, -1.0f), (float)ep.s_steps);
-        fl = fminf(fmaxf(fl, -1.0f), (float)ep.l_steps);
-        const int js = clampi((int)fs, 0, ep.s_steps - 1);
-        const int jl = clampi((int)fl, 0, ep.l_steps - 1);
-        d_sh[idx_s] = occ_lst[((size_t)jl * ep.s_steps + js) * ep.t_steps + idx_t];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float d = 10000.0f;
-        for (int idx_s = S - 1; idx_s >= 0; --idx_s) {
-            if (d_sh[idx_s] > 0.0f) d = 0.0f; else d += ep._s_step_size;
-            d_sh[idx_s] = d;
-        }
-    }
-    __syncthreads();
-    for (int idx_s = threadIdx.x; idx_s < S; idx_s += blockDim.x) {
-        dist_ts[(size_t)idx_t * S + idx_s] = d_sh[idx_s];
-    }
-}
-
-
-// ------------------------------------------------------------------------
-// Best plan of a batch of scenario rollouts (new): the lexicographically smallest
-// (constraint violation, cost, scenario id) -- the planner's own order (lon_planner.cu:153-170) applied to
-// whole plans, with the validity measure of the Python caller (max constr over states[1:-1],
-// planning/dyn_prog/poly_lat_dp_lon_planner.py:99-101) and the value of the plan (cost of the first node).
-// One workgroup; the winner's trajectory is written behind a 16-byte header {constr, cost, id, t_steps}
-// unless the record already holds a better one (reset == 0: running best over several chunks).
-// ------------------------------------------------------------------------
-__device__ __forceinline__ bool plan_better(float g, float c, int id, float bg, float bc, int bid)
-{
-    return g < bg || (g == bg && (c < bc || (c == bc && id < bid)));
-}
-
-__global__ void __launch_bounds__(256) k_best_plan(const TplLonState* __restrict__ trajs, int count, int id_first, int T,
-                                                   unsigned char* __restrict__ record, int reset)
-{
-    __shared__ float s_g[256], s_c[256];
-    __shared__ int s_id[256], s_take;
-    const int tid = threadIdx.x;
-    float bg = INFINITY, bc = INFINITY;
-    int bid = 0x7fffffff;
-    for (int j = tid; j < count; j += 256) {
-        const TplLonState* tr = trajs + (size_t)j * T;
-        float g;
-        if (T > 2) { g = tr[1].constr; for (int i = 2; i < T - 1; ++i) g = fmaxf(g, tr[i].constr); }
-        else { g = tr[0].constr; for (int i = 1; i < T; ++i) g = fmaxf(g, tr[i].constr); }
-        const float c = tr[0].cost;
-        if (plan_better(g, c, id_first + j, bg, bc, bid)) { bg = g; bc = c; bid = id_first + j; }
-    }
-    s_g[tid] = bg; s_c[tid] = bc; s_id[tid] = bid;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (tid < w && plan_better(s_g[tid + w], s_c[tid + w], s_id[tid + w], s_g[tid], s_c[tid], s_id[tid])) {
-            s_g[tid] = s_g[tid + w]; s_c[tid] = s_c[tid + w]; s_id[tid] = s_id[tid + w];
-        }
-        __syncthreads();
-    }
-    float* rf = reinterpret_cast<float*>(record);
-    int* ri = reinterpret_cast<int*>(record);
-    if (tid == 0) {
-        const bool have = s_id[0] != 0x7fffffff;
-        s_take = have && (reset || plan_better(s_g[0], s_c[0], s_id[0], rf[0], rf[1], ri[2]));
-        if (reset && !have) { rf[0] = INFINITY; rf[1] = INFINITY; ri[2] = 0x7fffffff; ri[3] = T; }
-    }
-    __syncthreads();
-    if (!s_take) return;
-    const float* src = reinterpret_cast<const float*>(trajs + (size_t)(s_id[0] - id_first) * T);
-    for (int e = tid; e < T * 7; e += 256) rf[4 + e] = src[e];
-    if (tid == 0) { rf[0] = s_g[0]; rf[1] = s_c[0]; ri[2] = s_id[0]; ri[3] = T; }
-}
-
-} // namespace
 
 // ==========================================================================
 // host side
@@ -967,7 +380,7 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap)
         {
             const bool in_lds = ring_b + maps_b <= 60 * 1024, rt = h->rule_set;
             auto go = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, dim3(h->n_rollouts), dim3(64), in_lds ? ring_b + maps_b : ring_b, fs,
+                hipLaunchKernelGGL(kernel, dim3(h->n_rollouts), dim3(512), in_lds ? ring_b + maps_b : ring_b, fs,
                                    h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
                                    h->d_path, dist, p, env->params, (size_t)0, (size_t)0, (size_t)0, h->rule);
             };
@@ -1865,7 +1278,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
         {
             const bool in_lds = ring_b + maps_b <= 60 * 1024, rt = h->rule_set;
             auto go = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, dim3(count), dim3(64), in_lds ? ring_b + maps_b : ring_b, h->stream,
+                hipLaunchKernelGGL(kernel, dim3(count), dim3(512), in_lds ? ring_b + maps_b : ring_b, h->stream,
                                    trajs, h->d_sc_inits + first, h->d_sc_tables, h->table_cells, paths, h->d_sc_dist, p, ep,
                                    tab_stride, path_stride, dist_elems, h->rule);
             };
