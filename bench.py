@@ -369,7 +369,7 @@ def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_c
     cells = S * V * A
     per_launch_s = (sweep_ms / 1e3) / max(1, launches)
     achieved = MC_CHUNK * cells * BYTES_PER_CELL / per_launch_s / 1e9
-    return {
+    res = {
         "metric": "dp_stage_sweeps_per_s", "unit": "stage-sweeps/s (one sweep = one stage of one scenario)",
         "value": steps * n_total * (T - 1) / el, "n_gpus": world, "scaling": "weak",
         "rollouts": n_total, "rollouts_per_gpu": MC_PER_GPU, "rollouts_per_s": steps * n_total / el,
@@ -386,20 +386,28 @@ def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_c
         "best_plan": {"constr": bk[0], "cost": bk[1], "id": bk[2], "identical_on_all_ranks": bool(identical)},
         "record_bytes": int(nbytes),
     }
+    traffic_block(res["roofline"], f"{S}x{V}x{A}@{MC_CHUNK}")
+    return res
 
 
-def traffic_block(out, p, cells, per_launch_s):
-    """L2<->fabric bytes per sweep launch from the committed PMC pass of this kernel (rocprofv3 cannot run inside the
-    timed process; profiles/README.md has the command)."""
-    for f in ("r02_dp_traffic.json", "r01_dp_traffic.json"):
+def traffic_block(roofline, key):
+    """L2<->fabric bytes per sweep launch and the issue-model fractions from the committed PMC passes of this kernel
+    (rocprofv3 cannot run inside the timed process; profiles/README.md has the commands).  `key`: "SxVxA" or "SxVxA@N"."""
+    for f in ("r03_dp_traffic.json", "r02_dp_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", f)) as fd:
-                tr = json.load(fd).get(f"{p.s_steps}x{p.v_steps}x{p.a_steps}")
+                tr = json.load(fd).get(key)
         except OSError:
             continue
-        if tr and tr.get("kernel", out["roofline"]["kernel"]) == out["roofline"]["kernel"]:
-            out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = f"profiles/{f} (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+        if tr and tr.get("kernel", roofline["kernel"]) == roofline["kernel"]:
+            roofline["traffic"] = tr["traffic_bytes_per_launch"]
+            roofline["traffic_source"] = f"profiles/{f} (2*FETCH_SIZE + WRITE_SIZE, factor calibrated for 12-byte lanes, separate --pmc passes)"
+            for k in ("valu_issue", "texture_addr", "l2_hit_rate"):
+                if k in tr:
+                    roofline[k] = tr[k]
+            if "valu_issue" in tr:
+                roofline["binding"] = ("not HBM: VALU issue and the texture-address path, each near 0.7 of the kernel's cycles by the "
+                                       "PMC instruction counts x measured per-instruction costs (model in " + f"profiles/{f})")
             return
 
 
@@ -536,7 +544,7 @@ def worker(args):
         if dist is not None:
             out["best_plan"] = {"constr": float(best[0]), "cost": float(best[1]), "rank": int(best[2])}
             out["collective"] = dict(collective, per_rank_value=rank_values)
-        traffic_block(out, p, cells, per_launch_s)
+        traffic_block(out["roofline"], f"{p.s_steps}x{p.v_steps}x{p.a_steps}")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = dp_cpu_baseline(p, ep, path, occ)
     del dp, env

@@ -1,9 +1,11 @@
 #!/bin/bash
 # PMC passes for the DP sweep kernel (separate --pmc runs, no tracing domains).
-# usage (on the GPU box, from the repo root): bash tools/pmc_dp.sh <outdir> [grid]
+# usage (on the GPU box, from the repo root): bash tools/pmc_dp.sh <outdir> [grid | mc]
+#   grid: target / config2 / config4 / default (tools/dp_only.py);  mc: the Monte-Carlo scenario workload (tools/mc_only.py)
 set -u
 OUT=${1:-gpurun_out/pmc}
 GRID=${2:-target}
+if [ "$GRID" = mc ]; then DRIVER="tools/mc_only.py"; DARGS="128"; else DRIVER="tools/dp_only.py"; DARGS="$GRID 1"; fi
 REPO=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -17,7 +19,7 @@ for C in \
   "TCC_REQ_sum TCC_READ_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
   ; do
   i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d "$REPO/$OUT/pass$i" -- python3 "$REPO/tools/dp_only.py" "$GRID" 1 > "$REPO/$OUT/pass$i.log" 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $C --output-format csv -d "$REPO/$OUT/pass$i" -- python3 "$REPO/$DRIVER" $DARGS > "$REPO/$OUT/pass$i.log" 2>&1 || echo "pass $i failed"
 done
 cd "$REPO"
 python3 tools/pmc_summary.py "$OUT" k_backward

@@ -2,7 +2,7 @@
 # End-of-round evidence run (on the GPU box, from the repo root):
 #   bash tools/profile_round.sh <tag>        -> gpurun_out/<tag>/...
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -16,6 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mc" -- pytho
 cd "$REPO"
 bash tools/pmc_dp.sh "gpurun_out/$TAG/pmc_target" target > "$OUT/pmc_target.txt" 2>&1
 bash tools/pmc_dp.sh "gpurun_out/$TAG/pmc_config4" config4 > "$OUT/pmc_config4.txt" 2>&1
+bash tools/pmc_dp.sh "gpurun_out/$TAG/pmc_mc" mc > "$OUT/pmc_mc.txt" 2>&1
 bash tools/pmc_ilqr.sh "gpurun_out/$TAG/pmc_ilqr" mpc > "$OUT/pmc_ilqr.txt" 2>&1
 find "$OUT" -name "*_agent_info.csv" -delete
 find "$OUT" -name "*counter_collection.csv" -size +2M -delete

@@ -29,8 +29,16 @@ int tplhip_default_device(int n_devices)
 
 int tplhip_copy_to_host(void* dst, const void* src, size_t bytes, hipStream_t stream, const char* context)
 {
-    static thread_local void* bounce = nullptr;             // lives as long as the thread (page-locked memory is per process)
-    static thread_local size_t cap = 0;
+    // one page-locked buffer per calling thread, given back when the thread ends (a short-lived worker thread that calls
+    // a getter must not leave up to 64 MB of pinned memory behind for the life of the process)
+    struct Bounce {
+        void* p = nullptr;
+        size_t cap = 0;
+        ~Bounce() { if (p) (void)hipHostFree(p); }
+    };
+    static thread_local Bounce tl;
+    void*& bounce = tl.p;
+    size_t& cap = tl.cap;
     if (bytes == 0) return TPLHIP_OK;
     if (bytes > ((size_t)64 << 20)) {                       // whole value tables of the largest grids: no 64 MB+ of page-locked memory for a debug read
         HIP_TRY(hipStreamSynchronize(stream), context);

@@ -240,13 +240,31 @@ class _ResultPool:
     def __init__(self, depth=8):                 # three kinds of result per cycle, each alternating between two buffers
         self._depth = depth
         self._arrays = []
+        # What sys.getrefcount reports for an array that ONLY the pool holds, seen from inside take(): an implementation
+        # detail of the interpreter (list + local + argument = 3 on CPython 3.10; newer interpreters count fewer), so it
+        # is measured on a throw-away array through the same code path instead of assumed.  No match -> no recycling.
+        self._idle = None
+        probe = np.empty(1, dtype=np.uint8)
+        self._arrays.append(probe)
+        del probe
+        self._idle = self._refs(0)
+        held = self._arrays[0]                   # one outside holder must read exactly one more, or the count is useless
+        if self._refs(0) != self._idle + 1:
+            self._idle = None
+        del held
+        self._arrays.clear()
+
+    def _refs(self, k):
+        a = self._arrays[k]
+        return sys.getrefcount(a)
 
     def take(self, shape, dtype):
-        for k in range(len(self._arrays)):
-            a = self._arrays[k]
-            if a.shape == shape and a.dtype == dtype and sys.getrefcount(a) == 3:     # the list, `a`, the argument
-                return a
-            del a
+        if self._idle is not None:
+            for k in range(len(self._arrays)):
+                a = self._arrays[k]
+                if a.shape == shape and a.dtype == dtype and sys.getrefcount(a) == self._idle:
+                    return a
+                del a
         a = np.empty(shape, dtype=dtype)
         self._arrays.append(a)
         del self._arrays[:-self._depth]
