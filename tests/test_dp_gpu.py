@@ -497,3 +497,22 @@ def test_filter_rule_variants_match_their_oracle_builds(name, quant, lerp):
         assert any(not np.array_equal(tables0[t].view(np.uint32), tables[t].view(np.uint32)) for t in range(1, T)), "the variant changes nothing here"
     with pytest.raises(ValueError):
         dp.set_filter_rule(3, 0)
+
+
+@pytest.mark.parametrize("dt_start", [None, 0.3, 0.6])
+def test_forward_rollout_forms_agree(dt_start, monkeypatch):
+    """The rollout runs with one step of speculation (eight wavefronts) where the table set fits the Infinity Cache and
+    one step per round (one wavefront) beyond; TPLHIP_DEBUG=no_fwd_spec forces the second form on a small grid.  Both
+    against the oracle, raw bits -- including dt_start values for which the terminal test of lon_planner.cu:93 fires
+    in the middle of a speculated pair or not at all, odd and even stage counts."""
+    for T in (5, 6):
+        p = sc.lon_params(96, 12, 9, T, dt_start=dt_start)
+        ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31, dt_start=dt_start)
+        path = sc.straight_path(p.path_steps, p.path_step_size)
+        occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
+        inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(5, seed=21)
+        for form in ("", "no_fwd_spec"):
+            monkeypatch.setenv("TPLHIP_DEBUG", form)
+            dp, env, trajs, tables, otrajs, dist = _run_both(p, ep, path, occ, inits)
+            for r, tr in enumerate(trajs):
+                assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (T, form, r)

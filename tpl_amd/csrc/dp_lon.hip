@@ -135,7 +135,7 @@ struct tplhip_dp_lon {
     int sc_last_first = 0, sc_last_count = 0;
     bool v3_ok = false;                  // the two-rows-per-lane geometry of k_backward3v fits this grid
     int v3_grid = 0;
-    bool no_v3 = false, no_fwd_overlap = false;   // TPLHIP_DEBUG overrides, read by reinit
+    bool no_v3 = false, no_fwd_overlap = false, no_fwd_spec = false;   // TPLHIP_DEBUG overrides, read by reinit
     FilterRule rule = kDefaultRule;      // R2 / R3 of the arithmetic contract (tplhip_dp_lon_set_filter_rule)
     bool rule_set = false;               // a non-default rule: only the general kernels implement it
     int s3_kc = 0, s3_grid = 0;          // k_backward3s (grids that leave the chip mostly empty): actions per round (0 = not used), grid
@@ -237,6 +237,13 @@ void launch_backward(tplhip_dp_lon* h, int idx_t, int nx)
         launch_backward_b<TERMINAL, KCHUNK, true>(h, idx_t, nx);
     else
         launch_backward_b<TERMINAL, KCHUNK, false>(h, idx_t, nx);
+}
+
+// Workgroup size of k_forward: 512 = one step of speculation, for table sets the Infinity Cache holds (the speculated
+// reads are 21 x as many); 64 = one step per round beyond that (see the kernel)
+int fwd_threads(const tplhip_dp_lon* h)
+{
+    return (!h->no_fwd_spec && sizeof(Node) * h->table_cells * (size_t)h->params.t_steps <= ((size_t)256 << 20)) ? 512 : 64;
 }
 
 // k_backward3v (dp_sweep.hip): the two-rows-per-lane geometry with the plain-fp32 instruction stream.  Needs buffer
@@ -380,7 +387,7 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap)
         {
             const bool in_lds = ring_b + maps_b <= 60 * 1024, rt = h->rule_set;
             auto go = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, dim3(h->n_rollouts), dim3(512), in_lds ? ring_b + maps_b : ring_b, fs,
+                hipLaunchKernelGGL(kernel, dim3(h->n_rollouts), dim3(fwd_threads(h)), in_lds ? ring_b + maps_b : ring_b, fs,
                                    h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
                                    h->d_path, dist, p, env->params, (size_t)0, (size_t)0, (size_t)0, h->rule);
             };
@@ -774,6 +781,7 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     h->use_buf = h->table_cells * sizeof(Node) < 0xffffffffull && !debug_opt("no_bufload");
     h->no_v3 = debug_opt("no_v3");
     h->no_fwd_overlap = debug_opt("no_fwd_overlap");
+    h->no_fwd_spec = debug_opt("no_fwd_spec");
     // "bounded": every float parameter finite and < 1e6 in magnitude, at most 1e5 stages.  Then no
     // cost or constraint sum of the sweep can overflow (largest single term ~ w * (1e6)^2 = 1e18, at
     // most 1e5 of them), no infinity and hence no NaN can appear, and a running lexicographic argmin
@@ -1278,7 +1286,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
         {
             const bool in_lds = ring_b + maps_b <= 60 * 1024, rt = h->rule_set;
             auto go = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, dim3(count), dim3(512), in_lds ? ring_b + maps_b : ring_b, h->stream,
+                hipLaunchKernelGGL(kernel, dim3(count), dim3(fwd_threads(h)), in_lds ? ring_b + maps_b : ring_b, h->stream,
                                    trajs, h->d_sc_inits + first, h->d_sc_tables, h->table_cells, paths, h->d_sc_dist, p, ep,
                                    tab_stride, path_stride, dist_elems, h->rule);
             };

@@ -467,6 +467,10 @@ constexpr int FWD_RING = 16;
 // A terminal node at step i chooses nothing (its successor follows the incoming jerk, which is not among the
 // speculated states in general): the wavefront of step i then evaluates step i+1 by itself.
 // blockDim = 512: wavefronts 0..6 speculate, wavefront 7 evaluates the known state.
+// blockDim = 64: no speculation, one step per round (the host's choice for table sets beyond the Infinity Cache: there
+// a round waits for the slowest of 441 x 8 scattered HBM reads instead of 21 x 8, and two steps in 6.9 us lose
+// against 2 x 2.9 us -- 173.7 against 145 us per 50-step rollout on 256x128x64, where the rollout is hidden behind the
+// next plan's sweeps anyway).
 // ------------------------------------------------------------------------
 template <bool IN_LDS, bool RULE_RT>
 __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs, const TplLonState* __restrict__ inits,
@@ -498,21 +502,26 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
     const int T = p.t_steps;
     float* out = reinterpret_cast<float*>(trajs + (size_t)r * T);
     TplLonState tp = inits[r];
-    for (int i = 0; i < T; i += 2) {
-        const int par = (i >> 1) & 1;
+    const bool spec = blockDim.x > 64;
+    const int w_eval = spec ? 7 : 0, step = spec ? 2 : 1;
+    for (int i = 0, round = 0; i < T; i += step, ++round) {
+        const int par = round & 1;
         const float dt0 = (i == 0) ? p.dt_start : p.dt;
         const Node* table1 = tables + (size_t)min(T - 1, i + 1) * table_cells;
         const Node* table2 = tables + (size_t)min(T - 1, i + 2) * table_cells;
-        const bool have2 = i + 1 < T;
+        const bool have2 = spec && i + 1 < T;
         // speculated state of this lane's group and its evaluation (wavefronts 0..6)
         const int grp = min(lane / N_FWD, 2), m = lane - grp * N_FWD;
         const bool lane_ok = lane < 3 * N_FWD;
         TplLonState b = tp;
         LaneEval e2 = LaneEval{0.0f, 0.0f, 0.0f, false};
-        if (wave == 7) {
+        if (wave == w_eval) {
             TplLonState a = tp;
             const int k = eval_node_wave<N_FWD>(a, table1, pth, dst, p, ep, dt0, true, rule);
-            if (lane == 0) { x_cur[par] = a; x_k[par] = k; }
+            if (lane == 0) {
+                x_cur[par] = a; x_k[par] = k;
+                if (!spec) x_nxt[par] = lon_dynamics(a, a.j, dt0);
+            }
         } else if (have2) {
             b = lon_dynamics(tp, action_jerk(p, 3 * wave + grp, N_FWD), dt0);            // state i+1 if action 3 wave + grp wins
             e2 = eval_lane(b, action_jerk(p, min(m, N_FWD - 1), N_FWD), table2, pth, dst, p, ep, p.dt, rule);
@@ -536,7 +545,7 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
                         x_nxt[par] = lon_dynamics(b, b.j, p.dt);
                     }
                 }
-            } else if (wave == 7) {
+            } else if (wave == w_eval) {
                 // step i was terminal: no action chosen, the successor follows the incoming jerk -- not speculated
                 TplLonState a = x_cur[par];
                 TplLonState c = lon_dynamics(a, a.j, dt0);
@@ -558,7 +567,7 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
             for (int e = tid; e < n; e += blockDim.x) out[base + e] = ring[e];
             __syncthreads();
         }
-        if (have2) tp = x_nxt[par];
+        if (have2 || !spec) tp = x_nxt[par];
     }
 }
 

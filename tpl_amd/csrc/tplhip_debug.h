@@ -5,6 +5,7 @@
 //     no_fastdiv     IEEE division in the sweeps (skips the brute-force proof of the reciprocal forms)
 //     no_bufload     plain global loads instead of buffer loads in k_backward
 //     no_fwd_overlap plan_resident: the forward rollout stays on the main stream
+//     no_fwd_spec    forward rollout without speculation on every grid (the form large table sets take anyway)
 //     kchunk=N       actions per barrier round of k_backward (1 or 3)
 //     tile_v=N, tile_a=N   traversal tile of the sweeps
 //     ilqr_no_lds, ilqr_lds_kb=N   iLQR: where the solver mirrors live (tests force both homes)
