@@ -773,6 +773,10 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     if (threads * 16 * 3 + path_lds > lds_max) h->kchunk = 1;
     h->big = h->kchunk == 1;                                // decided on the grid, before any override
     {
+        int b = 0;                                          // soaks: the large-grid kernels on a small grid (big=1) or the reverse
+        if (debug_opt("big", &b)) h->big = b != 0;
+    }
+    {
         int k = 0;                                          // tuning override: 3 or 1
         if (debug_opt("kchunk", &k) && (k == 3 || k == 1) && threads * 16 * (size_t)k + path_lds <= lds_max) h->kchunk = k;
     }

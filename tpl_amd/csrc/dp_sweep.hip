@@ -36,7 +36,8 @@
 
 // timing experiments only (tools/ab_dp.sh build WORK -- -DV3_ABLATE=n): 1 = phase 2 removed, 2 = row loads removed,
 // 3 = both s_barriers of an action removed (the LDS exchange stays, results are wrong), 4 = barriers AND the LDS row
-// exchange removed (a lane blends along s between its own two v-blended values)
+// exchange removed (a lane blends along s between its own two v-blended values), 5 / 6 = five / four row loads per action
+// instead of six (the rows left out are copies of loaded ones): the ceiling of any scheme that shares more rows
 #ifndef V3_ABLATE
 #define V3_ABLATE 0
 #endif
@@ -214,6 +215,11 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         lo[0] = load_row(x.r00); lo[1] = load_row(x.r10);
 #pragma unroll
         for (int i = 0; i < NV; ++i) { up[i][0] = load_row(x.r01[i]); up[i][1] = load_row(x.r11[i]); }
+#if V3_ABLATE == 5      // timing experiment: five row loads per action (2.5 per cell), the sixth row is a copy -- what ANY scheme with 2.5 loads per cell could gain at most
+        up[NV - 1][1] = up[NV - 1][0];
+#elif V3_ABLATE == 6    // ... four row loads per action (2 per cell: the asymptote of sharing a-blended rows along v)
+        up[NV - 1][0] = up[0][0]; up[NV - 1][1] = up[0][1];
+#endif
     };
 #if V3_ABLATE == 2       // timing experiment: no row loads at all (registers fed from lane ids), results are wrong
     lo[0] = lo[1] = Node3{(float)is, 1.0f, 1.0f};

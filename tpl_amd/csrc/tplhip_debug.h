@@ -7,6 +7,7 @@
 //     no_fwd_overlap plan_resident: the forward rollout stays on the main stream
 //     no_fwd_spec    forward rollout without speculation on every grid (the form large table sets take anyway)
 //     kchunk=N       actions per barrier round of k_backward (1 or 3)
+//     big=0|1        treat the grid as small / as several residency rounds deep (k_backward3s / k_backward3v), whatever its size
 //     tile_v=N, tile_a=N   traversal tile of the sweeps
 //     ilqr_no_lds, ilqr_lds_kb=N   iLQR: where the solver mirrors live (tests force both homes)
 // Nothing else in the library reads the environment (tpl_amd/_capi.py reads TPLHIP_LIB to locate the .so).
