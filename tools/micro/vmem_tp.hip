@@ -12,26 +12,29 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v3f __attribute__((ext_vector_type(3)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int BYTES, bool L2WALK>
+// STRIDE: bytes between consecutive lanes (0 = BYTES, a packed array; 16 with BYTES = 12: three of every four dwords of
+// a 16-byte cell array -- does a quad of lanes that never straddles a 64-byte sector cost the L1 fewer accesses?)
+template <int BYTES, bool L2WALK, int STRIDE = 0>
 __global__ void __launch_bounds__(256) k_load(const float* __restrict__ src, float* __restrict__ out, unsigned span_bytes)
 {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)span_bytes, 0x00020000);
-    const unsigned lane_off = (threadIdx.x & 63) * BYTES;
+    constexpr int LS = STRIDE ? STRIDE : BYTES;
+    const unsigned lane_off = (threadIdx.x & 63) * LS;
     // L1: every wave re-reads its own 8 x (64 x BYTES) window.  L2: the window start walks through span_bytes.
-    unsigned base = L2WALK ? ((blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 * 64 * BYTES) % (span_bytes - 16 * 64 * BYTES) : 0u;   // L1: one 8-load window for all
+    unsigned base = L2WALK ? ((blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 * 64 * LS) % (span_bytes - 16 * 64 * LS) : 0u;   // L1: one 8-load window for all
     float acc = 0.0f;
     unsigned lo = lane_off;
     for (int it = 0; it < ITERS; ++it) {
         asm volatile("" : "+v"(lo));      // keeps the (L1-resident) loads inside the loop
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const unsigned so = base + j * 64 * BYTES;
+            const unsigned so = base + j * 64 * LS;
             if constexpr (BYTES == 4)  { acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lo, so, 0)); }
             if constexpr (BYTES == 8)  { v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, lo, so, 0)); acc += v.x; }
             if constexpr (BYTES == 12) { v3f v = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(r, lo, so, 0)); acc += v.x; }
             if constexpr (BYTES == 16) { v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, lo, so, 0)); acc += v.x; }
         }
-        if (L2WALK) base = (base + 1031u * 64 * BYTES) % (span_bytes - 16 * 64 * BYTES);
+        if (L2WALK) base = (base + 1031u * 64 * LS) % (span_bytes - 16 * 64 * LS);
     }
     if (acc == 123.456f) out[threadIdx.x] = acc;
 }
@@ -60,5 +63,8 @@ int main()
     run("L2 dword", k_load<4, true>, l2, 4);   run("L2 dwordx2", k_load<8, true>, l2, 8);
     run("L2 dwordx3", k_load<12, true>, l2, 12); run("L2 dwordx4", k_load<16, true>, l2, 16);
     run("MALL dwordx3", k_load<12, true>, span, 12); run("MALL dwordx4", k_load<16, true>, span, 16);
+    run("L1 dwordx3 stride16", k_load<12, false, 16>, span, 12); run("L2 dwordx3 stride16", k_load<12, true, 16>, l2, 12);
+    run("L1 dwordx2 stride16", k_load<8, false, 16>, span, 8); run("L1 dword stride16", k_load<4, false, 16>, span, 4);
+    run("L1 dwordx3 stride24", k_load<12, false, 24>, span, 12); run("L1 dwordx3 stride32", k_load<12, false, 32>, span, 12);
     return 0;
 }
