@@ -51,6 +51,20 @@
 #ifndef V3_SETPRIO
 #define V3_SETPRIO 1
 #endif
+// rows of the next action requested during phase 2 of the current one (0, 2, 4 or 6 of the six; same-box A/B on 256x128x64,
+// with V3_FIRST_EARLY: 0 -> 40.8 us, 2 -> 40.5, 4 -> 40.3, 6 (only in cell 1: registers) -> 40.7; 6 in cell 0 is 66
+// registers = seven waves per SIMD, 42.3 us)
+#ifndef V3_PREFETCH
+#define V3_PREFETCH 4
+#endif
+// 1: the six rows of action 0 are requested at the top of the kernel, ahead of the descriptor / path copies to LDS
+// the cell of phase 2 in which those requests go out (0: behind its LDS reads, 1: behind the second cell's)
+#ifndef V3_PREFETCH_CELL
+#define V3_PREFETCH_CELL 0
+#endif
+#ifndef V3_FIRST_EARLY
+#define V3_FIRST_EARLY 1
+#endif
 
 namespace tplhip {
 namespace {
@@ -144,6 +158,46 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     float* dsc = reinterpret_cast<float*>(smem + (size_t)NV * row_slots * sizeof(v4f));
     float* pv = dsc + NV * N_BWD * 8;
     const ActDesc* __restrict__ d0 = acts + (size_t)row0 * N_BWD;
+    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<Node*>(next), 0, (int)((size_t)nrows * S * sizeof(Node)), 0x00020000);
+    const unsigned voff = (unsigned)js * 12u, row_bytes = (unsigned)S * 12u;
+    auto load_row = [&](int r) -> Node3 {
+        const v3f x = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(next_rsrc, (int)voff, (int)((unsigned)r * row_bytes), 0));
+        return Node3{x.x, x.y, x.z};
+    };
+    Node3 lo[2], up[NV][2];
+    // scalar descriptor words of ONE action: the rows (lower pair of row 0, upper pair of every row) and the two doubles
+    struct ActScalars { int r00, r10, r01[NV], r11[NV]; double j_term[NV], tn_v_d[NV]; };
+    auto fetch_scalars = [&](int k) {
+        ActScalars x;
+        x.r00 = d0[k].r00; x.r10 = d0[k].r10;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const ActDesc& e = d0[i * rs + k];
+            x.r01[i] = e.r01; x.r11[i] = e.r11; x.j_term[i] = e.j_term; x.tn_v_d[i] = e.tn_v_d;
+        }
+        return x;
+    };
+    // rows [from, to) of an action's six, in the order lower pair, upper pair of row 0, upper pair of row 1
+    auto issue_loads = [&](const ActScalars& x, int from = 0, int to = 2 + 2 * NV) {
+        if (from <= 0 && 0 < to) lo[0] = load_row(x.r00);
+        if (from <= 1 && 1 < to) lo[1] = load_row(x.r10);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (from <= 2 + 2 * i && 2 + 2 * i < to) up[i][0] = load_row(x.r01[i]);
+            if (from <= 3 + 2 * i && 3 + 2 * i < to) up[i][1] = load_row(x.r11[i]);
+        }
+#if V3_ABLATE == 5      // timing experiment: five row loads per action (2.5 per cell), the sixth row is a copy -- what ANY scheme with 2.5 loads per cell could gain at most
+        up[NV - 1][1] = up[NV - 1][0];
+#elif V3_ABLATE == 6    // ... four row loads per action (2 per cell: the asymptote of sharing a-blended rows along v)
+        up[NV - 1][0] = up[0][0]; up[NV - 1][1] = up[0][1];
+#endif
+    };
+    // the rows of action 0 are requested before anything else: their latency passes under the prologue
+    ActScalars cur = fetch_scalars(0);
+#if V3_FIRST_EARLY && V3_ABLATE != 2
+    issue_loads(cur);
+#endif
     for (int i = is; i < NV * N_BWD * 8; i += blockDim.x)
         dsc[i] = reinterpret_cast<const float*>(d0 + (i / (N_BWD * 8)) * rs + ((i >> 3) % N_BWD))[i & 7];
     for (int i = is; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];
@@ -179,13 +233,6 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             shared_mask |= (sh ? 1u : 0u) << (i * N_BWD + k);
         }
     }
-    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<Node*>(next), 0, (int)((size_t)nrows * S * sizeof(Node)), 0x00020000);
-    const unsigned voff = (unsigned)js * 12u, row_bytes = (unsigned)S * 12u;
-    auto load_row = [&](int r) -> Node3 {
-        const v3f x = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(next_rsrc, (int)voff, (int)((unsigned)r * row_bytes), 0));
-        return Node3{x.x, x.y, x.z};
-    };
     const float s_min_v = in_vgpr(p.s_min);
     const float s_scale = (float)(S - 1);
     const float s_scale_v = in_vgpr(s_scale);
@@ -198,36 +245,12 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     int bk[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) { best[i] = 0x7f8000007f800000ull; bk[i] = 0; }
-    Node3 lo[2], up[NV][2];
-    // scalar descriptor words of ONE action: the rows (lower pair of row 0, upper pair of every row) and the two doubles
-    struct ActScalars { int r00, r10, r01[NV], r11[NV]; double j_term[NV], tn_v_d[NV]; };
-    auto fetch_scalars = [&](int k) {
-        ActScalars x;
-        x.r00 = d0[k].r00; x.r10 = d0[k].r10;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const ActDesc& e = d0[i * rs + k];
-            x.r01[i] = e.r01; x.r11[i] = e.r11; x.j_term[i] = e.j_term; x.tn_v_d[i] = e.tn_v_d;
-        }
-        return x;
-    };
-    auto issue_loads = [&](const ActScalars& x) {
-        lo[0] = load_row(x.r00); lo[1] = load_row(x.r10);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) { up[i][0] = load_row(x.r01[i]); up[i][1] = load_row(x.r11[i]); }
-#if V3_ABLATE == 5      // timing experiment: five row loads per action (2.5 per cell), the sixth row is a copy -- what ANY scheme with 2.5 loads per cell could gain at most
-        up[NV - 1][1] = up[NV - 1][0];
-#elif V3_ABLATE == 6    // ... four row loads per action (2 per cell: the asymptote of sharing a-blended rows along v)
-        up[NV - 1][0] = up[0][0]; up[NV - 1][1] = up[0][1];
-#endif
-    };
 #if V3_ABLATE == 2       // timing experiment: no row loads at all (registers fed from lane ids), results are wrong
     lo[0] = lo[1] = Node3{(float)is, 1.0f, 1.0f};
     for (int i = 0; i < NV; ++i) up[i][0] = up[i][1] = Node3{(float)(is + i), 2.0f, 1.0f};
 #endif
     __syncthreads();                     // descriptors and path limits are in LDS
     const v4f* dsc4 = reinterpret_cast<const v4f*>(dsc);
-    ActScalars cur = fetch_scalars(0);
 #pragma unroll
     for (int k = 0; k < N_BWD; ++k) {
 #if !V3_EARLY_SMEM
@@ -242,7 +265,8 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             __builtin_amdgcn_s_setprio(V3_SETPRIO);
 #endif
 #if V3_ABLATE != 2
-            issue_loads(cur);
+            // (the first V3_PREFETCH rows were requested during phase 2 of action k-1, all of action 0's in the prologue)
+            issue_loads(cur, k > 0 ? V3_PREFETCH : (V3_FIRST_EARLY ? 2 + 2 * NV : 0));
 #endif
             v4f w[NV];
 #pragma unroll
@@ -323,6 +347,16 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const float nc = fmaf(nh.x, ws, nl.x * iws);
             const float ng = fmaf(nh.y, ws, nl.y * iws);
             const float nj = fmaf(nh.z, ws, nl.z * iws);
+#if V3_PREFETCH > 0 && V3_EARLY_SMEM && V3_ABLATE == 0
+            // The first rows of the NEXT action go out here, in the first cell of this one: their registers are free (the
+            // blends of phase 1 consumed them), the scalar row ids requested at the top of the phase have arrived with
+            // the LDS reads just consumed (one counter), and their latency passes under the rest of the phase.
+            if (i == V3_PREFETCH_CELL && k + 1 < N_BWD) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_loads(cur, 0, V3_PREFETCH);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
             const float alpha = div_const<PATH_DIV>(tn_s, rp_hi, rp_lo);
             const float f0 = fminf(floorf(alpha), path_top);
             const float pa = alpha - f0;
