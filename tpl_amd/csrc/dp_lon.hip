@@ -138,6 +138,7 @@ struct tplhip_dp_lon {
     bool no_v3 = false, no_fwd_overlap = false, no_fwd_spec = false;   // TPLHIP_DEBUG overrides, read by reinit
     FilterRule rule = kDefaultRule;      // R2 / R3 of the arithmetic contract (tplhip_dp_lon_set_filter_rule)
     bool rule_set = false;               // a non-default rule: only the general kernels implement it
+    bool s3_first_early = false;         // k_backward3s requests its first round's rows ahead of its prologue (grids of >= 4 wavefronts per SIMD)
     int s3_kc = 0, s3_grid = 0;          // k_backward3s (grids that leave the chip mostly empty): actions per round (0 = not used), grid
     size_t s3_lds = 0;
 
@@ -291,7 +292,7 @@ bool launch_backward3s_(tplhip_dp_lon* h, int idx_t, int nx)
     a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
     a.tile_v = h->tile_v; a.tile_a = h->tile_a;
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
-    return launch_backward3s(h->path_div3, h->range_div3, h->s3_kc, a, dim3(h->s3_grid, 1), h->s3_lds, h->stream);
+    return launch_backward3s(h->path_div3, h->range_div3, h->s3_kc, h->s3_first_early, a, dim3(h->s3_grid, 1), h->s3_lds, h->stream);
 }
 
 void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
@@ -826,6 +827,7 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
                 max_rows = std::max(max_rows, ((((x + 1) * p.v_steps) >> 3) - ((x * p.v_steps) >> 3)) * p.a_steps);
             h->s3_grid = 8 * max_rows;
             if (h->s3_lds <= (size_t)64 * 1024) h->s3_kc = want;
+            h->s3_first_early = (size_t)nrows * (h->vp_s_pad / 64) >= (size_t)h->n_cu * 4 * 4;
         }
     }
     if (h->lds_bytes > 160 * 1024)

@@ -57,6 +57,6 @@ size_t backward3v_lds_bytes(int s_pad, int path_steps);
 // k_backward3s: the same instruction stream, one cell per lane and kc (= 3) actions per barrier round, for grids
 // that leave the chip mostly empty (s_pad <= 256; grid = 8 * rows of the widest XCD share, as k_backward's)
 size_t backward3s_lds_bytes(int kc, int s_pad, int path_steps);
-bool launch_backward3s(int path_div, int range_div, int kc, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
+bool launch_backward3s(int path_div, int range_div, int kc, bool first_early, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
 
 } // namespace tplhip

@@ -66,6 +66,7 @@
 #define V3_FIRST_EARLY 1
 #endif
 
+
 namespace tplhip {
 namespace {
 
@@ -398,7 +399,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 // the same order and the same integer-key argmin as k_backward3v -- k_backward's work at ~2.5 instead of ~4.5 cycles
 // per instruction.
 // ------------------------------------------------------------------------
-template <int PATH_DIV, int RANGE_DIV, int KC>
+template <int PATH_DIV, int RANGE_DIV, int KC, bool FIRST_EARLY>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, const ActDesc* __restrict__ acts,
               const float* __restrict__ path_all, const float* __restrict__ pre_vmax_all,
@@ -444,6 +445,26 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     float* dsc = reinterpret_cast<float*>(smem + (size_t)KC * row_slots * sizeof(v4f));
     float* pv = dsc + N_BWD * 8;
     const ActDesc* __restrict__ d0 = acts + (size_t)row0 * N_BWD;
+    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<Node*>(next), 0, (int)((size_t)nrows * S * sizeof(Node)), 0x00020000);
+    const unsigned voff = (unsigned)js * 12u, row_bytes = (unsigned)S * 12u;
+    auto load_row = [&](int r) -> Node3 {
+        const v3f x = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(next_rsrc, (int)voff, (int)((unsigned)r * row_bytes), 0));
+        return Node3{x.x, x.y, x.z};
+    };
+    // FIRST_EARLY: the rows of the first round are requested before anything else, so that the prologue's own loads and the
+    // rows share one memory round trip (110 registers instead of 69).  Same-box A/B: 128x64x32 (4096 wavefronts, four per
+    // SIMD) 11.45 -> 10.5 us per sweep; 201x37x20 (2960 wavefronts) 9.89 -> 10.06 us: the host asks for it where the
+    // grid fills four wavefronts per SIMD (profiles/r03_dp_sweep_ablation.txt, block 5).
+    Node3 r00[KC], r10[KC], r01[KC], r11[KC];
+    if constexpr (FIRST_EARLY) {
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const ActDesc& x = d0[kk];
+            r00[kk] = load_row(x.r00); r10[kk] = load_row(x.r10);
+            r01[kk] = load_row(x.r01); r11[kk] = load_row(x.r11);
+        }
+    }
     for (int i = is; i < N_BWD * 8; i += blockDim.x) dsc[i] = reinterpret_cast<const float*>(d0 + (i >> 3))[i & 7];
     for (int i = is; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];
 
@@ -464,13 +485,6 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         sg = 0.0f; if (v > v_max) sg += v - v_max;
         sd_base = (double)(s + d0[0].vdt) + d0[0].a_term;
     }
-    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<Node*>(next), 0, (int)((size_t)nrows * S * sizeof(Node)), 0x00020000);
-    const unsigned voff = (unsigned)js * 12u, row_bytes = (unsigned)S * 12u;
-    auto load_row = [&](int r) -> Node3 {
-        const v3f x = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(next_rsrc, (int)voff, (int)((unsigned)r * row_bytes), 0));
-        return Node3{x.x, x.y, x.z};
-    };
     const float s_min_v = in_vgpr(p.s_min);
     const float s_scale = (float)(S - 1);
     const float s_scale_v = in_vgpr(s_scale);
@@ -486,12 +500,13 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 #pragma unroll
     for (int k0 = 0; k0 < N_BWD; k0 += KC) {
         // ---- phase 1: the four rows of each of the KC actions, requested together; then a-blend, v-blend
-        Node3 r00[KC], r10[KC], r01[KC], r11[KC];
+        if (k0 > 0 || !FIRST_EARLY) {
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) {
-            const ActDesc& x = d0[k0 + kk];
-            r00[kk] = load_row(x.r00); r10[kk] = load_row(x.r10);
-            r01[kk] = load_row(x.r01); r11[kk] = load_row(x.r11);
+            for (int kk = 0; kk < KC; ++kk) {
+                const ActDesc& x = d0[k0 + kk];
+                r00[kk] = load_row(x.r00); r10[kk] = load_row(x.r10);
+                r01[kk] = load_row(x.r01); r11[kk] = load_row(x.r11);
+            }
         }
         if (k0 > 0) asm volatile("s_barrier" ::: "memory");          // the row buffers of the last chunk are read
         else __syncthreads();                                         // descriptors and path limits are in LDS
@@ -588,18 +603,24 @@ size_t backward3s_lds_bytes(int kc, int s_pad, int path_steps)
 
 // one row per workgroup of a.s_pad <= 256 lanes, grid = 8 * (rows of the widest XCD share); kc = 3 (all nine actions per round
 // was built too: 128 registers with spills, 0.22 against 0.16 ms per default-grid plan)
-bool launch_backward3s(int path_div, int range_div, int kc, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
+bool launch_backward3s(int path_div, int range_div, int kc, bool first_early, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
     if (a.s_pad > 256 || lds_bytes > 64 * 1024) return false;
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, grid, dim3(a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
         return true;
     };
+    if (kc == 3 && first_early) {
+        if (path_div == 4 && range_div == 3) return go(k_backward3s<4, 3, 3, true>);
+        if (path_div == 3 && range_div == 3) return go(k_backward3s<3, 3, 3, true>);
+        if (path_div == 4 && range_div == 4) return go(k_backward3s<4, 4, 3, true>);
+        if (path_div == 3 && range_div == 4) return go(k_backward3s<3, 4, 3, true>);
+    }
     if (kc == 3) {
-        if (path_div == 4 && range_div == 3) return go(k_backward3s<4, 3, 3>);
-        if (path_div == 3 && range_div == 3) return go(k_backward3s<3, 3, 3>);
-        if (path_div == 4 && range_div == 4) return go(k_backward3s<4, 4, 3>);
-        if (path_div == 3 && range_div == 4) return go(k_backward3s<3, 4, 3>);
+        if (path_div == 4 && range_div == 3) return go(k_backward3s<4, 3, 3, false>);
+        if (path_div == 3 && range_div == 3) return go(k_backward3s<3, 3, 3, false>);
+        if (path_div == 4 && range_div == 4) return go(k_backward3s<4, 4, 3, false>);
+        if (path_div == 3 && range_div == 4) return go(k_backward3s<3, 4, 3, false>);
     }
     return false;
 }
