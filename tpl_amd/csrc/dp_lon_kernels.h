@@ -477,8 +477,11 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
                                                       const Node* __restrict__ tables, size_t table_cells,
                                                       const float* __restrict__ path, const float* __restrict__ dist_ts,
                                                       TplDpLonParams p, TplDpEnvParams ep,
-                                                      size_t stride_tables, size_t stride_path, size_t stride_dist, FilterRule rule_arg)
+                                                      size_t stride_tables, size_t stride_path, size_t stride_dist, FilterRule rule_arg,
+                                                      TplLonState* __restrict__ mirror)
 {
+    // mirror (may be null): page-locked HOST memory that receives the trajectories too -- the synchronous update() reads
+    // its result there when the stream has drained, with no copy command behind the rollout
     const FilterRule rule = RULE_RT ? rule_arg : kDefaultRule;
     tables += blockIdx.x * stride_tables;
     path += blockIdx.x * stride_path;
@@ -501,6 +504,7 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
     const int r = blockIdx.x;
     const int T = p.t_steps;
     float* out = reinterpret_cast<float*>(trajs + (size_t)r * T);
+    float* out2 = mirror ? reinterpret_cast<float*>(mirror + (size_t)r * T) : nullptr;
     TplLonState tp = inits[r];
     const bool spec = blockDim.x > 64;
     const int w_eval = spec ? 7 : 0, step = spec ? 2 : 1;
@@ -564,7 +568,11 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
         if ((last % FWD_RING) == FWD_RING - 1 || last == T - 1) {
             __syncthreads();
             const int n = ((last % FWD_RING) + 1) * 7, base = (last - (last % FWD_RING)) * 7;
-            for (int e = tid; e < n; e += blockDim.x) out[base + e] = ring[e];
+            for (int e = tid; e < n; e += blockDim.x) {
+                const float x = ring[e];
+                out[base + e] = x;
+                if (out2) out2[base + e] = x;
+            }
             __syncthreads();
         }
         if (have2 || !spec) tp = x_nxt[par];
