@@ -116,6 +116,8 @@ struct tplhip_dp_lon {
     size_t up_cap = 0;
     hipEvent_t ev_up = nullptr;
     bool up_inflight = false;
+    unsigned int* h_flag = nullptr;      // page-locked word a single-rollout plan publishes its sequence number in (update())
+    unsigned int flag_seq = 0;
     TplLonState* h_dl = nullptr;
     size_t dl_cap = 0;
 
@@ -324,7 +326,8 @@ int wait_pending_forwards(tplhip_dp_lon* h)
     return TPLHIP_OK;
 }
 
-int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState* mirror = nullptr)
+int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState* mirror = nullptr,
+                 unsigned int* done_flag = nullptr, unsigned int done_seq = 0)
 {
     const TplDpLonParams& p = h->params;
     const int T = p.t_steps;
@@ -390,7 +393,7 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState
             auto go = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(h->n_rollouts), dim3(fwd_threads(h)), in_lds ? ring_b + maps_b : ring_b, fs,
                                    h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
-                                   h->d_path, dist, p, env->params, (size_t)0, (size_t)0, (size_t)0, h->rule, mirror);
+                                   h->d_path, dist, p, env->params, (size_t)0, (size_t)0, (size_t)0, h->rule, mirror, done_flag, done_seq);
             };
             if (in_lds) { if (rt) go(k_forward<true, true>); else go(k_forward<true, false>); }
             else { if (rt) go(k_forward<false, true>); else go(k_forward<false, false>); }
@@ -661,6 +664,7 @@ int tplhip_dp_lon_destroy(tplhip_dp_lon* h)
     }
     if (h->h_up) (void)hipHostFree(h->h_up);
     if (h->h_dl) (void)hipHostFree(h->h_dl);
+    if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->ev_up) (void)hipEventDestroy(h->ev_up);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1023,9 +1027,23 @@ int tplhip_dp_lon_update_batch(tplhip_dp_lon* h, int n, const TplLonState* inits
         HIP_TRY(hipHostMalloc(&h->h_dl, sizeof(TplLonState) * cnt, hipHostMallocDefault), "pinned buffer allocation failed");
         h->dl_cap = cnt;
     }
-    rc = enqueue_plan(h, env, false, h->h_dl);
+    // one rollout = one workgroup: it publishes a sequence number in page-locked host memory behind its last store, and the
+    // host spins on that word instead of asking the runtime to wait for the stream (a bounded spin: then the plain wait)
+    if (!h->h_flag && hipHostMalloc(&h->h_flag, 64, hipHostMallocDefault) == hipSuccess) *h->h_flag = 0;
+    else (void)hipGetLastError();
+    const bool spin = n == 1 && h->h_flag != nullptr;
+    const unsigned int seq = ++h->flag_seq;
+    rc = enqueue_plan(h, env, false, h->h_dl, spin ? h->h_flag : nullptr, seq);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(h->stream), "lon planner forward pass failed");
+    bool seen = false;
+    if (spin) {
+        volatile unsigned int* f = h->h_flag;
+        for (long it = 0; it < 4000000 && !seen; ++it) {
+            seen = __atomic_load_n(const_cast<unsigned int*>(f), __ATOMIC_ACQUIRE) == seq;
+            if (!seen) __builtin_ia32_pause();
+        }
+    }
+    if (!seen) HIP_TRY(hipStreamSynchronize(h->stream), "lon planner forward pass failed");
     h->up_inflight = false;                                  // the uploads were ordered before what just finished
     std::memcpy(out_trajs, h->h_dl, sizeof(TplLonState) * cnt);
     return TPLHIP_OK;
@@ -1308,7 +1326,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
             auto go = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(count), dim3(fwd_threads(h)), in_lds ? ring_b + maps_b : ring_b, h->stream,
                                    trajs, h->d_sc_inits + first, h->d_sc_tables, h->table_cells, paths, h->d_sc_dist, p, ep,
-                                   tab_stride, path_stride, dist_elems, h->rule, (TplLonState*)nullptr);
+                                   tab_stride, path_stride, dist_elems, h->rule, (TplLonState*)nullptr, (unsigned int*)nullptr, 0u);
             };
             if (in_lds) { if (rt) go(k_forward<true, true>); else go(k_forward<true, false>); }
             else { if (rt) go(k_forward<false, true>); else go(k_forward<false, false>); }

@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
                                                       const float* __restrict__ path, const float* __restrict__ dist_ts,
                                                       TplDpLonParams p, TplDpEnvParams ep,
                                                       size_t stride_tables, size_t stride_path, size_t stride_dist, FilterRule rule_arg,
-                                                      TplLonState* __restrict__ mirror)
+                                                      TplLonState* __restrict__ mirror, unsigned int* __restrict__ done_flag, unsigned int done_seq)
 {
     // mirror (may be null): page-locked HOST memory that receives the trajectories too -- the synchronous update() reads
     // its result there when the stream has drained, with no copy command behind the rollout
@@ -576,6 +576,16 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
             __syncthreads();
         }
         if (have2 || !spec) tp = x_nxt[par];
+    }
+    // done_flag (host memory, single-rollout plans): the host spins on it instead of waiting for the stream to drain.
+    // The flush above ended with a workgroup barrier; every lane that stored to the mirror fences its own stores to
+    // system scope before the barrier below, and one lane then publishes the sequence number.
+    if (done_flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
