@@ -516,3 +516,43 @@ def test_forward_rollout_forms_agree(dt_start, monkeypatch):
             dp, env, trajs, tables, otrajs, dist = _run_both(p, ep, path, occ, inits)
             for r, tr in enumerate(trajs):
                 assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (T, form, r)
+
+
+def test_reeval_after_resident_plans_waits_for_their_rollouts():
+    """Back-to-back mode: the rollout of the last plan_resident() runs on its own stream and reads the path; reeval_traj
+    replaces that path.  It must wait for the pending rollouts first (the advisor's round-2 finding): two plans in
+    flight, then a re-evaluation on ANOTHER path, then the staged result of the second plan -- all three against the
+    oracle, raw bits."""
+    S, V, A, T = 256, 64, 40, 6                     # large enough for the back-to-back (second table set) mode
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    other_path = path.copy()
+    other_path[:, 5] = 9.5                          # another speed limit: the re-evaluation must not leak into the plan
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
+    init = sc.initial_state(0.0, 8.0, 0.0)
+    env = tpl_amd.DynProgEnvironment()
+    env.reinit_buffers(ep)
+    env.set_occ_map(occ)
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p)
+    dp.upload([init], path)
+    dp.plan_resident(env)
+    dp.plan_resident(env)
+    dp.stage_download(0)
+    cp, cep = O.cparams(p), O.cparams(ep)
+    tables, otrajs, _ = O.update(cp, cep, path, occ, [init])
+    # re-evaluate the oracle's plan on the other path while the rollouts may still be running
+    traj = tpl_amd.LonTraj()
+    traj.states = [tpl_amd.LonState() for _ in range(T)]
+    for st, row in zip(traj.states, otrajs[0]):
+        st.t, st.s, st.v, st.a, st.j, st.cost, st.constr = (float(x) for x in row)
+    got_re = _traj_np(dp.reeval_traj(traj, other_path, env))
+    got_plan = _traj_np(dp.collect_download(0)[0])
+    assert np.array_equal(got_plan.view(np.uint32), otrajs[0].view(np.uint32))
+    # the oracle re-costs the same states on the other path with the tables of the plan (lon_planner.cu:403-470)
+    dist2 = O.dist_map_path(cep, occ, other_path, p.path_steps, p.path_step_size)
+    out = (TplLonState * T)()
+    rc = O.lib().dpo_reeval(C.byref(cp), C.byref(cep), O.fptr(other_path), O.fptr(dist2), O.fptr(tables), traj._as_array(), T, out)
+    assert rc == 0
+    assert np.array_equal(got_re.view(np.uint32), O.states_to_np(out).view(np.uint32))
