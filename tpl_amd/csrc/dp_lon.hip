@@ -395,7 +395,10 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState
                                    h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
                                    h->d_path, dist, p, env->params, (size_t)0, (size_t)0, (size_t)0, h->rule, mirror, done_flag, done_seq);
             };
-            if (in_lds) { if (rt) go(k_forward<true, true>); else go(k_forward<true, false>); }
+            if (fwd_threads(h) == 64) {
+                if (in_lds) { if (rt) go(k_forward_seq<true, true>); else go(k_forward_seq<true, false>); }
+                else { if (rt) go(k_forward_seq<false, true>); else go(k_forward_seq<false, false>); }
+            } else if (in_lds) { if (rt) go(k_forward<true, true>); else go(k_forward<true, false>); }
             else { if (rt) go(k_forward<false, true>); else go(k_forward<false, false>); }
         }
         if (overlap) {
@@ -1328,7 +1331,10 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
                                    trajs, h->d_sc_inits + first, h->d_sc_tables, h->table_cells, paths, h->d_sc_dist, p, ep,
                                    tab_stride, path_stride, dist_elems, h->rule, (TplLonState*)nullptr, (unsigned int*)nullptr, 0u);
             };
-            if (in_lds) { if (rt) go(k_forward<true, true>); else go(k_forward<true, false>); }
+            if (fwd_threads(h) == 64) {
+                if (in_lds) { if (rt) go(k_forward_seq<true, true>); else go(k_forward_seq<true, false>); }
+                else { if (rt) go(k_forward_seq<false, true>); else go(k_forward_seq<false, false>); }
+            } else if (in_lds) { if (rt) go(k_forward<true, true>); else go(k_forward<true, false>); }
             else { if (rt) go(k_forward<false, true>); else go(k_forward<false, false>); }
         }
         hipLaunchKernelGGL(k_best_plan, dim3(1), dim3(256), 0, h->stream, trajs, count, id_base + first, T, h->d_sc_best, reset_best ? 1 : 0);

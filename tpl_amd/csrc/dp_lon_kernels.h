@@ -455,6 +455,106 @@ constexpr int FWD_RING = 16;
 // Scenario batches: rollout r belongs to scenario r (one rollout each); its tables, path and distance map are
 // stride_* elements further on (0 = shared by all rollouts, the single-plan case).
 // RULE_RT: the filter rule is the kernel argument (a non-default rule was set); otherwise the default folds away.
+// evalNode<N> as ONE function for the sequential rollout below (the same arithmetic as eval_lane + choose_action_wave, kept
+// in one piece: split that way and inlined, the one-wavefront rollout of a 256x128x64 x 50 plan measured 143 us instead of
+// 118 -- the compiler schedules the eight table reads of a step differently; profiles/r03_dp_forward_speculation.txt)
+template <int N>
+__device__ __forceinline__ void eval_node_wave_seq(TplLonState& tp, const Node* __restrict__ table_next,
+                                                   const float* __restrict__ path, const float* __restrict__ dist_ts,
+                                                   const TplDpLonParams& p, const TplDpEnvParams& ep, float dt, FilterRule rule)
+{
+    const int lane = threadIdx.x & 63;
+    const PathTap pt = path_tap(tp.s, p.path_step_size, p.path_steps);
+    const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
+    const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
+    const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, tp.t, cps_s, rule)
+                                 - (double)p.length_veh * 0.6);
+    const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist);
+    float sg = 0.0f;
+    if (tp.v > v_max) sg += tp.v - v_max;
+    if (roundf(tp.t / p.dt) == (float)(p.t_steps - 1)) {    // lon_planner.cu:93-97
+        tp.cost = sc;
+        return;
+    }
+    const float j = action_jerk(p, lane < N ? lane : N - 1, N);
+    const TplLonState tn = lon_dynamics(tp, j, dt);
+    const float4 node = read_node(p, table_next, tn.s, tn.v, tn.a, rule);
+    const PathTap pn = path_tap(tn.s, p.path_step_size, p.path_steps);
+    const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5]);
+    const ActionResult r = eval_action_tail(p, sc, sg, node, j, state_action_cost(p, j, dt),
+                                            tn.s, tn.v, tn.a, tp.s, s_dist, vmn);
+    const bool valid = lane < N;
+    const float g_in = (valid && !(r.constr != r.constr)) ? r.constr : INFINITY;       // lon_planner.cu:155
+    const float constr_min = wave_min(g_in);
+    const bool cand = valid && !(r.constr > constr_min);                              // :163
+    const float c_in = (cand && r.cost < INFINITY) ? r.cost : INFINITY;               // :166
+    const float cost_min = wave_min(c_in);
+    const unsigned long long hit = __ballot(cand && c_in == cost_min && cost_min < INFINITY);
+    const int idx_min = hit ? (int)__builtin_ctzll(hit) : 0;
+    tp.j = action_jerk(p, idx_min, N);
+    tp.cost = cost_min;
+    tp.constr = constr_min;
+}
+
+// The rollout, one wavefront and one step per round trip: the form for table sets beyond the Infinity Cache, where
+// speculation loses (see k_forward below).  Arguments as k_forward.
+template <bool IN_LDS, bool RULE_RT>
+__global__ void __launch_bounds__(64) k_forward_seq(TplLonState* __restrict__ trajs, const TplLonState* __restrict__ inits,
+                                                    const Node* __restrict__ tables, size_t table_cells,
+                                                    const float* __restrict__ path, const float* __restrict__ dist_ts,
+                                                    TplDpLonParams p, TplDpEnvParams ep,
+                                                    size_t stride_tables, size_t stride_path, size_t stride_dist, FilterRule rule_arg,
+                                                    TplLonState* __restrict__ mirror, unsigned int* __restrict__ done_flag, unsigned int done_seq)
+{
+    const FilterRule rule = RULE_RT ? rule_arg : kDefaultRule;
+    __builtin_amdgcn_s_setprio(3);
+    tables += blockIdx.x * stride_tables;
+    path += blockIdx.x * stride_path;
+    dist_ts += blockIdx.x * stride_dist;
+    extern __shared__ __attribute__((aligned(16))) char fwd_smem[];
+    float* ring = reinterpret_cast<float*>(fwd_smem);                       // FWD_RING x LonState (7 floats)
+    float* l_path = ring + FWD_RING * 7;
+    float* l_dist = l_path + p.path_steps * 7;
+    const int lane = threadIdx.x;
+    if constexpr (IN_LDS) {
+        for (int e = lane; e < p.path_steps * 7; e += 64) l_path[e] = path[e];
+        for (int e = lane; e < ep.t_steps * ep.s_steps; e += 64) l_dist[e] = dist_ts[e];
+        __syncthreads();
+    }
+    const float* pth = IN_LDS ? l_path : path;
+    const float* dst = IN_LDS ? l_dist : dist_ts;
+    const int r = blockIdx.x;
+    const int T = p.t_steps;
+    float* out = reinterpret_cast<float*>(trajs + (size_t)r * T);
+    float* out2 = mirror ? reinterpret_cast<float*>(mirror + (size_t)r * T) : nullptr;
+    TplLonState tp = inits[r];
+    for (int i = 0; i < T; ++i) {
+        const float dt = (i == 0) ? p.dt_start : p.dt;
+        eval_node_wave_seq<N_FWD>(tp, tables + (size_t)min(T - 1, i + 1) * table_cells, pth, dst, p, ep, dt, rule);
+        const int slot = i % FWD_RING;
+        if (lane == 0) {
+            float* q = ring + slot * 7;
+            q[0] = tp.t; q[1] = tp.s; q[2] = tp.v; q[3] = tp.a; q[4] = tp.j; q[5] = tp.cost; q[6] = tp.constr;
+        }
+        if (slot == FWD_RING - 1 || i == T - 1) {
+            __syncthreads();
+            const int n = (slot + 1) * 7, base = (i - slot) * 7;
+            for (int e = lane; e < n; e += 64) {
+                const float x = ring[e];
+                out[base + e] = x;
+                if (out2) out2[base + e] = x;
+            }
+            __syncthreads();
+        }
+        if (i < T - 1) tp = lon_dynamics(tp, tp.j, dt);
+    }
+    if (done_flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (lane == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ------------------------------------------------------------------------
 // The rollout with ONE STEP OF SPECULATION: a step cannot start before the step before it has chosen its action,
 // but that action is one of 21 -- so while one wavefront evaluates step i (evalNode<21> at the known state), seven
@@ -467,10 +567,8 @@ constexpr int FWD_RING = 16;
 // A terminal node at step i chooses nothing (its successor follows the incoming jerk, which is not among the
 // speculated states in general): the wavefront of step i then evaluates step i+1 by itself.
 // blockDim = 512: wavefronts 0..6 speculate, wavefront 7 evaluates the known state.
-// blockDim = 64: no speculation, one step per round (the host's choice for table sets beyond the Infinity Cache: there
-// a round waits for the slowest of 441 x 8 scattered HBM reads instead of 21 x 8, and two steps in 6.9 us lose
-// against 2 x 2.9 us -- 173.7 against 145 us per 50-step rollout on 256x128x64, where the rollout is hidden behind the
-// next plan's sweeps anyway).
+// For table sets beyond the Infinity Cache the host launches k_forward_seq instead: there a round waits for the slowest
+// of 441 x 8 scattered HBM reads instead of 21 x 8, and two steps in 6.9 us lose against 2 x 2.4 us.
 // ------------------------------------------------------------------------
 template <bool IN_LDS, bool RULE_RT>
 __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs, const TplLonState* __restrict__ inits,
@@ -483,6 +581,9 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
     // mirror (may be null): page-locked HOST memory that receives the trajectories too -- the synchronous update() reads
     // its result there when the stream has drained, with no copy command behind the rollout
     const FilterRule rule = RULE_RT ? rule_arg : kDefaultRule;
+    // a rollout is a handful of wavefronts on a dependent chain; in the back-to-back mode it shares its SIMDs with eight
+    // sweep wavefronts of the next plan each: highest priority, so that its few instructions issue when they are ready
+    __builtin_amdgcn_s_setprio(3);
     tables += blockIdx.x * stride_tables;
     path += blockIdx.x * stride_path;
     dist_ts += blockIdx.x * stride_dist;
@@ -506,14 +607,13 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
     float* out = reinterpret_cast<float*>(trajs + (size_t)r * T);
     float* out2 = mirror ? reinterpret_cast<float*>(mirror + (size_t)r * T) : nullptr;
     TplLonState tp = inits[r];
-    const bool spec = blockDim.x > 64;
-    const int w_eval = spec ? 7 : 0, step = spec ? 2 : 1;
+    constexpr int w_eval = 7, step = 2;
     for (int i = 0, round = 0; i < T; i += step, ++round) {
         const int par = round & 1;
         const float dt0 = (i == 0) ? p.dt_start : p.dt;
         const Node* table1 = tables + (size_t)min(T - 1, i + 1) * table_cells;
         const Node* table2 = tables + (size_t)min(T - 1, i + 2) * table_cells;
-        const bool have2 = spec && i + 1 < T;
+        const bool have2 = i + 1 < T;
         // speculated state of this lane's group and its evaluation (wavefronts 0..6)
         const int grp = min(lane / N_FWD, 2), m = lane - grp * N_FWD;
         const bool lane_ok = lane < 3 * N_FWD;
@@ -522,10 +622,7 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
         if (wave == w_eval) {
             TplLonState a = tp;
             const int k = eval_node_wave<N_FWD>(a, table1, pth, dst, p, ep, dt0, true, rule);
-            if (lane == 0) {
-                x_cur[par] = a; x_k[par] = k;
-                if (!spec) x_nxt[par] = lon_dynamics(a, a.j, dt0);
-            }
+            if (lane == 0) { x_cur[par] = a; x_k[par] = k; }
         } else if (have2) {
             b = lon_dynamics(tp, action_jerk(p, 3 * wave + grp, N_FWD), dt0);            // state i+1 if action 3 wave + grp wins
             e2 = eval_lane(b, action_jerk(p, min(m, N_FWD - 1), N_FWD), table2, pth, dst, p, ep, p.dt, rule);
@@ -575,7 +672,7 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
             }
             __syncthreads();
         }
-        if (have2 || !spec) tp = x_nxt[par];
+        if (have2) tp = x_nxt[par];
     }
     // done_flag (host memory, single-rollout plans): the host spins on it instead of waiting for the stream to drain.
     // The flush above ended with a workgroup barrier; every lane that stored to the mirror fences its own stores to
