@@ -199,15 +199,21 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 #if V3_FIRST_EARLY && V3_ABLATE != 2
     issue_loads(cur);
 #endif
-    for (int i = is; i < NV * N_BWD * 8; i += blockDim.x)
-        dsc[i] = reinterpret_cast<const float*>(d0 + (i / (N_BWD * 8)) * rs + ((i >> 3) % N_BWD))[i & 7];
-    for (int i = is; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];
-
+    // ONE memory round trip for the prologue (see k_backward3s): requests first, LDS stores after
+    const int bd = (int)blockDim.x;
+    auto dsc_word = [&](int i) { return reinterpret_cast<const float*>(d0 + (i / (N_BWD * 8)) * rs + ((i >> 3) % N_BWD))[i & 7]; };
+    float dsc_v = 0.0f, pv_v = 0.0f;
+    if (is < NV * N_BWD * 8) dsc_v = dsc_word(is);
+    if (is <= p.path_steps) pv_v = path[min(is, p.path_steps - 1) * 7 + 5];
     const float s = p.s_min + (float)js * p._s_step_size;
     const float acc = p.a_min + (float)ia * p._a_step_size;
     const float v_max = pre_vmax[js];
     const float s_dist = pre_sdist[js];
     const double prog = pre_prog[js];
+    if (is < NV * N_BWD * 8) dsc[is] = dsc_v;
+    if (is <= p.path_steps) pv[is] = pv_v;
+    for (int i = is + bd; i < NV * N_BWD * 8; i += bd) dsc[i] = dsc_word(i);                   // rows of 64 / 128 lanes
+    for (int i = is + bd; i <= p.path_steps; i += bd) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];
     float sc[NV], sg[NV];
     double sd_base[NV];
     {
@@ -465,14 +471,28 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             r01[kk] = load_row(x.r01); r11[kk] = load_row(x.r11);
         }
     }
-    for (int i = is; i < N_BWD * 8; i += blockDim.x) dsc[i] = reinterpret_cast<const float*>(d0 + (i >> 3))[i & 7];
-    for (int i = is; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];
-
+    // ONE memory round trip for the prologue: every lane requests its share of the descriptor words, of the path limits
+    // and its stage prelude values first, then stores to LDS (written as copy loops, each loop waits for its own loads:
+    // three round trips in front of the first row load on a grid where a sweep lasts as long as one workgroup's chain)
+    // (same-box A/B: 201x37x20 9.88 -> 9.73 us per sweep, 256x128x64 40.38 -> 40.20 in k_backward3v; behind the twelve early
+    // row requests of FIRST_EARLY the prologue's small loads only queue up, 10.46 -> 10.75: there the copy loops stay)
+    const int bd = FIRST_EARLY ? 0x40000000 : (int)blockDim.x;
+    float dsc_v = 0.0f, pv_v = 0.0f;
+    if constexpr (FIRST_EARLY) {
+        for (int i = is; i < N_BWD * 8; i += blockDim.x) dsc[i] = reinterpret_cast<const float*>(d0 + (i >> 3))[i & 7];
+        for (int i = is; i <= p.path_steps; i += blockDim.x) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];
+    }
+    if (!FIRST_EARLY && is < N_BWD * 8) dsc_v = reinterpret_cast<const float*>(d0 + (is >> 3))[is & 7];
+    if (!FIRST_EARLY && is <= p.path_steps) pv_v = path[min(is, p.path_steps - 1) * 7 + 5];
     const float s = p.s_min + (float)js * p._s_step_size;
     const float acc = p.a_min + (float)ia * p._a_step_size;
     const float v_max = pre_vmax[js];
     const float s_dist = pre_sdist[js];
     const double prog = pre_prog[js];
+    if (!FIRST_EARLY && is < N_BWD * 8) dsc[is] = dsc_v;
+    if (!FIRST_EARLY && is <= p.path_steps) pv[is] = pv_v;
+    for (int i = is + bd; i < N_BWD * 8; i += bd) dsc[i] = reinterpret_cast<const float*>(d0 + (i >> 3))[i & 7];      // rows of 64 lanes
+    for (int i = is + bd; i <= p.path_steps; i += bd) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];
     float sc, sg;
     double sd_base;
     {
