@@ -518,6 +518,31 @@ def test_forward_rollout_forms_agree(dt_start, monkeypatch):
                 assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (T, form, r)
 
 
+@pytest.mark.parametrize("env_s,obst", [(201, sc.OBSTACLES_OVERTAKE), (64, ()), (130, sc.OBSTACLES_OVERTAKE_TRAFFIC),
+                                        (1000, sc.random_obstacles(6, 11)), (9000, sc.OBSTACLES_OVERTAKE)])
+def test_plan_front_forms_agree(env_s, obst, monkeypatch):
+    """Distance map, stage prelude and terminal stage run as ONE launch (k_plan_front; every block builds the distance
+    slices it needs from occupancy bits) or, with TPLHIP_DEBUG=no_front and where two slices do not fit the LDS of a
+    block (9 000 environment stations), as the three kernels it stands for.  Both against the oracle, raw bits:
+    distance map (no obstacle at all = the 10 000-chain over the whole row, bit rows of 1 to 141 words), tables,
+    trajectories -- with dt_start values that put a stage between two time slices."""
+    S, V, A, T = 96, 10, 8, 5
+    for dt_start in (None, 0.3):
+        p = sc.lon_params(S, V, A, T, dt_start=dt_start)
+        ep = sc.env_params(t_steps=T, s_steps=env_s, l_steps=21, dt_start=dt_start)
+        path = sc.straight_path(p.path_steps, p.path_step_size)
+        occ = sc.occ_map(ep, obst)
+        inits = [sc.initial_state(0.0, 8.0, 0.0), sc.initial_state(30.0, 3.0, 0.5)]
+        for form in ("", "no_front"):
+            monkeypatch.setenv("TPLHIP_DEBUG", form)
+            dp, env, trajs, tables, otrajs, dist = _run_both(p, ep, path, occ, inits)
+            assert dp.info()["plan_front"] == ("three launches" if form else "k_plan_front")
+            assert np.array_equal(env.get_dist_map_path().view(np.uint32), dist.view(np.uint32)), (env_s, form)
+            _assert_tables_equal(dp, tables, T)
+            for r, tr in enumerate(trajs):
+                assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (env_s, form, r)
+
+
 def test_reeval_after_resident_plans_waits_for_their_rollouts():
     """Back-to-back mode: the rollout of the last plan_resident() runs on its own stream and reads the path; reeval_traj
     replaces that path.  It must wait for the pending rollouts first (the advisor's round-2 finding): two plans in

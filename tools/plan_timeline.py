@@ -5,6 +5,7 @@
 start and duration in us from the first kernel of the plan (memory copies are not in a kernel trace)."""
 import csv
 import glob
+import re
 import sys
 
 f = sorted(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"))[-1]
@@ -17,5 +18,6 @@ busy = 0
 for r in plan:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     busy += e - s
-    print(f"  {r['Kernel_Name'].split('(')[0][-44:]:46s} start {(s - t0) / 1e3:7.1f}  {(e - s) / 1e3:6.1f}")
+    name = re.search(r"(k_\w+(<[^>]*>)?|__amd_\w+)", r["Kernel_Name"])
+    print(f"  {(name.group(1) if name else r['Kernel_Name'][:44]):46s} start {(s - t0) / 1e3:7.1f}  {(e - s) / 1e3:6.1f}")
 print(f"  -> {busy / 1e3:.0f} us of kernels in a span of {(int(plan[-1]['End_Timestamp']) - t0) / 1e3:.0f} us")

@@ -137,7 +137,7 @@ struct tplhip_dp_lon {
     int sc_last_first = 0, sc_last_count = 0;
     bool v3_ok = false;                  // the two-rows-per-lane geometry of k_backward3v fits this grid
     int v3_grid = 0;
-    bool no_v3 = false, no_fwd_overlap = false, no_fwd_spec = false;   // TPLHIP_DEBUG overrides, read by reinit
+    bool no_v3 = false, no_fwd_overlap = false, no_fwd_spec = false, no_front = false;   // TPLHIP_DEBUG overrides, read by reinit
     FilterRule rule = kDefaultRule;      // R2 / R3 of the arithmetic contract (tplhip_dp_lon_set_filter_rule)
     bool rule_set = false;               // a non-default rule: only the general kernels implement it
     bool s3_first_early = false;         // k_backward3s requests its first round's rows ahead of its prologue (grids of >= 4 wavefronts per SIMD)
@@ -349,24 +349,40 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState
         h->env_bounded = ok;
     }
 
-    // env.updateDistMapPath, lon_planner.cu:343
-    hipLaunchKernelGGL(k_dist_map_path, dim3(env->params.t_steps), dim3(256),
-                       sizeof(float) * (size_t)env->params.s_steps, h->stream,
-                       env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params,
-                       (size_t)0, (size_t)0, (size_t)0);
-    hipLaunchKernelGGL(k_stage_prelude, dim3(T), dim3(256), 0, h->stream,
-                       h->d_pre_vmax, h->d_pre_sdist, h->d_pre_prog, h->d_path, env->d_dist, p, env->params,
-                       (size_t)0, (size_t)0, (size_t)0, h->rule);
-
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         HIP_TRY(hipEventCreate(&e0), "event creation failed");
         HIP_TRY(hipEventCreate(&e1), "event creation failed");
-        HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
+    }
+    // env.updateDistMapPath (lon_planner.cu:343), the stage prelude and the terminal stage (rule R4): one launch
+    // (k_plan_front) where two distance slices fit the LDS of a block, else the three kernels it stands for
+    const size_t front_lds = 2 * dist_slice_lds_bytes(env->params.s_steps);
+    const bool fused_front = front_lds <= 64 * 1024 && !h->no_front;
+    if (fused_front) {
+        if (h->timing) HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
+        const int nrows = p.v_steps * p.a_steps;
+        const int rpb = std::max(1, (nrows + 4 * h->n_cu - 1) / (4 * h->n_cu));
+        const dim3 grid(env->params.t_steps + (T - 1) + (nrows + rpb - 1) / rpb);
+        Node* term = h->d_tables + (size_t)(T - 1) * h->table_cells;
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, grid, dim3(256), front_lds, h->stream, env->d_dist, env->d_occ, h->d_path,
+                               h->d_pre_vmax, h->d_pre_sdist, h->d_pre_prog, term, p, env->params, rpb, h->rule);
+        };
+        if (h->rule_set) go(k_plan_front<true>); else go(k_plan_front<false>);
+    } else {
+        hipLaunchKernelGGL(k_dist_map_path, dim3(env->params.t_steps), dim3(256),
+                           dist_slice_lds_bytes(env->params.s_steps), h->stream,
+                           env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params,
+                           (size_t)0, (size_t)0, (size_t)0);
+        hipLaunchKernelGGL(k_stage_prelude, dim3(T), dim3(256), 0, h->stream,
+                           h->d_pre_vmax, h->d_pre_sdist, h->d_pre_prog, h->d_path, env->d_dist, p, env->params,
+                           (size_t)0, (size_t)0, (size_t)0, h->rule);
+        if (h->timing) HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
     }
     // backward pass, lon_planner.cu:347-361 -- no host sync between stages
     for (int i = T - 1; i > 0; --i) {
         const int nx = std::min(T - 1, i + 1);
+        if (i == T - 1 && fused_front) continue;
         launch_stage(h, i, nx, i == T - 1);
     }
     if (h->timing) {
@@ -794,6 +810,7 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     h->no_v3 = debug_opt("no_v3");
     h->no_fwd_overlap = debug_opt("no_fwd_overlap");
     h->no_fwd_spec = debug_opt("no_fwd_spec");
+    h->no_front = debug_opt("no_front");
     // "bounded": every float parameter finite and < 1e6 in magnitude, at most 1e5 stages.  Then no
     // cost or constraint sum of the sweep can overflow (largest single term ~ w * (1e6)^2 = 1e18, at
     // most 1e5 of them), no infinity and hence no NaN can appear, and a running lexicographic argmin
@@ -1083,7 +1100,7 @@ int tplhip_dp_lon_reeval(tplhip_dp_lon* h, const TplLonState* traj, int len, con
     HIP_TRY(hipMemcpyAsync(h->d_reeval, traj, sizeof(TplLonState) * (size_t)len,
                            hipMemcpyHostToDevice, h->stream), "copying trajectory to gpu failed");
     hipLaunchKernelGGL(k_dist_map_path, dim3(env->params.t_steps), dim3(256),
-                       sizeof(float) * (size_t)env->params.s_steps, h->stream,
+                       dist_slice_lds_bytes(env->params.s_steps), h->stream,
                        env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params,
                        (size_t)0, (size_t)0, (size_t)0);
     hipLaunchKernelGGL(k_reeval, dim3((len + 63) / 64), dim3(64), 0, h->stream,
@@ -1120,11 +1137,12 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
     std::snprintf(buf, (size_t)n,
                   "{\"sweep\": \"%s\", \"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
                   "\"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"big\": %d, "
-                  "\"bounded_inputs\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\", \"fwd_overlap\": %d}",
+                  "\"bounded_inputs\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\", \"fwd_overlap\": %d, \"plan_front\": \"%s\"}",
                   sweep, h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
                   (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->big ? 1 : 0,
                   (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
-                  h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded && h->params_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0);
+                  h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded && h->params_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0,
+                  h->no_front ? "three launches" : "k_plan_front");
     return TPLHIP_OK;
 }
 
@@ -1273,7 +1291,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
     const float* paths = h->d_sc_path + path_stride * first;
     const size_t tab_stride = h->table_cells * (size_t)T, pre_stride = S * (size_t)T;
 
-    hipLaunchKernelGGL(k_dist_map_path, dim3(ep.t_steps, count), dim3(256), sizeof(float) * (size_t)ep.s_steps, h->stream,
+    hipLaunchKernelGGL(k_dist_map_path, dim3(ep.t_steps, count), dim3(256), dist_slice_lds_bytes(ep.s_steps), h->stream,
                        h->d_sc_dist, h->d_sc_occ + occ_elems * first, paths, p.path_steps, p.path_step_size, ep,
                        dist_elems, occ_elems, path_stride);
     hipLaunchKernelGGL(k_stage_prelude, dim3(T, count), dim3(256), 0, h->stream,

@@ -725,11 +725,67 @@ __global__ void k_reeval(TplLonState* __restrict__ traj,
 }
 
 // ------------------------------------------------------------------------
-// updateDistMapPath, env.cu:131-158.  One block per time slice: the occupancy
-// lookups run in parallel into LDS, then one lane does the (order-dependent,
-// float-accumulating) backward scan, then the slice is written coalesced.
-// occ: [l][s][t] (t fastest).  dist: [t][s].
+// updateDistMapPath, env.cu:131-158: ONE time slice of the distance map, by a whole workgroup (blockDim.x a multiple of
+// 64), into LDS.  occ: [l][s][t] (t fastest).
+// The reference walks idx_s from s_steps-1 down with d = occ > 0 ? 0 : d + step, d starting at 10000: at station i
+// that is 0 at the nearest occupied station j >= i (10000 behind the last station if there is none) plus (j - i)
+// (s_steps - i) times the step, ADDED ONE AT A TIME.  The occupancy look-ups become one bit per station (a ballot per
+// wavefront), every lane finds its j in the bit row and repeats exactly those additions for its own station -- the same
+// floats, without one lane walking the row through LDS (201 dependent LDS round trips: 6.4 us of a 140 us plan).
 // ------------------------------------------------------------------------
+__device__ __forceinline__ void dist_slice_to_lds(float* __restrict__ d_sh, unsigned long long* __restrict__ occ_bits,
+                                                  const float* __restrict__ occ_lst, const float* __restrict__ path,
+                                                  int path_steps, float path_step_size, const TplDpEnvParams& ep, int idx_t)
+{
+    const int S = ep.s_steps;
+    const int words = (S + 63) >> 6;
+    for (int base = 0; base < S; base += blockDim.x) {
+        const int idx_s = base + threadIdx.x;
+        bool occupied = false;
+        if (idx_s < S) {
+            const float s = ep.s_min + (float)idx_s * ep._s_step_size;
+            const PathTap pt = path_tap(s, path_step_size, path_steps);
+            const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
+            const float cps_l = path_lerp(pt, path[pt.i0 * 7 + 3], path[pt.i1 * 7 + 3]);
+            float fs = (cps_s - ep.s_min) / ep._s_step_size;
+            float fl = (cps_l - ep.l_min) / ep._l_step_size;
+            fs = fminf(fmaxf(fs, -1.0f), (float)ep.s_steps);
+            fl = fminf(fmaxf(fl, -1.0f), (float)ep.l_steps);
+            const int js = clampi((int)fs, 0, ep.s_steps - 1);
+            const int jl = clampi((int)fl, 0, ep.l_steps - 1);
+            occupied = occ_lst[((size_t)jl * ep.s_steps + js) * ep.t_steps + idx_t] > 0.0f;
+        }
+        const unsigned long long bits = __ballot(occupied);
+        if ((threadIdx.x & 63) == 0 && idx_s < S) occ_bits[idx_s >> 6] = bits;
+    }
+    __syncthreads();
+    for (int idx_s = threadIdx.x; idx_s < S; idx_s += blockDim.x) {
+        int w = idx_s >> 6;
+        unsigned long long bits = occ_bits[w] >> (idx_s & 63);
+        int j = -1;
+        if (bits) {
+            j = idx_s + __builtin_ctzll(bits);
+        } else {
+            for (++w; w < words; ++w) {
+                bits = occ_bits[w];
+                if (bits) { j = (w << 6) + __builtin_ctzll(bits); break; }
+            }
+        }
+        float d = j >= 0 ? 0.0f : 10000.0f;
+        const int n = j >= 0 ? j - idx_s : S - idx_s;
+        for (int k = 0; k < n; ++k) d += ep._s_step_size;
+        d_sh[idx_s] = d;
+    }
+    __syncthreads();
+}
+
+// LDS of one slice: the distances, then the bit row
+__host__ __device__ inline size_t dist_slice_lds_bytes(int env_s_steps)
+{
+    return sizeof(float) * (((size_t)env_s_steps + 1) & ~(size_t)1) + sizeof(unsigned long long) * (((size_t)env_s_steps + 63) >> 6);
+}
+
+// One block per time slice; dist: [t][s].
 __global__ void k_dist_map_path(float* __restrict__ dist_ts, const float* __restrict__ occ_lst,
                                 const float* __restrict__ path, int path_steps, float path_step_size,
                                 TplDpEnvParams ep, size_t stride_dist, size_t stride_occ, size_t stride_path)
@@ -738,36 +794,92 @@ __global__ void k_dist_map_path(float* __restrict__ dist_ts, const float* __rest
     dist_ts += blockIdx.y * stride_dist;          // scenario batch, see k_stage_prelude
     occ_lst += blockIdx.y * stride_occ;
     path += blockIdx.y * stride_path;
-    float* d_sh = reinterpret_cast<float*>(smem);      // [s_steps]: occupancy flag, then distance
     const int idx_t = blockIdx.x;
     const int S = ep.s_steps;
-    for (int idx_s = threadIdx.x; idx_s < S; idx_s += blockDim.x) {
-        const float s = ep.s_min + (float)idx_s * ep._s_step_size;
-        const PathTap pt = path_tap(s, path_step_size, path_steps);
-        const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
-        const float cps_l = path_lerp(pt, path[pt.i0 * 7 + 3], path[pt.i1 * 7 + 3]);
-        float fs = (cps_s - ep.s_min) / ep._s_step_size;
-        float fl = (cps_l - ep.l_min) / ep._l_step_size;
-        fs = fminf(fmaxf(fs, -1.0f), (float)ep.s_steps);
-        fl = fminf(fmaxf(fl, -1.0f), (float)ep.l_steps);
-        const int js = clampi((int)fs, 0, ep.s_steps - 1);
-        const int jl = clampi((int)fl, 0, ep.l_steps - 1);
-        d_sh[idx_s] = occ_lst[((size_t)jl * ep.s_steps + js) * ep.t_steps + idx_t];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float d = 10000.0f;
-        for (int idx_s = S - 1; idx_s >= 0; --idx_s) {
-            if (d_sh[idx_s] > 0.0f) d = 0.0f; else d += ep._s_step_size;
-            d_sh[idx_s] = d;
-        }
-    }
-    __syncthreads();
+    float* d_sh = reinterpret_cast<float*>(smem);
+    unsigned long long* occ_bits = reinterpret_cast<unsigned long long*>(smem + sizeof(float) * (((size_t)S + 1) & ~(size_t)1));
+    dist_slice_to_lds(d_sh, occ_bits, occ_lst, path, path_steps, path_step_size, ep, idx_t);
     for (int idx_s = threadIdx.x; idx_s < S; idx_s += blockDim.x) {
         dist_ts[(size_t)idx_t * S + idx_s] = d_sh[idx_s];
     }
 }
 
+// ------------------------------------------------------------------------
+// The front of ONE plan in one launch: distance map, stage prelude and the terminal stage (three dependent launches of
+// 6.4 + 4.6 + 6.1 us on tpl's default grid, each far below the launch floor in work).  Roles by block index:
+//   [0, env.t_steps)               slice b of the distance map -> dist_ts (the rollout and reeval read it)
+//   [env.t_steps, +t_steps-1)      prelude of stage 1 .. t_steps-1 (k_stage_prelude's arithmetic)
+//   the rest                       rows_per_block rows of the terminal table (k_backward<TERMINAL>'s arithmetic, rule R4)
+// A prelude or terminal block builds the one or two distance slices ITS stage interpolates between in its own LDS
+// instead of waiting for another block's: no dependency inside the launch.
+// LDS: two slices (dist_slice_lds_bytes each).
+// ------------------------------------------------------------------------
+template <bool RULE_RT>
+__global__ void __launch_bounds__(256) k_plan_front(float* __restrict__ dist_ts, const float* __restrict__ occ_lst,
+                                                    const float* __restrict__ path,
+                                                    float* __restrict__ pre_vmax, float* __restrict__ pre_sdist,
+                                                    double* __restrict__ pre_prog, Node* __restrict__ term_out,
+                                                    TplDpLonParams p, TplDpEnvParams ep, int rows_per_block, FilterRule rule_arg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FilterRule rule = RULE_RT ? rule_arg : kDefaultRule;
+    const int ES = ep.s_steps, S = p.s_steps, T = p.t_steps;
+    const size_t slice_b = dist_slice_lds_bytes(ES), dist_b = sizeof(float) * (((size_t)ES + 1) & ~(size_t)1);
+    float* L0 = reinterpret_cast<float*>(smem);
+    unsigned long long* bits0 = reinterpret_cast<unsigned long long*>(smem + dist_b);
+    float* L1 = reinterpret_cast<float*>(smem + slice_b);
+    unsigned long long* bits1 = reinterpret_cast<unsigned long long*>(smem + slice_b + dist_b);
+    int b = blockIdx.x;
+    if (b < ep.t_steps) {
+        dist_slice_to_lds(L0, bits0, occ_lst, path, p.path_steps, p.path_step_size, ep, b);
+        for (int idx_s = threadIdx.x; idx_s < ES; idx_s += blockDim.x) dist_ts[(size_t)b * ES + idx_s] = L0[idx_s];
+        return;
+    }
+    b -= ep.t_steps;
+    const bool terminal = b >= T - 1;
+    const int stage = terminal ? T - 1 : b + 1;
+    const float t = p.dt_start + (float)(stage - 1) * p.dt;       // lon_planner.cu:196
+    // interpDistMapPath, env.cu:254-264, on the two slices of this stage
+    const Tap tt = make_tap(env_t_idx(ep, t) + 0.5f, ep.t_steps, rule);
+    dist_slice_to_lds(L0, bits0, occ_lst, path, p.path_steps, p.path_step_size, ep, tt.i0);
+    // (a weight of exactly 0 -- every stage time the reference produces: t_idx is a whole number -- makes the blend
+    // fma(q, 0, p * 1) = p for the finite distances of a slice, whatever q: the second slice is not built then)
+    const float* R1 = L0;
+    if (tt.i1 != tt.i0 && tt.w != 0.0f) {
+        dist_slice_to_lds(L1, bits1, occ_lst, path, p.path_steps, p.path_step_size, ep, tt.i1);
+        R1 = L1;
+    }
+    const int row0 = (b - (T - 1)) * rows_per_block, nrows = p.v_steps * p.a_steps;
+    for (int is = threadIdx.x; is < S; is += blockDim.x) {
+        const float s = p.s_min + (float)is * p._s_step_size;     // lon_planner.cu:197
+        const PathTap pt = path_tap(s, p.path_step_size, p.path_steps);
+        const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
+        const float scq = (cps_s - ep.s_min) / (ep.s_max - ep.s_min) * (float)(ep.s_steps - 1);
+        const Tap ts = make_tap(scq + 0.5f, ep.s_steps, rule);
+        const float d0 = lerp1(L0[ts.i0], R1[ts.i0], tt.w, rule);
+        const float d1 = lerp1(L0[ts.i1], R1[ts.i1], tt.w, rule);
+        const float s_dist = (float)((double)lerp1(d0, d1, ts.w, rule) - (double)p.length_veh * 0.6);
+        const double prog = (double)p.w_progress * fabs(1000.0 - (double)s);
+        if (!terminal) {
+            pre_vmax[(size_t)stage * S + is] = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
+            pre_sdist[(size_t)stage * S + is] = s_dist;
+            if (stage == 1) pre_prog[is] = prog;
+            continue;
+        }
+        // terminal stage, lon_planner.cu:93-97: the state cost only; constr and j keep their zero init
+        for (int r = row0; r < min(row0 + rows_per_block, nrows); ++r) {
+            const int ia = r / p.v_steps, iv = r - ia * p.v_steps;
+            const float v = p.v_min + (float)iv * p._v_step_size;
+            const float a = p.a_min + (float)ia * p._a_step_size;
+            float sc = 0.0f;                                      // stateCost lon_planner.cu:40-55
+            sc += p.w_a * (a * a);
+            sc = (float)((double)sc + prog);
+            const float gap = v * p.time_gap + p.gap_min - s_dist;
+            sc = (float)((double)sc + (double)p.w_safety_dist * fmax(0.0, (double)gap));
+            st_node(term_out + (size_t)r * S + is, sc, 0.0f, 0.0f);
+        }
+    }
+}
 
 // ------------------------------------------------------------------------
 // Best plan of a batch of scenario rollouts (new): the lexicographically smallest

@@ -6,6 +6,7 @@
 //     no_bufload     plain global loads instead of buffer loads in k_backward
 //     no_fwd_overlap plan_resident: the forward rollout stays on the main stream
 //     no_fwd_spec    forward rollout without speculation on every grid (the form large table sets take anyway)
+//     no_front       distance map, stage prelude and terminal stage as three launches instead of k_plan_front
 //     kchunk=N       actions per barrier round of k_backward (1 or 3)
 //     big=0|1        treat the grid as small / as several residency rounds deep (k_backward3s / k_backward3v), whatever its size
 //     tile_v=N, tile_a=N   traversal tile of the sweeps
