@@ -910,7 +910,13 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     return TPLHIP_OK;
 }
 
-int tplhip_dp_lon_upload(tplhip_dp_lon* h, int n, const TplLonState* inits, const float* path)
+} // extern "C"
+
+namespace {
+// guard: record the event that protects the staging buffer against the NEXT upload.  A caller that waits for the whole
+// stream before it returns (update_batch) does not need it -- and an event record between the upload and the first
+// kernel of the plan holds that kernel back by several microseconds.
+int upload_impl(tplhip_dp_lon* h, int n, const TplLonState* inits, const float* path, bool guard)
 {
     if (!h || !inits || !path || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
     if (!h->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the planner");
@@ -938,11 +944,36 @@ int tplhip_dp_lon_upload(tplhip_dp_lon* h, int n, const TplLonState* inits, cons
     if (!h->ev_up) HIP_TRY(hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming), "event creation failed");
     std::memcpy(h->h_up, path, path_b);
     std::memcpy(h->h_up + path_b, inits, init_b);
+#ifndef TPLHIP_UPLOAD_KERNEL
+#define TPLHIP_UPLOAD_KERNEL 1
+#endif
+#if TPLHIP_UPLOAD_KERNEL
+    // one launch instead of two copy commands (a hipMemcpyAsync costs the host ~6 us, a launch ~3, and the front of a plan
+    // is bound by how fast the host submits): a few workgroups read the page-locked buffer through its device mapping
+    {
+        const unsigned words_a = (unsigned)(path_b / 4), words_b = (unsigned)(init_b / 4);
+        const unsigned blocks = std::min(64u, (words_a + words_b + 255u) / 256u);
+        hipLaunchKernelGGL(k_upload_words, dim3(blocks), dim3(256), 0, h->stream, reinterpret_cast<const unsigned*>(h->h_up),
+                           reinterpret_cast<unsigned*>(h->d_path), words_a, reinterpret_cast<unsigned*>(h->d_inits), words_b);
+        HIP_TRY(hipGetLastError(), "upload launch failed");
+    }
+#else
     HIP_TRY(hipMemcpyAsync(h->d_path, h->h_up, path_b, hipMemcpyHostToDevice, h->stream), "copying path failed");
     HIP_TRY(hipMemcpyAsync(h->d_inits, h->h_up + path_b, init_b, hipMemcpyHostToDevice, h->stream), "copying initial states failed");
-    HIP_TRY(hipEventRecord(h->ev_up, h->stream), "event record failed");
-    h->up_inflight = true;
+#endif
+    if (guard) {
+        HIP_TRY(hipEventRecord(h->ev_up, h->stream), "event record failed");
+        h->up_inflight = true;
+    }
     return TPLHIP_OK;
+}
+} // namespace
+
+extern "C" {
+
+int tplhip_dp_lon_upload(tplhip_dp_lon* h, int n, const TplLonState* inits, const float* path)
+{
+    return upload_impl(h, n, inits, path, true);
 }
 
 int tplhip_dp_lon_plan_resident(tplhip_dp_lon* h, tplhip_dp_env* env)
@@ -1034,7 +1065,7 @@ int tplhip_dp_lon_update_batch(tplhip_dp_lon* h, int n, const TplLonState* inits
     int rc = check_env(h, env);
     if (rc) return rc;
     if (!out_trajs) return tplhip_fail(TPLHIP_EINVAL, "null output");
-    rc = tplhip_dp_lon_upload(h, n, inits, path);
+    rc = upload_impl(h, n, inits, path, false);              // this call returns after the stream has drained
     if (rc) return rc;
     // the rollout writes the trajectories into page-locked host memory as well: the result is there when the stream has
     // drained -- no copy command behind the rollout (0.149 -> 0.146 ms per default-grid plan).  (Also tried: no copy
@@ -1054,7 +1085,7 @@ int tplhip_dp_lon_update_batch(tplhip_dp_lon* h, int n, const TplLonState* inits
     const bool spin = n == 1 && h->h_flag != nullptr;
     const unsigned int seq = ++h->flag_seq;
     rc = enqueue_plan(h, env, false, h->h_dl, spin ? h->h_flag : nullptr, seq);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }          // the unguarded upload may still read the staging buffer
     bool seen = false;
     if (spin) {
         volatile unsigned int* f = h->h_flag;

@@ -725,6 +725,18 @@ __global__ void k_reeval(TplLonState* __restrict__ traj,
 }
 
 // ------------------------------------------------------------------------
+// Path + initial states from the page-locked staging buffer (read through its device mapping) to their device arrays.
+// ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_upload_words(const unsigned* __restrict__ src, unsigned* __restrict__ dst_a, unsigned words_a,
+                                                      unsigned* __restrict__ dst_b, unsigned words_b)
+{
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < words_a + words_b; i += gridDim.x * blockDim.x) {
+        const unsigned v = src[i];
+        if (i < words_a) dst_a[i] = v; else dst_b[i - words_a] = v;
+    }
+}
+
+// ------------------------------------------------------------------------
 // updateDistMapPath, env.cu:131-158: ONE time slice of the distance map, by a whole workgroup (blockDim.x a multiple of
 // 64), into LDS.  occ: [l][s][t] (t fastest).
 // The reference walks idx_s from s_steps-1 down with d = occ > 0 ? 0 : d + step, d starting at 10000: at station i
