@@ -1080,8 +1080,10 @@ int tplhip_dp_lon_update_batch(tplhip_dp_lon* h, int n, const TplLonState* inits
     }
     // one rollout = one workgroup: it publishes a sequence number in page-locked host memory behind its last store, and the
     // host spins on that word instead of asking the runtime to wait for the stream (a bounded spin: then the plain wait)
-    if (!h->h_flag && hipHostMalloc(&h->h_flag, 64, hipHostMallocDefault) == hipSuccess) *h->h_flag = 0;
-    else (void)hipGetLastError();
+    if (!h->h_flag) {
+        if (hipHostMalloc(&h->h_flag, 64, hipHostMallocDefault) == hipSuccess) *h->h_flag = 0;
+        else { (void)hipGetLastError(); h->h_flag = nullptr; }               // no flag word: the plain stream wait
+    }
     const bool spin = n == 1 && h->h_flag != nullptr;
     const unsigned int seq = ++h->flag_seq;
     rc = enqueue_plan(h, env, false, h->h_dl, spin ? h->h_flag : nullptr, seq);
