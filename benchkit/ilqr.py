@@ -188,7 +188,7 @@ def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrie
     return out
 
 
-def batch_sweep(device=0, batches=(256, 512, 1024, 2048, 4096), updates=3, warmup=1, workload="mpc"):
+def batch_sweep(device=0, batches=(256, 512, 1024, 2048, 4096), updates=3, warmup=2, workload="mpc"):
     """Problem-iterations/s against the batch size: 1024 problems are one wavefront per SIMD of the chip, so 2048 / 4096
     show what a second / fourth wavefront per SIMD hides of the dependent chains."""
     out = []
