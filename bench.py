@@ -341,7 +341,8 @@ def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_c
     # the one exchange of the path: every rank's record -> all ranks, sent from device memory
     ptr, nbytes = dp.best_record_device()                    # synchronises this rank's stream
     if dist is not None:
-        mine = torch.as_tensor(_DeviceBytes(ptr, nbytes), device=torch.device("cuda", device))
+        # (a copy inside HBM into memory of torch's own allocator: RCCL then never sees a foreign hipMalloc'd range)
+        mine = torch.as_tensor(_DeviceBytes(ptr, nbytes), device=torch.device("cuda", device)).clone()
         if rehearsal:
             mine = mine.cpu()
         gathered = [torch.empty_like(mine) for _ in range(world)]
