@@ -1068,9 +1068,9 @@ int tplhip_dp_lon_update_batch(tplhip_dp_lon* h, int n, const TplLonState* inits
     rc = upload_impl(h, n, inits, path, false);              // this call returns after the stream has drained
     if (rc) return rc;
     // the rollout writes the trajectories into page-locked host memory as well: the result is there when the stream has
-    // drained -- no copy command behind the rollout (0.149 -> 0.146 ms per default-grid plan).  (Also tried: no copy
-    // commands IN FRONT of the plan either, its first kernel reading path and initial state from the staging buffer through
-    // its device mapping -- 0.153 ms: ten blocks fetching 5.6 KB over PCIe cost more than two hipMemcpyAsync.)
+    // drained -- no copy command behind the rollout (0.149 -> 0.146 ms per default-grid plan).  (In front of the plan the
+    // upload is ONE small launch, see upload_impl; letting the plan's first kernel read the staging buffer itself was
+    // slower -- ten blocks, now hundreds, fetching the same 5.6 KB over PCIe.)
     const size_t cnt = (size_t)n * h->params.t_steps;
     if (cnt > h->dl_cap) {
         if (h->h_dl) (void)hipHostFree(h->h_dl);
