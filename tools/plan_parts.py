@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Host-side p50 of the three calls of a planning cycle on tpl's default grid: env.reinit_buffers, dp.reinit_buffers,
+dp.update (1.7 / 1.7 / 124 us on the round-3 box; the kernels of update() span 112 us, tools/plan_timeline.py)."""
 import time, numpy as np, sys
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tpl_amd
 from benchkit import scenarios as sc
 S, V, A, T = sc.GRIDS["default"]
