@@ -7,6 +7,7 @@
 //   1  one launch, barrier = ONE device counter                 (release add, relaxed poll, acquire fence)
 //   2  one launch, barrier = a counter per XCD + a device one   (the last arrival of an XCD forwards)
 //   3  hipLaunchCooperativeKernel + cooperative_groups grid sync
+//   5  form 0 captured once into a hipGraph, one hipGraphLaunch per run
 //   4  as 2, but only the LAST arrival of an XCD releases (one L2 write-back per XCD and stage): the others wait for their
 //      stores (vmcnt(0): a store is acknowledged by the L2) and add to the XCD's counter without a fence.  Relies on
 //      blockIdx.x & 7 being the XCD of a workgroup -- a property of the dispatcher, not of the memory model
@@ -183,11 +184,21 @@ int main(int argc, char** argv)
            occ * prop.multiProcessorCount);
     if (n_wg > occ * prop.multiProcessorCount) { printf("grid does not fit: persistent forms would deadlock\n"); return 1; }
     std::vector<float> got(init.size());
-    for (int form = 0; form < 5; ++form) {
+    for (int form = 0; form < 6; ++form) {
         for (int n_st : {1, stages}) {
             double best = 1e30, sum = 0.0;
             const int reps = 200;
             bool good = true;
+            hipGraphExec_t gexec = nullptr;
+            if (form == 5) {
+                hipGraph_t graph;
+                char* tab[2] = {t0, t1};
+                CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                for (int st = 0; st < n_st; ++st) hipLaunchKernelGGL(k_stage, dim3(n_wg), dim3(LANES), 0, s, tab[st & 1], tab[(st + 1) & 1], n_wg);
+                CK(hipStreamEndCapture(s, &graph));
+                CK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+                CK(hipGraphDestroy(graph));
+            }
             for (int rep = 0; rep < reps + 20; ++rep) {
                 CK(hipMemcpyAsync(t0, init.data(), bytes, hipMemcpyHostToDevice, s));
                 CK(hipMemsetAsync(ctr, 0, 4096, s));
@@ -201,6 +212,8 @@ int main(int argc, char** argv)
                     hipLaunchKernelGGL(k_plan<1>, dim3(n_wg), dim3(LANES), 0, s, t0, t1, n_wg, n_st, ctr, failed);
                 } else if (form == 2) {
                     hipLaunchKernelGGL(k_plan<2>, dim3(n_wg), dim3(LANES), 0, s, t0, t1, n_wg, n_st, ctr, failed);
+                } else if (form == 5) {
+                    CK(hipGraphLaunch(gexec, s));
                 } else if (form == 4) {
                     hipLaunchKernelGGL(k_plan<4>, dim3(n_wg), dim3(LANES), 0, s, t0, t1, n_wg, n_st, ctr, failed);
                 } else {
@@ -221,6 +234,7 @@ int main(int argc, char** argv)
                     if (!good) printf("   form %d: failed flag %d, %zu of %zu values differ\n", form, f, bad, got.size());
                 }
             }
+            if (gexec) CK(hipGraphExecDestroy(gexec));
             printf("form %d  %2d stage(s): launch -> completion %7.2f us mean, %7.2f us min%s\n", form, n_st, sum / reps, best,
                    n_st == stages ? (good ? "   result == host" : "   RESULT WRONG") : "");
         }
