@@ -10,6 +10,13 @@ namespace tplhip {
 constexpr int N_BWD = 9;    // evalNode<9>,  lon_planner.cu:201
 constexpr int N_FWD = 21;   // evalNode<21>, lon_planner.cu:220
 
+// ActDesc::flags.  With a weight of exactly 0 the blend fma(q, 0, p * 1) returns p for every finite q (table values are
+// finite and never -0: costs and constraint sums are >= +0, a jerk of zero is j_min + range * k/8 = +0), and with both
+// a-rows clamped to the same row q IS p: in both cases the plain-fp32 sweeps request the a0 rows only and blend them
+// with themselves -- the same bits for half the row loads of such an action (a third to a half of all actions on the
+// benchmark grids: the jerk grid lands on the acceleration grid).
+constexpr int ACT_SINGLE_A = 1;
+
 // Per-(row, action) constants of the backward sweep.  Everything here depends
 // only on (v, a, jerk_k, dt) -- never on the station or the stage.
 // The first eight floats are the part a sweep needs in VECTOR registers (operands of plain fp32
@@ -27,7 +34,7 @@ struct alignas(16) ActDesc {
     int r00, r10, r01, r11;   // next-stage rows (a*V + v) of the corners (a0,v0) (a1,v0) (a0,v1) (a1,v1)
     double a_term;      // ((0.5*a)*dt)*dt             lon_planner.cu:244   (the same for the nine actions of a row)
     float vdt;          // v*dt                                              (the same for the nine actions of a row)
-    int pad;
+    int flags;          // bit 0: the blend along a is trivial -- both a-rows are the same row (clamped) or wa == 0 -- see ACT_SINGLE_A
 };
 static_assert(sizeof(ActDesc) == 80, "ActDesc must be 80 bytes");
 

@@ -54,7 +54,7 @@ __global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p, Fi
     d.r10 = ta.i1 * p.v_steps + tv.i0;
     d.r01 = ta.i0 * p.v_steps + tv.i1;
     d.r11 = ta.i1 * p.v_steps + tv.i1;
-    d.pad = 0;
+    d.flags = ((d.r00 == d.r10 && d.r01 == d.r11) || d.wa == 0.0f) ? ACT_SINGLE_A : 0;
     d.tn_v_d = (double)tn.v;
     acts[idx] = d;
 }

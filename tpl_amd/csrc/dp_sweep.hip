@@ -51,19 +51,31 @@
 #ifndef V3_SETPRIO
 #define V3_SETPRIO 1
 #endif
-// rows of the next action requested during phase 2 of the current one (0, 2, 4 or 6 of the six; same-box A/B on 256x128x64,
-// with V3_FIRST_EARLY: 0 -> 40.8 us, 2 -> 40.5, 4 -> 40.3, 6 (only in cell 1: registers) -> 40.7; 6 in cell 0 is 66
-// registers = seven waves per SIMD, 42.3 us)
+// rows of the next action requested during phase 2 of the current one.  With V3_SINGLE_A (the shipped form) any value
+// above 0 means: its three a0 rows, the ones every action needs.  Without it: 0, 2, 4 or 6 of the six (same-box A/B on
+// 256x128x64, with V3_FIRST_EARLY: 0 -> 40.8 us, 2 -> 40.5, 4 -> 40.3, 6 (only in cell 1: registers) -> 40.7; 6 in cell 0
+// is 66 registers = seven waves per SIMD, 42.3 us)
 #ifndef V3_PREFETCH
 #define V3_PREFETCH 4
 #endif
-// 1: the six rows of action 0 are requested at the top of the kernel, ahead of the descriptor / path copies to LDS
 // the cell of phase 2 in which those requests go out (0: behind its LDS reads, 1: behind the second cell's)
 #ifndef V3_PREFETCH_CELL
 #define V3_PREFETCH_CELL 0
 #endif
+// 1: actions whose blend along a is trivial (ACT_SINGLE_A, dp_lon_internal.h) request and blend their a0 rows only:
+// 6 -> 3 row loads for a third to a half of all actions (same-box A/B: 256x128x64 42.5 -> 40.7 us per sweep,
+// 512x256x128 357 -> 339; conditional requests that CROSS a phase cost 8-14 registers = a wave per SIMD, 45 us)
+#ifndef V3_SINGLE_A
+#define V3_SINGLE_A 1
+#endif
+// 1: the rows of action 0 (its a0 rows with V3_SINGLE_A) are requested at the top of the kernel, ahead of the
+// descriptor / path copies to LDS
 #ifndef V3_FIRST_EARLY
 #define V3_FIRST_EARLY 1
+#endif
+// the same in k_backward3s (two of four row loads)
+#ifndef S3_SINGLE_A
+#define S3_SINGLE_A 1
 #endif
 
 
@@ -168,10 +180,11 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     };
     Node3 lo[2], up[NV][2];
     // scalar descriptor words of ONE action: the rows (lower pair of row 0, upper pair of every row) and the two doubles
-    struct ActScalars { int r00, r10, r01[NV], r11[NV]; double j_term[NV], tn_v_d[NV]; };
+    struct ActScalars { int r00, r10, r01[NV], r11[NV], single; double j_term[NV], tn_v_d[NV]; };
     auto fetch_scalars = [&](int k) {
         ActScalars x;
         x.r00 = d0[k].r00; x.r10 = d0[k].r10;
+        x.single = d0[k].flags & ACT_SINGLE_A;      // (a property of (a, k): the same for both rows of the pair)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const ActDesc& e = d0[i * rs + k];
@@ -194,10 +207,26 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         up[NV - 1][0] = up[0][0]; up[NV - 1][1] = up[0][1];
 #endif
     };
+    // the same by row mask (bit 0 lo[0], 1 lo[1], 2 + 2i up[i][0], 3 + 2i up[i][1]); A0_ROWS / A1_ROWS: the rows of the lower / upper a
+    constexpr unsigned A0_ROWS = 0x15u, A1_ROWS = 0x2au;
+    static_assert(NV == 2, "row masks are written for two rows per lane");
+    auto issue = [&](const ActScalars& x, unsigned m) {
+        if (m & 1u) lo[0] = load_row(x.r00);
+        if (m & 2u) lo[1] = load_row(x.r10);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if ((m >> (2 + 2 * i)) & 1u) up[i][0] = load_row(x.r01[i]);
+            if ((m >> (3 + 2 * i)) & 1u) up[i][1] = load_row(x.r11[i]);
+        }
+    };
     // the rows of action 0 are requested before anything else: their latency passes under the prologue
     ActScalars cur = fetch_scalars(0);
 #if V3_FIRST_EARLY && V3_ABLATE != 2
+#if V3_SINGLE_A && V3_ABLATE == 0
+    issue(cur, A0_ROWS);
+#else
     issue_loads(cur);
+#endif
 #endif
     // ONE memory round trip for the prologue (see k_backward3s): requests first, LDS stores after
     const int bd = (int)blockDim.x;
@@ -273,8 +302,63 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 #endif
 #if V3_ABLATE != 2
             // (the first V3_PREFETCH rows were requested during phase 2 of action k-1, all of action 0's in the prologue)
+#if V3_SINGLE_A && V3_ABLATE == 0
+            if (k > 0 ? V3_PREFETCH == 0 : !V3_FIRST_EARLY) issue(cur, A0_ROWS);
+#else
             issue_loads(cur, k > 0 ? V3_PREFETCH : (V3_FIRST_EARLY ? 2 + 2 * NV : 0));
 #endif
+#endif
+#if V3_SINGLE_A && V3_ABLATE == 0
+            // The blend along a is trivial for a third to a half of all (a, action) pairs -- the successor acceleration is
+            // clamped to the first / last a-row (both taps are the same row) or lands on an a-row (weight exactly 0, see
+            // ACT_SINGLE_A): such an action requests its three a0 rows only and blends them with themselves.  The a0 rows
+            // of every action are requested one phase ahead (they are needed either way); the a1 rows only exist inside
+            // the arm that loads them, so no register of theirs crosses an action.
+            v4f w[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) w[i] = dsc4[(i * N_BWD + k) * 2];
+            Node3 r[NV];
+            if (!cur.single) {
+                issue(cur, A1_ROWS);
+                Node3 bl = lerp3(lo[0], lo[1], w[0].x, w[0].y);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const Node3 bu = lerp3(up[i][0], up[i][1], w[i].x, w[i].y);
+                    r[i] = lerp3(bl, bu, w[i].z, w[i].w);
+                    if (i + 1 < NV) {
+                        if ((shared_mask >> (i * N_BWD + k)) & 1u) {
+                            bl = bu;
+                        } else {
+                            const ActDesc& y = d0[(i + 1) * rs + k];
+                            const Node3 q00 = load_row(y.r00), q10 = load_row(y.r10);
+                            bl = lerp3(q00, q10, w[i + 1].x, w[i + 1].y);
+                        }
+                    }
+                }
+            } else {
+                Node3 bl = lerp3(lo[0], lo[0], w[0].x, w[0].y);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const Node3 bu = lerp3(up[i][0], up[i][0], w[i].x, w[i].y);
+                    r[i] = lerp3(bl, bu, w[i].z, w[i].w);
+                    if (i + 1 < NV) {
+                        if ((shared_mask >> (i * N_BWD + k)) & 1u) {
+                            bl = bu;
+                        } else {
+                            const Node3 q00 = load_row(d0[(i + 1) * rs + k].r00);
+                            bl = lerp3(q00, q00, w[i + 1].x, w[i + 1].y);
+                        }
+                    }
+                }
+            }
+            if (k > 0) asm volatile("s_barrier" ::: "memory");      // everyone is done reading the row buffers of action k-1
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                v4f* Rk = R + i * row_slots;
+                *reinterpret_cast<v3f*>(Rk + is) = (v3f){r[i].c, r[i].g, r[i].j};
+                if (dup_last) *reinterpret_cast<v3f*>(Rk + S) = (v3f){r[i].c, r[i].g, r[i].j};
+            }
+#else
             v4f w[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) w[i] = dsc4[(i * N_BWD + k) * 2];
@@ -303,6 +387,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                     }
                 }
             }
+#endif
         }
 #if V3_ABLATE < 3
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -360,7 +445,11 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             // the LDS reads just consumed (one counter), and their latency passes under the rest of the phase.
             if (i == V3_PREFETCH_CELL && k + 1 < N_BWD) {
                 __builtin_amdgcn_sched_barrier(0);
+#if V3_SINGLE_A
+                issue(cur, A0_ROWS);
+#else
                 issue_loads(cur, 0, V3_PREFETCH);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
@@ -463,13 +552,17 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     // SIMD) 11.45 -> 10.5 us per sweep; 201x37x20 (2960 wavefronts) 9.89 -> 10.06 us: the host asks for it where the
     // grid fills four wavefronts per SIMD (profiles/r03_dp_sweep_ablation.txt, block 5).
     Node3 r00[KC], r10[KC], r01[KC], r11[KC];
+    // (ACT_SINGLE_A, see k_backward3v: an action whose blend along a is trivial requests its two a0 rows only)
+    // (not in the FIRST_EARLY instance: same-box A/B, 128x64x32 10.82 -> 11.8 us per sweep with it in every round, 10.94 in
+    // the later rounds only; 201x37x20 -- the other instance -- 10.08 -> 9.45)
+    auto request_rows = [&](int kk, const ActDesc& x, bool may_skip) {
+        r00[kk] = load_row(x.r00);
+        r01[kk] = load_row(x.r01);
+        if (!(may_skip && (x.flags & ACT_SINGLE_A))) { r10[kk] = load_row(x.r10); r11[kk] = load_row(x.r11); }
+    };
     if constexpr (FIRST_EARLY) {
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) {
-            const ActDesc& x = d0[kk];
-            r00[kk] = load_row(x.r00); r10[kk] = load_row(x.r10);
-            r01[kk] = load_row(x.r01); r11[kk] = load_row(x.r11);
-        }
+        for (int kk = 0; kk < KC; ++kk) request_rows(kk, d0[kk], false);
     }
     // ONE memory round trip for the prologue: every lane requests its share of the descriptor words, of the path limits
     // and its stage prelude values first, then stores to LDS (written as copy loops, each loop waits for its own loads:
@@ -522,19 +615,16 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         // ---- phase 1: the four rows of each of the KC actions, requested together; then a-blend, v-blend
         if (k0 > 0 || !FIRST_EARLY) {
 #pragma unroll
-            for (int kk = 0; kk < KC; ++kk) {
-                const ActDesc& x = d0[k0 + kk];
-                r00[kk] = load_row(x.r00); r10[kk] = load_row(x.r10);
-                r01[kk] = load_row(x.r01); r11[kk] = load_row(x.r11);
-            }
+            for (int kk = 0; kk < KC; ++kk) request_rows(kk, d0[k0 + kk], S3_SINGLE_A && !FIRST_EARLY);
         }
         if (k0 > 0) asm volatile("s_barrier" ::: "memory");          // the row buffers of the last chunk are read
         else __syncthreads();                                         // descriptors and path limits are in LDS
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
             const v4f w = dsc4[(k0 + kk) * 2];
-            const Node3 b0 = lerp3(r00[kk], r10[kk], w.x, w.y);
-            const Node3 b1 = lerp3(r01[kk], r11[kk], w.x, w.y);
+            const bool single = S3_SINGLE_A && !FIRST_EARLY && (d0[k0 + kk].flags & ACT_SINGLE_A);
+            const Node3 b0 = single ? lerp3(r00[kk], r00[kk], w.x, w.y) : lerp3(r00[kk], r10[kk], w.x, w.y);
+            const Node3 b1 = single ? lerp3(r01[kk], r01[kk], w.x, w.y) : lerp3(r01[kk], r11[kk], w.x, w.y);
             const Node3 r = lerp3(b0, b1, w.z, w.w);
             v4f* Rk = R + kk * row_slots;
             *reinterpret_cast<v3f*>(Rk + is) = (v3f){r.c, r.g, r.j};
