@@ -17,8 +17,12 @@ build)
         for f in $SRCS dp_lon_math.h dp_env_internal.h dp_lon_internal.h dp_lon_kernels.h tplhip_common.h tplhip_debug.h; do
             if [ "$rev" = WORK ]; then cp tpl_amd/csrc/$f $d/; else git show "$rev:tpl_amd/csrc/$f" > $d/$f; fi
         done
-        (cd $d && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
-            -fvisibility=hidden -I"$OLDPWD/include" "${extra[@]}" -shared -o "$OLDPWD/tools/ab_tmp/tplhip_$rev.so" $SRCS) \
+        # file by file with the Makefile's flags (dp_sweep.hip without the SLP vectoriser: packed fp32 forms are slow here)
+        (cd $d && for f in $SRCS; do
+            fl=""; [ "$f" = dp_sweep.hip ] && fl="-fno-slp-vectorize"
+            /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+                -fvisibility=hidden -I"$OLDPWD/include" $fl "${extra[@]}" -c $f -o ${f%.hip}.o || exit 1
+         done && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OLDPWD/tools/ab_tmp/tplhip_$rev.so" *.o) \
             2> "tools/ab_tmp/tplhip_$rev.log" || { echo "$rev: build failed"; exit 1; }
         rm -rf $top
         echo "built tools/ab_tmp/tplhip_$rev.so"
