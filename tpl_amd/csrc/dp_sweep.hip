@@ -320,9 +320,6 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             Node3 r[NV];
             if (!cur.single) {
                 issue(cur, A1_ROWS);
-                // everyone is done reading the row buffers of action k-1 -- asked here, the wait passes under the latency of
-                // the rows just requested (40.12 -> 39.82 us per sweep, same box)
-                if (k > 0) asm volatile("s_barrier" ::: "memory");
                 Node3 bl = lerp3(lo[0], lo[1], w[0].x, w[0].y);
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
@@ -354,7 +351,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                     }
                 }
             }
-            if (k > 0 && cur.single) asm volatile("s_barrier" ::: "memory");      // (the other arm has passed its barrier)
+            if (k > 0) asm volatile("s_barrier" ::: "memory");      // everyone is done reading the row buffers of action k-1
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 v4f* Rk = R + i * row_slots;
