@@ -63,8 +63,8 @@
 #define V3_PREFETCH_CELL 0
 #endif
 // 1: actions whose blend along a is trivial (ACT_SINGLE_A, dp_lon_internal.h) request and blend their a0 rows only:
-// 6 -> 3 row loads for a third to a half of all actions (same-box A/B: 256x128x64 42.5 -> 40.7 us per sweep,
-// 512x256x128 357 -> 339; conditional requests that CROSS a phase cost 8-14 registers = a wave per SIMD, 45 us)
+// 6 -> 3 row loads for a third to a half of all actions (same-box A/B: 256x128x64 40.85 -> 39.79 us per sweep,
+// 512x256x128 331.9 -> 327.1; conditional requests that CROSS a phase cost 8-14 registers = a wave per SIMD)
 #ifndef V3_SINGLE_A
 #define V3_SINGLE_A 1
 #endif
@@ -553,8 +553,8 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     // grid fills four wavefronts per SIMD (profiles/r03_dp_sweep_ablation.txt, block 5).
     Node3 r00[KC], r10[KC], r01[KC], r11[KC];
     // (ACT_SINGLE_A, see k_backward3v: an action whose blend along a is trivial requests its two a0 rows only)
-    // (not in the FIRST_EARLY instance: same-box A/B, 128x64x32 10.82 -> 11.8 us per sweep with it in every round, 10.94 in
-    // the later rounds only; 201x37x20 -- the other instance -- 10.08 -> 9.45)
+    // (not in the FIRST_EARLY instance, where it lost 1-9 % on 128x64x32; 201x37x20 -- the other instance -- gains 3 % per
+    // plan: profiles/r03_dp_sweep_ablation.txt, block 9)
     auto request_rows = [&](int kk, const ActDesc& x, bool may_skip) {
         r00[kk] = load_row(x.r00);
         r01[kk] = load_row(x.r01);
