@@ -408,8 +408,9 @@ def traffic_block(roofline, key):
                 if k in tr:
                     roofline[k] = tr[k]
             if "valu_issue" in tr:
-                roofline["binding"] = ("not HBM: VALU issue and the texture-address path, each near 0.7 of the kernel's cycles by the "
-                                       "PMC instruction counts x measured per-instruction costs (model in " + f"profiles/{f})")
+                roofline["binding"] = (f"not HBM: VALU issue ({tr['valu_issue']:.2f} of the kernel's cycles) ahead of the texture-address path "
+                                       f"({tr.get('texture_addr', 0.0):.2f}), by the PMC instruction counts x measured per-instruction costs "
+                                       f"(model in profiles/{f})")
             return
 
 
