@@ -317,8 +317,18 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             v4f w[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) w[i] = dsc4[(i * N_BWD + k) * 2];
-            Node3 r[NV];
+            // (barrier and stores inside the arms: results merged behind the branch cost a move per register)
+            const auto park = [&](const Node3 (&r)[NV]) {
+                if (k > 0) asm volatile("s_barrier" ::: "memory");      // everyone is done reading the row buffers of action k-1
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    v4f* Rk = R + i * row_slots;
+                    *reinterpret_cast<v3f*>(Rk + is) = (v3f){r[i].c, r[i].g, r[i].j};
+                    if (dup_last) *reinterpret_cast<v3f*>(Rk + S) = (v3f){r[i].c, r[i].g, r[i].j};
+                }
+            };
             if (!cur.single) {
+                Node3 r[NV];
                 issue(cur, A1_ROWS);
                 Node3 bl = lerp3(lo[0], lo[1], w[0].x, w[0].y);
 #pragma unroll
@@ -335,7 +345,9 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                         }
                     }
                 }
+                park(r);
             } else {
+                Node3 r[NV];
                 Node3 bl = lerp3(lo[0], lo[0], w[0].x, w[0].y);
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
@@ -350,13 +362,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                         }
                     }
                 }
-            }
-            if (k > 0) asm volatile("s_barrier" ::: "memory");      // everyone is done reading the row buffers of action k-1
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                v4f* Rk = R + i * row_slots;
-                *reinterpret_cast<v3f*>(Rk + is) = (v3f){r[i].c, r[i].g, r[i].j};
-                if (dup_last) *reinterpret_cast<v3f*>(Rk + S) = (v3f){r[i].c, r[i].g, r[i].j};
+                park(r);
             }
 #else
             v4f w[NV];
