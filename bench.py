@@ -408,9 +408,9 @@ def traffic_block(roofline, key):
                 if k in tr:
                     roofline[k] = tr[k]
             if "valu_issue" in tr:
-                roofline["binding"] = (f"not HBM: VALU issue ({tr['valu_issue']:.2f} of the kernel's cycles) ahead of the texture-address path "
-                                       f"({tr.get('texture_addr', 0.0):.2f}), by the PMC instruction counts x measured per-instruction costs "
-                                       f"(model in profiles/{f})")
+                roofline["binding"] = (f"not HBM: VALU issue {tr['valu_issue']:.2f} and the texture-address path {tr.get('texture_addr', 0.0):.2f} of the "
+                                       f"kernel's cycles (PMC instruction counts x measured per-instruction costs, model in profiles/{f}); neither "
+                                       "binds alone -- the rest is the latency of one row round trip per action at eight waves per SIMD (DESIGN 2.2b')")
             return
 
 
