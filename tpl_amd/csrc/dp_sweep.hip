@@ -34,49 +34,20 @@
 
 #include "dp_lon_internal.h"
 
-// timing experiments only (tools/ab_dp.sh build WORK -- -DV3_ABLATE=n): 1 = phase 2 removed, 2 = row loads removed,
-// 3 = both s_barriers of an action removed (the LDS exchange stays, results are wrong), 4 = barriers AND the LDS row
-// exchange removed (a lane blends along s between its own two v-blended values), 5 / 6 = five / four row loads per action
-// instead of six (the rows left out are copies of loaded ones): the ceiling of any scheme that shares more rows
-#ifndef V3_ABLATE
-#define V3_ABLATE 0
-#endif
-// wave priority while a wave requests and blends its rows (phase 1); phase 2 runs at priority 0.  Getting the loads out
-// and the block to its barrier first is worth 0.9 % (42.6 vs 43.0 us, same box); 0 switches it off
-// 1: the scalar descriptor words of action k+1 (row ids, j_term, tn_v) are requested at the start of phase 2 of action
-// k, so that neither the row loads nor the first instruction of a phase 2 wait for a scalar-memory round trip
-#ifndef V3_EARLY_SMEM
-#define V3_EARLY_SMEM 1
-#endif
-#ifndef V3_SETPRIO
-#define V3_SETPRIO 1
-#endif
-// rows of the next action requested during phase 2 of the current one.  With V3_SINGLE_A (the shipped form) any value
-// above 0 means: its three a0 rows, the ones every action needs.  Without it: 0, 2, 4 or 6 of the six (same-box A/B on
-// 256x128x64, with V3_FIRST_EARLY: 0 -> 40.8 us, 2 -> 40.5, 4 -> 40.3, 6 (only in cell 1: registers) -> 40.7; 6 in cell 0
-// is 66 registers = seven waves per SIMD, 42.3 us)
-#ifndef V3_PREFETCH
-#define V3_PREFETCH 4
-#endif
-// the cell of phase 2 in which those requests go out (0: behind its LDS reads, 1: behind the second cell's)
-#ifndef V3_PREFETCH_CELL
-#define V3_PREFETCH_CELL 0
-#endif
-// 1: actions whose blend along a is trivial (ACT_SINGLE_A, dp_lon_internal.h) request and blend their a0 rows only:
-// 6 -> 3 row loads for a third to a half of all actions (same-box A/B: 256x128x64 40.85 -> 39.79 us per sweep,
-// 512x256x128 331.9 -> 327.1; conditional requests that CROSS a phase cost 8-14 registers = a wave per SIMD)
-#ifndef V3_SINGLE_A
-#define V3_SINGLE_A 1
-#endif
-// 1: the rows of action 0 (its a0 rows with V3_SINGLE_A) are requested at the top of the kernel, ahead of the
-// descriptor / path copies to LDS
-#ifndef V3_FIRST_EARLY
-#define V3_FIRST_EARLY 1
-#endif
-// the same in k_backward3s (two of four row loads)
-#ifndef S3_SINGLE_A
-#define S3_SINGLE_A 1
-#endif
+// Measured choices of the two kernels below (same-box A/Bs and the timing experiments that priced them -- phase 2
+// removed, row loads removed, barriers removed, fewer loads per action, ... -- in profiles/r03_dp_sweep_ablation.txt;
+// the preprocessor switches those builds used are gone from this file, `git log -S V3_ABLATE` finds them):
+//  * wave priority 1 while a wave requests and blends its rows (phase 1), 0 in phase 2: the loads go out and the block
+//    reaches its barrier first (0.9 %);
+//  * the scalar descriptor words of action k+1 (row ids, j_term, tn_v) are requested at the start of phase 2 of action
+//    k: neither the row loads nor the first instruction of a phase 2 wait for a scalar-memory round trip;
+//  * the three a0 rows of action k+1 are requested from the first cell of phase 2 of action k, those of action 0 at the
+//    top of the kernel ahead of the descriptor / path copies to LDS (no request ahead: +6 us per 256x128x64 sweep; more
+//    rows or two actions ahead cost the eighth wavefront per SIMD and lose);
+//  * actions whose blend along a is trivial (ACT_SINGLE_A, dp_lon_internal.h) request and blend their a0 rows only:
+//    6 -> 3 row loads for a third to a half of all actions (40.85 -> 39.79 us; k_backward3s: 4 -> 2, in the instance
+//    that does not request its first round early).  A conditional request that CROSSES a phase costs this compiler 8-14
+//    registers = a wavefront per SIMD: the a1 rows only exist inside the arm of phase 1 that blends them.
 
 
 namespace tplhip {
@@ -192,22 +163,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         }
         return x;
     };
-    // rows [from, to) of an action's six, in the order lower pair, upper pair of row 0, upper pair of row 1
-    auto issue_loads = [&](const ActScalars& x, int from = 0, int to = 2 + 2 * NV) {
-        if (from <= 0 && 0 < to) lo[0] = load_row(x.r00);
-        if (from <= 1 && 1 < to) lo[1] = load_row(x.r10);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            if (from <= 2 + 2 * i && 2 + 2 * i < to) up[i][0] = load_row(x.r01[i]);
-            if (from <= 3 + 2 * i && 3 + 2 * i < to) up[i][1] = load_row(x.r11[i]);
-        }
-#if V3_ABLATE == 5      // timing experiment: five row loads per action (2.5 per cell), the sixth row is a copy -- what ANY scheme with 2.5 loads per cell could gain at most
-        up[NV - 1][1] = up[NV - 1][0];
-#elif V3_ABLATE == 6    // ... four row loads per action (2 per cell: the asymptote of sharing a-blended rows along v)
-        up[NV - 1][0] = up[0][0]; up[NV - 1][1] = up[0][1];
-#endif
-    };
-    // the same by row mask (bit 0 lo[0], 1 lo[1], 2 + 2i up[i][0], 3 + 2i up[i][1]); A0_ROWS / A1_ROWS: the rows of the lower / upper a
+    // row requests by mask (bit 0 lo[0], 1 lo[1], 2 + 2i up[i][0], 3 + 2i up[i][1]); A0_ROWS / A1_ROWS: the rows of the lower / upper a
     constexpr unsigned A0_ROWS = 0x15u, A1_ROWS = 0x2au;
     static_assert(NV == 2, "row masks are written for two rows per lane");
     auto issue = [&](const ActScalars& x, unsigned m) {
@@ -221,13 +177,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     };
     // the rows of action 0 are requested before anything else: their latency passes under the prologue
     ActScalars cur = fetch_scalars(0);
-#if V3_FIRST_EARLY && V3_ABLATE != 2
-#if V3_SINGLE_A && V3_ABLATE == 0
     issue(cur, A0_ROWS);
-#else
-    issue_loads(cur);
-#endif
-#endif
     // ONE memory round trip for the prologue (see k_backward3s): requests first, LDS stores after
     const int bd = (int)blockDim.x;
     auto dsc_word = [&](int i) { return reinterpret_cast<const float*>(d0 + (i / (N_BWD * 8)) * rs + ((i >> 3) % N_BWD))[i & 7]; };
@@ -281,34 +231,14 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     int bk[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) { best[i] = 0x7f8000007f800000ull; bk[i] = 0; }
-#if V3_ABLATE == 2       // timing experiment: no row loads at all (registers fed from lane ids), results are wrong
-    lo[0] = lo[1] = Node3{(float)is, 1.0f, 1.0f};
-    for (int i = 0; i < NV; ++i) up[i][0] = up[i][1] = Node3{(float)(is + i), 2.0f, 1.0f};
-#endif
     __syncthreads();                     // descriptors and path limits are in LDS
     const v4f* dsc4 = reinterpret_cast<const v4f*>(dsc);
 #pragma unroll
     for (int k = 0; k < N_BWD; ++k) {
-#if !V3_EARLY_SMEM
-        if (k > 0) cur = fetch_scalars(k);
-#endif
         // ---- phase 1: blend the next-stage rows around (v', a') for the NV cells (a, then v)
-#if V3_ABLATE == 4
-        Node3 own[NV];
-#endif
         {
-#if V3_SETPRIO
-            __builtin_amdgcn_s_setprio(V3_SETPRIO);
-#endif
-#if V3_ABLATE != 2
-            // (the first V3_PREFETCH rows were requested during phase 2 of action k-1, all of action 0's in the prologue)
-#if V3_SINGLE_A && V3_ABLATE == 0
-            if (k > 0 ? V3_PREFETCH == 0 : !V3_FIRST_EARLY) issue(cur, A0_ROWS);
-#else
-            issue_loads(cur, k > 0 ? V3_PREFETCH : (V3_FIRST_EARLY ? 2 + 2 * NV : 0));
-#endif
-#endif
-#if V3_SINGLE_A && V3_ABLATE == 0
+            __builtin_amdgcn_s_setprio(1);
+            // (the a0 rows were requested during phase 2 of action k-1, those of action 0 in the prologue)
             // The blend along a is trivial for a third to a half of all (a, action) pairs -- the successor acceleration is
             // clamped to the first / last a-row (both taps are the same row) or lands on an a-row (weight exactly 0, see
             // ACT_SINGLE_A): such an action requests its three a0 rows only and blends them with themselves.  The a0 rows
@@ -364,65 +294,21 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                 }
                 park(r);
             }
-#else
-            v4f w[NV];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) w[i] = dsc4[(i * N_BWD + k) * 2];
-            Node3 bl = lerp3(lo[0], lo[1], w[0].x, w[0].y);
-#if V3_ABLATE < 3
-            if (k > 0) asm volatile("s_barrier" ::: "memory");      // everyone is done reading the row buffers of action k-1
-#endif
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const Node3 bu = lerp3(up[i][0], up[i][1], w[i].x, w[i].y);
-                const Node3 r = lerp3(bl, bu, w[i].z, w[i].w);
-                v4f* Rk = R + i * row_slots;
-#if V3_ABLATE == 4
-                own[i] = r;
-#else
-                *reinterpret_cast<v3f*>(Rk + is) = (v3f){r.c, r.g, r.j};
-                if (dup_last) *reinterpret_cast<v3f*>(Rk + S) = (v3f){r.c, r.g, r.j};
-#endif
-                if (i + 1 < NV) {
-                    if ((shared_mask >> (i * N_BWD + k)) & 1u) {
-                        bl = bu;
-                    } else {
-                        const ActDesc& y = d0[(i + 1) * rs + k];
-                        const Node3 q00 = load_row(y.r00), q10 = load_row(y.r10);
-                        bl = lerp3(q00, q10, w[i + 1].x, w[i + 1].y);
-                    }
-                }
-            }
-#endif
         }
-#if V3_ABLATE < 3
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-#if V3_SETPRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
         // ---- phase 2: successor station, 1-D blend along s, costs, argmin -- per cell
         int kv = k;
         asm volatile("" : "+v"(kv));
-#if V3_EARLY_SMEM
         const ActScalars now = cur;
         if (k + 1 < N_BWD) {
             cur = fetch_scalars(k + 1);
             __builtin_amdgcn_sched_barrier(0);                 // the requests go out before this phase's arithmetic
         }
-#else
-        const ActScalars& now = cur;
-#endif
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const v4f u = dsc4[(i * N_BWD + k) * 2 + 1];
             const v4f* Rk = R + i * row_slots;
-#if V3_ABLATE == 1
-            best[i] += __float_as_uint(Rk[is].x + u.x);
-            continue;
-#endif
             // lonDynamics station part, lon_planner.cu:244
             const double sd = sd_base[i] + now.j_term[i];
             const float tn_s = fmaxf(s, (float)sd);
@@ -435,30 +321,20 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const float ws = (fr + 32768.0f) - 32768.0f;
             const float iws = 1.0f - ws;
             const int off = (int)(fminf(fl, s_scale) * 16.0f);
-#if V3_ABLATE == 4
-            const v4f nl = (v4f){own[i].c, own[i].g, own[i].j, (float)off}, nh = nl;
-#else
             const v4f nl = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off);
             const v4f nh = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off + 16);
-#endif
             asm volatile("" :: "v"(nl.w), "v"(nh.w));
             const float nc = fmaf(nh.x, ws, nl.x * iws);
             const float ng = fmaf(nh.y, ws, nl.y * iws);
             const float nj = fmaf(nh.z, ws, nl.z * iws);
-#if V3_PREFETCH > 0 && V3_EARLY_SMEM && V3_ABLATE == 0
             // The first rows of the NEXT action go out here, in the first cell of this one: their registers are free (the
             // blends of phase 1 consumed them), the scalar row ids requested at the top of the phase have arrived with
             // the LDS reads just consumed (one counter), and their latency passes under the rest of the phase.
-            if (i == V3_PREFETCH_CELL && k + 1 < N_BWD) {
+            if (i == 0 && k + 1 < N_BWD) {
                 __builtin_amdgcn_sched_barrier(0);
-#if V3_SINGLE_A
                 issue(cur, A0_ROWS);
-#else
-                issue_loads(cur, 0, V3_PREFETCH);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
-#endif
             const float alpha = div_const<PATH_DIV>(tn_s, rp_hi, rp_lo);
             const float f0 = fminf(floorf(alpha), path_top);
             const float pa = alpha - f0;
@@ -621,14 +497,14 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         // ---- phase 1: the four rows of each of the KC actions, requested together; then a-blend, v-blend
         if (k0 > 0 || !FIRST_EARLY) {
 #pragma unroll
-            for (int kk = 0; kk < KC; ++kk) request_rows(kk, d0[k0 + kk], S3_SINGLE_A && !FIRST_EARLY);
+            for (int kk = 0; kk < KC; ++kk) request_rows(kk, d0[k0 + kk], !FIRST_EARLY);
         }
         if (k0 > 0) asm volatile("s_barrier" ::: "memory");          // the row buffers of the last chunk are read
         else __syncthreads();                                         // descriptors and path limits are in LDS
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
             const v4f w = dsc4[(k0 + kk) * 2];
-            const bool single = S3_SINGLE_A && !FIRST_EARLY && (d0[k0 + kk].flags & ACT_SINGLE_A);
+            const bool single = !FIRST_EARLY && (d0[k0 + kk].flags & ACT_SINGLE_A);
             const Node3 b0 = single ? lerp3(r00[kk], r00[kk], w.x, w.y) : lerp3(r00[kk], r10[kk], w.x, w.y);
             const Node3 b1 = single ? lerp3(r01[kk], r01[kk], w.x, w.y) : lerp3(r01[kk], r11[kk], w.x, w.y);
             const Node3 r = lerp3(b0, b1, w.z, w.w);
