@@ -357,7 +357,7 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState
     // env.updateDistMapPath (lon_planner.cu:343), the stage prelude and the terminal stage (rule R4): one launch
     // (k_plan_front) where two distance slices fit the LDS of a block, else the three kernels it stands for
     const size_t front_lds = 2 * dist_slice_lds_bytes(env->params.s_steps);
-    const bool fused_front = front_lds <= 64 * 1024 && !h->no_front;
+    const bool fused_front = front_lds <= 48 * 1024 && !h->no_front;      // (the dynamic-LDS allowance of a launch without opt-in)
     if (fused_front) {
         if (h->timing) HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
         const int nrows = p.v_steps * p.a_steps;
