@@ -138,6 +138,7 @@ struct tplhip_dp_lon {
     bool v3_ok = false;                  // the two-rows-per-lane geometry of k_backward3v fits this grid
     int v3_grid = 0;
     bool no_v3 = false, no_fwd_overlap = false, no_fwd_spec = false, no_front = false;   // TPLHIP_DEBUG overrides, read by reinit
+    bool front_fused = true;                 // what the last plan did (info)
     FilterRule rule = kDefaultRule;      // R2 / R3 of the arithmetic contract (tplhip_dp_lon_set_filter_rule)
     bool rule_set = false;               // a non-default rule: only the general kernels implement it
     bool s3_first_early = false;         // k_backward3s requests its first round's rows ahead of its prologue (grids of >= 4 wavefronts per SIMD)
@@ -358,6 +359,7 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState
     // (k_plan_front) where two distance slices fit the LDS of a block, else the three kernels it stands for
     const size_t front_lds = 2 * dist_slice_lds_bytes(env->params.s_steps);
     const bool fused_front = front_lds <= 48 * 1024 && !h->no_front;      // (the dynamic-LDS allowance of a launch without opt-in)
+    h->front_fused = fused_front;
     if (fused_front) {
         if (h->timing) HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
         const int nrows = p.v_steps * p.a_steps;
@@ -1175,7 +1177,7 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
                   (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->big ? 1 : 0,
                   (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
                   h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded && h->params_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0,
-                  h->no_front ? "three launches" : "k_plan_front");
+                  h->front_fused && !h->no_front ? "k_plan_front" : "three launches");
     return TPLHIP_OK;
 }
 
