@@ -57,12 +57,17 @@ GRID_CASES = [
     pytest.param(128, 64, 66, 3, sc.random_obstacles(9, 7), None, id="s128-v64"),
     # an odd number of velocity rows: the last row pair of k_backward3v is row V-1 twice
     pytest.param(128, 37, 120, 3, sc.random_obstacles(5, 6), None, id="odd-v-steps-plain-fp32-sweep"),
+    # 64 acceleration rows: the jerk grid lands on the acceleration grid (blend weight exactly 0 for three of the nine
+    # actions) next to the clamped ones -- both kinds of ACT_SINGLE_A, in both plain-fp32 sweeps
+    pytest.param(128, 64, 64, 3, sc.OBSTACLES_OVERTAKE_TRAFFIC, None, id="a64-weight-zero-blends-3v"),
+    pytest.param(96, 10, 64, 4, sc.random_obstacles(6, 9), 0.4, id="a64-weight-zero-blends-3s"),
 ]
 
 EXPECTED_KERNEL = {"ragged-rows-v48": "k_backward3v", "ragged-rows-v50-dt_start": "k_backward3v", "full-rows-v40": "k_backward3v",
                    "s128-v64": "k_backward3v", "odd-v-steps-plain-fp32-sweep": "k_backward3v",
                    "reference-default-201x37x20": "k_backward3s", "tiny-33x9x7": "k_backward3s",
-                   "s512-kchunk3": "k_backward", "s1000-kchunk1": "k_backward"}
+                   "s512-kchunk3": "k_backward", "s1000-kchunk1": "k_backward",
+                   "a64-weight-zero-blends-3v": "k_backward3v", "a64-weight-zero-blends-3s": "k_backward3s"}
 
 
 @pytest.mark.parametrize("S,V,A,T,obst,dt_start", GRID_CASES)
