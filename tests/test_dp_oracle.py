@@ -108,6 +108,38 @@ def test_read_node_grid_points_and_quantisation():
     assert np.allclose(out[:3], table[-1, -1, -1, :3], rtol=2e-6)
 
 
+def test_blend_with_weight_zero_or_twin_rows_is_what_the_single_a_sweeps_compute():
+    """What ACT_SINGLE_A of the plain-fp32 sweeps rests on (tpl_amd/csrc/dp_lon_internal.h): the reference's blend
+    lerp(p, q, w) = fma(q, w, p * (1 - w)) returns p bit for bit when w == 0, whatever finite q is -- table values are
+    finite and never -0 -- and a blend of a row with itself needs only that row.  Checked in float32 on the oracle's
+    filter through a table whose two a-rows differ wildly: on an a-grid point the upper row does not matter."""
+    p, _ = _small()
+    rng = np.random.default_rng(7)
+    table = rng.uniform(0, 10, size=(p.a_steps, p.v_steps, p.s_steps, 4)).astype(np.float32)
+    table[..., 2] = rng.uniform(-3, 2, size=table.shape[:3]).astype(np.float32)       # the jerk channel may be negative
+    table[0, 0, 0, :3] = 0.0                                                            # ... and a cell may be all +0
+    twin = table.copy()
+    twin[1:] = rng.uniform(-1e6, 1e6, size=twin[1:].shape).astype(np.float32)           # every row above a-row 0: garbage
+    out, out2 = np.zeros(4, dtype=np.float32), np.zeros(4, dtype=np.float32)
+    for iv in (0, 3, p.v_steps - 1):
+        for i_s in (0, 5, p.s_steps - 1):
+            s = p.s_min + i_s * p._s_step_size
+            v = p.v_min + iv * p._v_step_size
+            O.lib().dpo_read_node(C.byref(p), O.fptr(table), s, v, p.a_min, O.fptr(out))        # a on the first a-row: w_a == 0
+            O.lib().dpo_read_node(C.byref(p), O.fptr(twin), s, v, p.a_min, O.fptr(out2))
+            assert np.array_equal(out.view(np.uint32), out2.view(np.uint32)), (iv, i_s, out, out2)
+            O.lib().dpo_read_node(C.byref(p), O.fptr(table), s, v, p.a_min - 7.0, O.fptr(out))  # clamped below: both taps are a-row 0
+            O.lib().dpo_read_node(C.byref(p), O.fptr(twin), s, v, p.a_min - 7.0, O.fptr(out2))
+            assert np.array_equal(out.view(np.uint32), out2.view(np.uint32)), (iv, i_s, out, out2)
+    # the identity itself, on random bit patterns of the admissible kind
+    pp = np.abs(rng.standard_normal(100000).astype(np.float32)) * np.float32(50.0)
+    pp[:100] = 0.0
+    qq = (rng.standard_normal(100000) * 1e5).astype(np.float32)
+    w = np.float32(0.0)
+    got = (qq.astype(np.float64) * float(w) + (pp * (np.float32(1.0) - w)).astype(np.float64)).astype(np.float32)   # fma: one rounding
+    assert np.array_equal(got.view(np.uint32), pp.view(np.uint32))
+
+
 def test_dist_map_path_scan():
     p, ep = _small()
     path = sc.straight_path(p.path_steps, p.path_step_size)
