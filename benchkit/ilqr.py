@@ -113,13 +113,17 @@ def flops_per_stage(problem, dims, dyn_evals):
     return F_BW.get((X, U), 0), f_deriv, f_roll
 
 
-def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrier=None, id_offset=0, workload="mpc"):
+def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrier=None, id_offset=0, workload="mpc", lib=None):
     """One rank's share of a batched-iLQR workload.  `seed` picks this rank's block of initial states,
     `barrier` (N > 1) brackets the timed region, `id_offset` is the global id of this rank's problem 0."""
     from tpl_amd.optim import genopt, optimizers as o
     w = WORKLOADS[workload]
     horizon = horizon or w["horizon"]
-    make = genopt.build(getattr(o, w["config"])(), w["problem"])
+    if lib:            # an experimental build of the same problem (tools/ab_*.py): never installed over the shipped library
+        from tpl_amd.optim import solver
+        make = solver.factory(lib, getattr(o, w["config"])().param_defaults)
+    else:
+        make = genopt.build(getattr(o, w["config"])(), w["problem"])
     opt = make(batch=batch, horizon=horizon, device=device)
     if workload == "mpc":
         x0 = initial_states(batch, seed)
@@ -166,13 +170,14 @@ def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrie
         "ms_per_update": el / updates * 1e3,
         "kernel_ms_per_update": kernel_ms / max(1, launches),
         "all_finite": bool(np.all(np.isfinite(opt.traj_costs))),
+        "form": opt.info().get("form"),
         "elapsed_s": el, "updates": updates, "iterations_per_update": iters,
         # algorithmic flops per batched iteration = batch x T x (F_bw + F_deriv + n_ls F_roll) over the
         # kernel time of one iteration, against the fp64 vector peak.  The path is latency-bound by construction
         # (50-250 dependent stages on one wavefront per problem); MFMA is not used.
         "roofline": {"bound": "valu_fp64", "unit": "TFLOP/s", "peak": FP64_VECTOR_PEAK_TFLOPS,
                      "achieved": per_iter * iters / k_s / 1e12, "frac": per_iter * iters / k_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                     "traffic": None, "kernel": "k_ilqr_update",
+                     "traffic": None, "kernel": "k_split_chain + k_split_refresh" if opt.info().get("form") == "split" else "k_ilqr_update",
                      "flops_per_stage": {"F_bw": f_bw, "F_deriv": f_deriv, "F_roll": f_roll, "n_ls": n_ls},
                      "algorithmic_flops_per_batched_iteration": per_iter,
                      "executed_flops_per_batched_iteration": per_iter_exec,

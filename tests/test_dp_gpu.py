@@ -267,19 +267,21 @@ def test_full_size_spot_checks(grid):
     assert np.array_equal(again[:, 5:].view(np.uint32), tr[:, 5:].view(np.uint32))
 
 
-def test_division_modes_agree(monkeypatch):
-    """The sweep forms its two divisions by run-time constants either with IEEE
-    division or with reciprocal forms that reinit proved exact by brute force
-    (k_verify_div); both code paths must give the same bits."""
-    S, V, A, T = 201, 20, 12, 6
+@pytest.mark.parametrize("S,V,A,T,kernel", [(201, 20, 12, 6, "k_backward3s"), (128, 64, 66, 3, "k_backward3v")])
+def test_division_modes_agree(S, V, A, T, kernel, monkeypatch):
+    """The plain-fp32 sweeps form their two divisions by run-time constants in the cheapest form reinit proved exact by
+    brute force (k_verify_div): one multiplication (power-of-two divisor), a two-float reciprocal, a reciprocal with
+    one Newton step on the quotient -- or as IEEE divisions where no proof holds.  Every form on the same kernel, and
+    the general sweep: the same bits."""
     p = sc.lon_params(S, V, A, T)
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
     path = sc.straight_path(p.path_steps, p.path_step_size)
     occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
     tabs = {}
-    for mode in ("fast", "ieee"):
-        if mode == "ieee":
-            monkeypatch.setenv("TPLHIP_DEBUG", "no_fastdiv")
+    forms = {}
+    for mode, dbg in (("fast", ""), ("ieee", "no_fastdiv"), ("form3", "div_form=3"), ("form5", "div_form=5"),
+                      ("general", "no_v3,no_s3")):
+        monkeypatch.setenv("TPLHIP_DEBUG", dbg)
         env = tpl_amd.DynProgEnvironment()
         env.reinit_buffers(ep)
         env.set_occ_map(occ)
@@ -287,27 +289,36 @@ def test_division_modes_agree(monkeypatch):
         dp.reinit_buffers(p)
         dp.update(sc.initial_state(0.0, 8.0, 0.0), path, env)
         info = dp.info()
-        assert info["sweep"] == ("k_backward" if mode == "ieee" else "k_backward3s"), info
-        assert (info["range_div3"] == 0) == (mode == "ieee"), info
+        assert info["sweep"] == ("k_backward" if mode == "general" else kernel), info
+        forms[mode] = (info["path_div3"], info["range_div3"])
         tabs[mode] = [dp.copy_table(t) for t in range(1, T)]
-    for a, b in zip(tabs["fast"], tabs["ieee"]):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    # a divisor the float reciprocal form is not exact for (0.3) must fall back, not guess
-    p2 = sc.lon_params(S, V, A, T)
-    p2.path_step_size = 0.3
-    p2.path_steps = 667
-    dp = tpl_amd.DynProgLonPlanner()
-    dp.reinit_buffers(p2)
-    assert dp.info()["path_div3"] in (0, 3, 4)
-    path2 = sc.straight_path(p2.path_steps, p2.path_step_size)
-    env = tpl_amd.DynProgEnvironment()
-    env.reinit_buffers(ep)
-    env.set_occ_map(occ)
-    trajs = dp.update_batch([sc.initial_state(0.0, 8.0, 0.0)], path2, env)
-    cp, cep = O.cparams(p2), O.cparams(ep)
-    tables, otrajs, _ = O.update(cp, cep, path2, occ, [sc.initial_state(0.0, 8.0, 0.0)])
-    _assert_tables_equal(dp, tables, T)
-    assert np.array_equal(_traj_np(trajs[0]).view(np.uint32), otrajs[0].view(np.uint32))
+    assert forms["ieee"] == (0, 0) and forms["fast"] == (4, 3), forms         # path step 1 m, range 200 m
+    assert forms["form5"] == (5, 5) and forms["form3"][1] == 3, forms
+    for mode in tabs:
+        for a, b in zip(tabs["fast"], tabs[mode]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), mode
+    monkeypatch.setenv("TPLHIP_DEBUG", "")
+    # divisors that used to send the grid to the general sweep (0.3 / 0.7 / 1.3 m path steps, a 157.3 m range): they stay
+    # on the plain-fp32 sweep, in whatever form holds for them, and match the oracle
+    for step, s_max in ((0.3, 200.0), (0.7, 157.3), (1.3, 157.3)):
+        p2 = sc.lon_params(S, V, A, T)
+        p2.path_step_size = step
+        p2.path_steps = int(np.ceil(260.0 / step))
+        p2.s_max = s_max
+        dp = tpl_amd.DynProgLonPlanner()
+        dp.reinit_buffers(p2)
+        info = dp.info()
+        assert info["path_div3"] in (0, 3, 4, 5) and info["range_div3"] in (0, 3, 4, 5), info
+        path2 = sc.straight_path(p2.path_steps, p2.path_step_size)
+        env = tpl_amd.DynProgEnvironment()
+        env.reinit_buffers(ep)
+        env.set_occ_map(occ)
+        trajs = dp.update_batch([sc.initial_state(0.0, 8.0, 0.0)], path2, env)
+        assert dp.info()["sweep"] == kernel, dp.info()
+        cp, cep = O.cparams(p2), O.cparams(ep)
+        tables, otrajs, _ = O.update(cp, cep, path2, occ, [sc.initial_state(0.0, 8.0, 0.0)])
+        _assert_tables_equal(dp, tables, T)
+        assert np.array_equal(_traj_np(trajs[0]).view(np.uint32), otrajs[0].view(np.uint32))
 
 
 def test_pipelined_downloads_match_the_blocking_one():
@@ -457,13 +468,17 @@ def test_unbounded_inputs_take_the_two_pass_kernel_and_still_match():
         assert np.array_equal(_traj_np(trajs[0]).view(np.uint32), otrajs[0].view(np.uint32))
 
 
-@pytest.mark.parametrize("name,quant,lerp", [("wfloor", 2, 0), ("wnone", 0, 0), ("lerp1", 1, 1), ("lerp2", 1, 2)])
-def test_filter_rule_variants_match_their_oracle_builds(name, quant, lerp):
+@pytest.mark.parametrize("name,quant,lerp", [("wfloor", 2, 0), ("wnone", 0, 0), ("lerp1", 1, 1), ("lerp2", 1, 2),
+                                             ("wfloor_lerp1", 2, 1), ("wfloor_lerp2", 2, 2), ("wnone_lerp1", 0, 1),
+                                             ("wnone_lerp2", 0, 2)])
+def test_filter_rule_variants_match_their_oracle_builds(name, quant, lerp, monkeypatch):
     """R2 (weight quantisation) and R3 (blend form) stand in for the reference's texture unit; they are run-time
-    parameters of the HIP planner (tplhip_dp_lon_set_filter_rule).  Each non-default rule must reproduce the
-    sensitivity build of the CPU restatement that makes the same choice (oracle/Makefile, _sens/) bit for bit --
-    tables, trajectories, re-evaluation -- on a small and on a several-rounds-deep grid, and setting the default again
-    must bring back the default result and the plain-fp32 sweep."""
+    parameters of the HIP planner (tplhip_dp_lon_set_filter_rule) and template parameters of the plain-fp32 sweeps,
+    which are built for all nine combinations.  Each non-default rule must reproduce the sensitivity build of the CPU
+    restatement that makes the same choice (oracle/Makefile, _sens/) bit for bit -- tables, trajectories,
+    re-evaluation -- on a small and on a several-rounds-deep grid, ON THE SAME KERNEL as the default rule, with the
+    Newton form of the divisions, with IEEE divisions, and on the general sweep; setting the default again must bring
+    back the default result."""
     import os
     import subprocess
     odir = os.path.join(O.ROOT, "oracle")
@@ -476,27 +491,34 @@ def test_filter_rule_variants_match_their_oracle_builds(name, quant, lerp):
         path = sc.straight_path(p.path_steps, p.path_step_size)
         occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
         inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(4, seed=3)
-        env = tpl_amd.DynProgEnvironment()
-        env.reinit_buffers(ep)
-        env.set_occ_map(occ)
-        dp = tpl_amd.DynProgLonPlanner()
-        dp.reinit_buffers(p)
-        dp.set_filter_rule(quant, lerp)
-        trajs = dp.update_batch(inits, path, env)
-        assert dp.info()["sweep"] == "k_backward", dp.info()
         cp, cep = O.cparams(p), O.cparams(ep)
         O.use(lib)
         try:
             tables, otrajs, _ = O.update(cp, cep, path, occ, inits)
         finally:
             O.use(None)
-        _assert_tables_equal(dp, tables, T)
-        for r, tr in enumerate(trajs):
-            assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (name, r)
+        for dbg, want_kernel, want_forms in (("", want_default, (5, 5)), ("no_fastdiv", want_default, (0, 0)),
+                                             ("no_v3,no_s3", "k_backward", None)):
+            monkeypatch.setenv("TPLHIP_DEBUG", dbg)
+            env = tpl_amd.DynProgEnvironment()
+            env.reinit_buffers(ep)
+            env.set_occ_map(occ)
+            dp = tpl_amd.DynProgLonPlanner()
+            dp.reinit_buffers(p)
+            dp.set_filter_rule(quant, lerp)
+            trajs = dp.update_batch(inits, path, env)
+            info = dp.info()
+            assert info["sweep"] == want_kernel, info
+            if want_forms:
+                assert (info["path_div3"], info["range_div3"]) == want_forms, info
+            _assert_tables_equal(dp, tables, T)
+            for r, tr in enumerate(trajs):
+                assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (name, r)
+        monkeypatch.setenv("TPLHIP_DEBUG", "")
         # the default rule again: default tables, default kernel
         dp.set_filter_rule(1, 0)
         trajs = dp.update_batch(inits, path, env)
-        assert dp.info()["sweep"] == want_default, dp.info()
+        assert dp.info()["sweep"] == "k_backward", dp.info()       # (this handle was created under no_v3,no_s3)
         tables0, otrajs0, _ = O.update(cp, cep, path, occ, inits)
         _assert_tables_equal(dp, tables0, T)
         assert any(not np.array_equal(tables0[t].view(np.uint32), tables[t].view(np.uint32)) for t in range(1, T)), "the variant changes nothing here"

@@ -183,7 +183,7 @@ def test_long_horizon_and_per_problem_parameters():
 
 
 @pytest.mark.parametrize("horizon,t_cap,lds_kb,want_lds", [(37, 37, None, 1), (21, None, None, 1), (21, None, 39, 0),
-                                                           (60, 60, None, 1), (13, 13, 8, 0)])
+                                                           (60, 60, None, 1), (13, 20, 8, 0)])
 def test_ragged_horizons_match_oracle(horizon, t_cap, lds_kb, want_lds, monkeypatch):
     """Horizons that are not a multiple of the rollout ring (8 stages) and BOTH homes of the trajectory mirrors.
     A single problem has a compute unit to itself, so its mirrors sit in LDS even at the default capacity of 299
@@ -264,3 +264,119 @@ def test_both_backward_pass_forms_pass_the_goldens_and_agree_bit_for_bit(name, t
         results.append([np.array(getattr(opt, f)) for f in ("x", "u", "k", "K", "lagrange_multiplier")])
     for a, b in zip(*results):
         assert np.array_equal(a, b)
+
+
+# ---- split-launch form (k_split_begin / _refresh / _chain / _end): the update() of a chip-filling batch as a sequence of
+# launches, so that the dependent chains run with several resident wavefronts per SIMD.  Forced here with
+# TPLHIP_DEBUG=ilqr_split=1 on batches of any size; the same routines in the same order: the same bits.
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_split_launch_passes_the_goldens(name, monkeypatch):
+    monkeypatch.setenv("TPLHIP_DEBUG", "ilqr_split=1")
+    model, _, kw, _ = cases.CASES[name]
+    g = np.load(os.path.join(GOLDEN, f"ilqr_{name}.npz"))
+    opt = _factory(model)()
+    cases.apply_inputs(opt, g)
+    snaps = cases.run_sequence(opt, int(g["in.shift"]))
+    assert opt.info()["form"] == "split", opt.info()
+    bad = cases.compare(snaps, g, first_order=bool(kw.get("first_order")))
+    assert not bad, "\n".join(bad)
+
+
+_BIT_FIELDS = ("x", "u", "k", "K", "lagrange_multiplier", "next_x", "next_u", "prev_x", "prev_k", "fx", "fu", "lx", "lu",
+               "lxx", "luu", "lux", "traj_costs", "iterations", "lg_iterations", "alpha", "mu", "mu_step",
+               "trajectory_changed", "improved", "termination_condition")
+
+
+@pytest.mark.parametrize("lds_kb", [None, 8, 40])
+def test_split_launch_matches_single_launch(lds_kb, monkeypatch):
+    """A ragged batch: per-problem iteration budgets and horizons, a convergence threshold that stops problems at
+    different iterations, two multiplier rounds.  Both forms, every field and every scalar: the same bits.  Run with the
+    split kernels' default LDS budget, a tight one (the mirrors and one of the arrays stay in global memory) and a
+    roomy one (arrays and mirrors resident)."""
+    make = _factory("trajectory_tracking_mpc")
+    B = 70
+    rng = np.random.default_rng(5)
+    x0 = np.zeros((B, 7))
+    x0[:, 1] = rng.uniform(-1, 1, B)
+    x0[:, 2] = rng.uniform(-0.2, 0.2, B)
+    x0[:, 4] = rng.uniform(4, 10, B)
+    results = []
+    for form in (0, 1):
+        dbg = f"ilqr_split={form}" + (f",ilqr_split_lds_kb={lds_kb}" if (form and lds_kb) else "")
+        monkeypatch.setenv("TPLHIP_DEBUG", dbg)
+        opt = make(batch=B, horizon=50)
+        cases.mpc(opt, seed=0, curvature=0.01, min_rel=1e-3)
+        opt.x[:, 0] = x0
+        opt.max_lg_iterations = 2
+        opt.lg_mult_limit = 50.0
+        opt.max_iterations = 3 + (np.arange(B) % 6)
+        opt.horizon = 50 - (np.arange(B) % 9)
+        out = []
+        for _ in range(2):
+            opt.update()
+            out.append({f: np.array(getattr(opt, f)) for f in _BIT_FIELDS})
+            opt.shift(1)
+        info = opt.info()
+        assert info["form"] == ("split" if form else "single"), info
+        if form and lds_kb:
+            assert info["lds_traj"] == (1 if lds_kb == 40 else 0) and (info["lds_arrays"] == 5) == (lds_kb == 40), info
+        results.append(out)
+    for a, b in zip(*results):
+        for f in _BIT_FIELDS:
+            assert np.array_equal(a[f], b[f], equal_nan=True), f
+    it = results[0][0]["iterations"]
+    assert len(np.unique(it)) > 2, it                  # the batch really is ragged
+
+
+@pytest.mark.parametrize("model,first_order", [("lateral_profile", False), ("simple_vehicle", True)])
+def test_split_launch_matches_single_launch_other_models(model, first_order, monkeypatch):
+    """The register-resident backward pass (two-state problems) and the first-order method through the split form."""
+    make = _factory(model)
+    name = {"lateral_profile": "lateral", "simple_vehicle": "simple_vehicle_first_order"}[model]
+    g = np.load(os.path.join(GOLDEN, f"ilqr_{name}.npz"))
+    B = 9
+    results = []
+    for form in (0, 1):
+        monkeypatch.setenv("TPLHIP_DEBUG", f"ilqr_split={form}")
+        one = make()
+        cases.apply_inputs(one, g)
+        T = int(one.horizon)
+        opt = make(batch=B, horizon=T)
+        cases.apply_inputs(opt, g)
+        x0 = np.array(one.x[0])
+        for b in range(B):
+            opt.x[b, 0] = x0 * (1.0 + 0.05 * b)
+        opt.update()
+        opt.update()
+        assert opt.info()["form"] == ("split" if form else "single")
+        results.append({f: np.array(getattr(opt, f)) for f in _BIT_FIELDS})
+    for f in _BIT_FIELDS:
+        assert np.array_equal(results[0][f], results[1][f], equal_nan=True), f
+
+
+def test_large_batch_takes_the_split_form_and_matches_oracle():
+    """4 096 problems (four per SIMD): update() picks the split form by itself; every 256th problem is re-solved by the
+    CPU oracle."""
+    make = _factory("trajectory_tracking_mpc")
+    B = 4096
+    opt = make(batch=B, horizon=50)
+    cases.mpc(opt, seed=0, min_rel=0.0)
+    rng = np.random.default_rng(1)
+    x0 = np.zeros((B, 7))
+    x0[:, 1] = rng.uniform(-1, 1, B)
+    x0[:, 2] = rng.uniform(-0.2, 0.2, B)
+    x0[:, 4] = rng.uniform(4, 10, B)
+    opt.x[:, 0] = x0
+    opt.max_iterations = 8
+    opt.update()
+    assert opt.info()["form"] == "split", opt.info()
+    assert np.all(opt.iterations == 8) and np.all(np.isfinite(opt.traj_costs))
+    for b in range(0, B, 256):
+        ref = OI.OracleOptim("trajectory_tracking_mpc")
+        cases.mpc(ref, seed=0, min_rel=0.0)
+        ref.max_iterations = 8
+        ref.x[0] = x0[b]
+        ref.update()
+        assert cases.scaled_err(opt.x[b], ref.x) < 1e-6, b
+        assert cases.scaled_err(opt.u[b], ref.u) < 1e-6, b
+        assert abs(opt.traj_costs[b] - ref.traj_costs) < 1e-8 * abs(ref.traj_costs), b

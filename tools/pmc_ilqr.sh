@@ -1,9 +1,12 @@
 #!/bin/bash
 # PMC passes for the batched iLQR kernel (SURVEY 8d asks for fp64 VALU-busy and MFMA-busy next to iterations/s).
-# usage (GPU box, repo root): bash tools/pmc_ilqr.sh <outdir> [mpc|lateral]
+# usage (GPU box, repo root): bash tools/pmc_ilqr.sh <outdir> [mpc|lateral] [batch] [kernel substring]
+# (TPLHIP_DEBUG=ilqr_split=1 in the environment selects the split-launch form)
 set -u
 OUT=${1:-gpurun_out/pmc_ilqr}
 WL=${2:-mpc}
+BATCH=${3:-1024}
+KERNEL=${4:-k_ilqr_update}
 REPO=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -14,7 +17,7 @@ for C in \
   "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" \
   ; do
   i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d "$REPO/$OUT/pass$i" -- python3 "$REPO/tools/ilqr_only.py" "$WL" > "$REPO/$OUT/pass$i.log" 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $C --output-format csv -d "$REPO/$OUT/pass$i" -- python3 "$REPO/tools/ilqr_only.py" "$WL" "$BATCH" > "$REPO/$OUT/pass$i.log" 2>&1 || echo "pass $i failed"
 done
 cd "$REPO"
-python3 tools/pmc_summary.py "$OUT" k_ilqr_update
+python3 tools/pmc_summary.py "$OUT" "$KERNEL" all

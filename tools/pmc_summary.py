@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Average every PMC counter over the dispatches of kernels whose name contains
-<substr>.  usage: python3 tools/pmc_summary.py <dir with pass*/> <substr>"""
+<substr>.  usage: python3 tools/pmc_summary.py <dir with pass*/> <substr> [all]
+("all": keep kernels instantiated with a leading `true` template argument, which the DP summaries skip)"""
 import csv
 import glob
 import os
@@ -13,7 +14,7 @@ for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"),
     for r in csv.DictReader(open(f)):
         if sub not in r.get("Kernel_Name", ""):
             continue
-        if "<true" in r["Kernel_Name"]:          # skip the trivial terminal-stage variant
+        if "<true" in r["Kernel_Name"] and "all" not in sys.argv[3:]:          # skip the trivial terminal-stage variant
             continue
         a = acc[r["Counter_Name"]]
         a[0] += float(r["Counter_Value"])

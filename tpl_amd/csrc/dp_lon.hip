@@ -95,9 +95,11 @@ struct tplhip_dp_lon {
     // cheap division forms, only used when k_verify_div proved them exact (see k_backward)
     float rcp_path_step = 0.0f;
     float rcp_path_lo = 0.0f, rcp_range_hi = 0.0f, rcp_range_lo = 0.0f;   // two-float reciprocals (k_backward3v)
-    int path_div3 = 0, range_div3 = 0;        // k_backward3v's forms: 4 = one multiplication, 3 = two-float, 0 = not proven
-    int verified_path3 = 0, verified_range3 = 0;
+    int path_div3 = 0, range_div3 = 0;        // the plain-fp32 sweeps' forms (div_const in dp_sweep.hip): 4, 3, 5 proven, 0 = IEEE division
+    float path_aux = 0.0f, range_aux = 0.0f;  // second operand of the chosen form: the reciprocal's low part (3) or the divisor (5, 0)
+    int verified_path3 = 0, verified_range3 = 0;   // bit 0: form 3 proven, bit 1: form 4, bit 2: form 5
     bool weights_nonneg = false;              // every cost weight >= +0: (constraint, cost) compare as one integer key
+    bool no_s3 = false;                       // TPLHIP_DEBUG=no_s3: small grids on the general sweep
     float verified_c[2] = {0.0f, 0.0f};      // divisors and range the proof covers
     float verified_xmax = 0.0f;
     int verified_s_steps = 0;                 // the coordinate check of the range divisor depends on s_steps - 1
@@ -140,7 +142,7 @@ struct tplhip_dp_lon {
     bool no_v3 = false, no_fwd_overlap = false, no_fwd_spec = false, no_front = false;   // TPLHIP_DEBUG overrides, read by reinit
     bool front_fused = true;                 // what the last plan did (info)
     FilterRule rule = kDefaultRule;      // R2 / R3 of the arithmetic contract (tplhip_dp_lon_set_filter_rule)
-    bool rule_set = false;               // a non-default rule: only the general kernels implement it
+    bool rule_set = false;               // a non-default rule (the plain-fp32 sweeps then take the division forms (5, 5) or (0, 0))
     bool s3_first_early = false;         // k_backward3s requests its first round's rows ahead of its prologue (grids of >= 4 wavefronts per SIMD)
     int s3_kc = 0, s3_grid = 0;          // k_backward3s (grids that leave the chip mostly empty): actions per round (0 = not used), grid
     size_t s3_lds = 0;
@@ -250,11 +252,35 @@ int fwd_threads(const tplhip_dp_lon* h)
     return (!h->no_fwd_spec && sizeof(Node) * h->table_cells * (size_t)h->params.t_steps <= ((size_t)256 << 20)) ? 512 : 64;
 }
 
+// The form of the two divisions by run-time constants in the plain-fp32 sweeps, from what k_verify_div proved.  The
+// default filter rule is built with every pair of forms: the cheapest proven one per divisor.  The other rules are built
+// with (5, 5) and (0, 0) only.
+void pick_div_forms(tplhip_dp_lon* h)
+{
+    auto best = [](int mask) { return (mask & 2) ? 4 : ((mask & 1) ? 3 : ((mask & 4) ? 5 : 0)); };
+    int pd = best(h->verified_path3), rd = best(h->verified_range3);
+    int forced = 0;
+    if (debug_opt("div_form", &forced)) {              // tests: this form where it is proven, else IEEE division
+        auto only = [&](int mask) { return ((forced == 3 && (mask & 1)) || (forced == 4 && (mask & 2)) || (forced == 5 && (mask & 4))) ? forced : 0; };
+        pd = only(h->verified_path3);
+        rd = only(h->verified_range3);
+    }
+    if (h->rule_set) {
+        const bool newton = (h->verified_path3 & 4) && (h->verified_range3 & 4) && (!forced || forced == 5);
+        pd = rd = newton ? 5 : 0;
+    }
+    h->path_div3 = pd;
+    h->range_div3 = rd;
+    h->path_aux = pd == 3 ? h->rcp_path_lo : h->params.path_step_size;
+    h->range_aux = rd == 3 ? h->rcp_range_lo : (h->params.s_max - h->params.s_min);
+}
+
 // k_backward3v (dp_sweep.hip): the two-rows-per-lane geometry with the plain-fp32 instruction stream.  Needs buffer
-// loads, both divisions proven in one of its cheap forms and non-negative weights (integer-key argmin).
+// loads and non-negative weights (integer-key argmin).  Every filter rule and every divisor runs on it: a division
+// without a proven cheap form is an IEEE division (pick_div_forms).
 bool use_v3(const tplhip_dp_lon* h)
 {
-    return !h->no_v3 && !h->rule_set && h->use_buf && h->weights_nonneg && h->path_div3 >= 3 && h->range_div3 >= 3
+    return !h->no_v3 && h->use_buf && h->weights_nonneg
            && backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps) <= 64 * 1024;
 }
 
@@ -271,11 +297,11 @@ void launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
     a.pre_prog = h->d_pre_prog;
     a.p = h->params;
     a.s_pad = h->vp_s_pad;
-    a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->rcp_path_lo;
-    a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
+    a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->path_aux;
+    a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->range_aux;
     a.tile_v = h->tile_v; a.tile_a = h->tile_a;
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
-    launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
+    launch_backward3v(h->rule, h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
 }
 
 bool launch_backward3s_(tplhip_dp_lon* h, int idx_t, int nx)
@@ -291,21 +317,33 @@ bool launch_backward3s_(tplhip_dp_lon* h, int idx_t, int nx)
     a.pre_prog = h->d_pre_prog;
     a.p = h->params;
     a.s_pad = h->vp_s_pad;
-    a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->rcp_path_lo;
-    a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
+    a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->path_aux;
+    a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->range_aux;
     a.tile_v = h->tile_v; a.tile_a = h->tile_a;
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
-    return launch_backward3s(h->path_div3, h->range_div3, h->s3_kc, h->s3_first_early, a, dim3(h->s3_grid, 1), h->s3_lds, h->stream);
+    return launch_backward3s(h->rule, h->path_div3, h->range_div3, h->s3_kc, h->s3_first_early, a, dim3(h->s3_grid, 1), h->s3_lds, h->stream);
+}
+
+// Which sweep a plan of this handle takes: 1 = k_backward3v, 2 = k_backward3s, 0 = the general k_backward.  Grids that
+// fill the chip take the two-rows-per-lane form; grids that do not take one cell per lane where a row fits a
+// 256-lane workgroup, and the two-rows form otherwise (rows of 257 .. 1024 stations: 300 x 37 x 20 runs k_backward3v).
+int sweep_kind(const tplhip_dp_lon* h)
+{
+    const bool running_argmin_ok = h->params_bounded && h->path_bounded && h->env_bounded && use_v3(h);
+    if (!running_argmin_ok) return 0;
+    if (h->big) return h->v3_ok ? 1 : 0;
+    if (h->s3_kc) return 2;
+    return (h->v3_ok && !h->no_s3) ? 1 : 0;
 }
 
 void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
 {
-    const bool running_argmin_ok = h->params_bounded && h->path_bounded && h->env_bounded && use_v3(h);
+    const int kind = sweep_kind(h);
     if (terminal) {
         launch_backward<true, 1>(h, i, nx);                       // rule R4 (no division in it)
-    } else if (running_argmin_ok && h->big && h->v3_ok) {
+    } else if (kind == 1) {
         launch_backward3(h, i, nx);                                   // two rows per lane, plain-fp32 stream
-    } else if (running_argmin_ok && !h->big && h->s3_kc && launch_backward3s_(h, i, nx)) {
+    } else if (kind == 2 && launch_backward3s_(h, i, nx)) {
         // the plain-fp32 stream, one cell per lane
     } else if (h->kchunk == 3) {
         launch_backward<false, 3>(h, i, nx);                 // the general sweep: two-pass argmin, any input
@@ -846,7 +884,8 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     {
         h->s3_kc = 0;
         const int want = 3;
-        if (!h->big && h->vp_s_pad <= 256 && !debug_opt("no_s3")) {
+        h->no_s3 = debug_opt("no_s3");
+        if (!h->big && h->vp_s_pad <= 256 && !h->no_s3) {
             h->s3_lds = backward3s_lds_bytes(want, h->vp_s_pad, p.path_steps);
             int max_rows = 0;
             for (int x = 0; x < 8; ++x)
@@ -883,28 +922,27 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
             h->verified_path3 = h->verified_range3 = 0;
             h->verified_c[0] = h->verified_c[1] = 0.0f;
             if (!off && std::isfinite(xmax) && xmax > 0.0f && s_range > 0.0f && p.path_step_size > 0.0f) {
-                if (!h->d_flag) HIP_TRY(hipMalloc(&h->d_flag, 4 * sizeof(unsigned int)), "flag allocation failed");
-                HIP_TRY(hipMemsetAsync(h->d_flag, 0, 4 * sizeof(unsigned int), h->stream), "flag clear failed");
+                if (!h->d_flag) HIP_TRY(hipMalloc(&h->d_flag, 6 * sizeof(unsigned int)), "flag allocation failed");
+                HIP_TRY(hipMemsetAsync(h->d_flag, 0, 6 * sizeof(unsigned int), h->stream), "flag clear failed");
                 unsigned int max_bits;
                 std::memcpy(&max_bits, &xmax, sizeof max_bits);
                 hipLaunchKernelGGL(k_verify_div, dim3(4096), dim3(256), 0, h->stream, h->d_flag,
                                    p.path_step_size, h->rcp_path_step, h->rcp_path_lo, 0.0f, max_bits);
-                hipLaunchKernelGGL(k_verify_div, dim3(4096), dim3(256), 0, h->stream, h->d_flag + 2,
+                hipLaunchKernelGGL(k_verify_div, dim3(4096), dim3(256), 0, h->stream, h->d_flag + 3,
                                    s_range, h->rcp_range_hi, h->rcp_range_lo, (float)(p.s_steps - 1), max_bits);
                 HIP_TRY(hipGetLastError(), "division check launch failed");
-                unsigned int flags[4] = {1, 1, 1, 1};
+                unsigned int flags[6] = {1, 1, 1, 1, 1, 1};
                 HIP_TRY(hipMemcpyAsync(flags, h->d_flag, sizeof flags, hipMemcpyDeviceToHost, h->stream), "flag copy failed");
                 HIP_TRY(hipStreamSynchronize(h->stream), "division check failed");
-                h->verified_path3 = flags[1] == 0 ? 4 : (flags[0] == 0 ? 3 : 0);
-                h->verified_range3 = flags[3] == 0 ? 4 : (flags[2] == 0 ? 3 : 0);
+                h->verified_path3 = (flags[0] == 0 ? 1 : 0) | (flags[1] == 0 ? 2 : 0) | (flags[2] == 0 ? 4 : 0);
+                h->verified_range3 = (flags[3] == 0 ? 1 : 0) | (flags[4] == 0 ? 2 : 0) | (flags[5] == 0 ? 4 : 0);
                 h->verified_c[0] = p.path_step_size;
                 h->verified_c[1] = s_range;
                 h->verified_xmax = xmax;
                 h->verified_s_steps = p.s_steps;
             }
         }
-        h->path_div3 = h->verified_path3;
-        h->range_div3 = h->verified_range3;
+        pick_div_forms(h);
     }
     // a re-parameterisation of an existing planner (tpl changes dt_start every cycle) only rebuilds the action table:
     // the launch is ordered before every later kernel of the stream, nothing here is read by the host
@@ -1167,8 +1205,8 @@ int tplhip_dp_lon_copy_table(tplhip_dp_lon* h, int t, float* out)
 int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
 {
     if (!h || !buf || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
-    const bool running_ok = h->params_bounded && h->path_bounded && h->env_bounded && use_v3(h);
-    const char* sweep = (running_ok && h->big && h->v3_ok) ? "k_backward3v" : ((running_ok && !h->big && h->s3_kc) ? "k_backward3s" : "k_backward");
+    const int kind = sweep_kind(h);
+    const char* sweep = kind == 1 ? "k_backward3v" : (kind == 2 ? "k_backward3s" : "k_backward");
     std::snprintf(buf, (size_t)n,
                   "{\"sweep\": \"%s\", \"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
                   "\"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"big\": %d, "
@@ -1182,7 +1220,7 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
 }
 
 // R2 / R3 of the HP-1 arithmetic contract as a run-time choice (see FilterRule in dp_lon_math.h).  Rebuilds the action
-// table; every later plan uses the general kernels unless the default (1, 0) is set again.
+// table; the plain-fp32 sweeps are built for all nine rules (dp_sweep.hip), so the choice of kernel does not change.
 int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_form)
 {
     if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
@@ -1193,6 +1231,7 @@ int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_f
     if (rc) return rc;
     h->rule = FilterRule{weight_quant, lerp_form};
     h->rule_set = !(weight_quant == kDefaultRule.quant && lerp_form == kDefaultRule.lerp);
+    if (h->have_params) pick_div_forms(h);
     h->tables_valid = false;
     if (h->have_params && h->d_acts) {
         const int nrows = h->params.v_steps * h->params.a_steps;
@@ -1353,11 +1392,11 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
             SweepArgs a;
             a.next = next; a.out = out; a.acts = h->d_acts; a.path = paths; a.pre_vmax = pv; a.pre_sdist = ps;
             a.pre_prog = h->d_pre_prog; a.p = p; a.s_pad = h->vp_s_pad;
-            a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->rcp_path_lo;
-            a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->rcp_range_lo;
+            a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->path_aux;
+            a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->range_aux;
             a.tile_v = h->tile_v; a.tile_a = h->tile_a;
             a.stride_tables = tab_stride; a.stride_pre = pre_stride; a.stride_path = path_stride;
-            launch_backward3v(h->path_div3, h->range_div3, a, dim3(h->v3_grid, count),
+            launch_backward3v(h->rule, h->path_div3, h->range_div3, a, dim3(h->v3_grid, count),
                               backward3v_lds_bytes(h->vp_s_pad, p.path_steps), h->stream);
         } else {
             auto go = [&](auto kernel) {

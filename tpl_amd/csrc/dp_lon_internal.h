@@ -49,21 +49,23 @@ struct SweepArgs {
     const double* pre_prog;    // [s_steps]
     TplDpLonParams p;
     int s_pad;
-    float rcp_path_hi, rcp_path_lo;      // 1/path_step_size as a two-float number
+    float rcp_path_hi, rcp_path_lo;      // 1/path_step_size as a two-float number (division forms 5 and 0: _lo = the divisor)
     float rcp_range_hi, rcp_range_lo;    // 1/(s_max - s_min) likewise
     int tile_v, tile_a;
     // scenario batch (blockIdx.y): element strides between consecutive scenarios, 0 = shared
     size_t stride_tables, stride_pre, stride_path;
 };
 
-// dp_sweep.hip.  path_div / range_div: 3 = two-float reciprocal (2 plain fp32 instructions), 4 = power-of-two
-// divisor (one multiplication); both only after k_verify_div proved them equal to IEEE division on the whole range.
-// Returns false when the combination is not built.
-bool launch_backward3v(int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
+// dp_sweep.hip.  path_div / range_div: the form of the two divisions by run-time constants -- 4 = power-of-two divisor
+// (one multiplication), 3 = two-float reciprocal (two plain fp32 instructions), 5 = reciprocal and one Newton step on the
+// quotient (three), each only after k_verify_div proved it equal to IEEE division on the whole range; 0 = IEEE division.
+// For forms 5 and 0 rcp_*_lo carries the divisor itself.  rule: R2 / R3 (FilterRule); a rule other than the default
+// is built with the pairs (5, 5) and (0, 0) only.  Returns false when the combination is not built.
+bool launch_backward3v(FilterRule rule, int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
 size_t backward3v_lds_bytes(int s_pad, int path_steps);
 // k_backward3s: the same instruction stream, one cell per lane and kc (= 3) actions per barrier round, for grids
 // that leave the chip mostly empty (s_pad <= 256; grid = 8 * rows of the widest XCD share, as k_backward's)
 size_t backward3s_lds_bytes(int kc, int s_pad, int path_steps);
-bool launch_backward3s(int path_div, int range_div, int kc, bool first_early, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
+bool launch_backward3s(FilterRule rule, int path_div, int range_div, int kc, bool first_early, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
 
 } // namespace tplhip

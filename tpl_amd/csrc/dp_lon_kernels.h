@@ -327,23 +327,27 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
 __global__ void k_verify_div(unsigned int* __restrict__ flags, float c, float r, float r_lo, float scale, unsigned int max_bits)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    bool bad_2 = false, bad_p = false;
+    bool bad_2 = false, bad_p = false, bad_n = false;
     for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= max_bits; b += stride) {
         const float x = __uint_as_float((unsigned int)b);
         const float qf = x / c;
         const float q2 = fmaf(x, r, x * r_lo);                       // two-float reciprocal r + r_lo
         const float qp = x * r;                                      // exact for a power-of-two divisor
+        const float qn = fmaf(fmaf(-qp, c, x), r, qp);               // one Newton step on the quotient: residual, correction
         if (scale > 0.0f) {
             const unsigned int want = __float_as_uint((qf * scale + 0.5f) - 0.5f);
             bad_2 |= (want != __float_as_uint((q2 * scale + 0.5f) - 0.5f));
             bad_p |= (want != __float_as_uint((qp * scale + 0.5f) - 0.5f));
+            bad_n |= (want != __float_as_uint((qn * scale + 0.5f) - 0.5f));
         } else {
             bad_2 |= (__float_as_uint(qf) != __float_as_uint(q2));
             bad_p |= (__float_as_uint(qf) != __float_as_uint(qp));
+            bad_n |= (__float_as_uint(qf) != __float_as_uint(qn));
         }
     }
     if (bad_2) atomicOr(&flags[0], 1u);      // two-float reciprocal is not exact here
     if (bad_p) atomicOr(&flags[1], 1u);      // a bare multiplication by the reciprocal is not exact here
+    if (bad_n) atomicOr(&flags[2], 1u);      // reciprocal + one Newton step is not exact here
 }
 
 // ------------------------------------------------------------------------

@@ -64,23 +64,51 @@ __device__ __forceinline__ float in_vgpr(float x)
     return x;
 }
 
-// x / c for a run-time constant c, in the form the host proved exact for this c (see k_verify_div)
+// x / c for a run-time constant c, in the cheapest form the host proved exact for this c (see k_verify_div):
+//   4  c is a power of two: one multiplication by 1/c
+//   3  two-float reciprocal r_hi + r_lo: fma(x, r_hi, x * r_lo)                             (two plain instructions)
+//   5  one Newton step on the quotient: q = x r; e = fma(-q, c, x); q' = fma(e, r, q)      (three; aux carries c)
+//   0  IEEE division (aux carries c): every divisor, ~10 instructions -- what keeps a grid whose divisors defeat all
+//      three proofs on the plain-fp32 sweeps instead of sending it to the general kernel
 template <int MODE>
-__device__ __forceinline__ float div_const(float x, float r_hi, float r_lo)
+__device__ __forceinline__ float div_const(float x, float r_hi, float aux)
 {
-    if (MODE == 4) return x * r_hi;              // c is a power of two
-    return fmaf(x, r_hi, x * r_lo);              // two-float reciprocal
+    if (MODE == 4) return x * r_hi;
+    if (MODE == 3) return fmaf(x, r_hi, x * aux);
+    if (MODE == 5) { const float q = x * r_hi; const float e = fmaf(-q, aux, x); return fmaf(e, r_hi, q); }
+    return x / aux;
 }
 
 struct Node3 { float c, g, j; };
 
-__device__ __forceinline__ Node3 lerp3(Node3 p, Node3 q, float w, float iw)      // rule R3
+// rule R3 (dp_lon_math.h, lerp1): 0 = fma(q, w, p (1 - w)), 1 = p (1 - w) + q w with every operation rounded, 2 = p + w (q - p)
+template <int LERP>
+__device__ __forceinline__ float blend1(float p, float q, float w, float iw)
+{
+    if (LERP == 1) { const float a = p * iw, b = q * w; return a + b; }
+    if (LERP == 2) { const float d = q - p; const float e = w * d; return p + e; }
+    return fmaf(q, w, p * iw);
+}
+
+template <int LERP>
+__device__ __forceinline__ Node3 lerp3(Node3 p, Node3 q, float w, float iw)
 {
     Node3 r;
-    r.c = fmaf(q.c, w, p.c * iw);
-    r.g = fmaf(q.g, w, p.g * iw);
-    r.j = fmaf(q.j, w, p.j * iw);
+    r.c = blend1<LERP>(p.c, q.c, w, iw);
+    r.g = blend1<LERP>(p.g, q.g, w, iw);
+    r.j = blend1<LERP>(p.j, q.j, w, iw);
     return r;
+}
+
+// rule R2 (quant_weight): the filter weight of the blend along s from the fraction fr in [0, 1)
+//   1  rint(fr * 256) / 256 as (fr + 2^15) - 2^15: the sum lands where floats are 2^-8 apart, so the addition itself
+//      rounds to nearest-even at 8 fractional bits;   2  floor(fr * 256) / 256;   0  not quantised
+template <int QUANT>
+__device__ __forceinline__ float s_weight(float fr)
+{
+    if (QUANT == 1) return (fr + 32768.0f) - 32768.0f;
+    if (QUANT == 2) return floorf(fr * 256.0f) * 0.00390625f;
+    return fr;
 }
 
 // ------------------------------------------------------------------------
@@ -92,7 +120,7 @@ __device__ __forceinline__ Node3 lerp3(Node3 p, Node3 q, float w, float iw)     
 // i.e. eight waves per SIMD, which beat the two-buffer / one-barrier / loads-in-flight-across-the-barrier form
 // (68-70 registers, seven waves) by 2 % -- 42.1 against 42.9 us per 256x128x64 sweep on the same box.
 // ------------------------------------------------------------------------
-template <int PATH_DIV, int RANGE_DIV>
+template <int PATH_DIV, int RANGE_DIV, int QUANT, int LERP>
 __global__ void __launch_bounds__(1024)
 k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, const ActDesc* __restrict__ acts,
               const float* __restrict__ path_all, const float* __restrict__ pre_vmax_all,
@@ -260,35 +288,35 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             if (!cur.single) {
                 Node3 r[NV];
                 issue(cur, A1_ROWS);
-                Node3 bl = lerp3(lo[0], lo[1], w[0].x, w[0].y);
+                Node3 bl = lerp3<LERP>(lo[0], lo[1], w[0].x, w[0].y);
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
-                    const Node3 bu = lerp3(up[i][0], up[i][1], w[i].x, w[i].y);
-                    r[i] = lerp3(bl, bu, w[i].z, w[i].w);
+                    const Node3 bu = lerp3<LERP>(up[i][0], up[i][1], w[i].x, w[i].y);
+                    r[i] = lerp3<LERP>(bl, bu, w[i].z, w[i].w);
                     if (i + 1 < NV) {
                         if ((shared_mask >> (i * N_BWD + k)) & 1u) {
                             bl = bu;
                         } else {
                             const ActDesc& y = d0[(i + 1) * rs + k];
                             const Node3 q00 = load_row(y.r00), q10 = load_row(y.r10);
-                            bl = lerp3(q00, q10, w[i + 1].x, w[i + 1].y);
+                            bl = lerp3<LERP>(q00, q10, w[i + 1].x, w[i + 1].y);
                         }
                     }
                 }
                 park(r);
             } else {
                 Node3 r[NV];
-                Node3 bl = lerp3(lo[0], lo[0], w[0].x, w[0].y);
+                Node3 bl = lerp3<LERP>(lo[0], lo[0], w[0].x, w[0].y);
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
-                    const Node3 bu = lerp3(up[i][0], up[i][0], w[i].x, w[i].y);
-                    r[i] = lerp3(bl, bu, w[i].z, w[i].w);
+                    const Node3 bu = lerp3<LERP>(up[i][0], up[i][0], w[i].x, w[i].y);
+                    r[i] = lerp3<LERP>(bl, bu, w[i].z, w[i].w);
                     if (i + 1 < NV) {
                         if ((shared_mask >> (i * N_BWD + k)) & 1u) {
                             bl = bu;
                         } else {
                             const Node3 q00 = load_row(d0[(i + 1) * rs + k].r00);
-                            bl = lerp3(q00, q00, w[i + 1].x, w[i + 1].y);
+                            bl = lerp3<LERP>(q00, q00, w[i + 1].x, w[i + 1].y);
                         }
                     }
                 }
@@ -318,15 +346,15 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const float xb = cs - 0.5f;
             const float fl = floorf(xb);
             const float fr = xb - fl;
-            const float ws = (fr + 32768.0f) - 32768.0f;
+            const float ws = s_weight<QUANT>(fr);
             const float iws = 1.0f - ws;
             const int off = (int)(fminf(fl, s_scale) * 16.0f);
             const v4f nl = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off);
             const v4f nh = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off + 16);
             asm volatile("" :: "v"(nl.w), "v"(nh.w));
-            const float nc = fmaf(nh.x, ws, nl.x * iws);
-            const float ng = fmaf(nh.y, ws, nl.y * iws);
-            const float nj = fmaf(nh.z, ws, nl.z * iws);
+            const float nc = blend1<LERP>(nl.x, nh.x, ws, iws);
+            const float ng = blend1<LERP>(nl.y, nh.y, ws, iws);
+            const float nj = blend1<LERP>(nl.z, nh.z, ws, iws);
             // The first rows of the NEXT action go out here, in the first cell of this one: their registers are free (the
             // blends of phase 1 consumed them), the scalar row ids requested at the top of the phase have arrived with
             // the LDS reads just consumed (one counter), and their latency passes under the rest of the phase.
@@ -376,7 +404,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 // the same order and the same integer-key argmin as k_backward3v -- k_backward's work at ~2.5 instead of ~4.5 cycles
 // per instruction.
 // ------------------------------------------------------------------------
-template <int PATH_DIV, int RANGE_DIV, int KC, bool FIRST_EARLY>
+template <int PATH_DIV, int RANGE_DIV, int QUANT, int LERP, int KC, bool FIRST_EARLY>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, const ActDesc* __restrict__ acts,
               const float* __restrict__ path_all, const float* __restrict__ pre_vmax_all,
@@ -505,9 +533,9 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         for (int kk = 0; kk < KC; ++kk) {
             const v4f w = dsc4[(k0 + kk) * 2];
             const bool single = !FIRST_EARLY && (d0[k0 + kk].flags & ACT_SINGLE_A);
-            const Node3 b0 = single ? lerp3(r00[kk], r00[kk], w.x, w.y) : lerp3(r00[kk], r10[kk], w.x, w.y);
-            const Node3 b1 = single ? lerp3(r01[kk], r01[kk], w.x, w.y) : lerp3(r01[kk], r11[kk], w.x, w.y);
-            const Node3 r = lerp3(b0, b1, w.z, w.w);
+            const Node3 b0 = single ? lerp3<LERP>(r00[kk], r00[kk], w.x, w.y) : lerp3<LERP>(r00[kk], r10[kk], w.x, w.y);
+            const Node3 b1 = single ? lerp3<LERP>(r01[kk], r01[kk], w.x, w.y) : lerp3<LERP>(r01[kk], r11[kk], w.x, w.y);
+            const Node3 r = lerp3<LERP>(b0, b1, w.z, w.w);
             v4f* Rk = R + kk * row_slots;
             *reinterpret_cast<v3f*>(Rk + is) = (v3f){r.c, r.g, r.j};
             if (dup_last) *reinterpret_cast<v3f*>(Rk + S) = (v3f){r.c, r.g, r.j};
@@ -530,15 +558,15 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const float xb = cs - 0.5f;
             const float fl = floorf(xb);
             const float fr = xb - fl;
-            const float ws = (fr + 32768.0f) - 32768.0f;
+            const float ws = s_weight<QUANT>(fr);
             const float iws = 1.0f - ws;
             const int off = (int)(fminf(fl, s_scale) * 16.0f);
             const v4f nl = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off);
             const v4f nh = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off + 16);
             asm volatile("" :: "v"(nl.w), "v"(nh.w));
-            const float nc = fmaf(nh.x, ws, nl.x * iws);
-            const float ng = fmaf(nh.y, ws, nl.y * iws);
-            const float nj = fmaf(nh.z, ws, nl.z * iws);
+            const float nc = blend1<LERP>(nl.x, nh.x, ws, iws);
+            const float ng = blend1<LERP>(nl.y, nh.y, ws, iws);
+            const float nj = blend1<LERP>(nl.z, nh.z, ws, iws);
             const float alpha = div_const<PATH_DIV>(tn_s, rp_hi, rp_lo);
             const float f0 = fminf(floorf(alpha), path_top);
             const float pa = alpha - f0;
@@ -570,22 +598,142 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 
 } // namespace
 
-size_t backward3v_lds_bytes(int s_pad, int path_steps)
+// ---- launchers.  This file is compiled three times (Makefile): TPL_SWEEP_RULESET 0 = the default filter rule with every
+// pair of division forms, 1 and 2 = four of the eight other (R2, R3) rules each, with both divisions in the Newton form
+// (5, 5) or both as IEEE divisions (0, 0) -- a rule other than the default is only ever selected to follow a dump of the
+// reference build, and then runs on the same plain-fp32 sweeps as the default.
+#ifndef TPL_SWEEP_RULESET
+#define TPL_SWEEP_RULESET 0
+#endif
+
+namespace {
+
+template <int QUANT, int LERP, class Go>
+bool pick_div_v(int path_div, int range_div, bool all_forms, Go go)
 {
-    return (size_t)2 * (s_pad + 1) * 16 + (size_t)2 * N_BWD * 8 * sizeof(float) + sizeof(float) * ((size_t)path_steps + 1);
+    if (path_div == 5 && range_div == 5) return go(k_backward3v<5, 5, QUANT, LERP>);
+    if (path_div == 0 && range_div == 0) return go(k_backward3v<0, 0, QUANT, LERP>);
+    if constexpr (QUANT == 1 && LERP == 0) {
+        if (all_forms) {
+            if (path_div == 4 && range_div == 3) return go(k_backward3v<4, 3, QUANT, LERP>);
+            if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3, QUANT, LERP>);
+            if (path_div == 4 && range_div == 4) return go(k_backward3v<4, 4, QUANT, LERP>);
+            if (path_div == 3 && range_div == 4) return go(k_backward3v<3, 4, QUANT, LERP>);
+            if (path_div == 4 && range_div == 5) return go(k_backward3v<4, 5, QUANT, LERP>);
+            if (path_div == 3 && range_div == 5) return go(k_backward3v<3, 5, QUANT, LERP>);
+            if (path_div == 5 && range_div == 3) return go(k_backward3v<5, 3, QUANT, LERP>);
+            if (path_div == 5 && range_div == 4) return go(k_backward3v<5, 4, QUANT, LERP>);
+            if (path_div == 4 && range_div == 0) return go(k_backward3v<4, 0, QUANT, LERP>);
+            if (path_div == 3 && range_div == 0) return go(k_backward3v<3, 0, QUANT, LERP>);
+            if (path_div == 5 && range_div == 0) return go(k_backward3v<5, 0, QUANT, LERP>);
+            if (path_div == 0 && range_div == 3) return go(k_backward3v<0, 3, QUANT, LERP>);
+            if (path_div == 0 && range_div == 4) return go(k_backward3v<0, 4, QUANT, LERP>);
+            if (path_div == 0 && range_div == 5) return go(k_backward3v<0, 5, QUANT, LERP>);
+        }
+    }
+    return false;
 }
 
-bool launch_backward3v(int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
+template <int QUANT, int LERP, bool FE, class Go>
+bool pick_div_s(int path_div, int range_div, bool all_forms, Go go)
+{
+    if (path_div == 5 && range_div == 5) return go(k_backward3s<5, 5, QUANT, LERP, 3, FE>);
+    if (path_div == 0 && range_div == 0) return go(k_backward3s<0, 0, QUANT, LERP, 3, FE>);
+    if constexpr (QUANT == 1 && LERP == 0) {
+        if (all_forms) {
+            if (path_div == 4 && range_div == 3) return go(k_backward3s<4, 3, QUANT, LERP, 3, FE>);
+            if (path_div == 3 && range_div == 3) return go(k_backward3s<3, 3, QUANT, LERP, 3, FE>);
+            if (path_div == 4 && range_div == 4) return go(k_backward3s<4, 4, QUANT, LERP, 3, FE>);
+            if (path_div == 3 && range_div == 4) return go(k_backward3s<3, 4, QUANT, LERP, 3, FE>);
+            if (path_div == 4 && range_div == 5) return go(k_backward3s<4, 5, QUANT, LERP, 3, FE>);
+            if (path_div == 3 && range_div == 5) return go(k_backward3s<3, 5, QUANT, LERP, 3, FE>);
+            if (path_div == 5 && range_div == 3) return go(k_backward3s<5, 3, QUANT, LERP, 3, FE>);
+            if (path_div == 5 && range_div == 4) return go(k_backward3s<5, 4, QUANT, LERP, 3, FE>);
+            if (path_div == 4 && range_div == 0) return go(k_backward3s<4, 0, QUANT, LERP, 3, FE>);
+            if (path_div == 3 && range_div == 0) return go(k_backward3s<3, 0, QUANT, LERP, 3, FE>);
+            if (path_div == 5 && range_div == 0) return go(k_backward3s<5, 0, QUANT, LERP, 3, FE>);
+            if (path_div == 0 && range_div == 3) return go(k_backward3s<0, 3, QUANT, LERP, 3, FE>);
+            if (path_div == 0 && range_div == 4) return go(k_backward3s<0, 4, QUANT, LERP, 3, FE>);
+            if (path_div == 0 && range_div == 5) return go(k_backward3s<0, 5, QUANT, LERP, 3, FE>);
+        }
+    }
+    return false;
+}
+
+template <int QUANT, int LERP>
+bool launch_v_rule(int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, grid, dim3(a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
         return true;
     };
-    if (path_div == 4 && range_div == 3) return go(k_backward3v<4, 3>);
-    if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3>);
-    if (path_div == 4 && range_div == 4) return go(k_backward3v<4, 4>);
-    if (path_div == 3 && range_div == 4) return go(k_backward3v<3, 4>);
+    return pick_div_v<QUANT, LERP>(path_div, range_div, true, go);
+}
+
+template <int QUANT, int LERP>
+bool launch_s_rule(int path_div, int range_div, bool first_early, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
+{
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, dim3(a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
+        return true;
+    };
+    return first_early ? pick_div_s<QUANT, LERP, true>(path_div, range_div, true, go)
+                       : pick_div_s<QUANT, LERP, false>(path_div, range_div, true, go);
+}
+
+} // namespace
+
+#if TPL_SWEEP_RULESET == 1
+bool launch_backward3v_rules_a(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st)
+{
+    if (r.quant == 1 && r.lerp == 1) return launch_v_rule<1, 1>(pd, rd, a, grid, lds, st);
+    if (r.quant == 1 && r.lerp == 2) return launch_v_rule<1, 2>(pd, rd, a, grid, lds, st);
+    if (r.quant == 2 && r.lerp == 0) return launch_v_rule<2, 0>(pd, rd, a, grid, lds, st);
+    if (r.quant == 2 && r.lerp == 1) return launch_v_rule<2, 1>(pd, rd, a, grid, lds, st);
     return false;
+}
+bool launch_backward3s_rules_a(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st)
+{
+    if (r.quant == 1 && r.lerp == 1) return launch_s_rule<1, 1>(pd, rd, fe, a, grid, lds, st);
+    if (r.quant == 1 && r.lerp == 2) return launch_s_rule<1, 2>(pd, rd, fe, a, grid, lds, st);
+    if (r.quant == 2 && r.lerp == 0) return launch_s_rule<2, 0>(pd, rd, fe, a, grid, lds, st);
+    if (r.quant == 2 && r.lerp == 1) return launch_s_rule<2, 1>(pd, rd, fe, a, grid, lds, st);
+    return false;
+}
+#elif TPL_SWEEP_RULESET == 2
+bool launch_backward3v_rules_b(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st)
+{
+    if (r.quant == 2 && r.lerp == 2) return launch_v_rule<2, 2>(pd, rd, a, grid, lds, st);
+    if (r.quant == 0 && r.lerp == 0) return launch_v_rule<0, 0>(pd, rd, a, grid, lds, st);
+    if (r.quant == 0 && r.lerp == 1) return launch_v_rule<0, 1>(pd, rd, a, grid, lds, st);
+    if (r.quant == 0 && r.lerp == 2) return launch_v_rule<0, 2>(pd, rd, a, grid, lds, st);
+    return false;
+}
+bool launch_backward3s_rules_b(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st)
+{
+    if (r.quant == 2 && r.lerp == 2) return launch_s_rule<2, 2>(pd, rd, fe, a, grid, lds, st);
+    if (r.quant == 0 && r.lerp == 0) return launch_s_rule<0, 0>(pd, rd, fe, a, grid, lds, st);
+    if (r.quant == 0 && r.lerp == 1) return launch_s_rule<0, 1>(pd, rd, fe, a, grid, lds, st);
+    if (r.quant == 0 && r.lerp == 2) return launch_s_rule<0, 2>(pd, rd, fe, a, grid, lds, st);
+    return false;
+}
+#else
+bool launch_backward3v_rules_a(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
+bool launch_backward3v_rules_b(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
+bool launch_backward3s_rules_a(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
+bool launch_backward3s_rules_b(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
+
+size_t backward3v_lds_bytes(int s_pad, int path_steps)
+{
+    return (size_t)2 * (s_pad + 1) * 16 + (size_t)2 * N_BWD * 8 * sizeof(float) + sizeof(float) * ((size_t)path_steps + 1);
+}
+
+bool launch_backward3v(FilterRule rule, int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
+{
+    if (rule.quant == kDefaultRule.quant && rule.lerp == kDefaultRule.lerp)
+        return launch_v_rule<1, 0>(path_div, range_div, a, grid, lds_bytes, stream);
+    return launch_backward3v_rules_a(rule, path_div, range_div, a, grid, lds_bytes, stream)
+           || launch_backward3v_rules_b(rule, path_div, range_div, a, grid, lds_bytes, stream);
 }
 
 size_t backward3s_lds_bytes(int kc, int s_pad, int path_steps)
@@ -595,26 +743,14 @@ size_t backward3s_lds_bytes(int kc, int s_pad, int path_steps)
 
 // one row per workgroup of a.s_pad <= 256 lanes, grid = 8 * (rows of the widest XCD share); kc = 3 (all nine actions per round
 // was built too: 128 registers with spills, 0.22 against 0.16 ms per default-grid plan)
-bool launch_backward3s(int path_div, int range_div, int kc, bool first_early, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
+bool launch_backward3s(FilterRule rule, int path_div, int range_div, int kc, bool first_early, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
-    if (a.s_pad > 256 || lds_bytes > 64 * 1024) return false;
-    auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, dim3(a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
-        return true;
-    };
-    if (kc == 3 && first_early) {
-        if (path_div == 4 && range_div == 3) return go(k_backward3s<4, 3, 3, true>);
-        if (path_div == 3 && range_div == 3) return go(k_backward3s<3, 3, 3, true>);
-        if (path_div == 4 && range_div == 4) return go(k_backward3s<4, 4, 3, true>);
-        if (path_div == 3 && range_div == 4) return go(k_backward3s<3, 4, 3, true>);
-    }
-    if (kc == 3) {
-        if (path_div == 4 && range_div == 3) return go(k_backward3s<4, 3, 3, false>);
-        if (path_div == 3 && range_div == 3) return go(k_backward3s<3, 3, 3, false>);
-        if (path_div == 4 && range_div == 4) return go(k_backward3s<4, 4, 3, false>);
-        if (path_div == 3 && range_div == 4) return go(k_backward3s<3, 4, 3, false>);
-    }
-    return false;
+    if (a.s_pad > 256 || lds_bytes > 64 * 1024 || kc != 3) return false;
+    if (rule.quant == kDefaultRule.quant && rule.lerp == kDefaultRule.lerp)
+        return launch_s_rule<1, 0>(path_div, range_div, first_early, a, grid, lds_bytes, stream);
+    return launch_backward3s_rules_a(rule, path_div, range_div, first_early, a, grid, lds_bytes, stream)
+           || launch_backward3s_rules_b(rule, path_div, range_div, first_early, a, grid, lds_bytes, stream);
 }
+#endif
 
 } // namespace tplhip

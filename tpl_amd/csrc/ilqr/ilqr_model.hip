@@ -99,6 +99,7 @@ struct DevState {
     double* cand_c;                    // [batch][N_ALPHA][rows]       stage costs of the candidates
     int rows;                          // t_cap + 1
     long long* stamps;                 // diagnostic builds only
+    int* run;                          // [batch] split-launch form: 1 = the problem left its iteration loop in this round
     // LDS residency (decided by the host per launch, see plan_lds):
     int lds_traj;                      // 1: x, u, k, K, uMax, uMin of the problem are mirrored in LDS
     int n_lds_arrays;                  // array parameters copied into LDS
@@ -228,22 +229,30 @@ __device__ __forceinline__ double dot_lds(PA a, int sa, PB b, int sb)
 
 constexpr int ROLL_RING = 8;
 
-// LDS working set of one problem
+// LDS working set of one problem.  The Riccati pass and the line search never run at the same time (the terminal value
+// function is written after the last read of the cost block, the ring is first written after the last gain is stored):
+// their blocks share storage, which is what lets a problem's trajectory mirrors fit next to it when two workgroups
+// per SIMD are resident (k_split_chain: 20 KB per workgroup).
 struct Lds {
-    double Vxx[NX * NX];
-    double Vx[NX];
-    double F[NX * NXU];        // [fx | fu], row-major over the NXU columns
-    double W[NX * (NXU + 1)];  // Vxx [fx fu], and Vx as one more column (second-order pass)
-    double q[NXU];             // [Qx ; Qu]
-    double Qxx[NX * NX];
-    double Qux[NU * NX];
-    double Quu[NU * NU];
-    double red[N_ALPHA];
+    union {
+        struct {               // backward pass
+            double Vxx[NX * NX];
+            double Vx[NX];
+            double F[NX * NXU];        // [fx | fu], row-major over the NXU columns
+            double W[NX * (NXU + 1)];  // Vxx [fx fu], and Vx as one more column (second-order pass)
+            double q[NXU];             // [Qx ; Qu]
+            double Qxx[NX * NX];
+            double Qux[NU * NX];
+            double Quu[NU * NU];
+        };
+        struct {               // line search
+            // rollouts: RING stages of every candidate's (x_{t+1}, u_t) collect here and go out to the candidate
+            // arrays in one coalesced sweep of all 64 lanes (see line_search_rollouts); then the stage costs
+            double ring_x[N_ALPHA * ROLL_RING * NX];
+            double ring_u[N_ALPHA * ROLL_RING * NU];
+        };
+    };
     double dump[2];            // where lanes without an entry park what they loaded
-    // line-search rollouts: RING stages of every candidate's (x_{t+1}, u_t) collect here and go out
-    // to the candidate arrays in one coalesced sweep of all 64 lanes (see line_search_rollouts)
-    double ring_x[N_ALPHA * ROLL_RING * NX];
-    double ring_u[N_ALPHA * ROLL_RING * NU];
 };
 
 // ---- backward Riccati pass, optim.c:926-985, as a function of its own (NOT inlined) -- same reason as
@@ -285,7 +294,7 @@ __device__ __forceinline__ double uni_d(double d)
     return __longlong_as_double((long long)uni_u64((unsigned long long)__double_as_longlong(d)));
 }
 
-__device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, LdsAS* s)
+__device__ __forceinline__ void riccati_backward_impl(const RiccatiArgs& A, LdsAS* s)
 {
     const int lane = (int)threadIdx.x;
     const GlbCD FX = uni_g(A.FX), LXX = uni_g(A.LXX), FU = uni_g(A.FU), LUX = uni_g(A.LUX), LX = uni_g(A.LX),
@@ -556,6 +565,9 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
 #endif
 }
 
+// the call boundary k_ilqr_update needs (see above); k_split_chain, which holds nothing else, takes the body inline
+__device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, LdsAS* s) { riccati_backward_impl(A, s); }
+
 // ---- the same pass for problems with two or three states and one input (tpl's lateral and speed profile problems: what
 // its default planner solves, one problem per call, twice per cycle).  With matrices this small the lane-parallel form
 // above is all exchange and no work: three LDS round trips per stage for a dozen multiplications.  Here every lane
@@ -774,7 +786,7 @@ struct RolloutArgs {
 };
 
 template <bool LT, bool SECOND_ORDER, int INT_TYPE>
-__device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs A, LdsAS* s)
+__device__ __forceinline__ void line_search_rollouts_impl(const RolloutArgs& A, LdsAS* s)
 {
     // Candidate c runs on the QUAD of lanes 4c .. 4c+3: all four hold the same state and
     // control, the model's dynamics spread their independent look-ups and sin/cos evaluations
@@ -918,6 +930,12 @@ __device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs
 #ifdef TPL_ILQR_STAMP
     if (lane == 0 && A.stamp_acc) { A.stamp_acc[14] += racc[0]; A.stamp_acc[15] += racc[1]; A.stamp_acc[4] += racc[2]; }
 #endif
+}
+
+template <bool LT, bool SECOND_ORDER, int INT_TYPE>
+__device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs A, LdsAS* s)
+{
+    line_search_rollouts_impl<LT, SECOND_ORDER, INT_TYPE>(A, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -1396,6 +1414,533 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
 }
 
 // ---------------------------------------------------------------------------
+// The same update() as a SEQUENCE OF LAUNCHES, for batches that fill the chip more than once.
+//
+// k_ilqr_update keeps the whole solve in one launch, which is what a latency caller wants -- but a
+// wavefront's register allocation is fixed at launch to the maximum over the kernel's call graph, and
+// the derivative refresh (hundreds of live temporaries) drives that to 484 registers + scratch: ONE
+// wavefront per SIMD, every dependent fp64 chain of the Riccati pass and of the rollouts exposed in
+// full.  Splitting the iteration by register class gives the chains a kernel of their own:
+//
+//   k_split_begin    initial rollout and cost (first round only) + multiplier update   optim.c:1101-1132
+//   k_split_refresh  derivative refresh, lane = stage, any register count            optim.c:896-911
+//   k_split_chain    terminal value function, Riccati pass, the eight rollouts, their stage costs,
+//                    accept-first, mu schedule, termination test                     optim.c:914-1006
+//                    -- no derivative routine in its call graph: it is built for >= 2 resident
+//                    wavefronts per SIMD (TPL_ILQR_CHAIN_WAVES), which hide each other's chains
+//   k_split_end      terminationCondition = 1 when the iteration budget was used up  optim.c:1147-1149
+//
+// The state that the single launch carries in registers between iterations (J, mu, muStep, alpha, the
+// flags, the iteration counter) lives in the problem's scalar record between launches; a problem that
+// left its iteration loop (min_rel_cost_change) is marked in `run` and its later launches return at
+// once.  Same routines, same operation order: both forms produce the same bits
+// (tests/test_ilqr_gpu.py::test_split_launch_matches_single_launch).
+// ---------------------------------------------------------------------------
+#ifndef TPL_ILQR_CHAIN_WAVES
+#define TPL_ILQR_CHAIN_WAVES 2
+#endif
+#ifndef TPL_ILQR_CHAIN_INLINE    /* 1: the Riccati pass and the rollouts inlined into k_split_chain (its register budget then binds them) */
+#define TPL_ILQR_CHAIN_INLINE 1
+#endif
+constexpr bool CHAIN_INLINE = TPL_ILQR_CHAIN_INLINE != 0;
+constexpr int LDS_HEAD = (int)((sizeof(Lds) + 15) / 16 * 2);      // doubles the Lds block takes at the head of the dynamic LDS
+
+struct SplitProb {
+    double* sc;
+    int T, opt_start, max_iter, max_lg, int_type;
+    bool second_order;
+    double dt;
+};
+
+__device__ __forceinline__ SplitProb split_prob(const DevState& st, int b)
+{
+    SplitProb p;
+    p.sc = st.scalars + (int64_t)b * TPL_S_COUNT;
+    p.T = (int)p.sc[TPL_S_HORIZON];
+    p.opt_start = (int)p.sc[TPL_S_OPT_START];
+    p.max_iter = (int)p.sc[TPL_S_MAX_ITERATIONS];
+    p.max_lg = (int)p.sc[TPL_S_MAX_LG_ITERATIONS];
+    p.int_type = (int)p.sc[TPL_S_INTEGRATOR_TYPE];
+    p.second_order = p.sc[TPL_S_USE_QUADRATIC_TERMS] != 0.0;
+    p.dt = p.sc[TPL_S_DT];
+    return p;
+}
+
+// array parameters -> LDS (the host pointed Params::<array>.data there); false: wrong aperture guess
+__device__ __forceinline__ bool split_lds_arrays(const DevState& st, int b, double* dyn, double* sc)
+{
+    const int lane = threadIdx.x;
+    if (st.n_lds_arrays > 0 || st.lds_traj) {
+        if ((unsigned long long)(void*)dyn != st.lds_dyn_flat) {
+            if (lane == 0) sc[TPL_S_TERMINATION_CONDITION] = -99.0;
+            return false;
+        }
+        for (int a = 0; a < st.n_lds_arrays; ++a) {
+            const double* src = st.lds_src[a] + (int64_t)b * st.lds_src_stride[a];
+            double* dst = dyn + st.lds_off[a];
+            for (int e = lane; e < st.lds_len[a]; e += WAVE) dst[e] = src[e];
+        }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(WAVE) void k_split_begin(DevState st, int lg)
+{
+    extern __shared__ __attribute__((aligned(16))) double dynall[];
+    double* const dyn = dynall + LDS_HEAD;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const SplitProb pr = split_prob(st, b);
+    double* const sc = pr.sc;
+    if (lg > 0 && lg >= pr.max_lg) return;
+    Params P_regs;
+    load_params_uniform(P_regs, &st.params[b]);
+    const Params& P = P_regs;
+    const int T = pr.T, opt_start = pr.opt_start, int_type = pr.int_type;
+    const double dt = pr.dt;
+    double* X_ = fld(st, TPL_F_X, b);
+    double* U_ = fld(st, TPL_F_U, b);
+    double* IS = fld(st, TPL_F_INT_STEP, b);
+    double* LAM = fld(st, TPL_F_LAGRANGE_MULTIPLIER, b);
+    const double* BW = fld(st, TPL_F_BARRIER_WEIGHT, b);
+    const double* LGL = fld(st, TPL_F_LG_MULT_LIMIT, b);
+    if (!split_lds_arrays(st, b, dyn, sc)) return;
+    __syncthreads();
+
+    if (lg == 0) {
+        // ---- initial trajectory rollout and its cost, optim.c:1101-1111 (as in k_ilqr_update)
+        double J = 0.0;
+        double* CC = st.cand_c + (int64_t)b * N_ALPHA * st.rows;
+        if (lane < 4) {
+            double x[NX], u[NU], xn[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)opt_start * NX + i];
+            for (int t = opt_start; t < T; ++t) {
+#pragma unroll
+                for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
+                if (lane == 0) IS[t] = dt;
+                dynamics_quad(P, x, u, t, dt, int_type, xn);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    x[i] = xn[i];
+                    if (lane == 0) X_[(int64_t)(t + 1) * NX + i] = xn[i];
+                }
+            }
+            if (lane == 0) IS[T] = dt;
+        }
+        __syncthreads();
+        for (int t = opt_start + lane; t < T; t += WAVE) {
+            double x[NX], u[NU], c;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
+#pragma unroll
+            for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
+            costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
+            CC[t] = c;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            double x[NX], c;
+            int t = opt_start;
+            for (; t + 8 <= T; t += 8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = CC[t + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) J += v[q];
+            }
+            for (; t < T; ++t) J += CC[t];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)T * NX + i];
+            endCosts(P, x, (double)T, dt, &c, 1);
+            J += c;
+            sc[TPL_S_TRAJ_COSTS] = J;
+            sc[TPL_S_LG_ITERATIONS] = (double)(pr.max_lg > 0 ? pr.max_lg : 0);
+        }
+        __syncthreads();
+        if (pr.max_lg <= 0) return;
+    }
+    // ---- multiplier update, optim.c:1119-1132 (lane = stage), and the loop state of this round
+    if (NC > 0) {
+        for (int t = opt_start + lane; t < T; t += WAVE) {
+            double x[NX], u[NU], lam[NCM], g[NCM];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
+#pragma unroll
+            for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
+#pragma unroll
+            for (int c = 0; c < NCM; ++c) { lam[c] = LAM[(int64_t)t * NCM + c]; g[c] = 0.0; }
+            constraints(P, x, u, lam, BW, (double)t, IS[t], g, 1);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                double v = lam[c] + BW[c] * g[c];
+                v = v > 0.0 ? v : 0.0;
+                v = LGL[c] < v ? LGL[c] : v;
+                LAM[(int64_t)t * NCM + c] = v;
+            }
+        }
+    }
+    if (lane == 0) {
+        sc[TPL_S_TRAJECTORY_CHANGED] = 1.0;
+        sc[TPL_S_IMPROVED] = 0.0;
+        sc[TPL_S_ITERATIONS] = 0.0;
+        st.run[b] = 0;
+    }
+}
+
+// Derivative refresh: one wavefront per problem, lane = stage, as in k_ilqr_update.  (Measured and dropped,
+// profiles/r04_ilqr_split_ab.txt: the seven routines spread over three wavefronts per problem -- Jacobians / gradients
+// and small Hessians / state Hessian -- 3.8 -> 4.8 ms per update of 1 024 problems: a wavefront's fixed start-up, the
+// parameter record, the arrays' copy to LDS, the state loads, costs more than the routines it no longer runs; and the
+// kernel held to 256 registers for two wavefronts per SIMD: 218 registers in scratch, 10.9 -> 12.1 ms at 4 096.)
+__global__ __launch_bounds__(WAVE) void k_split_refresh(DevState st, int lg, int it)
+{
+    extern __shared__ __attribute__((aligned(16))) double dynall[];
+    double* const dyn = dynall + LDS_HEAD;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const SplitProb pr = split_prob(st, b);
+    if (lg >= pr.max_lg || it >= pr.max_iter || st.run[b] != 0) return;
+    if (pr.sc[TPL_S_TRAJECTORY_CHANGED] == 0.0) return;
+    const bool second_order = pr.second_order;
+    Params P_regs;
+    load_params_uniform(P_regs, &st.params[b]);
+    const Params& P = P_regs;
+    if (!split_lds_arrays(st, b, dyn, pr.sc)) return;
+    __syncthreads();
+    const int T = pr.T;
+    const double* X_ = fld(st, TPL_F_X, b);
+    const double* U_ = fld(st, TPL_F_U, b);
+    const double* IS = fld(st, TPL_F_INT_STEP, b);
+    const double* LAM = fld(st, TPL_F_LAGRANGE_MULTIPLIER, b);
+    const double* BW = fld(st, TPL_F_BARRIER_WEIGHT, b);
+    double* FX = fld(st, TPL_F_FX, b);
+    double* FU = fld(st, TPL_F_FU, b);
+    double* LX = fld(st, TPL_F_LX, b);
+    double* LU = fld(st, TPL_F_LU, b);
+    double* LXX = fld(st, TPL_F_LXX, b);
+    double* LUU = fld(st, TPL_F_LUU, b);
+    double* LUX = fld(st, TPL_F_LUX, b);
+    for (int t = lane; t < T; t += WAVE) {
+        double x[NX], u[NU], lam[NCM];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
+#pragma unroll
+        for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
+#pragma unroll
+        for (int c = 0; c < NCM; ++c) lam[c] = LAM[(int64_t)t * NCM + c];
+        const double ist = IS[t];
+        stateJacobian(P, x, u, (double)t, ist, FX + (int64_t)t * NX * NX, 1);
+        actionJacobian(P, x, u, (double)t, ist, FU + (int64_t)t * NX * NU, 1);
+        stateGradient(P, x, u, lam, BW, (double)t, ist, LX + (int64_t)t * NX, 1);
+        actionGradient(P, x, u, lam, BW, (double)t, ist, LU + (int64_t)t * NU, 1);
+        if (second_order) {
+            stateStateHessian(P, x, u, lam, BW, (double)t, ist, LXX + (int64_t)t * NX * NX, 1);
+            actionActionHessian(P, x, u, lam, BW, (double)t, ist, LUU + (int64_t)t * NU * NU, 1);
+            actionStateHessian(P, x, u, lam, BW, (double)t, ist, LUX + (int64_t)t * NU * NX, 1);
+        }
+    }
+}
+
+template <bool SECOND_ORDER, int INT_TYPE>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TPL_ILQR_CHAIN_WAVES, TPL_ILQR_CHAIN_WAVES)))
+void k_split_chain(DevState st, int lg, int it)
+{
+    extern __shared__ __attribute__((aligned(16))) double dynall[];
+    Lds& s = *reinterpret_cast<Lds*>(dynall);
+    double* const dyn = dynall + LDS_HEAD;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const SplitProb pr = split_prob(st, b);
+    double* const sc = pr.sc;
+    if (lg >= pr.max_lg || it >= pr.max_iter || st.run[b] != 0) return;
+    const Params* const P_mem = &st.params[b];
+    Params P_regs;
+    load_params_uniform(P_regs, P_mem);
+    const Params& P = P_regs;
+    const int T = pr.T, opt_start = pr.opt_start;
+    const double dt = pr.dt;
+    const double min_rel = sc[TPL_S_MIN_REL_COST_CHANGE];
+    double mu = sc[TPL_S_MU];
+    int mu_step = (int)sc[TPL_S_MU_STEP];
+    double alpha;
+    double J = sc[TPL_S_TRAJ_COSTS];
+    bool improved = sc[TPL_S_IMPROVED] != 0.0;
+    bool traj_changed = false;                         // k_split_refresh has just brought the derivatives up to date
+
+    double* X_ = fld(st, TPL_F_X, b);
+    double* U_ = fld(st, TPL_F_U, b);
+    double* IS = fld(st, TPL_F_INT_STEP, b);
+    double* NIS = fld(st, TPL_F_NEXT_INT_STEP, b);
+    double* NXT_X = fld(st, TPL_F_NEXT_X, b);
+    double* NXT_U = fld(st, TPL_F_NEXT_U, b);
+    double* PRV_X = fld(st, TPL_F_PREV_X, b);
+    double* PRV_K = fld(st, TPL_F_PREV_K, b);
+    double* FX = fld(st, TPL_F_FX, b);
+    double* FU = fld(st, TPL_F_FU, b);
+    double* LX = fld(st, TPL_F_LX, b);
+    double* LU = fld(st, TPL_F_LU, b);
+    double* LXX = fld(st, TPL_F_LXX, b);
+    double* LUU = fld(st, TPL_F_LUU, b);
+    double* LUX = fld(st, TPL_F_LUX, b);
+    double* G_ = fld(st, TPL_F_G, b);
+    double* KFF = fld(st, TPL_F_K_FF, b);
+    double* KFB = fld(st, TPL_F_K_FB, b);
+    double* LAM = fld(st, TPL_F_LAGRANGE_MULTIPLIER, b);
+    const double* BW = fld(st, TPL_F_BARRIER_WEIGHT, b);
+    const double* UMAX = fld(st, TPL_F_U_MAX, b);
+    const double* UMIN = fld(st, TPL_F_U_MIN, b);
+    double* CX = st.cand_x + (int64_t)b * N_ALPHA * st.rows * NX;
+    double* CU = st.cand_u + (int64_t)b * N_ALPHA * st.rows * NU;
+    double* CC = st.cand_c + (int64_t)b * N_ALPHA * st.rows;
+
+    if (!split_lds_arrays(st, b, dyn, sc)) return;
+    const int R = st.rows;
+    double* XL = dyn;
+    double* UL = XL + (int64_t)R * NX;
+    double* KL = UL + (int64_t)R * NU;
+    double* KBL = KL + (int64_t)R * NU;
+    double* UMXL = KBL + (int64_t)R * NU * NX;
+    double* UMNL = UMXL + (int64_t)R * NU;
+    const bool lt = st.lds_traj != 0;
+    const double* Xr = lt ? XL : X_;
+    const double* Ur = lt ? UL : U_;
+    const double* KFFr = lt ? KL : KFF;
+    const double* KFBr = lt ? KBL : KFB;
+    const double* UMAXr = lt ? UMXL : UMAX;
+    const double* UMINr = lt ? UMNL : UMIN;
+    if (lt) {                                          // the mirrors live for one launch: bring them in
+        for (int e = lane; e < T * NU; e += WAVE) { UMXL[e] = UMAX[e]; UMNL[e] = UMIN[e]; UL[e] = U_[e]; }
+        for (int e = lane; e < (T + 1) * NX; e += WAVE) XL[e] = X_[e];
+    }
+    // value function at the end of the horizon, optim.c:914-916
+    if (lane == 0) {
+        double x[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)T * NX + i];
+        endGradient(P, x, (double)T, IS[T], s.Vx, 1);
+        if (SECOND_ORDER) endHessian(P, x, (double)T, IS[T], s.Vxx, 1);
+    }
+    __syncthreads();
+
+    // The Lds block sits at the head of the dynamic LDS.  Its LDS offset goes through an opaque scalar: as a constant
+    // expression in the call arguments this hipcc mis-selects the address-space round trip of the dynamic-LDS symbol
+    // ("Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base").
+    unsigned sl_off = (unsigned)(unsigned long long)dynall;
+    asm volatile("" : "+s"(sl_off));
+    LdsAS* const sl = (LdsAS*)(unsigned long long)sl_off;
+    if constexpr (SECOND_ORDER) {
+        RiccatiArgs ra;
+        ra.FX = FX; ra.LXX = LXX; ra.FU = FU; ra.LUX = LUX; ra.LX = LX; ra.LU = LU; ra.LUU = LUU;
+        ra.U_ = U_; ra.UMAX = UMAX; ra.UMIN = UMIN; ra.KFF = KFF; ra.KFB = KFB; ra.KL = KL; ra.KBL = KBL;
+        ra.mu = mu; ra.T = T; ra.lt = lt ? 1 : 0;
+        ra.stamp_acc = nullptr;
+        if constexpr (SMALL_BACKWARD) riccati_backward_small(ra, sl);
+        else if constexpr (CHAIN_INLINE) riccati_backward_impl(ra, sl);
+        else riccati_backward(ra, sl);
+    } else {
+        // ---- first-order backward pass, optim.c:1044-1073
+        for (int t = T - 1; t >= 0; --t) {
+            double qx = 0.0, qu = 0.0;
+            if (lane < NX) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < NX; ++m) acc += FX[(int64_t)t * NX * NX + m * NX + lane] * s.Vx[m];
+                qx = LX[(int64_t)t * NX + lane] + acc;
+            }
+            if (lane < NU) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < NX; ++m) acc += FU[(int64_t)t * NX * NU + m * NU + lane] * s.Vx[m];
+                qu = LU[(int64_t)t * NU + lane] + acc;
+                G_[(int64_t)t * NU + lane] = qu;
+                double kk = qu;
+                const double c = U_[(int64_t)t * NU + lane] - qu;
+                if (c > UMAX[(int64_t)t * NU + lane]) kk = U_[(int64_t)t * NU + lane] - UMAX[(int64_t)t * NU + lane];
+                if (c < UMIN[(int64_t)t * NU + lane]) kk = U_[(int64_t)t * NU + lane] - UMIN[(int64_t)t * NU + lane];
+                KFF[(int64_t)t * NU + lane] = kk;
+                if (lt) KL[(int64_t)t * NU + lane] = kk;
+            }
+            __syncthreads();
+            if (lane < NX) s.Vx[lane] = qx;
+            __syncthreads();
+        }
+    }
+
+    // ---- line search, optim.c:859-873: all eight alphas at once, accept the first
+    const double J_prev = J;
+    double Jc = INFINITY;
+    {
+        RolloutArgs ra;
+        ra.CX = CX; ra.CU = CU; ra.X_ = X_; ra.KFFr = KFFr; ra.Ur = Ur; ra.UMAXr = UMAXr; ra.UMINr = UMINr;
+        ra.KFBr = KFBr; ra.Xr = Xr; ra.P = P_mem; ra.dt = dt; ra.rows = st.rows; ra.opt_start = opt_start;
+        ra.T = T; ra.int_type = INT_TYPE; ra.second_order = SECOND_ORDER;
+        ra.stamp_acc = nullptr;
+        if constexpr (CHAIN_INLINE) {
+            if (lt) line_search_rollouts_impl<true, SECOND_ORDER, INT_TYPE>(ra, sl);
+            else line_search_rollouts_impl<false, SECOND_ORDER, INT_TYPE>(ra, sl);
+        } else {
+            if (lt) line_search_rollouts<true, SECOND_ORDER, INT_TYPE>(ra, sl);
+            else line_search_rollouts<false, SECOND_ORDER, INT_TYPE>(ra, sl);
+        }
+    }
+    __syncthreads();
+    // stage costs of all candidates and stages, 64 at a time
+    const int cc_rows = T + 1;
+    const bool cc_lds = N_ALPHA * cc_rows <= N_ALPHA * ROLL_RING * NX;
+    {
+        const int n_t = T - opt_start;
+        for (int idx = lane; idx < N_ALPHA * n_t; idx += WAVE) {
+            const int cand = idx & (N_ALPHA - 1);
+            const int t = opt_start + (idx >> 3);
+            const double* cx = CX + ((int64_t)cand * st.rows + t) * NX;
+            const double* cu = CU + ((int64_t)cand * st.rows + t) * NU;
+            double x[NX], u[NU], c;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = cx[i];
+#pragma unroll
+            for (int d = 0; d < NU; ++d) u[d] = cu[d];
+            costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
+            if (cc_lds) s.ring_x[cand * cc_rows + t] = c;
+            else CC[(int64_t)cand * st.rows + t] = c;
+        }
+    }
+    __syncthreads();
+    // ordered sums, cost += c for t = optStart..T-1, then the end costs (:776-790)
+    if (lane < N_ALPHA) {
+        const double* cc = cc_lds ? &s.ring_x[lane * cc_rows] : CC + (int64_t)lane * st.rows;
+        double cost = 0.0, c;
+        int t = opt_start;
+        for (; t + 8 <= T; t += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = cc[t + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cost += v[q];
+        }
+        for (; t < T; ++t) cost += cc[t];
+        double x[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = CX[((int64_t)lane * st.rows + T) * NX + i];
+        endCosts(P, x, (double)T, dt, &c, 1);
+        cost += c;
+        Jc = cost;
+    }
+    // testImprovement, optim.c:840-857
+    const bool ok = lane < N_ALPHA && Jc < J && isfinite(Jc) && Jc >= 0.0;
+    const unsigned long long okm = __ballot(ok);
+    const bool accepted = okm != 0ull;
+    const int pick = accepted ? (int)__builtin_ctzll(okm) : N_ALPHA - 1;
+    {
+        double a = 1.0;
+        for (int i = 0; i < pick; ++i) a *= 10.0;
+        alpha = 1.0 / a;
+    }
+    __syncthreads();
+    {
+        const double* cx = CX + (int64_t)pick * st.rows * NX;
+        const double* cu = CU + (int64_t)pick * st.rows * NU;
+        if (accepted) {
+            J = __shfl(Jc, pick, WAVE);
+            for (int e0 = 0; e0 < (T + 1) * NX; e0 += WAVE * 8) {
+                double ox[8], nv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = e0 + k * WAVE + lane;
+                    if (e < (T + 1) * NX) { ox[k] = X_[e]; nv[k] = cx[e]; }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = e0 + k * WAVE + lane;
+                    if (e < (T + 1) * NX) { PRV_X[e] = ox[k]; NXT_X[e] = nv[k]; X_[e] = nv[k]; }
+                }
+            }
+            for (int e0 = 0; e0 < T * NU; e0 += WAVE * 4) {
+                double ok_[4], nu_[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = e0 + k * WAVE + lane;
+                    if (e < T * NU) { ok_[k] = KFF[e]; nu_[k] = (e >= opt_start * NU) ? cu[e] : 0.0; }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = e0 + k * WAVE + lane;
+                    if (e < T * NU) {
+                        PRV_K[e] = ok_[k];
+                        if (e >= opt_start * NU) { NXT_U[e] = nu_[k]; U_[e] = nu_[k]; }
+                    }
+                }
+            }
+            for (int e = lane; e < T + 1; e += WAVE) { NIS[e] = dt; IS[e] = dt; }
+            traj_changed = true;
+            improved = true;
+        } else {
+            // the reference leaves the last tried rollout (alpha = 1e-7) in next_*
+            for (int e0 = 0; e0 < (T + 1) * NX; e0 += WAVE * 8) {
+                double nv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = e0 + k * WAVE + lane;
+                    if (e < (T + 1) * NX) nv[k] = cx[e];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = e0 + k * WAVE + lane;
+                    if (e < (T + 1) * NX) NXT_X[e] = nv[k];
+                }
+            }
+            for (int e0 = opt_start * NU; e0 < T * NU; e0 += WAVE * 4) {
+                double nu_[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = e0 + k * WAVE + lane;
+                    if (e < T * NU) nu_[k] = cu[e];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = e0 + k * WAVE + lane;
+                    if (e < T * NU) NXT_U[e] = nu_[k];
+                }
+            }
+            for (int e = lane; e < T + 1; e += WAVE) NIS[e] = dt;
+        }
+    }
+    if (SECOND_ORDER) {                                // mu schedule, optim.c:989-999
+        mu_step = accepted ? (mu_step - 1 > 0 ? mu_step - 1 : 0) : (mu_step + 1 < 7 ? mu_step + 1 : 7);
+        if (mu_step == 0) {
+            mu = 0.0;
+        } else {
+            double m = 1.0;
+            for (int i = 0; i < mu_step - 1; ++i) m *= 10.0;
+            mu = m;
+        }
+    }
+    const double rel = fabs(J - J_prev) / J;
+    if (lane == 0) {
+        sc[TPL_S_TRAJ_COSTS] = J;
+        sc[TPL_S_ITERATIONS] = (double)(it + 1);
+        sc[TPL_S_ALPHA] = alpha;
+        sc[TPL_S_MU] = mu;
+        sc[TPL_S_MU_STEP] = (double)mu_step;
+        sc[TPL_S_TRAJECTORY_CHANGED] = traj_changed ? 1.0 : 0.0;
+        sc[TPL_S_IMPROVED] = improved ? 1.0 : 0.0;
+        if (rel < min_rel) {                           // optim.c:1001-1006: leaves the iteration loop of this round
+            sc[TPL_S_TERMINATION_CONDITION] = 2.0;
+            st.run[b] = 1;
+        }
+    }
+}
+
+__global__ void k_split_end(DevState st, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    double* sc = st.scalars + (int64_t)b * TPL_S_COUNT;
+    if (sc[TPL_S_TERMINATION_CONDITION] == -99.0) return;
+    if ((int)sc[TPL_S_ITERATIONS] == (int)sc[TPL_S_MAX_ITERATIONS]) sc[TPL_S_TERMINATION_CONDITION] = 1.0;   // optim.c:1147-1149
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 
@@ -1431,6 +1976,7 @@ struct ArrayParam {
     int per_problem = 0;
     double* dev = nullptr;           // into the handle's device parameter arena (not owned)
     long long lds_off = -1;          // doubles from the dynamic LDS base, -1: stays in global memory
+    long long lds_off_split = -1;    // the same for the split-launch kernels (their own LDS layout)
 };
 
 // fields the kernel reads from the host's hands, and the ones update() returns eagerly
@@ -1494,6 +2040,18 @@ struct tplhip_ilqr {
     unsigned long long lds_aperture = 0;         // flat address of LDS offset 0 (0: unknown, no LDS residency)
     size_t lds_static = 0;                       // static LDS of k_ilqr_update
     size_t lds_dyn_bytes = 0;                    // dynamic LDS of the next launch
+    // split-launch form (k_split_*): its own view of the device state (parameter records that point into ITS LDS layout)
+    DevState dev_split{};
+    Params* d_params_split = nullptr;
+    size_t lds_dyn_bytes_split = 0;              // dynamic LDS of the split kernels (Lds block + arrays + mirrors)
+    size_t lds_optin_split = 0;
+    int* d_run = nullptr;
+    int split_mode = -1;                         // TPLHIP_DEBUG ilqr_split=0|1; -1: by batch size
+    bool split_uniform = false;                  // integrator and order are the same for the whole batch
+    int split_int_type = 0;
+    bool split_second_order = true;
+    int max_iter_max = 0, max_lg_max = 0;        // over the batch: how many launches a round / an update needs
+    int last_form = 0;                           // 0 single launch, 1 split (info)
 };
 
 namespace {
@@ -1544,11 +2102,56 @@ void plan_lds(tplhip_ilqr* h)
     d.lds_dyn_flat = h->lds_aperture + h->lds_static;
 }
 
+// The split-launch kernels keep everything in dynamic LDS: the Lds block at the head, then what fits of the array
+// parameters and the trajectory mirrors.  Their budget is what lets TPL_ILQR_CHAIN_WAVES workgroups per SIMD stay
+// resident (160 KB per compute unit, four SIMDs): occupancy first, residency second -- co-resident wavefronts hide
+// a wait on L2 that the single launch's lone wavefront would sit through.
+void plan_lds_split(tplhip_ilqr* h)
+{
+    DevState& d = h->dev_split;
+    d = h->dev;
+    d.params = h->d_params_split;
+    d.run = h->d_run;
+    d.lds_traj = 0;
+    d.n_lds_arrays = 0;
+    d.lds_dyn_flat = 0;
+    h->lds_dyn_bytes_split = (size_t)LDS_HEAD * sizeof(double);
+    for (auto& a : h->parray) a.lds_off_split = -1;
+    if (!h->lds_aperture || tplhip::debug_opt("ilqr_no_lds")) return;
+    size_t wg_bytes = (size_t)160 * 1024 / (4 * TPL_ILQR_CHAIN_WAVES);
+    int kb = 0;
+    if (tplhip::debug_opt("ilqr_split_lds_kb", &kb)) wg_bytes = std::min((size_t)150, std::max((size_t)8, (size_t)kb)) * 1024;
+    if (wg_bytes <= (size_t)LDS_HEAD * sizeof(double)) return;
+    const size_t budget = wg_bytes / sizeof(double) - LDS_HEAD;
+    const size_t traj = (size_t)h->rows * (NX + NU + NU + NU * NX + NU + NU);
+    size_t arrays = 0;
+    for (int i = 0; i < TPL_N_PARAMS; ++i)
+        if (g_params[i].is_array && h->parray[i].elems > 0 && h->parray[i].dev) arrays += ((size_t)h->parray[i].elems + 1) & ~(size_t)1;
+    size_t off = 0;
+    if (traj + arrays <= budget) { d.lds_traj = 1; off = traj; }         // the mirrors only when the arrays fit as well
+    for (int i = 0; i < TPL_N_PARAMS; ++i) {
+        if (!g_params[i].is_array) continue;
+        ArrayParam& a = h->parray[i];
+        if (a.elems <= 0 || !a.dev) continue;
+        if (off + (size_t)a.elems > budget) continue;
+        const int k = d.n_lds_arrays++;
+        d.lds_src[k] = a.dev;
+        d.lds_src_stride[k] = a.per_problem ? a.elems : 0;
+        d.lds_len[k] = (int)a.elems;
+        d.lds_off[k] = (int)off;
+        a.lds_off_split = (long long)off;
+        off += ((size_t)a.elems + 1) & ~(size_t)1;
+    }
+    h->lds_dyn_bytes_split = (LDS_HEAD + off) * sizeof(double);
+    d.lds_dyn_flat = h->lds_aperture + (unsigned long long)LDS_HEAD * sizeof(double);   // the split kernels have no static LDS
+}
+
 int upload_params(tplhip_ilqr* h)
 {
     // layout of the parameter arena: the Params records, then every non-empty array parameter
     auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
-    size_t need = pad(sizeof(Params) * (size_t)h->batch);
+    const size_t rec_bytes = pad(sizeof(Params) * (size_t)h->batch);      // one block of parameter records
+    size_t need = 2 * rec_bytes;                                           // single-launch form, split-launch form
     for (int i = 0; i < TPL_N_PARAMS; ++i)
         if (g_params[i].is_array) need += pad(h->parray[i].host.size() * sizeof(double));
     if (need > h->parena_cap) {
@@ -1561,9 +2164,10 @@ int upload_params(tplhip_ilqr* h)
         HIP_TRY(hipMalloc((void**)&h->d_parena, cap), "parameter array allocation failed");
         h->parena_cap = cap;
         h->d_params = reinterpret_cast<Params*>(h->d_parena);
+        h->d_params_split = reinterpret_cast<Params*>(h->d_parena + rec_bytes);
         h->dev.params = h->d_params;
     }
-    size_t off = pad(sizeof(Params) * (size_t)h->batch);
+    size_t off = 2 * rec_bytes;
     for (int i = 0; i < TPL_N_PARAMS; ++i) {
         if (!g_params[i].is_array) continue;
         ArrayParam& a = h->parray[i];
@@ -1576,9 +2180,10 @@ int upload_params(tplhip_ilqr* h)
     }
     for (auto& a : h->parray) a.lds_off = -1;
     plan_lds(h);
-    Params* staged = reinterpret_cast<Params*>(h->h_parena);
+    plan_lds_split(h);
+    for (int form = 0; form < 2; ++form)
     for (int b = 0; b < h->batch; ++b) {
-        Params& P = staged[b];
+        Params& P = reinterpret_cast<Params*>(h->h_parena + (form ? rec_bytes : 0))[b];
         std::memset(&P, 0, sizeof(Params));
         for (int i = 0; i < TPL_N_PARAMS; ++i) {
             char* slot = (char*)&P + g_params[i].offset;
@@ -1586,8 +2191,10 @@ int upload_params(tplhip_ilqr* h)
                 const ArrayParam& a = h->parray[i];
                 DynArr d;
                 d.data = a.dev ? a.dev + (a.per_problem ? (size_t)b * a.elems : 0) : nullptr;
-                if (a.lds_off >= 0)     // the kernel copies the array to this LDS address first
-                    d.data = (const double*)(uintptr_t)(h->dev.lds_dyn_flat + (unsigned long long)a.lds_off * sizeof(double));
+                const long long lds_off = form ? a.lds_off_split : a.lds_off;
+                const unsigned long long lds_base = form ? h->dev_split.lds_dyn_flat : h->dev.lds_dyn_flat;
+                if (lds_off >= 0)       // the kernel copies the array to this LDS address first
+                    d.data = (const double*)(uintptr_t)(lds_base + (unsigned long long)lds_off * sizeof(double));
                 d.ndim = a.ndim;
                 d.n0 = a.ndim > 0 ? a.dims[0] : 0;
                 d.n1 = a.ndim > 1 ? a.dims[1] : 0;
@@ -1630,6 +2237,50 @@ int upload_inputs(tplhip_ilqr* h)
     return upload_params(h);
 }
 
+// Which form runs: the split sequence pays off when the batch fills the chip more than once (a second wavefront per
+// SIMD has something to hide behind) and needs one integrator and one order for the whole batch (they are template
+// parameters of k_split_chain).  TPLHIP_DEBUG ilqr_split=0|1 forces either (tests run both).
+bool use_split(const tplhip_ilqr* h)
+{
+    if (!h->split_uniform || !h->d_run) return false;
+    if (h->split_mode >= 0) return h->split_mode != 0;
+    return (long long)h->batch > 4LL * h->n_cu;
+}
+
+template <bool SO, int INT>
+int launch_chain(tplhip_ilqr* h, int lg, int it)
+{
+    const void* fn = reinterpret_cast<const void*>(&k_split_chain<SO, INT>);
+    if (h->lds_dyn_bytes_split > 48 * 1024 && h->lds_dyn_bytes_split > h->lds_optin_split) {
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dyn_bytes_split), "raising the LDS limit failed");
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_split_begin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dyn_bytes_split), "raising the LDS limit failed");
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_split_refresh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dyn_bytes_split), "raising the LDS limit failed");
+        h->lds_optin_split = h->lds_dyn_bytes_split;
+    }
+    hipLaunchKernelGGL((k_split_chain<SO, INT>), dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes_split, h->stream, h->dev_split, lg, it);
+    return TPLHIP_OK;
+}
+
+int launch_split(tplhip_ilqr* h)
+{
+    const size_t lds = h->lds_dyn_bytes_split;
+    const int rounds = std::max(1, h->max_lg_max);
+    for (int lg = 0; lg < rounds; ++lg) {
+        hipLaunchKernelGGL(k_split_begin, dim3(h->batch), dim3(WAVE), lds, h->stream, h->dev_split, lg);
+        if (lg >= h->max_lg_max) break;
+        for (int it = 0; it < h->max_iter_max; ++it) {
+            hipLaunchKernelGGL(k_split_refresh, dim3(h->batch), dim3(WAVE), lds, h->stream, h->dev_split, lg, it);
+            int rc;
+            const int ty = h->split_int_type;
+            if (h->split_second_order) rc = ty == EULER ? launch_chain<true, EULER>(h, lg, it) : (ty == HEUN ? launch_chain<true, HEUN>(h, lg, it) : launch_chain<true, RK4>(h, lg, it));
+            else rc = ty == EULER ? launch_chain<false, EULER>(h, lg, it) : (ty == HEUN ? launch_chain<false, HEUN>(h, lg, it) : launch_chain<false, RK4>(h, lg, it));
+            if (rc) return rc;
+        }
+    }
+    hipLaunchKernelGGL(k_split_end, dim3((h->batch + 255) / 256), dim3(256), 0, h->stream, h->dev_split, h->batch);
+    return TPLHIP_OK;
+}
+
 int launch(tplhip_ilqr* h)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1638,12 +2289,18 @@ int launch(tplhip_ilqr* h)
         HIP_TRY(hipEventCreate(&e1), "event creation failed");
         HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
     }
-    if (h->lds_dyn_bytes > 48 * 1024 && h->lds_dyn_bytes > h->lds_optin) {       // more than the default allowance: opt in
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ilqr_update), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)h->lds_dyn_bytes), "raising the LDS limit failed");
-        h->lds_optin = h->lds_dyn_bytes;
+    if (use_split(h)) {
+        h->last_form = 1;
+        if (int rc = launch_split(h)) return rc;
+    } else {
+        h->last_form = 0;
+        if (h->lds_dyn_bytes > 48 * 1024 && h->lds_dyn_bytes > h->lds_optin) {       // more than the default allowance: opt in
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ilqr_update), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)h->lds_dyn_bytes), "raising the LDS limit failed");
+            h->lds_optin = h->lds_dyn_bytes;
+        }
+        hipLaunchKernelGGL(k_ilqr_update, dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes, h->stream, h->dev);
     }
-    hipLaunchKernelGGL(k_ilqr_update, dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes, h->stream, h->dev);
     HIP_TRY(hipGetLastError(), "solver launch failed");
     if (h->timing) {
         HIP_TRY(hipEventRecord(e1, h->stream), "event record failed");
@@ -1709,6 +2366,15 @@ int check_settings(tplhip_ilqr* h)
         if (os < 0 || os > T) return fail(TPLHIP_EINVAL, "opt_start %d outside [0, horizon]", os);
         const int it = (int)sc[TPL_S_INTEGRATOR_TYPE];
         if (it < 0 || it > 2) return fail(TPLHIP_EINVAL, "unknown integrator type %d", it);
+        // what the split-launch form needs to know about the batch as a whole
+        const bool so = sc[TPL_S_USE_QUADRATIC_TERMS] != 0.0;
+        const int mi = (int)sc[TPL_S_MAX_ITERATIONS], ml = (int)sc[TPL_S_MAX_LG_ITERATIONS];
+        if (b == 0) { h->split_uniform = true; h->split_int_type = it; h->split_second_order = so; h->max_iter_max = mi; h->max_lg_max = ml; }
+        else {
+            if (it != h->split_int_type || so != h->split_second_order) h->split_uniform = false;
+            h->max_iter_max = std::max(h->max_iter_max, mi);
+            h->max_lg_max = std::max(h->max_lg_max, ml);
+        }
     }
     return TPLHIP_OK;
 }
@@ -1792,6 +2458,13 @@ int tplhip_ilqr_create(int device, int batch, int t_cap, tplhip_ilqr** out)
     err = hipMalloc(&h->dev.cand_x, cand_x * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&h->dev.cand_u, cand_u * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&h->dev.cand_c, (size_t)batch * N_ALPHA * h->rows * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc((void**)&h->d_run, (size_t)batch * sizeof(int));
+    if (err == hipSuccess) err = hipMemsetAsync(h->d_run, 0, (size_t)batch * sizeof(int), h->stream);
+    h->dev.run = h->d_run;
+    {
+        int v = 0;
+        if (tplhip::debug_opt("ilqr_split", &v)) h->split_mode = v ? 1 : 0;
+    }
     if (err != hipSuccess) { tplhip_ilqr_destroy(h); return fail(TPLHIP_EDEVICE, "%s: solver workspace allocation failed", hipGetErrorString(err)); }
     h->dev.params = nullptr;                                // set by the first upload_params
     h->dev.stamps = nullptr;
@@ -1855,6 +2528,7 @@ int tplhip_ilqr_destroy(tplhip_ilqr* h)
     (void)hipFree(h->dev.cand_x);
     (void)hipFree(h->dev.cand_u);
     (void)hipFree(h->dev.cand_c);
+    (void)hipFree(h->d_run);
     for (double* p : h->d_snapshot) (void)hipFree(p);
     (void)hipFree(h->d_snapshot_scalars);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -2082,9 +2756,12 @@ int tplhip_ilqr_download(tplhip_ilqr* h)
 int tplhip_ilqr_info(tplhip_ilqr* h, char* buf, int n)
 {
     if (!h || !buf || n < 1) return fail(TPLHIP_EINVAL, "bad argument");
+    const bool sp = h->last_form == 1;
     std::snprintf(buf, (size_t)n, "{\"batch\": %d, \"t_cap\": %d, \"lds_traj\": %d, \"lds_arrays\": %d, \"lds_dyn_bytes\": %zu, "
-                  "\"lds_static_bytes\": %zu}", h->batch, h->rows - 1, h->dev.lds_traj, h->dev.n_lds_arrays, h->lds_dyn_bytes,
-                  h->lds_static);
+                  "\"lds_static_bytes\": %zu, \"form\": \"%s\", \"chain_waves_per_simd\": %d}", h->batch, h->rows - 1,
+                  sp ? h->dev_split.lds_traj : h->dev.lds_traj, sp ? h->dev_split.n_lds_arrays : h->dev.n_lds_arrays,
+                  sp ? h->lds_dyn_bytes_split : h->lds_dyn_bytes, sp ? (size_t)0 : h->lds_static,
+                  sp ? "split" : "single", sp ? TPL_ILQR_CHAIN_WAVES : 1);
     return TPLHIP_OK;
 }
 

@@ -3,6 +3,7 @@
 //     no_v3          large grids: the general two-pass sweep (k_backward) instead of k_backward3v
 //     no_s3          small grids: k_backward instead of k_backward3s
 //     no_fastdiv     IEEE division in the sweeps (skips the brute-force proof of the reciprocal forms)
+//     div_form=N     plain-fp32 sweeps: division form N (3, 4, 5; dp_sweep.hip) where it is proven, IEEE division elsewhere
 //     no_bufload     plain global loads instead of buffer loads in k_backward
 //     no_fwd_overlap plan_resident: the forward rollout stays on the main stream
 //     no_fwd_spec    forward rollout without speculation on every grid (the form large table sets take anyway)
@@ -11,6 +12,7 @@
 //     big=0|1        treat the grid as small / as several residency rounds deep (k_backward3s / k_backward3v), whatever its size
 //     tile_v=N, tile_a=N   traversal tile of the sweeps
 //     ilqr_no_lds, ilqr_lds_kb=N   iLQR: where the solver mirrors live (tests force both homes)
+//     ilqr_split=0|1, ilqr_split_lds_kb=N   iLQR: single launch / split-launch sequence whatever the batch size; LDS budget of the split kernels
 // Nothing else in the library reads the environment (tpl_amd/_capi.py reads TPLHIP_LIB to locate the .so).
 #pragma once
 
