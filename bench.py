@@ -37,6 +37,7 @@ BYTES_PER_CELL = 32            # read next float4 + write this f
 PLANS_PER_STEP = 24            # one step = one batch of plans (keeps the timed region of 20 steps above a second)
 MC_PER_GPU = 1024              # BASELINE configs[4]: 8192 Monte-Carlo rollouts on 8 GPUs
 MC_CHUNK = 64                  # scenarios swept per launch (value tables for that many: 64 x 157 MB)
+MC_BLOCK = 128                 # scenarios built on the host and handed to the device at a time (160 MB)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -257,20 +258,32 @@ def mpc_cpu_baseline(ticks=1000, horizon=20):
 # workloads
 # ------------------------------------------------------------------------------------------------
 
-def dp_setup(grid, device):
+def rank_scenario(rank):
+    """The headline workload of rank r: rank 0 plans the scenario the N = 1 line is quoted on; every further rank gets
+    its own start speed and its own obstacle train (moved along the road and re-timed), so that the all-gathered argmin
+    of an N-rank run is over N DIFFERENT plans (same grid, same cost per sweep)."""
+    from benchkit import scenarios as sc
+    if rank == 0:
+        return sc.OBSTACLES_OVERTAKE_TRAFFIC, sc.initial_state(0.0, 8.0, 0.0)
+    obst = tuple((s0 + 7.0 * rank, v + 0.25 * rank, length) for (s0, v, length) in sc.OBSTACLES_OVERTAKE_TRAFFIC)
+    return obst, sc.initial_state(0.0, 8.0 + 0.5 * rank, 0.0)
+
+
+def dp_setup(grid, device, rank=0):
     import tpl_amd
     from benchkit import scenarios as sc
     S, V, A, T = sc.GRIDS[grid]
     p = sc.lon_params(S, V, A, T)
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
     path = sc.straight_path(p.path_steps, p.path_step_size)
-    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
+    obstacles, init = rank_scenario(rank)
+    occ = sc.occ_map(ep, obstacles)
     env = tpl_amd.DynProgEnvironment(device)
     env.reinit_buffers(ep)
     env.set_occ_map(occ)
     dp = tpl_amd.DynProgLonPlanner(device)
     dp.reinit_buffers(p)
-    dp.upload([sc.initial_state(0.0, 8.0, 0.0)], path)
+    dp.upload([init], path)
     return dp, env, p, ep, path, occ
 
 
@@ -280,18 +293,35 @@ def sweep_kernel_name(info):
 
 def mc_scenarios(ep, first, n):
     """Monte-Carlo scenarios [first, first + n) of the 8192-rollout workload: perturbed initial state and an own
-    set of moving obstacles per scenario id (seeded by the id, so every rank count gives the same scenarios)."""
+    set of moving obstacles per scenario id (seeded by the id, so every rank count gives the same scenarios).
+    The occupancy maps (31 x 201 x 50 floats per scenario: 1.25 GB per 1024) are written by ONE broadcast per call, not
+    by a Python loop per scenario, slice and obstacle; mc_rollouts asks for MC_BLOCK scenarios at a time and hands each
+    block to the device before it builds the next -- eight ranks set up on one host together.
+    Same float64 interval arithmetic as benchkit.scenarios.occ_map (checked in tests/test_sharding.py)."""
     import numpy as np
     from benchkit import scenarios as sc
-    occs = np.empty((n, ep.l_steps, ep.s_steps, ep.t_steps), dtype=np.float32)
+    KMAX = 6
+    s0 = np.full((n, KMAX), np.nan)
+    v = np.zeros((n, KMAX))
     inits = []
     for i in range(n):
-        sid = first + i
-        rng = np.random.default_rng(77000 + sid)
+        rng = np.random.default_rng(77000 + first + i)
         k = int(rng.integers(2, 7))
-        obst = tuple((float(a), float(b), 4.0) for a, b in zip(rng.uniform(30.0, 180.0, k), rng.uniform(0.0, 10.0, k)))
-        occs[i] = sc.occ_map(ep, obst)
+        s0[i, :k] = rng.uniform(30.0, 180.0, k)
+        v[i, :k] = rng.uniform(0.0, 10.0, k)
         inits.append(sc.initial_state(0.0, float(rng.uniform(2.0, 14.0)), float(rng.uniform(-1.0, 1.0))))
+    length, sweep_length, half_width = 4.0, 0.5, 1.5
+    st = ep.s_min + np.arange(ep.s_steps) * ((ep.s_max - ep.s_min) / (ep.s_steps - 1))
+    lt = ep.l_min + np.arange(ep.l_steps) * ((ep.l_max - ep.l_min) / (ep.l_steps - 1))
+    lmask = np.abs(lt) <= half_width
+    t = np.array([0.0 if i == 0 else ep.dt_start + (i - 1) * ep.dt for i in range(ep.t_steps)])
+    lmask_f = lmask.astype(np.float32)[None, :, None, None]
+    lo = s0[:, :, None] + v[:, :, None] * t[None, None, :] - 0.5 * length                                # [n, K, T]
+    hi = s0[:, :, None] + v[:, :, None] * t[None, None, :] + 0.5 * length + max(sweep_length, ep.dt) * v[:, :, None]
+    with np.errstate(invalid="ignore"):                                                                   # unused obstacle slots are NaN: never inside
+        inside = (st[None, None, :, None] >= lo[:, :, None, :]) & (st[None, None, :, None] <= hi[:, :, None, :])     # [n, K, S, T]
+    smask = inside.any(axis=1).astype(np.float32)                                                         # [n, S, T]
+    occs = lmask_f * smask[:, None, :, :]
     return occs, inits
 
 
@@ -320,12 +350,17 @@ def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_c
     path = sc.straight_path(p.path_steps, p.path_step_size)
     n_total = MC_PER_GPU * world
     lo, hi = sharding.shard_range(n_total, rank, world)
-    occs, inits = mc_scenarios(ep, lo, hi - lo)
+    n = hi - lo
+    t_setup0 = time.perf_counter()
     dp = tpl_amd.DynProgLonPlanner(device)
     dp.reinit_buffers(p)
-    dp.upload_scenarios(occs, ep, inits, path, chunk=MC_CHUNK)
+    # the scenario set goes up block by block: one 128-scenario buffer on the host (160 MB), not the whole 1.25 GB
+    dp.upload_scenarios(None, ep, None, path, chunk=MC_CHUNK, n=n)
+    for b0 in range(0, n, MC_BLOCK):
+        occs, inits = mc_scenarios(ep, lo + b0, min(MC_BLOCK, n - b0))
+        dp.set_scenario_block(b0, occs, inits)
     del occs
-    n = hi - lo
+    setup_s = time.perf_counter() - t_setup0
 
     def one_pass():
         for first in range(0, n, MC_CHUNK):
@@ -387,6 +422,7 @@ def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_c
                      "algorithmic_bytes_per_launch": MC_CHUNK * cells * BYTES_PER_CELL, "rank": rank},
         "best_plan": {"constr": bk[0], "cost": bk[1], "id": bk[2], "identical_on_all_ranks": bool(identical)},
         "record_bytes": int(nbytes),
+        "setup_s": setup_s,
     }
     traffic_block(res["roofline"], f"{S}x{V}x{A}@{MC_CHUNK}")
     return res
@@ -465,7 +501,8 @@ def worker(args):
         assert collective["ranks_seen"] == world, collective
 
     from tpl_amd import sharding
-    dp, env, p, ep, path, occ = dp_setup(args.grid, local_rank)
+    t_setup0 = time.perf_counter()
+    dp, env, p, ep, path, occ = dp_setup(args.grid, local_rank, rank)
     cells = p.s_steps * p.v_steps * p.a_steps
     sweeps_per_plan = p.t_steps - 1
     plans_per_step = 2 if args.grid == "config4" else PLANS_PER_STEP
@@ -481,6 +518,7 @@ def worker(args):
 
     run(args.warmup)
     dp.sync()
+    setup_s = {"headline": time.perf_counter() - t_setup0}
     dp.timing_enable(True)
     barrier()
     t0 = time.perf_counter()
@@ -495,7 +533,7 @@ def worker(args):
     sweep_ms, sweep_launches = dp.timing_get()
     dp.timing_enable(False)
 
-    rank_values = None
+    rank_values = rank_plans = None
     if dist is not None:
         cdev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
         mine = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -506,6 +544,11 @@ def worker(args):
         t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own plan (cost, constraint sum, speed at the last stage): N different scenarios give N different entries
+        plan = torch.tensor([float(rec[1]), float(rec[0]), float(traj.states[-1].v)], dtype=torch.float64, device=cdev)
+        plans = [torch.zeros(3, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(plans, plan)
+        rank_plans = [{"cost": float(q[0]), "constr": float(q[1]), "v_end": float(q[2])} for q in plans]
 
     total_sweeps = sweeps_per_plan * plans_per_step * args.steps * world
     out = None
@@ -549,7 +592,7 @@ def worker(args):
             out["note"] = f"{world} ranks share ONE device over gloo: exercises the N > 1 code path, says nothing about scaling"
         if dist is not None:
             out["best_plan"] = {"constr": float(best[0]), "cost": float(best[1]), "rank": int(best[2])}
-            out["collective"] = dict(collective, per_rank_value=rank_values)
+            out["collective"] = dict(collective, per_rank_value=rank_values, per_rank_plan=rank_plans)
         traffic_block(out["roofline"], f"{p.s_steps}x{p.v_steps}x{p.a_steps}")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = dp_cpu_baseline(p, ep, path, occ)
@@ -631,7 +674,18 @@ def launcher(args, argv):
     out, _ = procs[0].communicate()
     rc = 1 if procs[0].returncode != 0 else 0          # a rank killed by a signal has a NEGATIVE code: any non-zero is failure
     for pr in procs[1:]:
-        rc = rc or (1 if pr.wait() != 0 else 0)
+        # every rank is waited for (no short circuit); once one has failed the others may sit in a collective that
+        # will never complete: give them a moment, then end them -- exactly the processes started above, by handle
+        try:
+            code = pr.wait(timeout=30 if rc else None)
+        except subprocess.TimeoutExpired:
+            pr.terminate()
+            try:
+                code = pr.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                code = pr.wait()
+        rc = rc or (1 if code != 0 else 0)
     # ONE JSON line on stdout: rank 0's (gloo announces its connections on stdout in the rehearsal set-up)
     lines = [ln for ln in out.decode("utf8", "replace").splitlines() if ln.startswith("{")]
     if lines:

@@ -246,6 +246,13 @@ TPLHIP_API size_t tplhip_dp_lon_record_bytes(int t_steps);
  * chunk = scenarios swept per launch (value tables for that many are allocated: chunk x t_steps x cells x 12 B). */
 TPLHIP_API int tplhip_dp_lon_scenarios_upload(tplhip_dp_lon* h, int n, const float* occ_nlst, const TplDpEnvParams* ep,
                                               const TplLonState* inits, const float* paths, int n_paths, int chunk);
+/* Block-wise form of the upload, for scenario sets whose occupancy maps the caller would rather not hold in host memory
+ * at once (1 024 scenarios of 31 x 201 x 50 floats are 1.25 GB): _scenarios_upload with occ_nlst == NULL and
+ * inits == NULL reserves everything for n scenarios (maps zeroed), then every block [first, first + count) is handed
+ * over with _scenarios_set_block (occ_block: float[count][l][s][t], inits: TplLonState[count]); synchronous, the
+ * caller may reuse its buffer afterwards. */
+TPLHIP_API int tplhip_dp_lon_scenarios_set_block(tplhip_dp_lon* h, int first, int count, const float* occ_block,
+                                                 const TplLonState* inits);
 /* Enqueue the complete plans of scenarios [first, first + count), count <= chunk: distance maps, stage preludes,
  * t_steps-1 batched sweeps, the forward rollouts and the reduction into the record (reset_best != 0 starts a new
  * record, 0 keeps the better of the record and this launch).  Scenario i carries the id id_base + i. */

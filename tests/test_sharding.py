@@ -155,3 +155,32 @@ def test_bench_launcher_starts_its_ranks_and_fails_loudly_without_a_gpu():
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
     assert b"needs a GPU" in p.stderr or b"No HIP GPUs are available" in p.stderr or b"no usable HIP device" in p.stderr
+
+
+def test_mc_scenarios_block_builder_equals_the_per_scenario_maps():
+    """bench.py builds the occupancy maps of a rank's Monte-Carlo scenarios with one broadcast per block of scenarios
+    (eight ranks set up on one host together); scenario by scenario they are benchkit.scenarios.occ_map of the same
+    obstacles, and a scenario id gives the same scenario whatever block it is built in."""
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import bench
+    from benchkit import scenarios as sc
+    ep = sc.env_params(t_steps=7, s_steps=101, l_steps=11)
+    occs, inits = bench.mc_scenarios(ep, 5, 9)
+    for i in range(9):
+        rng = np.random.default_rng(77000 + 5 + i)
+        k = int(rng.integers(2, 7))
+        obst = tuple((float(a), float(b), 4.0) for a, b in zip(rng.uniform(30.0, 180.0, k), rng.uniform(0.0, 10.0, k)))
+        assert np.array_equal(occs[i], sc.occ_map(ep, obst)), i
+        v0, a0 = float(rng.uniform(2.0, 14.0)), float(rng.uniform(-1.0, 1.0))
+        assert (inits[i].v, inits[i].a) == (np.float32(v0), np.float32(a0))
+    again, _ = bench.mc_scenarios(ep, 9, 3)
+    assert np.array_equal(again, occs[4:7])
+
+
+def test_headline_scenarios_differ_between_ranks():
+    import bench
+    o0, i0 = bench.rank_scenario(0)
+    o3, i3 = bench.rank_scenario(3)
+    from benchkit import scenarios as sc
+    assert o0 == sc.OBSTACLES_OVERTAKE_TRAFFIC and (i0.s, i0.v, i0.a) == (0.0, 8.0, 0.0)
+    assert o3 != o0 and i3.v == 9.5

@@ -237,6 +237,7 @@ SIGNATURES = {
     "tplhip_dp_lon_record_bytes": (C.c_size_t, [C.c_int]),
     "tplhip_dp_lon_scenarios_upload": (C.c_int, [_vp, C.c_int, _P(C.c_float), _P(TplDpEnvParams), _P(TplLonState),
                                                  _P(C.c_float), C.c_int, C.c_int]),
+    "tplhip_dp_lon_scenarios_set_block": (C.c_int, [_vp, C.c_int, C.c_int, _P(C.c_float), _P(TplLonState)]),
     "tplhip_dp_lon_scenarios_plan": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tplhip_dp_lon_scenarios_download": (C.c_int, [_vp, _P(TplLonState)]),
     "tplhip_dp_lon_scenarios_best": (C.c_int, [_vp, C.c_void_p]),

@@ -1304,7 +1304,7 @@ size_t tplhip_dp_lon_record_bytes(int t_steps)
 int tplhip_dp_lon_scenarios_upload(tplhip_dp_lon* h, int n, const float* occ_nlst, const TplDpEnvParams* ep_in,
                                    const TplLonState* inits, const float* paths, int n_paths, int chunk)
 {
-    if (!h || !occ_nlst || !ep_in || !inits || !paths) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (!h || !ep_in || !paths || ((occ_nlst == nullptr) != (inits == nullptr))) return tplhip_fail(TPLHIP_EINVAL, "null argument");
     if (!h->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the planner");
     if (n < 1 || chunk < 1 || (n_paths != 1 && n_paths != n))
         return tplhip_fail(TPLHIP_EINVAL, "need n >= 1, chunk >= 1 and one path or one per scenario (n = %d, chunk = %d, n_paths = %d)", n, chunk, n_paths);
@@ -1332,9 +1332,14 @@ int tplhip_dp_lon_scenarios_upload(tplhip_dp_lon* h, int n, const float* occ_nls
     HIP_TRY(hipMalloc(&h->d_sc_best, record_bytes(p.t_steps)), "plan record allocation failed");
     HIP_TRY(hipMemsetAsync(h->d_sc_tables, 0, sizeof(Node) * h->table_cells * T * chunk, h->stream), "value table clear failed");
     HIP_TRY(hipMemsetAsync(h->d_sc_trajs, 0, sizeof(TplLonState) * T * n, h->stream), "trajectory clear failed");
-    HIP_TRY(hipMemcpyAsync(h->d_sc_occ, occ_nlst, sizeof(float) * occ_elems * n, hipMemcpyHostToDevice, h->stream), "copying occupancy maps failed");
+    if (occ_nlst) {
+        HIP_TRY(hipMemcpyAsync(h->d_sc_occ, occ_nlst, sizeof(float) * occ_elems * n, hipMemcpyHostToDevice, h->stream), "copying occupancy maps failed");
+        HIP_TRY(hipMemcpyAsync(h->d_sc_inits, inits, sizeof(TplLonState) * (size_t)n, hipMemcpyHostToDevice, h->stream), "copying initial states failed");
+    } else {                                         // reserve only: the blocks follow (tplhip_dp_lon_scenarios_set_block)
+        HIP_TRY(hipMemsetAsync(h->d_sc_occ, 0, sizeof(float) * occ_elems * n, h->stream), "occupancy clear failed");
+        HIP_TRY(hipMemsetAsync(h->d_sc_inits, 0, sizeof(TplLonState) * (size_t)n, h->stream), "initial state clear failed");
+    }
     HIP_TRY(hipMemcpyAsync(h->d_sc_path, paths, sizeof(float) * path_elems * n_paths, hipMemcpyHostToDevice, h->stream), "copying paths failed");
-    HIP_TRY(hipMemcpyAsync(h->d_sc_inits, inits, sizeof(TplLonState) * (size_t)n, hipMemcpyHostToDevice, h->stream), "copying initial states failed");
     HIP_TRY(hipStreamSynchronize(h->stream), "scenario upload failed");
     h->sc_n = n; h->sc_chunk = chunk; h->sc_paths = n_paths; h->sc_ep = ep;
     {
@@ -1345,6 +1350,23 @@ int tplhip_dp_lon_scenarios_upload(tplhip_dp_lon* h, int n, const float* occ_nls
         h->sc_bounded = ok && h->params_bounded;
     }
     h->sc_last_first = h->sc_last_count = 0;
+    return TPLHIP_OK;
+}
+
+int tplhip_dp_lon_scenarios_set_block(tplhip_dp_lon* h, int first, int count, const float* occ_block, const TplLonState* inits)
+{
+    if (!h || !occ_block || !inits) return tplhip_fail(TPLHIP_EINVAL, "null argument");
+    if (h->sc_n < 1) return tplhip_fail(TPLHIP_ESTATE, "no scenarios uploaded");
+    if (first < 0 || count < 1 || first + count > h->sc_n)
+        return tplhip_fail(TPLHIP_EINVAL, "scenario block [%d, %d) does not fit (%d scenarios)", first, first + count, h->sc_n);
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    const TplDpEnvParams& ep = h->sc_ep;
+    const size_t occ_elems = (size_t)ep.l_steps * ep.s_steps * ep.t_steps;
+    HIP_TRY(hipMemcpyAsync(h->d_sc_occ + occ_elems * first, occ_block, sizeof(float) * occ_elems * count, hipMemcpyHostToDevice, h->stream),
+            "copying occupancy maps failed");
+    HIP_TRY(hipMemcpyAsync(h->d_sc_inits + first, inits, sizeof(TplLonState) * (size_t)count, hipMemcpyHostToDevice, h->stream),
+            "copying initial states failed");
+    HIP_TRY(hipStreamSynchronize(h->stream), "scenario upload failed");
     return TPLHIP_OK;
 }
 

@@ -483,28 +483,50 @@ class DynProgLonPlanner:
 
     # ---- scenario batches (new) -----------------------------------
 
-    def upload_scenarios(self, occ_maps, env_params, initial_states, paths, chunk=32):
+    def upload_scenarios(self, occ_maps, env_params, initial_states, paths, chunk=32, n=None):
         """n independent scenarios, resident on the device: ``occ_maps`` float32[n, l, s, t] (per scenario the
         layout of ``DynProgEnvironment.get_occ_map``), ``initial_states`` n LonStates, ``paths`` one
         float32[path_steps, 7] shared by all or float32[n, path_steps, 7].  ``chunk`` scenarios are swept per
-        launch (value tables are allocated for that many)."""
+        launch (value tables are allocated for that many).  ``occ_maps=None, initial_states=None, n=N`` reserves the
+        device side for N scenarios; the maps then arrive block by block (``set_scenario_block``)."""
         ep = env_params
-        occ = np.ascontiguousarray(occ_maps, dtype=np.float32)
-        n = len(initial_states)
-        want = (n, ep.l_steps, ep.s_steps, ep.t_steps)
-        if occ.shape != want:
-            raise ValueError(f"array has incorrect shape, expected: {want}, got: {occ.shape}")
+        reserve = occ_maps is None
+        if reserve:
+            if initial_states is not None or n is None:
+                raise ValueError("reserving needs occ_maps=None, initial_states=None and n")
+        else:
+            occ = np.ascontiguousarray(occ_maps, dtype=np.float32)
+            n = len(initial_states)
+            want = (n, ep.l_steps, ep.s_steps, ep.t_steps)
+            if occ.shape != want:
+                raise ValueError(f"array has incorrect shape, expected: {want}, got: {occ.shape}")
         paths = np.ascontiguousarray(paths, dtype=np.float32)
         if paths.ndim == 2:
             paths = paths[None]
         if paths.shape[1:] != (self.params.path_steps, 7) or paths.shape[0] not in (1, n):
             raise ValueError(f"array has incorrect shape, expected: (1 or {n}, {self.params.path_steps}, 7), got: {paths.shape}")
-        inits = (TplLonState * n)()
+        inits = None
+        if not reserve:
+            inits = (TplLonState * n)()
+            for i, s in enumerate(initial_states):
+                C.memmove(C.byref(inits[i]), C.byref(s._c), C.sizeof(TplLonState))
+        check(self._lib.tplhip_dp_lon_scenarios_upload(self._h, n, None if reserve else _fptr(occ), C.byref(ep._c), inits,
+                                                       _fptr(paths), paths.shape[0], int(chunk)))
+        self._sc_n = n
+        self._sc_ep = ep
+
+    def set_scenario_block(self, first, occ_maps, initial_states):
+        """Scenarios [first, first + len(initial_states)) of a reserved set: float32[count, l, s, t] and their states."""
+        ep = self._sc_ep
+        occ = np.ascontiguousarray(occ_maps, dtype=np.float32)
+        count = len(initial_states)
+        want = (count, ep.l_steps, ep.s_steps, ep.t_steps)
+        if occ.shape != want:
+            raise ValueError(f"array has incorrect shape, expected: {want}, got: {occ.shape}")
+        inits = (TplLonState * count)()
         for i, s in enumerate(initial_states):
             C.memmove(C.byref(inits[i]), C.byref(s._c), C.sizeof(TplLonState))
-        check(self._lib.tplhip_dp_lon_scenarios_upload(self._h, n, _fptr(occ), C.byref(ep._c), inits, _fptr(paths),
-                                                       paths.shape[0], int(chunk)))
-        self._sc_n = n
+        check(self._lib.tplhip_dp_lon_scenarios_set_block(self._h, int(first), count, _fptr(occ), inits))
 
     def plan_scenarios(self, first=0, count=None, id_base=0, reset_best=True):
         """Enqueue the plans of scenarios [first, first + count) (one launch per stage for all of them) and fold
