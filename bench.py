@@ -400,9 +400,9 @@ def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_c
         ids = torch.tensor([bk[2], -bk[2]], dtype=torch.int64, device="cpu" if rehearsal else torch.device("cuda", device))
         dist.all_reduce(ids, op=dist.ReduceOp.MAX)
         identical = int(ids[0].item()) == bk[2] and int(-ids[1].item()) == bk[2]
-        t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else torch.device("cuda", device))
+        t = torch.tensor([el, setup_s], dtype=torch.float64, device="cpu" if rehearsal else torch.device("cuda", device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        el, setup_s = float(t[0].item()), float(t[1].item())            # both: the slowest rank's
     cells = S * V * A
     per_launch_s = (sweep_ms / 1e3) / max(1, launches)
     achieved = MC_CHUNK * cells * BYTES_PER_CELL / per_launch_s / 1e9
@@ -549,6 +549,9 @@ def worker(args):
         plans = [torch.zeros(3, dtype=torch.float64, device=cdev) for _ in range(world)]
         dist.all_gather(plans, plan)
         rank_plans = [{"cost": float(q[0]), "constr": float(q[1]), "v_end": float(q[2])} for q in plans]
+        su = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(su, torch.tensor([setup_s["headline"]], dtype=torch.float64, device=cdev))
+        setup_s["headline_per_rank"] = [float(q.item()) for q in su]
 
     total_sweeps = sweeps_per_plan * plans_per_step * args.steps * world
     out = None
@@ -590,6 +593,7 @@ def worker(args):
         if rehearsal:
             out["rehearsal"] = True
             out["note"] = f"{world} ranks share ONE device over gloo: exercises the N > 1 code path, says nothing about scaling"
+        out["setup_s"] = setup_s
         if dist is not None:
             out["best_plan"] = {"constr": float(best[0]), "cost": float(best[1]), "rank": int(best[2])}
             out["collective"] = dict(collective, per_rank_value=rank_values, per_rank_plan=rank_plans)

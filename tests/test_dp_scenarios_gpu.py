@@ -33,16 +33,20 @@ CASES = [
     pytest.param(128, 64, 32, 4, 8, 8, False, id="B8-config2-grid"),
     pytest.param(201, 37, 20, 6, 8, 3, False, id="B8-in-chunks-of-3-reference-default-grid"),     # odd v_steps, ragged rows
     pytest.param(96, 16, 10, 5, 4, 4, True, id="B4-own-path-per-scenario"),
-    pytest.param(96, 17, 10, 5, 3, 3, "step0.3", id="B3-generic-kernel-path-step-0.3"),      # no proven cheap division: k_backward
+    pytest.param(96, 17, 10, 5, 3, 3, "step0.3", id="B3-path-step-0.3"),      # a divisor without a proven two-float form: Newton form or IEEE
+    pytest.param(96, 17, 10, 5, 3, 3, "general", id="B3-general-sweep"),       # TPLHIP_DEBUG=no_v3: the batched form of k_backward
 ]
 
 
 @pytest.mark.parametrize("S,V,A,T,n,chunk,own_paths", CASES)
-def test_batched_scenarios_bit_exact(S, V, A, T, n, chunk, own_paths):
+def test_batched_scenarios_bit_exact(S, V, A, T, n, chunk, own_paths, monkeypatch):
     p = sc.lon_params(S, V, A, T)
     want_kernel = "k_backward3v"
     if own_paths == "step0.3":
-        p.path_step_size, p.path_steps, own_paths, want_kernel = 0.3, 667, False, "k_backward"
+        p.path_step_size, p.path_steps, own_paths = 0.3, 667, False
+    elif own_paths == "general":
+        monkeypatch.setenv("TPLHIP_DEBUG", "no_v3")
+        own_paths, want_kernel = False, "k_backward"
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
     occs, inits = _scenarios(n, ep, seed=S + n)
     if own_paths:

@@ -7,7 +7,6 @@
 set -eu
 cd "$(dirname "$0")/.."
 INC="$PWD/tpl_amd/models/trajectory_tracking_mpc.inc"
-LIB=tpl_amd/models/libilqr_trajectory_tracking_mpc.so
 case "${1:-}" in
 build)
     shift
@@ -22,15 +21,13 @@ build)
         echo "built tools/ab_tmp/$rev.so (headers and model text of the working tree)"
     done ;;
 run)
-    cp $LIB tools/ab_tmp/.shipped.so
+    # (every build is loaded from its own path; the shipped solver is never overwritten)
     for r in $(seq 1 "${2:-2}"); do
         for so in tools/ab_tmp/*.so; do
-            cp "$so" $LIB
             printf "%-14s " "$(basename "$so" .so)"
-            python3 -m benchkit.ilqr --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; print(round(json.loads(sys.stdin.read())['value'], 1))"
+            python3 tools/ilqr_only.py mpc 1024 "$PWD/$so" 2>&1 | tail -1
         done
-    done
-    cp tools/ab_tmp/.shipped.so $LIB ;;
+    done ;;
 *)
     echo "usage: $0 build <rev>... | run [rounds]"; exit 2 ;;
 esac

@@ -1,9 +1,8 @@
 #!/bin/bash
 # Kernel-trace A/B of libtplhip.so builds on the default-grid plan: average k_backward3s time per build.
 R=$PWD
-cp tpl_amd/libtplhip.so tools/ab_tmp/.shipped_tplhip
 for so in tools/ab_tmp/tplhip_*.so; do
-  cp "$so" tpl_amd/libtplhip.so
+  export TPLHIP_LIB="$R/$so"      # loaded from its own path: the shipped library is never overwritten
   n=$(basename "$so" .so)
   (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/abtrace_$n -- python3 $R/tools/dp_default_plan.py > /dev/null 2>&1)
   python3 - $n <<'PY'
@@ -14,4 +13,4 @@ for r in csv.DictReader(open(f)):
         print(sys.argv[1], r['Name'].split('(')[0][-30:], r['Calls'], f"{float(r['AverageNs'])/1e3:.2f} us (min {float(r['MinNs'])/1e3:.2f})")
 PY
 done
-cp tools/ab_tmp/.shipped_tplhip tpl_amd/libtplhip.so
+unset TPLHIP_LIB

@@ -7,7 +7,6 @@ set -eu
 cd "$(dirname "$0")/.."
 REPO=$PWD
 INC="$REPO/tpl_amd/models/trajectory_tracking_mpc.inc"
-LIB=tpl_amd/models/libilqr_trajectory_tracking_mpc.so
 case "${1:-}" in
 build)
     mkdir -p tools/ab_tmp
@@ -20,13 +19,12 @@ build)
 run)
     OUT=${2:-gpurun_out/pmc_ilqr_lds}
     mkdir -p "$OUT"
-    cp $LIB tools/ab_tmp/.shipped_ilqr.so
+    # (the ablation builds are loaded from their own path -- tools/ilqr_only.py takes it -- and never installed over the
+    # shipped solver: they do not produce solutions)
     for v in 0 1 2; do
-        cp tools/ab_tmp/ilqr_abl$v.so $LIB
         (cd /tmp && TMPDIR=/tmp rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAVES \
-            --output-format csv -d "$REPO/$OUT/abl$v/pass1" -- python3 "$REPO/tools/ilqr_only.py" mpc > "$REPO/$OUT/abl$v.log" 2>&1) || echo "abl$v failed"
+            --output-format csv -d "$REPO/$OUT/abl$v/pass1" -- python3 "$REPO/tools/ilqr_only.py" mpc 1024 "$REPO/tools/ab_tmp/ilqr_abl$v.so" > "$REPO/$OUT/abl$v.log" 2>&1) || echo "abl$v failed"
         echo "== TPL_ILQR_ABLATE=$v"; python3 tools/pmc_summary.py "$OUT/abl$v" k_ilqr_update
-    done
-    cp tools/ab_tmp/.shipped_ilqr.so $LIB ;;
+    done ;;
 *) echo "usage: $0 build | run [outdir]"; exit 2 ;;
 esac

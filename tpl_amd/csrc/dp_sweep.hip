@@ -50,6 +50,10 @@
 //    registers = a wavefront per SIMD: the a1 rows only exist inside the arm of phase 1 that blends them.
 
 
+#ifndef TPL_SWEEP_VGUARD
+#define TPL_SWEEP_VGUARD 0
+#endif
+
 namespace tplhip {
 namespace {
 
@@ -375,6 +379,9 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             float g = sg[i] + ng;
             const float dj = nj - u.x;
             c += w_snap_v * (dj * dj);
+#if TPL_SWEEP_VGUARD            /* experiment (profiles/r04_dp_sweep_ablation.txt, block 12): skip the fp64 term where no lane of the wave exceeds the limit */
+            if (__builtin_amdgcn_ballot_w64(u.w > vmn) != 0ull)
+#endif
             g = (float)((double)g + fmax(now.tn_v_d[i] - (double)vmn, 0.0));
             const float s_change = tn_s - s;
             g += fmaxf(s_change - s_dist, 0.0f);
@@ -579,6 +586,9 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             float g = sg + ng;
             const float dj = nj - u.x;
             c += w_snap_v * (dj * dj);
+#if TPL_SWEEP_VGUARD
+            if (__builtin_amdgcn_ballot_w64(u.w > vmn) != 0ull)
+#endif
             g = (float)((double)g + fmax(e.tn_v_d - (double)vmn, 0.0));
             const float s_change = tn_s - s;
             g += fmaxf(s_change - s_dist, 0.0f);
