@@ -48,11 +48,16 @@
 //    6 -> 3 row loads for a third to a half of all actions (40.85 -> 39.79 us; k_backward3s: 4 -> 2, in the instance
 //    that does not request its first round early).  A conditional request that CROSSES a phase costs this compiler 8-14
 //    registers = a wavefront per SIMD: the a1 rows only exist inside the arm of phase 1 that blends them.
+// Round 4 (profiles/r04_dp_sweep_ablation.txt, blocks 12 and 13; both switches are gone again, `git log -S TPL_SWEEP_` finds them):
+//  * a wave-uniform guard around the fp64 speed-limit term -- `if (ballot(tn_v > vmn)) g = (float)((double)g + fmax(tn_v_d
+//    - vmn, 0))`, exact because adding +0.0 in double and rounding back is the identity -- LOSES: 39.47 -> 39.91 us per
+//    256x128x64 sweep, 10.75 -> 10.83 on 128x64x32.  With v up to 36 m/s against limits of 9-14 m/s most rows exceed the
+//    limit in every lane: compare and branch are paid everywhere, the six fp64 instructions saved on a third of the rows;
+//  * the a1 rows of the NEXT action requested a phase ahead straight into LDS (gfx950's `buffer_load_dwordx3 ... lds`,
+//    no vector register): lane i's 12 bytes land at M0 + 16 i (tools/micro/lds_direct_probe.hip), i.e. 3 KB per wavefront
+//    for the three rows, 21.9 KB per workgroup = seven workgroups per compute unit instead of eight: 37.96 -> 41.58 us
+//    (256x128x64), 319.6 -> 350.3 (512x256x128), bit-identical.  The sweep is at its plateau for this decomposition.
 
-
-#ifndef TPL_SWEEP_VGUARD
-#define TPL_SWEEP_VGUARD 0
-#endif
 
 namespace tplhip {
 namespace {
@@ -379,9 +384,6 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             float g = sg[i] + ng;
             const float dj = nj - u.x;
             c += w_snap_v * (dj * dj);
-#if TPL_SWEEP_VGUARD            /* experiment (profiles/r04_dp_sweep_ablation.txt, block 12): skip the fp64 term where no lane of the wave exceeds the limit */
-            if (__builtin_amdgcn_ballot_w64(u.w > vmn) != 0ull)
-#endif
             g = (float)((double)g + fmax(now.tn_v_d[i] - (double)vmn, 0.0));
             const float s_change = tn_s - s;
             g += fmaxf(s_change - s_dist, 0.0f);
@@ -586,9 +588,6 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             float g = sg + ng;
             const float dj = nj - u.x;
             c += w_snap_v * (dj * dj);
-#if TPL_SWEEP_VGUARD
-            if (__builtin_amdgcn_ballot_w64(u.w > vmn) != 0ull)
-#endif
             g = (float)((double)g + fmax(e.tn_v_d - (double)vmn, 0.0));
             const float s_change = tn_s - s;
             g += fmaxf(s_change - s_dist, 0.0f);
