@@ -48,7 +48,8 @@
 //    6 -> 3 row loads for a third to a half of all actions (40.85 -> 39.79 us; k_backward3s: 4 -> 2, in the instance
 //    that does not request its first round early).  A conditional request that CROSSES a phase costs this compiler 8-14
 //    registers = a wavefront per SIMD: the a1 rows only exist inside the arm of phase 1 that blends them.
-// Round 4 (profiles/r04_dp_sweep_ablation.txt, blocks 12 and 13; both switches are gone again, `git log -S TPL_SWEEP_` finds them):
+// Round 4 (profiles/r04_dp_sweep_ablation.txt, blocks 12 and 13; both switches are gone again: `git log -S TPL_SWEEP_VGUARD`
+// finds the first, profiles/r04_a1_lds_staging.patch is the second):
 //  * a wave-uniform guard around the fp64 speed-limit term -- `if (ballot(tn_v > vmn)) g = (float)((double)g + fmax(tn_v_d
 //    - vmn, 0))`, exact because adding +0.0 in double and rounding back is the identity -- LOSES: 39.47 -> 39.91 us per
 //    256x128x64 sweep, 10.75 -> 10.83 on 128x64x32.  With v up to 36 m/s against limits of 9-14 m/s most rows exceed the
