@@ -325,6 +325,76 @@ def mc_scenarios(ep, first, n):
     return occs, inits
 
 
+def dp_general_sweep_price(device, grid="target", plans=3):
+    """What leaving the plain-fp32 sweeps costs, and how often it happens ("fast-path fences"):
+    * us per sweep of this grid on the general kernel (TPLHIP_DEBUG=no_v3,no_s3: k_backward, two-pass argmin, IEEE
+      divisions, any input) next to the kernel the planner selects by itself, same plan, same box;
+    * the plain-fp32 sweep with both divisions as IEEE divisions (no_fastdiv) -- what a divisor without a proven
+      reciprocal form pays now that it no longer changes kernels;
+    * the kernel and the division forms the planner selects for path_step_size x s_max combinations (forms: 4 one
+      multiplication, 3 two-float reciprocal, 5 reciprocal + Newton step, 0 IEEE division; dp_sweep.hip)."""
+    import tpl_amd
+    from benchkit import scenarios as sc
+    S, V, A, T = sc.GRIDS[grid]
+    T = min(T, 6)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
+    env = tpl_amd.DynProgEnvironment(device)
+    env.reinit_buffers(ep)
+    env.set_occ_map(occ)
+    out = {"grid": [S, V, A], "t_steps": T}
+    saved = os.environ.get("TPLHIP_DEBUG")
+    try:
+        for key, dbg in (("selected", ""), ("path_step_0.7", ""), ("ieee_divisions", "no_fastdiv"), ("general", "no_v3,no_s3")):
+            os.environ["TPLHIP_DEBUG"] = dbg
+            p = sc.lon_params(S, V, A, T)
+            if key == "path_step_0.7":                     # not a power of two: two-float reciprocal behind the tiny-dividend test
+                p.path_step_size, p.path_steps = 0.7, 300
+            dp = tpl_amd.DynProgLonPlanner(device)
+            dp.reinit_buffers(p)
+            dp.upload([sc.initial_state(0.0, 8.0, 0.0)], sc.straight_path(p.path_steps, p.path_step_size))
+            dp.plan_resident(env)
+            dp.sync()
+            dp.timing_enable(True)
+            for _ in range(plans):
+                dp.plan_resident(env)
+            dp.sync()
+            ms, n = dp.timing_get()
+            dp.timing_enable(False)
+            info = dp.info()
+            out[key] = {"kernel": info["sweep"], "us_per_sweep": ms / max(1, n) * 1e3, "division_forms": [info["path_div3"], info["range_div3"]]}
+            del dp
+        os.environ["TPLHIP_DEBUG"] = ""
+        table = []
+        for s_max in (100.0, 157.3, 200.0):
+            for step in (0.1, 0.2, 0.25, 0.3, 0.5, 0.7, 0.75, 1.0, 1.3, 2.0):
+                p = sc.lon_params(S, V, A, 3)
+                p.s_max = s_max
+                p.path_step_size = step
+                p.path_steps = int(s_max / step) + 8
+                dp = tpl_amd.DynProgLonPlanner(device)
+                dp.reinit_buffers(p)
+                ep3 = sc.env_params(t_steps=3, s_steps=201, l_steps=31)
+                ep3.s_max = s_max
+                env3 = tpl_amd.DynProgEnvironment(device)
+                env3.reinit_buffers(ep3)
+                env3.set_occ_map(sc.occ_map(ep3, sc.OBSTACLES_OVERTAKE_TRAFFIC))
+                dp.update(sc.initial_state(0.0, 8.0, 0.0), sc.straight_path(p.path_steps, p.path_step_size), env3)
+                info = dp.info()
+                del env3
+                table.append({"path_step_size": step, "s_max": s_max, "kernel": info["sweep"],
+                              "division_forms": [info["path_div3"], info["range_div3"]]})
+                del dp
+        out["selection"] = table
+        out["on_plain_fp32_sweeps"] = sum(1 for r in table if r["kernel"] != "k_backward") / len(table)
+    finally:
+        if saved is None:
+            os.environ.pop("TPLHIP_DEBUG", None)
+        else:
+            os.environ["TPLHIP_DEBUG"] = saved
+    return out
+
+
 class _DeviceBytes:
     """Zero-copy view of device memory for torch (``__cuda_array_interface__``)."""
 
@@ -636,6 +706,7 @@ def worker(args):
                 il["cpu_baseline"] = ilqr_cpu_baseline(x0_mpc, 50, 10.0, "mpc")
                 lat["cpu_baseline"] = ilqr_cpu_baseline(x0_lat, 250, 6.0, "lateral")
             il["batch_sweep"] = bench_ilqr.batch_sweep(local_rank)
+            secondary["general_sweep"] = dp_general_sweep_price(local_rank)
             if not args.no_cpu_baseline:
                 secondary["ilqr_single_problem_crossover"] = ilqr_crossover(local_rank)
             from benchkit import latency

@@ -193,14 +193,14 @@ def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrie
     return out
 
 
-def batch_sweep(device=0, batches=(256, 512, 1024, 2048, 4096), updates=3, warmup=2, workload="mpc"):
-    """Problem-iterations/s against the batch size: 1024 problems are one wavefront per SIMD of the chip, so 2048 / 4096
-    show what a second / fourth wavefront per SIMD hides of the dependent chains."""
+def batch_sweep(device=0, batches=(256, 512, 1024, 2048, 4096, 8192), updates=3, warmup=2, workload="mpc"):
+    """Problem-iterations/s against the batch size: 1024 problems are one wavefront per SIMD of the chip; beyond that
+    update() takes the split-launch form, whose chain kernel keeps two wavefronts per SIMD resident (`form`)."""
     out = []
     for b in batches:
         r = run(device=device, batch=b, updates=updates, warmup=warmup, workload=workload)
-        out.append({"batch": b, "batched_iters_per_s": r["value"], "problem_iterations_per_s": r["problem_iterations_per_s"],
-                    "kernel_ms_per_update": r["kernel_ms_per_update"]})
+        out.append({"batch": b, "form": r["form"], "batched_iters_per_s": r["value"],
+                    "problem_iterations_per_s": r["problem_iterations_per_s"], "kernel_ms_per_update": r["kernel_ms_per_update"]})
     return out
 
 

@@ -322,13 +322,20 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
 // scale > 0 (the station-range divisor): the forms are compared on what the sweep derives from the quotient -- the
 // filter coordinate ((q * scale + 0.5) - 0.5, lon_planner.cu:35 + arr_tex_surf.cuh:142-149) -- not on the quotient
 // itself: for dividends below ~1e-34 their x * r_lo term underflows and the quotient's last bit can differ, but every
-// quotient below 2^-26 / scale yields the coordinate 0 either way.  scale == 0: raw quotients.
+// quotient below 2^-26 / scale yields the coordinate 0 either way.  scale == 0 (the path step): raw quotients, for the
+// dividends 0 and [2^-96, max]: below 2^-96 the products of the reciprocal forms underflow and their last bit is not the
+// division's for ANY divisor that is not a power of two (brute force on the host: every mismatch of 0.1, 0.2, 0.3, 0.7,
+// 0.75, 1.3 lies below 1.3e-31) -- the sweeps send a wavefront that holds such a dividend through an IEEE division
+// (kDivTinyBits, dp_sweep.hip), so the proof does not have to cover them.
 // ------------------------------------------------------------------------
+constexpr unsigned int kDivTinyBits = 0x0F800000u;      // 2^-96 as a float
+
 __global__ void k_verify_div(unsigned int* __restrict__ flags, float c, float r, float r_lo, float scale, unsigned int max_bits)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     bool bad_2 = false, bad_p = false, bad_n = false;
     for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= max_bits; b += stride) {
+        if (scale == 0.0f && b > 0 && b < kDivTinyBits) continue;
         const float x = __uint_as_float((unsigned int)b);
         const float qf = x / c;
         const float q2 = fmaf(x, r, x * r_lo);                       // two-float reciprocal r + r_lo

@@ -89,6 +89,19 @@ __device__ __forceinline__ float div_const(float x, float r_hi, float aux)
     return x / aux;
 }
 
+// The path-step division: the reciprocal forms are proven for the dividends 0 and [2^-96, max] (k_verify_div); a
+// wavefront in which any lane holds a positive dividend below that -- which takes a successor station that cancels to
+// within 1e-29 m of the road's origin -- divides the IEEE way.  One integer add, one compare and a branch never taken.
+template <int MODE>
+__device__ __forceinline__ float div_path(float x, float r_hi, float aux, float c)
+{
+    if (MODE == 3 || MODE == 5) {
+        const bool tiny = (__float_as_uint(x) - 1u) < (0x0F800000u - 1u);        // 0 < x < 2^-96 (x >= 0 here)
+        if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) return x / c;
+    }
+    return div_const<MODE>(x, r_hi, aux);
+}
+
 struct Node3 { float c, g, j; };
 
 // rule R3 (dp_lon_math.h, lerp1): 0 = fma(q, w, p (1 - w)), 1 = p (1 - w) + q w with every operation rounded, 2 = p + w (q - p)
@@ -373,7 +386,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                 issue(cur, A0_ROWS);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const float alpha = div_const<PATH_DIV>(tn_s, rp_hi, rp_lo);
+            const float alpha = div_path<PATH_DIV>(tn_s, rp_hi, rp_lo, p.path_step_size);
             const float f0 = fminf(floorf(alpha), path_top);
             const float pa = alpha - f0;
             const float pia = 1.0f - pa;
@@ -577,7 +590,7 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const float nc = blend1<LERP>(nl.x, nh.x, ws, iws);
             const float ng = blend1<LERP>(nl.y, nh.y, ws, iws);
             const float nj = blend1<LERP>(nl.z, nh.z, ws, iws);
-            const float alpha = div_const<PATH_DIV>(tn_s, rp_hi, rp_lo);
+            const float alpha = div_path<PATH_DIV>(tn_s, rp_hi, rp_lo, p.path_step_size);
             const float f0 = fminf(floorf(alpha), path_top);
             const float pa = alpha - f0;
             const float pia = 1.0f - pa;
