@@ -211,8 +211,15 @@ TPLHIP_API int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n);
  * which disagrees (tests/test_dp_reference_golden.py names the variant) is answered by this call:
  *   weight_quant  1 = filter weight rint(a * 256) / 256 (default), 2 = floor(a * 256) / 256, 0 = not quantised
  *   lerp_form     0 = fma(q, w, p * (1 - w)) (default), 1 = p * (1 - w) + q * w (every operation rounded), 2 = p + w * (q - p)
- * A non-default rule plans with the general sweep kernel (the plain-fp32 sweeps implement the default only). */
+ * The plain-fp32 sweeps are built for all nine combinations: the choice of kernel does not depend on the rule. */
 TPLHIP_API int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_form);
+/* Rule R1 of the same contract: 0 (default) = one IEEE rounding per operation of the reference source, 1 = the
+ * multiply-adds nvcc contracts by default in device code (-fmad=true: library/CMakeLists.txt passes nothing else to
+ * nvcc), written out as fma() calls -- lonDynamics (lon_planner.cu:240-250), interpPath (common.cuh:124-136), the grid
+ * points (lon_planner.cu:196-199, env.cu:144), s_dist and the cost sums of evalNode (lon_planner.cu:40-65, 84, 110,
+ * 148).  Deterministic (no compiler decides): oracle/dp_lon_oracle.c built -DDPO_R1_FMA=1 is the same arithmetic.
+ * Contracted plans run on the general kernels. */
+TPLHIP_API int tplhip_dp_lon_set_contraction(tplhip_dp_lon* h, int on);
 /* HIP-event timing of the backward sweeps (events recorded on the planner's
  * stream around the loop of launches).  enable=1 starts accumulating; get
  * returns the summed ms and the number of sweep launches since enable. */

@@ -56,13 +56,37 @@
  *   -DDPO_LERP_FORM=2      blend = p + w*(q-p)
  *   -ffp-contract=fast -mfma (instead of -ffp-contract=off): the compiler fuses
  *                          multiply-adds of lonDynamics / interpPath / the cost sums
- *                          like nvcc's default -fmad=true does
+ *                          like nvcc's default -fmad=true does -- but WHICH ones is
+ *                          this compiler's choice (gcc), not nvcc's
+ *   -DDPO_R1_FMA=1         (built -ffp-contract=off) the contraction written out: every
+ *                          a*b + c of the reference source whose product and sum have the
+ *                          same type becomes fma(a, b, c), a*b + c*d becomes
+ *                          fma(a, b, c*d), a - b*c becomes fma(-b, c, a) -- the
+ *                          left-to-right rule of LLVM's DAG combiner, which is what NVVM
+ *                          applies under nvcc's default -fmad=true.  A product whose sum is
+ *                          formed in another type (the float coordinate products that meet a
+ *                          double 0.5, lon_planner.cu:35; arr_tex_surf.cuh:148) has a conversion
+ *                          in between and stays unfused.  Deterministic across gcc / hipcc:
+ *                          the HIP planner's tplhip_dp_lon_set_contraction(h, 1) is
+ *                          compared with this build bit for bit.  The sites:
+ *                            lonDynamics  s: fmaf(v,dt,s) -> fma((.5a)dt, dt, .) -> fma(((j/6)dt)dt, dt, .)
+ *                                         v: fmaf(a,dt,v) -> fma((.5j)dt, dt, .);  a: fmaf(j,dt,a)
+ *                            interpPath   fmaf(p0, 1-alpha, p1*alpha) per field
+ *                            grid points  fmaf((float)i, step, min) for t, s, v, a and the dist-map stations
+ *                            evalNode     s_dist = fma(-len, 0.6, interp); the two double cost terms;
+ *                                         gap = fmaf(v, time_gap, gap_min) - s_dist; the action jerk
+ *                                         fmaf(j_max-j_min, k/(N-1), j_min); cost = fmaf(w_snap, d*d, cost)
+ *                          (sums whose other addend is the literal 0 -- "cost = 0; cost += w*x" --
+ *                          give the product's own rounding either way.)
  */
 #ifndef DPO_WEIGHT_QUANT
 #define DPO_WEIGHT_QUANT 1
 #endif
 #ifndef DPO_LERP_FORM
 #define DPO_LERP_FORM 0
+#endif
+#ifndef DPO_R1_FMA
+#define DPO_R1_FMA 0
 #endif
 #include "../include/tplhip.h"
 
@@ -79,6 +103,15 @@
 
 static inline int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+/* rule R1: a*b + c in float / in double, unfused (default) or contracted (-DDPO_R1_FMA=1) */
+#if DPO_R1_FMA
+static inline float  madf(float a, float b, float c)    { return fmaf(a, b, c); }
+static inline double madd(double a, double b, double c) { return fma(a, b, c); }
+#else
+static inline float  madf(float a, float b, float c)    { return a * b + c; }
+static inline double madd(double a, double b, double c) { return a * b + c; }
+#endif
+
 /* ------------------------------------------------------------ dynamics -- */
 
 /* lon_planner.cu:240-250 */
@@ -89,17 +122,17 @@ DPO_API void dpo_lon_dynamics(const TplLonState* x0, float j, float dt, TplLonSt
     r.t = x0->t + dt;
     {
         /* x0.s + x0.v*dt is float; the 0.5 and 1.0/6.0 literals promote the rest to double */
-        float  sf = x0->s + x0->v * dt;
-        double sd = (double)sf + ((0.5 * (double)x0->a) * (double)dt) * (double)dt;
-        sd = sd + ((((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt) * (double)dt;
+        float  sf = madf(x0->v, dt, x0->s);
+        double sd = madd((0.5 * (double)x0->a) * (double)dt, (double)dt, (double)sf);
+        sd = madd((((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt, (double)dt, sd);
         r.s = fmaxf(x0->s, (float)sd);
     }
     {
-        float  vf = x0->v + x0->a * dt;
-        double vd = (double)vf + ((0.5 * (double)j) * (double)dt) * (double)dt;
+        float  vf = madf(x0->a, dt, x0->v);
+        double vd = madd((0.5 * (double)j) * (double)dt, (double)dt, (double)vf);
         r.v = fmaxf(0.0f, (float)vd);
     }
-    r.a = x0->a + j * dt;
+    r.a = madf(j, dt, x0->a);
     r.j = j;
     *out = r;
 }
@@ -130,7 +163,7 @@ DPO_API void dpo_interp_path(const float* path, float distance, float path_step_
     const float* p1 = path + (size_t)i1 * 7;
     float* r = (float*)&res;
     for (int c = 0; c < 7; ++c) {
-        r[c] = p0[c] * alpha_inv + p1[c] * alpha;
+        r[c] = madf(p0[c], alpha_inv, p1[c] * alpha);
     }
     *out = res;
 }
@@ -208,7 +241,7 @@ DPO_API void dpo_dist_map_path(const TplDpEnvParams* ep, const float* occ_lst,
     for (int idx_t = 0; idx_t < ep->t_steps; ++idx_t) {
         float d = 10000.0f;
         for (int idx_s = ep->s_steps - 1; idx_s >= 0; --idx_s) {
-            const float s = ep->s_min + (float)idx_s * ep->_s_step_size;
+            const float s = madf((float)idx_s, ep->_s_step_size, ep->s_min);
             TplPathState cps;
             dpo_interp_path(path, s, path_step_size, path_steps, &cps);
             float fs = (cps.s - ep->s_min) / ep->_s_step_size;
@@ -281,17 +314,17 @@ DPO_API void dpo_eval_node(const TplDpLonParams* p, const TplDpEnvParams* ep, in
     dpo_interp_path(path, tp->s, p->path_step_size, p->path_steps, &cps);
 
     const float v_max = cps.v_max;
-    const float s_dist = (float)((double)dpo_interp_dist_map_path(ep, dist_ts, tp->t, cps.s)
-                                 - (double)p->length_veh * 0.6);
+    const float s_dist = (float)madd(-(double)p->length_veh, 0.6,
+                                     (double)dpo_interp_dist_map_path(ep, dist_ts, tp->t, cps.s));
 
     /* stateCost :40-55 */
     float state_cost = 0.0f;
     state_cost += p->w_a * (tp->a * tp->a);
-    state_cost = (float)((double)state_cost + (double)p->w_progress * fabs(1000.0 - (double)tp->s));
+    state_cost = (float)madd((double)p->w_progress, fabs(1000.0 - (double)tp->s), (double)state_cost);
     {
-        float gap = tp->v * p->time_gap + p->gap_min - s_dist;
+        float gap = madf(tp->v, p->time_gap, p->gap_min) - s_dist;
         double m = (double)gap > 0.0 ? (double)gap : 0.0;           /* max(0.0, gap) */
-        state_cost = (float)((double)state_cost + (double)p->w_safety_dist * m);
+        state_cost = (float)madd((double)p->w_safety_dist, m, (double)state_cost);
     }
 
     float state_constr = 0.0f;
@@ -310,7 +343,7 @@ DPO_API void dpo_eval_node(const TplDpLonParams* p, const TplDpEnvParams* ep, in
     const int n_eval = choose_action ? N : 1;
     for (int j_idx = 0; j_idx < n_eval; ++j_idx) {
         const float j = choose_action
-            ? p->j_min + (p->j_max - p->j_min) * ((float)j_idx / (float)(N - 1))
+            ? madf(p->j_max - p->j_min, (float)j_idx / (float)(N - 1), p->j_min)
             : tp->j;
 
         TplLonState tn;
@@ -323,7 +356,7 @@ DPO_API void dpo_eval_node(const TplDpLonParams* p, const TplDpEnvParams* ep, in
         dpo_read_node(p, table_next, tn.s, tn.v, tn.a, node);
         cost += node[0];
         constr += node[1];
-        cost += p->w_snap * ((node[2] - j) * (node[2] - j));
+        cost = madf(p->w_snap, (node[2] - j) * (node[2] - j), cost);
         {
             float c = 0.0f;                                         /* stateActionCost :57-64 */
             c += p->w_j * ((j * dt) * (j * dt));
@@ -370,7 +403,7 @@ DPO_API void dpo_eval_node(const TplDpLonParams* p, const TplDpEnvParams* ep, in
             idx_min = k;
         }
     }
-    tp->j = p->j_min + (p->j_max - p->j_min) * ((float)idx_min / (float)(N - 1));
+    tp->j = madf(p->j_max - p->j_min, (float)idx_min / (float)(N - 1), p->j_min);
     tp->cost = cost_min;
     tp->constr = constr_min;
 }
@@ -394,10 +427,10 @@ DPO_API void dpo_backward_stage(const TplDpLonParams* p, const TplDpEnvParams* e
             for (int is = 0; is < S; ++is) {
                 TplLonState tp;
                 memset(&tp, 0, sizeof tp);
-                tp.t = p->dt_start + (float)(idx_t - 1) * p->dt;
-                tp.s = p->s_min + (float)is * p->_s_step_size;
-                tp.v = p->v_min + (float)iv * p->_v_step_size;
-                tp.a = p->a_min + (float)ia * p->_a_step_size;
+                tp.t = madf((float)(idx_t - 1), p->dt, p->dt_start);
+                tp.s = madf((float)is, p->_s_step_size, p->s_min);
+                tp.v = madf((float)iv, p->_v_step_size, p->v_min);
+                tp.a = madf((float)ia, p->_a_step_size, p->a_min);
                 dpo_eval_node(p, ep, 9, &tp, table_next, path, dist_ts, p->dt, 1, force_terminal);
                 float* o = table_out + (((size_t)ia * V + iv) * S + is) * 4;
                 o[0] = tp.cost; o[1] = tp.constr; o[2] = tp.j; o[3] = 0.0f;

@@ -40,6 +40,8 @@ VARIANTS = [
     ("lerp1", "blend p(1-w) + qw, every operation rounded"),
     ("lerp2", "blend p + w(q-p)"),
     ("fma_wfloor", "FMA contraction AND truncated weights"),
+    ("fma_explicit", "R1 flipped deterministically: the multiply-adds nvcc -fmad=true contracts, written out as fma() (-DDPO_R1_FMA=1)"),
+    ("fma_explicit_wfloor", "explicit contraction AND truncated weights"),
 ]
 
 CASES = {
@@ -99,6 +101,8 @@ def compare(base, var):
 
 def main():
     quick = "--quick" in sys.argv
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--variants=")]
+    variants = [(v, d) for v, d in VARIANTS if not only or v in only[0]]
     n_inits = 8 if quick else 64
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "sensitivity"], stdout=subprocess.DEVNULL)
     out = {"what": __doc__.split("\n\n")[0], "initial_states_per_case": n_inits, "cases": {}}
@@ -108,13 +112,13 @@ def main():
         O.use(None)
         base = plan(case, n_inits)
         res = {}
-        for v, desc in VARIANTS:
+        for v, desc in variants:
             O.use(os.path.join(ROOT, "oracle", "_sens", f"libdp_lon_oracle_{v}.so"))
             res[v] = dict(compare(base, plan(case, n_inits)), variant=desc)
             print(f"[{cname}] {v}: {res[v]}", file=sys.stderr, flush=True)
         O.use(None)
         out["cases"][cname] = res
-    dst = os.path.join(ROOT, "profiles", "r02_dp_parity_sensitivity.json")
+    dst = os.path.join(ROOT, "profiles", "r04_dp_parity_sensitivity.json" if only else "r02_dp_parity_sensitivity.json")
     if not quick:
         with open(dst, "w") as fd:
             json.dump(out, fd, indent=1)

@@ -526,6 +526,61 @@ def test_filter_rule_variants_match_their_oracle_builds(name, quant, lerp, monke
         dp.set_filter_rule(3, 0)
 
 
+@pytest.mark.parametrize("name,quant,lerp", [("fma_explicit", 1, 0), ("fma_explicit_wfloor", 2, 0)])
+def test_contraction_matches_its_oracle_build(name, quant, lerp):
+    """R1 as a run-time choice (tplhip_dp_lon_set_contraction): the multiply-adds nvcc contracts by default, written out
+    as fma() on both sides -- no compiler decides what fuses.  The HIP planner with contraction on reproduces the
+    restatement built -DDPO_R1_FMA=1 bit for bit (distance map, tables, rollouts, re-evaluation) on a small and a
+    several-rounds-deep grid, on its general kernels; switching it off again restores the default tables and the
+    plain-fp32 sweep."""
+    import os
+    import subprocess
+    odir = os.path.join(O.ROOT, "oracle")
+    lib = os.path.join(odir, f"_sens/libdp_lon_oracle_{name}.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", odir, f"_sens/libdp_lon_oracle_{name}.so"])
+    for (S, V, A, T), want_default, dt_start in (((201, 37, 20, 6), "k_backward3s", None), ((128, 64, 66, 3), "k_backward3v", 0.4)):
+        p = sc.lon_params(S, V, A, T, dt_start=dt_start)
+        ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31, dt_start=dt_start)
+        path = sc.straight_path(p.path_steps, p.path_step_size)
+        path[:, 2] *= 0.97                                              # stations lag the distance: interpPath blends for real
+        path[:, 5] += 0.3 * np.sin(np.arange(p.path_steps) / 7.0).astype(np.float32)
+        occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
+        inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(4, seed=3)
+        cp, cep = O.cparams(p), O.cparams(ep)
+        O.use(lib)
+        try:
+            tables, otrajs, dist = O.update(cp, cep, path, occ, inits)
+        finally:
+            O.use(None)
+        env = tpl_amd.DynProgEnvironment()
+        env.reinit_buffers(ep)
+        env.set_occ_map(occ)
+        dp = tpl_amd.DynProgLonPlanner()
+        dp.reinit_buffers(p)
+        dp.set_contraction(True)
+        dp.set_filter_rule(quant, lerp)
+        trajs = dp.update_batch(inits, path, env)
+        assert dp.info()["sweep"] == "k_backward", dp.info()
+        assert np.array_equal(env.get_dist_map_path().view(np.uint32), dist.view(np.uint32))
+        _assert_tables_equal(dp, tables, T)
+        for r, tr in enumerate(trajs):
+            assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (name, r)
+        for r, tr in enumerate(trajs):                                  # re-costing a plan gives the forward pass' numbers
+            again = _traj_np(dp.reeval_traj(tr, path, env))
+            assert np.array_equal(again[:, 5:].view(np.uint32), otrajs[r][:, 5:].view(np.uint32)), (name, "reeval", r)
+        # off again (and the default filter rule): default tables, default kernel
+        dp.set_contraction(False)
+        dp.set_filter_rule(1, 0)
+        trajs = dp.update_batch(inits, path, env)
+        assert dp.info()["sweep"] == want_default, dp.info()
+        tables0, otrajs0, _ = O.update(cp, cep, path, occ, inits)
+        _assert_tables_equal(dp, tables0, T)
+        assert any(not np.array_equal(tables0[t].view(np.uint32), tables[t].view(np.uint32)) for t in range(1, T)), "contraction changes nothing here"
+    with pytest.raises(ValueError):
+        dp.set_contraction(2)
+
+
 @pytest.mark.parametrize("dt_start", [None, 0.3, 0.6])
 def test_forward_rollout_forms_agree(dt_start, monkeypatch):
     """The rollout runs with one step of speculation (eight wavefronts) where the table set fits the Infinity Cache and

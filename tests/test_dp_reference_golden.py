@@ -46,7 +46,11 @@ VARIANTS = [("contract", None, "the checker: no contraction, weight rint(a*256)/
             ("wnone", "_sens/libdp_lon_oracle_wnone.so", "R2: weight not quantised"),
             ("lerp1", "_sens/libdp_lon_oracle_lerp1.so", "R3: blend p*(1-w) + q*w, every operation rounded"),
             ("lerp2", "_sens/libdp_lon_oracle_lerp2.so", "R3: blend p + w*(q-p)"),
-            ("fma_wfloor", "_sens/libdp_lon_oracle_fma_wfloor.so", "R1 + R2: contracted AND truncated weights")]
+            ("fma_wfloor", "_sens/libdp_lon_oracle_fma_wfloor.so", "R1 + R2: contracted AND truncated weights"),
+            # the same flip of R1 WITHOUT a compiler in the loop: every contracted multiply-add written as fma()
+            # (left-to-right, as NVVM's DAG combiner folds them); the HIP planner follows with set_contraction(True)
+            ("fma_explicit", "_sens/libdp_lon_oracle_fma_explicit.so", "R1: explicit fma() at every site nvcc -fmad=true contracts -> DynProgLonPlanner.set_contraction(True)"),
+            ("fma_explicit_wfloor", "_sens/libdp_lon_oracle_fma_explicit_wfloor.so", "R1 + R2: explicit contraction AND truncated weights -> set_contraction(True) + set_filter_rule(2, 0)")]
 
 
 def variant_table(g):

@@ -277,10 +277,11 @@ void pick_div_forms(tplhip_dp_lon* h)
 
 // k_backward3v (dp_sweep.hip): the two-rows-per-lane geometry with the plain-fp32 instruction stream.  Needs buffer
 // loads and non-negative weights (integer-key argmin).  Every filter rule and every divisor runs on it: a division
-// without a proven cheap form is an IEEE division (pick_div_forms).
+// without a proven cheap form is an IEEE division (pick_div_forms).  Contracted arithmetic (rule R1 = 1,
+// tplhip_dp_lon_set_contraction) is the general kernels' alone: the plain-fp32 sweeps pre-fold unfused sub-expressions.
 bool use_v3(const tplhip_dp_lon* h)
 {
-    return !h->no_v3 && h->use_buf && h->weights_nonneg
+    return !h->no_v3 && h->use_buf && h->weights_nonneg && !h->rule.fma
            && backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps) <= 64 * 1024;
 }
 
@@ -413,7 +414,7 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState
         hipLaunchKernelGGL(k_dist_map_path, dim3(env->params.t_steps), dim3(256),
                            dist_slice_lds_bytes(env->params.s_steps), h->stream,
                            env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params,
-                           (size_t)0, (size_t)0, (size_t)0);
+                           (size_t)0, (size_t)0, (size_t)0, h->rule);
         hipLaunchKernelGGL(k_stage_prelude, dim3(T), dim3(256), 0, h->stream,
                            h->d_pre_vmax, h->d_pre_sdist, h->d_pre_prog, h->d_path, env->d_dist, p, env->params,
                            (size_t)0, (size_t)0, (size_t)0, h->rule);
@@ -1175,7 +1176,7 @@ int tplhip_dp_lon_reeval(tplhip_dp_lon* h, const TplLonState* traj, int len, con
     hipLaunchKernelGGL(k_dist_map_path, dim3(env->params.t_steps), dim3(256),
                        dist_slice_lds_bytes(env->params.s_steps), h->stream,
                        env->d_dist, env->d_occ, h->d_path, p.path_steps, p.path_step_size, env->params,
-                       (size_t)0, (size_t)0, (size_t)0);
+                       (size_t)0, (size_t)0, (size_t)0, h->rule);
     hipLaunchKernelGGL(k_reeval, dim3((len + 63) / 64), dim3(64), 0, h->stream,
                        h->d_reeval, h->d_tables, h->table_cells, h->d_path, env->d_dist, p, env->params, h->rule);
     HIP_TRY(hipGetLastError(), "reeval launch failed");
@@ -1229,8 +1230,8 @@ int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_f
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     int rc = wait_pending_forwards(h);
     if (rc) return rc;
-    h->rule = FilterRule{weight_quant, lerp_form};
-    h->rule_set = !(weight_quant == kDefaultRule.quant && lerp_form == kDefaultRule.lerp);
+    h->rule = FilterRule{weight_quant, lerp_form, h->rule.fma};
+    h->rule_set = !(weight_quant == kDefaultRule.quant && lerp_form == kDefaultRule.lerp && h->rule.fma == 0);
     if (h->have_params) pick_div_forms(h);
     h->tables_valid = false;
     if (h->have_params && h->d_acts) {
@@ -1239,6 +1240,21 @@ int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_f
         HIP_TRY(hipGetLastError(), "action table launch failed");
     }
     return TPLHIP_OK;
+}
+
+// R1 of the HP-1 arithmetic contract as a run-time choice: 0 = one rounding per operation of the reference source (the
+// default), 1 = the multiply-adds nvcc's default -fmad=true contracts, written out as fma() (FilterRule::fma in
+// dp_lon_math.h; the sites are listed in the header of oracle/dp_lon_oracle.c).  Rebuilds the action table.  Contracted
+// plans run on the general kernels (two-pass argmin sweep, rollout, re-evaluation, stage prelude, distance map).
+int tplhip_dp_lon_set_contraction(tplhip_dp_lon* h, int on)
+{
+    if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
+    if (on != 0 && on != 1) return tplhip_fail(TPLHIP_EINVAL, "contraction: 0 (one rounding per operation) or 1 (fused multiply-adds)");
+    const FilterRule r = h->rule;
+    h->rule.fma = on;
+    const int rc = tplhip_dp_lon_set_filter_rule(h, r.quant, r.lerp);
+    if (rc) h->rule = r;
+    return rc;
 }
 
 int tplhip_dp_lon_timing_enable(tplhip_dp_lon* h, int enable)
@@ -1389,7 +1405,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
 
     hipLaunchKernelGGL(k_dist_map_path, dim3(ep.t_steps, count), dim3(256), dist_slice_lds_bytes(ep.s_steps), h->stream,
                        h->d_sc_dist, h->d_sc_occ + occ_elems * first, paths, p.path_steps, p.path_step_size, ep,
-                       dist_elems, occ_elems, path_stride);
+                       dist_elems, occ_elems, path_stride, h->rule);
     hipLaunchKernelGGL(k_stage_prelude, dim3(T, count), dim3(256), 0, h->stream,
                        h->d_sc_pre_vmax, h->d_sc_pre_sdist, h->d_pre_prog, paths, h->d_sc_dist, p, ep,
                        pre_stride, path_stride, dist_elems, h->rule);

@@ -30,16 +30,24 @@ __global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p, Fi
 
     TplLonState tp;
     tp.t = 0.0f; tp.s = 0.0f; tp.j = 0.0f; tp.cost = 0.0f; tp.constr = 0.0f;
-    tp.v = p.v_min + (float)iv * p._v_step_size;      // lon_planner.cu:198
-    tp.a = p.a_min + (float)ia * p._a_step_size;      // lon_planner.cu:199
+    tp.v = grid_pt(p.v_min, (float)iv, p._v_step_size, rule);      // lon_planner.cu:198
+    tp.a = grid_pt(p.a_min, (float)ia, p._a_step_size, rule);      // lon_planner.cu:199
     const float dt = p.dt;
-    const float j = action_jerk(p, k, N_BWD);
-    const TplLonState tn = lon_dynamics(tp, j, dt);
+    const float j = action_jerk(p, k, N_BWD, rule);
+    const TplLonState tn = lon_dynamics(tp, j, dt, rule);
 
     ActDesc d;
-    d.a_term = ((0.5 * (double)tp.a) * (double)dt) * (double)dt;
-    d.j_term = ((((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt) * (double)dt;
-    d.vdt = tp.v * dt;
+    if (rule.fma) {
+        // contracted station update (rule R1 = 1): s' = fma(j_term, dt, fma(a_term, dt, (double)fmaf(vdt, dt, s))) -- the
+        // last factor dt of each product is fused with its sum, so the descriptor carries the factors in front of it
+        d.a_term = (0.5 * (double)tp.a) * (double)dt;
+        d.j_term = (((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt;
+        d.vdt = tp.v;
+    } else {
+        d.a_term = ((0.5 * (double)tp.a) * (double)dt) * (double)dt;
+        d.j_term = ((((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt) * (double)dt;
+        d.vdt = tp.v * dt;
+    }
     d.j = j;
     d.wj_cost = state_action_cost(p, j, dt);
     // lon_planner.cu:125-130: a' < a_min and a' > a_max exclude each other, and adding the
@@ -76,18 +84,18 @@ __global__ void k_stage_prelude(float* __restrict__ pre_vmax, float* __restrict_
     pre_sdist += blockIdx.y * stride_pre;
     path += blockIdx.y * stride_path;
     dist_ts += blockIdx.y * stride_dist;
-    const float t = p.dt_start + (float)(idx_t - 1) * p.dt;       // lon_planner.cu:196
+    const float t = grid_pt(p.dt_start, (float)(idx_t - 1), p.dt, rule);       // lon_planner.cu:196
     for (int is = threadIdx.x; is < p.s_steps; is += blockDim.x) {
-        const float s = p.s_min + (float)is * p._s_step_size;     // lon_planner.cu:197
+        const float s = grid_pt(p.s_min, (float)is, p._s_step_size, rule);     // lon_planner.cu:197
         const PathTap pt = path_tap(s, p.path_step_size, p.path_steps);
-        const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
-        const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
-        const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, t, cps_s, rule)
-                                     - (double)p.length_veh * 0.6);
+        const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2], rule);
+        const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5], rule);
+        const float s_dist = s_dist_of(interp_dist_map_path(ep, dist_ts, t, cps_s, rule), p, rule);
         pre_vmax[(size_t)idx_t * p.s_steps + is] = v_max;
         pre_sdist[(size_t)idx_t * p.s_steps + is] = s_dist;
         if (idx_t == 1 && blockIdx.y == 0) {
-            pre_prog[is] = (double)p.w_progress * fabs(1000.0 - (double)s);
+            // (contracted arithmetic fuses the product with the cost sum: the table then carries the multiplicand)
+            pre_prog[is] = rule.fma ? fabs(1000.0 - (double)s) : (double)p.w_progress * fabs(1000.0 - (double)s);
         }
     }
 }
@@ -156,9 +164,9 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
     const bool active = row_ok && is < S;
     (void)nblocks;
 
-    const float s = p.s_min + (float)is * p._s_step_size;
-    const float v = p.v_min + (float)iv * p._v_step_size;
-    const float a = p.a_min + (float)ia * p._a_step_size;
+    const float s = grid_pt(p.s_min, (float)is, p._s_step_size, rule);
+    const float v = grid_pt(p.v_min, (float)iv, p._v_step_size, rule);
+    const float a = grid_pt(p.a_min, (float)ia, p._a_step_size, rule);
 
     float v_max = 0.0f, s_dist = 0.0f;
     double prog = 0.0;
@@ -171,11 +179,11 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
     // stateCost lon_planner.cu:40-55 (progress term precomputed per station)
     float sc = 0.0f;
     sc += p.w_a * (a * a);
-    sc = (float)((double)sc + prog);
+    sc = rule.fma ? (float)fma((double)p.w_progress, prog, (double)sc) : (float)((double)sc + prog);
     {
-        const float gap = v * p.time_gap + p.gap_min - s_dist;
+        const float gap = madf(v, p.time_gap, p.gap_min, rule) - s_dist;
         const double m = fmax(0.0, (double)gap);
-        sc = (float)((double)sc + (double)p.w_safety_dist * m);
+        sc = (float)madd((double)p.w_safety_dist, m, (double)sc, rule);
     }
     float sg = 0.0f;
     if (v > v_max) sg += v - v_max;
@@ -248,10 +256,17 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
             if (active) {
                 const ActDesc* d = acts + (size_t)row * N_BWD + k;
                 // lonDynamics station part, lon_planner.cu:244
-                const float sf = s + d->vdt;
-                double sd = (double)sf + d->a_term;
-                sd = sd + d->j_term;
-                const float tn_s = fmaxf(s, (float)sd);
+                float tn_s;
+                if (rule.fma) {                        // see k_build_actions: the descriptor carries the factors in front of dt
+                    const float sf = fmaf(d->vdt, p.dt, s);
+                    const double sd = fma(d->j_term, (double)p.dt, fma(d->a_term, (double)p.dt, (double)sf));
+                    tn_s = fmaxf(s, (float)sd);
+                } else {
+                    const float sf = s + d->vdt;
+                    double sd = (double)sf + d->a_term;
+                    sd = sd + d->j_term;
+                    tn_s = fmaxf(s, (float)sd);
+                }
                 // readNode coordinate along s (lon_planner.cu:35).  tn_s >= s >= s_min, so the
                 // coordinate is never negative and only the upper clamp can bite.
                 const float xs = tn_s - p.s_min;
@@ -267,13 +282,13 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
                 // interpPath(tn.s).v_max, lon_planner.cu:114
                 const float alpha = tn_s / p.path_step_size;
                 const PathTap pt = path_tap_q(alpha, p.path_steps);
-                const float vmn = path_lerp(pt, pv[pt.i0], pv[pt.i1]);
+                const float vmn = path_lerp(pt, pv[pt.i0], pv[pt.i1], rule);
 
                 c = sc;
                 g = sg;
                 c += node.x;
                 g += node.y;
-                c += p.w_snap * ((node.z - d->j) * (node.z - d->j));
+                c = madf(p.w_snap, (node.z - d->j) * (node.z - d->j), c, rule);
                 c += d->wj_cost;
                 // lon_planner.cu:114-118 compares and subtracts in double; float -> double is
                 // exact and order preserving, so the test itself can stay in float
@@ -307,7 +322,7 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
             idx_min = k;
         }
     }
-    const float j_best = action_jerk(p, idx_min, N_BWD);
+    const float j_best = action_jerk(p, idx_min, N_BWD, rule);
     st_node(out + (size_t)row * S + is, cost_min, constr_min, j_best);
 }
 
@@ -391,20 +406,19 @@ __device__ __forceinline__ LaneEval eval_lane(const TplLonState& tp, float j, co
                                               const TplDpLonParams& p, const TplDpEnvParams& ep, float dt, FilterRule rule)
 {
     const PathTap pt = path_tap(tp.s, p.path_step_size, p.path_steps);
-    const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
-    const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
-    const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, tp.t, cps_s, rule)
-                                 - (double)p.length_veh * 0.6);
-    const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist);
+    const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2], rule);
+    const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5], rule);
+    const float s_dist = s_dist_of(interp_dist_map_path(ep, dist_ts, tp.t, cps_s, rule), p, rule);
+    const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist, rule);
     float sg = 0.0f;
     if (tp.v > v_max) sg += tp.v - v_max;
     if (roundf(tp.t / p.dt) == (float)(p.t_steps - 1)) return LaneEval{sc, 0.0f, sc, true};    // lon_planner.cu:93-97
-    const TplLonState tn = lon_dynamics(tp, j, dt);
+    const TplLonState tn = lon_dynamics(tp, j, dt, rule);
     const float4 node = read_node(p, table_next, tn.s, tn.v, tn.a, rule);
     const PathTap pn = path_tap(tn.s, p.path_step_size, p.path_steps);
-    const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5]);
+    const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5], rule);
     const ActionResult r = eval_action_tail(p, sc, sg, node, j, state_action_cost(p, j, dt),
-                                            tn.s, tn.v, tn.a, tp.s, s_dist, vmn);
+                                            tn.s, tn.v, tn.a, tp.s, s_dist, vmn, rule);
     return LaneEval{r.cost, r.constr, sc, false};
 }
 
@@ -437,7 +451,7 @@ __device__ __forceinline__ int eval_node_wave(TplLonState& tp, const Node* __res
 {
     const int lane = threadIdx.x & 63;
     const int k = choose_action ? lane : 0;
-    const float j = choose_action ? action_jerk(p, k < N ? k : N - 1, N) : tp.j;
+    const float j = choose_action ? action_jerk(p, k < N ? k : N - 1, N, rule) : tp.j;
     const LaneEval e = eval_lane(tp, j, table_next, path, dist_ts, p, ep, dt, rule);
     if (e.terminal) {
         tp.cost = e.sc;
@@ -449,7 +463,7 @@ __device__ __forceinline__ int eval_node_wave(TplLonState& tp, const Node* __res
         return -1;
     }
     const Choice c = choose_action_wave(lane < N, e.cost, e.constr, 0);
-    tp.j = action_jerk(p, c.lane, N);
+    tp.j = action_jerk(p, c.lane, N, rule);
     tp.cost = c.cost;
     tp.constr = c.constr;
     return c.lane;
@@ -476,24 +490,23 @@ __device__ __forceinline__ void eval_node_wave_seq(TplLonState& tp, const Node* 
 {
     const int lane = threadIdx.x & 63;
     const PathTap pt = path_tap(tp.s, p.path_step_size, p.path_steps);
-    const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
-    const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
-    const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, tp.t, cps_s, rule)
-                                 - (double)p.length_veh * 0.6);
-    const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist);
+    const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2], rule);
+    const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5], rule);
+    const float s_dist = s_dist_of(interp_dist_map_path(ep, dist_ts, tp.t, cps_s, rule), p, rule);
+    const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist, rule);
     float sg = 0.0f;
     if (tp.v > v_max) sg += tp.v - v_max;
     if (roundf(tp.t / p.dt) == (float)(p.t_steps - 1)) {    // lon_planner.cu:93-97
         tp.cost = sc;
         return;
     }
-    const float j = action_jerk(p, lane < N ? lane : N - 1, N);
-    const TplLonState tn = lon_dynamics(tp, j, dt);
+    const float j = action_jerk(p, lane < N ? lane : N - 1, N, rule);
+    const TplLonState tn = lon_dynamics(tp, j, dt, rule);
     const float4 node = read_node(p, table_next, tn.s, tn.v, tn.a, rule);
     const PathTap pn = path_tap(tn.s, p.path_step_size, p.path_steps);
-    const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5]);
+    const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5], rule);
     const ActionResult r = eval_action_tail(p, sc, sg, node, j, state_action_cost(p, j, dt),
-                                            tn.s, tn.v, tn.a, tp.s, s_dist, vmn);
+                                            tn.s, tn.v, tn.a, tp.s, s_dist, vmn, rule);
     const bool valid = lane < N;
     const float g_in = (valid && !(r.constr != r.constr)) ? r.constr : INFINITY;       // lon_planner.cu:155
     const float constr_min = wave_min(g_in);
@@ -502,7 +515,7 @@ __device__ __forceinline__ void eval_node_wave_seq(TplLonState& tp, const Node* 
     const float cost_min = wave_min(c_in);
     const unsigned long long hit = __ballot(cand && c_in == cost_min && cost_min < INFINITY);
     const int idx_min = hit ? (int)__builtin_ctzll(hit) : 0;
-    tp.j = action_jerk(p, idx_min, N);
+    tp.j = action_jerk(p, idx_min, N, rule);
     tp.cost = cost_min;
     tp.constr = constr_min;
 }
@@ -557,7 +570,7 @@ __global__ void __launch_bounds__(64) k_forward_seq(TplLonState* __restrict__ tr
             }
             __syncthreads();
         }
-        if (i < T - 1) tp = lon_dynamics(tp, tp.j, dt);
+        if (i < T - 1) tp = lon_dynamics(tp, tp.j, dt, rule);
     }
     if (done_flag) {
         __threadfence_system();
@@ -635,8 +648,8 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
             const int k = eval_node_wave<N_FWD>(a, table1, pth, dst, p, ep, dt0, true, rule);
             if (lane == 0) { x_cur[par] = a; x_k[par] = k; }
         } else if (have2) {
-            b = lon_dynamics(tp, action_jerk(p, 3 * wave + grp, N_FWD), dt0);            // state i+1 if action 3 wave + grp wins
-            e2 = eval_lane(b, action_jerk(p, min(m, N_FWD - 1), N_FWD), table2, pth, dst, p, ep, p.dt, rule);
+            b = lon_dynamics(tp, action_jerk(p, 3 * wave + grp, N_FWD, rule), dt0, rule);            // state i+1 if action 3 wave + grp wins
+            e2 = eval_lane(b, action_jerk(p, min(m, N_FWD - 1), N_FWD, rule), table2, pth, dst, p, ep, p.dt, rule);
         }
         __syncthreads();
         if (have2) {
@@ -648,23 +661,23 @@ __global__ void __launch_bounds__(512) k_forward(TplLonState* __restrict__ trajs
                         b.cost = e2.sc;
                     } else {
                         const Choice c = choose_action_wave(lane_ok && grp == g, e2.cost, e2.constr, g * N_FWD);
-                        b.j = action_jerk(p, c.lane - g * N_FWD, N_FWD);
+                        b.j = action_jerk(p, c.lane - g * N_FWD, N_FWD, rule);
                         b.cost = c.cost;
                         b.constr = c.constr;
                     }
                     if (lane == g * N_FWD) {
                         x_mid[par] = b;
-                        x_nxt[par] = lon_dynamics(b, b.j, p.dt);
+                        x_nxt[par] = lon_dynamics(b, b.j, p.dt, rule);
                     }
                 }
             } else if (wave == w_eval) {
                 // step i was terminal: no action chosen, the successor follows the incoming jerk -- not speculated
                 TplLonState a = x_cur[par];
-                TplLonState c = lon_dynamics(a, a.j, dt0);
+                TplLonState c = lon_dynamics(a, a.j, dt0, rule);
                 eval_node_wave<N_FWD>(c, table2, pth, dst, p, ep, p.dt, true, rule);
                 if (lane == 0) {
                     x_mid[par] = c;
-                    x_nxt[par] = lon_dynamics(c, c.j, p.dt);
+                    x_nxt[par] = lon_dynamics(c, c.j, p.dt, rule);
                 }
             }
         }
@@ -712,23 +725,22 @@ __global__ void k_reeval(TplLonState* __restrict__ traj,
     const Node* table_next = tables + (size_t)nx * table_cells;
 
     const PathTap pt = path_tap(tp.s, p.path_step_size, p.path_steps);
-    const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
-    const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
-    const float s_dist = (float)((double)interp_dist_map_path(ep, dist_ts, tp.t, cps_s, rule)
-                                 - (double)p.length_veh * 0.6);
-    const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist);
+    const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2], rule);
+    const float v_max = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5], rule);
+    const float s_dist = s_dist_of(interp_dist_map_path(ep, dist_ts, tp.t, cps_s, rule), p, rule);
+    const float sc = state_cost(p, tp.s, tp.v, tp.a, s_dist, rule);
     float sg = 0.0f;
     if (tp.v > v_max) sg += tp.v - v_max;
     if (roundf(tp.t / p.dt) == (float)(p.t_steps - 1)) {
         tp.cost = sc;
     } else {
         const float j = tp.j;
-        const TplLonState tn = lon_dynamics(tp, j, dt);
+        const TplLonState tn = lon_dynamics(tp, j, dt, rule);
         const float4 node = read_node(p, table_next, tn.s, tn.v, tn.a, rule);
         const PathTap pn = path_tap(tn.s, p.path_step_size, p.path_steps);
-        const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5]);
+        const float vmn = path_lerp(pn, path[pn.i0 * 7 + 5], path[pn.i1 * 7 + 5], rule);
         const ActionResult r = eval_action_tail(p, sc, sg, node, j, state_action_cost(p, j, dt),
-                                                tn.s, tn.v, tn.a, tp.s, s_dist, vmn);
+                                                tn.s, tn.v, tn.a, tp.s, s_dist, vmn, rule);
         tp.cost = r.cost;
         tp.constr = r.constr;
     }
@@ -758,7 +770,8 @@ __global__ void __launch_bounds__(256) k_upload_words(const unsigned* __restrict
 // ------------------------------------------------------------------------
 __device__ __forceinline__ void dist_slice_to_lds(float* __restrict__ d_sh, unsigned long long* __restrict__ occ_bits,
                                                   const float* __restrict__ occ_lst, const float* __restrict__ path,
-                                                  int path_steps, float path_step_size, const TplDpEnvParams& ep, int idx_t)
+                                                  int path_steps, float path_step_size, const TplDpEnvParams& ep, int idx_t,
+                                                  FilterRule rule = kDefaultRule)
 {
     const int S = ep.s_steps;
     const int words = (S + 63) >> 6;
@@ -766,10 +779,10 @@ __device__ __forceinline__ void dist_slice_to_lds(float* __restrict__ d_sh, unsi
         const int idx_s = base + threadIdx.x;
         bool occupied = false;
         if (idx_s < S) {
-            const float s = ep.s_min + (float)idx_s * ep._s_step_size;
+            const float s = grid_pt(ep.s_min, (float)idx_s, ep._s_step_size, rule);
             const PathTap pt = path_tap(s, path_step_size, path_steps);
-            const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
-            const float cps_l = path_lerp(pt, path[pt.i0 * 7 + 3], path[pt.i1 * 7 + 3]);
+            const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2], rule);
+            const float cps_l = path_lerp(pt, path[pt.i0 * 7 + 3], path[pt.i1 * 7 + 3], rule);
             float fs = (cps_s - ep.s_min) / ep._s_step_size;
             float fl = (cps_l - ep.l_min) / ep._l_step_size;
             fs = fminf(fmaxf(fs, -1.0f), (float)ep.s_steps);
@@ -811,7 +824,8 @@ __host__ __device__ inline size_t dist_slice_lds_bytes(int env_s_steps)
 // One block per time slice; dist: [t][s].
 __global__ void k_dist_map_path(float* __restrict__ dist_ts, const float* __restrict__ occ_lst,
                                 const float* __restrict__ path, int path_steps, float path_step_size,
-                                TplDpEnvParams ep, size_t stride_dist, size_t stride_occ, size_t stride_path)
+                                TplDpEnvParams ep, size_t stride_dist, size_t stride_occ, size_t stride_path,
+                                FilterRule rule = kDefaultRule)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     dist_ts += blockIdx.y * stride_dist;          // scenario batch, see k_stage_prelude
@@ -821,7 +835,7 @@ __global__ void k_dist_map_path(float* __restrict__ dist_ts, const float* __rest
     const int S = ep.s_steps;
     float* d_sh = reinterpret_cast<float*>(smem);
     unsigned long long* occ_bits = reinterpret_cast<unsigned long long*>(smem + sizeof(float) * (((size_t)S + 1) & ~(size_t)1));
-    dist_slice_to_lds(d_sh, occ_bits, occ_lst, path, path_steps, path_step_size, ep, idx_t);
+    dist_slice_to_lds(d_sh, occ_bits, occ_lst, path, path_steps, path_step_size, ep, idx_t, rule);
     for (int idx_s = threadIdx.x; idx_s < S; idx_s += blockDim.x) {
         dist_ts[(size_t)idx_t * S + idx_s] = d_sh[idx_s];
     }
@@ -854,37 +868,38 @@ __global__ void __launch_bounds__(256) k_plan_front(float* __restrict__ dist_ts,
     unsigned long long* bits1 = reinterpret_cast<unsigned long long*>(smem + slice_b + dist_b);
     int b = blockIdx.x;
     if (b < ep.t_steps) {
-        dist_slice_to_lds(L0, bits0, occ_lst, path, p.path_steps, p.path_step_size, ep, b);
+        dist_slice_to_lds(L0, bits0, occ_lst, path, p.path_steps, p.path_step_size, ep, b, rule);
         for (int idx_s = threadIdx.x; idx_s < ES; idx_s += blockDim.x) dist_ts[(size_t)b * ES + idx_s] = L0[idx_s];
         return;
     }
     b -= ep.t_steps;
     const bool terminal = b >= T - 1;
     const int stage = terminal ? T - 1 : b + 1;
-    const float t = p.dt_start + (float)(stage - 1) * p.dt;       // lon_planner.cu:196
+    const float t = grid_pt(p.dt_start, (float)(stage - 1), p.dt, rule);       // lon_planner.cu:196
     // interpDistMapPath, env.cu:254-264, on the two slices of this stage
     const Tap tt = make_tap(env_t_idx(ep, t) + 0.5f, ep.t_steps, rule);
-    dist_slice_to_lds(L0, bits0, occ_lst, path, p.path_steps, p.path_step_size, ep, tt.i0);
+    dist_slice_to_lds(L0, bits0, occ_lst, path, p.path_steps, p.path_step_size, ep, tt.i0, rule);
     // (a weight of exactly 0 -- every stage time the reference produces: t_idx is a whole number -- makes the blend
     // fma(q, 0, p * 1) = p for the finite distances of a slice, whatever q: the second slice is not built then)
     const float* R1 = L0;
     if (tt.i1 != tt.i0 && tt.w != 0.0f) {
-        dist_slice_to_lds(L1, bits1, occ_lst, path, p.path_steps, p.path_step_size, ep, tt.i1);
+        dist_slice_to_lds(L1, bits1, occ_lst, path, p.path_steps, p.path_step_size, ep, tt.i1, rule);
         R1 = L1;
     }
     const int row0 = (b - (T - 1)) * rows_per_block, nrows = p.v_steps * p.a_steps;
     for (int is = threadIdx.x; is < S; is += blockDim.x) {
-        const float s = p.s_min + (float)is * p._s_step_size;     // lon_planner.cu:197
+        const float s = grid_pt(p.s_min, (float)is, p._s_step_size, rule);     // lon_planner.cu:197
         const PathTap pt = path_tap(s, p.path_step_size, p.path_steps);
-        const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2]);
+        const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2], rule);
         const float scq = (cps_s - ep.s_min) / (ep.s_max - ep.s_min) * (float)(ep.s_steps - 1);
         const Tap ts = make_tap(scq + 0.5f, ep.s_steps, rule);
         const float d0 = lerp1(L0[ts.i0], R1[ts.i0], tt.w, rule);
         const float d1 = lerp1(L0[ts.i1], R1[ts.i1], tt.w, rule);
-        const float s_dist = (float)((double)lerp1(d0, d1, ts.w, rule) - (double)p.length_veh * 0.6);
-        const double prog = (double)p.w_progress * fabs(1000.0 - (double)s);
+        const float s_dist = s_dist_of(lerp1(d0, d1, ts.w, rule), p, rule);
+        const double away = fabs(1000.0 - (double)s);
+        const double prog = rule.fma ? away : (double)p.w_progress * away;       // (contracted: the multiplicand, see k_stage_prelude)
         if (!terminal) {
-            pre_vmax[(size_t)stage * S + is] = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5]);
+            pre_vmax[(size_t)stage * S + is] = path_lerp(pt, path[pt.i0 * 7 + 5], path[pt.i1 * 7 + 5], rule);
             pre_sdist[(size_t)stage * S + is] = s_dist;
             if (stage == 1) pre_prog[is] = prog;
             continue;
@@ -892,13 +907,13 @@ __global__ void __launch_bounds__(256) k_plan_front(float* __restrict__ dist_ts,
         // terminal stage, lon_planner.cu:93-97: the state cost only; constr and j keep their zero init
         for (int r = row0; r < min(row0 + rows_per_block, nrows); ++r) {
             const int ia = r / p.v_steps, iv = r - ia * p.v_steps;
-            const float v = p.v_min + (float)iv * p._v_step_size;
-            const float a = p.a_min + (float)ia * p._a_step_size;
+            const float v = grid_pt(p.v_min, (float)iv, p._v_step_size, rule);
+            const float a = grid_pt(p.a_min, (float)ia, p._a_step_size, rule);
             float sc = 0.0f;                                      // stateCost lon_planner.cu:40-55
             sc += p.w_a * (a * a);
-            sc = (float)((double)sc + prog);
-            const float gap = v * p.time_gap + p.gap_min - s_dist;
-            sc = (float)((double)sc + (double)p.w_safety_dist * fmax(0.0, (double)gap));
+            sc = rule.fma ? (float)fma((double)p.w_progress, prog, (double)sc) : (float)((double)sc + prog);
+            const float gap = madf(v, p.time_gap, p.gap_min, rule) - s_dist;
+            sc = (float)madd((double)p.w_safety_dist, fmax(0.0, (double)gap), (double)sc, rule);
             st_node(term_out + (size_t)r * S + is, sc, 0.0f, 0.0f);
         }
     }

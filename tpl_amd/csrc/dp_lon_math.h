@@ -26,8 +26,19 @@ __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x,
 // library (and the plain-fp32 sweeps of dp_sweep.hip) is built for the default rule: a default argument folds away.
 //   quant: 1 = weight rint(a * 256) / 256 (default), 2 = floor(a * 256) / 256, 0 = not quantised
 //   lerp : 0 = fma(q, w, p * (1 - w)) (default), 1 = p * (1 - w) + q * w with every operation rounded, 2 = p + w * (q - p)
-struct FilterRule { int quant, lerp; };
-constexpr FilterRule kDefaultRule{1, 0};
+//   fma  : rule R1.  0 = one rounding per operation of the reference source (default), 1 = the contraction nvcc's default
+//          -fmad=true applies, written out: a*b + c -> fma(a, b, c), a*b + c*d -> fma(a, b, c*d), a - b*c -> fma(-b, c, a)
+//          wherever product and sum have the same type (madf / madd below; the sites are listed in the header of
+//          oracle/dp_lon_oracle.c, -DDPO_R1_FMA=1).  Implemented by the general kernels (tplhip_dp_lon_set_contraction);
+//          the plain-fp32 sweeps pre-fold parts of the unfused expressions and keep the default.
+struct FilterRule { int quant, lerp, fma; };
+constexpr FilterRule kDefaultRule{1, 0, 0};
+
+// a*b + c under rule R1 (this file is built -ffp-contract=off: the unfused form keeps its two roundings)
+__device__ __forceinline__ float madf(float a, float b, float c, FilterRule r) { return r.fma ? fmaf(a, b, c) : a * b + c; }
+__device__ __forceinline__ double madd(double a, double b, double c, FilterRule r) { return r.fma ? fma(a, b, c) : a * b + c; }
+// grid point i of an axis, lon_planner.cu:196-199 / env.cu:144
+__device__ __forceinline__ float grid_pt(float x_min, float i, float step, FilterRule r = kDefaultRule) { return madf(i, step, x_min, r); }
 
 __device__ __forceinline__ float quant_weight(float alpha, FilterRule r)
 {
@@ -103,18 +114,18 @@ __device__ __forceinline__ float4 lerp4w(float4 p, float4 q, float w, float iw)
 }
 
 // lonDynamics, lon_planner.cu:240-250
-__device__ __forceinline__ TplLonState lon_dynamics(const TplLonState& x0, float j, float dt)
+__device__ __forceinline__ TplLonState lon_dynamics(const TplLonState& x0, float j, float dt, FilterRule rule = kDefaultRule)
 {
     TplLonState r;
     r.t = x0.t + dt;
-    float sf = x0.s + x0.v * dt;
-    double sd = (double)sf + ((0.5 * (double)x0.a) * (double)dt) * (double)dt;
-    sd = sd + ((((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt) * (double)dt;
+    float sf = madf(x0.v, dt, x0.s, rule);
+    double sd = madd((0.5 * (double)x0.a) * (double)dt, (double)dt, (double)sf, rule);
+    sd = madd((((1.0 / 6.0) * (double)j) * (double)dt) * (double)dt, (double)dt, sd, rule);
     r.s = fmaxf(x0.s, (float)sd);
-    float vf = x0.v + x0.a * dt;
-    double vd = (double)vf + ((0.5 * (double)j) * (double)dt) * (double)dt;
+    float vf = madf(x0.a, dt, x0.v, rule);
+    double vd = madd((0.5 * (double)j) * (double)dt, (double)dt, (double)vf, rule);
     r.v = fmaxf(0.0f, (float)vd);
-    r.a = x0.a + j * dt;
+    r.a = madf(j, dt, x0.a, rule);
     r.j = j;
     r.cost = 0.0f;
     r.constr = 0.0f;
@@ -142,9 +153,9 @@ __device__ __forceinline__ PathTap path_tap(float distance, float path_step_size
     return t;
 }
 
-__device__ __forceinline__ float path_lerp(const PathTap& t, float p0, float p1)
+__device__ __forceinline__ float path_lerp(const PathTap& t, float p0, float p1, FilterRule rule = kDefaultRule)
 {
-    return p0 * t.ia + p1 * t.a;
+    return madf(p0, t.ia, p1 * t.a, rule);
 }
 
 // path_tap with the quotient distance / path_step_size already formed.
@@ -218,21 +229,27 @@ __device__ __forceinline__ float4 read_node(const TplDpLonParams& p, const Node*
 }
 
 // stateCost, lon_planner.cu:40-55
-__device__ __forceinline__ float state_cost(const TplDpLonParams& p, float s, float v, float a, float s_dist)
+__device__ __forceinline__ float state_cost(const TplDpLonParams& p, float s, float v, float a, float s_dist, FilterRule rule = kDefaultRule)
 {
     float cost = 0.0f;
     cost += p.w_a * (a * a);
-    cost = (float)((double)cost + (double)p.w_progress * fabs(1000.0 - (double)s));
-    float gap = v * p.time_gap + p.gap_min - s_dist;
+    cost = (float)madd((double)p.w_progress, fabs(1000.0 - (double)s), (double)cost, rule);
+    float gap = madf(v, p.time_gap, p.gap_min, rule) - s_dist;
     double m = fmax(0.0, (double)gap);
-    cost = (float)((double)cost + (double)p.w_safety_dist * m);
+    cost = (float)madd((double)p.w_safety_dist, m, (double)cost, rule);
     return cost;
 }
 
-// jerk of action k out of N, lon_planner.cu:148-149
-__device__ __forceinline__ float action_jerk(const TplDpLonParams& p, int k, int N)
+// s_dist of evalNode, lon_planner.cu:84: distance-map value minus 0.6 vehicle lengths, formed in double
+__device__ __forceinline__ float s_dist_of(float dist_value, const TplDpLonParams& p, FilterRule rule = kDefaultRule)
 {
-    return p.j_min + (p.j_max - p.j_min) * ((float)k / (float)(N - 1));
+    return (float)madd(-(double)p.length_veh, 0.6, (double)dist_value, rule);
+}
+
+// jerk of action k out of N, lon_planner.cu:148-149
+__device__ __forceinline__ float action_jerk(const TplDpLonParams& p, int k, int N, FilterRule rule = kDefaultRule)
+{
+    return madf(p.j_max - p.j_min, (float)k / (float)(N - 1), p.j_min, rule);
 }
 
 struct ActionResult { float cost, constr; };
@@ -242,13 +259,13 @@ __device__ __forceinline__ ActionResult eval_action_tail(const TplDpLonParams& p
                                                           float state_c, float state_g,
                                                           float4 node, float j, float wj_cost,
                                                           float tn_s, float tn_v, float tn_a,
-                                                          float tp_s, float s_dist, float v_max_next)
+                                                          float tp_s, float s_dist, float v_max_next, FilterRule rule = kDefaultRule)
 {
     float cost = state_c;
     float constr = state_g;
     cost += node.x;
     constr += node.y;
-    cost += p.w_snap * ((node.z - j) * (node.z - j));
+    cost = madf(p.w_snap, (node.z - j) * (node.z - j), cost, rule);
     cost += wj_cost;
     const double v_max = (double)v_max_next;
     if ((double)tn_v > v_max) {

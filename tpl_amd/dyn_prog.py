@@ -575,6 +575,11 @@ class DynProgLonPlanner:
         choice; ``(1, 0)`` is the default.  See ``tplhip_dp_lon_set_filter_rule`` in include/tplhip.h."""
         check(self._lib.tplhip_dp_lon_set_filter_rule(self._h, int(weight_quant), int(lerp_form)))
 
+    def set_contraction(self, on=True):
+        """R1 of the HP-1 arithmetic contract: the multiply-adds nvcc fuses by default (-fmad=true), written out as
+        fma() calls; off is the default.  See ``tplhip_dp_lon_set_contraction`` in include/tplhip.h."""
+        check(self._lib.tplhip_dp_lon_set_contraction(self._h, int(on)))
+
     def timing_enable(self, enable=True):
         check(self._lib.tplhip_dp_lon_timing_enable(self._h, 1 if enable else 0))
 
