@@ -16,11 +16,11 @@ variants = sys.argv[2:] or ["BASE=1"]
 objs = []
 for v in variants:
     for kv in v.split(","):
-        k, val = kv.split("=")
+        k, val = kv.split("=", 1)
         os.environ[k] = val
     objs.append(bench.dp_setup(grid, 0))
     for kv in v.split(","):
-        os.environ.pop(kv.split("=")[0], None)
+        os.environ.pop(kv.split("=", 1)[0], None)
 res = {v: [] for v in variants}
 for rnd in range(5):
     for v, (dp, env, p, *_rest) in zip(variants, objs):

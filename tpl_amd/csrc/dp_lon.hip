@@ -90,6 +90,8 @@ struct tplhip_dp_lon {
     bool use_buf = false;                // buffer loads: one stage table addressable with 32-bit byte offsets
     int vp_s_pad = 0;                    // s_steps rounded up to whole wavefronts (k_backward3v / 3s)
     int tile_v = 8, tile_a = 8;          // traversal tiles, see k_backward
+    int tile_v3 = 8;                     // strip height of k_backward3v (the skewed traversal has a working set of its own)
+    int skew_q16 = 0;                    // k_backward3v: skew of the traversal along v + a dt / 2 (dp_sweep.hip), 16.16 pairs per a-row
     size_t lds_bytes = 0, lds1_bytes = 0;     // k_backward's LDS block at kchunk actions per round / at one
 
     // cheap division forms, only used when k_verify_div proved them exact (see k_backward)
@@ -300,7 +302,7 @@ void launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
     a.s_pad = h->vp_s_pad;
     a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->path_aux;
     a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->range_aux;
-    a.tile_v = h->tile_v; a.tile_a = h->tile_a;
+    a.tile_v = h->tile_v3; a.tile_a = h->tile_a; a.skew_q16 = h->skew_q16;
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
     launch_backward3v(h->rule, h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
 }
@@ -320,7 +322,7 @@ bool launch_backward3s_(tplhip_dp_lon* h, int idx_t, int nx)
     a.s_pad = h->vp_s_pad;
     a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->path_aux;
     a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->range_aux;
-    a.tile_v = h->tile_v; a.tile_a = h->tile_a;
+    a.tile_v = h->tile_v; a.tile_a = h->tile_a; a.skew_q16 = h->skew_q16;
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
     return launch_backward3s(h->rule, h->path_div3, h->range_div3, h->s3_kc, h->s3_first_early, a, dim3(h->s3_grid, 1), h->s3_lds, h->stream);
 }
@@ -878,7 +880,29 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         int max_pairs = 0;
         for (int x = 0; x < 8; ++x) max_pairs = std::max(max_pairs, (((x + 1) * np) >> 3) - ((x * np) >> 3));
         h->v3_grid = 8 * max_pairs * p.a_steps;
-        h->v3_ok = h->vp_s_pad <= 1024 && (h->tile_v % 2 == 0);
+        h->v3_ok = h->vp_s_pad <= 1024;
+        // rows that read the same next-stage rows: v + a dt / 2 = const (see the kernel); in row PAIRS per a-row
+        {
+            // (used where the rectangular traversal already had to shrink its strips to stay inside L2 -- tables beyond ~100 MB;
+            // on 256x128x64 both traversals move the same bytes and take the same time; TPLHIP_DEBUG=skew=0|1 forces either)
+            int forced = -1;
+            (void)debug_opt("skew", &forced);
+            const bool on = forced < 0 ? h->tile_v < 8 : forced != 0;
+            const double k = (p._v_step_size > 0.0f && std::isfinite(p.dt)) ? 0.5 * (double)p.dt * (double)p._a_step_size / (double)p._v_step_size / 2.0 : 0.0;
+            h->skew_q16 = (on && k > 0.0 && k < 64.0) ? (int)std::lround(k * 65536.0) : 0;
+            // Strip height of the skewed traversal: the workgroups resident on an XCD walk one strip down ALL a-rows
+            // together and touch (strip + 2) v'-rows of every a'-row: the tallest even strip whose band stays inside the
+            // XCD's 4 MiB L2 (512x256x128: 2 rows -- FETCH_SIZE 453 -> 275 MB per sweep, profiles/r04_dp_config4_skew.txt;
+            // 256x128x64: 8, as before)
+            h->tile_v3 = h->tile_v;
+            int ov = 0;
+            if (h->skew_q16 && !debug_opt("tile_v", &ov)) {
+                h->tile_v3 = 8;
+                while (h->tile_v3 > 2 && (size_t)p.a_steps * (h->tile_v3 + 2) * p.s_steps * sizeof(Node) > (size_t)3584 * 1024)
+                    h->tile_v3 -= 2;
+            }
+            h->v3_ok = h->v3_ok && (h->tile_v3 % 2 == 0);
+        }
     }
     // Grids that leave the chip mostly empty (the kchunk = 3 class above) with rows of at most 256 lanes: k_backward3s,
     // one cell per lane on the plain-fp32 instruction stream, three actions per barrier round (TPLHIP_DEBUG=no_s3: k_backward)
@@ -1211,12 +1235,13 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
     std::snprintf(buf, (size_t)n,
                   "{\"sweep\": \"%s\", \"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
                   "\"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"big\": %d, "
-                  "\"bounded_inputs\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\", \"fwd_overlap\": %d, \"plan_front\": \"%s\"}",
+                  "\"bounded_inputs\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\", \"fwd_overlap\": %d, \"plan_front\": \"%s\", "
+                  "\"skew_pairs_per_a_row\": %.4f, \"tile_v3\": %d}",
                   sweep, h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
                   (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->big ? 1 : 0,
                   (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
                   h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded && h->params_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0,
-                  h->front_fused && !h->no_front ? "k_plan_front" : "three launches");
+                  h->front_fused && !h->no_front ? "k_plan_front" : "three launches", (double)h->skew_q16 / 65536.0, h->tile_v3);
     return TPLHIP_OK;
 }
 
@@ -1432,7 +1457,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
             a.pre_prog = h->d_pre_prog; a.p = p; a.s_pad = h->vp_s_pad;
             a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->path_aux;
             a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->range_aux;
-            a.tile_v = h->tile_v; a.tile_a = h->tile_a;
+            a.tile_v = h->tile_v3; a.tile_a = h->tile_a; a.skew_q16 = h->skew_q16;
             a.stride_tables = tab_stride; a.stride_pre = pre_stride; a.stride_path = path_stride;
             launch_backward3v(h->rule, h->path_div3, h->range_div3, a, dim3(h->v3_grid, count),
                               backward3v_lds_bytes(h->vp_s_pad, p.path_steps), h->stream);

@@ -52,6 +52,7 @@ struct SweepArgs {
     float rcp_path_hi, rcp_path_lo;      // 1/path_step_size as a two-float number (division forms 5 and 0: _lo = the divisor)
     float rcp_range_hi, rcp_range_lo;    // 1/(s_max - s_min) likewise
     int tile_v, tile_a;
+    int skew_q16;              // k_backward3v: rotation of the row pairs of an a-row, pairs per a-row in 16.16 fixed point (0: none)
     // scenario batch (blockIdx.y): element strides between consecutive scenarios, 0 = shared
     size_t stride_tables, stride_pre, stride_path;
 };

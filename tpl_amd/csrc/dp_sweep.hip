@@ -180,7 +180,14 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         const int tile = rem / (a.tile_a * w);
         const int r = rem - tile * (a.tile_a * w);
         ia = tile * a.tile_a + r / w;
-        iv = NV * (p_lo + strip * tv + (r - (r / w) * w));
+        // Skew: the successor row of (a, v) under the action that leads to a' is v' = v + dt (a + a') / 2, so the source rows
+        // that read the SAME next-stage rows lie on lines v + a dt / 2 = const.  The pairs of an a-row are rotated
+        // (inside the XCD's share, a bijection per a-row) by that slope, a.skew_q16 / 65536 pairs per a-row: the
+        // workgroups resident on an XCD at one time -- a few pairs by several dozen a-rows -- then touch a band of
+        // v' rows as narrow as the strip itself instead of one widened by the a-extent (profiles/r04_dp_config4_skew.txt).
+        int lp = strip * tv + (r - (r / w) * w);
+        if (a.skew_q16) { lp -= (int)(((long long)ia * a.skew_q16) >> 16) % vx; if (lp < 0) lp += vx; }
+        iv = NV * (p_lo + lp);
     }
     const int row0 = ia * V + iv;
     const int rs = (iv + 1 < V) ? N_BWD : 0;            // descriptor stride to the lane's second row (0: the row twice)

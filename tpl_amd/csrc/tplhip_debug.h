@@ -11,6 +11,7 @@
 //     kchunk=N       actions per barrier round of k_backward (1 or 3)
 //     big=0|1        treat the grid as small / as several residency rounds deep (k_backward3s / k_backward3v), whatever its size
 //     tile_v=N, tile_a=N   traversal tile of the sweeps
+//     skew=0|1       k_backward3v: rectangular traversal / strips skewed along v + a dt / 2, whatever the table size
 //     ilqr_no_lds, ilqr_lds_kb=N   iLQR: where the solver mirrors live (tests force both homes)
 //     ilqr_split=0|1, ilqr_split_lds_kb=N   iLQR: single launch / split-launch sequence whatever the batch size; LDS budget of the split kernels
 // Nothing else in the library reads the environment (tpl_amd/_capi.py reads TPLHIP_LIB to locate the .so).
