@@ -501,7 +501,7 @@ def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_c
 def traffic_block(roofline, key):
     """L2<->fabric bytes per sweep launch and the issue-model fractions from the committed PMC passes of this kernel
     (rocprofv3 cannot run inside the timed process; profiles/README.md has the commands).  `key`: "SxVxA" or "SxVxA@N"."""
-    for f in ("r03_dp_traffic.json", "r02_dp_traffic.json"):
+    for f in ("r04_dp_traffic.json", "r03_dp_traffic.json", "r02_dp_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", f)) as fd:
                 tr = json.load(fd).get(key)
@@ -509,7 +509,9 @@ def traffic_block(roofline, key):
             continue
         if tr and tr.get("kernel", roofline["kernel"]) == roofline["kernel"]:
             roofline["traffic"] = tr["traffic_bytes_per_launch"]
-            roofline["traffic_source"] = f"profiles/{f} (2*FETCH_SIZE + WRITE_SIZE, factor calibrated for 12-byte lanes, separate --pmc passes)"
+            roofline["traffic_source"] = (f"profiles/{f} (2*FETCH_SIZE + WRITE_SIZE, factor calibrated for 12-byte lanes, separate --pmc passes); "
+                                          "a constant of the repository, not measured in this run: rocprofv3 cannot run inside the timed process")
+            roofline["traffic_profiled_kernel_rev"] = tr.get("profiled_kernel_rev", "before round 4")
             for k in ("valu_issue", "texture_addr", "l2_hit_rate"):
                 if k in tr:
                     roofline[k] = tr[k]

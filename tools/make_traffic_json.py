@@ -67,6 +67,15 @@ def main():
         key, path = kv.split("=", 1)
         grid, _, n = key.partition("@")
         out[key] = entry(parse(path), kernel, int(n) if n else 1)
+    # which sweep source these counters were taken on: bench.py copies them into its line as constants of the repository,
+    # and says which revision of the kernel they describe
+    import subprocess
+    try:
+        rev = subprocess.check_output(["git", "log", "-1", "--format=%h", "--", "tpl_amd/csrc/dp_sweep.hip"], text=True).strip()
+    except Exception:
+        rev = "unknown"
+    for v in out.values():
+        v["profiled_kernel_rev"] = rev
     with open(f"profiles/{tag}_dp_traffic.json", "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk not in ("note", "model")} for k, v in out.items()}, indent=1))
