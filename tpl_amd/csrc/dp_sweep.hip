@@ -97,7 +97,10 @@ __device__ __forceinline__ float div_path(float x, float r_hi, float aux, float 
 {
     if (MODE == 3 || MODE == 5) {
         const bool tiny = (__float_as_uint(x) - 1u) < (0x0F800000u - 1u);        // 0 < x < 2^-96 (x >= 0 here)
-        if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) return x / c;
+        if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) {
+            asm volatile("; tiny dividend: IEEE division");      // (a side effect: keeps the division BEHIND the branch -- without it hipcc
+            return x / c;                                          //  computes both forms for every cell and selects: 39.3 -> 43.1 us)
+        }
     }
     return div_const<MODE>(x, r_hi, aux);
 }
