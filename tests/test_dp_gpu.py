@@ -625,6 +625,29 @@ def test_plan_front_forms_agree(env_s, obst, monkeypatch):
                 assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (env_s, form, r)
 
 
+@pytest.mark.parametrize("dt_start", [None, 0.3, 0.6])
+def test_one_stage_plan_forms_agree(dt_start, monkeypatch):
+    """t_steps = 1: the reference's sweep loop (lon_planner.cu:347) does not run, so no table is ever written and the
+    single rollout step reads table 0 as allocated (zeros) -- with a dt_start for which its terminal test does not fire
+    the zeros are really read.  The fused front, whose terminal role would fill that table, must not be taken: both
+    forms against the oracle, raw bits (the advisor's round-3 finding)."""
+    p = sc.lon_params(96, 10, 8, 1, dt_start=dt_start)
+    ep = sc.env_params(t_steps=2, s_steps=201, l_steps=21, dt_start=dt_start)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
+    inits = [sc.initial_state(0.0, 8.0, 0.0), sc.initial_state(30.0, 3.0, 0.5)]
+    got = {}
+    for form in ("", "no_front"):
+        monkeypatch.setenv("TPLHIP_DEBUG", form)
+        dp, env, trajs, tables, otrajs, dist = _run_both(p, ep, path, occ, inits)
+        assert dp.info()["plan_front"] == "three launches", dp.info()
+        for r, tr in enumerate(trajs):
+            assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (form, r)
+        got[form] = [_traj_np(tr) for tr in trajs]
+    for a, b in zip(got[""], got["no_front"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_reeval_after_resident_plans_waits_for_their_rollouts():
     """Back-to-back mode: the rollout of the last plan_resident() runs on its own stream and reads the path; reeval_traj
     replaces that path.  It must wait for the pending rollouts first (the advisor's round-2 finding): two plans in

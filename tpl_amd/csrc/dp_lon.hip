@@ -24,7 +24,9 @@
 // dp_sweep.hip.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -399,10 +401,14 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState
     // env.updateDistMapPath (lon_planner.cu:343), the stage prelude and the terminal stage (rule R4): one launch
     // (k_plan_front) where two distance slices fit the LDS of a block, else the three kernels it stands for
     const size_t front_lds = 2 * dist_slice_lds_bytes(env->params.s_steps);
-    const bool fused_front = front_lds <= 48 * 1024 && !h->no_front;      // (the dynamic-LDS allowance of a launch without opt-in)
+    // (a plan of ONE stage launches no sweep at all -- the reference's loop, lon_planner.cu:347, does not run -- so nothing
+    // may write a terminal table either: the fused front, whose terminal role always runs, is for T >= 2)
+    const bool fused_front = front_lds <= 48 * 1024 && !h->no_front && T >= 2;      // (48 KB: the dynamic-LDS allowance of a launch without opt-in)
     h->front_fused = fused_front;
+    // (the timed span of a plan starts HERE in both forms: distance map, prelude and the T - 1 stage launches -- so that
+    // the microseconds per launch bench.py derives are comparable across no_front, large environments and rounds)
+    if (h->timing) HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
     if (fused_front) {
-        if (h->timing) HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
         const int nrows = p.v_steps * p.a_steps;
         const int rpb = std::max(1, (nrows + 4 * h->n_cu - 1) / (4 * h->n_cu));
         const dim3 grid(env->params.t_steps + (T - 1) + (nrows + rpb - 1) / rpb);
@@ -420,7 +426,6 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState
         hipLaunchKernelGGL(k_stage_prelude, dim3(T), dim3(256), 0, h->stream,
                            h->d_pre_vmax, h->d_pre_sdist, h->d_pre_prog, h->d_path, env->d_dist, p, env->params,
                            (size_t)0, (size_t)0, (size_t)0, h->rule);
-        if (h->timing) HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
     }
     // backward pass, lon_planner.cu:347-361 -- no host sync between stages
     for (int i = T - 1; i > 0; --i) {
@@ -1070,7 +1075,7 @@ int tplhip_dp_lon_download(tplhip_dp_lon* h, TplLonState* out_trajs)
     if (n > h->dl_cap) {
         if (h->h_dl) (void)hipHostFree(h->h_dl);
         h->h_dl = nullptr; h->dl_cap = 0;
-        HIP_TRY(hipHostMalloc(&h->h_dl, sizeof(TplLonState) * n, hipHostMallocDefault), "pinned buffer allocation failed");
+        HIP_TRY(hipHostMalloc(&h->h_dl, sizeof(TplLonState) * n, hipHostMallocCoherent | hipHostMallocMapped), "pinned buffer allocation failed");
         h->dl_cap = n;
     }
     const bool on_fwd = h->fwd_stream && (h->fwd_pending[0] || h->fwd_pending[1]);
@@ -1140,13 +1145,15 @@ int tplhip_dp_lon_update_batch(tplhip_dp_lon* h, int n, const TplLonState* inits
     if (cnt > h->dl_cap) {
         if (h->h_dl) (void)hipHostFree(h->h_dl);
         h->h_dl = nullptr; h->dl_cap = 0;
-        HIP_TRY(hipHostMalloc(&h->h_dl, sizeof(TplLonState) * cnt, hipHostMallocDefault), "pinned buffer allocation failed");
+        // (coherent + mapped, stated: the rollout kernel stores the trajectory and then the flag word through the device
+        // mapping, and the host reads the trajectory as soon as it has SEEN the flag -- no runtime call in between)
+        HIP_TRY(hipHostMalloc(&h->h_dl, sizeof(TplLonState) * cnt, hipHostMallocCoherent | hipHostMallocMapped), "pinned buffer allocation failed");
         h->dl_cap = cnt;
     }
     // one rollout = one workgroup: it publishes a sequence number in page-locked host memory behind its last store, and the
     // host spins on that word instead of asking the runtime to wait for the stream (a bounded spin: then the plain wait)
     if (!h->h_flag) {
-        if (hipHostMalloc(&h->h_flag, 64, hipHostMallocDefault) == hipSuccess) *h->h_flag = 0;
+        if (hipHostMalloc(&h->h_flag, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) *h->h_flag = 0;
         else { (void)hipGetLastError(); h->h_flag = nullptr; }               // no flag word: the plain stream wait
     }
     const bool spin = n == 1 && h->h_flag != nullptr;
@@ -1156,9 +1163,19 @@ int tplhip_dp_lon_update_batch(tplhip_dp_lon* h, int n, const TplLonState* inits
     bool seen = false;
     if (spin) {
         volatile unsigned int* f = h->h_flag;
-        for (long it = 0; it < 4000000 && !seen; ++it) {
+        // bounded by TIME (2 ms: an order of magnitude above the slowest single-rollout plan), then the plain stream wait
+        const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        for (long it = 0; !seen; ++it) {
             seen = __atomic_load_n(const_cast<unsigned int*>(f), __ATOMIC_ACQUIRE) == seq;
-            if (!seen) __builtin_ia32_pause();
+            if (seen) break;
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#elif defined(__aarch64__)
+            asm volatile("yield");
+#else
+            std::this_thread::yield();
+#endif
+            if ((it & 255) == 255 && std::chrono::steady_clock::now() > give_up) break;
         }
     }
     if (!seen) HIP_TRY(hipStreamSynchronize(h->stream), "lon planner forward pass failed");
