@@ -1,0 +1,19 @@
+#!/bin/bash
+# Randomised parity soaks of a round's last revision (GPU box, repo root):  bash tools/parity_soak.sh > gpurun_out/<tag>/parity_soak.txt
+run() { echo "  $*"; ( "$@" 2>&1 | tail -2 | sed 's/^/        /' ); }
+echo "DP (s,v,a) planner, HIP vs oracle/dp_lon_oracle.c, tables of every stage + 3 trajectories per configuration, bit for bit"
+run python tests/fuzz_dp.py 1000 60000
+TPLHIP_DEBUG=big=1 run python tests/fuzz_dp.py 500 61000
+echo "  (the next four: TPLHIP_DEBUG = no_v3,no_s3 | no_fastdiv | div_form=5 | skew=1,big=1)"
+TPLHIP_DEBUG=no_v3,no_s3 run python tests/fuzz_dp.py 100 62000
+TPLHIP_DEBUG=no_fastdiv run python tests/fuzz_dp.py 200 63000
+TPLHIP_DEBUG=div_form=5 run python tests/fuzz_dp.py 200 64000
+TPLHIP_DEBUG=skew=1,big=1 run python tests/fuzz_dp.py 300 65000
+echo "Scenario batches + device-side best-plan record"
+run python tests/fuzz_scenarios.py 60 500
+echo "Occupancy pipeline (f-1), lateral lattice (f-2), (s,ds,l) planner (f-3)"
+run python tests/fuzz_engines.py 40 200
+echo "iLQR, HIP vs oracle/ilqr_oracle.cpp, 7 problems x 10 seeds; then the same through the split-launch form"
+run python tests/fuzz_ilqr.py 10
+echo "  (TPLHIP_DEBUG=ilqr_split=1)"
+TPLHIP_DEBUG=ilqr_split=1 run python tests/fuzz_ilqr.py 10
