@@ -4,7 +4,11 @@ path step sizes that are and are not powers of two, speed-limit profiles, obstac
 and trajectory of the HIP planner compared bit for bit with oracle/dp_lon_oracle.c.  Not collected by pytest (a soak
 tool; tests/test_dp_gpu.py::test_fuzz_sample runs a short sample of it).
 
-    python tests/fuzz_dp.py [cases] [first seed]"""
+    python tests/fuzz_dp.py [cases] [first seed] [--rules]
+
+--rules: every case also draws one of the 18 arithmetic rule combinations (R2 weight rule x R3 blend form x R1
+contraction: set_filter_rule / set_contraction) and is compared with the oracle build that makes the same choices
+(oracle/Makefile: _sens/libdp_lon_oracle_r<quant><lerp><fma>.so, built on demand)."""
 import os
 import sys
 
@@ -55,15 +59,35 @@ def random_case(seed):
     return p, ep, path.astype(np.float32), occ, inits
 
 
-def run_case(seed):
+def rule_oracle(quant, lerp, fma):
+    import subprocess
+    odir = os.path.join(O.ROOT, "oracle")
+    rel = f"_sens/libdp_lon_oracle_r{quant}{lerp}{fma}.so"
+    if not os.path.exists(os.path.join(odir, rel)):
+        subprocess.check_call(["make", "-s", "-C", odir, rel])
+    return os.path.join(odir, rel)
+
+
+def run_case(seed, rules=False):
     p, ep, path, occ, inits = random_case(seed)
     env = tpl_amd.DynProgEnvironment()
     env.reinit_buffers(ep)
     env.set_occ_map(occ)
     dp = tpl_amd.DynProgLonPlanner()
     dp.reinit_buffers(p)
+    rule = None
+    if rules:
+        rng = np.random.default_rng(77 + seed)
+        rule = (int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 2)))
+        dp.set_contraction(bool(rule[2]))
+        dp.set_filter_rule(rule[0], rule[1])
+        O.use(rule_oracle(*rule))
     trajs = dp.update_batch(inits, path, env)
-    tables, otrajs, dist = O.update(O.cparams(p), O.cparams(ep), path, occ, inits)
+    try:
+        tables, otrajs, dist = O.update(O.cparams(p), O.cparams(ep), path, occ, inits)
+    finally:
+        if rules:
+            O.use(None)
     assert np.array_equal(env.get_dist_map_path().view(np.uint32), dist.view(np.uint32)), f"seed {seed}: distance map"
     for t in range(1, p.t_steps):
         got = dp.copy_table(t)
@@ -77,13 +101,15 @@ def run_case(seed):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    rules = "--rules" in sys.argv
+    n = int(args[0]) if len(args) > 0 else 100
+    first = int(args[1]) if len(args) > 1 else 0
     kinds = {}
     for seed in range(first, first + n):
-        k = run_case(seed)
+        k = run_case(seed, rules)
         kinds[k] = kinds.get(k, 0) + 1
-    print(f"{n} random configurations bit-identical; sweep kernels taken: {kinds}")
+    print(f"{n} random configurations{' under random arithmetic rules' if rules else ''} bit-identical; sweep kernels taken: {kinds}")
 
 
 if __name__ == "__main__":

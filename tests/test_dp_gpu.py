@@ -115,6 +115,8 @@ def test_fuzz_sample():
     import fuzz_dp
     for seed in range(12):
         fuzz_dp.run_case(seed)
+    for seed in range(100, 112):               # ... and under randomly drawn arithmetic rules (R2 x R3 x R1)
+        fuzz_dp.run_case(seed, rules=True)
 
 
 def test_single_row_axes_are_refused():
@@ -527,12 +529,12 @@ def test_filter_rule_variants_match_their_oracle_builds(name, quant, lerp, monke
 
 
 @pytest.mark.parametrize("name,quant,lerp", [("fma_explicit", 1, 0), ("fma_explicit_wfloor", 2, 0)])
-def test_contraction_matches_its_oracle_build(name, quant, lerp):
+def test_contraction_matches_its_oracle_build(name, quant, lerp, monkeypatch):
     """R1 as a run-time choice (tplhip_dp_lon_set_contraction): the multiply-adds nvcc contracts by default, written out
     as fma() on both sides -- no compiler decides what fuses.  The HIP planner with contraction on reproduces the
     restatement built -DDPO_R1_FMA=1 bit for bit (distance map, tables, rollouts, re-evaluation) on a small and a
-    several-rounds-deep grid, on its general kernels; switching it off again restores the default tables and the
-    plain-fp32 sweep."""
+    several-rounds-deep grid -- on the SAME plain-fp32 sweeps as the default (Newton-form and IEEE divisions) and on the
+    general sweep; switching it off again restores the default tables."""
     import os
     import subprocess
     odir = os.path.join(O.ROOT, "oracle")
@@ -553,27 +555,33 @@ def test_contraction_matches_its_oracle_build(name, quant, lerp):
             tables, otrajs, dist = O.update(cp, cep, path, occ, inits)
         finally:
             O.use(None)
-        env = tpl_amd.DynProgEnvironment()
-        env.reinit_buffers(ep)
-        env.set_occ_map(occ)
-        dp = tpl_amd.DynProgLonPlanner()
-        dp.reinit_buffers(p)
-        dp.set_contraction(True)
-        dp.set_filter_rule(quant, lerp)
-        trajs = dp.update_batch(inits, path, env)
-        assert dp.info()["sweep"] == "k_backward", dp.info()
-        assert np.array_equal(env.get_dist_map_path().view(np.uint32), dist.view(np.uint32))
-        _assert_tables_equal(dp, tables, T)
-        for r, tr in enumerate(trajs):
-            assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (name, r)
-        for r, tr in enumerate(trajs):                                  # re-costing a plan gives the forward pass' numbers
-            again = _traj_np(dp.reeval_traj(tr, path, env))
-            assert np.array_equal(again[:, 5:].view(np.uint32), otrajs[r][:, 5:].view(np.uint32)), (name, "reeval", r)
-        # off again (and the default filter rule): default tables, default kernel
+        for dbg, want_kernel, want_forms in (("", want_default, (5, 5)), ("no_fastdiv", want_default, (0, 0)),
+                                             ("no_v3,no_s3", "k_backward", None)):
+            monkeypatch.setenv("TPLHIP_DEBUG", dbg)
+            env = tpl_amd.DynProgEnvironment()
+            env.reinit_buffers(ep)
+            env.set_occ_map(occ)
+            dp = tpl_amd.DynProgLonPlanner()
+            dp.reinit_buffers(p)
+            dp.set_contraction(True)
+            dp.set_filter_rule(quant, lerp)
+            trajs = dp.update_batch(inits, path, env)
+            info = dp.info()
+            assert info["sweep"] == want_kernel, info
+            if want_forms:
+                assert (info["path_div3"], info["range_div3"]) == want_forms, info
+            assert np.array_equal(env.get_dist_map_path().view(np.uint32), dist.view(np.uint32))
+            _assert_tables_equal(dp, tables, T)
+            for r, tr in enumerate(trajs):
+                assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (name, dbg, r)
+            for r, tr in enumerate(trajs):                              # re-costing a plan gives the forward pass' numbers
+                again = _traj_np(dp.reeval_traj(tr, path, env))
+                assert np.array_equal(again[:, 5:].view(np.uint32), otrajs[r][:, 5:].view(np.uint32)), (name, dbg, "reeval", r)
+        monkeypatch.setenv("TPLHIP_DEBUG", "")
+        # off again (and the default filter rule): default tables
         dp.set_contraction(False)
         dp.set_filter_rule(1, 0)
         trajs = dp.update_batch(inits, path, env)
-        assert dp.info()["sweep"] == want_default, dp.info()
         tables0, otrajs0, _ = O.update(cp, cep, path, occ, inits)
         _assert_tables_equal(dp, tables0, T)
         assert any(not np.array_equal(tables0[t].view(np.uint32), tables[t].view(np.uint32)) for t in range(1, T)), "contraction changes nothing here"

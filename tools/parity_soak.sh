@@ -9,6 +9,9 @@ TPLHIP_DEBUG=no_v3,no_s3 run python tests/fuzz_dp.py 100 62000
 TPLHIP_DEBUG=no_fastdiv run python tests/fuzz_dp.py 200 63000
 TPLHIP_DEBUG=div_form=5 run python tests/fuzz_dp.py 200 64000
 TPLHIP_DEBUG=skew=1,big=1 run python tests/fuzz_dp.py 300 65000
+echo "  (random arithmetic rules: R2 x R3 x R1, each case against the oracle build of its rule)"
+run python tests/fuzz_dp.py 300 66000 --rules
+TPLHIP_DEBUG=big=1 run python tests/fuzz_dp.py 150 67000 --rules
 echo "Scenario batches + device-side best-plan record"
 run python tests/fuzz_scenarios.py 60 500
 echo "Occupancy pipeline (f-1), lateral lattice (f-2), (s,ds,l) planner (f-3)"

@@ -281,11 +281,11 @@ void pick_div_forms(tplhip_dp_lon* h)
 
 // k_backward3v (dp_sweep.hip): the two-rows-per-lane geometry with the plain-fp32 instruction stream.  Needs buffer
 // loads and non-negative weights (integer-key argmin).  Every filter rule and every divisor runs on it: a division
-// without a proven cheap form is an IEEE division (pick_div_forms).  Contracted arithmetic (rule R1 = 1,
-// tplhip_dp_lon_set_contraction) is the general kernels' alone: the plain-fp32 sweeps pre-fold unfused sub-expressions.
+// without a proven cheap form is an IEEE division (pick_div_forms); contracted arithmetic (rule R1 = 1,
+// tplhip_dp_lon_set_contraction) is a template variant of the same kernels.
 bool use_v3(const tplhip_dp_lon* h)
 {
-    return !h->no_v3 && h->use_buf && h->weights_nonneg && !h->rule.fma
+    return !h->no_v3 && h->use_buf && h->weights_nonneg
            && backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps) <= 64 * 1024;
 }
 

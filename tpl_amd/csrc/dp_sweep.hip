@@ -108,13 +108,21 @@ __device__ __forceinline__ float div_path(float x, float r_hi, float aux, float 
 struct Node3 { float c, g, j; };
 
 // rule R3 (dp_lon_math.h, lerp1): 0 = fma(q, w, p (1 - w)), 1 = p (1 - w) + q w with every operation rounded, 2 = p + w (q - p)
+// (the template argument LERP of this file also carries rule R1 in bit 2 -- LERP = blend form + 4 x contraction -- so that
+// the kernels keep four template parameters; kFma<LERP> reads it)
+template <int LERP> constexpr bool kFma = (LERP & 4) != 0;
+
 template <int LERP>
 __device__ __forceinline__ float blend1(float p, float q, float w, float iw)
 {
-    if (LERP == 1) { const float a = p * iw, b = q * w; return a + b; }
-    if (LERP == 2) { const float d = q - p; const float e = w * d; return p + e; }
+    if ((LERP & 3) == 1) { const float a = p * iw, b = q * w; return a + b; }
+    if ((LERP & 3) == 2) { const float d = q - p; const float e = w * d; return p + e; }
     return fmaf(q, w, p * iw);
 }
+
+// a*b + c under rule R1: unfused (two roundings; the file is built -ffp-contract=off) or contracted
+template <int LERP> __device__ __forceinline__ float mad1(float a, float b, float c) { return kFma<LERP> ? fmaf(a, b, c) : a * b + c; }
+template <int LERP> __device__ __forceinline__ double mad1(double a, double b, double c) { return kFma<LERP> ? fma(a, b, c) : a * b + c; }
 
 template <int LERP>
 __device__ __forceinline__ Node3 lerp3(Node3 p, Node3 q, float w, float iw)
@@ -245,11 +253,11 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     float dsc_v = 0.0f, pv_v = 0.0f;
     if (is < NV * N_BWD * 8) dsc_v = dsc_word(is);
     if (is <= p.path_steps) pv_v = path[min(is, p.path_steps - 1) * 7 + 5];
-    const float s = p.s_min + (float)js * p._s_step_size;
-    const float acc = p.a_min + (float)ia * p._a_step_size;
+    const float s = mad1<LERP>((float)js, p._s_step_size, p.s_min);
+    const float acc = mad1<LERP>((float)ia, p._a_step_size, p.a_min);
     const float v_max = pre_vmax[js];
     const float s_dist = pre_sdist[js];
-    const double prog = pre_prog[js];
+    const double prog = pre_prog[js];                // (contracted arithmetic: the multiplicand |1000 - s|, see k_stage_prelude)
     if (is < NV * N_BWD * 8) dsc[is] = dsc_v;
     if (is <= p.path_steps) pv[is] = pv_v;
     for (int i = is + bd; i < NV * N_BWD * 8; i += bd) dsc[i] = dsc_word(i);                   // rows of 64 / 128 lanes
@@ -259,14 +267,17 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     {
         float c0 = 0.0f;
         c0 += p.w_a * (acc * acc);
-        const float x = (float)((double)c0 + prog);
+        const float x = kFma<LERP> ? (float)fma((double)p.w_progress, prog, (double)c0) : (float)((double)c0 + prog);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const float v = p.v_min + (float)(iv + (rs ? i : 0)) * p._v_step_size;
-            const float gap = (v * p.time_gap + p.gap_min) - s_dist;
-            sc[i] = (float)((double)x + (double)p.w_safety_dist * fmax(0.0, (double)gap));
+            const float v = mad1<LERP>((float)(iv + (rs ? i : 0)), p._v_step_size, p.v_min);
+            const float gap = mad1<LERP>(v, p.time_gap, p.gap_min) - s_dist;
+            sc[i] = (float)mad1<LERP>((double)p.w_safety_dist, fmax(0.0, (double)gap), (double)x);
             sg[i] = 0.0f; if (v > v_max) sg[i] += v - v_max;
-            sd_base[i] = (double)(s + d0[i * rs].vdt) + d0[i * rs].a_term;
+            // station update, lon_planner.cu:244.  Contracted, the descriptor carries the factors in front of the fused dt
+            // (k_build_actions): vdt = v, a_term = (a / 2) dt, j_term = ((j / 6) dt) dt
+            sd_base[i] = kFma<LERP> ? fma(d0[i * rs].a_term, (double)p.dt, (double)fmaf(d0[i * rs].vdt, p.dt, s))
+                                    : (double)(s + d0[i * rs].vdt) + d0[i * rs].a_term;
         }
     }
     unsigned shared_mask = 0;
@@ -287,6 +298,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     const float rp_hi = in_vgpr(a.rcp_path_hi), rp_lo = in_vgpr(a.rcp_path_lo);
     const float w_snap_v = in_vgpr(p.w_snap);
     const float path_top = (float)(p.path_steps - 1);
+    const double dt_d = (double)p.dt;
     const bool dup_last = is == S - 1;
     unsigned long long best[NV];
     int bk[NV];
@@ -371,7 +383,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const v4f u = dsc4[(i * N_BWD + k) * 2 + 1];
             const v4f* Rk = R + i * row_slots;
             // lonDynamics station part, lon_planner.cu:244
-            const double sd = sd_base[i] + now.j_term[i];
+            const double sd = kFma<LERP> ? fma(now.j_term[i], dt_d, sd_base[i]) : sd_base[i] + now.j_term[i];
             const float tn_s = fmaxf(s, (float)sd);
             const float xs = tn_s - s_min_v;
             const float qs = div_const<RANGE_DIV>(xs, rr_hi, rr_lo);
@@ -403,11 +415,11 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const int t4 = (int)(f0 * 4.0f);
             const float pv0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4);
             const float pv1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4 + 4);
-            const float vmn = pv0 * pia + pv1 * pa;
+            const float vmn = mad1<LERP>(pv0, pia, pv1 * pa);
             float c = sc[i] + nc;
             float g = sg[i] + ng;
             const float dj = nj - u.x;
-            c += w_snap_v * (dj * dj);
+            c = mad1<LERP>(w_snap_v, dj * dj, c);
             g = (float)((double)g + fmax(now.tn_v_d[i] - (double)vmn, 0.0));
             const float s_change = tn_s - s;
             g += fmaxf(s_change - s_dist, 0.0f);
@@ -425,7 +437,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             if (i == 0 || rs) st_node(out + (size_t)(row0 + i) * S + is, __uint_as_float((unsigned)best[i]), __uint_as_float((unsigned)(best[i] >> 32)),
-                    action_jerk(p, bk[i], N_BWD));
+                    action_jerk(p, bk[i], N_BWD, FilterRule{QUANT, LERP & 3, kFma<LERP> ? 1 : 0}));
     }
 }
 
@@ -520,8 +532,8 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     }
     if (!FIRST_EARLY && is < N_BWD * 8) dsc_v = reinterpret_cast<const float*>(d0 + (is >> 3))[is & 7];
     if (!FIRST_EARLY && is <= p.path_steps) pv_v = path[min(is, p.path_steps - 1) * 7 + 5];
-    const float s = p.s_min + (float)js * p._s_step_size;
-    const float acc = p.a_min + (float)ia * p._a_step_size;
+    const float s = mad1<LERP>((float)js, p._s_step_size, p.s_min);
+    const float acc = mad1<LERP>((float)ia, p._a_step_size, p.a_min);
     const float v_max = pre_vmax[js];
     const float s_dist = pre_sdist[js];
     const double prog = pre_prog[js];
@@ -534,12 +546,12 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     {
         float c0 = 0.0f;
         c0 += p.w_a * (acc * acc);
-        const float x = (float)((double)c0 + prog);
-        const float v = p.v_min + (float)iv * p._v_step_size;
-        const float gap = (v * p.time_gap + p.gap_min) - s_dist;
-        sc = (float)((double)x + (double)p.w_safety_dist * fmax(0.0, (double)gap));
+        const float x = kFma<LERP> ? (float)fma((double)p.w_progress, prog, (double)c0) : (float)((double)c0 + prog);
+        const float v = mad1<LERP>((float)iv, p._v_step_size, p.v_min);
+        const float gap = mad1<LERP>(v, p.time_gap, p.gap_min) - s_dist;
+        sc = (float)mad1<LERP>((double)p.w_safety_dist, fmax(0.0, (double)gap), (double)x);
         sg = 0.0f; if (v > v_max) sg += v - v_max;
-        sd_base = (double)(s + d0[0].vdt) + d0[0].a_term;
+        sd_base = kFma<LERP> ? fma(d0[0].a_term, (double)p.dt, (double)fmaf(d0[0].vdt, p.dt, s)) : (double)(s + d0[0].vdt) + d0[0].a_term;
     }
     const float s_min_v = in_vgpr(p.s_min);
     const float s_scale = (float)(S - 1);
@@ -583,7 +595,7 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const ActDesc& e = d0[k];
             const v4f u = dsc4[k * 2 + 1];
             const v4f* Rk = R + kk * row_slots;
-            const double sd = sd_base + e.j_term;                    // lonDynamics station part, lon_planner.cu:244
+            const double sd = kFma<LERP> ? fma(e.j_term, (double)p.dt, sd_base) : sd_base + e.j_term;      // lonDynamics station part, lon_planner.cu:244
             const float tn_s = fmaxf(s, (float)sd);
             const float xs = tn_s - s_min_v;
             const float qs = div_const<RANGE_DIV>(xs, rr_hi, rr_lo);
@@ -607,11 +619,11 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const int t4 = (int)(f0 * 4.0f);
             const float pv0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4);
             const float pv1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4 + 4);
-            const float vmn = pv0 * pia + pv1 * pa;
+            const float vmn = mad1<LERP>(pv0, pia, pv1 * pa);
             float c = sc + nc;
             float g = sg + ng;
             const float dj = nj - u.x;
-            c += w_snap_v * (dj * dj);
+            c = mad1<LERP>(w_snap_v, dj * dj, c);
             g = (float)((double)g + fmax(e.tn_v_d - (double)vmn, 0.0));
             const float s_change = tn_s - s;
             g += fmaxf(s_change - s_dist, 0.0f);
@@ -626,13 +638,15 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         }
     }
     if (active)
-        st_node(out + (size_t)row0 * S + is, __uint_as_float((unsigned)best), __uint_as_float((unsigned)(best >> 32)), action_jerk(p, bk, N_BWD));
+        st_node(out + (size_t)row0 * S + is, __uint_as_float((unsigned)best), __uint_as_float((unsigned)(best >> 32)),
+                action_jerk(p, bk, N_BWD, FilterRule{QUANT, LERP & 3, kFma<LERP> ? 1 : 0}));
 }
 
 } // namespace
 
-// ---- launchers.  This file is compiled three times (Makefile): TPL_SWEEP_RULESET 0 = the default filter rule with every
-// pair of division forms, 1 and 2 = four of the eight other (R2, R3) rules each, with both divisions in the Newton form
+// ---- launchers.  This file is compiled five times (Makefile): TPL_SWEEP_RULESET 0 = the default rules with every
+// pair of division forms, 1 and 2 = four of the eight other (R2, R3) rules each, 3 and 4 = the nine (R2, R3) rules under
+// contracted arithmetic (R1 = 1), all of those with both divisions in the Newton form
 // (5, 5) or both as IEEE divisions (0, 0) -- a rule other than the default is only ever selected to follow a dump of the
 // reference build, and then runs on the same plain-fp32 sweeps as the default.
 #ifndef TPL_SWEEP_RULESET
@@ -716,45 +730,29 @@ bool launch_s_rule(int path_div, int range_div, bool first_early, const SweepArg
 
 } // namespace
 
+// (Q, L, F): weight rule, blend form, contraction; the kernels take L + 4 F as their LERP argument
+#define TPL_RULE_V(Q, L, F) if (r.quant == Q && r.lerp == L && r.fma == F) return launch_v_rule<Q, L + 4 * F>(pd, rd, a, grid, lds, st);
+#define TPL_RULE_S(Q, L, F) if (r.quant == Q && r.lerp == L && r.fma == F) return launch_s_rule<Q, L + 4 * F>(pd, rd, fe, a, grid, lds, st);
+#define TPL_RULE_FILE(NAME, RULES_V, RULES_S) \
+    bool launch_backward3v_rules_##NAME(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st) { RULES_V return false; } \
+    bool launch_backward3s_rules_##NAME(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st) { RULES_S return false; }
 #if TPL_SWEEP_RULESET == 1
-bool launch_backward3v_rules_a(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st)
-{
-    if (r.quant == 1 && r.lerp == 1) return launch_v_rule<1, 1>(pd, rd, a, grid, lds, st);
-    if (r.quant == 1 && r.lerp == 2) return launch_v_rule<1, 2>(pd, rd, a, grid, lds, st);
-    if (r.quant == 2 && r.lerp == 0) return launch_v_rule<2, 0>(pd, rd, a, grid, lds, st);
-    if (r.quant == 2 && r.lerp == 1) return launch_v_rule<2, 1>(pd, rd, a, grid, lds, st);
-    return false;
-}
-bool launch_backward3s_rules_a(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st)
-{
-    if (r.quant == 1 && r.lerp == 1) return launch_s_rule<1, 1>(pd, rd, fe, a, grid, lds, st);
-    if (r.quant == 1 && r.lerp == 2) return launch_s_rule<1, 2>(pd, rd, fe, a, grid, lds, st);
-    if (r.quant == 2 && r.lerp == 0) return launch_s_rule<2, 0>(pd, rd, fe, a, grid, lds, st);
-    if (r.quant == 2 && r.lerp == 1) return launch_s_rule<2, 1>(pd, rd, fe, a, grid, lds, st);
-    return false;
-}
+TPL_RULE_FILE(a, TPL_RULE_V(1, 1, 0) TPL_RULE_V(1, 2, 0) TPL_RULE_V(2, 0, 0) TPL_RULE_V(2, 1, 0),
+                 TPL_RULE_S(1, 1, 0) TPL_RULE_S(1, 2, 0) TPL_RULE_S(2, 0, 0) TPL_RULE_S(2, 1, 0))
 #elif TPL_SWEEP_RULESET == 2
-bool launch_backward3v_rules_b(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st)
-{
-    if (r.quant == 2 && r.lerp == 2) return launch_v_rule<2, 2>(pd, rd, a, grid, lds, st);
-    if (r.quant == 0 && r.lerp == 0) return launch_v_rule<0, 0>(pd, rd, a, grid, lds, st);
-    if (r.quant == 0 && r.lerp == 1) return launch_v_rule<0, 1>(pd, rd, a, grid, lds, st);
-    if (r.quant == 0 && r.lerp == 2) return launch_v_rule<0, 2>(pd, rd, a, grid, lds, st);
-    return false;
-}
-bool launch_backward3s_rules_b(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st)
-{
-    if (r.quant == 2 && r.lerp == 2) return launch_s_rule<2, 2>(pd, rd, fe, a, grid, lds, st);
-    if (r.quant == 0 && r.lerp == 0) return launch_s_rule<0, 0>(pd, rd, fe, a, grid, lds, st);
-    if (r.quant == 0 && r.lerp == 1) return launch_s_rule<0, 1>(pd, rd, fe, a, grid, lds, st);
-    if (r.quant == 0 && r.lerp == 2) return launch_s_rule<0, 2>(pd, rd, fe, a, grid, lds, st);
-    return false;
-}
+TPL_RULE_FILE(b, TPL_RULE_V(2, 2, 0) TPL_RULE_V(0, 0, 0) TPL_RULE_V(0, 1, 0) TPL_RULE_V(0, 2, 0),
+                 TPL_RULE_S(2, 2, 0) TPL_RULE_S(0, 0, 0) TPL_RULE_S(0, 1, 0) TPL_RULE_S(0, 2, 0))
+#elif TPL_SWEEP_RULESET == 3      /* contracted arithmetic (rule R1 = 1), first half */
+TPL_RULE_FILE(c, TPL_RULE_V(1, 0, 1) TPL_RULE_V(2, 0, 1) TPL_RULE_V(0, 0, 1) TPL_RULE_V(1, 1, 1) TPL_RULE_V(1, 2, 1),
+                 TPL_RULE_S(1, 0, 1) TPL_RULE_S(2, 0, 1) TPL_RULE_S(0, 0, 1) TPL_RULE_S(1, 1, 1) TPL_RULE_S(1, 2, 1))
+#elif TPL_SWEEP_RULESET == 4      /* contracted arithmetic, second half */
+TPL_RULE_FILE(d, TPL_RULE_V(2, 1, 1) TPL_RULE_V(2, 2, 1) TPL_RULE_V(0, 1, 1) TPL_RULE_V(0, 2, 1),
+                 TPL_RULE_S(2, 1, 1) TPL_RULE_S(2, 2, 1) TPL_RULE_S(0, 1, 1) TPL_RULE_S(0, 2, 1))
 #else
-bool launch_backward3v_rules_a(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
-bool launch_backward3v_rules_b(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
-bool launch_backward3s_rules_a(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
-bool launch_backward3s_rules_b(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
+#define TPL_RULE_DECL(NAME) \
+    bool launch_backward3v_rules_##NAME(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st); \
+    bool launch_backward3s_rules_##NAME(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
+TPL_RULE_DECL(a) TPL_RULE_DECL(b) TPL_RULE_DECL(c) TPL_RULE_DECL(d)
 
 size_t backward3v_lds_bytes(int s_pad, int path_steps)
 {
@@ -763,8 +761,11 @@ size_t backward3v_lds_bytes(int s_pad, int path_steps)
 
 bool launch_backward3v(FilterRule rule, int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
-    if (rule.quant == kDefaultRule.quant && rule.lerp == kDefaultRule.lerp)
+    if (rule.quant == kDefaultRule.quant && rule.lerp == kDefaultRule.lerp && !rule.fma)
         return launch_v_rule<1, 0>(path_div, range_div, a, grid, lds_bytes, stream);
+    if (rule.fma)
+        return launch_backward3v_rules_c(rule, path_div, range_div, a, grid, lds_bytes, stream)
+               || launch_backward3v_rules_d(rule, path_div, range_div, a, grid, lds_bytes, stream);
     return launch_backward3v_rules_a(rule, path_div, range_div, a, grid, lds_bytes, stream)
            || launch_backward3v_rules_b(rule, path_div, range_div, a, grid, lds_bytes, stream);
 }
@@ -779,8 +780,11 @@ size_t backward3s_lds_bytes(int kc, int s_pad, int path_steps)
 bool launch_backward3s(FilterRule rule, int path_div, int range_div, int kc, bool first_early, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
     if (a.s_pad > 256 || lds_bytes > 64 * 1024 || kc != 3) return false;
-    if (rule.quant == kDefaultRule.quant && rule.lerp == kDefaultRule.lerp)
+    if (rule.quant == kDefaultRule.quant && rule.lerp == kDefaultRule.lerp && !rule.fma)
         return launch_s_rule<1, 0>(path_div, range_div, first_early, a, grid, lds_bytes, stream);
+    if (rule.fma)
+        return launch_backward3s_rules_c(rule, path_div, range_div, first_early, a, grid, lds_bytes, stream)
+               || launch_backward3s_rules_d(rule, path_div, range_div, first_early, a, grid, lds_bytes, stream);
     return launch_backward3s_rules_a(rule, path_div, range_div, first_early, a, grid, lds_bytes, stream)
            || launch_backward3s_rules_b(rule, path_div, range_div, first_early, a, grid, lds_bytes, stream);
 }
