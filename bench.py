@@ -330,7 +330,9 @@ def dp_general_sweep_price(device, grid="target", plans=3):
     * us per sweep of this grid on the general kernel (TPLHIP_DEBUG=no_v3,no_s3: k_backward, two-pass argmin, IEEE
       divisions, any input) next to the kernel the planner selects by itself, same plan, same box;
     * the plain-fp32 sweep with both divisions as IEEE divisions (no_fastdiv) -- what a divisor without a proven
-      reciprocal form pays now that it no longer changes kernels;
+      reciprocal form pays now that it no longer changes kernels; with a path step that is not a power of two; under
+      contracted arithmetic (set_contraction) and with truncated filter weights (set_filter_rule(2, 0)) -- what a
+      non-default arithmetic rule costs on the same kernel;
     * the kernel and the division forms the planner selects for path_step_size x s_max combinations (forms: 4 one
       multiplication, 3 two-float reciprocal, 5 reciprocal + Newton step, 0 IEEE division; dp_sweep.hip)."""
     import tpl_amd
@@ -345,13 +347,18 @@ def dp_general_sweep_price(device, grid="target", plans=3):
     out = {"grid": [S, V, A], "t_steps": T}
     saved = os.environ.get("TPLHIP_DEBUG")
     try:
-        for key, dbg in (("selected", ""), ("path_step_0.7", ""), ("ieee_divisions", "no_fastdiv"), ("general", "no_v3,no_s3")):
+        for key, dbg in (("selected", ""), ("path_step_0.7", ""), ("contracted", ""), ("truncated_weights", ""), ("ieee_divisions", "no_fastdiv"),
+                         ("general", "no_v3,no_s3")):
             os.environ["TPLHIP_DEBUG"] = dbg
             p = sc.lon_params(S, V, A, T)
             if key == "path_step_0.7":                     # not a power of two: two-float reciprocal behind the tiny-dividend test
                 p.path_step_size, p.path_steps = 0.7, 300
             dp = tpl_amd.DynProgLonPlanner(device)
             dp.reinit_buffers(p)
+            if key == "contracted":                        # rule R1 = 1 (a template variant of the same kernel; divisions (5, 5))
+                dp.set_contraction(True)
+            if key == "truncated_weights":                 # rule R2 = floor
+                dp.set_filter_rule(2, 0)
             dp.upload([sc.initial_state(0.0, 8.0, 0.0)], sc.straight_path(p.path_steps, p.path_step_size))
             dp.plan_resident(env)
             dp.sync()

@@ -218,7 +218,7 @@ TPLHIP_API int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant,
  * nvcc), written out as fma() calls -- lonDynamics (lon_planner.cu:240-250), interpPath (common.cuh:124-136), the grid
  * points (lon_planner.cu:196-199, env.cu:144), s_dist and the cost sums of evalNode (lon_planner.cu:40-65, 84, 110,
  * 148).  Deterministic (no compiler decides): oracle/dp_lon_oracle.c built -DDPO_R1_FMA=1 is the same arithmetic.
- * Contracted plans run on the general kernels. */
+ * Every kernel honours it (template variants of the plain-fp32 sweeps): the choice of kernel does not change. */
 TPLHIP_API int tplhip_dp_lon_set_contraction(tplhip_dp_lon* h, int on);
 /* HIP-event timing of the backward sweeps (events recorded on the planner's
  * stream around the loop of launches).  enable=1 starts accumulating; get

@@ -1286,8 +1286,9 @@ int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_f
 
 // R1 of the HP-1 arithmetic contract as a run-time choice: 0 = one rounding per operation of the reference source (the
 // default), 1 = the multiply-adds nvcc's default -fmad=true contracts, written out as fma() (FilterRule::fma in
-// dp_lon_math.h; the sites are listed in the header of oracle/dp_lon_oracle.c).  Rebuilds the action table.  Contracted
-// plans run on the general kernels (two-pass argmin sweep, rollout, re-evaluation, stage prelude, distance map).
+// dp_lon_math.h; the sites are listed in the header of oracle/dp_lon_oracle.c).  Rebuilds the action table.  Every kernel
+// honours it: the plain-fp32 sweeps as template variants, the general sweep, rollout, re-evaluation, stage prelude and
+// distance map at run time.
 int tplhip_dp_lon_set_contraction(tplhip_dp_lon* h, int on)
 {
     if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");

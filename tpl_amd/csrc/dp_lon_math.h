@@ -29,8 +29,8 @@ __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x,
 //   fma  : rule R1.  0 = one rounding per operation of the reference source (default), 1 = the contraction nvcc's default
 //          -fmad=true applies, written out: a*b + c -> fma(a, b, c), a*b + c*d -> fma(a, b, c*d), a - b*c -> fma(-b, c, a)
 //          wherever product and sum have the same type (madf / madd below; the sites are listed in the header of
-//          oracle/dp_lon_oracle.c, -DDPO_R1_FMA=1).  Implemented by the general kernels (tplhip_dp_lon_set_contraction);
-//          the plain-fp32 sweeps pre-fold parts of the unfused expressions and keep the default.
+//          oracle/dp_lon_oracle.c, -DDPO_R1_FMA=1).  Set by tplhip_dp_lon_set_contraction; a run-time branch in the general
+//          kernels, a template bit of the plain-fp32 sweeps (kFma in dp_sweep.hip).
 struct FilterRule { int quant, lerp, fma; };
 constexpr FilterRule kDefaultRule{1, 0, 0};
 
