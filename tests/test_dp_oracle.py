@@ -283,3 +283,98 @@ def test_product_host_helpers_match_oracle():
         assert bytes(a) == bytes(b._c)
     many = traj.state(np.array([0.3, 2.0]))
     assert many.shape == (2, 4)
+
+
+# ---- rule R1 = 1 (explicit contraction, -DDPO_R1_FMA=1): the variant's arithmetic pinned WITHOUT a libm or a compiler in the
+# loop -- fused multiply-adds emulated in exact rational arithmetic with one round-to-nearest-even at the end
+def _rn(x, p, emin):
+    """Round the exact rational x to a binary float with p significand bits (ties to even; subnormals below 2^emin)."""
+    from fractions import Fraction
+    if x == 0:
+        return Fraction(0)
+    sign = -1 if x < 0 else 1
+    x = abs(x)
+    e = x.numerator.bit_length() - x.denominator.bit_length()
+    if Fraction(2) ** e > x:
+        e -= 1
+    e = max(e, emin)
+    q = Fraction(2) ** (e - p + 1)
+    n = x / q
+    lo = n.numerator // n.denominator
+    rem = n - lo
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and lo % 2 == 1):
+        lo += 1
+    return sign * lo * q
+
+
+def _f32(x):
+    return _rn(x, 24, -126)
+
+
+def _f64(x):
+    return _rn(x, 53, -1022)
+
+
+def _sens_lib(name):
+    import os
+    import subprocess
+    odir = os.path.join(O.ROOT, "oracle")
+    rel = f"_sens/libdp_lon_oracle_{name}.so"
+    if not os.path.exists(os.path.join(odir, rel)):
+        subprocess.check_call(["make", "-s", "-C", odir, rel])
+    return os.path.join(odir, rel)
+
+
+def test_explicit_contraction_of_lon_dynamics_and_interp_path_is_the_documented_one():
+    """lonDynamics (lon_planner.cu:240-250) and interpPath (common.cuh:124-136) of the -DDPO_R1_FMA=1 build against the rule
+    written in the header of oracle/dp_lon_oracle.c -- fmaf(v, dt, s) -> fma((.5 a) dt, dt, .) -> fma(((j / 6) dt) dt, dt, .);
+    fmaf(a, dt, v) -> fma((.5 j) dt, dt, .); fmaf(j, dt, a); fmaf(p0, 1 - alpha, p1 alpha) -- evaluated in exact
+    rationals, one rounding per (fused) operation.  And the default build is the same rule with every fma split in two."""
+    from fractions import Fraction as F
+    rng = np.random.default_rng(11)
+    for fma in (1, 0):
+        O.use(_sens_lib("fma_explicit") if fma else None)
+        try:
+            for _ in range(200):
+                s, v, a, j, dt = (np.float32(x) for x in (rng.uniform(0, 150), rng.uniform(0, 30), rng.uniform(-3, 1.5),
+                                                           rng.uniform(-3, 2), rng.choice([0.3, 0.71, 1.0, 1.25])))
+                x0 = _state(s=s, v=v, a=a)
+                out = TplLonState()
+                O.lib().dpo_lon_dynamics(C.byref(x0), j, dt, C.byref(out))
+                S, V, A, J, DT = (F(float(x)) for x in (s, v, a, j, dt))
+                sixth = F(1.0 / 6.0)
+                if fma:
+                    sf = _f32(V * DT + S)
+                    sd = _f64(_f64(_f64(F(1, 2) * A) * DT) * DT + sf)
+                    sd = _f64(_f64(_f64(_f64(sixth * J) * DT) * DT) * DT + sd)
+                    vf = _f32(A * DT + V)
+                    vd = _f64(_f64(_f64(F(1, 2) * J) * DT) * DT + vf)
+                    an = _f32(J * DT + A)
+                else:
+                    sf = _f32(_f32(V * DT) + S)
+                    sd = _f64(_f64(_f64(_f64(F(1, 2) * A) * DT) * DT) + sf)
+                    sd = _f64(_f64(_f64(_f64(_f64(sixth * J) * DT) * DT) * DT) + sd)
+                    vf = _f32(_f32(A * DT) + V)
+                    vd = _f64(_f64(_f64(_f64(F(1, 2) * J) * DT) * DT) + vf)
+                    an = _f32(_f32(J * DT) + A)
+                assert F(float(out.s)) == max(S, _f32(sd)), (fma, s, v, a, j, dt)
+                assert F(float(out.v)) == max(F(0), _f32(vd)), (fma, s, v, a, j, dt)
+                assert F(float(out.a)) == an, (fma, s, v, a, j, dt)
+            path = sc.straight_path(50, 0.7)
+            path[:, 5] = rng.uniform(5, 15, 50).astype(np.float32)
+            path[:, 2] = (path[:, 6] * np.float32(0.97)).astype(np.float32)
+            for _ in range(100):
+                d = np.float32(rng.uniform(0.0, 33.0))
+                ps = TplPathState()
+                O.lib().dpo_interp_path(O.fptr(path), d, np.float32(0.7), 50, C.byref(ps))
+                alpha = _f32(F(float(d)) / F(float(np.float32(0.7))))
+                i0 = min(49, max(0, int(alpha.numerator // alpha.denominator)))
+                i1 = min(49, max(0, -int((-alpha.numerator) // alpha.denominator)))
+                al = _f32(alpha - i0)
+                ia = _f32(_f64(1 - al))
+                for col, got in ((5, ps.v_max), (2, ps.s)):
+                    p0, p1 = F(float(path[i0, col])), F(float(path[i1, col]))
+                    want = _f32(p0 * ia + _f32(p1 * al)) if fma else _f32(_f32(p0 * ia) + _f32(p1 * al))
+                    assert F(float(got)) == want, (fma, d, col)
+        finally:
+            O.use(None)
