@@ -380,3 +380,16 @@ def test_large_batch_takes_the_split_form_and_matches_oracle():
         assert cases.scaled_err(opt.x[b], ref.x) < 1e-6, b
         assert cases.scaled_err(opt.u[b], ref.u) < 1e-6, b
         assert abs(opt.traj_costs[b] - ref.traj_costs) < 1e-8 * abs(ref.traj_costs), b
+
+
+def test_small_models_keep_the_single_launch_for_large_batches():
+    """The split form only pays where a heavy derivative refresh holds the single launch to one wavefront per SIMD (the
+    tracking MPCs); lateral_profile is measured slower through it at every batch size (profiles/r04_ilqr_split_ab.txt), so a
+    large batch of it must stay on the single launch unless the form is forced."""
+    make = _factory("lateral_profile")
+    g = np.load(os.path.join(GOLDEN, "ilqr_lateral.npz"))
+    opt = make(batch=2048, horizon=int(g["in.horizon"]))
+    cases.apply_inputs(opt, g)
+    opt.update()
+    assert opt.info()["form"] == "single", opt.info()
+    assert np.all(np.isfinite(opt.traj_costs))

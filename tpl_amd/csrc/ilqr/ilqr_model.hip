@@ -1439,6 +1439,9 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
 #ifndef TPL_ILQR_CHAIN_WAVES
 #define TPL_ILQR_CHAIN_WAVES 2
 #endif
+#ifndef TPL_ILQR_CHAIN_WAVES_MAX
+#define TPL_ILQR_CHAIN_WAVES_MAX TPL_ILQR_CHAIN_WAVES
+#endif
 #ifndef TPL_ILQR_CHAIN_INLINE    /* 1: the Riccati pass and the rollouts inlined into k_split_chain (its register budget then binds them) */
 #define TPL_ILQR_CHAIN_INLINE 1
 #endif
@@ -1643,7 +1646,7 @@ __global__ __launch_bounds__(WAVE) void k_split_refresh(DevState st, int lg, int
 }
 
 template <bool SECOND_ORDER, int INT_TYPE>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TPL_ILQR_CHAIN_WAVES, TPL_ILQR_CHAIN_WAVES)))
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TPL_ILQR_CHAIN_WAVES, TPL_ILQR_CHAIN_WAVES_MAX)))
 void k_split_chain(DevState st, int lg, int it)
 {
     extern __shared__ __attribute__((aligned(16))) double dynall[];
@@ -2240,11 +2243,17 @@ int upload_inputs(tplhip_ilqr* h)
 // Which form runs: the split sequence pays off when the batch fills the chip more than once (a second wavefront per
 // SIMD has something to hide behind) and needs one integrator and one order for the whole batch (they are template
 // parameters of k_split_chain).  TPLHIP_DEBUG ilqr_split=0|1 forces either (tests run both).
+// ... and where the single launch is held to one wavefront per SIMD by a HEAVY derivative refresh: tpl's two tracking MPCs
+// (six and seven states).  Measured on lateral_profile (two states, T = 250: the chain is 250 dependent stages of a
+// register-resident 2 x 2 recursion, the refresh is 94 registers): the split form is 1-3 % SLOWER at every batch size
+// (4.52 against 4.65 M problem-iterations/s at 4 096, profiles/r04_ilqr_split_ab.txt) -- small problems keep the single launch.
+constexpr bool SPLIT_AUTO = NX >= 6;
+
 bool use_split(const tplhip_ilqr* h)
 {
     if (!h->split_uniform || !h->d_run) return false;
     if (h->split_mode >= 0) return h->split_mode != 0;
-    return (long long)h->batch > 4LL * h->n_cu;
+    return SPLIT_AUTO && (long long)h->batch > 4LL * h->n_cu;
 }
 
 template <bool SO, int INT>
@@ -2464,6 +2473,16 @@ int tplhip_ilqr_create(int device, int batch, int t_cap, tplhip_ilqr** out)
     {
         int v = 0;
         if (tplhip::debug_opt("ilqr_split", &v)) h->split_mode = v ? 1 : 0;
+        // the split kernels place their Lds block at dynamic-LDS offset 0 and the host computes LDS addresses from that:
+        // it only holds while none of them has static LDS of its own (none has; a compiler that adds some turns the form off)
+        hipFuncAttributes fa;
+        const void* fns[] = {reinterpret_cast<const void*>(k_split_begin), reinterpret_cast<const void*>(k_split_refresh),
+                             reinterpret_cast<const void*>(&k_split_chain<true, EULER>), reinterpret_cast<const void*>(&k_split_chain<true, HEUN>),
+                             reinterpret_cast<const void*>(&k_split_chain<true, RK4>), reinterpret_cast<const void*>(&k_split_chain<false, EULER>),
+                             reinterpret_cast<const void*>(&k_split_chain<false, HEUN>), reinterpret_cast<const void*>(&k_split_chain<false, RK4>)};
+        for (const void* fn : fns)
+            if (hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.sharedSizeBytes != 0) h->split_mode = 0;
+        (void)hipGetLastError();
     }
     if (err != hipSuccess) { tplhip_ilqr_destroy(h); return fail(TPLHIP_EDEVICE, "%s: solver workspace allocation failed", hipGetErrorString(err)); }
     h->dev.params = nullptr;                                // set by the first upload_params
