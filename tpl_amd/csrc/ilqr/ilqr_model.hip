@@ -1624,7 +1624,15 @@ __global__ __launch_bounds__(WAVE) void k_split_refresh(DevState st, int lg, int
     double* LXX = fld(st, TPL_F_LXX, b);
     double* LUU = fld(st, TPL_F_LUU, b);
     double* LUX = fld(st, TPL_F_LUX, b);
-    for (int t = lane; t < T; t += WAVE) {
+    // blockIdx.y = block of 64 stages: NO loop over the stages in here, and one routine at a time (the largest first,
+    // nothing scheduled across the boundaries).  Around a stage loop the compiler hoists every parameter-only
+    // sub-expression of the seven routines and keeps them alive across all of them: 385 registers + 112 parked in AGPRs;
+    // this form holds 276, nothing parked.  (Each routine alone fits 98 ... 252 registers on the MPC model.  Measured with
+    // it, profiles/r04_ilqr_split_ab.txt: a second resident refresh wavefront -- 256 registers, 24 spilled -- does not
+    // help, nor do rows staged through LDS for contiguous stores: neither occupancy nor the strided stores bind it.)
+    {
+        const int t = (int)blockIdx.y * WAVE + lane;
+        if (t >= T) return;
         double x[NX], u[NU], lam[NCM];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
@@ -1633,12 +1641,15 @@ __global__ __launch_bounds__(WAVE) void k_split_refresh(DevState st, int lg, int
 #pragma unroll
         for (int c = 0; c < NCM; ++c) lam[c] = LAM[(int64_t)t * NCM + c];
         const double ist = IS[t];
-        stateJacobian(P, x, u, (double)t, ist, FX + (int64_t)t * NX * NX, 1);
-        actionJacobian(P, x, u, (double)t, ist, FU + (int64_t)t * NX * NU, 1);
+        if (second_order) stateStateHessian(P, x, u, lam, BW, (double)t, ist, LXX + (int64_t)t * NX * NX, 1);
+        __builtin_amdgcn_sched_barrier(0);
         stateGradient(P, x, u, lam, BW, (double)t, ist, LX + (int64_t)t * NX, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        stateJacobian(P, x, u, (double)t, ist, FX + (int64_t)t * NX * NX, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        actionJacobian(P, x, u, (double)t, ist, FU + (int64_t)t * NX * NU, 1);
         actionGradient(P, x, u, lam, BW, (double)t, ist, LU + (int64_t)t * NU, 1);
         if (second_order) {
-            stateStateHessian(P, x, u, lam, BW, (double)t, ist, LXX + (int64_t)t * NX * NX, 1);
             actionActionHessian(P, x, u, lam, BW, (double)t, ist, LUU + (int64_t)t * NU * NU, 1);
             actionStateHessian(P, x, u, lam, BW, (double)t, ist, LUX + (int64_t)t * NU * NX, 1);
         }
@@ -2054,6 +2065,7 @@ struct tplhip_ilqr {
     int split_int_type = 0;
     bool split_second_order = true;
     int max_iter_max = 0, max_lg_max = 0;        // over the batch: how many launches a round / an update needs
+    int horizon_max = 1;                         // ... and how many blocks of 64 stages the refresh covers
     int last_form = 0;                           // 0 single launch, 1 split (info)
 };
 
@@ -2278,7 +2290,7 @@ int launch_split(tplhip_ilqr* h)
         hipLaunchKernelGGL(k_split_begin, dim3(h->batch), dim3(WAVE), lds, h->stream, h->dev_split, lg);
         if (lg >= h->max_lg_max) break;
         for (int it = 0; it < h->max_iter_max; ++it) {
-            hipLaunchKernelGGL(k_split_refresh, dim3(h->batch), dim3(WAVE), lds, h->stream, h->dev_split, lg, it);
+            hipLaunchKernelGGL(k_split_refresh, dim3(h->batch, (h->horizon_max + WAVE - 1) / WAVE), dim3(WAVE), lds, h->stream, h->dev_split, lg, it);
             int rc;
             const int ty = h->split_int_type;
             if (h->split_second_order) rc = ty == EULER ? launch_chain<true, EULER>(h, lg, it) : (ty == HEUN ? launch_chain<true, HEUN>(h, lg, it) : launch_chain<true, RK4>(h, lg, it));
@@ -2378,11 +2390,12 @@ int check_settings(tplhip_ilqr* h)
         // what the split-launch form needs to know about the batch as a whole
         const bool so = sc[TPL_S_USE_QUADRATIC_TERMS] != 0.0;
         const int mi = (int)sc[TPL_S_MAX_ITERATIONS], ml = (int)sc[TPL_S_MAX_LG_ITERATIONS];
-        if (b == 0) { h->split_uniform = true; h->split_int_type = it; h->split_second_order = so; h->max_iter_max = mi; h->max_lg_max = ml; }
+        if (b == 0) { h->split_uniform = true; h->split_int_type = it; h->split_second_order = so; h->max_iter_max = mi; h->max_lg_max = ml; h->horizon_max = T; }
         else {
             if (it != h->split_int_type || so != h->split_second_order) h->split_uniform = false;
             h->max_iter_max = std::max(h->max_iter_max, mi);
             h->max_lg_max = std::max(h->max_lg_max, ml);
+            h->horizon_max = std::max(h->horizon_max, T);
         }
     }
     return TPLHIP_OK;
