@@ -2272,11 +2272,12 @@ template <bool SO, int INT>
 int launch_chain(tplhip_ilqr* h, int lg, int it)
 {
     const void* fn = reinterpret_cast<const void*>(&k_split_chain<SO, INT>);
-    if (h->lds_dyn_bytes_split > 48 * 1024 && h->lds_dyn_bytes_split > h->lds_optin_split) {
+    // more dynamic LDS than a launch gets without asking (only with TPLHIP_DEBUG=ilqr_split_lds_kb beyond 48): opt in, per
+    // instantiation -- a batch may come back with another integrator, i.e. another kernel
+    static thread_local size_t optin = 0;
+    if (h->lds_dyn_bytes_split > 48 * 1024 && h->lds_dyn_bytes_split > optin) {
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dyn_bytes_split), "raising the LDS limit failed");
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_split_begin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dyn_bytes_split), "raising the LDS limit failed");
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_split_refresh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dyn_bytes_split), "raising the LDS limit failed");
-        h->lds_optin_split = h->lds_dyn_bytes_split;
+        optin = h->lds_dyn_bytes_split;
     }
     hipLaunchKernelGGL((k_split_chain<SO, INT>), dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes_split, h->stream, h->dev_split, lg, it);
     return TPLHIP_OK;
@@ -2285,6 +2286,11 @@ int launch_chain(tplhip_ilqr* h, int lg, int it)
 int launch_split(tplhip_ilqr* h)
 {
     const size_t lds = h->lds_dyn_bytes_split;
+    if (lds > 48 * 1024 && lds > h->lds_optin_split) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_split_begin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "raising the LDS limit failed");
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_split_refresh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "raising the LDS limit failed");
+        h->lds_optin_split = lds;
+    }
     const int rounds = std::max(1, h->max_lg_max);
     for (int lg = 0; lg < rounds; ++lg) {
         hipLaunchKernelGGL(k_split_begin, dim3(h->batch), dim3(WAVE), lds, h->stream, h->dev_split, lg);
