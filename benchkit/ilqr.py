@@ -177,7 +177,7 @@ def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrie
         # (50-250 dependent stages on one wavefront per problem); MFMA is not used.
         "roofline": {"bound": "valu_fp64", "unit": "TFLOP/s", "peak": FP64_VECTOR_PEAK_TFLOPS,
                      "achieved": per_iter * iters / k_s / 1e12, "frac": per_iter * iters / k_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                     "traffic": None, "kernel": "k_split_chain + k_split_refresh" if opt.info().get("form") == "split" else "k_ilqr_update",
+                     "traffic": None, "kernel": {"split": "k_split_chain + k_split_refresh", "fused": "k_ilqr_fused"}.get(opt.info().get("form"), "k_ilqr_update"),
                      "flops_per_stage": {"F_bw": f_bw, "F_deriv": f_deriv, "F_roll": f_roll, "n_ls": n_ls},
                      "algorithmic_flops_per_batched_iteration": per_iter,
                      "executed_flops_per_batched_iteration": per_iter_exec,
@@ -195,7 +195,7 @@ def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrie
 
 def batch_sweep(device=0, batches=(256, 512, 1024, 2048, 4096, 8192), updates=3, warmup=2, workload="mpc"):
     """Problem-iterations/s against the batch size: 1024 problems are one wavefront per SIMD of the chip; beyond that
-    update() takes the split-launch form, whose chain kernel keeps two wavefronts per SIMD resident (`form`)."""
+    update() takes the fused form (the phases as calls inside one launch, two wavefronts per SIMD resident; `form`)."""
     out = []
     for b in batches:
         r = run(device=device, batch=b, updates=updates, warmup=warmup, workload=workload)

@@ -267,17 +267,22 @@ def test_both_backward_pass_forms_pass_the_goldens_and_agree_bit_for_bit(name, t
 
 
 # ---- split-launch form (k_split_begin / _refresh / _chain / _end): the update() of a chip-filling batch as a sequence of
-# launches, so that the dependent chains run with several resident wavefronts per SIMD.  Forced here with
-# TPLHIP_DEBUG=ilqr_split=1 on batches of any size; the same routines in the same order: the same bits.
+# launches, so that the dependent chains run with several resident wavefronts per SIMD -- and the fused form
+# (k_ilqr_fused): the same phases as calls inside one launch, compiled to the same two-wavefront register budget.  Forced
+# here with TPLHIP_DEBUG=ilqr_split=1 / =2 on batches of any size; the same routines in the same order: the same bits.
+_FORM_NAMES = {0: "single", 1: "split", 2: "fused"}
+
+
+@pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("name", list(cases.CASES))
-def test_split_launch_passes_the_goldens(name, monkeypatch):
-    monkeypatch.setenv("TPLHIP_DEBUG", "ilqr_split=1")
+def test_split_launch_passes_the_goldens(name, form, monkeypatch):
+    monkeypatch.setenv("TPLHIP_DEBUG", f"ilqr_split={form}")
     model, _, kw, _ = cases.CASES[name]
     g = np.load(os.path.join(GOLDEN, f"ilqr_{name}.npz"))
     opt = _factory(model)()
     cases.apply_inputs(opt, g)
     snaps = cases.run_sequence(opt, int(g["in.shift"]))
-    assert opt.info()["form"] == "split", opt.info()
+    assert opt.info()["form"] == _FORM_NAMES[form], opt.info()
     bad = cases.compare(snaps, g, first_order=bool(kw.get("first_order")))
     assert not bad, "\n".join(bad)
 
@@ -301,7 +306,7 @@ def test_split_launch_matches_single_launch(lds_kb, monkeypatch):
     x0[:, 2] = rng.uniform(-0.2, 0.2, B)
     x0[:, 4] = rng.uniform(4, 10, B)
     results = []
-    for form in (0, 1):
+    for form in (0, 1, 2):
         dbg = f"ilqr_split={form}" + (f",ilqr_split_lds_kb={lds_kb}" if (form and lds_kb) else "")
         monkeypatch.setenv("TPLHIP_DEBUG", dbg)
         opt = make(batch=B, horizon=50)
@@ -317,13 +322,14 @@ def test_split_launch_matches_single_launch(lds_kb, monkeypatch):
             out.append({f: np.array(getattr(opt, f)) for f in _BIT_FIELDS})
             opt.shift(1)
         info = opt.info()
-        assert info["form"] == ("split" if form else "single"), info
+        assert info["form"] == _FORM_NAMES[form], info
         if form and lds_kb:
             assert info["lds_traj"] == (1 if lds_kb == 40 else 0) and (info["lds_arrays"] == 5) == (lds_kb == 40), info
         results.append(out)
-    for a, b in zip(*results):
-        for f in _BIT_FIELDS:
-            assert np.array_equal(a[f], b[f], equal_nan=True), f
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            for f in _BIT_FIELDS:
+                assert np.array_equal(a[f], b[f], equal_nan=True), f
     it = results[0][0]["iterations"]
     assert len(np.unique(it)) > 2, it                  # the batch really is ragged
 
@@ -336,7 +342,7 @@ def test_split_launch_matches_single_launch_other_models(model, first_order, mon
     g = np.load(os.path.join(GOLDEN, f"ilqr_{name}.npz"))
     B = 9
     results = []
-    for form in (0, 1):
+    for form in (0, 1, 2):
         monkeypatch.setenv("TPLHIP_DEBUG", f"ilqr_split={form}")
         one = make()
         cases.apply_inputs(one, g)
@@ -348,15 +354,16 @@ def test_split_launch_matches_single_launch_other_models(model, first_order, mon
             opt.x[b, 0] = x0 * (1.0 + 0.05 * b)
         opt.update()
         opt.update()
-        assert opt.info()["form"] == ("split" if form else "single")
+        assert opt.info()["form"] == _FORM_NAMES[form]
         results.append({f: np.array(getattr(opt, f)) for f in _BIT_FIELDS})
-    for f in _BIT_FIELDS:
-        assert np.array_equal(results[0][f], results[1][f], equal_nan=True), f
+    for other in results[1:]:
+        for f in _BIT_FIELDS:
+            assert np.array_equal(results[0][f], other[f], equal_nan=True), f
 
 
-def test_large_batch_takes_the_split_form_and_matches_oracle():
-    """4 096 problems (four per SIMD): update() picks the split form by itself; every 256th problem is re-solved by the
-    CPU oracle."""
+def test_large_batch_takes_the_fused_form_and_matches_oracle():
+    """4 096 problems (four per SIMD): update() picks the two-wavefront fused form by itself; every 256th problem is
+    re-solved by the CPU oracle."""
     make = _factory("trajectory_tracking_mpc")
     B = 4096
     opt = make(batch=B, horizon=50)
@@ -369,7 +376,7 @@ def test_large_batch_takes_the_split_form_and_matches_oracle():
     opt.x[:, 0] = x0
     opt.max_iterations = 8
     opt.update()
-    assert opt.info()["form"] == "split", opt.info()
+    assert opt.info()["form"] == "fused", opt.info()
     assert np.all(opt.iterations == 8) and np.all(np.isfinite(opt.traj_costs))
     for b in range(0, B, 256):
         ref = OI.OracleOptim("trajectory_tracking_mpc")

@@ -108,6 +108,7 @@ struct DevState {
     int lds_len[TPL_N_PARAMS + 1];               // doubles
     int lds_off[TPL_N_PARAMS + 1];               // doubles from the dynamic LDS base
     unsigned long long lds_dyn_flat;   // flat address the host assumed for the dynamic LDS base
+    unsigned long long lds_base_flat;  // split / fused kernels: flat address of LDS offset 0 (their phases are functions and build their LDS pointers from it)
 };
 
 __device__ __forceinline__ double* fld(const DevState& st, int f, int b)
@@ -1455,10 +1456,22 @@ struct SplitProb {
     double dt;
 };
 
-__device__ __forceinline__ SplitProb split_prob(const DevState& st, int b)
+// The split kernels and the fused kernel below read the device state through a pointer (scalar loads from the constant
+// address space, field by field on demand): their phases are real functions, and a 600-byte struct passed by value would
+// travel through every lane's stack at each call.
+typedef const __attribute__((address_space(4))) DevState* CstDev;
+__device__ __forceinline__ CstDev uni_dev(const DevState* p) { return (CstDev)uni_u64((unsigned long long)p); }
+
+__device__ __forceinline__ double* fld(CstDev st, int f, int b)
+{
+    const int64_t rows = field_is_per_stage(f) ? st->rows : 1;
+    return (double*)st->f[f] + (int64_t)b * rows * field_width(f);
+}
+
+__device__ __forceinline__ SplitProb split_prob(CstDev st, int b)
 {
     SplitProb p;
-    p.sc = st.scalars + (int64_t)b * TPL_S_COUNT;
+    p.sc = (double*)st->scalars + (int64_t)b * TPL_S_COUNT;
     p.T = (int)p.sc[TPL_S_HORIZON];
     p.opt_start = (int)p.sc[TPL_S_OPT_START];
     p.max_iter = (int)p.sc[TPL_S_MAX_ITERATIONS];
@@ -1470,34 +1483,37 @@ __device__ __forceinline__ SplitProb split_prob(const DevState& st, int b)
 }
 
 // array parameters -> LDS (the host pointed Params::<array>.data there); false: wrong aperture guess
-__device__ __forceinline__ bool split_lds_arrays(const DevState& st, int b, double* dyn, double* sc)
+__device__ __forceinline__ bool split_lds_arrays(CstDev st, int b, double* dyn, double* sc)
 {
     const int lane = threadIdx.x;
-    if (st.n_lds_arrays > 0 || st.lds_traj) {
-        if ((unsigned long long)(void*)dyn != st.lds_dyn_flat) {
+    const int n_arrays = st->n_lds_arrays;
+    if (n_arrays > 0 || st->lds_traj) {
+        if ((unsigned long long)(void*)dyn != st->lds_dyn_flat) {
             if (lane == 0) sc[TPL_S_TERMINATION_CONDITION] = -99.0;
             return false;
         }
-        for (int a = 0; a < st.n_lds_arrays; ++a) {
-            const double* src = st.lds_src[a] + (int64_t)b * st.lds_src_stride[a];
-            double* dst = dyn + st.lds_off[a];
-            for (int e = lane; e < st.lds_len[a]; e += WAVE) dst[e] = src[e];
+        for (int a = 0; a < n_arrays; ++a) {
+            const double* src = (const double*)st->lds_src[a] + (int64_t)b * st->lds_src_stride[a];
+            double* dst = dyn + st->lds_off[a];
+            const int len = st->lds_len[a];
+            for (int e = lane; e < len; e += WAVE) dst[e] = src[e];
         }
     }
     return true;
 }
 
-__global__ __launch_bounds__(WAVE) void k_split_begin(DevState st, int lg)
+__device__ __forceinline__ void ph_begin(const DevState* stp, int lg_in, int b_in)
 {
-    extern __shared__ __attribute__((aligned(16))) double dynall[];
+    const CstDev st = uni_dev(stp);
+    double* const dynall = (double*)st->lds_base_flat;         // (a function cannot name the kernel's dynamic LDS block: see k_split_begin)
     double* const dyn = dynall + LDS_HEAD;
-    const int b = blockIdx.x;
+    const int lg = uni_i(lg_in), b = uni_i(b_in);
     const int lane = threadIdx.x;
     const SplitProb pr = split_prob(st, b);
     double* const sc = pr.sc;
     if (lg > 0 && lg >= pr.max_lg) return;
     Params P_regs;
-    load_params_uniform(P_regs, &st.params[b]);
+    load_params_uniform(P_regs, (const Params*)st->params + b);
     const Params& P = P_regs;
     const int T = pr.T, opt_start = pr.opt_start, int_type = pr.int_type;
     const double dt = pr.dt;
@@ -1513,7 +1529,7 @@ __global__ __launch_bounds__(WAVE) void k_split_begin(DevState st, int lg)
     if (lg == 0) {
         // ---- initial trajectory rollout and its cost, optim.c:1101-1111 (as in k_ilqr_update)
         double J = 0.0;
-        double* CC = st.cand_c + (int64_t)b * N_ALPHA * st.rows;
+        double* CC = (double*)st->cand_c + (int64_t)b * N_ALPHA * st->rows;
         if (lane < 4) {
             double x[NX], u[NU], xn[NX];
 #pragma unroll
@@ -1587,7 +1603,7 @@ __global__ __launch_bounds__(WAVE) void k_split_begin(DevState st, int lg)
         sc[TPL_S_TRAJECTORY_CHANGED] = 1.0;
         sc[TPL_S_IMPROVED] = 0.0;
         sc[TPL_S_ITERATIONS] = 0.0;
-        st.run[b] = 0;
+        ((int*)st->run)[b] = 0;
     }
 }
 
@@ -1596,18 +1612,19 @@ __global__ __launch_bounds__(WAVE) void k_split_begin(DevState st, int lg)
 // and small Hessians / state Hessian -- 3.8 -> 4.8 ms per update of 1 024 problems: a wavefront's fixed start-up, the
 // parameter record, the arrays' copy to LDS, the state loads, costs more than the routines it no longer runs; and the
 // kernel held to 256 registers for two wavefronts per SIMD: 218 registers in scratch, 10.9 -> 12.1 ms at 4 096.)
-__global__ __launch_bounds__(WAVE) void k_split_refresh(DevState st, int lg, int it)
+__device__ __forceinline__ void ph_refresh_block(const DevState* stp, int lg_in, int it_in, int b_in, int block_in)
 {
-    extern __shared__ __attribute__((aligned(16))) double dynall[];
+    const CstDev st = uni_dev(stp);
+    double* const dynall = (double*)st->lds_base_flat;
     double* const dyn = dynall + LDS_HEAD;
-    const int b = blockIdx.x;
+    const int lg = uni_i(lg_in), it = uni_i(it_in), b = uni_i(b_in), block = uni_i(block_in);
     const int lane = threadIdx.x;
     const SplitProb pr = split_prob(st, b);
-    if (lg >= pr.max_lg || it >= pr.max_iter || st.run[b] != 0) return;
+    if (lg >= pr.max_lg || it >= pr.max_iter || ((int*)st->run)[b] != 0) return;
     if (pr.sc[TPL_S_TRAJECTORY_CHANGED] == 0.0) return;
     const bool second_order = pr.second_order;
     Params P_regs;
-    load_params_uniform(P_regs, &st.params[b]);
+    load_params_uniform(P_regs, (const Params*)st->params + b);
     const Params& P = P_regs;
     if (!split_lds_arrays(st, b, dyn, pr.sc)) return;
     __syncthreads();
@@ -1631,7 +1648,7 @@ __global__ __launch_bounds__(WAVE) void k_split_refresh(DevState st, int lg, int
     // it, profiles/r04_ilqr_split_ab.txt: a second resident refresh wavefront -- 256 registers, 24 spilled -- does not
     // help, nor do rows staged through LDS for contiguous stores: neither occupancy nor the strided stores bind it.)
     {
-        const int t = (int)blockIdx.y * WAVE + lane;
+        const int t = block * WAVE + lane;
         if (t >= T) return;
         double x[NX], u[NU], lam[NCM];
 #pragma unroll
@@ -1657,18 +1674,18 @@ __global__ __launch_bounds__(WAVE) void k_split_refresh(DevState st, int lg, int
 }
 
 template <bool SECOND_ORDER, int INT_TYPE>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TPL_ILQR_CHAIN_WAVES, TPL_ILQR_CHAIN_WAVES_MAX)))
-void k_split_chain(DevState st, int lg, int it)
+__device__ __forceinline__ void ph_chain(const DevState* stp, int lg_in, int it_in, int b_in)
 {
-    extern __shared__ __attribute__((aligned(16))) double dynall[];
+    const CstDev st = uni_dev(stp);
+    double* const dynall = (double*)st->lds_base_flat;
     Lds& s = *reinterpret_cast<Lds*>(dynall);
     double* const dyn = dynall + LDS_HEAD;
-    const int b = blockIdx.x;
+    const int lg = uni_i(lg_in), it = uni_i(it_in), b = uni_i(b_in);
     const int lane = threadIdx.x;
     const SplitProb pr = split_prob(st, b);
     double* const sc = pr.sc;
-    if (lg >= pr.max_lg || it >= pr.max_iter || st.run[b] != 0) return;
-    const Params* const P_mem = &st.params[b];
+    if (lg >= pr.max_lg || it >= pr.max_iter || ((int*)st->run)[b] != 0) return;
+    const Params* const P_mem = (const Params*)st->params + b;
     Params P_regs;
     load_params_uniform(P_regs, P_mem);
     const Params& P = P_regs;
@@ -1704,19 +1721,19 @@ void k_split_chain(DevState st, int lg, int it)
     const double* BW = fld(st, TPL_F_BARRIER_WEIGHT, b);
     const double* UMAX = fld(st, TPL_F_U_MAX, b);
     const double* UMIN = fld(st, TPL_F_U_MIN, b);
-    double* CX = st.cand_x + (int64_t)b * N_ALPHA * st.rows * NX;
-    double* CU = st.cand_u + (int64_t)b * N_ALPHA * st.rows * NU;
-    double* CC = st.cand_c + (int64_t)b * N_ALPHA * st.rows;
+    double* CX = (double*)st->cand_x + (int64_t)b * N_ALPHA * st->rows * NX;
+    double* CU = (double*)st->cand_u + (int64_t)b * N_ALPHA * st->rows * NU;
+    double* CC = (double*)st->cand_c + (int64_t)b * N_ALPHA * st->rows;
 
     if (!split_lds_arrays(st, b, dyn, sc)) return;
-    const int R = st.rows;
+    const int R = st->rows;
     double* XL = dyn;
     double* UL = XL + (int64_t)R * NX;
     double* KL = UL + (int64_t)R * NU;
     double* KBL = KL + (int64_t)R * NU;
     double* UMXL = KBL + (int64_t)R * NU * NX;
     double* UMNL = UMXL + (int64_t)R * NU;
-    const bool lt = st.lds_traj != 0;
+    const bool lt = st->lds_traj != 0;
     const double* Xr = lt ? XL : X_;
     const double* Ur = lt ? UL : U_;
     const double* KFFr = lt ? KL : KFF;
@@ -1737,11 +1754,8 @@ void k_split_chain(DevState st, int lg, int it)
     }
     __syncthreads();
 
-    // The Lds block sits at the head of the dynamic LDS.  Its LDS offset goes through an opaque scalar: as a constant
-    // expression in the call arguments this hipcc mis-selects the address-space round trip of the dynamic-LDS symbol
-    // ("Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base").
-    unsigned sl_off = (unsigned)(unsigned long long)dynall;
-    asm volatile("" : "+s"(sl_off));
+    // The Lds block sits at the head of the dynamic LDS: LDS offset = the low half of its flat address.
+    const unsigned sl_off = (unsigned)uni_i((int)(unsigned)st->lds_base_flat);
     LdsAS* const sl = (LdsAS*)(unsigned long long)sl_off;
     if constexpr (SECOND_ORDER) {
         RiccatiArgs ra;
@@ -1787,7 +1801,7 @@ void k_split_chain(DevState st, int lg, int it)
     {
         RolloutArgs ra;
         ra.CX = CX; ra.CU = CU; ra.X_ = X_; ra.KFFr = KFFr; ra.Ur = Ur; ra.UMAXr = UMAXr; ra.UMINr = UMINr;
-        ra.KFBr = KFBr; ra.Xr = Xr; ra.P = P_mem; ra.dt = dt; ra.rows = st.rows; ra.opt_start = opt_start;
+        ra.KFBr = KFBr; ra.Xr = Xr; ra.P = P_mem; ra.dt = dt; ra.rows = st->rows; ra.opt_start = opt_start;
         ra.T = T; ra.int_type = INT_TYPE; ra.second_order = SECOND_ORDER;
         ra.stamp_acc = nullptr;
         if constexpr (CHAIN_INLINE) {
@@ -1807,8 +1821,8 @@ void k_split_chain(DevState st, int lg, int it)
         for (int idx = lane; idx < N_ALPHA * n_t; idx += WAVE) {
             const int cand = idx & (N_ALPHA - 1);
             const int t = opt_start + (idx >> 3);
-            const double* cx = CX + ((int64_t)cand * st.rows + t) * NX;
-            const double* cu = CU + ((int64_t)cand * st.rows + t) * NU;
+            const double* cx = CX + ((int64_t)cand * st->rows + t) * NX;
+            const double* cu = CU + ((int64_t)cand * st->rows + t) * NU;
             double x[NX], u[NU], c;
 #pragma unroll
             for (int i = 0; i < NX; ++i) x[i] = cx[i];
@@ -1816,13 +1830,13 @@ void k_split_chain(DevState st, int lg, int it)
             for (int d = 0; d < NU; ++d) u[d] = cu[d];
             costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
             if (cc_lds) s.ring_x[cand * cc_rows + t] = c;
-            else CC[(int64_t)cand * st.rows + t] = c;
+            else CC[(int64_t)cand * st->rows + t] = c;
         }
     }
     __syncthreads();
     // ordered sums, cost += c for t = optStart..T-1, then the end costs (:776-790)
     if (lane < N_ALPHA) {
-        const double* cc = cc_lds ? &s.ring_x[lane * cc_rows] : CC + (int64_t)lane * st.rows;
+        const double* cc = cc_lds ? &s.ring_x[lane * cc_rows] : CC + (int64_t)lane * st->rows;
         double cost = 0.0, c;
         int t = opt_start;
         for (; t + 8 <= T; t += 8) {
@@ -1835,7 +1849,7 @@ void k_split_chain(DevState st, int lg, int it)
         for (; t < T; ++t) cost += cc[t];
         double x[NX];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = CX[((int64_t)lane * st.rows + T) * NX + i];
+        for (int i = 0; i < NX; ++i) x[i] = CX[((int64_t)lane * st->rows + T) * NX + i];
         endCosts(P, x, (double)T, dt, &c, 1);
         cost += c;
         Jc = cost;
@@ -1852,8 +1866,8 @@ void k_split_chain(DevState st, int lg, int it)
     }
     __syncthreads();
     {
-        const double* cx = CX + (int64_t)pick * st.rows * NX;
-        const double* cu = CU + (int64_t)pick * st.rows * NU;
+        const double* cx = CX + (int64_t)pick * st->rows * NX;
+        const double* cu = CU + (int64_t)pick * st->rows * NU;
         if (accepted) {
             J = __shfl(Jc, pick, WAVE);
             for (int e0 = 0; e0 < (T + 1) * NX; e0 += WAVE * 8) {
@@ -1940,16 +1954,77 @@ void k_split_chain(DevState st, int lg, int it)
         sc[TPL_S_IMPROVED] = improved ? 1.0 : 0.0;
         if (rel < min_rel) {                           // optim.c:1001-1006: leaves the iteration loop of this round
             sc[TPL_S_TERMINATION_CONDITION] = 2.0;
-            st.run[b] = 1;
+            ((int*)st->run)[b] = 1;
         }
     }
 }
 
-__global__ void k_split_end(DevState st, int batch)
+// ---- the launches of the split sequence: one phase each
+// (every kernel first checks that its dynamic LDS block is where the host assumed -- LDS offset 0 behind the shared
+// aperture -- and flags the problem instead of computing on garbage if not)
+__device__ __forceinline__ bool lds_where_expected(const DevState* stp)
+{
+    extern __shared__ __attribute__((aligned(16))) double dynall[];
+    if ((unsigned long long)(void*)dynall == stp->lds_base_flat) return true;
+    if (threadIdx.x == 0) stp->scalars[(int64_t)blockIdx.x * TPL_S_COUNT + TPL_S_TERMINATION_CONDITION] = -99.0;
+    return false;
+}
+
+__global__ __launch_bounds__(WAVE) void k_split_begin(const DevState* stp, int lg) { if (lds_where_expected(stp)) ph_begin(stp, lg, (int)blockIdx.x); }
+
+__global__ __launch_bounds__(WAVE) void k_split_refresh(const DevState* stp, int lg, int it)
+{
+    if (lds_where_expected(stp)) ph_refresh_block(stp, lg, it, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+template <bool SECOND_ORDER, int INT_TYPE>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TPL_ILQR_CHAIN_WAVES, TPL_ILQR_CHAIN_WAVES_MAX)))
+void k_split_chain(const DevState* stp, int lg, int it)
+{
+    if (lds_where_expected(stp)) ph_chain<SECOND_ORDER, INT_TYPE>(stp, lg, it, (int)blockIdx.x);
+}
+
+// ---- ... and the SAME phases behind ONE launch: k_ilqr_fused.  What kept k_ilqr_update at one wavefront per SIMD was not
+// the sum of its phases but the compiler's view of them as one body -- parameter-only sub-expressions hoisted out of the
+// iteration and stage loops and kept alive across everything (484 registers + scratch).  As real calls every phase has
+// the registers it needs by itself (begin 175, refresh block 256, chain 201 on the MPC model) and the kernel holds two
+// wavefronts per SIMD with no launch between the phases; the loop state travels through the problem's scalar record as in
+// the split sequence (a few loads per phase).  Same routines, same order: the same bits as both other forms.
+// (the calls are to these out-of-line copies, which only k_ilqr_fused uses: a callee is compiled to the register budget
+// its callers share, so they get the two-wavefront budget while the split kernels above keep their own)
+__device__ __attribute__((noinline)) void fn_begin(const DevState* stp, int lg, int b) { ph_begin(stp, lg, b); }
+__device__ __attribute__((noinline)) void fn_refresh_block(const DevState* stp, int lg, int it, int b, int blk) { ph_refresh_block(stp, lg, it, b, blk); }
+template <bool SECOND_ORDER, int INT_TYPE>
+__device__ __attribute__((noinline)) void fn_chain(const DevState* stp, int lg, int it, int b) { ph_chain<SECOND_ORDER, INT_TYPE>(stp, lg, it, b); }
+
+template <bool SECOND_ORDER, int INT_TYPE>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TPL_ILQR_CHAIN_WAVES, TPL_ILQR_CHAIN_WAVES_MAX)))
+void k_ilqr_fused(const DevState* stp, int rounds, int iterations, int blocks)
+{
+    const int b = (int)blockIdx.x;
+    if (!lds_where_expected(stp)) return;
+    for (int lg = 0; lg < rounds; ++lg) {
+        fn_begin(stp, lg, b);
+        __syncthreads();
+        for (int it = 0; it < iterations; ++it) {
+            for (int blk = 0; blk < blocks; ++blk) fn_refresh_block(stp, lg, it, b, blk);
+            __syncthreads();
+            fn_chain<SECOND_ORDER, INT_TYPE>(stp, lg, it, b);
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        double* sc = stp->scalars + (int64_t)b * TPL_S_COUNT;
+        if (sc[TPL_S_TERMINATION_CONDITION] != -99.0 && (int)sc[TPL_S_ITERATIONS] == (int)sc[TPL_S_MAX_ITERATIONS])
+            sc[TPL_S_TERMINATION_CONDITION] = 1.0;                   // optim.c:1147-1149
+    }
+}
+
+__global__ void k_split_end(const DevState* stp, int batch)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    double* sc = st.scalars + (int64_t)b * TPL_S_COUNT;
+    double* sc = stp->scalars + (int64_t)b * TPL_S_COUNT;
     if (sc[TPL_S_TERMINATION_CONDITION] == -99.0) return;
     if ((int)sc[TPL_S_ITERATIONS] == (int)sc[TPL_S_MAX_ITERATIONS]) sc[TPL_S_TERMINATION_CONDITION] = 1.0;   // optim.c:1147-1149
 }
@@ -2056,6 +2131,10 @@ struct tplhip_ilqr {
     size_t lds_dyn_bytes = 0;                    // dynamic LDS of the next launch
     // split-launch form (k_split_*): its own view of the device state (parameter records that point into ITS LDS layout)
     DevState dev_split{};
+    DevState* h_dev_split = nullptr;             // page-locked staging of dev_split ...
+    DevState* d_dev_split = nullptr;             // ... and its copy in device memory: what the split / fused kernels read
+    DevState dev_split_uploaded{};               // last content sent (re-sent only when it changes)
+    bool dev_split_valid = false;
     Params* d_params_split = nullptr;
     size_t lds_dyn_bytes_split = 0;              // dynamic LDS of the split kernels (Lds block + arrays + mirrors)
     size_t lds_optin_split = 0;
@@ -2130,6 +2209,7 @@ void plan_lds_split(tplhip_ilqr* h)
     d.lds_traj = 0;
     d.n_lds_arrays = 0;
     d.lds_dyn_flat = 0;
+    d.lds_base_flat = h->lds_aperture;
     h->lds_dyn_bytes_split = (size_t)LDS_HEAD * sizeof(double);
     for (auto& a : h->parray) a.lds_off_split = -1;
     if (!h->lds_aperture || tplhip::debug_opt("ilqr_no_lds")) return;
@@ -2159,6 +2239,19 @@ void plan_lds_split(tplhip_ilqr* h)
     }
     h->lds_dyn_bytes_split = (LDS_HEAD + off) * sizeof(double);
     d.lds_dyn_flat = h->lds_aperture + (unsigned long long)LDS_HEAD * sizeof(double);   // the split kernels have no static LDS
+}
+
+// dev_split -> device memory (the split / fused kernels take a pointer), when it changed
+int upload_dev_split(tplhip_ilqr* h)
+{
+    if (!h->d_dev_split || !h->h_dev_split) return TPLHIP_OK;
+    if (h->dev_split_valid && std::memcmp(&h->dev_split_uploaded, &h->dev_split, sizeof(DevState)) == 0) return TPLHIP_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");        // the staging block may still be in flight
+    std::memcpy(h->h_dev_split, &h->dev_split, sizeof(DevState));
+    HIP_TRY(hipMemcpyAsync(h->d_dev_split, h->h_dev_split, sizeof(DevState), hipMemcpyHostToDevice, h->stream), "copying the solver state record failed");
+    std::memcpy(&h->dev_split_uploaded, &h->dev_split, sizeof(DevState));
+    h->dev_split_valid = true;
+    return TPLHIP_OK;
 }
 
 int upload_params(tplhip_ilqr* h)
@@ -2196,6 +2289,7 @@ int upload_params(tplhip_ilqr* h)
     for (auto& a : h->parray) a.lds_off = -1;
     plan_lds(h);
     plan_lds_split(h);
+    if (int rc = upload_dev_split(h)) return rc;
     for (int form = 0; form < 2; ++form)
     for (int b = 0; b < h->batch; ++b) {
         Params& P = reinterpret_cast<Params*>(h->h_parena + (form ? rec_bytes : 0))[b];
@@ -2261,11 +2355,13 @@ int upload_inputs(tplhip_ilqr* h)
 // (4.52 against 4.65 M problem-iterations/s at 4 096, profiles/r04_ilqr_split_ab.txt) -- small problems keep the single launch.
 constexpr bool SPLIT_AUTO = NX >= 6;
 
-bool use_split(const tplhip_ilqr* h)
+// 0 = k_ilqr_update (one launch, one wavefront per SIMD), 1 = the split sequence, 2 = k_ilqr_fused (one launch, the
+// phases as calls, two wavefronts per SIMD).  TPLHIP_DEBUG ilqr_split=0|1|2 forces one (tests run all three).
+int pick_form(const tplhip_ilqr* h)
 {
-    if (!h->split_uniform || !h->d_run) return false;
-    if (h->split_mode >= 0) return h->split_mode != 0;
-    return SPLIT_AUTO && (long long)h->batch > 4LL * h->n_cu;
+    if (!h->split_uniform || !h->d_run || !h->d_dev_split || !h->lds_aperture) return 0;
+    if (h->split_mode >= 0) return h->split_mode;
+    return (SPLIT_AUTO && (long long)h->batch > 4LL * h->n_cu) ? 2 : 0;
 }
 
 template <bool SO, int INT>
@@ -2279,7 +2375,7 @@ int launch_chain(tplhip_ilqr* h, int lg, int it)
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dyn_bytes_split), "raising the LDS limit failed");
         optin = h->lds_dyn_bytes_split;
     }
-    hipLaunchKernelGGL((k_split_chain<SO, INT>), dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes_split, h->stream, h->dev_split, lg, it);
+    hipLaunchKernelGGL((k_split_chain<SO, INT>), dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes_split, h->stream, h->d_dev_split, lg, it);
     return TPLHIP_OK;
 }
 
@@ -2293,10 +2389,10 @@ int launch_split(tplhip_ilqr* h)
     }
     const int rounds = std::max(1, h->max_lg_max);
     for (int lg = 0; lg < rounds; ++lg) {
-        hipLaunchKernelGGL(k_split_begin, dim3(h->batch), dim3(WAVE), lds, h->stream, h->dev_split, lg);
+        hipLaunchKernelGGL(k_split_begin, dim3(h->batch), dim3(WAVE), lds, h->stream, h->d_dev_split, lg);
         if (lg >= h->max_lg_max) break;
         for (int it = 0; it < h->max_iter_max; ++it) {
-            hipLaunchKernelGGL(k_split_refresh, dim3(h->batch, (h->horizon_max + WAVE - 1) / WAVE), dim3(WAVE), lds, h->stream, h->dev_split, lg, it);
+            hipLaunchKernelGGL(k_split_refresh, dim3(h->batch, (h->horizon_max + WAVE - 1) / WAVE), dim3(WAVE), lds, h->stream, h->d_dev_split, lg, it);
             int rc;
             const int ty = h->split_int_type;
             if (h->split_second_order) rc = ty == EULER ? launch_chain<true, EULER>(h, lg, it) : (ty == HEUN ? launch_chain<true, HEUN>(h, lg, it) : launch_chain<true, RK4>(h, lg, it));
@@ -2304,8 +2400,29 @@ int launch_split(tplhip_ilqr* h)
             if (rc) return rc;
         }
     }
-    hipLaunchKernelGGL(k_split_end, dim3((h->batch + 255) / 256), dim3(256), 0, h->stream, h->dev_split, h->batch);
+    hipLaunchKernelGGL(k_split_end, dim3((h->batch + 255) / 256), dim3(256), 0, h->stream, h->d_dev_split, h->batch);
     return TPLHIP_OK;
+}
+
+template <bool SO, int INT>
+int launch_fused_t(tplhip_ilqr* h)
+{
+    const void* fn = reinterpret_cast<const void*>(&k_ilqr_fused<SO, INT>);
+    static thread_local size_t optin = 0;
+    if (h->lds_dyn_bytes_split > 48 * 1024 && h->lds_dyn_bytes_split > optin) {
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dyn_bytes_split), "raising the LDS limit failed");
+        optin = h->lds_dyn_bytes_split;
+    }
+    hipLaunchKernelGGL((k_ilqr_fused<SO, INT>), dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes_split, h->stream, h->d_dev_split,
+                       std::max(1, h->max_lg_max), h->max_iter_max, (h->horizon_max + WAVE - 1) / WAVE);
+    return TPLHIP_OK;
+}
+
+int launch_fused(tplhip_ilqr* h)
+{
+    const int ty = h->split_int_type;
+    if (h->split_second_order) return ty == EULER ? launch_fused_t<true, EULER>(h) : (ty == HEUN ? launch_fused_t<true, HEUN>(h) : launch_fused_t<true, RK4>(h));
+    return ty == EULER ? launch_fused_t<false, EULER>(h) : (ty == HEUN ? launch_fused_t<false, HEUN>(h) : launch_fused_t<false, RK4>(h));
 }
 
 int launch(tplhip_ilqr* h)
@@ -2316,7 +2433,11 @@ int launch(tplhip_ilqr* h)
         HIP_TRY(hipEventCreate(&e1), "event creation failed");
         HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
     }
-    if (use_split(h)) {
+    const int form = pick_form(h);
+    if (form == 2) {
+        h->last_form = 2;
+        if (int rc = launch_fused(h)) return rc;
+    } else if (form == 1) {
         h->last_form = 1;
         if (int rc = launch_split(h)) return rc;
     } else {
@@ -2487,18 +2608,23 @@ int tplhip_ilqr_create(int device, int batch, int t_cap, tplhip_ilqr** out)
     if (err == hipSuccess) err = hipMalloc(&h->dev.cand_u, cand_u * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&h->dev.cand_c, (size_t)batch * N_ALPHA * h->rows * sizeof(double));
     if (err == hipSuccess) err = hipMalloc((void**)&h->d_run, (size_t)batch * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc((void**)&h->d_dev_split, sizeof(DevState));
+    if (err == hipSuccess) err = hipHostMalloc((void**)&h->h_dev_split, sizeof(DevState), hipHostMallocDefault);
     if (err == hipSuccess) err = hipMemsetAsync(h->d_run, 0, (size_t)batch * sizeof(int), h->stream);
     h->dev.run = h->d_run;
     {
         int v = 0;
-        if (tplhip::debug_opt("ilqr_split", &v)) h->split_mode = v ? 1 : 0;
+        if (tplhip::debug_opt("ilqr_split", &v)) h->split_mode = (v >= 0 && v <= 2) ? v : 1;
         // the split kernels place their Lds block at dynamic-LDS offset 0 and the host computes LDS addresses from that:
         // it only holds while none of them has static LDS of its own (none has; a compiler that adds some turns the form off)
         hipFuncAttributes fa;
         const void* fns[] = {reinterpret_cast<const void*>(k_split_begin), reinterpret_cast<const void*>(k_split_refresh),
                              reinterpret_cast<const void*>(&k_split_chain<true, EULER>), reinterpret_cast<const void*>(&k_split_chain<true, HEUN>),
                              reinterpret_cast<const void*>(&k_split_chain<true, RK4>), reinterpret_cast<const void*>(&k_split_chain<false, EULER>),
-                             reinterpret_cast<const void*>(&k_split_chain<false, HEUN>), reinterpret_cast<const void*>(&k_split_chain<false, RK4>)};
+                             reinterpret_cast<const void*>(&k_split_chain<false, HEUN>), reinterpret_cast<const void*>(&k_split_chain<false, RK4>),
+                             reinterpret_cast<const void*>(&k_ilqr_fused<true, EULER>), reinterpret_cast<const void*>(&k_ilqr_fused<true, HEUN>),
+                             reinterpret_cast<const void*>(&k_ilqr_fused<true, RK4>), reinterpret_cast<const void*>(&k_ilqr_fused<false, EULER>),
+                             reinterpret_cast<const void*>(&k_ilqr_fused<false, HEUN>), reinterpret_cast<const void*>(&k_ilqr_fused<false, RK4>)};
         for (const void* fn : fns)
             if (hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.sharedSizeBytes != 0) h->split_mode = 0;
         (void)hipGetLastError();
@@ -2567,6 +2693,8 @@ int tplhip_ilqr_destroy(tplhip_ilqr* h)
     (void)hipFree(h->dev.cand_u);
     (void)hipFree(h->dev.cand_c);
     (void)hipFree(h->d_run);
+    (void)hipFree(h->d_dev_split);
+    if (h->h_dev_split) (void)hipHostFree(h->h_dev_split);
     for (double* p : h->d_snapshot) (void)hipFree(p);
     (void)hipFree(h->d_snapshot_scalars);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -2794,12 +2922,12 @@ int tplhip_ilqr_download(tplhip_ilqr* h)
 int tplhip_ilqr_info(tplhip_ilqr* h, char* buf, int n)
 {
     if (!h || !buf || n < 1) return fail(TPLHIP_EINVAL, "bad argument");
-    const bool sp = h->last_form == 1;
+    const bool sp = h->last_form != 0;
     std::snprintf(buf, (size_t)n, "{\"batch\": %d, \"t_cap\": %d, \"lds_traj\": %d, \"lds_arrays\": %d, \"lds_dyn_bytes\": %zu, "
                   "\"lds_static_bytes\": %zu, \"form\": \"%s\", \"chain_waves_per_simd\": %d}", h->batch, h->rows - 1,
                   sp ? h->dev_split.lds_traj : h->dev.lds_traj, sp ? h->dev_split.n_lds_arrays : h->dev.n_lds_arrays,
                   sp ? h->lds_dyn_bytes_split : h->lds_dyn_bytes, sp ? (size_t)0 : h->lds_static,
-                  sp ? "split" : "single", sp ? TPL_ILQR_CHAIN_WAVES : 1);
+                  h->last_form == 2 ? "fused" : (sp ? "split" : "single"), sp ? TPL_ILQR_CHAIN_WAVES : 1);
     return TPLHIP_OK;
 }
 
