@@ -1,4 +1,4 @@
-"""Same-box A/B of the two update() forms on tpl's time-based tracking MPC (trajectory_tracking_mpc_time, X=6 U=2 C=4,
+"""Same-box A/B of the three update() forms (single launch / split sequence / fused) on tpl's time-based tracking MPC (trajectory_tracking_mpc_time, X=6 U=2 C=4,
 HEUN, N = 40, 20 iterations per update, min_rel_cost_change 0): python tools/ab_ilqr_mpc_time.py [batches...]"""
 import json
 import os
@@ -52,5 +52,5 @@ def run(batch, form):
 
 if __name__ == "__main__":
     for b in [int(a) for a in sys.argv[1:]] or [1024, 2048, 4096, 8192]:
-        for form in (0, 1):
+        for form in (0, 1, 2):
             print(json.dumps(run(b, form)), flush=True)

@@ -18,13 +18,16 @@ bash tools/pmc_dp.sh "gpurun_out/$TAG/pmc_target" target > "$OUT/pmc_target.txt"
 bash tools/pmc_dp.sh "gpurun_out/$TAG/pmc_config4" config4 > "$OUT/pmc_config4.txt" 2>&1
 bash tools/pmc_dp.sh "gpurun_out/$TAG/pmc_mc" mc > "$OUT/pmc_mc.txt" 2>&1
 bash tools/pmc_ilqr.sh "gpurun_out/$TAG/pmc_ilqr" mpc > "$OUT/pmc_ilqr.txt" 2>&1
-# the split-launch form of the batched iLQR update (4096 problems): kernel trace with the gaps between launches, PMC of the
-# chain and refresh kernels; and the same-box A/B of both forms over the batch size
+# the two-wavefront forms of the batched iLQR update (4096 problems): kernel traces (fused: one launch; split: with the gaps
+# between its launches), PMC of the fused kernel and of the split form's chain and refresh kernels; and the same-box A/B of
+# all three forms over the batch size
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_ilqr_fused" -- python3 "$REPO/tools/ilqr_only.py" mpc 4096 > "$OUT/trace_ilqr_fused.log" 2>&1)
+bash tools/pmc_ilqr.sh "gpurun_out/$TAG/pmc_ilqr_fused" mpc 4096 k_ilqr_fused > "$OUT/pmc_ilqr_fused.txt" 2>&1
 (cd /tmp && TPLHIP_DEBUG=ilqr_split=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_ilqr_split" -- python3 "$REPO/tools/ilqr_only.py" mpc 4096 > "$OUT/trace_ilqr_split.log" 2>&1)
 python3 tools/trace_gaps.py "$OUT/trace_ilqr_split" k_split > "$OUT/ilqr_split_gaps_4096.txt"
 TPLHIP_DEBUG=ilqr_split=1 bash tools/pmc_ilqr.sh "gpurun_out/$TAG/pmc_ilqr_split" mpc 4096 k_split_chain > "$OUT/pmc_ilqr_split_chain.txt" 2>&1
 python3 tools/pmc_summary.py "gpurun_out/$TAG/pmc_ilqr_split" k_split_refresh all > "$OUT/pmc_ilqr_split_refresh.txt" 2>&1
-python3 tools/ab_ilqr_split.py mpc --forms 0,1 1024 1536 2048 4096 8192 16384 > "$OUT/ilqr_split_ab.txt" 2>&1
+python3 tools/ab_ilqr_split.py mpc --forms 0,1,2 1024 1536 2048 4096 8192 16384 > "$OUT/ilqr_split_ab.txt" 2>&1
 python3 -c "import json, bench; json.dump(bench.dp_general_sweep_price(0), open('$OUT/dp_general_sweep.json', 'w'), indent=1)" > /dev/null 2>&1
 find "$OUT" -name "*_agent_info.csv" -delete
 find "$OUT" -name "*counter_collection.csv" -size +2M -delete

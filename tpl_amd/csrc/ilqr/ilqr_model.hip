@@ -2139,7 +2139,7 @@ struct tplhip_ilqr {
     size_t lds_dyn_bytes_split = 0;              // dynamic LDS of the split kernels (Lds block + arrays + mirrors)
     size_t lds_optin_split = 0;
     int* d_run = nullptr;
-    int split_mode = -1;                         // TPLHIP_DEBUG ilqr_split=0|1; -1: by batch size
+    int split_mode = -1;                         // TPLHIP_DEBUG ilqr_split=0|1|2; -1: by batch size and model
     bool split_uniform = false;                  // integrator and order are the same for the whole batch
     int split_int_type = 0;
     bool split_second_order = true;
@@ -2346,9 +2346,9 @@ int upload_inputs(tplhip_ilqr* h)
     return upload_params(h);
 }
 
-// Which form runs: the split sequence pays off when the batch fills the chip more than once (a second wavefront per
-// SIMD has something to hide behind) and needs one integrator and one order for the whole batch (they are template
-// parameters of k_split_chain).  TPLHIP_DEBUG ilqr_split=0|1 forces either (tests run both).
+// Which form runs: a two-wavefront form (split sequence or fused launch) pays off when the batch fills the chip more than
+// once (a second wavefront per SIMD has something to hide behind) and needs one integrator and one order for the whole
+// batch (they are template parameters of the chain phase).
 // ... and where the single launch is held to one wavefront per SIMD by a HEAVY derivative refresh: tpl's two tracking MPCs
 // (six and seven states).  Measured on lateral_profile (two states, T = 250: the chain is 250 dependent stages of a
 // register-resident 2 x 2 recursion, the refresh is 94 registers): the split form is 1-3 % SLOWER at every batch size

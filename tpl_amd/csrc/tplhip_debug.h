@@ -13,7 +13,7 @@
 //     tile_v=N, tile_a=N   traversal tile of the sweeps
 //     skew=0|1       k_backward3v: rectangular traversal / strips skewed along v + a dt / 2, whatever the table size
 //     ilqr_no_lds, ilqr_lds_kb=N   iLQR: where the solver mirrors live (tests force both homes)
-//     ilqr_split=0|1, ilqr_split_lds_kb=N   iLQR: single launch / split-launch sequence whatever the batch size; LDS budget of the split kernels
+//     ilqr_split=0|1|2, ilqr_split_lds_kb=N iLQR: single launch / split-launch sequence / fused launch whatever the batch size; LDS budget of the split and fused kernels
 // Nothing else in the library reads the environment (tpl_amd/_capi.py reads TPLHIP_LIB to locate the .so).
 #pragma once
 
