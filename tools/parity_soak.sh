@@ -16,7 +16,10 @@ echo "Scenario batches + device-side best-plan record"
 run python tests/fuzz_scenarios.py 60 500
 echo "Occupancy pipeline (f-1), lateral lattice (f-2), (s,ds,l) planner (f-3)"
 run python tests/fuzz_engines.py 40 200
-echo "iLQR, HIP vs oracle/ilqr_oracle.cpp, 7 problems x 10 seeds; then the same through the split-launch form"
-run python tests/fuzz_ilqr.py 10
+echo "iLQR, HIP vs oracle/ilqr_oracle.cpp, 7 problems x 10 seeds; then the same through the split-launch and the fused form"
+runl() { echo "  $*"; ( "$@" 2>&1 | tail -12 | sed 's/^/        /' ); }
+runl python tests/fuzz_ilqr.py 10
 echo "  (TPLHIP_DEBUG=ilqr_split=1)"
-TPLHIP_DEBUG=ilqr_split=1 run python tests/fuzz_ilqr.py 10
+TPLHIP_DEBUG=ilqr_split=1 runl python tests/fuzz_ilqr.py 10
+echo "  (TPLHIP_DEBUG=ilqr_split=2)"
+TPLHIP_DEBUG=ilqr_split=2 runl python tests/fuzz_ilqr.py 10
