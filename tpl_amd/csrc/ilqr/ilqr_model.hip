@@ -1986,10 +1986,13 @@ void k_split_chain(const DevState* stp, int lg, int it)
 
 // ---- ... and the SAME phases behind ONE launch: k_ilqr_fused.  What kept k_ilqr_update at one wavefront per SIMD was not
 // the sum of its phases but the compiler's view of them as one body -- parameter-only sub-expressions hoisted out of the
-// iteration and stage loops and kept alive across everything (484 registers + scratch).  As real calls every phase has
-// the registers it needs by itself (begin 175, refresh block 256, chain 201 on the MPC model) and the kernel holds two
-// wavefronts per SIMD with no launch between the phases; the loop state travels through the problem's scalar record as in
-// the split sequence (a few loads per phase).  Same routines, same order: the same bits as both other forms.
+// iteration and stage loops and kept alive across everything (484 registers + scratch).  As real calls every phase is
+// compiled by itself, to the 256 registers of a two-wavefront budget (MPC model: begin 248, refresh block 256 with ~75
+// spilled, chain 248; each saves the callee-saved registers it uses on entry), and the kernel holds two wavefronts per
+// SIMD with no launch between the phases; the loop state travels through the problem's scalar record as in the split
+// sequence (a few loads per phase, workgroup fences between phases).  Same routines, same order: the same bits as both
+// other forms.  8.5-8.7 M problem-iterations/s at 4 096 problems against 6.7 (single) / 7.8 (split):
+// profiles/r04_ilqr_split_ab.txt.
 // (the calls are to these out-of-line copies, which only k_ilqr_fused uses: a callee is compiled to the register budget
 // its callers share, so they get the two-wavefront budget while the split kernels above keep their own)
 __device__ __attribute__((noinline)) void fn_begin(const DevState* stp, int lg, int b) { ph_begin(stp, lg, b); }
@@ -2138,6 +2141,8 @@ struct tplhip_ilqr {
     Params* d_params_split = nullptr;
     size_t lds_dyn_bytes_split = 0;              // dynamic LDS of the split kernels (Lds block + arrays + mirrors)
     size_t lds_optin_split = 0;
+    size_t lds_optin_chain[6] = {0, 0, 0, 0, 0, 0};   // per chain-kernel / fused-kernel instantiation (order x integrator), of this
+    size_t lds_optin_fused[6] = {0, 0, 0, 0, 0, 0};   // handle's device
     int* d_run = nullptr;
     int split_mode = -1;                         // TPLHIP_DEBUG ilqr_split=0|1|2; -1: by batch size and model
     bool split_uniform = false;                  // integrator and order are the same for the whole batch
@@ -2370,7 +2375,7 @@ int launch_chain(tplhip_ilqr* h, int lg, int it)
     const void* fn = reinterpret_cast<const void*>(&k_split_chain<SO, INT>);
     // more dynamic LDS than a launch gets without asking (only with TPLHIP_DEBUG=ilqr_split_lds_kb beyond 48): opt in, per
     // instantiation -- a batch may come back with another integrator, i.e. another kernel
-    static thread_local size_t optin = 0;
+    size_t& optin = h->lds_optin_chain[(SO ? 3 : 0) + INT];
     if (h->lds_dyn_bytes_split > 48 * 1024 && h->lds_dyn_bytes_split > optin) {
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dyn_bytes_split), "raising the LDS limit failed");
         optin = h->lds_dyn_bytes_split;
@@ -2408,7 +2413,7 @@ template <bool SO, int INT>
 int launch_fused_t(tplhip_ilqr* h)
 {
     const void* fn = reinterpret_cast<const void*>(&k_ilqr_fused<SO, INT>);
-    static thread_local size_t optin = 0;
+    size_t& optin = h->lds_optin_fused[(SO ? 3 : 0) + INT];
     if (h->lds_dyn_bytes_split > 48 * 1024 && h->lds_dyn_bytes_split > optin) {
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dyn_bytes_split), "raising the LDS limit failed");
         optin = h->lds_dyn_bytes_split;
