@@ -8,6 +8,7 @@ largest magnitude -- ten times tighter than the north star's 1e-5 --,
 trajectory costs within 1e-8 relative, derivative blocks within 1e-6 / 1e-5,
 iteration counts and line-search outcomes equal (tests/ilqr_cases.compare)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -359,6 +360,15 @@ def test_split_launch_matches_single_launch_other_models(model, first_order, mon
     for other in results[1:]:
         for f in _BIT_FIELDS:
             assert np.array_equal(results[0][f], other[f], equal_nan=True), f
+
+
+def test_forms_fuzz_sample(monkeypatch):
+    """A short sample of tests/fuzz_ilqr_forms.py (the long run is a tool): every problem of the goldens as a ragged batch
+    with a random integrator and order -- the template parameters of the chain phase -- through all three forms."""
+    import fuzz_ilqr_forms
+    monkeypatch.setattr(sys, "argv", ["fuzz_ilqr_forms.py", "1"])
+    monkeypatch.setenv("TPLHIP_DEBUG", "")
+    assert fuzz_ilqr_forms.main() == 0
 
 
 def test_large_batch_takes_the_fused_form_and_matches_oracle():

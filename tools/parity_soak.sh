@@ -23,3 +23,5 @@ echo "  (TPLHIP_DEBUG=ilqr_split=1)"
 TPLHIP_DEBUG=ilqr_split=1 runl python tests/fuzz_ilqr.py 10
 echo "  (TPLHIP_DEBUG=ilqr_split=2)"
 TPLHIP_DEBUG=ilqr_split=2 runl python tests/fuzz_ilqr.py 10
+echo "iLQR launch forms against each other (single / split / fused), ragged batches, random integrator and order, bit for bit"
+run python tests/fuzz_ilqr_forms.py 25
