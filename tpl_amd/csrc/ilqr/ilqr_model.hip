@@ -1241,14 +1241,18 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
             }
             __syncthreads();
             STAMP(11);
-            // pass B: stage costs of all candidates and stages, 64 at a time
+            // pass B: stage costs and their ordered sums, 64 (candidate, stage) pairs at a time -- in the order the
+            // reference tries the step sizes (optim.c:859-873): alpha = 1 first, and the seven smaller steps only when
+            // that one does not improve the cost.  Most iterations accept alpha = 1: one pass over the stages instead of
+            // seven.  The costs of candidates nobody asks for are never formed; what is formed is formed as before.
             const int cc_rows = T + 1;
             const bool cc_lds = N_ALPHA * cc_rows <= N_ALPHA * ROLL_RING * NX;
-            {
+            for (int part = 0; part < 2; ++part) {
                 const int n_t = T - opt_start;
-                for (int idx = lane; idx < N_ALPHA * n_t; idx += WAVE) {
-                    const int cand = idx & (N_ALPHA - 1);
-                    const int t = opt_start + (idx >> 3);
+                const int c_lo = part ? 1 : 0, n_c = part ? N_ALPHA - 1 : 1;
+                for (int idx = lane; idx < n_c * n_t; idx += WAVE) {
+                    const int cand = part ? 1 + idx % (N_ALPHA - 1) : 0;
+                    const int t = opt_start + (part ? idx / (N_ALPHA - 1) : idx);
                     const double* cx = CX + ((int64_t)cand * st.rows + t) * NX;
                     const double* cu = CU + ((int64_t)cand * st.rows + t) * NU;
                     double x[NX], u[NU], c;
@@ -1257,33 +1261,34 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
 #pragma unroll
                     for (int d = 0; d < NU; ++d) u[d] = cu[d];
                     costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
-                    // into LDS where the rollouts' ring (idle now) can hold them: a store to global
-                    // memory would put a write acknowledgement in front of the next pass' loads
+                        // into LDS where the rollouts' ring (idle now) can hold them: a store to global
+                        // memory would put a write acknowledgement in front of the next pass' loads
                     if (cc_lds) s.ring_x[cand * cc_rows + t] = c;
                     else CC[(int64_t)cand * st.rows + t] = c;
                 }
-            }
-            __syncthreads();
-            STAMP(12);
-            // ordered sums, cost += c for t = optStart..T-1, then the end costs (:776-790)
-            if (lane < N_ALPHA) {
-                const double* cc = cc_lds ? &s.ring_x[lane * cc_rows] : CC + (int64_t)lane * st.rows;
-                double cost = 0.0, c;
-                int t = opt_start;
-                for (; t + 8 <= T; t += 8) {                    // eight loads in flight, additions in order
-                    double v[8];
+                __syncthreads();
+                STAMP(12);
+                // ordered sums, cost += c for t = optStart..T-1, then the end costs (:776-790)
+                if (lane >= c_lo && lane < c_lo + n_c) {
+                    const double* cc = cc_lds ? &s.ring_x[lane * cc_rows] : CC + (int64_t)lane * st.rows;
+                    double cost = 0.0, c;
+                    int t = opt_start;
+                    for (; t + 8 <= T; t += 8) {                    // eight loads in flight, additions in order
+                        double v[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = cc[t + q];
+                        for (int q = 0; q < 8; ++q) v[q] = cc[t + q];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) cost += v[q];
+                        for (int q = 0; q < 8; ++q) cost += v[q];
+                    }
+                    for (; t < T; ++t) cost += cc[t];
+                    double x[NX];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) x[i] = CX[((int64_t)lane * st.rows + T) * NX + i];
+                    endCosts(P, x, (double)T, dt, &c, 1);
+                    cost += c;
+                    Jc = cost;
                 }
-                for (; t < T; ++t) cost += cc[t];
-                double x[NX];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) x[i] = CX[((int64_t)lane * st.rows + T) * NX + i];
-                endCosts(P, x, (double)T, dt, &c, 1);
-                cost += c;
-                Jc = cost;
+                if (part == 0 && __ballot(lane == 0 && Jc < J && isfinite(Jc) && Jc >= 0.0) != 0ull) break;
             }
             STAMP(13);
             // testImprovement, optim.c:840-857
@@ -1813,14 +1818,18 @@ __device__ __forceinline__ void ph_chain(const DevState* stp, int lg_in, int it_
         }
     }
     __syncthreads();
-    // stage costs of all candidates and stages, 64 at a time
+    // pass B: stage costs and their ordered sums, 64 (candidate, stage) pairs at a time -- in the order the
+    // reference tries the step sizes (optim.c:859-873): alpha = 1 first, and the seven smaller steps only when
+    // that one does not improve the cost.  Most iterations accept alpha = 1: one pass over the stages instead of
+    // seven.  The costs of candidates nobody asks for are never formed; what is formed is formed as before.
     const int cc_rows = T + 1;
     const bool cc_lds = N_ALPHA * cc_rows <= N_ALPHA * ROLL_RING * NX;
-    {
+    for (int part = 0; part < 2; ++part) {
         const int n_t = T - opt_start;
-        for (int idx = lane; idx < N_ALPHA * n_t; idx += WAVE) {
-            const int cand = idx & (N_ALPHA - 1);
-            const int t = opt_start + (idx >> 3);
+        const int c_lo = part ? 1 : 0, n_c = part ? N_ALPHA - 1 : 1;
+        for (int idx = lane; idx < n_c * n_t; idx += WAVE) {
+            const int cand = part ? 1 + idx % (N_ALPHA - 1) : 0;
+            const int t = opt_start + (part ? idx / (N_ALPHA - 1) : idx);
             const double* cx = CX + ((int64_t)cand * st->rows + t) * NX;
             const double* cu = CU + ((int64_t)cand * st->rows + t) * NU;
             double x[NX], u[NU], c;
@@ -1832,27 +1841,28 @@ __device__ __forceinline__ void ph_chain(const DevState* stp, int lg_in, int it_
             if (cc_lds) s.ring_x[cand * cc_rows + t] = c;
             else CC[(int64_t)cand * st->rows + t] = c;
         }
-    }
-    __syncthreads();
-    // ordered sums, cost += c for t = optStart..T-1, then the end costs (:776-790)
-    if (lane < N_ALPHA) {
-        const double* cc = cc_lds ? &s.ring_x[lane * cc_rows] : CC + (int64_t)lane * st->rows;
-        double cost = 0.0, c;
-        int t = opt_start;
-        for (; t + 8 <= T; t += 8) {
-            double v[8];
+        __syncthreads();
+        // ordered sums, cost += c for t = optStart..T-1, then the end costs (:776-790)
+        if (lane >= c_lo && lane < c_lo + n_c) {
+            const double* cc = cc_lds ? &s.ring_x[lane * cc_rows] : CC + (int64_t)lane * st->rows;
+            double cost = 0.0, c;
+            int t = opt_start;
+            for (; t + 8 <= T; t += 8) {                    // eight loads in flight, additions in order
+                double v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = cc[t + q];
+                for (int q = 0; q < 8; ++q) v[q] = cc[t + q];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) cost += v[q];
+                for (int q = 0; q < 8; ++q) cost += v[q];
+            }
+            for (; t < T; ++t) cost += cc[t];
+            double x[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = CX[((int64_t)lane * st->rows + T) * NX + i];
+            endCosts(P, x, (double)T, dt, &c, 1);
+            cost += c;
+            Jc = cost;
         }
-        for (; t < T; ++t) cost += cc[t];
-        double x[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = CX[((int64_t)lane * st->rows + T) * NX + i];
-        endCosts(P, x, (double)T, dt, &c, 1);
-        cost += c;
-        Jc = cost;
+        if (part == 0 && __ballot(lane == 0 && Jc < J && isfinite(Jc) && Jc >= 0.0) != 0ull) break;
     }
     // testImprovement, optim.c:840-857
     const bool ok = lane < N_ALPHA && Jc < J && isfinite(Jc) && Jc >= 0.0;
