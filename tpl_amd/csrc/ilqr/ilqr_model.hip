@@ -1507,6 +1507,9 @@ __device__ __forceinline__ bool split_lds_arrays(CstDev st, int b, double* dyn, 
     return true;
 }
 
+// FUSED (all three phases): the caller is k_ilqr_fused, whose LDS lives for the whole update -- the array parameters and
+// the mirrors of the control bounds were brought in once by fused_setup() and are not fetched again by every phase.
+template <bool FUSED>
 __device__ __forceinline__ void ph_begin(const DevState* stp, int lg_in, int b_in)
 {
     const CstDev st = uni_dev(stp);
@@ -1528,8 +1531,10 @@ __device__ __forceinline__ void ph_begin(const DevState* stp, int lg_in, int b_i
     double* LAM = fld(st, TPL_F_LAGRANGE_MULTIPLIER, b);
     const double* BW = fld(st, TPL_F_BARRIER_WEIGHT, b);
     const double* LGL = fld(st, TPL_F_LG_MULT_LIMIT, b);
-    if (!split_lds_arrays(st, b, dyn, sc)) return;
-    __syncthreads();
+    if constexpr (!FUSED) {
+        if (!split_lds_arrays(st, b, dyn, sc)) return;
+        __syncthreads();
+    }
 
     if (lg == 0) {
         // ---- initial trajectory rollout and its cost, optim.c:1101-1111 (as in k_ilqr_update)
@@ -1610,6 +1615,17 @@ __device__ __forceinline__ void ph_begin(const DevState* stp, int lg_in, int b_i
         sc[TPL_S_ITERATIONS] = 0.0;
         ((int*)st->run)[b] = 0;
     }
+    if constexpr (FUSED) {
+        // the trajectory's LDS mirrors: filled here (after the initial rollout), kept current by the chain phase when it
+        // accepts a step, read by the refresh and the chain -- the split sequence refills them in every chain launch
+        if (st->lds_traj) {
+            __syncthreads();
+            double* XL = dyn;
+            double* UL = XL + (int64_t)st->rows * NX;
+            for (int e = lane; e < (T + 1) * NX; e += WAVE) XL[e] = X_[e];
+            for (int e = lane; e < T * NU; e += WAVE) UL[e] = U_[e];
+        }
+    }
 }
 
 // Derivative refresh: one wavefront per problem, lane = stage, as in k_ilqr_update.  (Measured and dropped,
@@ -1617,6 +1633,7 @@ __device__ __forceinline__ void ph_begin(const DevState* stp, int lg_in, int b_i
 // and small Hessians / state Hessian -- 3.8 -> 4.8 ms per update of 1 024 problems: a wavefront's fixed start-up, the
 // parameter record, the arrays' copy to LDS, the state loads, costs more than the routines it no longer runs; and the
 // kernel held to 256 registers for two wavefronts per SIMD: 218 registers in scratch, 10.9 -> 12.1 ms at 4 096.)
+template <bool FUSED>
 __device__ __forceinline__ void ph_refresh_block(const DevState* stp, int lg_in, int it_in, int b_in, int block_in)
 {
     const CstDev st = uni_dev(stp);
@@ -1631,11 +1648,16 @@ __device__ __forceinline__ void ph_refresh_block(const DevState* stp, int lg_in,
     Params P_regs;
     load_params_uniform(P_regs, (const Params*)st->params + b);
     const Params& P = P_regs;
-    if (!split_lds_arrays(st, b, dyn, pr.sc)) return;
-    __syncthreads();
+    if constexpr (!FUSED) {
+        if (!split_lds_arrays(st, b, dyn, pr.sc)) return;
+        __syncthreads();
+    }
     const int T = pr.T;
     const double* X_ = fld(st, TPL_F_X, b);
     const double* U_ = fld(st, TPL_F_U, b);
+    if constexpr (FUSED) {
+        if (st->lds_traj) { X_ = dyn; U_ = dyn + (int64_t)st->rows * NX; }       // the mirrors (ph_begin, ph_chain keep them current)
+    }
     const double* IS = fld(st, TPL_F_INT_STEP, b);
     const double* LAM = fld(st, TPL_F_LAGRANGE_MULTIPLIER, b);
     const double* BW = fld(st, TPL_F_BARRIER_WEIGHT, b);
@@ -1678,7 +1700,7 @@ __device__ __forceinline__ void ph_refresh_block(const DevState* stp, int lg_in,
     }
 }
 
-template <bool SECOND_ORDER, int INT_TYPE>
+template <bool SECOND_ORDER, int INT_TYPE, bool FUSED>
 __device__ __forceinline__ void ph_chain(const DevState* stp, int lg_in, int it_in, int b_in)
 {
     const CstDev st = uni_dev(stp);
@@ -1730,7 +1752,9 @@ __device__ __forceinline__ void ph_chain(const DevState* stp, int lg_in, int it_
     double* CU = (double*)st->cand_u + (int64_t)b * N_ALPHA * st->rows * NU;
     double* CC = (double*)st->cand_c + (int64_t)b * N_ALPHA * st->rows;
 
-    if (!split_lds_arrays(st, b, dyn, sc)) return;
+    if constexpr (!FUSED) {
+        if (!split_lds_arrays(st, b, dyn, sc)) return;
+    }
     const int R = st->rows;
     double* XL = dyn;
     double* UL = XL + (int64_t)R * NX;
@@ -1745,15 +1769,18 @@ __device__ __forceinline__ void ph_chain(const DevState* stp, int lg_in, int it_
     const double* KFBr = lt ? KBL : KFB;
     const double* UMAXr = lt ? UMXL : UMAX;
     const double* UMINr = lt ? UMNL : UMIN;
-    if (lt) {                                          // the mirrors live for one launch: bring them in
-        for (int e = lane; e < T * NU; e += WAVE) { UMXL[e] = UMAX[e]; UMNL[e] = UMIN[e]; UL[e] = U_[e]; }
-        for (int e = lane; e < (T + 1) * NX; e += WAVE) XL[e] = X_[e];
-    }
+    if constexpr (!FUSED) {
+        if (lt) {                                      // the mirrors live for one launch: bring them in
+            for (int e = lane; e < T * NU; e += WAVE) { UMXL[e] = UMAX[e]; UMNL[e] = UMIN[e]; UL[e] = U_[e]; }
+            for (int e = lane; e < (T + 1) * NX; e += WAVE) XL[e] = X_[e];
+        }
+    }                                                  // (fused: bounds from fused_setup, x and u from ph_begin / the last accepted step)
     // value function at the end of the horizon, optim.c:914-916
     if (lane == 0) {
         double x[NX];
+        const double* xs = (FUSED && lt) ? XL : X_;           // (fused: the mirror is current, and nearer)
 #pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)T * NX + i];
+        for (int i = 0; i < NX; ++i) x[i] = xs[(int64_t)T * NX + i];
         endGradient(P, x, (double)T, IS[T], s.Vx, 1);
         if (SECOND_ORDER) endHessian(P, x, (double)T, IS[T], s.Vxx, 1);
     }
@@ -1885,12 +1912,15 @@ __device__ __forceinline__ void ph_chain(const DevState* stp, int lg_in, int it_
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int e = e0 + k * WAVE + lane;
-                    if (e < (T + 1) * NX) { ox[k] = X_[e]; nv[k] = cx[e]; }
+                    if (e < (T + 1) * NX) { ox[k] = ((FUSED && lt) ? XL : X_)[e]; nv[k] = cx[e]; }
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int e = e0 + k * WAVE + lane;
-                    if (e < (T + 1) * NX) { PRV_X[e] = ox[k]; NXT_X[e] = nv[k]; X_[e] = nv[k]; }
+                    if (e < (T + 1) * NX) {
+                        PRV_X[e] = ox[k]; NXT_X[e] = nv[k]; X_[e] = nv[k];
+                        if constexpr (FUSED) { if (lt) XL[e] = nv[k]; }          // the mirror outlives this phase
+                    }
                 }
             }
             for (int e0 = 0; e0 < T * NU; e0 += WAVE * 4) {
@@ -1905,7 +1935,10 @@ __device__ __forceinline__ void ph_chain(const DevState* stp, int lg_in, int it_
                     const int e = e0 + k * WAVE + lane;
                     if (e < T * NU) {
                         PRV_K[e] = ok_[k];
-                        if (e >= opt_start * NU) { NXT_U[e] = nu_[k]; U_[e] = nu_[k]; }
+                        if (e >= opt_start * NU) {
+                            NXT_U[e] = nu_[k]; U_[e] = nu_[k];
+                            if constexpr (FUSED) { if (lt) UL[e] = nu_[k]; }
+                        }
                     }
                 }
             }
@@ -1980,18 +2013,18 @@ __device__ __forceinline__ bool lds_where_expected(const DevState* stp)
     return false;
 }
 
-__global__ __launch_bounds__(WAVE) void k_split_begin(const DevState* stp, int lg) { if (lds_where_expected(stp)) ph_begin(stp, lg, (int)blockIdx.x); }
+__global__ __launch_bounds__(WAVE) void k_split_begin(const DevState* stp, int lg) { if (lds_where_expected(stp)) ph_begin<false>(stp, lg, (int)blockIdx.x); }
 
 __global__ __launch_bounds__(WAVE) void k_split_refresh(const DevState* stp, int lg, int it)
 {
-    if (lds_where_expected(stp)) ph_refresh_block(stp, lg, it, (int)blockIdx.x, (int)blockIdx.y);
+    if (lds_where_expected(stp)) ph_refresh_block<false>(stp, lg, it, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 template <bool SECOND_ORDER, int INT_TYPE>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TPL_ILQR_CHAIN_WAVES, TPL_ILQR_CHAIN_WAVES_MAX)))
 void k_split_chain(const DevState* stp, int lg, int it)
 {
-    if (lds_where_expected(stp)) ph_chain<SECOND_ORDER, INT_TYPE>(stp, lg, it, (int)blockIdx.x);
+    if (lds_where_expected(stp)) ph_chain<SECOND_ORDER, INT_TYPE, false>(stp, lg, it, (int)blockIdx.x);
 }
 
 // ---- ... and the SAME phases behind ONE launch: k_ilqr_fused.  What kept k_ilqr_update at one wavefront per SIMD was not
@@ -2005,10 +2038,29 @@ void k_split_chain(const DevState* stp, int lg, int it)
 // profiles/r04_ilqr_split_ab.txt.
 // (the calls are to these out-of-line copies, which only k_ilqr_fused uses: a callee is compiled to the register budget
 // its callers share, so they get the two-wavefront budget while the split kernels above keep their own)
-__device__ __attribute__((noinline)) void fn_begin(const DevState* stp, int lg, int b) { ph_begin(stp, lg, b); }
-__device__ __attribute__((noinline)) void fn_refresh_block(const DevState* stp, int lg, int it, int b, int blk) { ph_refresh_block(stp, lg, it, b, blk); }
+__device__ __attribute__((noinline)) void fn_begin(const DevState* stp, int lg, int b) { ph_begin<true>(stp, lg, b); }
+__device__ __attribute__((noinline)) void fn_refresh_block(const DevState* stp, int lg, int it, int b, int blk) { ph_refresh_block<true>(stp, lg, it, b, blk); }
 template <bool SECOND_ORDER, int INT_TYPE>
-__device__ __attribute__((noinline)) void fn_chain(const DevState* stp, int lg, int it, int b) { ph_chain<SECOND_ORDER, INT_TYPE>(stp, lg, it, b); }
+__device__ __attribute__((noinline)) void fn_chain(const DevState* stp, int lg, int it, int b) { ph_chain<SECOND_ORDER, INT_TYPE, true>(stp, lg, it, b); }
+
+// what every phase of a launch of the split sequence fetches for itself, once per update: the array parameters and the
+// control bounds' mirrors into the LDS regions all phases agree on
+__device__ __attribute__((noinline)) void fused_setup(const DevState* stp, int b_in)
+{
+    const CstDev st = uni_dev(stp);
+    double* const dyn = (double*)st->lds_base_flat + LDS_HEAD;
+    const int b = uni_i(b_in), lane = threadIdx.x;
+    const SplitProb pr = split_prob(st, b);
+    if (!split_lds_arrays(st, b, dyn, pr.sc)) return;
+    if (st->lds_traj) {
+        const int R = st->rows;
+        double* UMXL = dyn + (int64_t)R * (NX + NU + NU + NU * NX);
+        double* UMNL = UMXL + (int64_t)R * NU;
+        const double* UMAX = fld(st, TPL_F_U_MAX, b);
+        const double* UMIN = fld(st, TPL_F_U_MIN, b);
+        for (int e = lane; e < pr.T * NU; e += WAVE) { UMXL[e] = UMAX[e]; UMNL[e] = UMIN[e]; }
+    }
+}
 
 template <bool SECOND_ORDER, int INT_TYPE>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TPL_ILQR_CHAIN_WAVES, TPL_ILQR_CHAIN_WAVES_MAX)))
@@ -2016,6 +2068,8 @@ void k_ilqr_fused(const DevState* stp, int rounds, int iterations, int blocks)
 {
     const int b = (int)blockIdx.x;
     if (!lds_where_expected(stp)) return;
+    fused_setup(stp, b);
+    __syncthreads();
     for (int lg = 0; lg < rounds; ++lg) {
         fn_begin(stp, lg, b);
         __syncthreads();
