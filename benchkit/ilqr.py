@@ -200,7 +200,8 @@ def batch_sweep(device=0, batches=(256, 512, 1024, 2048, 4096, 8192), updates=3,
     for b in batches:
         r = run(device=device, batch=b, updates=updates, warmup=warmup, workload=workload)
         out.append({"batch": b, "form": r["form"], "batched_iters_per_s": r["value"],
-                    "problem_iterations_per_s": r["problem_iterations_per_s"], "kernel_ms_per_update": r["kernel_ms_per_update"]})
+                    "problem_iterations_per_s": r["problem_iterations_per_s"], "kernel_ms_per_update": r["kernel_ms_per_update"],
+                    "fp64_frac": r["roofline"]["frac"]})
     return out
 
 
