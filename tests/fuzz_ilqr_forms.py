@@ -5,7 +5,7 @@ horizons and iteration budgets, a random integrator (EULER / HEUN / RK4: templat
 first-order method, one or two multiplier rounds, two updates with a shift in between.  Every field and scalar must agree
 bit for bit between the forms; the oracle is not involved (tests/fuzz_ilqr.py compares the solver with it).
 
-    python tests/fuzz_ilqr_forms.py [seeds per problem]"""
+    python tests/fuzz_ilqr_forms.py [seeds per problem]          (TPL_FORMS_FUZZ_DEBUG=ilqr_no_lds adds debug tokens to every leg)"""
 import os
 import sys
 
@@ -22,10 +22,11 @@ FIELDS = ("x", "u", "k", "K", "lagrange_multiplier", "next_x", "next_u", "prev_x
           "lxx", "luu", "lux", "traj_costs", "iterations", "lg_iterations", "alpha", "mu", "mu_step",
           "trajectory_changed", "improved", "termination_condition")
 FORMS = {0: "single", 1: "split", 2: "fused"}
+EXTRA = os.environ.get("TPL_FORMS_FUZZ_DEBUG", "")     # further TPLHIP_DEBUG tokens for every leg (ilqr_no_lds, ilqr_split_lds_kb=8 ...)
 
 
 def run(model, golden, seed, form):
-    os.environ["TPLHIP_DEBUG"] = f"ilqr_split={form}"
+    os.environ["TPLHIP_DEBUG"] = f"ilqr_split={form}" + ("," + EXTRA if EXTRA else "")
     rng = np.random.default_rng(seed)
     make = genopt.build(getattr(o, "config_" + model)(), model)
     g = np.load(os.path.join(GOLDEN, f"ilqr_{golden}.npz"))
