@@ -3,7 +3,7 @@
 library.  TPLHIP_DEBUG is read when a solver handle is created, so every leg runs in one process on one box; variant
 builds are loaded from their own path and never installed over the shipped library.
 
-    here:       python tools/ab_ilqr_split.py build NAME [--plain] [--model=M] [-DMACRO=V ...]  -> tools/ab_tmp/ilqr_NAME.so
+    here:       python tools/ab_ilqr_split.py build NAME [--ilp] [--model=M] [-DMACRO=V ...]  -> tools/ab_tmp/ilqr_NAME.so
     on the box: python tools/ab_ilqr_split.py [mpc|lateral] [--libs NAME,NAME] [--forms 0,1] [batches...]
 """
 import json
@@ -17,10 +17,11 @@ TMP = os.path.join(ROOT, "tools", "ab_tmp")
 
 
 def build(name, defines, model="trajectory_tracking_mpc"):
-    """(the shipped flags of tpl_amd/optim/genopt.py:compile_model; `--plain` among the defines drops its scheduler choice)"""
+    """(the shipped flags of tpl_amd/optim/genopt.py:compile_model; `--ilp` among the defines adds the max-ilp scheduler
+    strategy that was shipped for a while in round 4)"""
     os.makedirs(TMP, exist_ok=True)
-    sched = [] if "--plain" in defines else ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-    defines = [d for d in defines if d != "--plain"]
+    sched = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if "--ilp" in defines else []
+    defines = [d for d in defines if d not in ("--plain", "--ilp")]
     inc = os.path.join(ROOT, "tpl_amd", "models", f"{model}.inc")
     so = os.path.join(TMP, f"ilqr_{name}.so")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",

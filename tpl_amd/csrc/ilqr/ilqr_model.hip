@@ -940,6 +940,179 @@ __device__ __attribute__((noinline)) void line_search_rollouts(const RolloutArgs
 }
 
 // ---------------------------------------------------------------------------
+// The tail of one iteration, shared by k_ilqr_update and the chain phase of the split / fused forms: stage costs of the
+// candidates the rollouts left in CX / CU, the accept-first test, and the copies the reference makes after it
+// (optim.c:840-873, 960-985).  Returns whether a step was accepted; J, alpha and the two flags are updated.
+//   MIRRORS: the x / u mirrors in LDS outlive this call (single launch, fused form) -- keep them current on accept.
+//   OLD_X_FROM_MIRROR: read the trajectory being replaced from its mirror (it is current, and nearer).
+//   Stamp: diagnostic builds time the cost pass (12) and the ordered sums (13); a no-op otherwise.
+// ---------------------------------------------------------------------------
+struct IterTail {
+    double *X_, *U_, *IS, *NIS, *NXT_X, *NXT_U, *PRV_X, *PRV_K;
+    const double *KFF, *LAM, *BW;
+    double *CX, *CU, *CC, *XL, *UL;
+    int64_t rows;
+    int T, opt_start;
+    double dt;
+    bool lt;
+};
+
+template <bool MIRRORS, bool OLD_X_FROM_MIRROR, class Stamp>
+__device__ __forceinline__ bool iteration_tail(const IterTail& a, const Params& P, Lds& s, double& J, double& alpha,
+                                               bool& traj_changed, bool& improved, Stamp stamp)
+{
+    const int lane = threadIdx.x;
+    const int T = a.T, opt_start = a.opt_start;
+    const double dt = a.dt;
+    const bool lt = a.lt;
+    double* const X_ = a.X_; double* const U_ = a.U_; double* const IS = a.IS; double* const NIS = a.NIS;
+    double* const NXT_X = a.NXT_X; double* const NXT_U = a.NXT_U; double* const PRV_X = a.PRV_X; double* const PRV_K = a.PRV_K;
+    const double* const KFF = a.KFF; const double* const LAM = a.LAM; const double* const BW = a.BW;
+    double* const CX = a.CX; double* const CU = a.CU; double* const CC = a.CC; double* const XL = a.XL; double* const UL = a.UL;
+    double Jc = INFINITY;
+    // pass B: stage costs and their ordered sums, 64 (candidate, stage) pairs at a time -- in the order the
+    // reference tries the step sizes (optim.c:859-873): alpha = 1 first, and the seven smaller steps only when
+    // that one does not improve the cost.  Most iterations accept alpha = 1: one pass over the stages instead of
+    // seven.  The costs of candidates nobody asks for are never formed; what is formed is formed as before.
+    const int cc_rows = T + 1;
+    const bool cc_lds = N_ALPHA * cc_rows <= N_ALPHA * ROLL_RING * NX;
+    for (int part = 0; part < 2; ++part) {
+        const int n_t = T - opt_start;
+        const int c_lo = part ? 1 : 0, n_c = part ? N_ALPHA - 1 : 1;
+        for (int idx = lane; idx < n_c * n_t; idx += WAVE) {
+            const int cand = part ? 1 + idx % (N_ALPHA - 1) : 0;
+            const int t = opt_start + (part ? idx / (N_ALPHA - 1) : idx);
+            const double* cx = CX + ((int64_t)cand * a.rows + t) * NX;
+            const double* cu = CU + ((int64_t)cand * a.rows + t) * NU;
+            double x[NX], u[NU], c;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = cx[i];
+#pragma unroll
+            for (int d = 0; d < NU; ++d) u[d] = cu[d];
+            costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
+            // into LDS where the rollouts' ring (idle now) can hold them: a store to global
+            // memory would put a write acknowledgement in front of the next pass' loads
+            if (cc_lds) s.ring_x[cand * cc_rows + t] = c;
+            else CC[(int64_t)cand * a.rows + t] = c;
+        }
+        __syncthreads();
+        stamp(12);
+        // ordered sums, cost += c for t = optStart..T-1, then the end costs (:776-790)
+        if (lane >= c_lo && lane < c_lo + n_c) {
+            const double* cc = cc_lds ? &s.ring_x[lane * cc_rows] : CC + (int64_t)lane * a.rows;
+            double cost = 0.0, c;
+            int t = opt_start;
+            for (; t + 8 <= T; t += 8) {                    // eight loads in flight, additions in order
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = cc[t + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cost += v[q];
+            }
+            for (; t < T; ++t) cost += cc[t];
+            double x[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = CX[((int64_t)lane * a.rows + T) * NX + i];
+            endCosts(P, x, (double)T, dt, &c, 1);
+            cost += c;
+            Jc = cost;
+        }
+        if (part == 0 && __ballot(lane == 0 && Jc < J && isfinite(Jc) && Jc >= 0.0) != 0ull) break;
+    }
+    stamp(13);
+    // testImprovement, optim.c:840-857
+    const bool ok = lane < N_ALPHA && Jc < J && isfinite(Jc) && Jc >= 0.0;
+    const unsigned long long okm = __ballot(ok);
+    const bool accepted = okm != 0ull;
+    const int pick = accepted ? (int)__builtin_ctzll(okm) : N_ALPHA - 1;
+    {
+        double p10 = 1.0;
+        for (int i = 0; i < pick; ++i) p10 *= 10.0;
+        alpha = 1.0 / p10;
+    }
+    __syncthreads();                                   // candidates visible to the whole wave
+    const double* cx = CX + (int64_t)pick * a.rows * NX;
+    const double* cu = CU + (int64_t)pick * a.rows * NU;
+    if (accepted) {
+        J = __shfl(Jc, pick, WAVE);
+        // (all loads of a block of eight rows before its stores: loads and stores of a
+        // wavefront complete in order, a load behind a store waits for the write)
+        const double* const old_x = (OLD_X_FROM_MIRROR && lt) ? XL : X_;
+        for (int e0 = 0; e0 < (T + 1) * NX; e0 += WAVE * 8) {
+            double ox[8], nv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + k * WAVE + lane;
+                if (e < (T + 1) * NX) { ox[k] = old_x[e]; nv[k] = cx[e]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + k * WAVE + lane;
+                if (e < (T + 1) * NX) {
+                    PRV_X[e] = ox[k];
+                    NXT_X[e] = nv[k];
+                    X_[e] = nv[k];
+                    if constexpr (MIRRORS) { if (lt) XL[e] = nv[k]; }
+                }
+            }
+        }
+        for (int e0 = 0; e0 < T * NU; e0 += WAVE * 4) {
+            double ok_[4], nu_[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * WAVE + lane;
+                if (e < T * NU) { ok_[k] = KFF[e]; nu_[k] = (e >= opt_start * NU) ? cu[e] : 0.0; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * WAVE + lane;
+                if (e < T * NU) {
+                    PRV_K[e] = ok_[k];
+                    if (e >= opt_start * NU) {
+                        NXT_U[e] = nu_[k];
+                        U_[e] = nu_[k];
+                        if constexpr (MIRRORS) { if (lt) UL[e] = nu_[k]; }
+                    }
+                }
+            }
+        }
+        for (int e = lane; e < T + 1; e += WAVE) { NIS[e] = dt; IS[e] = dt; }
+        traj_changed = true;
+        improved = true;
+    } else {
+        // the reference leaves the last tried rollout (alpha = 1e-7) in next_*
+        for (int e0 = 0; e0 < (T + 1) * NX; e0 += WAVE * 8) {
+            double nv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + k * WAVE + lane;
+                if (e < (T + 1) * NX) nv[k] = cx[e];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + k * WAVE + lane;
+                if (e < (T + 1) * NX) NXT_X[e] = nv[k];
+            }
+        }
+        for (int e0 = opt_start * NU; e0 < T * NU; e0 += WAVE * 4) {
+            double nu_[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * WAVE + lane;
+                if (e < T * NU) nu_[k] = cu[e];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * WAVE + lane;
+                if (e < T * NU) NXT_U[e] = nu_[k];
+            }
+        }
+        for (int e = lane; e < T + 1; e += WAVE) NIS[e] = dt;
+    }
+    return accepted;
+}
+
+// ---------------------------------------------------------------------------
 // one update() of problem blockIdx.x  (optim.c:1091-1160)
 // ---------------------------------------------------------------------------
 // flat address of LDS offset 0 (the "shared aperture"); the host adds offsets to it to
@@ -1215,7 +1388,6 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
             STAMP(3);
             // ---- line search, optim.c:859-873: all eight alphas at once, accept the first
             const double J_prev = J;
-            double Jc = INFINITY;
             // pass A: the eight dynamics chains (lqrForwardPass :745-775 / lrForwardPass :803-818)
             {
                 RolloutArgs ra;
@@ -1241,146 +1413,12 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
             }
             __syncthreads();
             STAMP(11);
-            // pass B: stage costs and their ordered sums, 64 (candidate, stage) pairs at a time -- in the order the
-            // reference tries the step sizes (optim.c:859-873): alpha = 1 first, and the seven smaller steps only when
-            // that one does not improve the cost.  Most iterations accept alpha = 1: one pass over the stages instead of
-            // seven.  The costs of candidates nobody asks for are never formed; what is formed is formed as before.
-            const int cc_rows = T + 1;
-            const bool cc_lds = N_ALPHA * cc_rows <= N_ALPHA * ROLL_RING * NX;
-            for (int part = 0; part < 2; ++part) {
-                const int n_t = T - opt_start;
-                const int c_lo = part ? 1 : 0, n_c = part ? N_ALPHA - 1 : 1;
-                for (int idx = lane; idx < n_c * n_t; idx += WAVE) {
-                    const int cand = part ? 1 + idx % (N_ALPHA - 1) : 0;
-                    const int t = opt_start + (part ? idx / (N_ALPHA - 1) : idx);
-                    const double* cx = CX + ((int64_t)cand * st.rows + t) * NX;
-                    const double* cu = CU + ((int64_t)cand * st.rows + t) * NU;
-                    double x[NX], u[NU], c;
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) x[i] = cx[i];
-#pragma unroll
-                    for (int d = 0; d < NU; ++d) u[d] = cu[d];
-                    costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
-                        // into LDS where the rollouts' ring (idle now) can hold them: a store to global
-                        // memory would put a write acknowledgement in front of the next pass' loads
-                    if (cc_lds) s.ring_x[cand * cc_rows + t] = c;
-                    else CC[(int64_t)cand * st.rows + t] = c;
-                }
-                __syncthreads();
-                STAMP(12);
-                // ordered sums, cost += c for t = optStart..T-1, then the end costs (:776-790)
-                if (lane >= c_lo && lane < c_lo + n_c) {
-                    const double* cc = cc_lds ? &s.ring_x[lane * cc_rows] : CC + (int64_t)lane * st.rows;
-                    double cost = 0.0, c;
-                    int t = opt_start;
-                    for (; t + 8 <= T; t += 8) {                    // eight loads in flight, additions in order
-                        double v[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = cc[t + q];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) cost += v[q];
-                    }
-                    for (; t < T; ++t) cost += cc[t];
-                    double x[NX];
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) x[i] = CX[((int64_t)lane * st.rows + T) * NX + i];
-                    endCosts(P, x, (double)T, dt, &c, 1);
-                    cost += c;
-                    Jc = cost;
-                }
-                if (part == 0 && __ballot(lane == 0 && Jc < J && isfinite(Jc) && Jc >= 0.0) != 0ull) break;
-            }
-            STAMP(13);
-            // testImprovement, optim.c:840-857
-            const bool ok = lane < N_ALPHA && Jc < J && isfinite(Jc) && Jc >= 0.0;
-            const unsigned long long okm = __ballot(ok);
-            const bool accepted = okm != 0ull;
-            const int pick = accepted ? (int)__builtin_ctzll(okm) : N_ALPHA - 1;
-            {
-                double a = 1.0;
-                for (int i = 0; i < pick; ++i) a *= 10.0;
-                alpha = 1.0 / a;
-            }
-            __syncthreads();                                   // candidates visible to the whole wave
-            {
-                const double* cx = CX + (int64_t)pick * st.rows * NX;
-                const double* cu = CU + (int64_t)pick * st.rows * NU;
-                if (accepted) {
-                    J = __shfl(Jc, pick, WAVE);
-                    // (all loads of a block of eight rows before its stores: loads and stores of a
-                    // wavefront complete in order, a load behind a store waits for the write)
-                    for (int e0 = 0; e0 < (T + 1) * NX; e0 += WAVE * 8) {
-                        double ox[8], nv[8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const int e = e0 + k * WAVE + lane;
-                            if (e < (T + 1) * NX) { ox[k] = X_[e]; nv[k] = cx[e]; }
-                        }
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const int e = e0 + k * WAVE + lane;
-                            if (e < (T + 1) * NX) {
-                                PRV_X[e] = ox[k];
-                                NXT_X[e] = nv[k];
-                                X_[e] = nv[k];
-                                if (lt) XL[e] = nv[k];
-                            }
-                        }
-                    }
-                    for (int e0 = 0; e0 < T * NU; e0 += WAVE * 4) {
-                        double ok_[4], nu_[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int e = e0 + k * WAVE + lane;
-                            if (e < T * NU) { ok_[k] = KFF[e]; nu_[k] = (e >= opt_start * NU) ? cu[e] : 0.0; }
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int e = e0 + k * WAVE + lane;
-                            if (e < T * NU) {
-                                PRV_K[e] = ok_[k];
-                                if (e >= opt_start * NU) {
-                                    NXT_U[e] = nu_[k];
-                                    U_[e] = nu_[k];
-                                    if (lt) UL[e] = nu_[k];
-                                }
-                            }
-                        }
-                    }
-                    for (int e = lane; e < T + 1; e += WAVE) { NIS[e] = dt; IS[e] = dt; }
-                    traj_changed = true;
-                    improved = true;
-                } else {
-                    // the reference leaves the last tried rollout (alpha = 1e-7) in next_*
-                    for (int e0 = 0; e0 < (T + 1) * NX; e0 += WAVE * 8) {
-                        double nv[8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const int e = e0 + k * WAVE + lane;
-                            if (e < (T + 1) * NX) nv[k] = cx[e];
-                        }
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const int e = e0 + k * WAVE + lane;
-                            if (e < (T + 1) * NX) NXT_X[e] = nv[k];
-                        }
-                    }
-                    for (int e0 = opt_start * NU; e0 < T * NU; e0 += WAVE * 4) {
-                        double nu_[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int e = e0 + k * WAVE + lane;
-                            if (e < T * NU) nu_[k] = cu[e];
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int e = e0 + k * WAVE + lane;
-                            if (e < T * NU) NXT_U[e] = nu_[k];
-                        }
-                    }
-                    for (int e = lane; e < T + 1; e += WAVE) NIS[e] = dt;
-                }
-            }
+            IterTail tail;
+            tail.X_ = X_; tail.U_ = U_; tail.IS = IS; tail.NIS = NIS; tail.NXT_X = NXT_X; tail.NXT_U = NXT_U;
+            tail.PRV_X = PRV_X; tail.PRV_K = PRV_K; tail.KFF = KFF; tail.LAM = LAM; tail.BW = BW;
+            tail.CX = CX; tail.CU = CU; tail.CC = CC; tail.XL = XL; tail.UL = UL;
+            tail.rows = st.rows; tail.T = T; tail.opt_start = opt_start; tail.dt = dt; tail.lt = lt;
+            const bool accepted = iteration_tail<true, false>(tail, P, s, J, alpha, traj_changed, improved, [&](int i) { (void)i; STAMP(i); });
             __syncthreads();
 
             STAMP(5);
@@ -1829,7 +1867,6 @@ __device__ __forceinline__ void ph_chain(const DevState* stp, int lg_in, int it_
 
     // ---- line search, optim.c:859-873: all eight alphas at once, accept the first
     const double J_prev = J;
-    double Jc = INFINITY;
     {
         RolloutArgs ra;
         ra.CX = CX; ra.CU = CU; ra.X_ = X_; ra.KFFr = KFFr; ra.Ur = Ur; ra.UMAXr = UMAXr; ra.UMINr = UMINr;
@@ -1845,137 +1882,12 @@ __device__ __forceinline__ void ph_chain(const DevState* stp, int lg_in, int it_
         }
     }
     __syncthreads();
-    // pass B: stage costs and their ordered sums, 64 (candidate, stage) pairs at a time -- in the order the
-    // reference tries the step sizes (optim.c:859-873): alpha = 1 first, and the seven smaller steps only when
-    // that one does not improve the cost.  Most iterations accept alpha = 1: one pass over the stages instead of
-    // seven.  The costs of candidates nobody asks for are never formed; what is formed is formed as before.
-    const int cc_rows = T + 1;
-    const bool cc_lds = N_ALPHA * cc_rows <= N_ALPHA * ROLL_RING * NX;
-    for (int part = 0; part < 2; ++part) {
-        const int n_t = T - opt_start;
-        const int c_lo = part ? 1 : 0, n_c = part ? N_ALPHA - 1 : 1;
-        for (int idx = lane; idx < n_c * n_t; idx += WAVE) {
-            const int cand = part ? 1 + idx % (N_ALPHA - 1) : 0;
-            const int t = opt_start + (part ? idx / (N_ALPHA - 1) : idx);
-            const double* cx = CX + ((int64_t)cand * st->rows + t) * NX;
-            const double* cu = CU + ((int64_t)cand * st->rows + t) * NU;
-            double x[NX], u[NU], c;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = cx[i];
-#pragma unroll
-            for (int d = 0; d < NU; ++d) u[d] = cu[d];
-            costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
-            if (cc_lds) s.ring_x[cand * cc_rows + t] = c;
-            else CC[(int64_t)cand * st->rows + t] = c;
-        }
-        __syncthreads();
-        // ordered sums, cost += c for t = optStart..T-1, then the end costs (:776-790)
-        if (lane >= c_lo && lane < c_lo + n_c) {
-            const double* cc = cc_lds ? &s.ring_x[lane * cc_rows] : CC + (int64_t)lane * st->rows;
-            double cost = 0.0, c;
-            int t = opt_start;
-            for (; t + 8 <= T; t += 8) {                    // eight loads in flight, additions in order
-                double v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = cc[t + q];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) cost += v[q];
-            }
-            for (; t < T; ++t) cost += cc[t];
-            double x[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = CX[((int64_t)lane * st->rows + T) * NX + i];
-            endCosts(P, x, (double)T, dt, &c, 1);
-            cost += c;
-            Jc = cost;
-        }
-        if (part == 0 && __ballot(lane == 0 && Jc < J && isfinite(Jc) && Jc >= 0.0) != 0ull) break;
-    }
-    // testImprovement, optim.c:840-857
-    const bool ok = lane < N_ALPHA && Jc < J && isfinite(Jc) && Jc >= 0.0;
-    const unsigned long long okm = __ballot(ok);
-    const bool accepted = okm != 0ull;
-    const int pick = accepted ? (int)__builtin_ctzll(okm) : N_ALPHA - 1;
-    {
-        double a = 1.0;
-        for (int i = 0; i < pick; ++i) a *= 10.0;
-        alpha = 1.0 / a;
-    }
-    __syncthreads();
-    {
-        const double* cx = CX + (int64_t)pick * st->rows * NX;
-        const double* cu = CU + (int64_t)pick * st->rows * NU;
-        if (accepted) {
-            J = __shfl(Jc, pick, WAVE);
-            for (int e0 = 0; e0 < (T + 1) * NX; e0 += WAVE * 8) {
-                double ox[8], nv[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int e = e0 + k * WAVE + lane;
-                    if (e < (T + 1) * NX) { ox[k] = ((FUSED && lt) ? XL : X_)[e]; nv[k] = cx[e]; }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int e = e0 + k * WAVE + lane;
-                    if (e < (T + 1) * NX) {
-                        PRV_X[e] = ox[k]; NXT_X[e] = nv[k]; X_[e] = nv[k];
-                        if constexpr (FUSED) { if (lt) XL[e] = nv[k]; }          // the mirror outlives this phase
-                    }
-                }
-            }
-            for (int e0 = 0; e0 < T * NU; e0 += WAVE * 4) {
-                double ok_[4], nu_[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int e = e0 + k * WAVE + lane;
-                    if (e < T * NU) { ok_[k] = KFF[e]; nu_[k] = (e >= opt_start * NU) ? cu[e] : 0.0; }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int e = e0 + k * WAVE + lane;
-                    if (e < T * NU) {
-                        PRV_K[e] = ok_[k];
-                        if (e >= opt_start * NU) {
-                            NXT_U[e] = nu_[k]; U_[e] = nu_[k];
-                            if constexpr (FUSED) { if (lt) UL[e] = nu_[k]; }
-                        }
-                    }
-                }
-            }
-            for (int e = lane; e < T + 1; e += WAVE) { NIS[e] = dt; IS[e] = dt; }
-            traj_changed = true;
-            improved = true;
-        } else {
-            // the reference leaves the last tried rollout (alpha = 1e-7) in next_*
-            for (int e0 = 0; e0 < (T + 1) * NX; e0 += WAVE * 8) {
-                double nv[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int e = e0 + k * WAVE + lane;
-                    if (e < (T + 1) * NX) nv[k] = cx[e];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int e = e0 + k * WAVE + lane;
-                    if (e < (T + 1) * NX) NXT_X[e] = nv[k];
-                }
-            }
-            for (int e0 = opt_start * NU; e0 < T * NU; e0 += WAVE * 4) {
-                double nu_[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int e = e0 + k * WAVE + lane;
-                    if (e < T * NU) nu_[k] = cu[e];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int e = e0 + k * WAVE + lane;
-                    if (e < T * NU) NXT_U[e] = nu_[k];
-                }
-            }
-            for (int e = lane; e < T + 1; e += WAVE) NIS[e] = dt;
-        }
-    }
+    IterTail tail;
+    tail.X_ = X_; tail.U_ = U_; tail.IS = IS; tail.NIS = NIS; tail.NXT_X = NXT_X; tail.NXT_U = NXT_U;
+    tail.PRV_X = PRV_X; tail.PRV_K = PRV_K; tail.KFF = KFF; tail.LAM = LAM; tail.BW = BW;
+    tail.CX = CX; tail.CU = CU; tail.CC = CC; tail.XL = XL; tail.UL = UL;
+    tail.rows = st->rows; tail.T = T; tail.opt_start = opt_start; tail.dt = dt; tail.lt = lt;
+    const bool accepted = iteration_tail<FUSED, FUSED>(tail, P, s, J, alpha, traj_changed, improved, [](int) {});
     if (SECOND_ORDER) {                                // mu schedule, optim.c:989-999
         mu_step = accepted ? (mu_step - 1 > 0 ? mu_step - 1 : 0) : (mu_step + 1 < 7 ? mu_step + 1 : 7);
         if (mu_step == 0) {

@@ -816,15 +816,12 @@ def compile_model(name, out_dir=None, force=False):
             return paths["so"]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = paths["so"] + f".tmp{os.getpid()}"
-    # The solver is one wavefront's dependent chains.  For the heavy models (six or more states: tpl's tracking MPCs) the
-    # scheduler that orders for instruction-level parallelism instead of register pressure is 1.5-2 % faster in every
-    # launch form; lateral_profile loses 0.3-1.4 % with it and keeps the default (profiles/r04_ilqr_split_ab.txt).
-    # Scheduling does not touch the arithmetic.
-    with open(paths["inc"]) as f:
-        m = re.search(r"^#define TPL_X (\d+)", f.read(), re.M)
-    sched = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if m and int(m.group(1)) >= 6 else []
+    # (hipcc's default instruction scheduler.  `-mllvm -amdgpu-sched-strategy=max-ilp` is 1.5-2 % faster on the heavy models
+    # and was shipped for a few revisions of round 4 -- until one refactoring of k_ilqr_update came out of it with a wrong
+    # regularisation value for problems that end on two rejected steps (mu = 1 where mu_step = 2 says 10: the scheduler
+    # strategy, not the source, decided; profiles/r04_ilqr_split_ab.txt).  Not worth that risk.)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-fno-fast-math", "-ffp-contract=off", "-Wall", "-Wno-unused-function", *sched,
+           "-fvisibility=hidden", "-fno-fast-math", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
            f"-DTPL_MODEL_INC=\"{paths['inc']}\"", "-I", os.path.join(_PKG, "..", "include"),
            "-o", tmp, src]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
