@@ -1,3 +1,5 @@
+"""Which fields differ between the launch forms of the batched iLQR update() on one ragged batch of tests/fuzz_ilqr_forms.py
+(the case that exposed the max-ilp miscompile of round 4): python tools/dbg_forms.py [path of a solver library build]"""
 import sys, os
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np
