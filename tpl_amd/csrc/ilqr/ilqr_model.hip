@@ -1113,6 +1113,123 @@ __device__ __forceinline__ bool iteration_tail(const IterTail& a, const Params& 
 }
 
 // ---------------------------------------------------------------------------
+// Three more pieces both kernels run as they stand (k_ilqr_update; the begin / chain phases of the split and fused forms).
+// ---------------------------------------------------------------------------
+// Initial trajectory rollout and its cost, optim.c:1101-1111.  The dynamics chain is serial in t (one quad, see
+// dynamics_quad); the stage costs only need (x_t, u_t), so they are evaluated for all stages in parallel afterwards and
+// summed in the reference's order t = optStart..T-1.  Returns J on lane 0 (other lanes: 0).
+__device__ __forceinline__ double initial_rollout_cost(const Params& P, double* X_, const double* U_, double* IS, const double* LAM,
+                                                       const double* BW, double* CC, int T, int opt_start, double dt, int int_type)
+{
+    const int lane = threadIdx.x;
+    double J = 0.0;
+    if (lane < 4) {                                    // one quad: see dynamics_quad
+        double x[NX], u[NU], xn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)opt_start * NX + i];
+        for (int t = opt_start; t < T; ++t) {
+#pragma unroll
+            for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
+            if (lane == 0) IS[t] = dt;
+            dynamics_quad(P, x, u, t, dt, int_type, xn);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                x[i] = xn[i];
+                if (lane == 0) X_[(int64_t)(t + 1) * NX + i] = xn[i];
+            }
+        }
+        if (lane == 0) IS[T] = dt;
+    }
+    __syncthreads();
+    for (int t = opt_start + lane; t < T; t += WAVE) {
+        double x[NX], u[NU], c;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
+#pragma unroll
+        for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
+        costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
+        CC[t] = c;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        double x[NX], c;
+        int t = opt_start;
+        for (; t + 8 <= T; t += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = CC[t + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) J += v[q];
+        }
+        for (; t < T; ++t) J += CC[t];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)T * NX + i];
+        endCosts(P, x, (double)T, dt, &c, 1);
+        J += c;
+    }
+    return J;
+}
+
+// Multiplier update, optim.c:1119-1132 (lane = stage).
+__device__ __forceinline__ void multiplier_update(const Params& P, const double* X_, const double* U_, const double* IS, double* LAM,
+                                                  const double* BW, const double* LGL, int T, int opt_start)
+{
+    const int lane = threadIdx.x;
+    if (NC > 0) {
+        for (int t = opt_start + lane; t < T; t += WAVE) {
+            double x[NX], u[NU], lam[NCM], g[NCM];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
+#pragma unroll
+            for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
+#pragma unroll
+            for (int c = 0; c < NCM; ++c) { lam[c] = LAM[(int64_t)t * NCM + c]; g[c] = 0.0; }
+            constraints(P, x, u, lam, BW, (double)t, IS[t], g, 1);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                double v = lam[c] + BW[c] * g[c];
+                v = v > 0.0 ? v : 0.0;
+                v = LGL[c] < v ? LGL[c] : v;
+                LAM[(int64_t)t * NCM + c] = v;
+            }
+        }
+    }
+}
+
+// First-order backward pass, optim.c:1044-1073 (s.Vx holds the terminal gradient on entry).
+__device__ __forceinline__ void first_order_backward(Lds& s, const double* FX, const double* FU, const double* LX, const double* LU,
+                                                     const double* U_, const double* UMAX, const double* UMIN, double* G_, double* KFF,
+                                                     double* KL, bool lt, int T)
+{
+    const int lane = threadIdx.x;
+    for (int t = T - 1; t >= 0; --t) {
+        double qx = 0.0, qu = 0.0;
+        if (lane < NX) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < NX; ++m) acc += FX[(int64_t)t * NX * NX + m * NX + lane] * s.Vx[m];
+            qx = LX[(int64_t)t * NX + lane] + acc;
+        }
+        if (lane < NU) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < NX; ++m) acc += FU[(int64_t)t * NX * NU + m * NU + lane] * s.Vx[m];
+            qu = LU[(int64_t)t * NU + lane] + acc;
+            G_[(int64_t)t * NU + lane] = qu;
+            double kk = qu;
+            const double c = U_[(int64_t)t * NU + lane] - qu;
+            if (c > UMAX[(int64_t)t * NU + lane]) kk = U_[(int64_t)t * NU + lane] - UMAX[(int64_t)t * NU + lane];
+            if (c < UMIN[(int64_t)t * NU + lane]) kk = U_[(int64_t)t * NU + lane] - UMIN[(int64_t)t * NU + lane];
+            KFF[(int64_t)t * NU + lane] = kk;
+            if (lt) KL[(int64_t)t * NU + lane] = kk;
+        }
+        __syncthreads();
+        if (lane < NX) s.Vx[lane] = qx;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
 // one update() of problem blockIdx.x  (optim.c:1091-1160)
 // ---------------------------------------------------------------------------
 // flat address of LDS offset 0 (the "shared aperture"); the host adds offsets to it to
@@ -1217,55 +1334,9 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
     if (lane == 0 && st.stamps) for (int i = 4; i < 16; ++i) st.stamps[(int64_t)b * 16 + i] = 0;
     long long t_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
-    // ---- initial trajectory rollout, optim.c:1101-1111.  The dynamics chain is serial in
-    // t (one lane); the stage costs only need (x_t, u_t), so they are evaluated for all
-    // stages in parallel afterwards and summed in the reference's order t = optStart..T-1.
-    double J = 0.0;
+    // ---- initial trajectory rollout and its cost, optim.c:1101-1111
     double* CC = st.cand_c + (int64_t)b * N_ALPHA * st.rows;
-    if (lane < 4) {                                    // one quad: see dynamics_quad
-        double x[NX], u[NU], xn[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)opt_start * NX + i];
-        for (int t = opt_start; t < T; ++t) {
-#pragma unroll
-            for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
-            if (lane == 0) IS[t] = dt;
-            dynamics_quad(P, x, u, t, dt, int_type, xn);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                x[i] = xn[i];
-                if (lane == 0) X_[(int64_t)(t + 1) * NX + i] = xn[i];
-            }
-        }
-        if (lane == 0) IS[T] = dt;
-    }
-    __syncthreads();
-    for (int t = opt_start + lane; t < T; t += WAVE) {
-        double x[NX], u[NU], c;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
-#pragma unroll
-        for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
-        costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
-        CC[t] = c;
-    }
-    __syncthreads();
-    if (lane == 0) {
-        double x[NX], c;
-        int t = opt_start;
-        for (; t + 8 <= T; t += 8) {
-            double v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = CC[t + q];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) J += v[q];
-        }
-        for (; t < T; ++t) J += CC[t];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)T * NX + i];
-        endCosts(P, x, (double)T, dt, &c, 1);
-        J += c;
-    }
+    double J = initial_rollout_cost(P, X_, U_, IS, LAM, BW, CC, T, opt_start, dt, int_type);
     J = __shfl(J, 0, WAVE);
     __syncthreads();
     if (lt) {
@@ -1276,26 +1347,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
     STAMP(0);
 
     for (lg_it = 0; lg_it < max_lg; ++lg_it) {
-        // ---- multiplier update, optim.c:1119-1132 (lane = stage)
-        if (NC > 0) {
-            for (int t = opt_start + lane; t < T; t += WAVE) {
-                double x[NX], u[NU], lam[NCM], g[NCM];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
-#pragma unroll
-                for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
-#pragma unroll
-                for (int c = 0; c < NCM; ++c) { lam[c] = LAM[(int64_t)t * NCM + c]; g[c] = 0.0; }
-                constraints(P, x, u, lam, BW, (double)t, IS[t], g, 1);
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    double v = lam[c] + BW[c] * g[c];
-                    v = v > 0.0 ? v : 0.0;
-                    v = LGL[c] < v ? LGL[c] : v;
-                    LAM[(int64_t)t * NCM + c] = v;
-                }
-            }
-        }
+        multiplier_update(P, X_, U_, IS, LAM, BW, LGL, T, opt_start);      // optim.c:1119-1132
         __syncthreads();
         STAMP(1);
         traj_changed = true;
@@ -1357,32 +1409,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                 else riccati_backward(ra, (LdsAS*)(unsigned long long)(unsigned)(unsigned long long)&s);
 #endif
             } else {
-                // ---- first-order backward pass, optim.c:1044-1073
-                for (int t = T - 1; t >= 0; --t) {
-                    double qx = 0.0, qu = 0.0;
-                    if (lane < NX) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int m = 0; m < NX; ++m) acc += FX[(int64_t)t * NX * NX + m * NX + lane] * s.Vx[m];
-                        qx = LX[(int64_t)t * NX + lane] + acc;
-                    }
-                    if (lane < NU) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int m = 0; m < NX; ++m) acc += FU[(int64_t)t * NX * NU + m * NU + lane] * s.Vx[m];
-                        qu = LU[(int64_t)t * NU + lane] + acc;
-                        G_[(int64_t)t * NU + lane] = qu;
-                        double kk = qu;
-                        const double c = U_[(int64_t)t * NU + lane] - qu;
-                        if (c > UMAX[(int64_t)t * NU + lane]) kk = U_[(int64_t)t * NU + lane] - UMAX[(int64_t)t * NU + lane];
-                        if (c < UMIN[(int64_t)t * NU + lane]) kk = U_[(int64_t)t * NU + lane] - UMIN[(int64_t)t * NU + lane];
-                        KFF[(int64_t)t * NU + lane] = kk;
-                        if (lt) KL[(int64_t)t * NU + lane] = kk;
-                    }
-                    __syncthreads();
-                    if (lane < NX) s.Vx[lane] = qx;
-                    __syncthreads();
-                }
+                first_order_backward(s, FX, FU, LX, LU, U_, UMAX, UMIN, G_, KFF, KL, lt, T);   // optim.c:1044-1073
             }
 
             STAMP(3);
@@ -1575,78 +1602,18 @@ __device__ __forceinline__ void ph_begin(const DevState* stp, int lg_in, int b_i
     }
 
     if (lg == 0) {
-        // ---- initial trajectory rollout and its cost, optim.c:1101-1111 (as in k_ilqr_update)
-        double J = 0.0;
+        // ---- initial trajectory rollout and its cost, optim.c:1101-1111
         double* CC = (double*)st->cand_c + (int64_t)b * N_ALPHA * st->rows;
-        if (lane < 4) {
-            double x[NX], u[NU], xn[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)opt_start * NX + i];
-            for (int t = opt_start; t < T; ++t) {
-#pragma unroll
-                for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
-                if (lane == 0) IS[t] = dt;
-                dynamics_quad(P, x, u, t, dt, int_type, xn);
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    x[i] = xn[i];
-                    if (lane == 0) X_[(int64_t)(t + 1) * NX + i] = xn[i];
-                }
-            }
-            if (lane == 0) IS[T] = dt;
-        }
-        __syncthreads();
-        for (int t = opt_start + lane; t < T; t += WAVE) {
-            double x[NX], u[NU], c;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
-#pragma unroll
-            for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
-            costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
-            CC[t] = c;
-        }
-        __syncthreads();
+        const double J = initial_rollout_cost(P, X_, U_, IS, LAM, BW, CC, T, opt_start, dt, int_type);
         if (lane == 0) {
-            double x[NX], c;
-            int t = opt_start;
-            for (; t + 8 <= T; t += 8) {
-                double v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = CC[t + q];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) J += v[q];
-            }
-            for (; t < T; ++t) J += CC[t];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)T * NX + i];
-            endCosts(P, x, (double)T, dt, &c, 1);
-            J += c;
             sc[TPL_S_TRAJ_COSTS] = J;
             sc[TPL_S_LG_ITERATIONS] = (double)(pr.max_lg > 0 ? pr.max_lg : 0);
         }
         __syncthreads();
         if (pr.max_lg <= 0) return;
     }
-    // ---- multiplier update, optim.c:1119-1132 (lane = stage), and the loop state of this round
-    if (NC > 0) {
-        for (int t = opt_start + lane; t < T; t += WAVE) {
-            double x[NX], u[NU], lam[NCM], g[NCM];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)t * NX + i];
-#pragma unroll
-            for (int d = 0; d < NU; ++d) u[d] = U_[(int64_t)t * NU + d];
-#pragma unroll
-            for (int c = 0; c < NCM; ++c) { lam[c] = LAM[(int64_t)t * NCM + c]; g[c] = 0.0; }
-            constraints(P, x, u, lam, BW, (double)t, IS[t], g, 1);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                double v = lam[c] + BW[c] * g[c];
-                v = v > 0.0 ? v : 0.0;
-                v = LGL[c] < v ? LGL[c] : v;
-                LAM[(int64_t)t * NCM + c] = v;
-            }
-        }
-    }
+    // ---- multiplier update, optim.c:1119-1132, and the loop state of this round
+    multiplier_update(P, X_, U_, IS, LAM, BW, LGL, T, opt_start);
     if (lane == 0) {
         sc[TPL_S_TRAJECTORY_CHANGED] = 1.0;
         sc[TPL_S_IMPROVED] = 0.0;
@@ -1837,32 +1804,7 @@ __device__ __forceinline__ void ph_chain(const DevState* stp, int lg_in, int it_
         else if constexpr (CHAIN_INLINE) riccati_backward_impl(ra, sl);
         else riccati_backward(ra, sl);
     } else {
-        // ---- first-order backward pass, optim.c:1044-1073
-        for (int t = T - 1; t >= 0; --t) {
-            double qx = 0.0, qu = 0.0;
-            if (lane < NX) {
-                double acc = 0.0;
-#pragma unroll
-                for (int m = 0; m < NX; ++m) acc += FX[(int64_t)t * NX * NX + m * NX + lane] * s.Vx[m];
-                qx = LX[(int64_t)t * NX + lane] + acc;
-            }
-            if (lane < NU) {
-                double acc = 0.0;
-#pragma unroll
-                for (int m = 0; m < NX; ++m) acc += FU[(int64_t)t * NX * NU + m * NU + lane] * s.Vx[m];
-                qu = LU[(int64_t)t * NU + lane] + acc;
-                G_[(int64_t)t * NU + lane] = qu;
-                double kk = qu;
-                const double c = U_[(int64_t)t * NU + lane] - qu;
-                if (c > UMAX[(int64_t)t * NU + lane]) kk = U_[(int64_t)t * NU + lane] - UMAX[(int64_t)t * NU + lane];
-                if (c < UMIN[(int64_t)t * NU + lane]) kk = U_[(int64_t)t * NU + lane] - UMIN[(int64_t)t * NU + lane];
-                KFF[(int64_t)t * NU + lane] = kk;
-                if (lt) KL[(int64_t)t * NU + lane] = kk;
-            }
-            __syncthreads();
-            if (lane < NX) s.Vx[lane] = qx;
-            __syncthreads();
-        }
+        first_order_backward(s, FX, FU, LX, LU, U_, UMAX, UMIN, G_, KFF, KL, lt, T);   // optim.c:1044-1073
     }
 
     // ---- line search, optim.c:859-873: all eight alphas at once, accept the first
