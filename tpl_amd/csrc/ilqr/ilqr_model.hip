@@ -10,7 +10,15 @@
 //  * ONE WAVEFRONT PER PROBLEM (64-thread workgroup), `batch` workgroups per
 //    launch, one launch per update() -- the whole outer loop (initial rollout,
 //    multiplier update, every iLQR iteration, line search) runs inside the
-//    kernel, so there is no host round trip per iteration;
+//    kernel, so there is no host round trip per iteration.  Two kernels do
+//    that: k_ilqr_update (one body, 480 registers, one wavefront per SIMD:
+//    what a caller with up to 4 x CUs problems gets) and k_ilqr_fused (the
+//    phases as real calls, each compiled to 256 registers: two wavefronts per
+//    SIMD hide each other's dependent chains -- batches beyond that, for the
+//    models whose derivative refresh is heavy).  The split sequence
+//    k_split_* runs the same phases as launches (the A/B leg).  All three
+//    give the same bits; the pieces they share are functions further down
+//    (riccati_backward, line_search_rollouts, iteration_tail, ...);
 //  * derivative refresh and the multiplier update are parallel over the
 //    horizon (lane = stage);
 //  * the backward Riccati recursion is sequential in the stage but parallel
@@ -20,9 +28,10 @@
 //    small and too latency-bound for MFMA (v_mfma_f64_16x16x4 would be >90 %
 //    padding); DESIGN.md has the numbers;
 //  * the eight line-search candidates alpha = 10^-i are rolled out
-//    CONCURRENTLY on eight lanes and the first improving one in the order
+//    CONCURRENTLY on eight lane quads and the first improving one in the order
 //    i = 0..7 is taken, which is exactly the reference's accept-first result
-//    (optim.c:859-873) at the cost of a single rollout;
+//    (optim.c:859-873) at the cost of a single rollout; their stage costs are
+//    formed in that order too (alpha = 1 first, the rest only if it fails);
 //  * all state lives in HBM in the layout of the host mirrors (row-major
 //    [stage][...] per problem), so upload/download are plain copies and the
 //    backward pass reads each stage's blocks as contiguous, coalesced runs.
