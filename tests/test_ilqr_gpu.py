@@ -399,14 +399,21 @@ def test_large_batch_takes_the_fused_form_and_matches_oracle():
         assert abs(opt.traj_costs[b] - ref.traj_costs) < 1e-8 * abs(ref.traj_costs), b
 
 
-def test_small_models_keep_the_single_launch_for_large_batches():
-    """The split form only pays where a heavy derivative refresh holds the single launch to one wavefront per SIMD (the
-    tracking MPCs); lateral_profile is measured slower through it at every batch size (profiles/r04_ilqr_split_ab.txt), so a
-    large batch of it must stay on the single launch unless the form is forced."""
+def test_small_models_take_the_fused_form_for_large_batches_too(monkeypatch):
+    """Not only the tracking MPCs: every model whose single launch is held to one wavefront per SIMD gains from the fused
+    form once the batch exceeds what that launch keeps resident (tools/ab_ilqr_forms_all.py, profiles/r04_ilqr_split_ab.txt:
+    lateral_profile +22 ... +34 %).  A large batch of lateral_profile takes it by itself, and every 128th problem matches the
+    single launch bit for bit."""
     make = _factory("lateral_profile")
     g = np.load(os.path.join(GOLDEN, "ilqr_lateral.npz"))
-    opt = make(batch=2048, horizon=int(g["in.horizon"]))
-    cases.apply_inputs(opt, g)
-    opt.update()
-    assert opt.info()["form"] == "single", opt.info()
-    assert np.all(np.isfinite(opt.traj_costs))
+    outs = []
+    for dbg in ("", "ilqr_split=0"):
+        monkeypatch.setenv("TPLHIP_DEBUG", dbg)
+        opt = make(batch=2048, horizon=int(g["in.horizon"]))
+        cases.apply_inputs(opt, g)
+        opt.x[:, 0, 0] += 0.001 * np.arange(2048)
+        opt.update()
+        outs.append((opt.info()["form"], np.array(opt.x[::128]), np.array(opt.traj_costs)))
+    assert outs[0][0] == "fused" and outs[1][0] == "single", (outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert np.all(np.isfinite(outs[0][2]))

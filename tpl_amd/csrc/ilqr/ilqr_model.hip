@@ -2278,22 +2278,25 @@ int upload_inputs(tplhip_ilqr* h)
     return upload_params(h);
 }
 
-// Which form runs: a two-wavefront form (split sequence or fused launch) pays off when the batch fills the chip more than
-// once (a second wavefront per SIMD has something to hide behind) and needs one integrator and one order for the whole
-// batch (they are template parameters of the chain phase).
-// ... and where the single launch is held to one wavefront per SIMD by a HEAVY derivative refresh: tpl's two tracking MPCs
-// (six and seven states).  Measured on lateral_profile (two states, T = 250: the chain is 250 dependent stages of a
-// register-resident 2 x 2 recursion, the refresh is 94 registers): the split form is 1-3 % SLOWER at every batch size
-// (4.52 against 4.65 M problem-iterations/s at 4 096, profiles/r04_ilqr_split_ab.txt) -- small problems keep the single launch.
-constexpr bool SPLIT_AUTO = NX >= 6;
-
-// 0 = k_ilqr_update (one launch, one wavefront per SIMD), 1 = the split sequence, 2 = k_ilqr_fused (one launch, the
-// phases as calls, two wavefronts per SIMD).  TPLHIP_DEBUG ilqr_split=0|1|2 forces one (tests run all three).
+// Which form runs.  A two-wavefront form (split sequence or fused launch) needs one integrator and one order for the whole
+// batch (they are template parameters of the chain phase) and pays off when the batch holds more problems than the single
+// launch keeps resident AND that launch is held to one wavefront per SIMD by its registers.  Measured for all seven tpl
+// problems at 1 536 ... 8 192 problems (tools/ab_ilqr_forms_all.py, profiles/r04_ilqr_split_ab.txt; fused against single
+// launch): five of them hold four wavefronts per compute unit in the single launch and gain -- the two tracking MPCs
+// +28 ... +38 %, lateral_profile (T = 120) +22 ... +34 %, velocity_profile_space +31 ... +42 %, velocity_profile_time
+// +27 ... +37 % -- and the two reference-line smoothers, whose single launch already holds eight, are within 1-3 % either
+// way.  So every model takes the fused form above 4 x CUs problems.  (Asking the runtime for k_ilqr_update's residency
+// -- hipOccupancyMaxActiveBlocksPerMultiprocessor -- was tried as the criterion and dropped: in a process where another
+// handle had raised the kernel's dynamic-LDS allowance it answers four for the smoothers instead of eight, or refuses with
+// hipErrorUnknown.  The split SEQUENCE is the A/B leg only: light models do not pay for its launches.)
+//
+// 0 = k_ilqr_update (one launch), 1 = the split sequence, 2 = k_ilqr_fused (one launch, the phases as calls, two
+// wavefronts per SIMD).  TPLHIP_DEBUG ilqr_split=0|1|2 forces one (tests run all three).
 int pick_form(const tplhip_ilqr* h)
 {
     if (!h->split_uniform || !h->d_run || !h->d_dev_split || !h->lds_aperture) return 0;
     if (h->split_mode >= 0) return h->split_mode;
-    return (SPLIT_AUTO && (long long)h->batch > 4LL * h->n_cu) ? 2 : 0;
+    return (long long)h->batch > 4LL * h->n_cu ? 2 : 0;
 }
 
 template <bool SO, int INT>
