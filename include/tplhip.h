@@ -220,6 +220,16 @@ TPLHIP_API int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant,
  * 148).  Deterministic (no compiler decides): oracle/dp_lon_oracle.c built -DDPO_R1_FMA=1 is the same arithmetic.
  * Every kernel honours it (template variants of the plain-fp32 sweeps): the choice of kernel does not change. */
 TPLHIP_API int tplhip_dp_lon_set_contraction(tplhip_dp_lon* h, int on);
+/* Rule R3's ORDER and form (round 5).  The texture unit behind tex3D (lon_planner.cu:26-38, arr_tex_surf.cuh:142-149)
+ * blends eight texels; the default contract freezes three sequential 1-D blends along a, then v, then s.  The hardware's
+ * documentation gives the symmetric weighted sum of the eight corners, and a sequential implementation would as plausibly
+ * start with x (= s).  order: 0 = a -> v -> s (default), 1 = s -> v -> a, 2 = sum of w_c T_c over the eight corners with
+ * exact weight products and an fp32 accumulator in the order of the documented formula (corner = s + 2 v + 4 a), 3 = the
+ * same sum accumulated wide and rounded once (lerp_form does not apply to 2 and 3).  oracle/dp_lon_oracle.c built
+ * -DDPO_BLEND_ORDER=order is the same arithmetic; tests/test_dp_reference_golden.py lists the variants a dump is scored
+ * against.  Honoured by every kernel of the planner; the plain-fp32 sweeps exist for order 0 only, so a plan under
+ * another order runs the general sweep (tplhip_dp_lon_info -> "sweep": "k_backward"). */
+TPLHIP_API int tplhip_dp_lon_set_blend_order(tplhip_dp_lon* h, int order);
 /* HIP-event timing of the backward sweeps (events recorded on the planner's
  * stream around the loop of launches).  enable=1 starts accumulating; get
  * returns the summed ms and the number of sweep launches since enable. */

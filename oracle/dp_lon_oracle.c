@@ -78,6 +78,20 @@
  *                                         fmaf(j_max-j_min, k/(N-1), j_min); cost = fmaf(w_snap, d*d, cost)
  *                          (sums whose other addend is the literal 0 -- "cost = 0; cost += w*x" --
  *                          give the product's own rounding either way.)
+ *   -DDPO_BLEND_ORDER=1    rule R3's ORDER flipped: three sequential 1-D blends (the same lerp1) along the station axis
+ *                          first (the texture's x), then velocity (y), then acceleration (z) -- what a sequential
+ *                          implementation that starts with x would do.  The default a -> v -> s was chosen because it lets
+ *                          the sweep kernels blend whole rows with row-uniform weights; nothing in the reference says so.
+ *   -DDPO_BLEND_ORDER=2    the symmetric form the CUDA programming guide documents for 3-D linear filtering: the eight
+ *                          corner weights w_c = (1-alpha|alpha)(1-beta|beta)(1-gamma|gamma) formed as float products
+ *                          ((w_s * w_v) * w_a: EXACT for 8-bit weights -- at most 24 significant bits), then
+ *                          sum_c w_c T_c accumulated in fp32 in the order the guide writes the terms (corner index =
+ *                          s + 2 v + 4 a), every product and every sum rounded, no fma.  DPO_LERP_FORM does not apply.
+ *   -DDPO_BLEND_ORDER=3    the same sum with exact products and a double accumulator, rounded to float once at the end
+ *                          (a filter datapath wider than fp32).
+ *                          Both sums also decide the 2-D distance-map lookup (env.cu:260-263: x = t, y = s, z = 0; the t
+ *                          weight is 0 at the integral t index the planner asks for, so the sequential orders all give the
+ *                          blend along s alone -- lerp1(p, 0-weight q) == p for finite q -- and only the sums differ).
  */
 #ifndef DPO_WEIGHT_QUANT
 #define DPO_WEIGHT_QUANT 1
@@ -87,6 +101,9 @@
 #endif
 #ifndef DPO_R1_FMA
 #define DPO_R1_FMA 0
+#endif
+#ifndef DPO_BLEND_ORDER
+#define DPO_BLEND_ORDER 0
 #endif
 #include "../include/tplhip.h"
 
@@ -207,6 +224,23 @@ static inline float lerp1(float p, float q, float w)
 #endif
 }
 
+#if DPO_BLEND_ORDER >= 2
+/* sum_c w_c T_c over n corners in the order given: fp32 accumulator (every product and sum rounded; volatile keeps
+ * the roundings in every build) or exact products in a double accumulator with one final rounding */
+static inline float wsum(const float* w, const float* t, int n)
+{
+#if DPO_BLEND_ORDER == 2
+    volatile float acc = w[0] * t[0];
+    for (int c = 1; c < n; ++c) { volatile float pr = w[c] * t[c]; acc = acc + pr; }
+    return acc;
+#else
+    double acc = (double)w[0] * (double)t[0];
+    for (int c = 1; c < n; ++c) acc += (double)w[c] * (double)t[c];
+    return (float)acc;
+#endif
+}
+#endif
+
 /* ------------------------------------------------------------ dist map -- */
 
 static inline float env_t_idx(const TplDpEnvParams* ep, float t)
@@ -227,9 +261,18 @@ DPO_API float dpo_interp_dist_map_path(const TplDpEnvParams* ep, const float* di
     /* depth axis (size 1) always resolves to texel 0 with weight 0 */
     const float* r0 = dist_ts + (size_t)tt.i0 * ep->s_steps;
     const float* r1 = dist_ts + (size_t)tt.i1 * ep->s_steps;
+#if DPO_BLEND_ORDER >= 2
+    /* corner index = x + 2 y with x = t, y = s (the z weight is 0: those four terms are +0) */
+    const float wt1 = tt.w, wt0 = 1.0f - tt.w, ws1 = ts.w, ws0 = 1.0f - ts.w;
+    const float w[4] = { wt0 * ws0, wt1 * ws0, wt0 * ws1, wt1 * ws1 };
+    const float t4[4] = { r0[ts.i0], r1[ts.i0], r0[ts.i1], r1[ts.i1] };
+    return wsum(w, t4, 4);
+#else
+    /* x (= t) first, then y (= s); with tt.w == 0 every sequential order gives the same value */
     float a = lerp1(r0[ts.i0], r1[ts.i0], tt.w);      /* t_idx is integral -> tt.w == 0 */
     float b = lerp1(r0[ts.i1], r1[ts.i1], tt.w);
     return lerp1(a, b, ts.w);
+#endif
 }
 
 /* env.cu:131-158.  occ is [l_steps][s_steps][t_steps] (t fastest), point-read
@@ -281,6 +324,44 @@ DPO_API void dpo_read_node(const TplDpLonParams* p, const float* table,
     const float* r10 = table + ((size_t)ta.i1 * V + tv.i0) * S * 4;   /* a1 v0 */
     const float* r01 = table + ((size_t)ta.i0 * V + tv.i1) * S * 4;   /* a0 v1 */
     const float* r11 = table + ((size_t)ta.i1 * V + tv.i1) * S * 4;   /* a1 v1 */
+#if DPO_BLEND_ORDER == 1
+    for (int c = 0; c < 3; ++c) {                                     /* s, then v, then a */
+        const size_t k0 = (size_t)ts.i0 * 4 + c, k1 = (size_t)ts.i1 * 4 + c;
+        float x00 = lerp1(r00[k0], r00[k1], ts.w);                    /* a0 v0 */
+        float x01 = lerp1(r01[k0], r01[k1], ts.w);                    /* a0 v1 */
+        float x10 = lerp1(r10[k0], r10[k1], ts.w);                    /* a1 v0 */
+        float x11 = lerp1(r11[k0], r11[k1], ts.w);                    /* a1 v1 */
+        float y0 = lerp1(x00, x01, tv.w);
+        float y1 = lerp1(x10, x11, tv.w);
+        out[c] = lerp1(y0, y1, ta.w);
+    }
+    out[3] = 0.0f;
+    return;
+#elif DPO_BLEND_ORDER >= 2
+    {
+        /* corner index = s + 2 v + 4 a, weights ((w_s * w_v) * w_a) */
+        const float ws[2] = { 1.0f - ts.w, ts.w }, wv[2] = { 1.0f - tv.w, tv.w }, wa[2] = { 1.0f - ta.w, ta.w };
+        const float* rows[4] = { r00, r01, r10, r11 };                 /* [2 a + v] */
+        const size_t ks[2] = { (size_t)ts.i0 * 4, (size_t)ts.i1 * 4 };
+        float w[8];
+        for (int ia = 0; ia < 2; ++ia)
+            for (int iv = 0; iv < 2; ++iv)
+                for (int is = 0; is < 2; ++is) {
+                    volatile float wsv = ws[is] * wv[iv];
+                    w[is + 2 * iv + 4 * ia] = wsv * wa[ia];
+                }
+        for (int c = 0; c < 3; ++c) {
+            float t8[8];
+            for (int ia = 0; ia < 2; ++ia)
+                for (int iv = 0; iv < 2; ++iv)
+                    for (int is = 0; is < 2; ++is)
+                        t8[is + 2 * iv + 4 * ia] = rows[2 * ia + iv][ks[is] + c];
+            out[c] = wsum(w, t8, 8);
+        }
+        out[3] = 0.0f;
+        return;
+    }
+#endif
     for (int c = 0; c < 3; ++c) {
         float lo, hi;
         {

@@ -42,6 +42,10 @@ VARIANTS = [
     ("fma_wfloor", "FMA contraction AND truncated weights"),
     ("fma_explicit", "R1 flipped deterministically: the multiply-adds nvcc -fmad=true contracts, written out as fma() (-DDPO_R1_FMA=1)"),
     ("fma_explicit_wfloor", "explicit contraction AND truncated weights"),
+    # rule R3's ORDER and the symmetric form (round 5)
+    ("order_sva", "blend ORDER s -> v -> a (x first) instead of a -> v -> s, same 1-D lerp (-DDPO_BLEND_ORDER=1)"),
+    ("sum8_f32", "symmetric eight-corner sum, exact weight products, fp32 accumulator in the order of the documented formula (-DDPO_BLEND_ORDER=2)"),
+    ("sum8_wide", "the same sum with exact products in a double accumulator, one rounding (-DDPO_BLEND_ORDER=3)"),
 ]
 
 CASES = {
@@ -118,7 +122,7 @@ def main():
             print(f"[{cname}] {v}: {res[v]}", file=sys.stderr, flush=True)
         O.use(None)
         out["cases"][cname] = res
-    dst = os.path.join(ROOT, "profiles", "r04_dp_parity_sensitivity.json" if only else "r02_dp_parity_sensitivity.json")
+    dst = os.path.join(ROOT, "profiles", "r05_dp_parity_sensitivity.json" if only else "r02_dp_parity_sensitivity.json")
     if not quick:
         with open(dst, "w") as fd:
             json.dump(out, fd, indent=1)

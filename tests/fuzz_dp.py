@@ -8,7 +8,9 @@ tool; tests/test_dp_gpu.py::test_fuzz_sample runs a short sample of it).
 
 --rules: every case also draws one of the 18 arithmetic rule combinations (R2 weight rule x R3 blend form x R1
 contraction: set_filter_rule / set_contraction) and is compared with the oracle build that makes the same choices
-(oracle/Makefile: _sens/libdp_lon_oracle_r<quant><lerp><fma>.so, built on demand)."""
+(oracle/Makefile: _sens/libdp_lon_oracle_r<quant><lerp><fma>.so, built on demand).
+--orders: with --rules, every case also draws R3's blend order (set_blend_order: 0 a->v->s, 1 s->v->a, 2 / 3 the
+eight-corner sums; _sens/libdp_lon_oracle_r<quant><lerp><fma>o<order>.so) -- 72 combinations."""
 import os
 import sys
 
@@ -59,16 +61,16 @@ def random_case(seed):
     return p, ep, path.astype(np.float32), occ, inits
 
 
-def rule_oracle(quant, lerp, fma):
+def rule_oracle(quant, lerp, fma, order=0):
     import subprocess
     odir = os.path.join(O.ROOT, "oracle")
-    rel = f"_sens/libdp_lon_oracle_r{quant}{lerp}{fma}.so"
+    rel = f"_sens/libdp_lon_oracle_r{quant}{lerp}{fma}" + (f"o{order}" if order else "") + ".so"
     if not os.path.exists(os.path.join(odir, rel)):
         subprocess.check_call(["make", "-s", "-C", odir, rel])
     return os.path.join(odir, rel)
 
 
-def run_case(seed, rules=False):
+def run_case(seed, rules=False, orders=False):
     p, ep, path, occ, inits = random_case(seed)
     env = tpl_amd.DynProgEnvironment()
     env.reinit_buffers(ep)
@@ -78,9 +80,10 @@ def run_case(seed, rules=False):
     rule = None
     if rules:
         rng = np.random.default_rng(77 + seed)
-        rule = (int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 2)))
+        rule = (int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 2)), int(rng.integers(0, 4)) if orders else 0)
         dp.set_contraction(bool(rule[2]))
         dp.set_filter_rule(rule[0], rule[1])
+        dp.set_blend_order(rule[3])
         O.use(rule_oracle(*rule))
     trajs = dp.update_batch(inits, path, env)
     try:
@@ -103,13 +106,14 @@ def run_case(seed, rules=False):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     rules = "--rules" in sys.argv
+    orders = "--orders" in sys.argv
     n = int(args[0]) if len(args) > 0 else 100
     first = int(args[1]) if len(args) > 1 else 0
     kinds = {}
     for seed in range(first, first + n):
-        k = run_case(seed, rules)
+        k = run_case(seed, rules, orders)
         kinds[k] = kinds.get(k, 0) + 1
-    print(f"{n} random configurations{' under random arithmetic rules' if rules else ''} bit-identical; sweep kernels taken: {kinds}")
+    print(f"{n} random configurations{' under random arithmetic rules' if rules else ''}{' and blend orders' if rules and orders else ''} bit-identical; sweep kernels taken: {kinds}")
 
 
 if __name__ == "__main__":

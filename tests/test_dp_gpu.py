@@ -117,6 +117,8 @@ def test_fuzz_sample():
         fuzz_dp.run_case(seed)
     for seed in range(100, 112):               # ... and under randomly drawn arithmetic rules (R2 x R3 x R1)
         fuzz_dp.run_case(seed, rules=True)
+    for seed in range(200, 212):               # ... and under a random blend order on top (R3's order / form)
+        fuzz_dp.run_case(seed, rules=True, orders=True)
 
 
 def test_single_row_axes_are_refused():
@@ -470,6 +472,11 @@ def test_unbounded_inputs_take_the_two_pass_kernel_and_still_match():
         assert np.array_equal(_traj_np(trajs[0]).view(np.uint32), otrajs[0].view(np.uint32))
 
 
+# which sweep a plan under a non-default blend order (tplhip_dp_lon_set_blend_order) may take, by the kernel the default
+# order takes on the same grid
+BLEND_ORDER_KERNELS = {"k_backward3v": ("k_backward",), "k_backward3s": ("k_backward",), "k_backward": ("k_backward",)}
+
+
 @pytest.mark.parametrize("name,quant,lerp", [("wfloor", 2, 0), ("wnone", 0, 0), ("lerp1", 1, 1), ("lerp2", 1, 2),
                                              ("wfloor_lerp1", 2, 1), ("wfloor_lerp2", 2, 2), ("wnone_lerp1", 0, 1),
                                              ("wnone_lerp2", 0, 2)])
@@ -587,6 +594,80 @@ def test_contraction_matches_its_oracle_build(name, quant, lerp, monkeypatch):
         assert any(not np.array_equal(tables0[t].view(np.uint32), tables[t].view(np.uint32)) for t in range(1, T)), "contraction changes nothing here"
     with pytest.raises(ValueError):
         dp.set_contraction(2)
+
+
+@pytest.mark.parametrize("name,order,quant,lerp,fma", [("order_sva", 1, 1, 0, 0), ("sum8_f32", 2, 1, 0, 0), ("sum8_wide", 3, 1, 0, 0),
+                                                        ("fma_explicit_order_sva", 1, 1, 0, 1), ("r210o1", 1, 2, 1, 0),
+                                                        ("r020o1", 1, 0, 2, 0), ("r001o2", 2, 0, 0, 1), ("r200o3", 3, 2, 0, 0)])
+def test_blend_order_variants_match_their_oracle_builds(name, order, quant, lerp, fma, monkeypatch):
+    """R3's ORDER and form as a run-time choice (tplhip_dp_lon_set_blend_order): sequential blends s -> v -> a instead of
+    a -> v -> s, and the symmetric eight-corner sum (fp32 accumulator / wide accumulator) the texture hardware's
+    documentation gives.  Each must reproduce the build of the CPU restatement that makes the same choice
+    (-DDPO_BLEND_ORDER=n, alone and combined with the other rules) bit for bit: distance map, tables, rollouts,
+    re-evaluation, on a small and on a several-rounds-deep grid; setting order 0 again restores the default tables AND
+    the default (plain-fp32) kernel."""
+    import os
+    import subprocess
+    odir = os.path.join(O.ROOT, "oracle")
+    lib = os.path.join(odir, f"_sens/libdp_lon_oracle_{name}.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", odir, f"_sens/libdp_lon_oracle_{name}.so"])
+    for (S, V, A, T), want_default, dt_start in (((201, 37, 20, 6), "k_backward3s", None), ((128, 64, 66, 3), "k_backward3v", 0.4)):
+        p = sc.lon_params(S, V, A, T, dt_start=dt_start)
+        ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31, dt_start=dt_start)
+        path = sc.straight_path(p.path_steps, p.path_step_size)
+        path[:, 2] *= 0.97
+        path[:, 5] += 0.3 * np.sin(np.arange(p.path_steps) / 7.0).astype(np.float32)
+        occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
+        inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(4, seed=3)
+        cp, cep = O.cparams(p), O.cparams(ep)
+        O.use(lib)
+        try:
+            tables, otrajs, dist = O.update(cp, cep, path, occ, inits)
+        finally:
+            O.use(None)
+        for dbg in ("", "no_front", "no_v3,no_s3"):
+            monkeypatch.setenv("TPLHIP_DEBUG", dbg)
+            env = tpl_amd.DynProgEnvironment()
+            env.reinit_buffers(ep)
+            env.set_occ_map(occ)
+            dp = tpl_amd.DynProgLonPlanner()
+            dp.reinit_buffers(p)
+            dp.set_contraction(bool(fma))
+            dp.set_filter_rule(quant, lerp)
+            dp.set_blend_order(order)
+            trajs = dp.update_batch(inits, path, env)
+            info = dp.info()
+            assert info["sweep"] in BLEND_ORDER_KERNELS[want_default if "no_v3" not in dbg else "k_backward"], info
+            assert np.array_equal(env.get_dist_map_path().view(np.uint32), dist.view(np.uint32))
+            _assert_tables_equal(dp, tables, T)
+            for r, tr in enumerate(trajs):
+                assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (name, dbg, r)
+            for r, tr in enumerate(trajs):
+                again = _traj_np(dp.reeval_traj(tr, path, env))
+                assert np.array_equal(again[:, 5:].view(np.uint32), otrajs[r][:, 5:].view(np.uint32)), (name, dbg, "reeval", r)
+        monkeypatch.setenv("TPLHIP_DEBUG", "")
+        # order 0 on a fresh handle under the same other rules: the a -> v -> s tables of that build, on the plain-fp32 sweep
+        dp = tpl_amd.DynProgLonPlanner()
+        dp.reinit_buffers(p)
+        dp.set_contraction(bool(fma))
+        dp.set_filter_rule(quant, lerp)
+        dp.set_blend_order(order)
+        dp.set_blend_order(0)
+        base = os.path.join(odir, f"_sens/libdp_lon_oracle_r{quant}{lerp}{fma}.so")
+        if not os.path.exists(base):
+            subprocess.check_call(["make", "-s", "-C", odir, f"_sens/libdp_lon_oracle_r{quant}{lerp}{fma}.so"])
+        O.use(base)
+        try:
+            tables0, otrajs0, _ = O.update(cp, cep, path, occ, inits)
+        finally:
+            O.use(None)
+        trajs = dp.update_batch(inits, path, env)
+        assert dp.info()["sweep"] == want_default, dp.info()
+        _assert_tables_equal(dp, tables0, T)
+        assert any(not np.array_equal(tables0[t].view(np.uint32), tables[t].view(np.uint32)) for t in range(1, T)), "the order changes nothing here"
+    with pytest.raises(ValueError):
+        dp.set_blend_order(4)
 
 
 @pytest.mark.parametrize("dt_start", [None, 0.3, 0.6])

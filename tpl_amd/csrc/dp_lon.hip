@@ -285,7 +285,7 @@ void pick_div_forms(tplhip_dp_lon* h)
 // tplhip_dp_lon_set_contraction) is a template variant of the same kernels.
 bool use_v3(const tplhip_dp_lon* h)
 {
-    return !h->no_v3 && h->use_buf && h->weights_nonneg
+    return !h->no_v3 && h->use_buf && h->weights_nonneg && h->rule.order == 0
            && backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps) <= 64 * 1024;
 }
 
@@ -1272,8 +1272,8 @@ int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_f
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     int rc = wait_pending_forwards(h);
     if (rc) return rc;
-    h->rule = FilterRule{weight_quant, lerp_form, h->rule.fma};
-    h->rule_set = !(weight_quant == kDefaultRule.quant && lerp_form == kDefaultRule.lerp && h->rule.fma == 0);
+    h->rule = FilterRule{weight_quant, lerp_form, h->rule.fma, h->rule.order};
+    h->rule_set = !(weight_quant == kDefaultRule.quant && lerp_form == kDefaultRule.lerp && h->rule.fma == 0 && h->rule.order == 0);
     if (h->have_params) pick_div_forms(h);
     h->tables_valid = false;
     if (h->have_params && h->d_acts) {
@@ -1295,6 +1295,22 @@ int tplhip_dp_lon_set_contraction(tplhip_dp_lon* h, int on)
     if (on != 0 && on != 1) return tplhip_fail(TPLHIP_EINVAL, "contraction: 0 (one rounding per operation) or 1 (fused multiply-adds)");
     const FilterRule r = h->rule;
     h->rule.fma = on;
+    const int rc = tplhip_dp_lon_set_filter_rule(h, r.quant, r.lerp);
+    if (rc) h->rule = r;
+    return rc;
+}
+
+// R3's ORDER / form as a run-time choice (FilterRule::order in dp_lon_math.h): 0 = a -> v -> s (default), 1 = s -> v -> a,
+// 2 / 3 = the eight-corner sum in fp32 / wide.  Rollout, re-evaluation, stage prelude and the general sweep honour it at
+// run time; the plain-fp32 sweeps are built for order 0 only (they park ONE blended row per action, which no other order
+// allows), so a plan under another order takes the general sweep k_backward -- the price is in DESIGN.md 0.
+int tplhip_dp_lon_set_blend_order(tplhip_dp_lon* h, int order)
+{
+    if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
+    if (order < 0 || order > 3)
+        return tplhip_fail(TPLHIP_EINVAL, "blend order: 0 (a -> v -> s), 1 (s -> v -> a), 2 (eight-corner sum, fp32), 3 (eight-corner sum, wide)");
+    const FilterRule r = h->rule;
+    h->rule.order = order;
     const int rc = tplhip_dp_lon_set_filter_rule(h, r.quant, r.lerp);
     if (rc) h->rule = r;
     return rc;

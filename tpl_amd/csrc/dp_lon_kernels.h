@@ -212,7 +212,7 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
 #pragma unroll
         for (int kk = 0; kk < KCHUNK; ++kk) {
             const int k = k0 + kk;
-            if (active) {
+            if (active && rule.order == 0) {                   // (another blend order takes its eight taps in phase 2)
                 const ActDesc* d = acts + (size_t)row * N_BWD + k;
                 // (clamped successors name the same row twice; those repeats hit L1 -- branching
                 // around them serialises the loads and more than doubles the sweep time)
@@ -278,7 +278,19 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
                 const int i_lo = (int)fminf(fl, s_scale);
                 const int i_hi = min(i_lo + 1, S - 1);
                 const float4* Rk = R + kk * blockDim.x + rib * s_pad;
-                const float4 node = lerp4(Rk[i_lo], Rk[i_hi], ws, rule);
+                float4 node;
+                if (rule.order == 0) {
+                    node = lerp4(Rk[i_lo], Rk[i_hi], ws, rule);
+                } else {
+                    // rule R3 with another order (s -> v -> a) or as the eight-corner sum: no row can be blended ahead of the
+                    // station, so the cell gathers its eight taps itself (neighbouring lanes read neighbouring cells: the
+                    // requests coalesce, the repeats hit L1).  The price of following such a dump: DESIGN.md 0.
+                    const Node* r00 = next + (size_t)d->r00 * S; const Node* r01 = next + (size_t)d->r01 * S;
+                    const Node* r10 = next + (size_t)d->r10 * S; const Node* r11 = next + (size_t)d->r11 * S;
+                    const float4 n8[8] = {ld_node(r00 + i_lo), ld_node(r00 + i_hi), ld_node(r01 + i_lo), ld_node(r01 + i_hi),
+                                          ld_node(r10 + i_lo), ld_node(r10 + i_hi), ld_node(r11 + i_lo), ld_node(r11 + i_hi)};
+                    node = blend8_nodes(n8, ws, d->wv, d->wa, rule);
+                }
                 // interpPath(tn.s).v_max, lon_planner.cu:114
                 const float alpha = tn_s / p.path_step_size;
                 const PathTap pt = path_tap_q(alpha, p.path_steps);
@@ -893,9 +905,7 @@ __global__ void __launch_bounds__(256) k_plan_front(float* __restrict__ dist_ts,
         const float cps_s = path_lerp(pt, path[pt.i0 * 7 + 2], path[pt.i1 * 7 + 2], rule);
         const float scq = (cps_s - ep.s_min) / (ep.s_max - ep.s_min) * (float)(ep.s_steps - 1);
         const Tap ts = make_tap(scq + 0.5f, ep.s_steps, rule);
-        const float d0 = lerp1(L0[ts.i0], R1[ts.i0], tt.w, rule);
-        const float d1 = lerp1(L0[ts.i1], R1[ts.i1], tt.w, rule);
-        const float s_dist = s_dist_of(lerp1(d0, d1, ts.w, rule), p, rule);
+        const float s_dist = s_dist_of(dist_blend(L0[ts.i0], R1[ts.i0], L0[ts.i1], R1[ts.i1], tt.w, ts.w, rule), p, rule);
         const double away = fabs(1000.0 - (double)s);
         const double prog = rule.fma ? away : (double)p.w_progress * away;       // (contracted: the multiplicand, see k_stage_prelude)
         if (!terminal) {

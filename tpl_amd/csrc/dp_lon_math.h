@@ -31,8 +31,15 @@ __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x,
 //          wherever product and sum have the same type (madf / madd below; the sites are listed in the header of
 //          oracle/dp_lon_oracle.c, -DDPO_R1_FMA=1).  Set by tplhip_dp_lon_set_contraction; a run-time branch in the general
 //          kernels, a template bit of the plain-fp32 sweeps (kFma in dp_sweep.hip).
-struct FilterRule { int quant, lerp, fma; };
-constexpr FilterRule kDefaultRule{1, 0, 0};
+//   order: rule R3's ORDER / form (round 5; tplhip_dp_lon_set_blend_order).  0 = three sequential blends a -> v -> s (default:
+//          the order that lets the sweeps blend whole rows with row-uniform weights), 1 = s -> v -> a (the texture's x first),
+//          2 = the symmetric eight-corner sum  sum_c w_c T_c  with w_c = (w_s * w_v) * w_a (exact for 8-bit weights), products and
+//          sums rounded in fp32 in the order of the documented formula (corner = s + 2 v + 4 a), 3 = the same sum with exact
+//          products in a double accumulator and one rounding.  `lerp` does not apply to 2 and 3.  The distance map's 2-D
+//          lookup (x = t with weight 0, y = s) is the same for every sequential order and becomes a four-corner sum under 2 / 3.
+//          oracle/dp_lon_oracle.c -DDPO_BLEND_ORDER=n is the same arithmetic.
+struct FilterRule { int quant, lerp, fma, order; };
+constexpr FilterRule kDefaultRule{1, 0, 0, 0};
 
 // a*b + c under rule R1 (this file is built -ffp-contract=off: the unfused form keeps its two roundings)
 __device__ __forceinline__ float madf(float a, float b, float c, FilterRule r) { return r.fma ? fmaf(a, b, c) : a * b + c; }
@@ -73,6 +80,77 @@ __device__ __forceinline__ float lerp1(float p, float q, float w, FilterRule rul
 __device__ __forceinline__ float4 lerp4(float4 p, float4 q, float w, FilterRule rule = kDefaultRule)
 {
     return make_float4(lerp1(p.x, q.x, w, rule), lerp1(p.y, q.y, w, rule), lerp1(p.z, q.z, w, rule), 0.0f);
+}
+
+// sum_c w[c] t[c] over N corners in index order (rule.order 2: fp32, every product and sum rounded -- the file is built
+// -ffp-contract=off; 3: exact products, double accumulator, one rounding)
+template <int N>
+__device__ __forceinline__ float wsum(const float (&w)[N], const float (&t)[N], FilterRule rule)
+{
+    if (rule.order == 2) {
+        float acc = w[0] * t[0];
+#pragma unroll
+        for (int c = 1; c < N; ++c) { const float pr = w[c] * t[c]; acc = acc + pr; }
+        return acc;
+    }
+    double acc = (double)w[0] * (double)t[0];
+#pragma unroll
+    for (int c = 1; c < N; ++c) acc += (double)w[c] * (double)t[c];
+    return (float)acc;
+}
+
+// corner weights of the eight-corner sum, index s + 2 v + 4 a
+__device__ __forceinline__ void corner_weights(float ws, float wv, float wa, float (&w)[8])
+{
+    const float s2[2] = {1.0f - ws, ws}, v2[2] = {1.0f - wv, wv}, a2[2] = {1.0f - wa, wa};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { const float sv = s2[c & 1] * v2[(c >> 1) & 1]; w[c] = sv * a2[c >> 2]; }
+}
+
+// R3 over the eight corners of one channel, t[s + 2 v + 4 a]
+__device__ __forceinline__ float blend8(const float (&t)[8], float ws, float wv, float wa, FilterRule rule)
+{
+    if (rule.order == 1) {                                      // s, then v, then a
+        const float x00 = lerp1(t[0], t[1], ws, rule), x01 = lerp1(t[2], t[3], ws, rule);      // a0: v0, v1
+        const float x10 = lerp1(t[4], t[5], ws, rule), x11 = lerp1(t[6], t[7], ws, rule);      // a1: v0, v1
+        return lerp1(lerp1(x00, x01, wv, rule), lerp1(x10, x11, wv, rule), wa, rule);
+    }
+    if (rule.order >= 2) {
+        float w[8];
+        corner_weights(ws, wv, wa, w);
+        return wsum<8>(w, t, rule);
+    }
+    const float lo = lerp1(lerp1(t[0], t[4], wa, rule), lerp1(t[2], t[6], wa, rule), wv, rule);  // a, then v, then s
+    const float hi = lerp1(lerp1(t[1], t[5], wa, rule), lerp1(t[3], t[7], wa, rule), wv, rule);
+    return lerp1(lo, hi, ws, rule);
+}
+
+// the same for the three stored channels of eight nodes n[s + 2 v + 4 a]
+__device__ __forceinline__ float4 blend8_nodes(const float4 (&n)[8], float ws, float wv, float wa, FilterRule rule)
+{
+    float c[8], g[8], j[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { c[i] = n[i].x; g[i] = n[i].y; j[i] = n[i].z; }
+    if (rule.order >= 2) {
+        float w[8];
+        corner_weights(ws, wv, wa, w);
+        return make_float4(wsum<8>(w, c, rule), wsum<8>(w, g, rule), wsum<8>(w, j, rule), 0.0f);
+    }
+    return make_float4(blend8(c, ws, wv, wa, rule), blend8(g, ws, wv, wa, rule), blend8(j, ws, wv, wa, rule), 0.0f);
+}
+
+// The 2-D distance-map blend (env.cu:260-263: x = t, y = s): corners (t0,s0) (t1,s0) (t0,s1) (t1,s1).  Sequential orders
+// blend along t (x) first -- with the integral t index the planner asks for, wt == 0 and every order gives the blend along
+// s alone; the sums (order 2 / 3) take the four corners in the documented order x + 2 y.
+__device__ __forceinline__ float dist_blend(float p00, float p10, float p01, float p11, float wt, float ws, FilterRule rule)
+{
+    if (rule.order >= 2) {
+        const float wt0 = 1.0f - wt, ws0 = 1.0f - ws;
+        const float w[4] = {wt0 * ws0, wt * ws0, wt0 * ws, wt * ws};
+        const float t[4] = {p00, p10, p01, p11};
+        return wsum<4>(w, t, rule);
+    }
+    return lerp1(lerp1(p00, p10, wt, rule), lerp1(p01, p11, wt, rule), ws, rule);
 }
 
 // One cell of a value table in HBM: 12 bytes.  The reference keeps float4 texels whose fourth
@@ -195,9 +273,7 @@ __device__ __forceinline__ float interp_dist_map_path(const TplDpEnvParams& ep, 
     Tap ts = make_tap(sc + 0.5f, ep.s_steps, rule);
     PtrT r0 = dist_ts + (size_t)tt.i0 * ep.s_steps;
     PtrT r1 = dist_ts + (size_t)tt.i1 * ep.s_steps;
-    float a = lerp1(r0[ts.i0], r1[ts.i0], tt.w, rule);
-    float b = lerp1(r0[ts.i1], r1[ts.i1], tt.w, rule);
-    return lerp1(a, b, ts.w, rule);
+    return dist_blend(r0[ts.i0], r1[ts.i0], r0[ts.i1], r1[ts.i1], tt.w, ts.w, rule);
 }
 
 // coordinate of readNode, lon_planner.cu:34-37: float expression + double 0.5 -> float.
@@ -221,6 +297,11 @@ __device__ __forceinline__ float4 read_node(const TplDpLonParams& p, const Node*
     const Node* r10 = table + ((size_t)ta.i1 * V + tv.i0) * S;
     const Node* r01 = table + ((size_t)ta.i0 * V + tv.i1) * S;
     const Node* r11 = table + ((size_t)ta.i1 * V + tv.i1) * S;
+    if (rule.order != 0) {                                      // another blend order / the eight-corner sums
+        const float4 n[8] = {ld_node(r00 + ts.i0), ld_node(r00 + ts.i1), ld_node(r01 + ts.i0), ld_node(r01 + ts.i1),
+                             ld_node(r10 + ts.i0), ld_node(r10 + ts.i1), ld_node(r11 + ts.i0), ld_node(r11 + ts.i1)};
+        return blend8_nodes(n, ts.w, tv.w, ta.w, rule);
+    }
     float4 lo = lerp4(lerp4(ld_node(r00 + ts.i0), ld_node(r10 + ts.i0), ta.w, rule),
                       lerp4(ld_node(r01 + ts.i0), ld_node(r11 + ts.i0), ta.w, rule), tv.w, rule);
     float4 hi = lerp4(lerp4(ld_node(r00 + ts.i1), ld_node(r10 + ts.i1), ta.w, rule),

@@ -580,6 +580,11 @@ class DynProgLonPlanner:
         fma() calls; off is the default.  See ``tplhip_dp_lon_set_contraction`` in include/tplhip.h."""
         check(self._lib.tplhip_dp_lon_set_contraction(self._h, int(on)))
 
+    def set_blend_order(self, order=0):
+        """R3's order / form: 0 = sequential blends a -> v -> s (default), 1 = s -> v -> a, 2 / 3 = the symmetric
+        eight-corner sum with an fp32 / a wide accumulator.  See ``tplhip_dp_lon_set_blend_order`` in include/tplhip.h."""
+        check(self._lib.tplhip_dp_lon_set_blend_order(self._h, int(order)))
+
     def timing_enable(self, enable=True):
         check(self._lib.tplhip_dp_lon_timing_enable(self._h, 1 if enable else 0))
 
