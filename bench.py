@@ -332,7 +332,8 @@ def dp_general_sweep_price(device, grid="target", plans=3):
     * the plain-fp32 sweep with both divisions as IEEE divisions (no_fastdiv) -- what a divisor without a proven
       reciprocal form pays now that it no longer changes kernels; with a path step that is not a power of two; under
       contracted arithmetic (set_contraction) and with truncated filter weights (set_filter_rule(2, 0)) -- what a
-      non-default arithmetic rule costs on the same kernel;
+      non-default arithmetic rule costs on the same kernel; under another blend order / the eight-corner sums
+      (set_blend_order(1 | 2 | 3)) -- what following such a dump of the reference build costs;
     * the kernel and the division forms the planner selects for path_step_size x s_max combinations (forms: 4 one
       multiplication, 3 two-float reciprocal, 5 reciprocal + Newton step, 0 IEEE division; dp_sweep.hip)."""
     import tpl_amd
@@ -348,7 +349,7 @@ def dp_general_sweep_price(device, grid="target", plans=3):
     saved = os.environ.get("TPLHIP_DEBUG")
     try:
         for key, dbg in (("selected", ""), ("path_step_0.7", ""), ("contracted", ""), ("truncated_weights", ""), ("ieee_divisions", "no_fastdiv"),
-                         ("general", "no_v3,no_s3")):
+                         ("general", "no_v3,no_s3"), ("order_sva", ""), ("sum8_f32", ""), ("sum8_wide", "")):
             os.environ["TPLHIP_DEBUG"] = dbg
             p = sc.lon_params(S, V, A, T)
             if key == "path_step_0.7":                     # not a power of two: two-float reciprocal behind the tiny-dividend test
@@ -359,6 +360,8 @@ def dp_general_sweep_price(device, grid="target", plans=3):
                 dp.set_contraction(True)
             if key == "truncated_weights":                 # rule R2 = floor
                 dp.set_filter_rule(2, 0)
+            if key in ("order_sva", "sum8_f32", "sum8_wide"):   # rule R3's order / form (set_blend_order): eight taps per cell-action
+                dp.set_blend_order({"order_sva": 1, "sum8_f32": 2, "sum8_wide": 3}[key])
             dp.upload([sc.initial_state(0.0, 8.0, 0.0)], sc.straight_path(p.path_steps, p.path_step_size))
             dp.plan_resident(env)
             dp.sync()

@@ -224,12 +224,12 @@ int check_env(tplhip_dp_lon* h, tplhip_dp_env* env)
     return TPLHIP_OK;
 }
 
-template <bool TERMINAL, int KCHUNK, bool USE_BUF>
+template <bool TERMINAL, int KCHUNK, bool USE_BUF, bool ORDERED = false>
 void launch_backward_b(tplhip_dp_lon* h, int idx_t, int nx)
 {
     const size_t S = (size_t)h->params.s_steps;
     const size_t lds = TERMINAL ? 0 : h->lds_bytes;
-    hipLaunchKernelGGL((k_backward<TERMINAL, KCHUNK, USE_BUF>), dim3(h->grid), dim3(h->s_pad * h->rows_per_block),
+    hipLaunchKernelGGL((k_backward<TERMINAL, KCHUNK, USE_BUF, ORDERED>), dim3(h->grid), dim3(h->s_pad * h->rows_per_block),
                        lds, h->stream,
                        h->d_tables + (size_t)nx * h->table_cells,
                        h->d_tables + (size_t)idx_t * h->table_cells,
@@ -243,7 +243,9 @@ template <bool TERMINAL, int KCHUNK>
 void launch_backward(tplhip_dp_lon* h, int idx_t, int nx)
 {
     // buffer loads need 32-bit byte offsets inside one stage table
-    if (!TERMINAL && h->use_buf)
+    if (!TERMINAL && h->rule.order != 0)
+        launch_backward_b<TERMINAL, KCHUNK, false, !TERMINAL>(h, idx_t, nx);      // eight taps per cell-action, plain loads
+    else if (!TERMINAL && h->use_buf)
         launch_backward_b<TERMINAL, KCHUNK, true>(h, idx_t, nx);
     else
         launch_backward_b<TERMINAL, KCHUNK, false>(h, idx_t, nx);
@@ -285,7 +287,10 @@ void pick_div_forms(tplhip_dp_lon* h)
 // tplhip_dp_lon_set_contraction) is a template variant of the same kernels.
 bool use_v3(const tplhip_dp_lon* h)
 {
-    return !h->no_v3 && h->use_buf && h->weights_nonneg && h->rule.order == 0
+    if (h->rule.order != 0)
+        return !h->no_v3 && h->use_buf && h->weights_nonneg && backward3o_built(h->rule)
+               && backward3o_lds_bytes(h->vp_s_pad, h->params.path_steps) <= 64 * 1024;
+    return !h->no_v3 && h->use_buf && h->weights_nonneg
            && backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps) <= 64 * 1024;
 }
 
@@ -336,6 +341,7 @@ int sweep_kind(const tplhip_dp_lon* h)
 {
     const bool running_argmin_ok = h->params_bounded && h->path_bounded && h->env_bounded && use_v3(h);
     if (!running_argmin_ok) return 0;
+    if (h->rule.order != 0) return h->v3_ok ? 1 : 0;          // k_backward3o on every grid (no one-cell-per-lane form of it)
     if (h->big) return h->v3_ok ? 1 : 0;
     if (h->s3_kc) return 2;
     return (h->v3_ok && !h->no_s3) ? 1 : 0;
@@ -1248,7 +1254,7 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
 {
     if (!h || !buf || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
     const int kind = sweep_kind(h);
-    const char* sweep = kind == 1 ? "k_backward3v" : (kind == 2 ? "k_backward3s" : "k_backward");
+    const char* sweep = kind == 1 ? (h->rule.order != 0 ? "k_backward3o" : "k_backward3v") : (kind == 2 ? "k_backward3s" : "k_backward");
     std::snprintf(buf, (size_t)n,
                   "{\"sweep\": \"%s\", \"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
                   "\"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"big\": %d, "
@@ -1257,7 +1263,7 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
                   sweep, h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
                   (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->big ? 1 : 0,
                   (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
-                  h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded && h->params_bounded) ? "k_backward3v" : "k_backward", h->overlap ? 1 : 0,
+                  h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded && h->params_bounded) ? (h->rule.order != 0 ? "k_backward3o" : "k_backward3v") : "k_backward", h->overlap ? 1 : 0,
                   h->front_fused && !h->no_front ? "k_plan_front" : "three launches", (double)h->skew_q16 / 65536.0, h->tile_v3);
     return TPLHIP_OK;
 }
@@ -1501,7 +1507,8 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
                                    next, out, h->d_acts, paths, pv, ps, h->d_pre_prog, p, h->s_pad, h->rows_per_block, h->nblocks,
                                    h->tile_v, h->tile_a, tab_stride, pre_stride, path_stride, h->rule);
             };
-            if (h->use_buf) go(k_backward<false, 1, true>); else go(k_backward<false, 1, false>);
+            if (h->rule.order != 0) go(k_backward<false, 1, false, true>);
+            else if (h->use_buf) go(k_backward<false, 1, true>); else go(k_backward<false, 1, false>);
         }
     }
     if (h->timing) {

@@ -64,6 +64,10 @@ struct SweepArgs {
 // is built with the pairs (5, 5) and (0, 0) only.  Returns false when the combination is not built.
 bool launch_backward3v(FilterRule rule, int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
 size_t backward3v_lds_bytes(int s_pad, int path_steps);
+// k_backward3o: the same sweep for rule.order != 0 (six raw rows parked, eight LDS taps per cell-action); launch_backward3v
+// dispatches to it and sizes its LDS block itself.  Built for the weight rules rint and floor.
+size_t backward3o_lds_bytes(int s_pad, int path_steps);
+bool backward3o_built(FilterRule rule);
 // k_backward3s: the same instruction stream, one cell per lane and kc (= 3) actions per barrier round, for grids
 // that leave the chip mostly empty (s_pad <= 256; grid = 8 * rows of the widest XCD share, as k_backward's)
 size_t backward3s_lds_bytes(int kc, int s_pad, int path_steps);

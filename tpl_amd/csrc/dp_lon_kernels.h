@@ -110,7 +110,9 @@ __global__ void k_stage_prelude(float* __restrict__ pre_vmax, float* __restrict_
 // ------------------------------------------------------------------------
 // This is the GENERAL sweep (any input: two-pass argmin, IEEE divisions); the plain-fp32 sweeps of dp_sweep.hip take
 // over wherever their preconditions hold.
-template <bool TERMINAL, int KCHUNK, bool USE_BUF>
+// ORDERED: rule.order != 0 (another blend order / the eight-corner sums) -- a template bit so that the default instance keeps
+// its registers (a run-time test of rule.order in phase 2 cost it 20 us per 256x128x64 sweep).
+template <bool TERMINAL, int KCHUNK, bool USE_BUF, bool ORDERED = false>
 __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out,
                            const ActDesc* __restrict__ acts,
                            const float* __restrict__ path,
@@ -212,7 +214,7 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
 #pragma unroll
         for (int kk = 0; kk < KCHUNK; ++kk) {
             const int k = k0 + kk;
-            if (active && rule.order == 0) {                   // (another blend order takes its eight taps in phase 2)
+            if (active && !ORDERED) {                          // (another blend order takes its eight taps in phase 2)
                 const ActDesc* d = acts + (size_t)row * N_BWD + k;
                 // (clamped successors name the same row twice; those repeats hit L1 -- branching
                 // around them serialises the loads and more than doubles the sweep time)
@@ -279,7 +281,7 @@ __global__ void k_backward(const Node* __restrict__ next, Node* __restrict__ out
                 const int i_hi = min(i_lo + 1, S - 1);
                 const float4* Rk = R + kk * blockDim.x + rib * s_pad;
                 float4 node;
-                if (rule.order == 0) {
+                if (!ORDERED) {
                     node = lerp4(Rk[i_lo], Rk[i_hi], ws, rule);
                 } else {
                     // rule R3 with another order (s -> v -> a) or as the eight-corner sum: no row can be blended ahead of the

@@ -442,6 +442,292 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 }
 
 // ------------------------------------------------------------------------
+// k_backward3o: k_backward3v for rule R3 under ANOTHER ORDER (tplhip_dp_lon_set_blend_order; FilterRule::order):
+//   ORDER 1  three sequential blends s -> v -> a (the texture's x first),
+//   ORDER 2  the symmetric sum of w_c T_c over the eight corners, fp32 accumulator in the documented term order,
+//   ORDER 3  the same sum with exact products in a double accumulator, one rounding.
+// None of them lets a row be blended ahead of the station -- the station weight is the per-cell one and comes first (order 1)
+// or multiplies every corner (the sums) -- so phase 1 parks the six RAW rows of the pair and every cell-action takes its
+// eight taps from LDS.  Same geometry, traversal, prologue, division forms, cost arithmetic and integer-key argmin as
+// k_backward3v; what changes is the look-up:
+//   * LDS row block: one slot of 19 floats per station = 6 rows x (cost, constr, jerk) + one float of padding (an odd
+//     stride in dwords: conflict-free for the shifted reads) -- rows B0 (a0,v0) B1 (a1,v0) B2 (a0,v1) B3 (a1,v1) B4 (a0,v2)
+//     B5 (a1,v2); cell 0 blends B0..B3, cell 1 B2..B5 (the pair shares its middle v' row, see k_backward3v).  Both taps of a
+//     channel of a row are ONE ds_read2_b32 (offsets c and 19 + c): 12 LDS reads per cell-action against two.
+//   * Where the descriptors of the two rows do NOT share (rounding of the successor velocity near a grid row, the clamped
+//     edges), cell 1's own lower rows are parked over B2, B3 between the two cells (a workgroup is one row pair, so the
+//     case is uniform: two more barriers for that action).
+//   * ACT_SINGLE_A is not used: both a-rows are always requested (the same row twice where clamped).
+// Built for the weight rules rint and floor (an un-quantised weight makes the corner products inexact and takes the general
+// sweep), both contraction settings, and for order 1 all three blend forms.  Price: DESIGN.md 0.
+// ------------------------------------------------------------------------
+constexpr int SLOT_DW = 19;
+
+template <int ORDER, int LERP>
+__device__ __forceinline__ float fetch8(const float (&lo)[4], const float (&hi)[4], float ws, float iws, const v4f& w)
+{
+    // lo / hi: the taps at stations i, i + 1 of rows B0 (a0,v0) B1 (a1,v0) B2 (a0,v1) B3 (a1,v1); w = (wa, 1 - wa, wv, 1 - wv)
+    if (ORDER == 1) {
+        const float x00 = blend1<LERP>(lo[0], hi[0], ws, iws), x10 = blend1<LERP>(lo[1], hi[1], ws, iws);
+        const float x01 = blend1<LERP>(lo[2], hi[2], ws, iws), x11 = blend1<LERP>(lo[3], hi[3], ws, iws);
+        const float y0 = blend1<LERP>(x00, x01, w.z, w.w), y1 = blend1<LERP>(x10, x11, w.z, w.w);
+        return blend1<LERP>(y0, y1, w.x, w.y);
+    }
+    // corner c = s + 2 v + 4 a, weight (w_s * w_v) * w_a
+    const float sv00 = iws * w.w, sv10 = ws * w.w, sv01 = iws * w.z, sv11 = ws * w.z;
+    const float wc[8] = {sv00 * w.y, sv10 * w.y, sv01 * w.y, sv11 * w.y, sv00 * w.x, sv10 * w.x, sv01 * w.x, sv11 * w.x};
+    const float tc[8] = {lo[0], hi[0], lo[2], hi[2], lo[1], hi[1], lo[3], hi[3]};
+    if (ORDER == 2) {
+        float acc = wc[0] * tc[0];
+#pragma unroll
+        for (int c = 1; c < 8; ++c) { const float pr = wc[c] * tc[c]; acc = acc + pr; }
+        return acc;
+    }
+    double acc = (double)wc[0] * (double)tc[0];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) acc = fma((double)wc[c], (double)tc[c], acc);      // (the product of two floats is exact in double: fma == multiply, then add)
+    return (float)acc;
+}
+
+template <int PATH_DIV, int RANGE_DIV, int QUANT, int LERP, int ORDER>
+__global__ void __launch_bounds__(1024)
+k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, const ActDesc* __restrict__ acts,
+              const float* __restrict__ path_all, const float* __restrict__ pre_vmax_all,
+              const float* __restrict__ pre_sdist_all, const double* __restrict__ pre_prog, SweepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const TplDpLonParams& p = a.p;
+    const int S = p.s_steps, V = p.v_steps, A = p.a_steps;
+    const int nrows = V * A;
+    const int is = threadIdx.x;
+    const int s_pad = a.s_pad;
+    const size_t scn = blockIdx.y;
+    const Node* __restrict__ next = next_all + scn * a.stride_tables;
+    Node* __restrict__ out = out_all + scn * a.stride_tables;
+    const float* __restrict__ pre_vmax = pre_vmax_all + scn * a.stride_pre;
+    const float* __restrict__ pre_sdist = pre_sdist_all + scn * a.stride_pre;
+    const float* __restrict__ path = path_all + scn * a.stride_path;
+
+    constexpr int NV = 2;
+    // traversal: k_backward3v's (row pairs dealt to the XCDs, a-major tiles, optional skew)
+    const int xcd = blockIdx.x & 7;
+    const int NP = (V + NV - 1) / NV;
+    const int p_lo = (xcd * NP) >> 3, p_hi = ((xcd + 1) * NP) >> 3;
+    const int vx = p_hi - p_lo, tv = max(1, a.tile_v / NV);
+    const int q = (int)(blockIdx.x >> 3);
+    if (q >= vx * A) return;
+    int ia, iv;
+    {
+        const int full = vx / tv;
+        int strip = q / (A * tv), w = tv, rem = q - strip * (A * tv);
+        if (strip >= full) { strip = full; w = vx - full * tv; rem = q - full * (A * tv); }
+        const int tile = rem / (a.tile_a * w);
+        const int r = rem - tile * (a.tile_a * w);
+        ia = tile * a.tile_a + r / w;
+        int lp = strip * tv + (r - (r / w) * w);
+        if (a.skew_q16) { lp -= (int)(((long long)ia * a.skew_q16) >> 16) % vx; if (lp < 0) lp += vx; }
+        iv = NV * (p_lo + lp);
+    }
+    const int row0 = ia * V + iv;
+    const int rs = (iv + 1 < V) ? N_BWD : 0;            // descriptor stride to the lane's second row (0: the row twice)
+    const bool active = is < S;
+    const int js = min(is, S - 1);
+
+    // LDS: float R[s_pad + 1][SLOT_DW] (rounded up to 16 bytes) | float dsc[NV rows][9][8] | float pv[path_steps + 1]
+    const int row_slots = s_pad + 1;
+    float* R = reinterpret_cast<float*>(smem);
+    float* dsc = reinterpret_cast<float*>(smem + (((size_t)row_slots * SLOT_DW * sizeof(float) + 15) & ~(size_t)15));
+    float* pv = dsc + NV * N_BWD * 8;
+    const ActDesc* __restrict__ d0 = acts + (size_t)row0 * N_BWD;
+    const __amdgpu_buffer_rsrc_t next_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<Node*>(next), 0, (int)((size_t)nrows * S * sizeof(Node)), 0x00020000);
+    const unsigned voff = (unsigned)js * 12u, row_bytes = (unsigned)S * 12u;
+    auto load_row = [&](int r) -> Node3 {
+        const v3f x = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(next_rsrc, (int)voff, (int)((unsigned)r * row_bytes), 0));
+        return Node3{x.x, x.y, x.z};
+    };
+    Node3 lo[2], up[NV][2];
+    struct ActScalars { int r00, r10, r01[NV], r11[NV]; double j_term[NV], tn_v_d[NV]; };
+    auto fetch_scalars = [&](int k) {
+        ActScalars x;
+        x.r00 = d0[k].r00; x.r10 = d0[k].r10;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const ActDesc& e = d0[i * rs + k];
+            x.r01[i] = e.r01; x.r11[i] = e.r11; x.j_term[i] = e.j_term; x.tn_v_d[i] = e.tn_v_d;
+        }
+        return x;
+    };
+    constexpr unsigned A0_ROWS = 0x15u, A1_ROWS = 0x2au;
+    static_assert(NV == 2, "row masks are written for two rows per lane");
+    auto issue = [&](const ActScalars& x, unsigned m) {
+        if (m & 1u) lo[0] = load_row(x.r00);
+        if (m & 2u) lo[1] = load_row(x.r10);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if ((m >> (2 + 2 * i)) & 1u) up[i][0] = load_row(x.r01[i]);
+            if ((m >> (3 + 2 * i)) & 1u) up[i][1] = load_row(x.r11[i]);
+        }
+    };
+    ActScalars cur = fetch_scalars(0);
+    issue(cur, A0_ROWS);
+    const int bd = (int)blockDim.x;
+    auto dsc_word = [&](int i) { return reinterpret_cast<const float*>(d0 + (i / (N_BWD * 8)) * rs + ((i >> 3) % N_BWD))[i & 7]; };
+    float dsc_v = 0.0f, pv_v = 0.0f;
+    if (is < NV * N_BWD * 8) dsc_v = dsc_word(is);
+    if (is <= p.path_steps) pv_v = path[min(is, p.path_steps - 1) * 7 + 5];
+    const float s = mad1<LERP>((float)js, p._s_step_size, p.s_min);
+    const float acc = mad1<LERP>((float)ia, p._a_step_size, p.a_min);
+    const float v_max = pre_vmax[js];
+    const float s_dist = pre_sdist[js];
+    const double prog = pre_prog[js];
+    if (is < NV * N_BWD * 8) dsc[is] = dsc_v;
+    if (is <= p.path_steps) pv[is] = pv_v;
+    for (int i = is + bd; i < NV * N_BWD * 8; i += bd) dsc[i] = dsc_word(i);
+    for (int i = is + bd; i <= p.path_steps; i += bd) pv[i] = path[min(i, p.path_steps - 1) * 7 + 5];
+    float sc[NV], sg[NV];
+    double sd_base[NV];
+    {
+        float c0 = 0.0f;
+        c0 += p.w_a * (acc * acc);
+        const float x = kFma<LERP> ? (float)fma((double)p.w_progress, prog, (double)c0) : (float)((double)c0 + prog);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float v = mad1<LERP>((float)(iv + (rs ? i : 0)), p._v_step_size, p.v_min);
+            const float gap = mad1<LERP>(v, p.time_gap, p.gap_min) - s_dist;
+            sc[i] = (float)mad1<LERP>((double)p.w_safety_dist, fmax(0.0, (double)gap), (double)x);
+            sg[i] = 0.0f; if (v > v_max) sg[i] += v - v_max;
+            sd_base[i] = kFma<LERP> ? fma(d0[i * rs].a_term, (double)p.dt, (double)fmaf(d0[i * rs].vdt, p.dt, s))
+                                    : (double)(s + d0[i * rs].vdt) + d0[i * rs].a_term;
+        }
+    }
+    unsigned shared_mask = 0;
+#pragma unroll
+    for (int k = 0; k < N_BWD; ++k) {
+        const ActDesc& x = d0[k];
+        const ActDesc& y = d0[rs + k];
+        const bool sh = x.r01 == y.r00 && x.r11 == y.r10 && __float_as_uint(x.wa) == __float_as_uint(y.wa);
+        shared_mask |= (sh ? 1u : 0u) << k;
+    }
+    const float s_min_v = in_vgpr(p.s_min);
+    const float s_scale = (float)(S - 1);
+    const float s_scale_v = in_vgpr(s_scale);
+    const float rr_hi = in_vgpr(a.rcp_range_hi), rr_lo = in_vgpr(a.rcp_range_lo);
+    const float rp_hi = in_vgpr(a.rcp_path_hi), rp_lo = in_vgpr(a.rcp_path_lo);
+    const float w_snap_v = in_vgpr(p.w_snap);
+    const float path_top = (float)(p.path_steps - 1);
+    const double dt_d = (double)p.dt;
+    const bool dup_last = is == S - 1;
+    unsigned long long best[NV];
+    int bk[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { best[i] = 0x7f8000007f800000ull; bk[i] = 0; }
+    __syncthreads();                     // descriptors and path limits are in LDS
+    const v4f* dsc4 = reinterpret_cast<const v4f*>(dsc);
+    float* slot = R + is * SLOT_DW;
+    // one row into its place of a slot
+    const auto park_row = [&](float* sl, int b, const Node3& r) { sl[b * 3 + 0] = r.c; sl[b * 3 + 1] = r.g; sl[b * 3 + 2] = r.j; };
+#pragma unroll
+    for (int k = 0; k < N_BWD; ++k) {
+        // ---- phase 1: the raw rows of the pair into LDS
+        const bool shared = (shared_mask >> k) & 1u;
+        Node3 q00 = {0.0f, 0.0f, 0.0f}, q10 = {0.0f, 0.0f, 0.0f};
+        __builtin_amdgcn_s_setprio(1);
+        issue(cur, A1_ROWS);
+        if (!shared) { q00 = load_row(d0[rs + k].r00); q10 = load_row(d0[rs + k].r10); }
+        if (k > 0) asm volatile("s_barrier" ::: "memory");      // everyone is done reading the row block of action k-1
+        park_row(slot, 0, lo[0]); park_row(slot, 1, lo[1]);
+        park_row(slot, 2, up[0][0]); park_row(slot, 3, up[0][1]);
+        park_row(slot, 4, up[1][0]); park_row(slot, 5, up[1][1]);
+        if (dup_last) {                                          // the duplicate of the last station: one branch per action
+            float* d = slot + SLOT_DW;
+            park_row(d, 0, lo[0]); park_row(d, 1, lo[1]);
+            park_row(d, 2, up[0][0]); park_row(d, 3, up[0][1]);
+            park_row(d, 4, up[1][0]); park_row(d, 5, up[1][1]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_s_setprio(0);
+        // ---- phase 2: successor station, the eight taps, R3 in this ORDER, costs, argmin -- per cell
+        int kv = k;
+        asm volatile("" : "+v"(kv));
+        const ActScalars now = cur;
+        if (k + 1 < N_BWD) {
+            cur = fetch_scalars(k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (i == 1 && !shared) {
+                // cell 1 does not share cell 0's upper rows: its own lower rows take their place
+                asm volatile("s_barrier" ::: "memory");
+                park_row(slot, 2, q00); park_row(slot, 3, q10);
+                if (dup_last) { park_row(slot + SLOT_DW, 2, q00); park_row(slot + SLOT_DW, 3, q10); }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            const v4f w = dsc4[(i * N_BWD + k) * 2];
+            const v4f u = dsc4[(i * N_BWD + k) * 2 + 1];
+            const double sd = kFma<LERP> ? fma(now.j_term[i], dt_d, sd_base[i]) : sd_base[i] + now.j_term[i];
+            const float tn_s = fmaxf(s, (float)sd);
+            // (the path division first: its tiny-dividend branch ends a basic block, and whatever is in flight across it -- the
+            // 24 taps, were they requested first -- stays in registers on both sides)
+            const float alpha = div_path<PATH_DIV>(tn_s, rp_hi, rp_lo, p.path_step_size);
+            const float xs = tn_s - s_min_v;
+            const float qs = div_const<RANGE_DIV>(xs, rr_hi, rr_lo);
+            const float cs = qs * s_scale_v + 0.5f;
+            const float xb = cs - 0.5f;
+            const float fl = floorf(xb);
+            const float fr = xb - fl;
+            const float ws = s_weight<QUANT>(fr);
+            const float iws = 1.0f - ws;
+            const int off = (int)(fminf(fl, s_scale) * (float)(SLOT_DW * 4));
+            const float* T0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(R) + off) + i * 6;
+            float nch[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float tl[4] = {T0[ch], T0[3 + ch], T0[6 + ch], T0[9 + ch]};
+                const float th[4] = {T0[SLOT_DW + ch], T0[SLOT_DW + 3 + ch], T0[SLOT_DW + 6 + ch], T0[SLOT_DW + 9 + ch]};
+                nch[ch] = fetch8<ORDER, LERP & 3>(tl, th, ws, iws, w);
+            }
+            const float nc = nch[0], ng = nch[1], nj = nch[2];
+            if (i == 0 && k + 1 < N_BWD) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue(cur, A0_ROWS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float f0 = fminf(floorf(alpha), path_top);
+            const float pa = alpha - f0;
+            const float pia = 1.0f - pa;
+            const int t4 = (int)(f0 * 4.0f);
+            const float pv0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4);
+            const float pv1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4 + 4);
+            const float vmn = mad1<LERP>(pv0, pia, pv1 * pa);
+            float c = sc[i] + nc;
+            float g = sg[i] + ng;
+            const float dj = nj - u.x;
+            c = mad1<LERP>(w_snap_v, dj * dj, c);
+            g = (float)((double)g + fmax(now.tn_v_d[i] - (double)vmn, 0.0));
+            const float s_change = tn_s - s;
+            g += fmaxf(s_change - s_dist, 0.0f);
+            c += u.y;
+            g += u.z;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(g) << 32) | __float_as_uint(c);
+            const bool better = key < best[i];
+            best[i] = better ? key : best[i];
+            bk[i] = better ? kv : bk[i];
+            __builtin_amdgcn_sched_barrier(0);                 // one cell at a time: two cells' taps in flight cost a wavefront per SIMD
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(best[i]), "+v"(bk[i]));
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (i == 0 || rs) st_node(out + (size_t)(row0 + i) * S + is, __uint_as_float((unsigned)best[i]), __uint_as_float((unsigned)(best[i] >> 32)),
+                    action_jerk(p, bk[i], N_BWD, FilterRule{QUANT, LERP & 3, kFma<LERP> ? 1 : 0, ORDER}));
+    }
+}
+
+// ------------------------------------------------------------------------
 // k_backward3s: the plain-fp32 instruction stream of k_backward3v for grids that do NOT fill the chip (tpl's default
 // 201x37x20, 128x64x32): there a sweep is bound by how many instructions ONE SIMD has to issue for its two to four
 // wavefronts and by one workgroup's latency, not by loads.  One cell per lane (a row per workgroup: the shortest
@@ -728,11 +1014,27 @@ bool launch_s_rule(int path_div, int range_div, bool first_early, const SweepArg
                        : pick_div_s<QUANT, LERP, false>(path_div, range_div, true, go);
 }
 
+template <int QUANT, int LERP, int ORDER>
+bool launch_o_rule(int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
+{
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, dim3(a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
+        return true;
+    };
+    if (path_div == 5 && range_div == 5) return go(k_backward3o<5, 5, QUANT, LERP, ORDER>);
+    if (path_div == 0 && range_div == 0) return go(k_backward3o<0, 0, QUANT, LERP, ORDER>);
+    return false;
+}
+
 } // namespace
 
 // (Q, L, F): weight rule, blend form, contraction; the kernels take L + 4 F as their LERP argument
 #define TPL_RULE_V(Q, L, F) if (r.quant == Q && r.lerp == L && r.fma == F) return launch_v_rule<Q, L + 4 * F>(pd, rd, a, grid, lds, st);
 #define TPL_RULE_S(Q, L, F) if (r.quant == Q && r.lerp == L && r.fma == F) return launch_s_rule<Q, L + 4 * F>(pd, rd, fe, a, grid, lds, st);
+// (Q, L, F, O): ... and the blend order / form (k_backward3o); the eight-corner sums (O = 2, 3) have no blend form: L = 0 stands for all
+#define TPL_RULE_O(Q, L, F, O) if (r.quant == Q && (O != 1 || r.lerp == L) && r.fma == F && r.order == O) return launch_o_rule<Q, L + 4 * F, O>(pd, rd, a, grid, lds, st);
+#define TPL_ORDER_FILE(NAME, RULES_O) \
+    bool launch_backward3o_rules_##NAME(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st) { RULES_O return false; }
 #define TPL_RULE_FILE(NAME, RULES_V, RULES_S) \
     bool launch_backward3v_rules_##NAME(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st) { RULES_V return false; } \
     bool launch_backward3s_rules_##NAME(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st) { RULES_S return false; }
@@ -748,7 +1050,18 @@ TPL_RULE_FILE(c, TPL_RULE_V(1, 0, 1) TPL_RULE_V(2, 0, 1) TPL_RULE_V(0, 0, 1) TPL
 #elif TPL_SWEEP_RULESET == 4      /* contracted arithmetic, second half */
 TPL_RULE_FILE(d, TPL_RULE_V(2, 1, 1) TPL_RULE_V(2, 2, 1) TPL_RULE_V(0, 1, 1) TPL_RULE_V(0, 2, 1),
                  TPL_RULE_S(2, 1, 1) TPL_RULE_S(2, 2, 1) TPL_RULE_S(0, 1, 1) TPL_RULE_S(0, 2, 1))
+#elif TPL_SWEEP_RULESET == 5      /* blend order s -> v -> a (k_backward3o), one rounding per operation */
+TPL_ORDER_FILE(e, TPL_RULE_O(1, 0, 0, 1) TPL_RULE_O(1, 1, 0, 1) TPL_RULE_O(1, 2, 0, 1) TPL_RULE_O(2, 0, 0, 1) TPL_RULE_O(2, 1, 0, 1) TPL_RULE_O(2, 2, 0, 1))
+#elif TPL_SWEEP_RULESET == 6      /* blend order s -> v -> a, contracted arithmetic */
+TPL_ORDER_FILE(f, TPL_RULE_O(1, 0, 1, 1) TPL_RULE_O(1, 1, 1, 1) TPL_RULE_O(1, 2, 1, 1) TPL_RULE_O(2, 0, 1, 1) TPL_RULE_O(2, 1, 1, 1) TPL_RULE_O(2, 2, 1, 1))
+#elif TPL_SWEEP_RULESET == 7      /* the eight-corner sum, fp32 accumulator */
+TPL_ORDER_FILE(g, TPL_RULE_O(1, 0, 0, 2) TPL_RULE_O(2, 0, 0, 2) TPL_RULE_O(1, 0, 1, 2) TPL_RULE_O(2, 0, 1, 2))
+#elif TPL_SWEEP_RULESET == 8      /* the eight-corner sum, wide accumulator */
+TPL_ORDER_FILE(h, TPL_RULE_O(1, 0, 0, 3) TPL_RULE_O(2, 0, 0, 3) TPL_RULE_O(1, 0, 1, 3) TPL_RULE_O(2, 0, 1, 3))
 #else
+#define TPL_ORDER_DECL(NAME) \
+    bool launch_backward3o_rules_##NAME(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
+TPL_ORDER_DECL(e) TPL_ORDER_DECL(f) TPL_ORDER_DECL(g) TPL_ORDER_DECL(h)
 #define TPL_RULE_DECL(NAME) \
     bool launch_backward3v_rules_##NAME(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st); \
     bool launch_backward3s_rules_##NAME(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
@@ -759,8 +1072,25 @@ size_t backward3v_lds_bytes(int s_pad, int path_steps)
     return (size_t)2 * (s_pad + 1) * 16 + (size_t)2 * N_BWD * 8 * sizeof(float) + sizeof(float) * ((size_t)path_steps + 1);
 }
 
+size_t backward3o_lds_bytes(int s_pad, int path_steps)
+{
+    return ((((size_t)s_pad + 1) * SLOT_DW * sizeof(float) + 15) & ~(size_t)15) + (size_t)2 * N_BWD * 8 * sizeof(float) + sizeof(float) * ((size_t)path_steps + 1);
+}
+
+bool backward3o_built(FilterRule rule)
+{
+    return rule.order >= 1 && rule.order <= 3 && (rule.quant == 1 || rule.quant == 2);
+}
+
 bool launch_backward3v(FilterRule rule, int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
+    if (rule.order != 0) {                      // another blend order / the eight-corner sums: k_backward3o, its own LDS block
+        const size_t lds = backward3o_lds_bytes(a.s_pad, a.p.path_steps);
+        return launch_backward3o_rules_e(rule, path_div, range_div, a, grid, lds, stream)
+               || launch_backward3o_rules_f(rule, path_div, range_div, a, grid, lds, stream)
+               || launch_backward3o_rules_g(rule, path_div, range_div, a, grid, lds, stream)
+               || launch_backward3o_rules_h(rule, path_div, range_div, a, grid, lds, stream);
+    }
     if (rule.quant == kDefaultRule.quant && rule.lerp == kDefaultRule.lerp && !rule.fma)
         return launch_v_rule<1, 0>(path_div, range_div, a, grid, lds_bytes, stream);
     if (rule.fma)
