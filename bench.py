@@ -526,6 +526,10 @@ def traffic_block(roofline, key):
                 if k in tr:
                     roofline[k] = tr[k]
             if "valu_issue" in tr:
+                # what binds, as the PMC passes say it: `frac` stays the HBM fraction SURVEY 8d prescribes
+                # (algorithmic bytes per launch / launch time / 8 TB/s); `bound` names the resource the kernel is up against
+                roofline["bound"] = "valu_issue"
+                roofline["prescribed_bound"] = "hbm"
                 roofline["binding"] = (f"not HBM: VALU issue {tr['valu_issue']:.2f} and the texture-address path {tr.get('texture_addr', 0.0):.2f} of the "
                                        f"kernel's cycles (PMC instruction counts x measured per-instruction costs, model in profiles/{f}); neither "
                                        "binds alone -- the rest is the latency of one row round trip per action at eight waves per SIMD (DESIGN 2.2b')")

@@ -113,6 +113,25 @@ def flops_per_stage(problem, dims, dyn_evals):
     return F_BW.get((X, U), 0), f_deriv, f_roll
 
 
+def issue_block(roofline, problem, form, batch):
+    """Share of the issued instructions that are fp64 arithmetic, from the committed PMC pass of this kernel
+    (profiles/r0N_ilqr_issue.json, written by tools/profile_round.sh from rocprofv3 --pmc SQ_INSTS_VALU_*_F64 / SQ_INSTS_*;
+    rocprofv3 cannot run inside the timed process): a constant of the repository, keyed by problem / launch form."""
+    import json
+    for f in ("r05_ilqr_issue.json", "r04_ilqr_issue.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f)) as fd:
+                tab = json.load(fd)
+        except OSError:
+            continue
+        row = tab.get(f"{problem}/{form or 'single'}")
+        if row:
+            roofline["fp64_issue_share"] = row["fp64_issue_share"]
+            roofline["fp64_issue_share_source"] = f"profiles/{f} ({row.get('what', 'PMC pass')}; kernel revision {row.get('profiled_kernel_rev', '?')}, batch {row.get('batch', '?')})"
+            return
+    roofline["fp64_issue_share"] = None
+
+
 def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrier=None, id_offset=0, workload="mpc", lib=None):
     """One rank's share of a batched-iLQR workload.  `seed` picks this rank's block of initial states,
     `barrier` (N > 1) brackets the timed region, `id_offset` is the global id of this rank's problem 0."""
@@ -184,6 +203,21 @@ def run(device=0, batch=1024, horizon=None, updates=10, warmup=2, seed=0, barrie
                      "executed_tflops": per_iter_exec * iters / k_s / 1e12,
                      "mfma_busy": 0.0},
     }
+    # What a caller of the drop-in boundary waits for: Optim.update() = upload of the host mirrors the caller wrote (x0, u,
+    # bounds, multipliers, array parameters), the same launch, eager fetch of x / u / costs into the numpy views
+    # (ilqr_model.hip: tplhip_ilqr_update) -- next to the device-resident figure above, same problems, cold start each time.
+    call = []
+    for _ in range(3):
+        if workload == "mpc":
+            _configure(opt, x0)
+        else:
+            _configure_lateral(opt, x0, horizon)
+        t0 = time.perf_counter()
+        opt.update()
+        call.append((time.perf_counter() - t0) * 1e3)
+    out["update_call_ms"] = float(np.median(call))
+    out["update_call_batched_iters_per_s"] = iters / (out["update_call_ms"] * 1e-3)
+    issue_block(out["roofline"], w["problem"], out["form"], batch)
     # this rank's best problem as the fixed-size record of SURVEY 8e: {constr, cost, id, x[T+1,X], u[T,U]}
     b = int(np.argmin(np.where(np.isfinite(opt.traj_costs), opt.traj_costs, np.inf)))
     out["best_record"] = np.concatenate([[0.0, float(opt.traj_costs[b]), float(id_offset + b)],

@@ -218,7 +218,11 @@ TPLHIP_API int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant,
  * nvcc), written out as fma() calls -- lonDynamics (lon_planner.cu:240-250), interpPath (common.cuh:124-136), the grid
  * points (lon_planner.cu:196-199, env.cu:144), s_dist and the cost sums of evalNode (lon_planner.cu:40-65, 84, 110,
  * 148).  Deterministic (no compiler decides): oracle/dp_lon_oracle.c built -DDPO_R1_FMA=1 is the same arithmetic.
- * Every kernel honours it (template variants of the plain-fp32 sweeps): the choice of kernel does not change. */
+ * Every kernel honours it (template variants of the plain-fp32 sweeps): the choice of kernel does not change.
+ * This is a MODEL of nvcc's fusion -- the sites and the operand order (fma(a, b, c*d), left to right) are placed by hand
+ * on both sides, so bit parity is proven against this repository's restatement, not against an nvcc build -- until it
+ * has been checked against a dump or the SASS of the reference build ("Pinning HP-1").  The default
+ * stays 0, which is NOT what the reference binary most likely computes. */
 TPLHIP_API int tplhip_dp_lon_set_contraction(tplhip_dp_lon* h, int on);
 /* Rule R3's ORDER and form (round 5).  The texture unit behind tex3D (lon_planner.cu:26-38, arr_tex_surf.cuh:142-149)
  * blends eight texels; the default contract freezes three sequential 1-D blends along a, then v, then s.  The hardware's

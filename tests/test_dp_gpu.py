@@ -89,6 +89,45 @@ def test_tables_and_trajectories_bit_exact(S, V, A, T, obst, dt_start, request):
         assert np.array_equal(got.view(np.uint32), otrajs[r].view(np.uint32)), (r, got, otrajs[r])
 
 
+@pytest.mark.parametrize("S,V,A,T,order", [(128, 64, 66, 3, 0), (128, 37, 120, 3, 0), (201, 50, 42, 4, 0), (96, 21, 30, 3, 0),
+                                             (128, 37, 120, 3, 1), (201, 50, 42, 3, 2)])
+def test_skewed_traversal_writes_every_row(S, V, A, T, order, monkeypatch):
+    """The skewed traversal of the two-rows-per-lane sweeps (default on tables beyond ~100 MB: config 4) is a per-a-row
+    rotation of row pairs (dp_sweep.hip: `lp -= (ia * skew) % vx`); a wrong modulus leaves a row pair unwritten or
+    written twice.  TPLHIP_DEBUG=skew=1,big=1 forces it (and the large-grid kernel) on grids the oracle sweeps whole:
+    FULL tables compared, incl. an odd number of velocity rows (last pair = row V-1 twice), XCD shares of unequal size,
+    and the ordered form k_backward3o which shares the traversal."""
+    monkeypatch.setenv("TPLHIP_DEBUG", "skew=1,big=1")
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.random_obstacles(5, 6))
+    inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(2, seed=5)
+    env = tpl_amd.DynProgEnvironment()
+    env.reinit_buffers(ep)
+    env.set_occ_map(occ)
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p)
+    if order:
+        dp.set_blend_order(order)
+        import os
+        import subprocess
+        lib = os.path.join(O.ROOT, "oracle", f"_sens/libdp_lon_oracle_r100o{order}.so")
+        if not os.path.exists(lib):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(O.ROOT, "oracle"), f"_sens/libdp_lon_oracle_r100o{order}.so"])
+        O.use(lib)
+    try:
+        trajs = dp.update_batch(inits, path, env)
+        tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, inits)
+    finally:
+        O.use(None)
+    info = dp.info()
+    assert info["sweep"] == ("k_backward3o" if order else "k_backward3v") and info["skew_pairs_per_a_row"] > 0.0, info
+    _assert_tables_equal(dp, tables, T)
+    for r, tr in enumerate(trajs):
+        assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), r
+
+
 @pytest.mark.parametrize("S,V,A,T,dt_start", [(201, 37, 20, 10, None), (201, 37, 20, 6, 0.6), (128, 64, 32, 5, None),
                                               (70, 9, 7, 4, 0.3), (256, 12, 6, 3, None), (33, 3, 2, 3, None)])
 def test_small_grid_forms_agree_bit_for_bit(S, V, A, T, dt_start, monkeypatch):
@@ -263,6 +302,26 @@ def test_full_size_spot_checks(grid):
             want = np.array([tp.cost, tp.constr, tp.j, 0.0], dtype=np.float32)
             got = cur[ia[k], iv[k], i_s[k]]
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (t, ia[k], iv[k], i_s[k], got, want)
+
+    # ... and one whole random station column -- EVERY (v, a) row -- of two stages: the traversal of the large-grid sweep
+    # (XCD shares, strips, the skewed rotation of row pairs on tables beyond ~100 MB) decides which workgroup writes
+    # which row pair; random cells find one unwritten pair of 16 384 with p ~ 0.2, a column finds it always
+    for t in (T - 2, 2):
+        nxt = dp.copy_table(min(T - 1, t + 1))
+        cur = dp.copy_table(t)
+        i_s = int(rng.integers(0, S))
+        for ia in range(A):
+            for iv in range(V):
+                tp = TplLonState()
+                tp.t = np.float32(cp.dt_start) + np.float32(t - 1) * np.float32(cp.dt)
+                tp.s = np.float32(cp.s_min) + np.float32(i_s) * np.float32(cp._s_step_size)
+                tp.v = np.float32(cp.v_min) + np.float32(iv) * np.float32(cp._v_step_size)
+                tp.a = np.float32(cp.a_min) + np.float32(ia) * np.float32(cp._a_step_size)
+                O.lib().dpo_eval_node(C.byref(cp), C.byref(cep), 9, C.byref(tp), O.fptr(nxt), O.fptr(path),
+                                      O.fptr(dist), cp.dt, 1, 0)
+                want = np.array([tp.cost, tp.constr, tp.j, 0.0], dtype=np.float32)
+                got = cur[ia, iv, i_s]
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), ("column", t, ia, iv, i_s, got, want)
 
     tr = _traj_np(traj)
     assert np.all(np.diff(tr[:, 1]) >= 0.0)

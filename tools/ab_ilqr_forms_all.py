@@ -1,5 +1,6 @@
 """Same-box table of the three update() forms for EVERY tpl problem of the goldens at large batch sizes: which models gain
-from the two-wavefront forms (the library picks the fused form by itself only for models of six or more states).
+from the two-wavefront forms (the library picks the fused form by itself for EVERY model above 4 x CUs problems: five of the
+seven gain 22-42 % there, the two reference-line smoothers are indifferent -- table at the end of profiles/r04_ilqr_split_ab.txt).
 Each problem is set up from its golden's inputs, replicated with perturbed start states, min_rel_cost_change = 0 so that
 every problem runs its whole iteration budget.     python tools/ab_ilqr_forms_all.py [batches...]"""
 import json

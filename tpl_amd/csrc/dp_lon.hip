@@ -265,14 +265,17 @@ void pick_div_forms(tplhip_dp_lon* h)
 {
     auto best = [](int mask) { return (mask & 2) ? 4 : ((mask & 1) ? 3 : ((mask & 4) ? 5 : 0)); };
     int pd = best(h->verified_path3), rd = best(h->verified_range3);
+    // TPLHIP_DEBUG=div_form=N (tests, soaks): form N in {3, 4, 5} where it is proven, else IEEE division; N = 0: IEEE divisions
+    // everywhere, under every rule; any other value is ignored (the planner picks by itself)
     int forced = 0;
-    if (debug_opt("div_form", &forced)) {              // tests: this form where it is proven, else IEEE division
+    const bool forced_set = debug_opt("div_form", &forced) && (forced == 0 || forced == 3 || forced == 4 || forced == 5);
+    if (forced_set) {
         auto only = [&](int mask) { return ((forced == 3 && (mask & 1)) || (forced == 4 && (mask & 2)) || (forced == 5 && (mask & 4))) ? forced : 0; };
         pd = only(h->verified_path3);
         rd = only(h->verified_range3);
     }
     if (h->rule_set) {
-        const bool newton = (h->verified_path3 & 4) && (h->verified_range3 & 4) && (!forced || forced == 5);
+        const bool newton = (h->verified_path3 & 4) && (h->verified_range3 & 4) && (!forced_set || forced == 5);
         pd = rd = newton ? 5 : 0;
     }
     h->path_div3 = pd;
@@ -1268,18 +1271,17 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
     return TPLHIP_OK;
 }
 
-// R2 / R3 of the HP-1 arithmetic contract as a run-time choice (see FilterRule in dp_lon_math.h).  Rebuilds the action
-// table; the plain-fp32 sweeps are built for all nine rules (dp_sweep.hip), so the choice of kernel does not change.
-int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_form)
+// The arithmetic rules of the HP-1 contract as run-time choices (FilterRule in dp_lon_math.h).  One helper applies a new
+// rule: the handle is only changed AFTER the device is selected and pending rollouts -- which read h->rule -- have drained;
+// it rebuilds the action table and re-picks the division forms.
+namespace {
+int apply_rule(tplhip_dp_lon* h, FilterRule r)
 {
-    if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
-    if (weight_quant < 0 || weight_quant > 2 || lerp_form < 0 || lerp_form > 2)
-        return tplhip_fail(TPLHIP_EINVAL, "filter rule: weight_quant in {0 none, 1 rint, 2 floor}, lerp_form in {0, 1, 2}");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     int rc = wait_pending_forwards(h);
     if (rc) return rc;
-    h->rule = FilterRule{weight_quant, lerp_form, h->rule.fma, h->rule.order};
-    h->rule_set = !(weight_quant == kDefaultRule.quant && lerp_form == kDefaultRule.lerp && h->rule.fma == 0 && h->rule.order == 0);
+    h->rule = r;
+    h->rule_set = !(r.quant == kDefaultRule.quant && r.lerp == kDefaultRule.lerp && r.fma == 0 && r.order == 0);
     if (h->have_params) pick_div_forms(h);
     h->tables_valid = false;
     if (h->have_params && h->d_acts) {
@@ -1289,37 +1291,39 @@ int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_f
     }
     return TPLHIP_OK;
 }
+} // namespace
 
-// R1 of the HP-1 arithmetic contract as a run-time choice: 0 = one rounding per operation of the reference source (the
-// default), 1 = the multiply-adds nvcc's default -fmad=true contracts, written out as fma() (FilterRule::fma in
-// dp_lon_math.h; the sites are listed in the header of oracle/dp_lon_oracle.c).  Rebuilds the action table.  Every kernel
+// R2 / R3: the plain-fp32 sweeps are built for all nine (weight rule, blend form) pairs, so the choice of kernel does not change.
+int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_form)
+{
+    if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
+    if (weight_quant < 0 || weight_quant > 2 || lerp_form < 0 || lerp_form > 2)
+        return tplhip_fail(TPLHIP_EINVAL, "filter rule: weight_quant in {0 none, 1 rint, 2 floor}, lerp_form in {0, 1, 2}");
+    return apply_rule(h, FilterRule{weight_quant, lerp_form, h->rule.fma, h->rule.order});
+}
+
+// R1: 0 = one rounding per operation of the reference source (the default), 1 = the multiply-adds nvcc's default -fmad=true
+// contracts, written out as fma() (FilterRule::fma; the sites are listed in the header of oracle/dp_lon_oracle.c).  A MODEL of
+// nvcc's fusion until it has been checked against a dump or the SASS of the reference build.  Every kernel
 // honours it: the plain-fp32 sweeps as template variants, the general sweep, rollout, re-evaluation, stage prelude and
 // distance map at run time.
 int tplhip_dp_lon_set_contraction(tplhip_dp_lon* h, int on)
 {
     if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
     if (on != 0 && on != 1) return tplhip_fail(TPLHIP_EINVAL, "contraction: 0 (one rounding per operation) or 1 (fused multiply-adds)");
-    const FilterRule r = h->rule;
-    h->rule.fma = on;
-    const int rc = tplhip_dp_lon_set_filter_rule(h, r.quant, r.lerp);
-    if (rc) h->rule = r;
-    return rc;
+    return apply_rule(h, FilterRule{h->rule.quant, h->rule.lerp, on, h->rule.order});
 }
 
-// R3's ORDER / form as a run-time choice (FilterRule::order in dp_lon_math.h): 0 = a -> v -> s (default), 1 = s -> v -> a,
-// 2 / 3 = the eight-corner sum in fp32 / wide.  Rollout, re-evaluation, stage prelude and the general sweep honour it at
-// run time; the plain-fp32 sweeps are built for order 0 only (they park ONE blended row per action, which no other order
-// allows), so a plan under another order takes the general sweep k_backward -- the price is in DESIGN.md 0.
+// R3's ORDER / form (FilterRule::order): 0 = a -> v -> s (default), 1 = s -> v -> a, 2 / 3 = the eight-corner sum in fp32 /
+// wide.  Rollout, re-evaluation, stage prelude and the general sweep honour it at run time; the large-grid sweep has its own
+// form for it (k_backward3o, dp_sweep.hip: six raw rows parked, eight LDS taps per cell-action), built for the weight rules
+// rint and floor -- un-quantised weights under another order take the general sweep.  The price is in DESIGN.md 0.
 int tplhip_dp_lon_set_blend_order(tplhip_dp_lon* h, int order)
 {
     if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
     if (order < 0 || order > 3)
         return tplhip_fail(TPLHIP_EINVAL, "blend order: 0 (a -> v -> s), 1 (s -> v -> a), 2 (eight-corner sum, fp32), 3 (eight-corner sum, wide)");
-    const FilterRule r = h->rule;
-    h->rule.order = order;
-    const int rc = tplhip_dp_lon_set_filter_rule(h, r.quant, r.lerp);
-    if (rc) h->rule = r;
-    return rc;
+    return apply_rule(h, FilterRule{h->rule.quant, h->rule.lerp, h->rule.fma, order});
 }
 
 int tplhip_dp_lon_timing_enable(tplhip_dp_lon* h, int enable)
@@ -1438,8 +1442,8 @@ int tplhip_dp_lon_scenarios_set_block(tplhip_dp_lon* h, int first, int count, co
 {
     if (!h || !occ_block || !inits) return tplhip_fail(TPLHIP_EINVAL, "null argument");
     if (h->sc_n < 1) return tplhip_fail(TPLHIP_ESTATE, "no scenarios uploaded");
-    if (first < 0 || count < 1 || first + count > h->sc_n)
-        return tplhip_fail(TPLHIP_EINVAL, "scenario block [%d, %d) does not fit (%d scenarios)", first, first + count, h->sc_n);
+    if (first < 0 || count < 1 || first > h->sc_n || count > h->sc_n - first)      // (no first + count: it overflows for huge arguments)
+        return tplhip_fail(TPLHIP_EINVAL, "scenario block of %d from %d does not fit (%d scenarios)", count, first, h->sc_n);
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     const TplDpEnvParams& ep = h->sc_ep;
     const size_t occ_elems = (size_t)ep.l_steps * ep.s_steps * ep.t_steps;
@@ -1455,8 +1459,8 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
 {
     if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
     if (h->sc_n < 1) return tplhip_fail(TPLHIP_ESTATE, "no scenarios uploaded");
-    if (first < 0 || count < 1 || count > h->sc_chunk || first + count > h->sc_n)
-        return tplhip_fail(TPLHIP_EINVAL, "scenario range [%d, %d) does not fit (%d scenarios, %d per launch)", first, first + count, h->sc_n, h->sc_chunk);
+    if (first < 0 || count < 1 || count > h->sc_chunk || first > h->sc_n || count > h->sc_n - first)
+        return tplhip_fail(TPLHIP_EINVAL, "scenario range of %d from %d does not fit (%d scenarios, %d per launch)", count, first, h->sc_n, h->sc_chunk);
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     const TplDpLonParams& p = h->params;
     const TplDpEnvParams& ep = h->sc_ep;

@@ -14,8 +14,8 @@
 //    that: k_ilqr_update (one body, 480 registers, one wavefront per SIMD:
 //    what a caller with up to 4 x CUs problems gets) and k_ilqr_fused (the
 //    phases as real calls, each compiled to 256 registers: two wavefronts per
-//    SIMD hide each other's dependent chains -- batches beyond that, for the
-//    models whose derivative refresh is heavy).  The split sequence
+//    SIMD hide each other's dependent chains -- every uniform batch beyond
+//    4 x CUs problems, whatever the model: pick_form()).  The split sequence
 //    k_split_* runs the same phases as launches (the A/B leg).  All three
 //    give the same bits; the pieces they share are functions further down
 //    (riccati_backward, line_search_rollouts, iteration_tail, ...);
@@ -48,6 +48,8 @@
 #include <cstdio>
 #include <cstring>
 #include <iterator>
+#include <map>
+#include <mutex>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -2055,7 +2057,6 @@ struct tplhip_ilqr {
     double kernel_ms = 0.0;
     int64_t launches = 0;
     int n_cu = 256;                              // compute units of the device
-    size_t lds_optin = 0;                        // dynamic LDS the kernel is currently allowed (hipFuncSetAttribute)
     unsigned long long lds_aperture = 0;         // flat address of LDS offset 0 (0: unknown, no LDS residency)
     size_t lds_static = 0;                       // static LDS of k_ilqr_update
     size_t lds_dyn_bytes = 0;                    // dynamic LDS of the next launch
@@ -2067,9 +2068,6 @@ struct tplhip_ilqr {
     bool dev_split_valid = false;
     Params* d_params_split = nullptr;
     size_t lds_dyn_bytes_split = 0;              // dynamic LDS of the split kernels (Lds block + arrays + mirrors)
-    size_t lds_optin_split = 0;
-    size_t lds_optin_chain[6] = {0, 0, 0, 0, 0, 0};   // per chain-kernel / fused-kernel instantiation (order x integrator), of this
-    size_t lds_optin_fused[6] = {0, 0, 0, 0, 0, 0};   // handle's device
     int* d_run = nullptr;
     int split_mode = -1;                         // TPLHIP_DEBUG ilqr_split=0|1|2; -1: by batch size and model
     bool split_uniform = false;                  // integrator and order are the same for the whole batch
@@ -2299,17 +2297,30 @@ int pick_form(const tplhip_ilqr* h)
     return (long long)h->batch > 4LL * h->n_cu ? 2 : 0;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a setting per FUNCTION and DEVICE, shared by every handle of this model
+// library: a process-global table keeps the largest value set so far and only ever raises it (a second handle with a
+// smaller requirement must not lower the limit under the first one's feet).
+int raise_lds_limit(int device, const void* fn, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> limit;
+    if (bytes <= 48 * 1024) return TPLHIP_OK;                 // what every launch gets without asking
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& cur = limit[{device, fn}];
+    if (bytes > cur) {
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), "raising the LDS limit failed");
+        cur = bytes;
+    }
+    return TPLHIP_OK;
+}
+
 template <bool SO, int INT>
 int launch_chain(tplhip_ilqr* h, int lg, int it)
 {
     const void* fn = reinterpret_cast<const void*>(&k_split_chain<SO, INT>);
     // more dynamic LDS than a launch gets without asking (only with TPLHIP_DEBUG=ilqr_split_lds_kb beyond 48): opt in, per
     // instantiation -- a batch may come back with another integrator, i.e. another kernel
-    size_t& optin = h->lds_optin_chain[(SO ? 3 : 0) + INT];
-    if (h->lds_dyn_bytes_split > 48 * 1024 && h->lds_dyn_bytes_split > optin) {
-        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dyn_bytes_split), "raising the LDS limit failed");
-        optin = h->lds_dyn_bytes_split;
-    }
+    if (int rc = raise_lds_limit(h->device, fn, h->lds_dyn_bytes_split)) return rc;
     hipLaunchKernelGGL((k_split_chain<SO, INT>), dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes_split, h->stream, h->d_dev_split, lg, it);
     return TPLHIP_OK;
 }
@@ -2317,11 +2328,8 @@ int launch_chain(tplhip_ilqr* h, int lg, int it)
 int launch_split(tplhip_ilqr* h)
 {
     const size_t lds = h->lds_dyn_bytes_split;
-    if (lds > 48 * 1024 && lds > h->lds_optin_split) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_split_begin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "raising the LDS limit failed");
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_split_refresh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "raising the LDS limit failed");
-        h->lds_optin_split = lds;
-    }
+    if (int rc = raise_lds_limit(h->device, reinterpret_cast<const void*>(k_split_begin), lds)) return rc;
+    if (int rc = raise_lds_limit(h->device, reinterpret_cast<const void*>(k_split_refresh), lds)) return rc;
     const int rounds = std::max(1, h->max_lg_max);
     for (int lg = 0; lg < rounds; ++lg) {
         hipLaunchKernelGGL(k_split_begin, dim3(h->batch), dim3(WAVE), lds, h->stream, h->d_dev_split, lg);
@@ -2343,11 +2351,7 @@ template <bool SO, int INT>
 int launch_fused_t(tplhip_ilqr* h)
 {
     const void* fn = reinterpret_cast<const void*>(&k_ilqr_fused<SO, INT>);
-    size_t& optin = h->lds_optin_fused[(SO ? 3 : 0) + INT];
-    if (h->lds_dyn_bytes_split > 48 * 1024 && h->lds_dyn_bytes_split > optin) {
-        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_dyn_bytes_split), "raising the LDS limit failed");
-        optin = h->lds_dyn_bytes_split;
-    }
+    if (int rc = raise_lds_limit(h->device, fn, h->lds_dyn_bytes_split)) return rc;
     hipLaunchKernelGGL((k_ilqr_fused<SO, INT>), dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes_split, h->stream, h->d_dev_split,
                        std::max(1, h->max_lg_max), h->max_iter_max, (h->horizon_max + WAVE - 1) / WAVE);
     return TPLHIP_OK;
@@ -2377,11 +2381,7 @@ int launch(tplhip_ilqr* h)
         if (int rc = launch_split(h)) return rc;
     } else {
         h->last_form = 0;
-        if (h->lds_dyn_bytes > 48 * 1024 && h->lds_dyn_bytes > h->lds_optin) {       // more than the default allowance: opt in
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ilqr_update), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)h->lds_dyn_bytes), "raising the LDS limit failed");
-            h->lds_optin = h->lds_dyn_bytes;
-        }
+        if (int rc = raise_lds_limit(h->device, reinterpret_cast<const void*>(k_ilqr_update), h->lds_dyn_bytes)) return rc;      // more than the default allowance: opt in
         hipLaunchKernelGGL(k_ilqr_update, dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes, h->stream, h->dev);
     }
     HIP_TRY(hipGetLastError(), "solver launch failed");
