@@ -267,6 +267,17 @@ struct Lds {
     double dump[2];            // where lanes without an entry park what they loaded
 };
 
+// Diagnostic builds that PRICE a part by leaving it out (results are not solutions; tools/ilqr_ablate.sh,
+// tools/ab_ilqr_remap.py): 1 = no backward pass, 2 = no rollouts (k_ilqr_update only); in every launch form: 3 = no stage
+// costs of the candidates, 4 = the rollouts cover half the stages -- both change which steps are accepted and with it how
+// often the derivatives are refreshed, so they only bound; the clean prices come from DOING A PART TWICE, which leaves every
+// result and every decision as it is: 5 = the first half of the stages is rolled out a second time (the time it adds is what
+// two problems per wavefront in the rollouts could save per problem at unchanged occupancy and LDS residency), 6 = every
+// stage cost of the candidates is evaluated twice (what folding the cost pass into the rollouts could save at most).
+#ifndef TPL_ILQR_ABLATE
+#define TPL_ILQR_ABLATE 0
+#endif
+
 // ---- backward Riccati pass, optim.c:926-985, as a function of its own (NOT inlined) -- same reason as
 // line_search_rollouts: inside k_ilqr_update its loop ran with 85 AGPR moves, 30 SGPR-spill reloads
 // and 6 scratch stores per stage (of 513 instructions), all issued by the one wavefront of the SIMD.
@@ -587,9 +598,6 @@ __device__ __attribute__((noinline)) void riccati_backward(const RiccatiArgs A, 
 // straight dependent chain without a wait in it; lane 0 stores the gains.  Same operations in the same order as the
 // lane-parallel form (the dots accumulate from zero in index order, only the lower triangle of Qxx is formed and
 // mirrored), so both give the same bits.
-#ifndef TPL_ILQR_ABLATE
-#define TPL_ILQR_ABLATE 0
-#endif
 #ifndef TPL_ILQR_SMALL_NX
 #define TPL_ILQR_SMALL_NX 2
 #endif
@@ -856,8 +864,23 @@ __device__ __forceinline__ void line_search_rollouts_impl(const RolloutArgs& A, 
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)opt_start * NX + i];
 
-    for (int t0 = opt_start; t0 < T; t0 += ROLL_RING) {
-        const int n = (T - t0 < ROLL_RING) ? T - t0 : ROLL_RING;
+#if TPL_ILQR_ABLATE == 4
+    const int T_roll = opt_start + (T - opt_start) / 2;
+#else
+    const int T_roll = T;
+#endif
+#if TPL_ILQR_ABLATE == 5
+    for (int pass = 0; pass < 2; ++pass) {
+    const int T_pass = pass == 0 ? T_roll : opt_start + (T_roll - opt_start) / 2;
+    if (pass == 1) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = X_[(int64_t)opt_start * NX + i];
+    }
+#else
+    const int T_pass = T_roll;
+#endif
+    for (int t0 = opt_start; t0 < T_pass; t0 += ROLL_RING) {
+        const int n = (T_pass - t0 < ROLL_RING) ? T_pass - t0 : ROLL_RING;
         if (active) {
             for (int k = 0; k < n; ++k) {
                 const int t = t0 + k;
@@ -939,6 +962,9 @@ __device__ __forceinline__ void line_search_rollouts_impl(const RolloutArgs& A, 
         lds_sync();
         RSTAMP(2);
     }
+#if TPL_ILQR_ABLATE == 5
+    }
+#endif
 #ifdef TPL_ILQR_STAMP
     if (lane == 0 && A.stamp_acc) { A.stamp_acc[14] += racc[0]; A.stamp_acc[15] += racc[1]; A.stamp_acc[4] += racc[2]; }
 #endif
@@ -1000,7 +1026,19 @@ __device__ __forceinline__ bool iteration_tail(const IterTail& a, const Params& 
             for (int i = 0; i < NX; ++i) x[i] = cx[i];
 #pragma unroll
             for (int d = 0; d < NU; ++d) u[d] = cu[d];
+#if TPL_ILQR_ABLATE == 3
+            c = x[0] * 1e-9;
+#else
             costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c, 1);
+#if TPL_ILQR_ABLATE == 6
+            {
+                double c2;
+                asm volatile("" : "+v"(x[0]), "+v"(u[0]));       // (a second evaluation the compiler cannot merge with the first)
+                costs(P, x, u, LAM + (int64_t)t * NCM, BW, (double)t, dt, &c2, 1);
+                asm volatile("" :: "v"(c2));
+            }
+#endif
+#endif
             // into LDS where the rollouts' ring (idle now) can hold them: a store to global
             // memory would put a write acknowledgement in front of the next pass' loads
             if (cc_lds) s.ring_x[cand * cc_rows + t] = c;
@@ -1903,13 +1941,16 @@ void k_split_chain(const DevState* stp, int lg, int it)
 // profiles/r04_ilqr_split_ab.txt.
 // (the calls are to these out-of-line copies, which only k_ilqr_fused uses: a callee is compiled to the register budget
 // its callers share, so they get the two-wavefront budget while the split kernels above keep their own)
-__device__ __attribute__((noinline)) void fn_begin(const DevState* stp, int lg, int b) { ph_begin<true>(stp, lg, b); }
-__device__ __attribute__((noinline)) void fn_refresh_block(const DevState* stp, int lg, int it, int b, int blk) { ph_refresh_block<true>(stp, lg, it, b, blk); }
-template <bool SECOND_ORDER, int INT_TYPE>
+// (W = wavefronts per SIMD the calling kernel is compiled for: one set of out-of-line copies per instance of the kernel, so
+// that each set is compiled to ITS caller's register budget -- 256 registers under W = 2, 512 under W = 1)
+template <int W> __device__ __attribute__((noinline)) void fn_begin(const DevState* stp, int lg, int b) { ph_begin<true>(stp, lg, b); }
+template <int W> __device__ __attribute__((noinline)) void fn_refresh_block(const DevState* stp, int lg, int it, int b, int blk) { ph_refresh_block<true>(stp, lg, it, b, blk); }
+template <bool SECOND_ORDER, int INT_TYPE, int W>
 __device__ __attribute__((noinline)) void fn_chain(const DevState* stp, int lg, int it, int b) { ph_chain<SECOND_ORDER, INT_TYPE, true>(stp, lg, it, b); }
 
 // what every phase of a launch of the split sequence fetches for itself, once per update: the array parameters and the
 // control bounds' mirrors into the LDS regions all phases agree on
+template <int W>
 __device__ __attribute__((noinline)) void fused_setup(const DevState* stp, int b_in)
 {
     const CstDev st = uni_dev(stp);
@@ -1927,21 +1968,20 @@ __device__ __attribute__((noinline)) void fused_setup(const DevState* stp, int b
     }
 }
 
-template <bool SECOND_ORDER, int INT_TYPE>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TPL_ILQR_CHAIN_WAVES, TPL_ILQR_CHAIN_WAVES_MAX)))
-void k_ilqr_fused(const DevState* stp, int rounds, int iterations, int blocks)
+template <bool SECOND_ORDER, int INT_TYPE, int W>
+__device__ __forceinline__ void fused_body(const DevState* stp, int rounds, int iterations, int blocks)
 {
     const int b = (int)blockIdx.x;
     if (!lds_where_expected(stp)) return;
-    fused_setup(stp, b);
+    fused_setup<W>(stp, b);
     __syncthreads();
     for (int lg = 0; lg < rounds; ++lg) {
-        fn_begin(stp, lg, b);
+        fn_begin<W>(stp, lg, b);
         __syncthreads();
         for (int it = 0; it < iterations; ++it) {
-            for (int blk = 0; blk < blocks; ++blk) fn_refresh_block(stp, lg, it, b, blk);
+            for (int blk = 0; blk < blocks; ++blk) fn_refresh_block<W>(stp, lg, it, b, blk);
             __syncthreads();
-            fn_chain<SECOND_ORDER, INT_TYPE>(stp, lg, it, b);
+            fn_chain<SECOND_ORDER, INT_TYPE, W>(stp, lg, it, b);
             __syncthreads();
         }
     }
@@ -1950,6 +1990,23 @@ void k_ilqr_fused(const DevState* stp, int rounds, int iterations, int blocks)
         if (sc[TPL_S_TERMINATION_CONDITION] != -99.0 && (int)sc[TPL_S_ITERATIONS] == (int)sc[TPL_S_MAX_ITERATIONS])
             sc[TPL_S_TERMINATION_CONDITION] = 1.0;                   // optim.c:1147-1149
     }
+}
+
+template <bool SECOND_ORDER, int INT_TYPE>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(TPL_ILQR_CHAIN_WAVES, TPL_ILQR_CHAIN_WAVES_MAX)))
+void k_ilqr_fused(const DevState* stp, int rounds, int iterations, int blocks)
+{
+    fused_body<SECOND_ORDER, INT_TYPE, TPL_ILQR_CHAIN_WAVES>(stp, rounds, iterations, blocks);
+}
+
+// The same phases as calls at ONE wavefront per SIMD (round 5): what k_ilqr_update is for batches of up to 4 x CUs problems,
+// without the one body -- every phase compiled by itself to the full register file (no AGPR parking, no scratch), nothing
+// hoisted across a call.  TPLHIP_DEBUG=ilqr_split=3 selects it; whether update() takes it by itself: pick_form().
+template <bool SECOND_ORDER, int INT_TYPE>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_ilqr_fused1(const DevState* stp, int rounds, int iterations, int blocks)
+{
+    fused_body<SECOND_ORDER, INT_TYPE, 1>(stp, rounds, iterations, blocks);
 }
 
 __global__ void k_split_end(const DevState* stp, int batch)
@@ -2347,21 +2404,26 @@ int launch_split(tplhip_ilqr* h)
     return TPLHIP_OK;
 }
 
-template <bool SO, int INT>
+template <bool SO, int INT, bool ONE>
 int launch_fused_t(tplhip_ilqr* h)
 {
-    const void* fn = reinterpret_cast<const void*>(&k_ilqr_fused<SO, INT>);
+    const void* fn = ONE ? reinterpret_cast<const void*>(&k_ilqr_fused1<SO, INT>) : reinterpret_cast<const void*>(&k_ilqr_fused<SO, INT>);
     if (int rc = raise_lds_limit(h->device, fn, h->lds_dyn_bytes_split)) return rc;
-    hipLaunchKernelGGL((k_ilqr_fused<SO, INT>), dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes_split, h->stream, h->d_dev_split,
-                       std::max(1, h->max_lg_max), h->max_iter_max, (h->horizon_max + WAVE - 1) / WAVE);
+    if (ONE)
+        hipLaunchKernelGGL((k_ilqr_fused1<SO, INT>), dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes_split, h->stream, h->d_dev_split,
+                           std::max(1, h->max_lg_max), h->max_iter_max, (h->horizon_max + WAVE - 1) / WAVE);
+    else
+        hipLaunchKernelGGL((k_ilqr_fused<SO, INT>), dim3(h->batch), dim3(WAVE), h->lds_dyn_bytes_split, h->stream, h->d_dev_split,
+                           std::max(1, h->max_lg_max), h->max_iter_max, (h->horizon_max + WAVE - 1) / WAVE);
     return TPLHIP_OK;
 }
 
+template <bool ONE>
 int launch_fused(tplhip_ilqr* h)
 {
     const int ty = h->split_int_type;
-    if (h->split_second_order) return ty == EULER ? launch_fused_t<true, EULER>(h) : (ty == HEUN ? launch_fused_t<true, HEUN>(h) : launch_fused_t<true, RK4>(h));
-    return ty == EULER ? launch_fused_t<false, EULER>(h) : (ty == HEUN ? launch_fused_t<false, HEUN>(h) : launch_fused_t<false, RK4>(h));
+    if (h->split_second_order) return ty == EULER ? launch_fused_t<true, EULER, ONE>(h) : (ty == HEUN ? launch_fused_t<true, HEUN, ONE>(h) : launch_fused_t<true, RK4, ONE>(h));
+    return ty == EULER ? launch_fused_t<false, EULER, ONE>(h) : (ty == HEUN ? launch_fused_t<false, HEUN, ONE>(h) : launch_fused_t<false, RK4, ONE>(h));
 }
 
 int launch(tplhip_ilqr* h)
@@ -2373,9 +2435,12 @@ int launch(tplhip_ilqr* h)
         HIP_TRY(hipEventRecord(e0, h->stream), "event record failed");
     }
     const int form = pick_form(h);
-    if (form == 2) {
+    if (form == 3) {
+        h->last_form = 3;
+        if (int rc = launch_fused<true>(h)) return rc;
+    } else if (form == 2) {
         h->last_form = 2;
-        if (int rc = launch_fused(h)) return rc;
+        if (int rc = launch_fused<false>(h)) return rc;
     } else if (form == 1) {
         h->last_form = 1;
         if (int rc = launch_split(h)) return rc;
@@ -2549,7 +2614,7 @@ int tplhip_ilqr_create(int device, int batch, int t_cap, tplhip_ilqr** out)
     h->dev.run = h->d_run;
     {
         int v = 0;
-        if (tplhip::debug_opt("ilqr_split", &v)) h->split_mode = (v >= 0 && v <= 2) ? v : 1;
+        if (tplhip::debug_opt("ilqr_split", &v)) h->split_mode = (v >= 0 && v <= 3) ? v : 1;
         // the split kernels place their Lds block at dynamic-LDS offset 0 and the host computes LDS addresses from that:
         // it only holds while none of them has static LDS of its own (none has; a compiler that adds some turns the form off)
         hipFuncAttributes fa;
@@ -2559,7 +2624,10 @@ int tplhip_ilqr_create(int device, int batch, int t_cap, tplhip_ilqr** out)
                              reinterpret_cast<const void*>(&k_split_chain<false, HEUN>), reinterpret_cast<const void*>(&k_split_chain<false, RK4>),
                              reinterpret_cast<const void*>(&k_ilqr_fused<true, EULER>), reinterpret_cast<const void*>(&k_ilqr_fused<true, HEUN>),
                              reinterpret_cast<const void*>(&k_ilqr_fused<true, RK4>), reinterpret_cast<const void*>(&k_ilqr_fused<false, EULER>),
-                             reinterpret_cast<const void*>(&k_ilqr_fused<false, HEUN>), reinterpret_cast<const void*>(&k_ilqr_fused<false, RK4>)};
+                             reinterpret_cast<const void*>(&k_ilqr_fused<false, HEUN>), reinterpret_cast<const void*>(&k_ilqr_fused<false, RK4>),
+                             reinterpret_cast<const void*>(&k_ilqr_fused1<true, EULER>), reinterpret_cast<const void*>(&k_ilqr_fused1<true, HEUN>),
+                             reinterpret_cast<const void*>(&k_ilqr_fused1<true, RK4>), reinterpret_cast<const void*>(&k_ilqr_fused1<false, EULER>),
+                             reinterpret_cast<const void*>(&k_ilqr_fused1<false, HEUN>), reinterpret_cast<const void*>(&k_ilqr_fused1<false, RK4>)};
         for (const void* fn : fns)
             if (hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.sharedSizeBytes != 0) h->split_mode = 0;
         (void)hipGetLastError();
@@ -2862,7 +2930,7 @@ int tplhip_ilqr_info(tplhip_ilqr* h, char* buf, int n)
                   "\"lds_static_bytes\": %zu, \"form\": \"%s\", \"chain_waves_per_simd\": %d}", h->batch, h->rows - 1,
                   sp ? h->dev_split.lds_traj : h->dev.lds_traj, sp ? h->dev_split.n_lds_arrays : h->dev.n_lds_arrays,
                   sp ? h->lds_dyn_bytes_split : h->lds_dyn_bytes, sp ? (size_t)0 : h->lds_static,
-                  h->last_form == 2 ? "fused" : (sp ? "split" : "single"), sp ? TPL_ILQR_CHAIN_WAVES : 1);
+                  h->last_form == 3 ? "fused1" : (h->last_form == 2 ? "fused" : (sp ? "split" : "single")), (sp && h->last_form != 3) ? TPL_ILQR_CHAIN_WAVES : 1);
     return TPLHIP_OK;
 }
 
