@@ -21,7 +21,7 @@ GOLDEN = os.path.join(HERE, "golden")
 FIELDS = ("x", "u", "k", "K", "lagrange_multiplier", "next_x", "next_u", "prev_x", "prev_k", "fx", "fu", "lx", "lu",
           "lxx", "luu", "lux", "traj_costs", "iterations", "lg_iterations", "alpha", "mu", "mu_step",
           "trajectory_changed", "improved", "termination_condition")
-FORMS = {0: "single", 1: "split", 2: "fused"}
+FORMS = {0: "single", 1: "split", 2: "fused", 3: "fused1"}
 EXTRA = os.environ.get("TPL_FORMS_FUZZ_DEBUG", "")     # further TPLHIP_DEBUG tokens for every leg (ilqr_no_lds, ilqr_split_lds_kb=8 ...)
 
 

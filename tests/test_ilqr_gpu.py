@@ -267,11 +267,38 @@ def test_both_backward_pass_forms_pass_the_goldens_and_agree_bit_for_bit(name, t
         assert np.array_equal(a, b)
 
 
+@pytest.mark.xfail(strict=True, reason="ROCm 7.2.0 (AMD clang 22.0.0git roc-7.2.0) miscompiles k_ilqr_update under -amdgpu-sched-strategy=max-ilp: "
+                                       "the allocator's AGPR copies of mu sit in front of a loop exit's exec restore "
+                                       "(profiles/r05_ilqr_max_ilp_root_cause.txt); the build refuses such a library "
+                                       "(tests/test_isa_check.py) -- this test keeps the symptom on record and turns into an "
+                                       "unexpected pass (= a failure) the day a toolchain fixes it")
+def test_max_ilp_build_leaves_the_right_mu(tmp_path, monkeypatch):
+    """The symptom of round 4's max-ilp divergence, on the box: the single launch of a library built with the max-ilp
+    scheduler strategy (check_isa=False: the scan would refuse it) leaves mu = 1 where mu_step = 2 says 10 on problems that
+    end on two rejected steps; the fused form of the same library has the right value."""
+    import shutil
+    import fuzz_ilqr_forms as F
+    from tpl_amd.optim import genopt, optimizers as o, solver
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not shutil.which(hipcc) and not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    model = "trajectory_tracking_mpc_time"
+    so = str(tmp_path / "libilqr_max_ilp.so")
+    genopt.compile_model(model, force=True, extra_flags=["-mllvm", "-amdgpu-sched-strategy=max-ilp"], so_path=so, check_isa=False)
+    monkeypatch.setattr(genopt, "build", lambda cfg, name=None, out_dir=None: solver.factory(so, cfg.param_defaults))
+    single, _ = F.run(model, "mpc_time", 7, 0)
+    fused, _ = F.run(model, "mpc_time", 7, 2)
+    mu_step = single[0]["mu_step"]
+    want = np.where(mu_step == 0, 0.0, 10.0 ** (mu_step - 1))
+    assert np.array_equal(fused[0]["mu"], want)
+    assert np.array_equal(single[0]["mu"], want), (single[0]["mu"], want)       # fails under the miscompile: mu = 1 where 10 is due
+
+
 # ---- split-launch form (k_split_begin / _refresh / _chain / _end): the update() of a chip-filling batch as a sequence of
 # launches, so that the dependent chains run with several resident wavefronts per SIMD -- and the fused form
 # (k_ilqr_fused): the same phases as calls inside one launch, compiled to the same two-wavefront register budget.  Forced
 # here with TPLHIP_DEBUG=ilqr_split=1 / =2 on batches of any size; the same routines in the same order: the same bits.
-_FORM_NAMES = {0: "single", 1: "split", 2: "fused"}
+_FORM_NAMES = {0: "single", 1: "split", 2: "fused", 3: "fused1"}
 
 
 @pytest.mark.parametrize("form", [1, 2])
@@ -307,7 +334,7 @@ def test_split_launch_matches_single_launch(lds_kb, monkeypatch):
     x0[:, 2] = rng.uniform(-0.2, 0.2, B)
     x0[:, 4] = rng.uniform(4, 10, B)
     results = []
-    for form in (0, 1, 2):
+    for form in (0, 1, 2, 3):                           # (3: the fused phases at one wavefront per SIMD, k_ilqr_fused1 -- the A/B leg of round 5)
         dbg = f"ilqr_split={form}" + (f",ilqr_split_lds_kb={lds_kb}" if (form and lds_kb) else "")
         monkeypatch.setenv("TPLHIP_DEBUG", dbg)
         opt = make(batch=B, horizon=50)
@@ -343,7 +370,7 @@ def test_split_launch_matches_single_launch_other_models(model, first_order, mon
     g = np.load(os.path.join(GOLDEN, f"ilqr_{name}.npz"))
     B = 9
     results = []
-    for form in (0, 1, 2):
+    for form in (0, 1, 2, 3):
         monkeypatch.setenv("TPLHIP_DEBUG", f"ilqr_split={form}")
         one = make()
         cases.apply_inputs(one, g)

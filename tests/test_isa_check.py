@@ -1,0 +1,73 @@
+"""The build-time scan of the solver libraries' device listings for vector instructions that execute with EXEC = 0
+(tpl_amd/optim/isa_check.py) -- the root cause of round 4's max-ilp divergence (profiles/r05_ilqr_max_ilp_root_cause.txt): a
+register-allocator copy of the value a divergent loop computes, placed in the loop's exit block in front of the exec restore."""
+import os
+import shutil
+
+import pytest
+
+from tpl_amd.optim import genopt, isa_check
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+BAD = """
+_ZN1kE:                                 ; @_ZN1kE
+.LBB14_599:
+	s_add_i32 s6, s6, 1
+	v_cmp_eq_u32_e32 vcc, s6, v2
+	v_mul_f64 v[4:5], v[4:5], s[8:9]
+	s_or_b64 s[4:5], vcc, s[4:5]
+	s_andn2_b64 exec, exec, s[4:5]
+	s_cbranch_execnz .LBB14_599
+; %bb.600:
+	s_mov_b32 s74, 0
+	v_accvgpr_write_b32 a226, v5            ;  Reload Reuse
+	v_accvgpr_write_b32 a227, v4            ;  Reload Reuse
+	s_mov_b32 s75, 0x40240000
+	s_or_b64 exec, exec, s[4:5]
+.LBB14_601:
+	s_or_b64 exec, exec, s[2:3]
+	v_accvgpr_write_b32 a31, v2
+"""
+GOOD = BAD.replace("""	s_mov_b32 s74, 0
+	v_accvgpr_write_b32 a226, v5            ;  Reload Reuse
+	v_accvgpr_write_b32 a227, v4            ;  Reload Reuse
+	s_mov_b32 s75, 0x40240000
+	s_or_b64 exec, exec, s[4:5]
+""", """	s_or_b64 exec, exec, s[4:5]
+	s_mov_b32 s74, 0
+	v_accvgpr_write_b32 a226, v5            ;  Reload Reuse
+	v_accvgpr_write_b32 a227, v4            ;  Reload Reuse
+""")
+
+
+def test_scan_flags_copies_in_front_of_the_exec_restore(tmp_path):
+    bad, good = tmp_path / "bad.s", tmp_path / "good.s"
+    bad.write_text(BAD)
+    good.write_text(GOOD)
+    hits = isa_check.scan(str(bad))
+    assert [h[3].split()[0] for h in hits] == ["v_accvgpr_write_b32", "v_accvgpr_write_b32"] and hits[0][1] == "_ZN1kE"
+    assert isa_check.scan(str(good)) == []
+    # lane-addressed moves do not depend on EXEC
+    lanes = tmp_path / "lanes.s"
+    lanes.write_text(BAD.replace("v_accvgpr_write_b32 a226, v5", "v_readlane_b32 s3, v255, 4").replace("v_accvgpr_write_b32 a227, v4", "v_writelane_b32 v255, s3, 5"))
+    assert isa_check.scan(str(lanes)) == []
+
+
+def test_max_ilp_build_is_refused_and_the_default_build_is_clean(tmp_path):
+    """The whole chain on the real thing: trajectory_tracking_mpc_time built with `-mllvm -amdgpu-sched-strategy=max-ilp`
+    (cross-compiled here, no GPU needed) contains the misplaced copies -- compile_model refuses the library and names the
+    instructions; the same source under the default scheduler passes the scan (every shipped library went through it)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not shutil.which(hipcc) and not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    model = "trajectory_tracking_mpc_time"
+    if not os.path.exists(os.path.join(ROOT, "tpl_amd", "models", f"{model}.inc")):
+        pytest.skip("generated model header not in this tree")
+    so = str(tmp_path / "libilqr_max_ilp.so")
+    with pytest.raises(RuntimeError, match="EXEC = 0") as e:
+        genopt.compile_model(model, force=True, extra_flags=["-mllvm", "-amdgpu-sched-strategy=max-ilp"], so_path=so)
+    assert "v_accvgpr_write_b32" in str(e.value) and "k_ilqr_update" in str(e.value)
+    assert not os.path.exists(so)
+    so2 = str(tmp_path / "libilqr_default.so")
+    assert genopt.compile_model(model, force=True, so_path=so2) == so2 and os.path.exists(so2)

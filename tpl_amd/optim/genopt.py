@@ -805,9 +805,13 @@ def generate(cfg, name=None, out_dir=None, force=False):
     return paths["inc"]
 
 
-def compile_model(name, out_dir=None, force=False):
-    """hipcc the solver template against ``<name>.inc`` -> libilqr_<name>.so."""
-    paths = model_paths(name, out_dir)
+def compile_model(name, out_dir=None, force=False, extra_flags=None, so_path=None, check_isa=True):
+    """hipcc the solver template against ``<name>.inc`` -> libilqr_<name>.so (``so_path``: a variant build somewhere else,
+    ``extra_flags``: its additional compiler flags, ``check_isa=False``: keep a library whose listing fails the EXEC = 0 scan;
+    all three for tests and A/B tools)."""
+    paths = dict(model_paths(name, out_dir))
+    if so_path:
+        paths["so"] = so_path
     src = os.path.join(CSRC_ILQR, "ilqr_model.hip")
     deps = [paths["inc"], src, os.path.abspath(__file__), os.path.join(CSRC_ILQR, "..", "tplhip_debug.h")] \
         + [os.path.join(CSRC_ILQR, f) for f in os.listdir(CSRC_ILQR) if f.endswith(".h")]
@@ -816,19 +820,45 @@ def compile_model(name, out_dir=None, force=False):
             return paths["so"]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = paths["so"] + f".tmp{os.getpid()}"
-    # (hipcc's default instruction scheduler.  `-mllvm -amdgpu-sched-strategy=max-ilp` is 1.5-2 % faster on the heavy models
-    # and was shipped for a few revisions of round 4 -- until one refactoring of k_ilqr_update came out of it with a wrong
-    # regularisation value for problems that end on two rejected steps (mu = 1 where mu_step = 2 says 10: the scheduler
-    # strategy, not the source, decided; profiles/r04_ilqr_split_ab.txt).  Not worth that risk.)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-fno-fast-math", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-           f"-DTPL_MODEL_INC=\"{paths['inc']}\"", "-I", os.path.join(_PKG, "..", "include"),
-           "-o", tmp, src]
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    if proc.returncode != 0:
-        raise RuntimeError("\n" + proc.stdout.decode("utf8", "replace"))
+    # hipcc's default instruction scheduler.  `-mllvm -amdgpu-sched-strategy=max-ilp` is 1.5-2 % faster on the heavy models
+    # and was shipped for a few revisions of round 4 -- until one refactoring of k_ilqr_update came out of it with mu = 1
+    # where mu_step = 2 says 10.  Root cause (round 5, profiles/r05_ilqr_max_ilp_root_cause.txt): a COMPILER bug, not undefined
+    # behaviour in the source -- ROCm 7.2.0's register allocator placed its AGPR copies of the value a divergent loop computes
+    # (the `m *= 10` loop of the mu schedule) in the loop's exit block IN FRONT of the `s_or_b64 exec` that re-enables the
+    # lanes, where no lane executes them; the copies only land there when the scheduler has moved scalar code above that
+    # restore, which max-ilp does and the default strategy does not.  "Does not" is checked, not assumed: the device listing
+    # of every library built here is scanned for vector instructions at EXEC = 0 (tpl_amd/optim/isa_check.py), and a hit
+    # fails the build -- whatever scheduler, whatever ROCm.  tests/test_ilqr_gpu.py::test_max_ilp_build_is_caught builds the
+    # max-ilp variant on the box: the scan must flag it, and its wrong mu is an expected (strict) failure.
+    import shutil
+    import tempfile
+    work = tempfile.mkdtemp(prefix=f"tplhip_{name}_")
+    try:
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-fvisibility=hidden", "-fno-fast-math", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+               f"-DTPL_MODEL_INC=\"{paths['inc']}\"", "-I", os.path.join(_PKG, "..", "include"),
+               "-save-temps", *(extra_flags or []), "-o", tmp, src]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=work)
+        if proc.returncode != 0:
+            raise RuntimeError("\n" + proc.stdout.decode("utf8", "replace"))
+        listings = [os.path.join(work, f) for f in os.listdir(work) if f.endswith(".s") and "amdgcn" in f]
+        hits = [h for lst in listings for h in exec0_hits(lst)]
+        if check_isa and (not listings or hits):
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError(f"{name}: " + ("no device listing to check" if not listings else
+                               "the compiler placed vector instructions where EXEC = 0 (spill code in front of a loop exit's exec "
+                               "restore; profiles/r05_ilqr_max_ilp_root_cause.txt):\n" + "\n".join(f"  {fn} line {n}: {txt}" for _, fn, n, txt in hits[:12])))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
     os.replace(tmp, paths["so"])
     return paths["so"]
+
+
+def exec0_hits(listing):
+    """Vector instructions of a hipcc listing that execute with EXEC = 0 (isa_check.py)."""
+    from . import isa_check
+    return isa_check.scan(listing)
 
 
 def build_module(cfg, name=None, out_dir=None):
