@@ -71,3 +71,15 @@ def test_max_ilp_build_is_refused_and_the_default_build_is_clean(tmp_path):
     assert not os.path.exists(so)
     so2 = str(tmp_path / "libilqr_default.so")
     assert genopt.compile_model(model, force=True, so_path=so2) == so2 and os.path.exists(so2)
+
+
+def test_libtplhip_listings_pass_the_scan():
+    """The same scan over every translation unit of libtplhip.so (`make -C tpl_amd/csrc check-isa`: device listings into a
+    scratch directory, scanned, removed)."""
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not shutil.which(hipcc) and not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tpl_amd", "csrc"), "-j8", "check-isa"], capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONPATH=ROOT), timeout=1500)
+    assert r.returncode == 0 and "0 vector instruction(s) at EXEC = 0" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
