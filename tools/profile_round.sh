@@ -2,7 +2,7 @@
 # End-of-round evidence run (on the GPU box, from the repo root):
 #   bash tools/profile_round.sh <tag>        -> gpurun_out/<tag>/...
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -29,6 +29,8 @@ TPLHIP_DEBUG=ilqr_split=1 bash tools/pmc_ilqr.sh "gpurun_out/$TAG/pmc_ilqr_split
 python3 tools/pmc_summary.py "gpurun_out/$TAG/pmc_ilqr_split" k_split_refresh all > "$OUT/pmc_ilqr_split_refresh.txt" 2>&1
 python3 tools/ab_ilqr_split.py mpc --forms 0,1,2 1024 1536 2048 4096 8192 16384 > "$OUT/ilqr_split_ab.txt" 2>&1
 python3 -c "import json, bench; json.dump(bench.dp_general_sweep_price(0), open('$OUT/dp_general_sweep.json', 'w'), indent=1)" > /dev/null 2>&1
+# the SURVEY 8(f) kernels: traces, one PMC pass each, k_ll_backward against the grid size (-> gpurun_out/${TAG}_f)
+bash tools/profile_f_rows.sh "$TAG" > "$OUT/f_rows.log" 2>&1
 find "$OUT" -name "*_agent_info.csv" -delete
 find "$OUT" -name "*counter_collection.csv" -size +2M -delete
 tail -n 3 "$OUT"/bench_*.json | cut -c1-600
