@@ -402,6 +402,11 @@ TPLHIP_API int tplhip_lat_lon_reinit(tplhip_lat_lon* h, const TplLatLonParams* p
 /* updateTrajDp, :579-643: states[0] is the start state; the t_steps states of the DP plan come
  * back in states[0..t_steps-1].  Needs an environment whose update() ran. */
 TPLHIP_API int tplhip_lat_lon_update_traj_dp(tplhip_lat_lon* h, tplhip_dp_env* env, TplLatLonState* states);
+/* The texture unit's frozen arithmetic (tplhip_dp_lon_set_filter_rule / _set_blend_order above: weight rule, blend form, blend
+ * order / eight-corner sums) for THIS planner's filtered fetches: the forward pass' lerp_cached_scaled of the value tables
+ * (lat_lon_planner.cu:206-273 with interp = true, arr_tex_surf.cuh:160-167), interpDistMapLon (env.cu:236-252) and the
+ * reference-line texture (common.cuh:93-95).  The backward pass point-samples (no filter).  Default (1, 0, 0). */
+TPLHIP_API int tplhip_lat_lon_set_filter_rule(tplhip_lat_lon* h, int weight_quant, int lerp_form, int blend_order);
 /* updateTrajSmooth, :645-760 (host: resampling + two LQR smoothing passes, utils.hpp:278-348).
  * smooth0 = trajSmooth.states[0]; out holds up to cap states, *n_out their number. */
 TPLHIP_API int tplhip_lat_lon_update_traj_smooth(tplhip_lat_lon* h, const TplLatLonState* traj_dp, int n_dp,

@@ -43,7 +43,68 @@ typedef struct { float x, y, z, w; } f4;
 
 static int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 static float sq(float x) { return x * x; }
-static float lerp1(float p, float q, float w) { return fmaf(q, w, p * (1.0f - w)); }
+/* The texture filter's frozen choices as build switches, exactly those of oracle/dp_lon_oracle.c (rules R2, R3 and R3's order):
+ *   -DLLO_WEIGHT_QUANT=1 rint (default) | 2 floor | 0 none      -DLLO_LERP_FORM=0 fma(q, w, p(1-w)) (default) | 1 | 2
+ *   -DLLO_BLEND_ORDER=0 z -> y -> x (default: the slowest axis first) | 1 x -> y -> z | 2 eight-corner sum, fp32 | 3 the sum, wide
+ * They act on every filtered fetch of this planner: the value tables (x = s, y = ds, z = l), the longitudinal distance map
+ * (x = t, y = s, z = l) and the 1-D reference-line texture.  tplhip_lat_lon_set_filter_rule is the same choice on the HIP side. */
+#ifndef LLO_WEIGHT_QUANT
+#define LLO_WEIGHT_QUANT 1
+#endif
+#ifndef LLO_LERP_FORM
+#define LLO_LERP_FORM 0
+#endif
+#ifndef LLO_BLEND_ORDER
+#define LLO_BLEND_ORDER 0
+#endif
+static float lerp1(float p, float q, float w)
+{
+#if LLO_LERP_FORM == 0
+    return fmaf(q, w, p * (1.0f - w));
+#elif LLO_LERP_FORM == 1
+    volatile float a = p * (1.0f - w), b = q * w;
+    return a + b;
+#else
+    volatile float d = q - p;
+    volatile float e = w * d;
+    return p + e;
+#endif
+}
+
+/* sum of w[c] t[c] in index order: fp32 accumulator (every product and sum rounded) or exact products in a double accumulator */
+#if LLO_BLEND_ORDER >= 2
+static float wsum(const float* w, const float* t, int n)
+{
+#if LLO_BLEND_ORDER == 3
+    double acc = (double)w[0] * (double)t[0];
+    for (int c = 1; c < n; ++c) acc += (double)w[c] * (double)t[c];
+    return (float)acc;
+#else
+    volatile float acc = w[0] * t[0];
+    for (int c = 1; c < n; ++c) { volatile float pr = w[c] * t[c]; acc = acc + pr; }
+    return acc;
+#endif
+}
+#endif
+
+/* rule R3 over the eight corners t[x + 2 y + 4 z] with the weights of the three axes */
+static float blend8(const float* t, float wx, float wy, float wz)
+{
+#if LLO_BLEND_ORDER == 0
+    float lo = lerp1(lerp1(t[0], t[4], wz), lerp1(t[2], t[6], wz), wy);          /* z, then y, then x */
+    float hi = lerp1(lerp1(t[1], t[5], wz), lerp1(t[3], t[7], wz), wy);
+    return lerp1(lo, hi, wx);
+#elif LLO_BLEND_ORDER == 1
+    float y0 = lerp1(lerp1(t[0], t[1], wx), lerp1(t[2], t[3], wx), wy);          /* x, then y, then z */
+    float y1 = lerp1(lerp1(t[4], t[5], wx), lerp1(t[6], t[7], wx), wy);
+    return lerp1(y0, y1, wz);
+#else
+    const float x2[2] = {1.0f - wx, wx}, y2[2] = {1.0f - wy, wy}, z2[2] = {1.0f - wz, wz};
+    float w[8];
+    for (int c = 0; c < 8; ++c) { volatile float xy = x2[c & 1] * y2[(c >> 1) & 1]; w[c] = xy * z2[c >> 2]; }
+    return wsum(w, t, 8);
+#endif
+}
 
 static Tap make_tap(float x_plus_half, int n)
 {
@@ -51,7 +112,13 @@ static Tap make_tap(float x_plus_half, int n)
     float xb = x_plus_half - 0.5f;
     float fl = floorf(xb);
     float alpha = xb - fl;
+#if LLO_WEIGHT_QUANT == 1
     t.w = rintf(alpha * 256.0f) / 256.0f;
+#elif LLO_WEIGHT_QUANT == 2
+    t.w = floorf(alpha * 256.0f) / 256.0f;
+#else
+    t.w = alpha;
+#endif
     int i = (int)fminf(fmaxf(fl, -1.0f), (float)n);
     t.i0 = clampi(i, 0, n - 1);
     t.i1 = clampi(i + 1, 0, n - 1);
@@ -78,19 +145,24 @@ static float dist_lon_x(const Ctx* c, float t, float s, float l)
     float lc = roundf((l - ep->l_min) / (ep->l_max - ep->l_min) * (ep->l_steps - 1));
     Tap tt = make_tap(t_idx + 0.5f, ep->t_steps), ts = make_tap(sc + 0.5f, ep->s_steps), tl = make_tap(lc + 0.5f, ep->l_steps);
 #define AT(il, is, it) c->dist_lon[((((size_t)(il)) * ep->s_steps + (is)) * ep->t_steps + (it)) * 2]
-    float b00 = lerp1(AT(tl.i0, ts.i0, tt.i0), AT(tl.i1, ts.i0, tt.i0), tl.w);
-    float b10 = lerp1(AT(tl.i0, ts.i1, tt.i0), AT(tl.i1, ts.i1, tt.i0), tl.w);
-    float b01 = lerp1(AT(tl.i0, ts.i0, tt.i1), AT(tl.i1, ts.i0, tt.i1), tl.w);
-    float b11 = lerp1(AT(tl.i0, ts.i1, tt.i1), AT(tl.i1, ts.i1, tt.i1), tl.w);
+    /* corners x + 2 y + 4 z with x = t, y = s, z = l (default order: l, then s, then t) */
+    const float t8[8] = { AT(tl.i0, ts.i0, tt.i0), AT(tl.i0, ts.i0, tt.i1), AT(tl.i0, ts.i1, tt.i0), AT(tl.i0, ts.i1, tt.i1),
+                          AT(tl.i1, ts.i0, tt.i0), AT(tl.i1, ts.i0, tt.i1), AT(tl.i1, ts.i1, tt.i0), AT(tl.i1, ts.i1, tt.i1) };
 #undef AT
-    return lerp1(lerp1(b00, b10, ts.w), lerp1(b01, b11, ts.w), tt.w);
+    return blend8(t8, tt.w, ts.w, tl.w);
 }
 
 static f4 tex_lerp(const Ctx* c, float s)
 {
     Tap t = make_tap(s / c->ref_step + 0.5f, c->n_ref);
     f4 a = c->ref_tex[t.i0], b = c->ref_tex[t.i1], r;
+#if LLO_BLEND_ORDER >= 2
+    const float w2[2] = {1.0f - t.w, t.w};
+    const float vx[2] = {a.x, b.x}, vy[2] = {a.y, b.y}, vz[2] = {a.z, b.z}, vw[2] = {a.w, b.w};
+    r.x = wsum(w2, vx, 2); r.y = wsum(w2, vy, 2); r.z = wsum(w2, vz, 2); r.w = wsum(w2, vw, 2);
+#else
     r.x = lerp1(a.x, b.x, t.w); r.y = lerp1(a.y, b.y, t.w); r.z = lerp1(a.z, b.z, t.w); r.w = lerp1(a.w, b.w, t.w);
+#endif
     return r;
 }
 
@@ -228,12 +300,11 @@ static f4 fetch_linear(const Ctx* c, const float* tab, float s, float ds, float 
     float* out = &r.x;
     for (int ch = 0; ch < 4; ++ch) {
 #define AT(il, id, is) tab[4 * (((size_t)(il) * p->ds_steps + (id)) * p->s_steps + (is)) + ch]
-        float c00 = lerp1(AT(tl.i0, td.i0, ts.i0), AT(tl.i1, td.i0, ts.i0), tl.w);
-        float c10 = lerp1(AT(tl.i0, td.i1, ts.i0), AT(tl.i1, td.i1, ts.i0), tl.w);
-        float c01 = lerp1(AT(tl.i0, td.i0, ts.i1), AT(tl.i1, td.i0, ts.i1), tl.w);
-        float c11 = lerp1(AT(tl.i0, td.i1, ts.i1), AT(tl.i1, td.i1, ts.i1), tl.w);
+        /* corners x + 2 y + 4 z with x = s, y = ds, z = l (default order: l, then ds, then s) */
+        const float t8[8] = { AT(tl.i0, td.i0, ts.i0), AT(tl.i0, td.i0, ts.i1), AT(tl.i0, td.i1, ts.i0), AT(tl.i0, td.i1, ts.i1),
+                              AT(tl.i1, td.i0, ts.i0), AT(tl.i1, td.i0, ts.i1), AT(tl.i1, td.i1, ts.i0), AT(tl.i1, td.i1, ts.i1) };
 #undef AT
-        out[ch] = lerp1(lerp1(c00, c10, td.w), lerp1(c01, c11, td.w), ts.w);
+        out[ch] = blend8(t8, ts.w, td.w, tl.w);
     }
     return r;
 }

@@ -18,12 +18,29 @@ STATE_F = ("t", "s", "ds", "dds", "ddds", "l", "dl", "ddl", "dddl", "cost", "con
 CART_F = ("t", "distance", "x", "y", "v", "a", "heading", "k", "cost", "constr", "flags_constr")
 
 
+_path = LIB
+
+
+def use(path=None):
+    """Switch to another build of the restatement (a texture-filter variant under oracle/_sens/: built on demand), or back to the
+    default with None."""
+    global _lib, _path
+    _path = path or LIB
+    _lib = None
+    if path and not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), os.path.relpath(path, os.path.join(ROOT, "oracle"))])
+
+
+def variant(quant, lerp, order):
+    return os.path.join(ROOT, "oracle", "_sens", f"liblat_lon_oracle_r{quant}{lerp}o{order}.so")
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
+        if not os.path.exists(_path):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liblat_lon_oracle.so"])
-        l = C.CDLL(LIB)
+        l = C.CDLL(_path)
         PP, EP, SP, CP = (C.POINTER(TplLatLonParams), C.POINTER(TplDpEnvParams), C.POINTER(TplLatLonState),
                           C.POINTER(TplLatLonCartState))
         l.llo_dynamics.argtypes = [SP, C.c_float, C.c_float, C.c_float, SP]

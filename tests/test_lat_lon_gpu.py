@@ -172,3 +172,42 @@ def test_errors():
     bad.l_steps = 1
     with pytest.raises(ValueError):
         pl.reinit_buffers(bad)
+
+
+@pytest.mark.parametrize("quant,lerp,order", [(2, 0, 0), (1, 1, 0), (1, 0, 1), (1, 0, 2), (1, 0, 3), (2, 2, 1), (0, 1, 2)])
+def test_filter_rule_variants_match_their_oracle_builds(quant, lerp, order):
+    """The texture filter's frozen arithmetic -- weight rule, blend form, blend order / eight-corner sums -- as a run-time choice of
+    this planner too (tplhip_lat_lon_set_filter_rule; HP-1: tests/test_dp_gpu.py).  It reaches the forward pass' filtered fetch of
+    the value tables, the distance-map and the reference-line look-ups; each variant must reproduce the build of
+    oracle/lat_lon_oracle.c that makes the same choice (-DLLO_WEIGHT_QUANT / -DLLO_LERP_FORM / -DLLO_BLEND_ORDER) bit for bit:
+    tables, the DP trajectory, the re-evaluated trajectory."""
+    env, o, dist_lon = _env("arc", 1)
+    p = _params()
+    start = _start(l=0.37)
+    oll.use(oll.variant(quant, lerp, order))
+    try:
+        tables, otraj = oll.update_traj_dp(p, o.c, dist_lon, o.ref, o.step, start)
+        ore = oll.reeval(p, o.c, dist_lon, o.ref, o.step, otraj)
+    finally:
+        oll.use(None)
+    tables0, otraj0 = oll.update_traj_dp(p, o.c, dist_lon, o.ref, o.step, start)
+    pl = tpl_amd.DynProgLatLonPlanner()
+    pl.reinit_buffers(p)
+    pl.set_filter_rule(quant, lerp, order)
+    pl.traj_dp[0] = start
+    pl.update_traj_dp(env)
+    _assert_tables(pl, tables, p.t_steps)
+    assert bytes(pl.traj_dp._as_array()) == bytes(otraj)
+    re = pl.reeval_traj(pl.traj_dp, env)
+    assert bytes(re._as_array()) == bytes(ore)
+    # (the backward tables are point sampled: only the prelude's filtered distances and reference-line values reach them, and on
+    # this scene several variants give the default's bits; truncated weights do not)
+    if (quant, lerp, order) == (2, 0, 0):
+        assert bytes(otraj) != bytes(otraj0) or any(not np.array_equal(tables[t], tables0[t]) for t in range(1, p.t_steps))
+    # the default comes back
+    pl.set_filter_rule(1, 0, 0)
+    pl.traj_dp[0] = start
+    pl.update_traj_dp(env)
+    assert bytes(pl.traj_dp._as_array()) == bytes(otraj0)
+    with pytest.raises(ValueError):
+        pl.set_filter_rule(1, 0, 4)

@@ -190,6 +190,7 @@ SIGNATURES = {
     "tplhip_lat_lon_destroy": (C.c_int, [_vp]),
     "tplhip_lat_lon_reinit": (C.c_int, [_vp, _P(TplLatLonParams), C.c_int]),
     "tplhip_lat_lon_update_traj_dp": (C.c_int, [_vp, _vp, _P(TplLatLonState)]),
+    "tplhip_lat_lon_set_filter_rule": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "tplhip_lat_lon_update_traj_smooth": (C.c_int, [_vp, _P(TplLatLonState), C.c_int, _P(TplLatLonState),
                                                     _P(TplLatLonState), C.c_int, _P(C.c_int)]),
     "tplhip_lat_lon_frenet_to_cartesian": (C.c_int, [_vp, _P(TplLatLonState), C.c_int, _P(TplLatLonCartState)]),

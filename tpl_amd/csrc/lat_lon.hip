@@ -63,28 +63,34 @@ __host__ __device__ inline float sqf(float x) { return x * x; }
 
 // interpDistMapLon(t, s, l).x, env.cu:236-252; dist_lon is float[l][s][t][2]
 __device__ __forceinline__ float dist_lon_x(const float* __restrict__ dist_lon, const TplDpEnvParams& ep,
-                                            float t, float s, float l)
+                                            float t, float s, float l, FilterRule rule = kDefaultRule)
 {
     const float t_idx = env_t_idx(ep, t);
     const float sc = (s - ep.s_min) / (ep.s_max - ep.s_min) * (float)(ep.s_steps - 1);
     const float lc = roundf((l - ep.l_min) / (ep.l_max - ep.l_min) * (float)(ep.l_steps - 1));
-    const Tap tt = make_tap(t_idx + 0.5f, ep.t_steps);
-    const Tap ts = make_tap(sc + 0.5f, ep.s_steps);
-    const Tap tl = make_tap(lc + 0.5f, ep.l_steps);
+    const Tap tt = make_tap(t_idx + 0.5f, ep.t_steps, rule);
+    const Tap ts = make_tap(sc + 0.5f, ep.s_steps, rule);
+    const Tap tl = make_tap(lc + 0.5f, ep.l_steps, rule);
     auto at = [&](int il, int is, int it) { return dist_lon[(((size_t)il * ep.s_steps + is) * ep.t_steps + it) * 2]; };
-    const float b00 = lerp1(at(tl.i0, ts.i0, tt.i0), at(tl.i1, ts.i0, tt.i0), tl.w);
-    const float b10 = lerp1(at(tl.i0, ts.i1, tt.i0), at(tl.i1, ts.i1, tt.i0), tl.w);
-    const float b01 = lerp1(at(tl.i0, ts.i0, tt.i1), at(tl.i1, ts.i0, tt.i1), tl.w);
-    const float b11 = lerp1(at(tl.i0, ts.i1, tt.i1), at(tl.i1, ts.i1, tt.i1), tl.w);
-    return lerp1(lerp1(b00, b10, ts.w), lerp1(b01, b11, ts.w), tt.w);
+    // corners x + 2 y + 4 z of the texture: x = t, y = s, z = l (the default order blends l, then s, then t)
+    const float t8[8] = {at(tl.i0, ts.i0, tt.i0), at(tl.i0, ts.i0, tt.i1), at(tl.i0, ts.i1, tt.i0), at(tl.i0, ts.i1, tt.i1),
+                         at(tl.i1, ts.i0, tt.i0), at(tl.i1, ts.i0, tt.i1), at(tl.i1, ts.i1, tt.i0), at(tl.i1, ts.i1, tt.i1)};
+    return blend8(t8, tt.w, ts.w, tl.w, rule);
+}
+
+// a 1-D filtered fetch under the rule: the two-corner sum for the sum forms (order 2 / 3), the blend otherwise
+__device__ __forceinline__ float lerp_1d(float a, float b, float w, FilterRule rule)
+{
+    if (rule.order >= 2) { const float w2[2] = {1.0f - w, w}; const float t2[2] = {a, b}; return wsum<2>(w2, t2, rule); }
+    return lerp1(a, b, w, rule);
 }
 
 // ref_line.texLerp(s), common.cuh:93-95: (v_max, d_left, d_right, semantic) of the float texture
-__device__ __forceinline__ float4 ref_tex(const float4* __restrict__ ref, int n_ref, float ref_step, float s)
+__device__ __forceinline__ float4 ref_tex(const float4* __restrict__ ref, int n_ref, float ref_step, float s, FilterRule rule = kDefaultRule)
 {
-    const Tap tp = make_tap(s / ref_step + 0.5f, n_ref);
+    const Tap tp = make_tap(s / ref_step + 0.5f, n_ref, rule);
     const float4 a = ref[tp.i0], b = ref[tp.i1];
-    return make_float4(lerp1(a.x, b.x, tp.w), lerp1(a.y, b.y, tp.w), lerp1(a.z, b.z, tp.w), lerp1(a.w, b.w, tp.w));
+    return make_float4(lerp_1d(a.x, b.x, tp.w, rule), lerp_1d(a.y, b.y, tp.w, rule), lerp_1d(a.z, b.z, tp.w, rule), lerp_1d(a.w, b.w, tp.w, rule));
 }
 
 // Source of interpDistMapLon(tp.t, tp.s, .) for one (t, s): either the precomputed profile across
@@ -93,16 +99,19 @@ struct DistSrc {
     const float* profile;            // [env l_steps] or nullptr
     const float* dist_lon;
     float t, s;
+    FilterRule rule = kDefaultRule;  // the texture filter's rules (tplhip_lat_lon_set_filter_rule)
 };
 
 __device__ __forceinline__ float dist_at(const DistSrc& d, const TplDpEnvParams& ep, float l)
 {
     if (d.profile) {
         const float lc = roundf((l - ep.l_min) / (ep.l_max - ep.l_min) * (float)(ep.l_steps - 1));
-        const Tap tl = make_tap(lc + 0.5f, ep.l_steps);        // integral coordinate: weight 0, texel i0
-        return lerp1(d.profile[tl.i0], d.profile[tl.i1], tl.w);
+        // integral coordinate: weight 0, texel i0 -- under every rule (the profile was filtered along s and t with the rule; a weight of
+        // exactly 0 along l leaves x for the finite distances of the map in the blends and adds +0 terms in the sums)
+        const Tap tl = make_tap(lc + 0.5f, ep.l_steps, d.rule);
+        return d.profile[tl.i0];
     }
-    return dist_lon_x(d.dist_lon, ep, d.t, d.s, l);
+    return dist_lon_x(d.dist_lon, ep, d.t, d.s, l, d.rule);
 }
 
 // Evaluator::getMid, lat_lon_planner.cu:83-124.  WAVE_PAR: called by a whole, converged wavefront
@@ -230,37 +239,49 @@ __device__ __forceinline__ int point_idx(float x, float x_min, float step, int n
     return clampi((int)fminf(fmaxf(floorf(c), -1.0f), (float)n), 0, n - 1);
 }
 
-// lerp_cached_scaled (arr_tex_surf.cuh:160-167): filtered fetch, rules R2/R3 (l, then ds, then s)
+// lerp_cached_scaled (arr_tex_surf.cuh:160-167): filtered fetch under the planner's filter rule (default R2/R3: l, then ds, then s)
 __device__ __forceinline__ float4 lerp_node(const float4* __restrict__ tab, const TplLatLonParams& p,
-                                            float s, float ds, float l, float step_s, float step_ds, float step_l)
+                                            float s, float ds, float l, float step_s, float step_ds, float step_l,
+                                            FilterRule rule = kDefaultRule)
 {
-    const Tap ts = make_tap((s - p.s_min) / step_s + 0.5f, p.s_steps);
-    const Tap td = make_tap((ds - p.ds_min) / step_ds + 0.5f, p.ds_steps);
-    const Tap tl = make_tap((l - p.l_min) / step_l + 0.5f, p.l_steps);
+    const Tap ts = make_tap((s - p.s_min) / step_s + 0.5f, p.s_steps, rule);
+    const Tap td = make_tap((ds - p.ds_min) / step_ds + 0.5f, p.ds_steps, rule);
+    const Tap tl = make_tap((l - p.l_min) / step_l + 0.5f, p.l_steps, rule);
     auto at = [&](int il, int id, int is) { return tab[((size_t)il * p.ds_steps + id) * p.s_steps + is]; };
-    auto l4 = [](float4 a, float4 b, float w) {
-        return make_float4(lerp1(a.x, b.x, w), lerp1(a.y, b.y, w), lerp1(a.z, b.z, w), lerp1(a.w, b.w, w));
-    };
-    const float4 c00 = l4(at(tl.i0, td.i0, ts.i0), at(tl.i1, td.i0, ts.i0), tl.w);
-    const float4 c10 = l4(at(tl.i0, td.i1, ts.i0), at(tl.i1, td.i1, ts.i0), tl.w);
-    const float4 c01 = l4(at(tl.i0, td.i0, ts.i1), at(tl.i1, td.i0, ts.i1), tl.w);
-    const float4 c11 = l4(at(tl.i0, td.i1, ts.i1), at(tl.i1, td.i1, ts.i1), tl.w);
-    return l4(l4(c00, c10, td.w), l4(c01, c11, td.w), ts.w);
+    // corners x + 2 y + 4 z of the texture: x = s, y = ds, z = l
+    const float4 n[8] = {at(tl.i0, td.i0, ts.i0), at(tl.i0, td.i0, ts.i1), at(tl.i0, td.i1, ts.i0), at(tl.i0, td.i1, ts.i1),
+                         at(tl.i1, td.i0, ts.i0), at(tl.i1, td.i0, ts.i1), at(tl.i1, td.i1, ts.i0), at(tl.i1, td.i1, ts.i1)};
+    float cx[8], cy[8], cz[8], cw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { cx[i] = n[i].x; cy[i] = n[i].y; cz[i] = n[i].z; cw[i] = n[i].w; }
+    return make_float4(blend8(cx, ts.w, td.w, tl.w, rule), blend8(cy, ts.w, td.w, tl.w, rule),
+                       blend8(cz, ts.w, td.w, tl.w, rule), blend8(cw, ts.w, td.w, tl.w, rule));
 }
 
-// ------------------------------------------------------------------------
-// per-(stage, station) prelude: reference-line texel and the distance profile across the
-// environment's lateral cells.  ref_s: float4[s]; profile: float[t][s][env l_steps].
-// ------------------------------------------------------------------------
+// the 2-D filter along s (y) and t (x) on ONE lateral cell of the distance map: what the 3-D filter of dist_lon_x reduces to at
+// an integral lateral coordinate (weight 0 along l) under every rule -- corners t[x + 2 y]
+__device__ __forceinline__ float blend4_xy(const float (&t)[4], float wx, float wy, FilterRule rule)
+{
+    if (rule.order == 1) return lerp1(lerp1(t[0], t[1], wx, rule), lerp1(t[2], t[3], wx, rule), wy, rule);      // x, then y (, then z)
+    if (rule.order >= 2) {
+        const float x2[2] = {1.0f - wx, wx}, y2[2] = {1.0f - wy, wy};
+        float w[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float xy = x2[c & 1] * y2[c >> 1]; w[c] = xy * 1.0f; }
+        return wsum<4>(w, t, rule);
+    }
+    return lerp1(lerp1(t[0], t[2], wy, rule), lerp1(t[1], t[3], wy, rule), wx, rule);                               // (z, then) y, then x
+}
+
 __global__ void k_ll_prelude(float4* __restrict__ ref_s, float* __restrict__ profile,
                              const float4* __restrict__ ref, int n_ref, float ref_step,
                              const float* __restrict__ dist_lon, TplLatLonParams p, TplDpEnvParams ep,
-                             float step_s)
+                             float step_s, FilterRule rule)
 {
     const int idx_t = blockIdx.x;
     for (int idx_s = threadIdx.x; idx_s < p.s_steps; idx_s += blockDim.x) {
         const float s = p.s_min + (float)idx_s * step_s;
-        if (idx_t == 0) ref_s[idx_s] = ref_tex(ref, n_ref, ref_step, s);
+        if (idx_t == 0) ref_s[idx_s] = ref_tex(ref, n_ref, ref_step, s, rule);
         if (idx_t >= 1) {
             const float t = p.dt_start + (float)(idx_t - 1) * p.dt;
             float* out = profile + ((size_t)idx_t * p.s_steps + idx_s) * ep.l_steps;
@@ -270,11 +291,11 @@ __global__ void k_ll_prelude(float4* __restrict__ ref_s, float* __restrict__ pro
                 // distances of the map
                 const float t_idx = env_t_idx(ep, t);
                 const float sc = (s - ep.s_min) / (ep.s_max - ep.s_min) * (float)(ep.s_steps - 1);
-                const Tap tt = make_tap(t_idx + 0.5f, ep.t_steps);
-                const Tap ts = make_tap(sc + 0.5f, ep.s_steps);
+                const Tap tt = make_tap(t_idx + 0.5f, ep.t_steps, rule);
+                const Tap ts = make_tap(sc + 0.5f, ep.s_steps, rule);
                 auto at = [&](int is, int it) { return dist_lon[(((size_t)il * ep.s_steps + is) * ep.t_steps + it) * 2]; };
-                out[il] = lerp1(lerp1(at(ts.i0, tt.i0), at(ts.i1, tt.i0), ts.w),
-                                lerp1(at(ts.i0, tt.i1), at(ts.i1, tt.i1), ts.w), tt.w);
+                const float t4[4] = {at(ts.i0, tt.i0), at(ts.i0, tt.i1), at(ts.i1, tt.i0), at(ts.i1, tt.i1)};     // x = t, y = s
+                out[il] = blend4_xy(t4, tt.w, ts.w, rule);
             }
         }
     }
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(LL_FWD_THREADS)
 void k_ll_forward(TplLatLonState* __restrict__ traj, const float4* __restrict__ tables, size_t table_cells,
                   const float4* __restrict__ ref, int n_ref, float ref_step,
                   const float* __restrict__ dist_lon, TplLatLonParams p, TplDpEnvParams ep,
-                  float step_s, float step_ds, float step_l)
+                  float step_s, float step_ds, float step_l, FilterRule rule)
 {
     constexpr int NDDS = 21, NDL = 21, NW = LL_FWD_THREADS / 64;
     __shared__ float sh_dfwd[NDL];
@@ -407,9 +428,9 @@ void k_ll_forward(TplLatLonState* __restrict__ traj, const float4* __restrict__ 
     TplLatLonState tp = traj[0];
     for (int idx_t = 0; idx_t < p.t_steps; ++idx_t) {
         const float dt = (idx_t == 0) ? p.dt_start : p.dt;
-        const float4 rp = ref_tex(ref, n_ref, ref_step, tp.s);
+        const float4 rp = ref_tex(ref, n_ref, ref_step, tp.s, rule);
         DistSrc src;
-        src.profile = nullptr; src.dist_lon = dist_lon; src.t = tp.t; src.s = tp.s;
+        src.profile = nullptr; src.dist_lon = dist_lon; src.t = tp.t; src.s = tp.s; src.rule = rule;
         const Eval st = eval_state<true>(p, ep, src, tp, dt, rp);  // every thread, same result
         tp.cost = st.cost; tp.constr = st.constr; tp.flags_constr = (uint8_t)st.flags;
         if (idx_t < p.t_steps - 1) {
@@ -434,7 +455,7 @@ void k_ll_forward(TplLatLonState* __restrict__ traj, const float4* __restrict__ 
                 const float d_safety = d_fwd - p.gap_min - tp.ds * p.time_gap;
                 const float dds = action_dds(p, dds_idx, NDDS);
                 const TplLatLonState tn = ll_dynamics(tp, dds, dl, dt);
-                const float4 nn = lerp_node(next, p, tn.s, tn.ds, tn.l, step_s, step_ds, step_l);
+                const float4 nn = lerp_node(next, p, tn.s, tn.ds, tn.l, step_s, step_ds, step_l, rule);
                 const Eval ev = eval_action(p, tp, dt, d_fwd, d_safety, dds, dl, tn.s, tn.l, nn.z, nn.w);
                 const float c = ev.cost + nn.x, g = ev.constr + nn.y;
                 if (eval_less(c, g, best_c, best_g)) {
@@ -493,15 +514,15 @@ void k_ll_forward(TplLatLonState* __restrict__ traj, const float4* __restrict__ 
 // reevalTraj, lat_lon_planner.cu:357-404: one thread per node (a node only writes itself)
 __global__ void k_ll_reeval(TplLatLonState* __restrict__ out, const TplLatLonState* __restrict__ in, int len,
                             const float4* __restrict__ ref, int n_ref, float ref_step,
-                            const float* __restrict__ dist_lon, TplLatLonParams p, TplDpEnvParams ep)
+                            const float* __restrict__ dist_lon, TplLatLonParams p, TplDpEnvParams ep, FilterRule rule)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= len) return;
     TplLatLonState tp = in[idx];
     const float dt = (idx == len - 1) ? 0.0f : in[idx + 1].t - tp.t;
-    const float4 rp = ref_tex(ref, n_ref, ref_step, tp.s);
+    const float4 rp = ref_tex(ref, n_ref, ref_step, tp.s, rule);
     DistSrc src;
-    src.profile = nullptr; src.dist_lon = dist_lon; src.t = tp.t; src.s = tp.s;
+    src.profile = nullptr; src.dist_lon = dist_lon; src.t = tp.t; src.s = tp.s; src.rule = rule;
     const Eval st = eval_state(p, ep, src, tp, dt, rp);
     tp.cost = st.cost; tp.constr = st.constr; tp.flags_constr = (uint8_t)st.flags;
     const float l_next = tp.l + dt * tp.dl;
@@ -648,6 +669,7 @@ struct tplhip_lat_lon {
     size_t traj_cap = 0;
     float4* d_q = nullptr;
     bool tables_valid = false;
+    FilterRule rule = kDefaultRule;     // the texture filter's rules (tplhip_lat_lon_set_filter_rule)
 };
 
 namespace {
@@ -860,7 +882,7 @@ int tplhip_lat_lon_update_traj_dp(tplhip_lat_lon* h, tplhip_dp_env* env, TplLatL
     HIP_TRY(hipMemcpyAsync(h->d_traj, states, sizeof(TplLatLonState) * (size_t)p.t_steps, hipMemcpyHostToDevice, h->stream),
             "copying trajectory to gpu failed");
     hipLaunchKernelGGL(k_ll_prelude, dim3(p.t_steps), dim3(256), 0, h->stream,
-                       h->d_ref_s, h->d_profile, h->d_ref, n_ref, env->ref_step, env->d_dist_lon, p, ep, ss);
+                       h->d_ref_s, h->d_profile, h->d_ref, n_ref, env->ref_step, env->d_dist_lon, p, ep, ss, h->rule);
     const int threads = 256;                                             // k_ll_backward's launch bound
     const int row_blocks = (p.s_steps * p.ds_steps + threads - 1) / threads;
     for (int i = p.t_steps - 1; i > 0; --i) {
@@ -871,12 +893,25 @@ int tplhip_lat_lon_update_traj_dp(tplhip_lat_lon* h, tplhip_dp_env* env, TplLatL
     }
     hipLaunchKernelGGL(k_ll_forward, dim3(1), dim3(LL_FWD_THREADS), 0, h->stream,
                        h->d_traj, h->d_tables, h->table_cells, h->d_ref, n_ref, env->ref_step, env->d_dist_lon,
-                       p, ep, ss, sd, sl);
+                       p, ep, ss, sd, sl, h->rule);
     HIP_TRY(hipGetLastError(), "lon planner backward pass failed");
     HIP_TRY(hipMemcpyAsync(states, h->d_traj, sizeof(TplLatLonState) * (size_t)p.t_steps, hipMemcpyDeviceToHost, h->stream),
             "copying trajectory to host failed");
     HIP_TRY(hipStreamSynchronize(h->stream), "lon planner forward pass failed");
     h->tables_valid = true;
+    return TPLHIP_OK;
+}
+
+// The texture filter's rules (R2 weight rule, R3 blend form and order: FilterRule, dp_lon_math.h) for every filtered fetch of this
+// planner -- the forward pass' value-table fetch, the distance-map and reference-line look-ups of the prelude, the rollout and
+// the re-evaluation.  oracle/lat_lon_oracle.c built -DLLO_WEIGHT_QUANT / -DLLO_LERP_FORM / -DLLO_BLEND_ORDER is the same choice.
+int tplhip_lat_lon_set_filter_rule(tplhip_lat_lon* h, int weight_quant, int lerp_form, int blend_order)
+{
+    if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
+    if (weight_quant < 0 || weight_quant > 2 || lerp_form < 0 || lerp_form > 2 || blend_order < 0 || blend_order > 3)
+        return tplhip_fail(TPLHIP_EINVAL, "filter rule: weight_quant in {0 none, 1 rint, 2 floor}, lerp_form in {0, 1, 2}, blend_order in {0, 1, 2, 3}");
+    h->rule = FilterRule{weight_quant, lerp_form, 0, blend_order};
+    h->tables_valid = false;
     return TPLHIP_OK;
 }
 
@@ -973,7 +1008,7 @@ int tplhip_lat_lon_reeval_traj(tplhip_lat_lon* h, tplhip_dp_env* env, const TplL
             "copying reeval trajectory to gpu failed");
     hipLaunchKernelGGL(k_ll_reeval, dim3((n + 63) / 64), dim3(64), 0, h->stream,
                        h->d_traj, h->d_traj2, n, h->d_ref, (int)env->ref_line.size(), env->ref_step,
-                       env->d_dist_lon, h->params, env->params);
+                       env->d_dist_lon, h->params, env->params, h->rule);
     HIP_TRY(hipGetLastError(), "reeval trajectory failed");
     HIP_TRY(hipMemcpyAsync(out, h->d_traj, sizeof(TplLatLonState) * (size_t)n, hipMemcpyDeviceToHost, h->stream),
             "copying reeval trajectory to cpu failed");

@@ -243,6 +243,11 @@ class DynProgLatLonPlanner:
             self.traj_smooth.states = self.traj_smooth.states[:1]
             self.traj_smooth_cart.states = self.traj_smooth_cart.states[:1]
 
+    def set_filter_rule(self, weight_quant=1, lerp_form=0, blend_order=0):
+        """The texture filter's rules for this planner's filtered fetches (value tables in the forward pass, distance map,
+        reference line); ``(1, 0, 0)`` is the default.  See ``tplhip_lat_lon_set_filter_rule`` in include/tplhip.h."""
+        check(self._lib.tplhip_lat_lon_set_filter_rule(self._h, int(weight_quant), int(lerp_form), int(blend_order)))
+
     def update_traj_dp(self, env):
         T = self.params.t_steps
         cur = self.traj_dp._as_array()
