@@ -35,11 +35,23 @@ CASES = [
     pytest.param(96, 16, 10, 5, 4, 4, True, id="B4-own-path-per-scenario"),
     pytest.param(96, 17, 10, 5, 3, 3, "step0.3", id="B3-path-step-0.3"),      # a divisor without a proven two-float form: Newton form or IEEE
     pytest.param(96, 17, 10, 5, 3, 3, "general", id="B3-general-sweep"),       # TPLHIP_DEBUG=no_v3: the batched form of k_backward
+    # rule R3 under another blend order: the batched form of k_backward3o (and of the general sweep's eight-tap path)
+    pytest.param(128, 32, 12, 5, 3, 3, "order1", id="B3-blend-order-s-v-a"),
+    pytest.param(96, 17, 10, 5, 4, 2, "order2", id="B4-eight-corner-sum-in-chunks"),
+    pytest.param(96, 17, 10, 5, 3, 3, "order3-general", id="B3-wide-sum-general-sweep"),
 ]
 
 
+@pytest.fixture
+def request_cleanup():
+    todo = []
+    yield todo
+    for f in todo:
+        f()
+
+
 @pytest.mark.parametrize("S,V,A,T,n,chunk,own_paths", CASES)
-def test_batched_scenarios_bit_exact(S, V, A, T, n, chunk, own_paths, monkeypatch):
+def test_batched_scenarios_bit_exact(S, V, A, T, n, chunk, own_paths, monkeypatch, request_cleanup):
     p = sc.lon_params(S, V, A, T)
     want_kernel = "k_backward3v"
     if own_paths == "step0.3":
@@ -47,6 +59,21 @@ def test_batched_scenarios_bit_exact(S, V, A, T, n, chunk, own_paths, monkeypatc
     elif own_paths == "general":
         monkeypatch.setenv("TPLHIP_DEBUG", "no_v3")
         own_paths, want_kernel = False, "k_backward"
+    order = 0
+    if isinstance(own_paths, str) and own_paths.startswith("order"):
+        order = int(own_paths[5])
+        want_kernel = "k_backward3o"
+        if own_paths.endswith("general"):
+            monkeypatch.setenv("TPLHIP_DEBUG", "no_v3")
+            want_kernel = "k_backward"
+        own_paths = False
+        import os
+        import subprocess
+        lib = os.path.join(O.ROOT, "oracle", f"_sens/libdp_lon_oracle_r100o{order}.so")
+        if not os.path.exists(lib):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(O.ROOT, "oracle"), f"_sens/libdp_lon_oracle_r100o{order}.so"])
+        O.use(lib)
+        request_cleanup.append(lambda: O.use(None))
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
     occs, inits = _scenarios(n, ep, seed=S + n)
     if own_paths:
@@ -57,6 +84,8 @@ def test_batched_scenarios_bit_exact(S, V, A, T, n, chunk, own_paths, monkeypatc
         paths = sc.straight_path(p.path_steps, p.path_step_size)[None]
     dp = tpl_amd.DynProgLonPlanner()
     dp.reinit_buffers(p)
+    if order:
+        dp.set_blend_order(order)
     dp.upload_scenarios(occs, ep, inits, paths, chunk=chunk)
     assert dp.info()["scenario_kernel"] == want_kernel, dp.info()
     cp, cep = O.cparams(p), O.cparams(ep)
