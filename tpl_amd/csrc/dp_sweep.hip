@@ -570,7 +570,6 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         }
     };
     ActScalars cur = fetch_scalars(0);
-    issue(cur, A0_ROWS);
     const int bd = (int)blockDim.x;
     auto dsc_word = [&](int i) { return reinterpret_cast<const float*>(d0 + (i / (N_BWD * 8)) * rs + ((i >> 3) % N_BWD))[i & 7]; };
     float dsc_v = 0.0f, pv_v = 0.0f;
@@ -633,7 +632,9 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         const bool shared = (shared_mask >> k) & 1u;
         Node3 q00 = {0.0f, 0.0f, 0.0f}, q10 = {0.0f, 0.0f, 0.0f};
         __builtin_amdgcn_s_setprio(1);
-        issue(cur, A1_ROWS);
+        // (all six rows here: requesting the a0 rows a phase ahead, as k_backward3v does, costs nine registers across phase 2 and
+        // buys nothing in a kernel bound by LDS and VALU throughput -- 63.2 / 64.8 / 77.5 us with, 62.9 / 64.8 / 73.8 without)
+        issue(cur, A0_ROWS | A1_ROWS);
         if (!shared) { q00 = load_row(d0[rs + k].r00); q10 = load_row(d0[rs + k].r10); }
         if (k > 0) asm volatile("s_barrier" ::: "memory");      // everyone is done reading the row block of action k-1
         park_row(slot, 0, lo[0]); park_row(slot, 1, lo[1]);
@@ -689,11 +690,6 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                 nch[ch] = fetch8<ORDER, LERP & 3>(tl, th, ws, iws, w);
             }
             const float nc = nch[0], ng = nch[1], nj = nch[2];
-            if (i == 0 && k + 1 < N_BWD) {
-                __builtin_amdgcn_sched_barrier(0);
-                issue(cur, A0_ROWS);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             const float f0 = fminf(floorf(alpha), path_top);
             const float pa = alpha - f0;
             const float pia = 1.0f - pa;
