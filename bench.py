@@ -532,7 +532,7 @@ def traffic_block(roofline, key):
                 roofline["prescribed_bound"] = "hbm"
                 roofline["binding"] = (f"not HBM: VALU issue {tr['valu_issue']:.2f} and the texture-address path {tr.get('texture_addr', 0.0):.2f} of the "
                                        f"kernel's cycles (PMC instruction counts x measured per-instruction costs, model in profiles/{f}); neither "
-                                       "binds alone -- the rest is the latency of one row round trip per action at eight waves per SIMD (DESIGN 2.2b')")
+                                       "binds alone -- the rest is the latency of one row round trip per action at eight waves per SIMD (docs/NOTEBOOK.md 2.2b')")
             return
 
 

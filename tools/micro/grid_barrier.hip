@@ -1,6 +1,6 @@
 // What does a stage boundary cost on gfx950 -- a kernel boundary against a grid-wide barrier inside ONE launch?
 // The small-grid DP plan (201x37x20 x 10 stages) is nine dependent sweeps of ~10 us, each as long as one workgroup's
-// chain; this probe runs the SHAPE of such a plan -- 740 workgroups of 256 lanes, every stage reads
+// chain (docs/NOTEBOOK.md 2.2d); this probe runs the SHAPE of such a plan -- 740 workgroups of 256 lanes, every stage reads
 // four 12-byte rows that OTHER workgroups (other XCDs) wrote in the stage before, a little arithmetic, one 12-byte
 // store per lane -- in four forms and checks the result of each against the host:
 //   0  one launch per stage                                     (what the planner does today)
