@@ -4,7 +4,11 @@
 length) -> occupancy image, Frenet occupancy and distance map bit for bit; the lateral lattice (values 1e-5, discrete
 outcomes identical, the final trajectory to 1e-12); the (s,ds,l) tables and trajectory bit for bit.
 
-    python tests/fuzz_engines.py [scenes] [first seed]"""
+    python tests/fuzz_engines.py [scenes] [first seed] [--rules]
+
+--rules: the (s,ds,l) planner of every scene also draws one of the 36 texture-filter rules (weight rule x blend form x blend
+order / eight-corner sums: DynProgLatLonPlanner.set_filter_rule) and is compared with the build of oracle/lat_lon_oracle.c that
+makes the same choice."""
 import os
 import sys
 
@@ -20,7 +24,7 @@ import tpl_amd                                  # noqa: E402
 from benchkit import scenarios as sc             # noqa: E402
 
 
-def run_scene(seed):
+def run_scene(seed, rules=False):
     rng = np.random.default_rng(5000 + seed)
     T = int(rng.integers(3, 12))
     dt = float(rng.choice([0.5, 1.0, 0.8]))
@@ -88,9 +92,18 @@ def run_scene(seed):
     st.s, st.ds, st.l = float(rng.uniform(0, 30)), float(rng.uniform(0, 14)), float(rng.uniform(-1.5, 1.5))
     ll = tpl_amd.DynProgLatLonPlanner()
     ll.reinit_buffers(qp)
+    rule = None
+    if rules:
+        rule = (int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 4)))
+        ll.set_filter_rule(*rule)
+        oll.use(oll.variant(*rule))
     ll.traj_dp[0] = st
     ll.update_traj_dp(env)
-    tables, otraj = oll.update_traj_dp(qp, o.c, dl, o.ref, o.step, st)
+    try:
+        tables, otraj = oll.update_traj_dp(qp, o.c, dl, o.ref, o.step, st)
+    finally:
+        if rules:
+            oll.use(None)
     for t in range(1, qp.t_steps):
         g = ll.copy_backward_pass_tex(t)
         assert np.array_equal(g.view(np.uint32), tables[t].view(np.uint32)), f"seed {seed}: (s,ds,l) stage {t}"
@@ -99,15 +112,17 @@ def run_scene(seed):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    rules = "--rules" in sys.argv
+    n = int(args[0]) if len(args) > 0 else 100
+    first = int(args[1]) if len(args) > 1 else 0
     cells = objs = 0
     for seed in range(first, first + n):
-        c, k = run_scene(seed)
+        c, k = run_scene(seed, rules)
         cells += c
         objs += k
     print(f"{n} random scenes ({objs} objects, {cells} occupied Frenet cells): occupancy pipeline and (s,ds,l) planner "
-          "bit-identical, lateral lattice within 1e-5 with identical discrete outcomes")
+          f"{'(under random texture-filter rules) ' if rules else ''}bit-identical, lateral lattice within 1e-5 with identical discrete outcomes")
 
 
 if __name__ == "__main__":
