@@ -453,7 +453,9 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 //   * LDS row block: one slot of 19 floats per station = 6 rows x (cost, constr, jerk) + one float of padding (an odd
 //     stride in dwords: conflict-free for the shifted reads) -- rows B0 (a0,v0) B1 (a1,v0) B2 (a0,v1) B3 (a1,v1) B4 (a0,v2)
 //     B5 (a1,v2); cell 0 blends B0..B3, cell 1 B2..B5 (the pair shares its middle v' row, see k_backward3v).  Both taps of a
-//     channel of a row are ONE ds_read2_b32 (offsets c and 19 + c): 12 LDS reads per cell-action against two.
+//     channel of a row are ONE ds_read2_b32 (offsets c and 19 + c): 12 LDS reads per cell-action against two.  (A channel-major
+//     slot of 28 floats -- the four rows of a cell as one 16-byte read per channel and tap, six reads instead of twelve for the
+//     same bytes -- measured 78.9 / 79.3 / 84.6 us against 63.5 / 65.2 / 73.9: the wide reads of neighbouring lanes collide.)
 //   * Where the descriptors of the two rows do NOT share (rounding of the successor velocity near a grid row, the clamped
 //     edges), cell 1's own lower rows are parked over B2, B3 between the two cells (a workgroup is one row pair, so the
 //     case is uniform: two more barriers for that action).
