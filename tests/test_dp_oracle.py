@@ -378,3 +378,115 @@ def test_explicit_contraction_of_lon_dynamics_and_interp_path_is_the_documented_
                     assert F(float(got)) == want, (fma, d, col)
         finally:
             O.use(None)
+
+
+@pytest.mark.parametrize("name,order", [(None, 0), ("order_sva", 1), ("sum8_f32", 2), ("sum8_wide", 3)])
+def test_read_node_blend_orders_are_the_documented_ones(name, order):
+    """readNode (lon_planner.cu:26-38 through the software filter of rules R2 / R3) of the default build and of the three
+    blend-order builds (-DDPO_BLEND_ORDER=1 | 2 | 3) against the rule written in the header of oracle/dp_lon_oracle.c,
+    evaluated in exact rationals with one rounding per operation: three sequential blends fma(q, w, p (1 - w)) along
+    a, v, s (default) or s, v, a (order 1); the eight-corner sum with weights (w_s w_v) w_a, corner index s + 2 v + 4 a,
+    products and sums rounded in fp32 in that order (order 2) or exact products in a double accumulator and one final
+    rounding (order 3).  Pins the corner indexing and the operation order of every variant independently of the C."""
+    from fractions import Fraction as F
+    p, _ = _small()
+    rng = np.random.default_rng(21 + order)
+    table = rng.uniform(0, 10, size=(p.a_steps, p.v_steps, p.s_steps, 4)).astype(np.float32)
+    out = np.zeros(4, dtype=np.float32)
+
+    def tap(x, x_min, x_max, n):
+        t1 = _f32(F(float(x)) - F(float(x_min)))
+        t2 = _f32(F(float(x_max)) - F(float(x_min)))
+        c = _f32(_f32(t1 / t2) * (n - 1))
+        xb = _f32(_f32(c + F(1, 2)) - F(1, 2))
+        fl = xb.numerator // xb.denominator
+        alpha = xb - fl
+        q = alpha * 256
+        r = q.numerator // q.denominator                      # rint: to nearest, ties to even
+        rem = q - r
+        if rem > F(1, 2) or (rem == F(1, 2) and r % 2 == 1):
+            r += 1
+        return min(n - 1, max(0, fl)), min(n - 1, max(0, fl + 1)), F(r, 256)
+
+    def lerp(pv, qv, w):
+        return _f32(qv * w + _f32(pv * _f32(1 - w)))            # fmaf(q, w, p * (1 - w))
+
+    O.use(_sens_lib(name) if name else None)
+    try:
+        for _ in range(300):
+            s = np.float32(rng.uniform(p.s_min, p.s_max))
+            v = np.float32(rng.uniform(p.v_min, p.v_max))
+            a = np.float32(rng.uniform(p.a_min, p.a_max))
+            O.lib().dpo_read_node(C.byref(p), O.fptr(table), s, v, a, O.fptr(out))
+            s0, s1, ws = tap(s, p.s_min, p.s_max, p.s_steps)
+            v0, v1, wv = tap(v, p.v_min, p.v_max, p.v_steps)
+            a0, a1, wa = tap(a, p.a_min, p.a_max, p.a_steps)
+            for ch in range(3):
+                T = lambda ia, iv, i_s: F(float(table[ia, iv, i_s, ch]))
+                if order == 0:
+                    lo = lerp(lerp(T(a0, v0, s0), T(a1, v0, s0), wa), lerp(T(a0, v1, s0), T(a1, v1, s0), wa), wv)
+                    hi = lerp(lerp(T(a0, v0, s1), T(a1, v0, s1), wa), lerp(T(a0, v1, s1), T(a1, v1, s1), wa), wv)
+                    want = lerp(lo, hi, ws)
+                elif order == 1:
+                    y0 = lerp(lerp(T(a0, v0, s0), T(a0, v0, s1), ws), lerp(T(a0, v1, s0), T(a0, v1, s1), ws), wv)
+                    y1 = lerp(lerp(T(a1, v0, s0), T(a1, v0, s1), ws), lerp(T(a1, v1, s0), T(a1, v1, s1), ws), wv)
+                    want = lerp(y0, y1, wa)
+                else:
+                    s2, v2, a2 = (_f32(1 - ws), ws), (_f32(1 - wv), wv), (_f32(1 - wa), wa)
+                    corners = [(i_s, iv, ia) for ia in (0, 1) for iv in (0, 1) for i_s in (0, 1)]       # index s + 2 v + 4 a
+                    w = [_f32(_f32(s2[i_s] * v2[iv]) * a2[ia]) for i_s, iv, ia in corners]
+                    t = [T((a0, a1)[ia], (v0, v1)[iv], (s0, s1)[i_s]) for i_s, iv, ia in corners]
+                    if order == 2:
+                        acc = _f32(w[0] * t[0])
+                        for c in range(1, 8):
+                            acc = _f32(acc + _f32(w[c] * t[c]))
+                        want = acc
+                    else:
+                        acc = _f64(w[0] * t[0])
+                        for c in range(1, 8):
+                            acc = _f64(acc + _f64(w[c] * t[c]))
+                        want = _f32(acc)
+                assert F(float(out[ch])) == want, (order, ch, float(s), float(v), float(a), float(out[ch]), float(want))
+    finally:
+        O.use(None)
+
+
+@pytest.mark.parametrize("name,order", [(None, 0), ("order_sva", 1), ("sum8_f32", 2), ("sum8_wide", 3)])
+def test_dist_map_lookup_under_the_blend_orders(name, order):
+    """interpDistMapPath (env.cu:254-264: x = t, y = s, z = 0) at the integral t index the planner asks for: every sequential
+    order gives the blend along s alone (a weight of exactly 0 leaves p for finite q), the sums the two non-zero corner terms
+    (1 - w) p + w q, rounded per product and sum in fp32 (order 2) or once (order 3)."""
+    from fractions import Fraction as F
+    p, ep = _small()
+    rng = np.random.default_rng(5)
+    dist = rng.uniform(0.0, 120.0, size=(ep.t_steps, ep.s_steps)).astype(np.float32)
+    O.use(_sens_lib(name) if name else None)
+    try:
+        lib = O.lib()
+        for _ in range(300):
+            it = int(rng.integers(0, ep.t_steps))
+            t = np.float32(0.0) if it == 0 else np.float32(ep.dt_start + (it - 1) * ep.dt)
+            s = np.float32(rng.uniform(ep.s_min, ep.s_max))
+            got = lib.dpo_interp_dist_map_path(C.byref(ep), O.fptr(dist), t, s)
+            t1 = _f32(F(float(s)) - F(float(ep.s_min)))
+            t2 = _f32(F(float(ep.s_max)) - F(float(ep.s_min)))
+            c = _f32(_f32(t1 / t2) * (ep.s_steps - 1))
+            xb = _f32(_f32(c + F(1, 2)) - F(1, 2))
+            fl = xb.numerator // xb.denominator
+            q = (xb - fl) * 256
+            r = q.numerator // q.denominator
+            rem = q - r
+            if rem > F(1, 2) or (rem == F(1, 2) and r % 2 == 1):
+                r += 1
+            w = F(r, 256)
+            i0, i1 = min(ep.s_steps - 1, max(0, fl)), min(ep.s_steps - 1, max(0, fl + 1))
+            pv, qv = F(float(dist[it, i0])), F(float(dist[it, i1]))
+            if order <= 1:
+                want = _f32(qv * w + _f32(pv * _f32(1 - w)))
+            elif order == 2:
+                want = _f32(_f32(_f32(1 - w) * pv) + _f32(w * qv))        # (the two zero-weight corners add +0)
+            else:
+                want = _f32(_f64(_f64(_f32(1 - w) * pv) + _f64(w * qv)))
+            assert F(float(got)) == want, (order, it, float(s), got, float(want))
+    finally:
+        O.use(None)
