@@ -1,11 +1,13 @@
 #!/bin/bash
 # PMC passes for the DP sweep kernel (separate --pmc runs, no tracing domains).
-# usage (on the GPU box, from the repo root): bash tools/pmc_dp.sh <outdir> [grid | mc]
+# usage (on the GPU box, from the repo root): bash tools/pmc_dp.sh <outdir> [grid | mc] [blend order]
 #   grid: target / config2 / config4 / default (tools/dp_only.py);  mc: the Monte-Carlo scenario workload (tools/mc_only.py)
+#   blend order 1 | 2 | 3: the plan runs k_backward3o (set_blend_order)
 set -u
 OUT=${1:-gpurun_out/pmc}
 GRID=${2:-target}
-if [ "$GRID" = mc ]; then DRIVER="tools/mc_only.py"; DARGS="128"; else DRIVER="tools/dp_only.py"; DARGS="$GRID 1"; fi
+ORDER=${3:-0}
+if [ "$GRID" = mc ]; then DRIVER="tools/mc_only.py"; DARGS="128"; else DRIVER="tools/dp_only.py"; DARGS="$GRID 1 $ORDER"; fi
 REPO=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
