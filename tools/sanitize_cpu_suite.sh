@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd "$REPO/tpl_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-gpu-sanitize \
     -fno-omit-frame-pointer -ffp-contract=off -fno-fast-math -fvisibility=hidden -fno-slp-vectorize -I"$REPO/include" \
-    -o "$OUT/libtplhip_san.so" common.hip dp_lon.hip dp_sweep.hip dp_env.hip poly_lat.hip lat_lon.hip planning.hip \
+    -o "$OUT/libtplhip_san.so" $(sed -n 's/^SRCS := //p' Makefile) \
     > "$OUT/build.log" 2>&1 || { echo "sanitized build failed, see $OUT/build.log"; exit 1; }
 cd "$REPO"
 cp tpl_amd/libtplhip.so "$OUT/libtplhip_shipped.so"
