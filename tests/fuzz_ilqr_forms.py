@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised bit-identity soak of the three launch forms of the batched iLQR update() (single launch / split sequence /
-fused launch, TPLHIP_DEBUG=ilqr_split=0|1|2): every problem of the goldens as a ragged batch -- per-problem start states,
+"""Randomised bit-identity soak of the launch forms of the batched iLQR update() (single launch / split sequence /
+fused launch / the fused phases at one wavefront per SIMD, TPLHIP_DEBUG=ilqr_split=0|1|2|3): every problem of the goldens as a ragged batch -- per-problem start states,
 horizons and iteration budgets, a random integrator (EULER / HEUN / RK4: template parameters of the chain phase), second- or
 first-order method, one or two multiplier rounds, two updates with a shift in between.  Every field and scalar must agree
 bit for bit between the forms; the oracle is not involved (tests/fuzz_ilqr.py compares the solver with it).
@@ -63,7 +63,7 @@ def main():
     for model, golden in problems:
         for s in range(n):
             ref, what = run(model, golden, 1000 * s + 7, 0)
-            for form in (1, 2):
+            for form in (1, 2, 3):
                 got, _ = run(model, golden, 1000 * s + 7, form)
                 for step, (a, b) in enumerate(zip(ref, got)):
                     for f in FIELDS:
@@ -71,9 +71,9 @@ def main():
                             bad.append((model, golden, s, FORMS[form], step, f))
             seen.add((model,) + what[1:])
             total += 1
-    print(f"{total} ragged batches x 3 forms x 2 updates over {len({p[0] for p in problems})} models; "
+    print(f"{total} ragged batches x 4 forms x 2 updates over {len({p[0] for p in problems})} models; "
           f"(model, integrator, second order) combinations drawn: {len(seen)}")
-    print(f"{len(bad)} field mismatches between the forms" + (":" if bad else " -- all three forms bit-identical"))
+    print(f"{len(bad)} field mismatches between the forms" + (":" if bad else " -- all four forms bit-identical"))
     for row in bad[:40]:
         print("   ", row)
     return 1 if bad else 0
