@@ -730,6 +730,41 @@ def test_blend_order_variants_match_their_oracle_builds(name, order, quant, lerp
         dp.set_blend_order(4)
 
 
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("S,V,A,T,dt_start", [(128, 64, 64, 3, None), (96, 10, 64, 4, 0.4), (201, 37, 20, 4, None)])
+def test_blend_order_with_trivial_a_blends(S, V, A, T, dt_start, order):
+    """k_backward3o requests and parks only the a0 rows of an action whose blend along a is trivial (ACT_SINGLE_A: both a-rows
+    clamped to the same row, or a weight of exactly 0) and reads half the taps.  64 acceleration rows put the jerk grid on the
+    acceleration grid (weight exactly 0 for three of the nine actions) next to the clamped ones; 20 rows have the clamped kind
+    only.  Full tables and rollouts against the oracle build of the order, raw bits."""
+    import os
+    import subprocess
+    lib = os.path.join(O.ROOT, "oracle", f"_sens/libdp_lon_oracle_r100o{order}.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(O.ROOT, "oracle"), f"_sens/libdp_lon_oracle_r100o{order}.so"])
+    p = sc.lon_params(S, V, A, T, dt_start=dt_start)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31, dt_start=dt_start)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.random_obstacles(6, 9))
+    inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(3, seed=7)
+    env = tpl_amd.DynProgEnvironment()
+    env.reinit_buffers(ep)
+    env.set_occ_map(occ)
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p)
+    dp.set_blend_order(order)
+    trajs = dp.update_batch(inits, path, env)
+    assert dp.info()["sweep"] == "k_backward3o", dp.info()
+    O.use(lib)
+    try:
+        tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, inits)
+    finally:
+        O.use(None)
+    _assert_tables_equal(dp, tables, T)
+    for r, tr in enumerate(trajs):
+        assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), r
+
+
 @pytest.mark.parametrize("dt_start", [None, 0.3, 0.6])
 def test_forward_rollout_forms_agree(dt_start, monkeypatch):
     """The rollout runs with one step of speculation (eight wavefronts) where the table set fits the Infinity Cache and

@@ -459,7 +459,10 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 //   * Where the descriptors of the two rows do NOT share (rounding of the successor velocity near a grid row, the clamped
 //     edges), cell 1's own lower rows are parked over B2, B3 between the two cells (a workgroup is one row pair, so the
 //     case is uniform: two more barriers for that action).
-//   * ACT_SINGLE_A is not used: both a-rows are always requested (the same row twice where clamped).
+//   * ACT_SINGLE_A (the blend along a is trivial: twin a-rows, or a weight of exactly 0): the three a0 rows only are requested
+//     and parked, and a cell reads four taps per channel pair (fetch8_single) -- exact, see there; 63.2 -> 59.9 us (order 1).
+//   * Six wavefronts per SIMD for the sequential order (80 registers without a spill: 59.9 -> 55.2 us); the sums need 83-90
+//     registers and stay at five.
 // Built for the weight rules rint and floor (an un-quantised weight makes the corner products inexact and takes the general
 // sweep), both contraction settings, and for order 1 all three blend forms.  Price: DESIGN.md 0.
 // ------------------------------------------------------------------------
@@ -491,8 +494,26 @@ __device__ __forceinline__ float fetch8(const float (&lo)[4], const float (&hi)[
     return (float)acc;
 }
 
+// The same for an action whose blend along a is trivial (ACT_SINGLE_A: both a-rows are the same row, or the weight along a is
+// exactly 0): lo / hi hold the a0 rows B0 (v0), B2 (v1) only.  With twin rows the a1 taps ARE the a0 taps; with weight 0 they
+// only meet the factor 0 (finite table values: the product is +0, the blend returns its other operand) -- so the a1 taps are
+// replaced by the a0 taps, and under order 1 the two s-blends and the v-blend of the a1 side are the a0 side's, bit for bit.
+template <int ORDER, int LERP>
+__device__ __forceinline__ float fetch8_single(const float (&lo)[2], const float (&hi)[2], float ws, float iws, const v4f& w)
+{
+    if (ORDER == 1) {
+        const float x00 = blend1<LERP>(lo[0], hi[0], ws, iws), x01 = blend1<LERP>(lo[1], hi[1], ws, iws);
+        const float y0 = blend1<LERP>(x00, x01, w.z, w.w);
+        return blend1<LERP>(y0, y0, w.x, w.y);
+    }
+    const float l4[4] = {lo[0], lo[0], lo[1], lo[1]}, h4[4] = {hi[0], hi[0], hi[1], hi[1]};
+    return fetch8<ORDER, LERP>(l4, h4, ws, iws, w);
+}
+
+// (six wavefronts per SIMD for the sequential order, whose kernels fit 80 registers without a spill: 59.9 -> 55.2 us per
+// 256x128x64 sweep; the sums need 83-90 registers -- held to 80 they spill 12-60 bytes and lose 1-13 % -- and stay at five)
 template <int PATH_DIV, int RANGE_DIV, int QUANT, int LERP, int ORDER>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ORDER == 1 ? 6 : 1)))
 k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, const ActDesc* __restrict__ acts,
               const float* __restrict__ path_all, const float* __restrict__ pre_vmax_all,
               const float* __restrict__ pre_sdist_all, const double* __restrict__ pre_prog, SweepArgs a)
@@ -549,10 +570,11 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         return Node3{x.x, x.y, x.z};
     };
     Node3 lo[2], up[NV][2];
-    struct ActScalars { int r00, r10, r01[NV], r11[NV]; double j_term[NV], tn_v_d[NV]; };
+    struct ActScalars { int r00, r10, r01[NV], r11[NV], single; double j_term[NV], tn_v_d[NV]; };
     auto fetch_scalars = [&](int k) {
         ActScalars x;
         x.r00 = d0[k].r00; x.r10 = d0[k].r10;
+        x.single = d0[k].flags & ACT_SINGLE_A;      // (a property of (a, k): the same for both rows of the pair)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const ActDesc& e = d0[i * rs + k];
@@ -636,17 +658,28 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         __builtin_amdgcn_s_setprio(1);
         // (all six rows here: requesting the a0 rows a phase ahead, as k_backward3v does, costs nine registers across phase 2 and
         // buys nothing in a kernel bound by LDS and VALU throughput -- 63.2 / 64.8 / 77.5 us with, 62.9 / 64.8 / 73.8 without)
-        issue(cur, A0_ROWS | A1_ROWS);
-        if (!shared) { q00 = load_row(d0[rs + k].r00); q10 = load_row(d0[rs + k].r10); }
-        if (k > 0) asm volatile("s_barrier" ::: "memory");      // everyone is done reading the row block of action k-1
-        park_row(slot, 0, lo[0]); park_row(slot, 1, lo[1]);
-        park_row(slot, 2, up[0][0]); park_row(slot, 3, up[0][1]);
-        park_row(slot, 4, up[1][0]); park_row(slot, 5, up[1][1]);
-        if (dup_last) {                                          // the duplicate of the last station: one branch per action
-            float* d = slot + SLOT_DW;
-            park_row(d, 0, lo[0]); park_row(d, 1, lo[1]);
-            park_row(d, 2, up[0][0]); park_row(d, 3, up[0][1]);
-            park_row(d, 4, up[1][0]); park_row(d, 5, up[1][1]);
+        // An action whose blend along a is trivial (a third to a half of all (a, action) pairs, see ACT_SINGLE_A) requests and parks
+        // its three a0 rows only -- B0, B2, B4 -- and its cells read four taps per channel pair instead of eight (fetch8_single).
+        const bool single = cur.single != 0;
+        if (single) {
+            issue(cur, A0_ROWS);
+            if (!shared) q00 = load_row(d0[rs + k].r00);
+            if (k > 0) asm volatile("s_barrier" ::: "memory");  // everyone is done reading the row block of action k-1
+            park_row(slot, 0, lo[0]); park_row(slot, 2, up[0][0]); park_row(slot, 4, up[1][0]);
+            if (dup_last) { float* d = slot + SLOT_DW; park_row(d, 0, lo[0]); park_row(d, 2, up[0][0]); park_row(d, 4, up[1][0]); }
+        } else {
+            issue(cur, A0_ROWS | A1_ROWS);
+            if (!shared) { q00 = load_row(d0[rs + k].r00); q10 = load_row(d0[rs + k].r10); }
+            if (k > 0) asm volatile("s_barrier" ::: "memory");
+            park_row(slot, 0, lo[0]); park_row(slot, 1, lo[1]);
+            park_row(slot, 2, up[0][0]); park_row(slot, 3, up[0][1]);
+            park_row(slot, 4, up[1][0]); park_row(slot, 5, up[1][1]);
+            if (dup_last) {                                      // the duplicate of the last station: one branch per action
+                float* d = slot + SLOT_DW;
+                park_row(d, 0, lo[0]); park_row(d, 1, lo[1]);
+                park_row(d, 2, up[0][0]); park_row(d, 3, up[0][1]);
+                park_row(d, 4, up[1][0]); park_row(d, 5, up[1][1]);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_s_setprio(0);
@@ -663,8 +696,9 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             if (i == 1 && !shared) {
                 // cell 1 does not share cell 0's upper rows: its own lower rows take their place
                 asm volatile("s_barrier" ::: "memory");
-                park_row(slot, 2, q00); park_row(slot, 3, q10);
-                if (dup_last) { park_row(slot + SLOT_DW, 2, q00); park_row(slot + SLOT_DW, 3, q10); }
+                park_row(slot, 2, q00);
+                if (!single) park_row(slot, 3, q10);
+                if (dup_last) { park_row(slot + SLOT_DW, 2, q00); if (!single) park_row(slot + SLOT_DW, 3, q10); }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             const v4f w = dsc4[(i * N_BWD + k) * 2];
@@ -685,11 +719,20 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const int off = (int)(fminf(fl, s_scale) * (float)(SLOT_DW * 4));
             const float* T0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(R) + off) + i * 6;
             float nch[3];
+            if (single) {
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const float tl[4] = {T0[ch], T0[3 + ch], T0[6 + ch], T0[9 + ch]};
-                const float th[4] = {T0[SLOT_DW + ch], T0[SLOT_DW + 3 + ch], T0[SLOT_DW + 6 + ch], T0[SLOT_DW + 9 + ch]};
-                nch[ch] = fetch8<ORDER, LERP & 3>(tl, th, ws, iws, w);
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float tl[2] = {T0[ch], T0[6 + ch]};
+                    const float th[2] = {T0[SLOT_DW + ch], T0[SLOT_DW + 6 + ch]};
+                    nch[ch] = fetch8_single<ORDER, LERP & 3>(tl, th, ws, iws, w);
+                }
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float tl[4] = {T0[ch], T0[3 + ch], T0[6 + ch], T0[9 + ch]};
+                    const float th[4] = {T0[SLOT_DW + ch], T0[SLOT_DW + 3 + ch], T0[SLOT_DW + 6 + ch], T0[SLOT_DW + 9 + ch]};
+                    nch[ch] = fetch8<ORDER, LERP & 3>(tl, th, ws, iws, w);
+                }
             }
             const float nc = nch[0], ng = nch[1], nj = nch[2];
             const float f0 = fminf(floorf(alpha), path_top);
