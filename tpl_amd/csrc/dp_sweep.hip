@@ -506,6 +506,26 @@ __device__ __forceinline__ float fetch8_single(const float (&lo)[2], const float
         const float y0 = blend1<LERP>(x00, x01, w.z, w.w);
         return blend1<LERP>(y0, y0, w.x, w.y);
     }
+    // the sums: with a weight of exactly 0 along a (uniform for the action: a scalar test) the four a1 corners carry the weight
+    // (w_s w_v) * 0 = 0, their products are +-0 and leave the accumulator as it is, and the a0 corners' weight is (w_s w_v) * 1:
+    // four terms instead of eight, no product with w_a.  Twin rows with another weight keep all eight terms on the twin taps.
+    // (As with every ACT_SINGLE_A shortcut, the one thing that can differ is the SIGN of a result that is itself a zero -- a -0 sum
+    // of four -0 terms would have met +0 products -- and no consumer sees it: eval_action_tail adds the node to sums that start at
+    // +0.0f, and squares (node.z - j).)
+    if (__builtin_amdgcn_readfirstlane(__float_as_int(w.x)) == 0) {
+        const float wc[4] = {iws * w.w, ws * w.w, iws * w.z, ws * w.z};
+        const float tc[4] = {lo[0], hi[0], lo[1], hi[1]};
+        if (ORDER == 2) {
+            float acc = wc[0] * tc[0];
+#pragma unroll
+            for (int c = 1; c < 4; ++c) { const float pr = wc[c] * tc[c]; acc = acc + pr; }
+            return acc;
+        }
+        double acc = (double)wc[0] * (double)tc[0];
+#pragma unroll
+        for (int c = 1; c < 4; ++c) acc = fma((double)wc[c], (double)tc[c], acc);
+        return (float)acc;
+    }
     const float l4[4] = {lo[0], lo[0], lo[1], lo[1]}, h4[4] = {hi[0], hi[0], hi[1], hi[1]};
     return fetch8<ORDER, LERP>(l4, h4, ws, iws, w);
 }
