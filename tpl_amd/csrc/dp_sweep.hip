@@ -482,16 +482,11 @@ __device__ __forceinline__ float fetch8(const float (&lo)[4], const float (&hi)[
     const float sv00 = iws * w.w, sv10 = ws * w.w, sv01 = iws * w.z, sv11 = ws * w.z;
     const float wc[8] = {sv00 * w.y, sv10 * w.y, sv01 * w.y, sv11 * w.y, sv00 * w.x, sv10 * w.x, sv01 * w.x, sv11 * w.x};
     const float tc[8] = {lo[0], hi[0], lo[2], hi[2], lo[1], hi[1], lo[3], hi[3]};
-    if (ORDER == 2) {
-        float acc = wc[0] * tc[0];
+    static_assert(ORDER == 1 || ORDER == 2, "the wide sum (order 3) is formed corner by corner in k_backward3o itself");
+    float acc = wc[0] * tc[0];
 #pragma unroll
-        for (int c = 1; c < 8; ++c) { const float pr = wc[c] * tc[c]; acc = acc + pr; }
-        return acc;
-    }
-    double acc = (double)wc[0] * (double)tc[0];
-#pragma unroll
-    for (int c = 1; c < 8; ++c) acc = fma((double)wc[c], (double)tc[c], acc);      // (the product of two floats is exact in double: fma == multiply, then add)
-    return (float)acc;
+    for (int c = 1; c < 8; ++c) { const float pr = wc[c] * tc[c]; acc = acc + pr; }
+    return acc;
 }
 
 // The same for an action whose blend along a is trivial (ACT_SINGLE_A: both a-rows are the same row, or the weight along a is
@@ -515,23 +510,18 @@ __device__ __forceinline__ float fetch8_single(const float (&lo)[2], const float
     if (__builtin_amdgcn_readfirstlane(__float_as_int(w.x)) == 0) {
         const float wc[4] = {iws * w.w, ws * w.w, iws * w.z, ws * w.z};
         const float tc[4] = {lo[0], hi[0], lo[1], hi[1]};
-        if (ORDER == 2) {
-            float acc = wc[0] * tc[0];
+        float acc = wc[0] * tc[0];
 #pragma unroll
-            for (int c = 1; c < 4; ++c) { const float pr = wc[c] * tc[c]; acc = acc + pr; }
-            return acc;
-        }
-        double acc = (double)wc[0] * (double)tc[0];
-#pragma unroll
-        for (int c = 1; c < 4; ++c) acc = fma((double)wc[c], (double)tc[c], acc);
-        return (float)acc;
+        for (int c = 1; c < 4; ++c) { const float pr = wc[c] * tc[c]; acc = acc + pr; }
+        return acc;
     }
     const float l4[4] = {lo[0], lo[0], lo[1], lo[1]}, h4[4] = {hi[0], hi[0], hi[1], hi[1]};
     return fetch8<ORDER, LERP>(l4, h4, ws, iws, w);
 }
 
 // (six wavefronts per SIMD for the sequential order, whose kernels fit 80 registers without a spill: 59.9 -> 55.2 us per
-// 256x128x64 sweep; the sums need 83-90 registers -- held to 80 they spill 12-60 bytes and lose 1-13 % -- and stay at five)
+// 256x128x64 sweep; the sums reach six by themselves -- the fp32 sum at 75-80 registers once a zero weight along a drops four
+// corners, the wide sum at 67-72 formed corner by corner; their first forms needed 83-96 and, held to 80, spilled and lost)
 template <int PATH_DIV, int RANGE_DIV, int QUANT, int LERP, int ORDER>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ORDER == 1 ? 6 : 1)))
 k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, const ActDesc* __restrict__ acts,
@@ -739,7 +729,33 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const int off = (int)(fminf(fl, s_scale) * (float)(SLOT_DW * 4));
             const float* T0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(R) + off) + i * 6;
             float nch[3];
-            if (single) {
+            if constexpr (ORDER == 3) {
+                // the wide sum corner by corner: one weight as a double at a time, three accumulators (the channel-by-channel form
+                // of fetch8 kept eight weights as doubles: 92-96 registers against these 67-72)
+                const float sv00 = iws * w.w, sv10 = ws * w.w, sv01 = iws * w.z, sv11 = ws * w.z;
+                double acc[3];
+                auto term = [&](bool first, float wf, int o) {
+                    asm volatile("" : "+v"(wf));
+                    const double wd = (double)wf;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) acc[ch] = first ? wd * (double)T0[o + ch] : fma(wd, (double)T0[o + ch], acc[ch]);
+                };
+                if (single) {
+                    // the a0 rows B0 (v0), B2 (v1) only: with a weight of exactly 0 along a the four a0 corners with the weights
+                    // w_s w_v (see fetch8_single), otherwise the twin taps under all eight weights
+                    if (__builtin_amdgcn_readfirstlane(__float_as_int(w.x)) == 0) {
+                        term(true, sv00, 0); term(false, sv10, SLOT_DW); term(false, sv01, 6); term(false, sv11, SLOT_DW + 6);
+                    } else {
+                        term(true, sv00 * w.y, 0); term(false, sv10 * w.y, SLOT_DW); term(false, sv01 * w.y, 6); term(false, sv11 * w.y, SLOT_DW + 6);
+                        term(false, sv00 * w.x, 0); term(false, sv10 * w.x, SLOT_DW); term(false, sv01 * w.x, 6); term(false, sv11 * w.x, SLOT_DW + 6);
+                    }
+                } else {
+                    term(true, sv00 * w.y, 0); term(false, sv10 * w.y, SLOT_DW); term(false, sv01 * w.y, 6); term(false, sv11 * w.y, SLOT_DW + 6);
+                    term(false, sv00 * w.x, 3); term(false, sv10 * w.x, SLOT_DW + 3); term(false, sv01 * w.x, 9); term(false, sv11 * w.x, SLOT_DW + 9);
+                }
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) nch[ch] = (float)acc[ch];
+            } else if (single) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     const float tl[2] = {T0[ch], T0[6 + ch]};
