@@ -4,7 +4,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 One "step" = one batch of PLANS_PER_STEP complete DP plans on device-resident inputs (each: distance map,
-t_steps-1 backward stage sweeps over the (s,v,a) grid, one forward rollout).  value = stage sweeps per second
+t_steps-1 backward stage sweeps over the (s,v,a) grid, one forward rollout), dealt to PLANS_IN_FLIGHT planners with a
+stream each (--in-flight 1: one planner, every plan behind the previous one).  value = stage sweeps per second
 over the whole job (all ranks), timed over exactly K steps between barrier + device synchronize on both sides,
 max over ranks.  For N > 1 the plans (independent scenarios) are sharded across ranks with no data-path
 collective ("scaling": "weak"); the only exchange is ONE all-gather of the best-plan record at the end of the
@@ -35,6 +36,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_MEASURED_GBS = 4910.0  # tools/micro/chip_peaks.hip on the box: copy (read + write) of 2 GiB arrays, profiles/r03_micro_chip_peaks.txt
 BYTES_PER_CELL = 32            # read next float4 + write this float4
 PLANS_PER_STEP = 24            # one step = one batch of plans (keeps the timed region of 20 steps above a second)
+PLANS_IN_FLIGHT = 2            # planners (own HIP stream each) the batch is dealt to: the sweeps of ONE plan depend on each other,
+                               # those of two plans do not -- the second plan's workgroups take the slots a sweep leaves free
+                               # while its last workgroups drain (tools/two_plans_in_flight.py: 1 -> 2 streams +14 %, 3 lose)
 MC_PER_GPU = 1024              # BASELINE configs[4]: 8192 Monte-Carlo rollouts on 8 GPUs
 MC_CHUNK = 64                  # scenarios swept per launch (value tables for that many: 64 x 157 MB)
 MC_BLOCK = 128                 # scenarios built on the host and handed to the device at a time (160 MB)
@@ -598,17 +602,38 @@ def worker(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the batch of a step is dealt to PLANS_IN_FLIGHT planners, each with its own stream, tables and environment (the
+    # environment holds the distance map a plan writes): same scenario, same inputs -- so every planner must return the
+    # first one's trajectory bit for bit (checked below, outside the timed region)
+    in_flight = args.in_flight if args.in_flight is not None else (1 if args.grid == "config4" else PLANS_IN_FLIGHT)
+    in_flight = max(1, min(in_flight, plans_per_step))
+    fleet = [(dp, env)] + [dp_setup(args.grid, local_rank, rank)[:2] for _ in range(in_flight - 1)]
+
     def run(n_steps):
-        for _ in range(n_steps * plans_per_step):
-            dp.plan_resident(env)
+        for i in range(n_steps * plans_per_step):
+            q, e = fleet[i % in_flight]
+            q.plan_resident(e)
+
+    def sync_all():
+        for q, _ in fleet:
+            q.sync()
 
     run(args.warmup)
-    dp.sync()
-    setup_s = {"headline": time.perf_counter() - t_setup0}
+    sync_all()
+    # the sweep kernel ALONE on the chip (one plan at a time on one stream): the launch duration the roofline's per-launch
+    # figures are quoted on -- with two plans in flight a launch shares the chip and its duration says little by itself
     dp.timing_enable(True)
+    for _ in range(4):
+        dp.plan_resident(env)
+    alone_ms, alone_launches = dp.timing_get()
+    dp.timing_enable(False)
+    setup_s = {"headline": time.perf_counter() - t_setup0}
+    for q, _ in fleet:
+        q.timing_enable(True)
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
+    sync_all()
     # N > 1: the path's only exchange -- ONE all-gather of every rank's best-plan record (1.4 KB),
     # followed by the same lexicographic argmin on every rank
     traj = dp.download()[0]
@@ -616,8 +641,17 @@ def worker(args):
     best = sharding.allgather_best(rec, dist, torch.device("cpu") if rehearsal else torch.device("cuda", local_rank))
     barrier()
     elapsed = time.perf_counter() - t0
-    sweep_ms, sweep_launches = dp.timing_get()
-    dp.timing_enable(False)
+    rank0_elapsed = elapsed                         # this rank's own clock (the roofline block is rank 0's)
+    sweep_ms = sweep_launches = 0
+    for q, _ in fleet:
+        ms, n = q.timing_get()
+        sweep_ms, sweep_launches = sweep_ms + ms, sweep_launches + n
+        q.timing_enable(False)
+    for q, _ in fleet[1:]:
+        other = q.download()[0]
+        assert all(tuple(getattr(x, f) for f in ("t", "s", "v", "a", "j", "cost", "constr")) ==
+                   tuple(getattr(y, f) for f in ("t", "s", "v", "a", "j", "cost", "constr"))
+                   for x, y in zip(traj.states, other.states)), "two planners in flight disagree on the same scenario"
 
     rank_values = rank_plans = None
     if dist is not None:
@@ -642,8 +676,18 @@ def worker(args):
     total_sweeps = sweeps_per_plan * plans_per_step * args.steps * world
     out = None
     if rank == 0:
+        # Per launch (HIP events on each planner's stream, summed): with one plan in flight that IS the kernel's duration
+        # and `achieved` = bytes per launch / duration, as SURVEY 8d prescribes.  With two in flight a launch shares the
+        # chip for its whole life: its duration (what rocprofv3 lists too) nearly doubles while the chip moves two launches'
+        # bytes -- there `achieved` = the bytes of ALL sweep launches of the timed region / the timed region (a lower bound:
+        # the region holds the fronts, rollouts and gaps too), and the per-launch figures sit beside it.
         per_launch_s = (sweep_ms / 1e3) / max(1, sweep_launches)
-        achieved = cells * BYTES_PER_CELL / per_launch_s / 1e9
+        alone_s = (alone_ms / 1e3) / max(1, alone_launches)
+        own_launches = sweeps_per_plan * plans_per_step * args.steps
+        if in_flight == 1:
+            achieved = cells * BYTES_PER_CELL / per_launch_s / 1e9
+        else:
+            achieved = own_launches * cells * BYTES_PER_CELL / rank0_elapsed / 1e9
         out = {
             "metric": "dp_stage_sweeps_per_s",
             "value": total_sweeps / elapsed,
@@ -663,14 +707,29 @@ def worker(args):
                             f"each dist map + {sweeps_per_plan} backward sweeps + forward rollout",
                 "grid": [p.s_steps, p.v_steps, p.a_steps], "t_steps": p.t_steps,
                 "plans_per_step_per_gpu": plans_per_step, "ms_per_plan": elapsed / args.steps / plans_per_step * 1e3,
+                "plans_in_flight_per_gpu": in_flight,
                 "parallelism": f"independent plans x{world}" + (", one all-gather of the best plan" if world > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": sweep_kernel_name(dp.info()),
-                "launch_us": per_launch_s * 1e6,
+                # the kernel's duration ALONE on the chip (HIP events; = per_launch_s with one plan in flight): what a trace of
+                # `--in-flight 1` lists.  With two in flight the events of a stream also span the waits behind the other
+                # stream's launches (`stream_us_per_launch`), and a trace lists start-to-end durations of launches that share
+                # the chip (profiles/README.md) -- neither is a duration the bytes of ONE launch can be divided by
+                "launch_us": (per_launch_s if in_flight == 1 else alone_s) * 1e6,
+                "stream_us_per_launch": per_launch_s * 1e6,
+                "effective_us_per_launch": rank0_elapsed / own_launches * 1e6,
                 "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
+                "launches_in_flight": in_flight,
+                "achieved_is": ("algorithmic bytes per launch / the launch's HIP-event duration" if in_flight == 1 else
+                                f"algorithmic bytes of the rank's {own_launches} sweep launches / its timed region "
+                                f"({in_flight} plans in flight: the chip moves the bytes of overlapping launches; a lower bound, the region "
+                                "holds the fronts, rollouts and gaps too; `alone` is the prescribed per-launch figure)"),
+                # the same kernel alone on the chip (4 plans on one stream, outside the timed region): the contract's per-launch figure
+                "alone": {"launch_us": alone_s * 1e6, "achieved": cells * BYTES_PER_CELL / alone_s / 1e9,
+                          "frac": cells * BYTES_PER_CELL / alone_s / 1e9 / HBM_PEAK_GBS},
                 # context only (`frac` stays against the prescribed 8 TB/s): what a plain copy kernel reaches on this part
                 "frac_of_measured_copy_rate": achieved / HBM_COPY_MEASURED_GBS,
                 "measured_copy_rate_source": "profiles/r03_micro_chip_peaks.txt (read 6.5, copy 4.9, triad 5.4 TB/s)",
@@ -686,7 +745,7 @@ def worker(args):
         traffic_block(out["roofline"], f"{p.s_steps}x{p.v_steps}x{p.a_steps}")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = dp_cpu_baseline(p, ep, path, occ)
-    del dp, env
+    del dp, env, fleet
 
     secondary = {}
     if not args.no_secondary:
@@ -792,6 +851,9 @@ def main():
     ap.add_argument("--grid", default="target", help="target (256x128x64, default) | config2 | config4 | default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=None,
+                    help=f"planners (streams) a step's plans are dealt to; 1 = every plan behind the previous one "
+                         f"(default {PLANS_IN_FLIGHT}; 1 on config4, whose sweeps are 16 residency rounds deep and gain nothing)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launcher(args, sys.argv[1:]))

@@ -38,6 +38,20 @@ def test_one_line_with_the_contract_fields():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert 0.05 < rf["frac"] < 1.0
     assert rf["kernel"].startswith("k_backward3v")       # the large-grid sweep is the one that ran
+    # two plans in flight by default: `achieved` is all sweep bytes over the timed region (never more than the whole-job rate
+    # implies), and the kernel alone on the chip -- the contract's per-launch figure -- sits beside it
+    assert rf["launches_in_flight"] == 2 == d["config"]["plans_in_flight_per_gpu"]
+    assert abs(rf["achieved"] - d["value"] * rf["algorithmic_bytes_per_launch"] / 1e9) / rf["achieved"] < 1e-6
+    assert rf["stream_us_per_launch"] > rf["launch_us"] == rf["alone"]["launch_us"] > rf["effective_us_per_launch"] > 20.0
+    assert 0.05 < rf["alone"]["frac"] < rf["frac"]
+
+
+def test_one_plan_in_flight_keeps_the_per_launch_roofline():
+    d = _bench({}, "--no-secondary", "--in-flight", "1")
+    rf = d["roofline"]
+    assert rf["launches_in_flight"] == 1
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["launch_us"] * 1e-6) / 1e9) / rf["achieved"] < 1e-6
+    assert abs(rf["launch_us"] - rf["alone"]["launch_us"]) / rf["launch_us"] < 0.1
 
 
 def test_collectives_run_through_rccl_with_one_rank():

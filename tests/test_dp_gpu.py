@@ -454,6 +454,44 @@ def test_one_wait_per_plan_keeps_every_plan_exact(S, V, A, T, cycles):
     assert np.array_equal(again.view(np.uint32), first.view(np.uint32))
 
 
+@pytest.mark.parametrize("S,V,A,T", [(201, 37, 20, 10), (128, 64, 66, 6), (256, 128, 64, 4)],
+                         ids=["small-grid-sweep", "two-rows-per-lane-sweep", "headline-grid"])
+def test_plans_in_flight_on_two_planners_equal_the_oracle(S, V, A, T):
+    """bench.py's headline deals its plans to TWO planners (own stream, tables and environment each) from one host
+    thread, launches interleaved and nothing waited for in between: the sweeps of both plans share the chip.  Different
+    scenario per planner, six plans each with a new start state every time -- every trajectory and the last plan's
+    tables equal the oracle's, whichever planner's workgroups ran beside them."""
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occs = [sc.occ_map(ep, sc.OBSTACLES_OVERTAKE), sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)]
+    fleet = []
+    for occ in occs:
+        env = tpl_amd.DynProgEnvironment()
+        env.reinit_buffers(ep)
+        env.set_occ_map(occ)
+        dp = tpl_amd.DynProgLonPlanner()
+        dp.reinit_buffers(p)
+        fleet.append((dp, env))
+    n = 6 if S * V * A < 1 << 20 else 2
+    inits = [[sc.initial_state(0.3 * k + q, 5.0 + 0.7 * k + q, 0.1 * ((k + q) % 3)) for q in range(2)] for k in range(n)]
+    got = [[], []]
+    for k in range(n):
+        for q, (dp, env) in enumerate(fleet):
+            if k > 0:
+                got[q].append(_traj_np(dp.collect_download((k - 1) & 1)[0]))
+            dp.upload([inits[k][q]], path)
+            dp.plan_resident(env)
+            dp.stage_download(k & 1)
+    for q, (dp, env) in enumerate(fleet):
+        got[q].append(_traj_np(dp.collect_download((n - 1) & 1)[0]))
+    for q, (dp, env) in enumerate(fleet):
+        for k in range(n):
+            tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occs[q], [inits[k][q]])
+            assert np.array_equal(got[q][k].view(np.uint32), otrajs[0].view(np.uint32)), (q, k)
+        _assert_tables_equal(dp, tables, T)
+
+
 def test_two_threads_with_their_own_engines():
     """Different engine objects may be driven from different threads (own non-blocking streams, thread-local error
     slot and bounce buffer; ctypes releases the GIL during the calls): two threads, each with its own environment

@@ -11,6 +11,9 @@ python bench.py --steps 20 --warmup 3 --grid config2 --no-cpu-baseline --no-seco
 python bench.py --steps 5 --warmup 1 --grid config4 --no-cpu-baseline --no-secondary > "$OUT/bench_config4.json" 2>/dev/null
 cd /tmp && export TMPDIR=/tmp && export PYTHONPATH="$REPO${PYTHONPATH:+:$PYTHONPATH}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_dp" -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/trace_dp.log" 2>&1
+# (the default line keeps two plans in flight: the sweep's duration in that trace is its duration WHILE sharing the chip; the same
+# command with one plan in flight gives the kernel alone -- `roofline.alone` of the line)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_dp_alone" -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --in-flight 1 > "$OUT/trace_dp_alone.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_ilqr" -- python3 "$REPO/tools/ilqr_only.py" mpc > "$OUT/trace_ilqr.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mc" -- python3 "$REPO/tools/mc_only.py" > "$OUT/trace_mc.log" 2>&1
 cd "$REPO"
