@@ -1,5 +1,7 @@
 #!/bin/bash
-# same-box A/B of the V3_STAGGER builds in tools/ab_tmp (see tools/batch_vs_streams.py)
+# Same-box A/B of experiment builds of libtplhip.so in tools/ab_tmp/ (tplhip_base.so = the tree; the V3_STAGGER / V3_INTERLEAVE
+# builds come from the four- and twenty-line patches kept in profiles/r05_dp_batch_vs_streams.json -- the switches are not in
+# the tree; build: hipcc the patched dp_sweep.hip with the Makefile's flags + -D..., link with the other objects of tpl_amd/csrc).
 cd "$(dirname "$0")/.."
 out=gpurun_out/stagger; mkdir -p $out
 TPLHIP_LIB=$PWD/tools/ab_tmp/tplhip_base.so python tools/batch_vs_streams.py target 48 > $out/batch_vs_streams.json 2> $out/batch.err || exit 1
