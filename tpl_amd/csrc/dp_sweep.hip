@@ -74,6 +74,17 @@ __device__ __forceinline__ float in_vgpr(float x)
     return x;
 }
 
+// LDS byte addresses of the per-cell look-ups (blended-row slot, path sample): index x scale + BASE formed in float by ONE fma
+// and converted -- a multiplication, a conversion and an integer add otherwise, i.e. two VALU instructions less per cell and
+// action (round 5, same box: 40.75 -> 39.55 us per 256x128x64 sweep alone, 35.4 -> 34.3 with two plans in flight;
+// profiles/r05_dp_addr_fma_ab.txt).  The operands are integers below 2^17, so the fma is exact; the base is the low half of
+// the generic address (= the LDS offset), pinned in a vector register.  k_backward3v only: k_backward3s (a lone workgroup's chain,
+// not VALU issue) gains nothing from it, k_backward3o has no register to spare (spills / a wavefront per SIMD less).
+typedef const __attribute__((address_space(3))) v4f* LdsV4;
+typedef const __attribute__((address_space(3))) float* LdsF;
+__device__ __forceinline__ float lds_base_f(const void* q) { return in_vgpr((float)(unsigned)(unsigned long long)q); }
+__device__ __forceinline__ unsigned lds_addr(float idx, float scale, float base_f) { return (unsigned)fmaf(idx, scale, base_f); }
+
 // x / c for a run-time constant c, in the cheapest form the host proved exact for this c (see k_verify_div):
 //   4  c is a power of two: one multiplication by 1/c
 //   3  two-float reciprocal r_hi + r_lo: fma(x, r_hi, x * r_lo)                             (two plain instructions)
@@ -297,6 +308,13 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     const float rr_hi = in_vgpr(a.rcp_range_hi), rr_lo = in_vgpr(a.rcp_range_lo);
     const float rp_hi = in_vgpr(a.rcp_path_hi), rp_lo = in_vgpr(a.rcp_path_lo);
     const float w_snap_v = in_vgpr(p.w_snap);
+    // (three registers: the instances whose path division needs a reciprocal pair sit at 72-73 registers -- those at 72 hold
+    // seven wavefronts per SIMD and would lose one -- and keep the integer form)
+    constexpr bool ADDR_FMA = PATH_DIV == 4 || PATH_DIV == 0;
+    float rk_base_f[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) rk_base_f[i] = ADDR_FMA ? lds_base_f(R + i * row_slots) : 0.0f;
+    const float pv_base_f = ADDR_FMA ? lds_base_f(pv) : 0.0f;
     const float path_top = (float)(p.path_steps - 1);
     const double dt_d = (double)p.dt;
     const bool dup_last = is == S - 1;
@@ -305,7 +323,11 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 #pragma unroll
     for (int i = 0; i < NV; ++i) { best[i] = 0x7f8000007f800000ull; bk[i] = 0; }
     __syncthreads();                     // descriptors and path limits are in LDS
-    const v4f* dsc4 = reinterpret_cast<const v4f*>(dsc);
+    // (the descriptor copy's LDS address stays in ONE vector register where there is one to spare: otherwise it is moved there
+    // from a scalar one per action)
+    unsigned dsc_addr = (unsigned)(unsigned long long)dsc;
+    if constexpr (ADDR_FMA) asm volatile("" : "+v"(dsc_addr));
+    const LdsV4 dsc4 = (LdsV4)(unsigned long long)dsc_addr;
 #pragma unroll
     for (int k = 0; k < N_BWD; ++k) {
         // ---- phase 1: blend the next-stage rows around (v', a') for the NV cells (a, then v)
@@ -338,6 +360,9 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                 for (int i = 0; i < NV; ++i) {
                     const Node3 bu = lerp3<LERP>(up[i][0], up[i][1], w[i].x, w[i].y);
                     r[i] = lerp3<LERP>(bl, bu, w[i].z, w[i].w);
+                    // (the cell's row is finished HERE, ahead of the shared / not-shared branch: left to the compiler it sinks behind
+                    // the branch, keeps both blends alive across it and pays three moves per action and four registers for that)
+                    if (i + 1 < NV) asm volatile("" : "+v"(r[i].c), "+v"(r[i].g), "+v"(r[i].j));
                     if (i + 1 < NV) {
                         if ((shared_mask >> (i * N_BWD + k)) & 1u) {
                             bl = bu;
@@ -356,6 +381,9 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                 for (int i = 0; i < NV; ++i) {
                     const Node3 bu = lerp3<LERP>(up[i][0], up[i][0], w[i].x, w[i].y);
                     r[i] = lerp3<LERP>(bl, bu, w[i].z, w[i].w);
+                    // (the cell's row is finished HERE, ahead of the shared / not-shared branch: left to the compiler it sinks behind
+                    // the branch, keeps both blends alive across it and pays three moves per action and four registers for that)
+                    if (i + 1 < NV) asm volatile("" : "+v"(r[i].c), "+v"(r[i].g), "+v"(r[i].j));
                     if (i + 1 < NV) {
                         if ((shared_mask >> (i * N_BWD + k)) & 1u) {
                             bl = bu;
@@ -381,7 +409,6 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const v4f u = dsc4[(i * N_BWD + k) * 2 + 1];
-            const v4f* Rk = R + i * row_slots;
             // lonDynamics station part, lon_planner.cu:244
             const double sd = kFma<LERP> ? fma(now.j_term[i], dt_d, sd_base[i]) : sd_base[i] + now.j_term[i];
             const float tn_s = fmaxf(s, (float)sd);
@@ -393,9 +420,17 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const float fr = xb - fl;
             const float ws = s_weight<QUANT>(fr);
             const float iws = 1.0f - ws;
-            const int off = (int)(fminf(fl, s_scale) * 16.0f);
-            const v4f nl = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off);
-            const v4f nh = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off + 16);
+            v4f nl, nh;
+            if constexpr (ADDR_FMA) {
+                const unsigned off = lds_addr(fminf(fl, s_scale), 16.0f, rk_base_f[i]);
+                nl = *(LdsV4)(unsigned long long)off;
+                nh = *(LdsV4)(unsigned long long)(off + 16u);
+            } else {
+                const int off = (int)(fminf(fl, s_scale) * 16.0f);
+                const char* Rk = reinterpret_cast<const char*>(R + i * row_slots);
+                nl = *reinterpret_cast<const v4f*>(Rk + off);
+                nh = *reinterpret_cast<const v4f*>(Rk + off + 16);
+            }
             asm volatile("" :: "v"(nl.w), "v"(nh.w));
             const float nc = blend1<LERP>(nl.x, nh.x, ws, iws);
             const float ng = blend1<LERP>(nl.y, nh.y, ws, iws);
@@ -412,9 +447,16 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const float f0 = fminf(floorf(alpha), path_top);
             const float pa = alpha - f0;
             const float pia = 1.0f - pa;
-            const int t4 = (int)(f0 * 4.0f);
-            const float pv0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4);
-            const float pv1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4 + 4);
+            float pv0, pv1;
+            if constexpr (ADDR_FMA) {
+                const unsigned t4 = lds_addr(f0, 4.0f, pv_base_f);
+                pv0 = *(LdsF)(unsigned long long)t4;
+                pv1 = *(LdsF)(unsigned long long)(t4 + 4u);
+            } else {
+                const int t4 = (int)(f0 * 4.0f);
+                pv0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4);
+                pv1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pv) + t4 + 4);
+            }
             const float vmn = mad1<LERP>(pv0, pia, pv1 * pa);
             float c = sc[i] + nc;
             float g = sg[i] + ng;
@@ -957,7 +999,6 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             asm volatile("" : "+v"(kv));
             const ActDesc& e = d0[k];
             const v4f u = dsc4[k * 2 + 1];
-            const v4f* Rk = R + kk * row_slots;
             const double sd = kFma<LERP> ? fma(e.j_term, (double)p.dt, sd_base) : sd_base + e.j_term;      // lonDynamics station part, lon_planner.cu:244
             const float tn_s = fmaxf(s, (float)sd);
             const float xs = tn_s - s_min_v;
@@ -968,6 +1009,7 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const float fr = xb - fl;
             const float ws = s_weight<QUANT>(fr);
             const float iws = 1.0f - ws;
+            const v4f* Rk = R + kk * row_slots;
             const int off = (int)(fminf(fl, s_scale) * 16.0f);
             const v4f nl = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off);
             const v4f nh = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(Rk) + off + 16);
