@@ -308,9 +308,10 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     const float rr_hi = in_vgpr(a.rcp_range_hi), rr_lo = in_vgpr(a.rcp_range_lo);
     const float rp_hi = in_vgpr(a.rcp_path_hi), rp_lo = in_vgpr(a.rcp_path_lo);
     const float w_snap_v = in_vgpr(p.w_snap);
-    // (three registers: the instances whose path division needs a reciprocal pair sit at 72-73 registers -- those at 72 hold
-    // seven wavefronts per SIMD and would lose one -- and keep the integer form)
-    constexpr bool ADDR_FMA = PATH_DIV == 4 || PATH_DIV == 0;
+    // (three registers: the instances whose path division needs a reciprocal pair sit at 72-75 registers; those at 72 -- the
+    // station range divided by one multiplication or the IEEE way -- hold seven wavefronts per SIMD, would lose one, and keep the
+    // integer form; the others hold six either way)
+    constexpr bool ADDR_FMA = PATH_DIV == 4 || PATH_DIV == 0 || RANGE_DIV == 3 || RANGE_DIV == 5;
     float rk_base_f[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) rk_base_f[i] = ADDR_FMA ? lds_base_f(R + i * row_slots) : 0.0f;
