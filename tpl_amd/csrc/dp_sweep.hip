@@ -375,6 +375,24 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                     }
                 }
                 park(r);
+            } else if (__builtin_amdgcn_readfirstlane((int)__float_as_uint(w[0].x)) == 0) {
+                // a weight of exactly 0 along a (the jerk grid lands on the acceleration grid: 106 of the 576 (a, action) pairs of
+                // 256x128x64): the blend of a row with itself IS the row -- fma(p, 0, p * 1) = p for every finite p in every blend form,
+                // see ACT_SINGLE_A -- so the three blends along a are not computed (a wave-uniform test; same box, two plans in flight:
+                // 34.4 -> 33.9 us per sweep, nothing for a lone launch; profiles/r05_dp_addr_fma_ab.txt, call 6)
+                Node3 r[NV];
+                Node3 bl = lo[0];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const Node3 bu = up[i][0];
+                    r[i] = lerp3<LERP>(bl, bu, w[i].z, w[i].w);
+                    if (i + 1 < NV) asm volatile("" : "+v"(r[i].c), "+v"(r[i].g), "+v"(r[i].j));
+                    if (i + 1 < NV) {
+                        if ((shared_mask >> (i * N_BWD + k)) & 1u) bl = bu;
+                        else bl = load_row(d0[(i + 1) * rs + k].r00);
+                    }
+                }
+                park(r);
             } else {
                 Node3 r[NV];
                 Node3 bl = lerp3<LERP>(lo[0], lo[0], w[0].x, w[0].y);
