@@ -66,14 +66,22 @@ TPL_HD inline void tpl_sincos_core(double a, double* s, double* c)
 // scalar branch.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TPL_ANY_LANE(cond) (__builtin_amdgcn_ballot_w64(cond) != 0ull)
+// First statement of the block behind `if (TPL_ANY_LANE(c))`: with it the test is a compare and `s_cbranch_vccz`, two
+// instructions where no lane takes the path; without it the compiler folds the uniform test into the per-lane one behind it --
+// compare, s_cmp, s_cselect, s_and, s_and_saveexec, branch, s_or: seven.  A rollout stage passes eight such tests, and on a
+// lone wavefront an instruction of any class is four cycles (round 5: 6.33 -> 6.50 k batched iterations/s at 1 024 x N = 50,
+// profiles/r05_ilqr_guards_ab.txt).
+#define TPL_SLOW_PATH() asm volatile("; slow path")
 #else
 #define TPL_ANY_LANE(cond) (cond)
+#define TPL_SLOW_PATH() do { } while (0)
 #endif
 
 TPL_HD inline void tpl_sincos(double a, double* s, double* c)
 {
     tpl_sincos_core(a, s, c);
     if (TPL_ANY_LANE(!(fabs(a) < 1.0e5))) {
+        TPL_SLOW_PATH();
         if (!(fabs(a) < 1.0e5)) sincos(a, s, c);
     }
 }
@@ -87,6 +95,7 @@ TPL_HD inline double tpl_tan(double a)
     tpl_sincos_core(a, &s, &c);
     double r = s / c;
     if (TPL_ANY_LANE(!(fabs(a) < 1.0e5))) {
+        TPL_SLOW_PATH();
         if (!(fabs(a) < 1.0e5)) r = tan(a);
     }
     return r;
@@ -168,6 +177,7 @@ TPL_HD inline double tpl_fmod_pos(double x, double m)
 {
     double r = x;
     if (TPL_ANY_LANE(!(fabs(x) < m))) {
+        TPL_SLOW_PATH();
         if (!(fabs(x) < m)) r = fmod(x, m);
     }
     return r;
@@ -177,8 +187,15 @@ TPL_HD inline double tpl_fmod_pos(double x, double m)
 TPL_HD inline double tpl_short_angle_dist(double a0, double a1)
 {
     const double m = M_PI * 2;
-    const double da = tpl_fmod_pos(a1 - a0, m);
-    return tpl_fmod_pos(2 * da, m) - da;
+    // ONE test for both remainders: below pi in magnitude the difference is its own remainder and so is its double
+    // (|2 d| < 2 pi), i.e. the two fmod calls return their arguments -- the same two operations, the same bits
+    const double d = a1 - a0;
+    if (TPL_ANY_LANE(!(fabs(d) < M_PI))) {
+        TPL_SLOW_PATH();
+        const double da = tpl_fmod_pos(d, m);
+        return tpl_fmod_pos(2 * da, m) - da;
+    }
+    return 2 * d - d;
 }
 
 // __lerp_angle, optim.c:394-411
@@ -296,7 +313,12 @@ __device__ inline double tpl_quad_bcast(double v, int src)
 
 __device__ inline double tpl_quad_pick(int q, double a0, double a1, double a2, double a3)
 {
-    return (q == 0) ? a0 : (q == 1) ? a1 : (q == 2) ? a2 : a3;
+    // selects on the halves (as a ?: chain on doubles the compiler builds a switch: masked branches, eight instructions)
+    int lo = __double2loint(a3), hi = __double2hiint(a3);
+    lo = (q == 2) ? __double2loint(a2) : lo; hi = (q == 2) ? __double2hiint(a2) : hi;
+    lo = (q == 1) ? __double2loint(a1) : lo; hi = (q == 1) ? __double2hiint(a1) : hi;
+    lo = (q == 0) ? __double2loint(a0) : lo; hi = (q == 0) ? __double2hiint(a0) : hi;
+    return __hiloint2double(hi, lo);
 }
 
 // lane q of the quad: tpl_lerp (or tpl_lerp_angle where bit q of angle_mask is set) of arrs[q]
@@ -325,6 +347,7 @@ __device__ inline double tpl_tan_sc(double a, double s, double c)
 {
     double r = s / c;
     if (TPL_ANY_LANE(!(fabs(a) < 1.0e5))) {
+        TPL_SLOW_PATH();
         if (!(fabs(a) < 1.0e5)) r = tan(a);
     }
     return r;

@@ -2926,11 +2926,16 @@ int tplhip_ilqr_info(tplhip_ilqr* h, char* buf, int n)
 {
     if (!h || !buf || n < 1) return fail(TPLHIP_EINVAL, "bad argument");
     const bool sp = h->last_form != 0;
+    // TPL_ILQR_SCHED: the instruction scheduler strategy this library was compiled under (genopt.compile_model passes it)
+#ifndef TPL_ILQR_SCHED
+#define TPL_ILQR_SCHED "default"
+#endif
     std::snprintf(buf, (size_t)n, "{\"batch\": %d, \"t_cap\": %d, \"lds_traj\": %d, \"lds_arrays\": %d, \"lds_dyn_bytes\": %zu, "
-                  "\"lds_static_bytes\": %zu, \"form\": \"%s\", \"chain_waves_per_simd\": %d}", h->batch, h->rows - 1,
+                  "\"lds_static_bytes\": %zu, \"form\": \"%s\", \"chain_waves_per_simd\": %d, \"scheduler\": \"%s\"}", h->batch, h->rows - 1,
                   sp ? h->dev_split.lds_traj : h->dev.lds_traj, sp ? h->dev_split.n_lds_arrays : h->dev.n_lds_arrays,
                   sp ? h->lds_dyn_bytes_split : h->lds_dyn_bytes, sp ? (size_t)0 : h->lds_static,
-                  h->last_form == 3 ? "fused1" : (h->last_form == 2 ? "fused" : (sp ? "split" : "single")), (sp && h->last_form != 3) ? TPL_ILQR_CHAIN_WAVES : 1);
+                  h->last_form == 3 ? "fused1" : (h->last_form == 2 ? "fused" : (sp ? "split" : "single")), (sp && h->last_form != 3) ? TPL_ILQR_CHAIN_WAVES : 1,
+                  TPL_ILQR_SCHED);
     return TPLHIP_OK;
 }
 

@@ -805,10 +805,26 @@ def generate(cfg, name=None, out_dir=None, force=False):
     return paths["inc"]
 
 
-def compile_model(name, out_dir=None, force=False, extra_flags=None, so_path=None, check_isa=True):
+SCHEDULERS = ("max-ilp", "default")
+
+
+def compile_model(name, out_dir=None, force=False, extra_flags=None, so_path=None, check_isa=True, scheduler=None):
     """hipcc the solver template against ``<name>.inc`` -> libilqr_<name>.so (``so_path``: a variant build somewhere else,
-    ``extra_flags``: its additional compiler flags, ``check_isa=False``: keep a library whose listing fails the EXEC = 0 scan;
-    all three for tests and A/B tools)."""
+    ``extra_flags``: its additional compiler flags, ``check_isa=False``: keep a library whose listing fails the EXEC = 0 scan,
+    ``scheduler``: "max-ilp" or "default" and nothing else; all four for tests and A/B tools).
+
+    Which instruction scheduler: `-mllvm -amdgpu-sched-strategy=max-ilp` is 2 % faster on the heavy models (the solver's
+    kernels are dependent chains on one wavefront; profiles/r05_ilqr_guards_ab.txt) and is tried FIRST; a library whose device
+    listing fails the scan below is thrown away and built again under hipcc's default strategy, and only a second failure is an
+    error.  History: max-ilp was shipped for a few revisions of round 4 -- until one refactoring of k_ilqr_update came out of it
+    with mu = 1 where mu_step = 2 says 10.  Root cause (round 5, profiles/r05_ilqr_max_ilp_root_cause.txt): a COMPILER bug, not
+    undefined behaviour in the source -- ROCm 7.2.0's register allocator placed its AGPR copies of the value a divergent loop
+    computes (the `m *= 10` loop of the mu schedule) in the loop's exit block IN FRONT of the `s_or_b64 exec` that re-enables
+    the lanes, where no lane executes them; the copies only land there when the scheduler has moved scalar code above that
+    restore.  Whether a given source comes out that way is the compiler's business (round 5's change of builtins.h moved all
+    nine models out of it), so it is CHECKED on every build, not assumed: the device listing is scanned for vector instructions
+    at EXEC = 0 (tpl_amd/optim/isa_check.py) -- whatever scheduler, whatever ROCm.  `Optim.info()["scheduler"]` names the
+    strategy a loaded library was built under; tests/test_ilqr_gpu.py builds the OTHER one on the box and compares bits."""
     paths = dict(model_paths(name, out_dir))
     if so_path:
         paths["so"] = so_path
@@ -820,39 +836,42 @@ def compile_model(name, out_dir=None, force=False, extra_flags=None, so_path=Non
             return paths["so"]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = paths["so"] + f".tmp{os.getpid()}"
-    # hipcc's default instruction scheduler.  `-mllvm -amdgpu-sched-strategy=max-ilp` is 1.5-2 % faster on the heavy models
-    # and was shipped for a few revisions of round 4 -- until one refactoring of k_ilqr_update came out of it with mu = 1
-    # where mu_step = 2 says 10.  Root cause (round 5, profiles/r05_ilqr_max_ilp_root_cause.txt): a COMPILER bug, not undefined
-    # behaviour in the source -- ROCm 7.2.0's register allocator placed its AGPR copies of the value a divergent loop computes
-    # (the `m *= 10` loop of the mu schedule) in the loop's exit block IN FRONT of the `s_or_b64 exec` that re-enables the
-    # lanes, where no lane executes them; the copies only land there when the scheduler has moved scalar code above that
-    # restore, which max-ilp does and the default strategy does not.  "Does not" is checked, not assumed: the device listing
-    # of every library built here is scanned for vector instructions at EXEC = 0 (tpl_amd/optim/isa_check.py), and a hit
-    # fails the build -- whatever scheduler, whatever ROCm.  tests/test_ilqr_gpu.py::test_max_ilp_build_is_caught builds the
-    # max-ilp variant on the box: the scan must flag it, and its wrong mu is an expected (strict) failure.
     import shutil
     import tempfile
-    work = tempfile.mkdtemp(prefix=f"tplhip_{name}_")
-    try:
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-fvisibility=hidden", "-fno-fast-math", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-               f"-DTPL_MODEL_INC=\"{paths['inc']}\"", "-I", os.path.join(_PKG, "..", "include"),
-               "-save-temps", *(extra_flags or []), "-o", tmp, src]
-        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=work)
-        if proc.returncode != 0:
-            raise RuntimeError("\n" + proc.stdout.decode("utf8", "replace"))
-        listings = [os.path.join(work, f) for f in os.listdir(work) if f.endswith(".s") and "amdgcn" in f]
-        hits = [h for lst in listings for h in exec0_hits(lst)]
-        if check_isa and (not listings or hits):
-            if os.path.exists(tmp):
-                os.remove(tmp)
-            raise RuntimeError(f"{name}: " + ("no device listing to check" if not listings else
-                               "the compiler placed vector instructions where EXEC = 0 (spill code in front of a loop exit's exec "
-                               "restore; profiles/r05_ilqr_max_ilp_root_cause.txt):\n" + "\n".join(f"  {fn} line {n}: {txt}" for _, fn, n, txt in hits[:12])))
-    finally:
-        shutil.rmtree(work, ignore_errors=True)
-    os.replace(tmp, paths["so"])
-    return paths["so"]
+    if scheduler is not None and scheduler not in SCHEDULERS:
+        raise ValueError(f"scheduler must be one of {SCHEDULERS}")
+    # a caller that names a strategy in its own flags (the tests of the scan do) gets exactly that build
+    own = any("amdgpu-sched-strategy" in f for f in (extra_flags or []))
+    order = ("as given",) if own else ((scheduler,) if scheduler else SCHEDULERS)
+    failure = None
+    for sched in order:
+        work = tempfile.mkdtemp(prefix=f"tplhip_{name}_")
+        try:
+            sflags = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if sched == "max-ilp" else []
+            label = "max-ilp" if own and any(f.endswith("=max-ilp") for f in extra_flags) else ("default" if sched == "as given" else sched)
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                   "-fvisibility=hidden", "-fno-fast-math", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+                   f"-DTPL_MODEL_INC=\"{paths['inc']}\"", f"-DTPL_ILQR_SCHED=\"{label}\"", "-I", os.path.join(_PKG, "..", "include"),
+                   "-save-temps", *sflags, *(extra_flags or []), "-o", tmp, src]
+            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=work)
+            if proc.returncode != 0:
+                raise RuntimeError("\n" + proc.stdout.decode("utf8", "replace"))
+            listings = [os.path.join(work, f) for f in os.listdir(work) if f.endswith(".s") and "amdgcn" in f]
+            hits = [h for lst in listings for h in exec0_hits(lst)]
+            if check_isa and (not listings or hits):
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                failure = f"{name} ({label} scheduler): " + ("no device listing to check" if not listings else
+                          "the compiler placed vector instructions where EXEC = 0 (spill code in front of a loop exit's exec "
+                          "restore; profiles/r05_ilqr_max_ilp_root_cause.txt):\n" + "\n".join(f"  {fn} line {n}: {txt}" for _, fn, n, txt in hits[:12]))
+                continue
+            os.replace(tmp, paths["so"])
+            if failure:
+                print(f"[genopt] {failure.splitlines()[0]} -- library rebuilt under the {label} scheduler", file=sys.stderr)
+            return paths["so"]
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    raise RuntimeError(failure)
 
 
 def exec0_hits(listing):
