@@ -16,9 +16,11 @@ profiles/r05_ilqr_max_ilp_root_cause.txt): a divergent loop leaves through
 LLVM's AMDGPU backend keeps spill code behind the exec restore of a block by treating the restore as the block's
 PROLOGUE -- which only works while the restore is the block's first instruction; a scalar move scheduled above it ends
 the prologue early and the allocator's copies land in front of the restore.  A compiler bug (ROCm 7.2.0, AMD clang 22.0.0git roc-7.2.0),
-not undefined behaviour in the source: the default scheduler does not move scalar code above the restore, so its
-listings are clean -- which this script CHECKS instead of assuming (tpl_amd/optim/genopt.py runs it on every solver
-library it builds; a hit fails the build).
+not undefined behaviour in the source: the default scheduler did not move scalar code above the restore on those sources, so
+its listings were clean -- and whether a given source comes out of max-ilp with the misplaced copies turned out to depend on
+unrelated code (a change of builtins.h at the end of round 5 moved all nine models out of it).  So this script CHECKS instead
+of assuming: tpl_amd/optim/genopt.py runs it on every solver library it builds -- under max-ilp first (2 % faster on the heavy
+models), and on a hit the library is thrown away and built under the default strategy; only a second hit fails the build.
 
     python -m tpl_amd.optim.isa_check listing.s [...]      (or tools/find_exec0_spills.py) exit code 1 when anything is found
 """
