@@ -151,7 +151,9 @@ TPLHIP_API int tplhip_ilqr_sync(tplhip_ilqr* h);
 TPLHIP_API int tplhip_ilqr_download(tplhip_ilqr* h);           /* device -> mirrors */
 /* HIP-event time of the solver kernel launches since the last call with reset=1 */
 /* Where the solver keeps its working set for the next launch, as a small JSON object (diagnostics / tests):
- * {"batch", "t_cap", "lds_traj": 1 when x, u, k, K, uMin, uMax are mirrored in LDS, "lds_arrays", "lds_dyn_bytes", ...}.
+ * {"batch", "t_cap", "lds_traj": 1 when x, u, k, K, uMin, uMax are mirrored in LDS, "lds_arrays", "lds_dyn_bytes", ...,
+ *  "form": the launch form of the last update, "scheduler": the instruction scheduler strategy the library was compiled under
+ *  ("max-ilp" where its device listing passed the EXEC = 0 scan, else "default": tpl_amd/optim/genopt.py:compile_model)}.
  * Valid after the first update() / upload(). */
 TPLHIP_API int tplhip_ilqr_info(tplhip_ilqr* h, char* buf, int n);
 TPLHIP_API int tplhip_ilqr_timing(tplhip_ilqr* h, int reset, double* kernel_ms, int64_t* launches);
