@@ -211,14 +211,18 @@ __device__ __forceinline__ void dynamics_quad(const Params& P, const double* x, 
 }
 
 // The workgroup IS one wavefront.  LDS operations of a wave are issued and completed in
-// program order, so an exchange through LDS between its lanes needs no s_barrier and --
+// program order, so an exchange through LDS between its lanes needs no s_barrier, and --
 // unlike __syncthreads(), which also drains vmcnt -- must not wait for the global loads
-// that were issued on purpose to fly across it: wait for the LDS queue only and stop
-// the compiler from moving memory operations across.
+// that were issued on purpose to fly across it.  It needs no s_waitcnt either: a ds_read
+// behind a ds_write of the same wavefront is executed behind it and returns what was
+// written, whichever lane wrote it (until round 5 an lgkmcnt(0) sat here: the reads of an
+// exchange were only ISSUED once the writes had completed -- one LDS latency per exchange,
+// three exchanges per Riccati stage: 6.94 -> 7.06 k batched iterations/s at 1 024 x N = 50,
+// every field of a 512-problem batch bit-identical; profiles/r05_ilqr_guards_ab.txt).  What
+// remains is the compiler: it must not move memory operations across.
 __device__ __forceinline__ void lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
