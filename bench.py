@@ -273,6 +273,29 @@ def rank_scenario(rank):
     return obst, sc.initial_state(0.0, 8.0 + 0.5 * rank, 0.0)
 
 
+def scenario_deck(rank, ep):
+    """The inputs the timed region deals to its plans: FOUR obstacle sets -- the rank's headline
+    scenario (rank_scenario), the reference's overtake scene without the faster car, and two seeded stress sets
+    (K = 8, s0 ~ U(30, 180), v ~ U(0, 10)) -- and SEVEN start states (the headline's (0, 8, 0) and six of
+    SURVEY 8d's batch variants v0 ~ U(2, 14), a0 ~ U(-1, 1)): 28 different (obstacles, start) pairs, so the data-dependent
+    arms of the sweep (ACT_SINGLE_A thirds, shared / not-shared rows, the obstacle rows of pre_sdist) and of the rollout
+    are not the same in every plan.  Returns (occupancy maps, start states)."""
+    from benchkit import scenarios as sc
+    obst0, init0 = rank_scenario(rank)
+    shift = 7.0 * rank
+    sets = [obst0,
+            tuple((s0 + shift, v, ln) for (s0, v, ln) in sc.OBSTACLES_OVERTAKE),
+            sc.random_obstacles(4 + rank, 8), sc.random_obstacles(9 + rank, 6)]
+    return [sc.occ_map(ep, o) for o in sets], [init0] + sc.random_initial_states(6, seed=5 + rank)
+
+
+def deal(i, in_flight):
+    """Which (obstacle set, start state) plan i of the timed region gets -- deterministic by plan index; the two planners in
+    flight walk the deck with different offsets, the set and the state with coprime periods (4 and 7)."""
+    lane, j = i % in_flight, i // in_flight
+    return (j + lane) % 4, (j + 3 * lane) % 7
+
+
 def dp_setup(grid, device, rank=0):
     import tpl_amd
     from benchkit import scenarios as sc
@@ -287,12 +310,21 @@ def dp_setup(grid, device, rank=0):
     env.set_occ_map(occ)
     dp = tpl_amd.DynProgLonPlanner(device)
     dp.reinit_buffers(p)
+    if os.environ.get("TPL_BENCH_R1") == "0":       # A/B legs only (tools/, profiles/): rule R1 = 0, one rounding per operation
+        dp.set_contraction(False)
     dp.upload([init], path)
     return dp, env, p, ep, path, occ
 
 
 def sweep_kernel_name(info):
     return info["sweep"]
+
+
+def arithmetic_name(info):
+    """The HP-1 arithmetic rule of a planner as one string (tplhip_dp_lon_info -> "rule")."""
+    r = info["rule"]
+    return (f"R1={r['fma']} ({'contracted like nvcc -fmad=true' if r['fma'] else 'one rounding per operation'}),"
+            f"R2={('none', 'rint', 'floor')[r['quant']]},R3={('fma', 'mul-add', 'p+w(q-p)')[r['lerp']]}/{('avs', 'sva', 'sum8_f32', 'sum8_wide')[r['order']]}")
 
 
 def mc_scenarios(ep, first, n):
@@ -335,8 +367,9 @@ def dp_general_sweep_price(device, grid="target", plans=3):
       divisions, any input) next to the kernel the planner selects by itself, same plan, same box;
     * the plain-fp32 sweep with both divisions as IEEE divisions (no_fastdiv) -- what a divisor without a proven
       reciprocal form pays now that it no longer changes kernels; with a path step that is not a power of two; under
-      contracted arithmetic (set_contraction) and with truncated filter weights (set_filter_rule(2, 0)) -- what a
-      non-default arithmetic rule costs on the same kernel; under another blend order / the eight-corner sums
+      one rounding per operation (set_contraction(False): R1 = 0, the default until round 5 -- built with every division
+      form like the default) and with truncated filter weights (set_filter_rule(2, 0)) -- what a non-default arithmetic
+      rule costs on the same kernel; under another blend order / the eight-corner sums
       (set_blend_order(1 | 2 | 3)) -- what following such a dump of the reference build costs;
     * the kernel and the division forms the planner selects for path_step_size x s_max combinations (forms: 4 one
       multiplication, 3 two-float reciprocal, 5 reciprocal + Newton step, 0 IEEE division; dp_sweep.hip)."""
@@ -352,7 +385,7 @@ def dp_general_sweep_price(device, grid="target", plans=3):
     out = {"grid": [S, V, A], "t_steps": T}
     saved = os.environ.get("TPLHIP_DEBUG")
     try:
-        for key, dbg in (("selected", ""), ("path_step_0.7", ""), ("contracted", ""), ("truncated_weights", ""), ("ieee_divisions", "no_fastdiv"),
+        for key, dbg in (("selected", ""), ("path_step_0.7", ""), ("unfused", ""), ("truncated_weights", ""), ("ieee_divisions", "no_fastdiv"),
                          ("general", "no_v3,no_s3"), ("order_sva", ""), ("sum8_f32", ""), ("sum8_wide", "")):
             os.environ["TPLHIP_DEBUG"] = dbg
             p = sc.lon_params(S, V, A, T)
@@ -360,8 +393,8 @@ def dp_general_sweep_price(device, grid="target", plans=3):
                 p.path_step_size, p.path_steps = 0.7, 300
             dp = tpl_amd.DynProgLonPlanner(device)
             dp.reinit_buffers(p)
-            if key == "contracted":                        # rule R1 = 1 (a template variant of the same kernel; divisions (5, 5))
-                dp.set_contraction(True)
+            if key == "unfused":                           # rule R1 = 0 (a template variant of the same kernel, same division forms)
+                dp.set_contraction(False)
             if key == "truncated_weights":                 # rule R2 = floor
                 dp.set_filter_rule(2, 0)
             if key in ("order_sva", "sum8_f32", "sum8_wide"):   # rule R3's order / form (set_blend_order): eight taps per cell-action
@@ -567,6 +600,9 @@ def worker(args):
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        if not rehearsal and torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+            raise SystemExit(f"bench.py --gpus {world}: this node shows {torch.cuda.device_count()} GPU(s) to rank {rank}; "
+                             f"one process per GPU needs {world} (lower --gpus, or widen HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES)")
         torch.cuda.set_device(local_rank)
         if rehearsal:
             dist.init_process_group("gloo")
@@ -602,29 +638,65 @@ def worker(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the batch of a step is dealt to PLANS_IN_FLIGHT planners, each with its own stream, tables and environment (the
-    # environment holds the distance map a plan writes): same scenario, same inputs -- so every planner must return the
-    # first one's trajectory bit for bit (checked below, outside the timed region)
+    # the batch of a step is dealt to PLANS_IN_FLIGHT planners, each with its own stream and tables, and with its own
+    # environments (an environment holds the distance map a plan writes) -- one per obstacle set of the deck.  Every plan
+    # gets its own (obstacle set, start state) pair, deterministic by plan index (scenario_deck / deal): upload() of the
+    # start state + plan_resident() on that set's environment, nothing waited for in between.
+    import tpl_amd
     in_flight = args.in_flight if args.in_flight is not None else (1 if args.grid == "config4" else PLANS_IN_FLIGHT)
     in_flight = max(1, min(in_flight, plans_per_step))
-    fleet = [(dp, env)] + [dp_setup(args.grid, local_rank, rank)[:2] for _ in range(in_flight - 1)]
+    occs, starts = scenario_deck(rank, ep)
+    fleet = []
+    for lane in range(in_flight):
+        q = dp if lane == 0 else dp_setup(args.grid, local_rank, rank)[0]
+        envs = []
+        for o in occs:
+            e = tpl_amd.DynProgEnvironment(local_rank)
+            e.reinit_buffers(ep)
+            e.set_occ_map(o)
+            envs.append(e)
+        fleet.append((q, envs))
+    del env
+    counter = [0]                                    # plans dealt so far (warm-up included: the deck keeps turning)
+    last = {}                                        # lane -> (obstacle set, start state) of its most recent plan
 
     def run(n_steps):
-        for i in range(n_steps * plans_per_step):
-            q, e = fleet[i % in_flight]
-            q.plan_resident(e)
+        for _ in range(n_steps * plans_per_step):
+            i = counter[0]
+            counter[0] += 1
+            lane = i % in_flight
+            q, envs = fleet[lane]
+            io, ist = deal(i, in_flight)
+            q.upload([starts[ist]], path)
+            q.plan_resident(envs[io])
+            last[lane] = (io, ist)
 
     def sync_all():
         for q, _ in fleet:
             q.sync()
 
+    def plan_hash(traj):
+        return sharding.plan_record(np.array([[s.t, s.s, s.v, s.a, s.j, s.cost, s.constr] for s in traj.states], dtype=np.float32), 0).tobytes()
+
+    # warm-up, first half: every pair of the deck once on the LAST lane's planner, one at a time -- the records the spot
+    # check after the timed region compares against (another planner, another moment, same bits)
+    want = {}
+    qa, ea = fleet[-1]
+    for io in range(len(occs)):
+        for ist in range(len(starts)):
+            qa.upload([starts[ist]], path)
+            qa.plan_resident(ea[io])
+            want[(io, ist)] = plan_hash(qa.download()[0])
+    assert len(set(want.values())) > len(want) // 2, "the deck's plans are (nearly) all the same: inputs are not varied"
     run(args.warmup)
     sync_all()
-    # the sweep kernel ALONE on the chip (one plan at a time on one stream): the launch duration the roofline's per-launch
-    # figures are quoted on -- with two plans in flight a launch shares the chip and its duration says little by itself
+    # the sweep kernel ALONE on the chip (one plan at a time on one stream, the deck's first four pairs): the launch
+    # duration the roofline's per-launch figures are quoted on -- with two plans in flight a launch shares the chip and
+    # its duration says little by itself
     dp.timing_enable(True)
-    for _ in range(4):
-        dp.plan_resident(env)
+    for k in range(4):
+        dp.upload([starts[k]], path)
+        dp.plan_resident(fleet[0][1][k])
     alone_ms, alone_launches = dp.timing_get()
     dp.timing_enable(False)
     setup_s = {"headline": time.perf_counter() - t_setup0}
@@ -647,11 +719,11 @@ def worker(args):
         ms, n = q.timing_get()
         sweep_ms, sweep_launches = sweep_ms + ms, sweep_launches + n
         q.timing_enable(False)
-    for q, _ in fleet[1:]:
-        other = q.download()[0]
-        assert all(tuple(getattr(x, f) for f in ("t", "s", "v", "a", "j", "cost", "constr")) ==
-                   tuple(getattr(y, f) for f in ("t", "s", "v", "a", "j", "cost", "constr"))
-                   for x, y in zip(traj.states, other.states)), "two planners in flight disagree on the same scenario"
+    # spot check: the LAST plan of every lane against the record of its (obstacle set, start state) pair from warm-up
+    spot = 0
+    for lane, (q, _) in enumerate(fleet):
+        assert plan_hash(q.download()[0]) == want[last[lane]], f"lane {lane}: plan of deck pair {last[lane]} differs from its warm-up record"
+        spot += 1
 
     rank_values = rank_plans = None
     if dist is not None:
@@ -684,10 +756,13 @@ def worker(args):
         per_launch_s = (sweep_ms / 1e3) / max(1, sweep_launches)
         alone_s = (alone_ms / 1e3) / max(1, alone_launches)
         own_launches = sweeps_per_plan * plans_per_step * args.steps
-        if in_flight == 1:
-            achieved = cells * BYTES_PER_CELL / per_launch_s / 1e9
-        else:
-            achieved = own_launches * cells * BYTES_PER_CELL / rank0_elapsed / 1e9
+        # `achieved` / `frac`: ALWAYS the per-launch figure SURVEY 8d prescribes -- algorithmic bytes of one launch / the
+        # kernel's duration alone on the chip (HIP events on the launching stream; with one plan in flight that is the
+        # timed region's own average, with two it is the four-plan run on one stream just before it).  What two plans in
+        # flight add is reported under `in_flight`, never mixed into `frac`.
+        launch_s = per_launch_s if in_flight == 1 else alone_s
+        achieved = cells * BYTES_PER_CELL / launch_s / 1e9
+        aggregate = own_launches * cells * BYTES_PER_CELL / rank0_elapsed / 1e9
         out = {
             "metric": "dp_stage_sweeps_per_s",
             "value": total_sweeps / elapsed,
@@ -703,33 +778,33 @@ def worker(args):
             "data": "synthetic",
             "config": {
                 "workload": f"DP (s,v,a) planner, {p.s_steps}x{p.v_steps}x{p.a_steps} grid, "
-                            f"{p.t_steps} stages, straight 200 m path, 5 moving obstacles; one step = {plans_per_step} plans, "
-                            f"each dist map + {sweeps_per_plan} backward sweeps + forward rollout",
+                            f"{p.t_steps} stages, straight 200 m path; one step = {plans_per_step} plans, each with its own start state "
+                            f"and one of 4 obstacle sets (28 pairs, dealt by plan index): upload + dist map + {sweeps_per_plan} backward sweeps + forward rollout",
                 "grid": [p.s_steps, p.v_steps, p.a_steps], "t_steps": p.t_steps,
                 "plans_per_step_per_gpu": plans_per_step, "ms_per_plan": elapsed / args.steps / plans_per_step * 1e3,
                 "plans_in_flight_per_gpu": in_flight,
+                # the HP-1 arithmetic contract the sweeps ran under (tplhip_dp_lon_info): R1 = 1 is nvcc's default
+                # contraction of the reference's device code, the best estimate of what the reference binary computes
+                "arithmetic": arithmetic_name(dp.info()),
+                "inputs": {"obstacle_sets": len(occs), "start_states": len(starts), "plans_spot_checked": spot},
                 "parallelism": f"independent plans x{world}" + (", one all-gather of the best plan" if world > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": sweep_kernel_name(dp.info()),
-                # the kernel's duration ALONE on the chip (HIP events; = per_launch_s with one plan in flight): what a trace of
-                # `--in-flight 1` lists.  With two in flight the events of a stream also span the waits behind the other
-                # stream's launches (`stream_us_per_launch`), and a trace lists start-to-end durations of launches that share
-                # the chip (profiles/README.md) -- neither is a duration the bytes of ONE launch can be divided by
-                "launch_us": (per_launch_s if in_flight == 1 else alone_s) * 1e6,
-                "stream_us_per_launch": per_launch_s * 1e6,
-                "effective_us_per_launch": rank0_elapsed / own_launches * 1e6,
+                # the kernel's duration ALONE on the chip (HIP events; the timed region's own average with one plan in flight): what
+                # a trace of `--in-flight 1` lists
+                "launch_us": launch_s * 1e6,
                 "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
-                "launches_in_flight": in_flight,
-                "achieved_is": ("algorithmic bytes per launch / the launch's HIP-event duration" if in_flight == 1 else
-                                f"algorithmic bytes of the rank's {own_launches} sweep launches / its timed region "
-                                f"({in_flight} plans in flight: the chip moves the bytes of overlapping launches; a lower bound, the region "
-                                "holds the fronts, rollouts and gaps too; `alone` is the prescribed per-launch figure)"),
-                # the same kernel alone on the chip (4 plans on one stream, outside the timed region): the contract's per-launch figure
-                "alone": {"launch_us": alone_s * 1e6, "achieved": cells * BYTES_PER_CELL / alone_s / 1e9,
-                          "frac": cells * BYTES_PER_CELL / alone_s / 1e9 / HBM_PEAK_GBS},
+                "achieved_is": "algorithmic bytes per launch / the launch's HIP-event duration alone on the chip"
+                               + ("" if in_flight == 1 else " (four plans on one stream just before the timed region)"),
+                # the whole timed region: with two plans in flight launches overlap for their whole life -- the events of a stream
+                # also span the waits behind the other stream's launches (`stream_us_per_launch`), and a trace lists start-to-end
+                # durations of launches that share the chip (profiles/README.md); the chip's rate is the bytes of ALL the rank's
+                # sweep launches / the region (a lower bound: the region holds uploads, fronts, rollouts and gaps too)
+                "in_flight": {"launches_in_flight": in_flight, "achieved": aggregate, "frac": aggregate / HBM_PEAK_GBS,
+                              "stream_us_per_launch": per_launch_s * 1e6, "effective_us_per_launch": rank0_elapsed / own_launches * 1e6},
                 # context only (`frac` stays against the prescribed 8 TB/s): what a plain copy kernel reaches on this part
                 "frac_of_measured_copy_rate": achieved / HBM_COPY_MEASURED_GBS,
                 "measured_copy_rate_source": "profiles/r03_micro_chip_peaks.txt (read 6.5, copy 4.9, triad 5.4 TB/s)",
@@ -745,7 +820,7 @@ def worker(args):
         traffic_block(out["roofline"], f"{p.s_steps}x{p.v_steps}x{p.a_steps}")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = dp_cpu_baseline(p, ep, path, occ)
-    del dp, env, fleet
+    del dp, fleet
 
     secondary = {}
     if not args.no_secondary:
@@ -795,6 +870,31 @@ def worker(args):
     if rank == 0:
         if secondary:
             out["secondary"] = secondary
+            # BASELINE's metric has three parts: "DP stage-sweeps/s + batched iLQR iters/s; p50 plan latency".  `value` is the
+            # first; the other two are mirrored from `secondary` into objects the driver's record keeps
+            il = secondary["batched_ilqr"]
+            ilr = il["roofline"]
+            out["roofline"]["ilqr"] = {
+                "value": il["value"], "unit": il["unit"], "config": il["config"]["workload"], "dtype": il["dtype"],
+                "problem_iterations_per_s": il["problem_iterations_per_s"],
+                "bound": ilr["bound"], "achieved": ilr["achieved"], "peak": ilr["peak"], "roofline_unit": ilr["unit"], "frac": ilr["frac"],
+                "kernel": ilr["kernel"], "ms_per_update": il["ms_per_update"], "kernel_ms_per_update": il["kernel_ms_per_update"],
+                "update_call_ms": il.get("update_call_ms"), "n_gpus": il.get("n_gpus", 1),
+            }
+            if "cpu_baseline" in il:
+                out["roofline"]["ilqr"]["cpu_baseline"] = il["cpu_baseline"]
+            if "plan_latency" in secondary:
+                pl = secondary["plan_latency"]
+                lat = {"dp_default_grid": pl["dp_default_plan"]["p50_ms"], "mpc_tick": pl["mpc_closed_loop"]["p50_ms"],
+                       "env_update": pl["env_update"]["p50_ms"], "poly_lat_update": pl["poly_lat_update"]["p50_ms"],
+                       "lat_lon_update": pl["lat_lon_update"]["p50_ms"],
+                       "what": "p50 wall time of one call through the drop-in surface, host buffers in and out (benchkit/latency.py); "
+                               "dp_default_grid = DynProgLonPlanner.update on the reference's default 201x37x20x10 grid, "
+                               "mpc_tick = Optim.update() of the tracking MPC (N = 20) in the closed loop of configs[0]"}
+                cb = pl["mpc_closed_loop"].get("cpu_baseline")
+                if cb:
+                    lat["mpc_tick_cpu_baseline"] = cb.get("p50_ms", cb.get("value"))
+                out["config"]["p50_plan_latency_ms"] = lat
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -213,27 +213,37 @@ TPLHIP_API int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n);
  *   lerp_form     0 = fma(q, w, p * (1 - w)) (default), 1 = p * (1 - w) + q * w (every operation rounded), 2 = p + w * (q - p)
  * The plain-fp32 sweeps are built for all nine combinations: the choice of kernel does not depend on the rule. */
 TPLHIP_API int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_form);
-/* Rule R1 of the same contract: 0 (default) = one IEEE rounding per operation of the reference source, 1 = the
- * multiply-adds nvcc contracts by default in device code (-fmad=true: library/CMakeLists.txt passes nothing else to
- * nvcc), written out as fma() calls -- lonDynamics (lon_planner.cu:240-250), interpPath (common.cuh:124-136), the grid
- * points (lon_planner.cu:196-199, env.cu:144), s_dist and the cost sums of evalNode (lon_planner.cu:40-65, 84, 110,
- * 148).  Deterministic (no compiler decides): oracle/dp_lon_oracle.c built -DDPO_R1_FMA=1 is the same arithmetic.
- * Every kernel honours it (template variants of the plain-fp32 sweeps): the choice of kernel does not change.
- * This is a MODEL of nvcc's fusion -- the sites and the operand order (fma(a, b, c*d), left to right) are placed by hand
- * on both sides, so bit parity is proven against this repository's restatement, not against an nvcc build -- until it
- * has been checked against a dump or the SASS of the reference build ("Pinning HP-1").  The default
- * stays 0, which is NOT what the reference binary most likely computes. */
+/* Rule R1 of the same contract: 1 (DEFAULT since round 6) = the multiply-adds nvcc contracts by default in device code
+ * (-fmad=true: library/CMakeLists.txt:89-99 passes nothing else to nvcc; its -ffast-math reaches the host compiler only),
+ * written out as fma() calls -- lonDynamics (lon_planner.cu:240-250), interpPath (common.cuh:124-136), the grid points
+ * (lon_planner.cu:196-199, env.cu:144), s_dist and the cost sums of evalNode (lon_planner.cu:40-65, 84, 110, 148);
+ * 0 = one IEEE rounding per operation of the reference source (the default until round 5).  Deterministic (no compiler
+ * decides): oracle/dp_lon_oracle.c under dpo_set_rule(., ., on, .) is the same arithmetic.  Every kernel honours it; the
+ * plain-fp32 sweeps are built with every division form for BOTH settings, so neither the choice of kernel nor its speed
+ * depends on it.  R1 = 1 is a MODEL of nvcc's fusion -- the sites and the operand order (fma(a, b, c*d), left to right) are
+ * placed by hand on both sides, so bit parity is proven against this repository's restatement, not against an nvcc build --
+ * until it has been checked against a dump or the SASS of the reference build ("Pinning HP-1").  The host
+ * helpers tplhip_lon_dynamics / tplhip_lon_traj_state are the HOST instantiation of the reference's function (compiled for
+ * baseline x86-64, which has no fused multiply-add): one rounding per operation whatever this switch says. */
 TPLHIP_API int tplhip_dp_lon_set_contraction(tplhip_dp_lon* h, int on);
 /* Rule R3's ORDER and form (round 5).  The texture unit behind tex3D (lon_planner.cu:26-38, arr_tex_surf.cuh:142-149)
  * blends eight texels; the default contract freezes three sequential 1-D blends along a, then v, then s.  The hardware's
  * documentation gives the symmetric weighted sum of the eight corners, and a sequential implementation would as plausibly
  * start with x (= s).  order: 0 = a -> v -> s (default), 1 = s -> v -> a, 2 = sum of w_c T_c over the eight corners with
  * exact weight products and an fp32 accumulator in the order of the documented formula (corner = s + 2 v + 4 a), 3 = the
- * same sum accumulated wide and rounded once (lerp_form does not apply to 2 and 3).  oracle/dp_lon_oracle.c built
- * -DDPO_BLEND_ORDER=order is the same arithmetic; tests/test_dp_reference_golden.py lists the variants a dump is scored
- * against.  Honoured by every kernel of the planner; the plain-fp32 sweeps exist for order 0 only, so a plan under
- * another order runs the general sweep (tplhip_dp_lon_info -> "sweep": "k_backward"). */
+ * same sum accumulated wide and rounded once (lerp_form does not apply to 2 and 3).  oracle/dp_lon_oracle.c under
+ * dpo_set_rule(., ., ., order) is the same arithmetic; tests/test_dp_reference_golden.py lists the variants a dump is scored
+ * against.  Honoured by every kernel of the planner.  The large-grid sweep has its own form for another order
+ * (tplhip_dp_lon_info -> "sweep": "k_backward3o": weight rules rint / floor, row buffers + path <= 64 KB of LDS, on every
+ * grid); un-quantised weights under another order, and inputs the plain-fp32 sweeps refuse, take the general sweep
+ * ("k_backward"). */
 TPLHIP_API int tplhip_dp_lon_set_blend_order(tplhip_dp_lon* h, int order);
+/* Diagnostics, host only (works without a GPU): 1 if a plain-fp32 sweep instance is built for this arithmetic rule and this
+ * pair of division forms (4 = one multiplication, 3 = two-float reciprocal, 5 = reciprocal + Newton step, 0 = IEEE division),
+ * else 0.  kind 1 = the two-rows-per-lane sweep (k_backward3v; k_backward3o when order != 0), 2 = one cell per lane
+ * (k_backward3s).  The planner only ever selects built combinations (tests/test_capi.py walks them all); should that ever
+ * drift, a stage without an instance is swept by the general kernel, never skipped. */
+TPLHIP_API int tplhip_dp_lon_sweep_built(int weight_quant, int lerp_form, int contraction, int order, int path_div, int range_div, int kind);
 /* HIP-event timing of the backward sweeps (events recorded on the planner's
  * stream around the loop of launches).  enable=1 starts accumulating; get
  * returns the summed ms and the number of sweep launches since enable. */

@@ -43,67 +43,63 @@ typedef struct { float x, y, z, w; } f4;
 
 static int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 static float sq(float x) { return x * x; }
-/* The texture filter's frozen choices as build switches, exactly those of oracle/dp_lon_oracle.c (rules R2, R3 and R3's order):
- *   -DLLO_WEIGHT_QUANT=1 rint (default) | 2 floor | 0 none      -DLLO_LERP_FORM=0 fma(q, w, p(1-w)) (default) | 1 | 2
- *   -DLLO_BLEND_ORDER=0 z -> y -> x (default: the slowest axis first) | 1 x -> y -> z | 2 eight-corner sum, fp32 | 3 the sum, wide
+/* The texture filter's frozen choices as RUN-TIME state (round 6; build switches until round 5), exactly those of
+ * oracle/dp_lon_oracle.c (rules R2, R3 and R3's order):
+ *   quant  1 rint (default) | 2 floor | 0 none            lerp  0 fma(q, w, p(1-w)) (default) | 1 | 2
+ *   order  0 z -> y -> x (default: the slowest axis first) | 1 x -> y -> z | 2 eight-corner sum, fp32 | 3 the sum, wide
  * They act on every filtered fetch of this planner: the value tables (x = s, y = ds, z = l), the longitudinal distance map
- * (x = t, y = s, z = l) and the 1-D reference-line texture.  tplhip_lat_lon_set_filter_rule is the same choice on the HIP side. */
-#ifndef LLO_WEIGHT_QUANT
-#define LLO_WEIGHT_QUANT 1
-#endif
-#ifndef LLO_LERP_FORM
-#define LLO_LERP_FORM 0
-#endif
-#ifndef LLO_BLEND_ORDER
-#define LLO_BLEND_ORDER 0
-#endif
+ * (x = t, y = s, z = l) and the 1-D reference-line texture.  llo_set_rule selects the rule for all later calls of this library
+ * (process-wide); tplhip_lat_lon_set_filter_rule is the same choice on the HIP side.  The file is built -ffp-contract=off:
+ * every operation below keeps its own rounding. */
+typedef struct { int quant, lerp, order; } LloRule;
+static LloRule g_rule = { 1, 0, 0 };
+
+LLO_API int llo_set_rule(int quant, int lerp, int order)
+{
+    if (quant < 0 || quant > 2 || lerp < 0 || lerp > 2 || order < 0 || order > 3) return -1;
+    g_rule.quant = quant; g_rule.lerp = lerp; g_rule.order = order;
+    return 0;
+}
+
+LLO_API void llo_get_rule(int out[3]) { out[0] = g_rule.quant; out[1] = g_rule.lerp; out[2] = g_rule.order; }
+
 static float lerp1(float p, float q, float w)
 {
-#if LLO_LERP_FORM == 0
+    if (g_rule.lerp == 1) { const float a = p * (1.0f - w), b = q * w; return a + b; }
+    if (g_rule.lerp == 2) { const float d = q - p; const float e = w * d; return p + e; }
     return fmaf(q, w, p * (1.0f - w));
-#elif LLO_LERP_FORM == 1
-    volatile float a = p * (1.0f - w), b = q * w;
-    return a + b;
-#else
-    volatile float d = q - p;
-    volatile float e = w * d;
-    return p + e;
-#endif
 }
 
 /* sum of w[c] t[c] in index order: fp32 accumulator (every product and sum rounded) or exact products in a double accumulator */
-#if LLO_BLEND_ORDER >= 2
 static float wsum(const float* w, const float* t, int n)
 {
-#if LLO_BLEND_ORDER == 3
-    double acc = (double)w[0] * (double)t[0];
-    for (int c = 1; c < n; ++c) acc += (double)w[c] * (double)t[c];
-    return (float)acc;
-#else
-    volatile float acc = w[0] * t[0];
-    for (int c = 1; c < n; ++c) { volatile float pr = w[c] * t[c]; acc = acc + pr; }
+    if (g_rule.order == 3) {
+        double acc = (double)w[0] * (double)t[0];
+        for (int c = 1; c < n; ++c) acc += (double)w[c] * (double)t[c];
+        return (float)acc;
+    }
+    float acc = w[0] * t[0];
+    for (int c = 1; c < n; ++c) { const float pr = w[c] * t[c]; acc = acc + pr; }
     return acc;
-#endif
 }
-#endif
 
 /* rule R3 over the eight corners t[x + 2 y + 4 z] with the weights of the three axes */
 static float blend8(const float* t, float wx, float wy, float wz)
 {
-#if LLO_BLEND_ORDER == 0
-    float lo = lerp1(lerp1(t[0], t[4], wz), lerp1(t[2], t[6], wz), wy);          /* z, then y, then x */
-    float hi = lerp1(lerp1(t[1], t[5], wz), lerp1(t[3], t[7], wz), wy);
-    return lerp1(lo, hi, wx);
-#elif LLO_BLEND_ORDER == 1
-    float y0 = lerp1(lerp1(t[0], t[1], wx), lerp1(t[2], t[3], wx), wy);          /* x, then y, then z */
-    float y1 = lerp1(lerp1(t[4], t[5], wx), lerp1(t[6], t[7], wx), wy);
-    return lerp1(y0, y1, wz);
-#else
+    if (g_rule.order == 0) {
+        float lo = lerp1(lerp1(t[0], t[4], wz), lerp1(t[2], t[6], wz), wy);          /* z, then y, then x */
+        float hi = lerp1(lerp1(t[1], t[5], wz), lerp1(t[3], t[7], wz), wy);
+        return lerp1(lo, hi, wx);
+    }
+    if (g_rule.order == 1) {
+        float y0 = lerp1(lerp1(t[0], t[1], wx), lerp1(t[2], t[3], wx), wy);          /* x, then y, then z */
+        float y1 = lerp1(lerp1(t[4], t[5], wx), lerp1(t[6], t[7], wx), wy);
+        return lerp1(y0, y1, wz);
+    }
     const float x2[2] = {1.0f - wx, wx}, y2[2] = {1.0f - wy, wy}, z2[2] = {1.0f - wz, wz};
     float w[8];
-    for (int c = 0; c < 8; ++c) { volatile float xy = x2[c & 1] * y2[(c >> 1) & 1]; w[c] = xy * z2[c >> 2]; }
+    for (int c = 0; c < 8; ++c) { const float xy = x2[c & 1] * y2[(c >> 1) & 1]; w[c] = xy * z2[c >> 2]; }
     return wsum(w, t, 8);
-#endif
 }
 
 static Tap make_tap(float x_plus_half, int n)
@@ -112,13 +108,9 @@ static Tap make_tap(float x_plus_half, int n)
     float xb = x_plus_half - 0.5f;
     float fl = floorf(xb);
     float alpha = xb - fl;
-#if LLO_WEIGHT_QUANT == 1
-    t.w = rintf(alpha * 256.0f) / 256.0f;
-#elif LLO_WEIGHT_QUANT == 2
-    t.w = floorf(alpha * 256.0f) / 256.0f;
-#else
-    t.w = alpha;
-#endif
+    if (g_rule.quant == 1)      t.w = rintf(alpha * 256.0f) / 256.0f;
+    else if (g_rule.quant == 2) t.w = floorf(alpha * 256.0f) / 256.0f;
+    else                        t.w = alpha;
     int i = (int)fminf(fmaxf(fl, -1.0f), (float)n);
     t.i0 = clampi(i, 0, n - 1);
     t.i1 = clampi(i + 1, 0, n - 1);
@@ -156,13 +148,13 @@ static f4 tex_lerp(const Ctx* c, float s)
 {
     Tap t = make_tap(s / c->ref_step + 0.5f, c->n_ref);
     f4 a = c->ref_tex[t.i0], b = c->ref_tex[t.i1], r;
-#if LLO_BLEND_ORDER >= 2
-    const float w2[2] = {1.0f - t.w, t.w};
-    const float vx[2] = {a.x, b.x}, vy[2] = {a.y, b.y}, vz[2] = {a.z, b.z}, vw[2] = {a.w, b.w};
-    r.x = wsum(w2, vx, 2); r.y = wsum(w2, vy, 2); r.z = wsum(w2, vz, 2); r.w = wsum(w2, vw, 2);
-#else
-    r.x = lerp1(a.x, b.x, t.w); r.y = lerp1(a.y, b.y, t.w); r.z = lerp1(a.z, b.z, t.w); r.w = lerp1(a.w, b.w, t.w);
-#endif
+    if (g_rule.order >= 2) {
+        const float w2[2] = {1.0f - t.w, t.w};
+        const float vx[2] = {a.x, b.x}, vy[2] = {a.y, b.y}, vz[2] = {a.z, b.z}, vw[2] = {a.w, b.w};
+        r.x = wsum(w2, vx, 2); r.y = wsum(w2, vy, 2); r.z = wsum(w2, vz, 2); r.w = wsum(w2, vw, 2);
+    } else {
+        r.x = lerp1(a.x, b.x, t.w); r.y = lerp1(a.y, b.y, t.w); r.z = lerp1(a.z, b.z, t.w); r.w = lerp1(a.w, b.w, t.w);
+    }
     return r;
 }
 

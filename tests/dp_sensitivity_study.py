@@ -2,10 +2,10 @@
 """How far do the frozen arithmetic rules of the HP-1 restatement move its results?
 
 The reference's DP (s,v,a) planner is CUDA (nvcc + texture hardware) and cannot run here, so the
-oracle freezes three choices the reference BINARY may make differently (oracle/dp_lon_oracle.c,
-rules R1-R3): no FMA contraction, texture weights rounded to 8 fractional bits with rint, blend
-formula fma(q, w, p(1-w)).  This script builds the oracle with each choice flipped
-(``make -C oracle sensitivity``) and measures, against the default build on identical inputs:
+oracle freezes choices the reference BINARY may make differently (oracle/dp_lon_oracle.c, rules
+R1-R3): which multiply-adds are contracted, texture weights rounded to 8 fractional bits with rint,
+blend formula fma(q, w, p(1-w)), blend order a -> v -> s.  This script runs the ONE checker library
+under each choice flipped (dpo_set_rule) and measures, against the default rule on identical inputs:
 
   * the fraction of value-table cells whose ARGMIN JERK differs (stored per cell, all stages),
   * the largest relative difference of the stored cost / constraint values,
@@ -13,15 +13,13 @@ formula fma(q, w, p(1-w)).  This script builds the oracle with each choice flipp
     nodes whose chosen jerk differs,
 
 on BASELINE configs[1] (128x64x32, 50 stages) and on the reference's default grid (201x37x20, 10
-stages).  Output: profiles/r02_dp_parity_sensitivity.json and a markdown table on stdout (pasted
-into DESIGN.md).  Test infrastructure: runs in the build container only (the variant libraries need
-FMA3 hardware and are not shipped).
+stages).  Output: profiles/r06_dp_parity_sensitivity.json and a markdown table on stdout (DESIGN.md
+2.4).  Since round 6 the BASE is the contracted default (R1 = 1); rounds 2-5 measured against R1 = 0.
 
-    python tests/dp_sensitivity_study.py [--quick]
+    python tests/dp_sensitivity_study.py [--quick] [--variants=a,b]
 """
 import json
 import os
-import subprocess
 import sys
 
 import numpy as np
@@ -34,18 +32,16 @@ import oracle_dp as O                      # noqa: E402
 from benchkit import scenarios as sc        # noqa: E402
 
 VARIANTS = [
-    ("fma", "FMA contraction like nvcc -fmad=true (gcc -ffp-contract=fast -mfma)"),
-    ("wfloor", "filter weight truncated to 8 fractional bits (floor) instead of rint"),
-    ("wnone", "un-quantised filter weights"),
-    ("lerp1", "blend p(1-w) + qw, every operation rounded"),
-    ("lerp2", "blend p + w(q-p)"),
-    ("fma_wfloor", "FMA contraction AND truncated weights"),
-    ("fma_explicit", "R1 flipped deterministically: the multiply-adds nvcc -fmad=true contracts, written out as fma() (-DDPO_R1_FMA=1)"),
-    ("fma_explicit_wfloor", "explicit contraction AND truncated weights"),
+    ("unfused", dict(fma=0), "R1 = 0: one rounding per source operation, nothing contracted (the default of rounds 1-5)"),
+    ("wfloor", dict(quant=2), "filter weight truncated to 8 fractional bits (floor) instead of rint"),
+    ("wnone", dict(quant=0), "un-quantised filter weights"),
+    ("lerp1", dict(lerp=1), "blend p(1-w) + qw, every operation rounded"),
+    ("lerp2", dict(lerp=2), "blend p + w(q-p)"),
+    ("unfused_wfloor", dict(fma=0, quant=2), "nothing contracted AND truncated weights"),
     # rule R3's ORDER and the symmetric form (round 5)
-    ("order_sva", "blend ORDER s -> v -> a (x first) instead of a -> v -> s, same 1-D lerp (-DDPO_BLEND_ORDER=1)"),
-    ("sum8_f32", "symmetric eight-corner sum, exact weight products, fp32 accumulator in the order of the documented formula (-DDPO_BLEND_ORDER=2)"),
-    ("sum8_wide", "the same sum with exact products in a double accumulator, one rounding (-DDPO_BLEND_ORDER=3)"),
+    ("order_sva", dict(order=1), "blend ORDER s -> v -> a (x first) instead of a -> v -> s, same 1-D lerp"),
+    ("sum8_f32", dict(order=2), "symmetric eight-corner sum, exact weight products, fp32 accumulator in the order of the documented formula"),
+    ("sum8_wide", dict(order=3), "the same sum with exact products in a double accumulator, one rounding"),
 ]
 
 CASES = {
@@ -106,23 +102,21 @@ def compare(base, var):
 def main():
     quick = "--quick" in sys.argv
     only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--variants=")]
-    variants = [(v, d) for v, d in VARIANTS if not only or v in only[0]]
+    variants = [(v, kw, d) for v, kw, d in VARIANTS if not only or v in only[0]]
     n_inits = 8 if quick else 64
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "sensitivity"], stdout=subprocess.DEVNULL)
     out = {"what": __doc__.split("\n\n")[0], "initial_states_per_case": n_inits, "cases": {}}
     for cname, case in CASES.items():
         if quick and "config2" in cname:
             continue
-        O.use(None)
+        O.set_rule()
         base = plan(case, n_inits)
         res = {}
-        for v, desc in variants:
-            O.use(os.path.join(ROOT, "oracle", "_sens", f"libdp_lon_oracle_{v}.so"))
-            res[v] = dict(compare(base, plan(case, n_inits)), variant=desc)
+        for v, kw, desc in variants:
+            with O.rule(**kw):
+                res[v] = dict(compare(base, plan(case, n_inits)), variant=desc, rule=O.get_rule() if False else dict(O.DEFAULT_RULE, **kw))
             print(f"[{cname}] {v}: {res[v]}", file=sys.stderr, flush=True)
-        O.use(None)
         out["cases"][cname] = res
-    dst = os.path.join(ROOT, "profiles", "r05_dp_parity_sensitivity.json" if only else "r02_dp_parity_sensitivity.json")
+    dst = os.path.join(ROOT, "profiles", "r06_dp_parity_sensitivity.json")
     if not quick:
         with open(dst, "w") as fd:
             json.dump(out, fd, indent=1)

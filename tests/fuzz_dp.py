@@ -8,9 +8,9 @@ tool; tests/test_dp_gpu.py::test_fuzz_sample runs a short sample of it).
 
 --rules: every case also draws one of the 18 arithmetic rule combinations (R2 weight rule x R3 blend form x R1
 contraction: set_filter_rule / set_contraction) and is compared with the oracle build that makes the same choices
-(oracle/Makefile: _sens/libdp_lon_oracle_r<quant><lerp><fma>.so, built on demand).
+(the ONE checker library under dpo_set_rule(quant, lerp, fma, order)).
 --orders: with --rules, every case also draws R3's blend order (set_blend_order: 0 a->v->s, 1 s->v->a, 2 / 3 the
-eight-corner sums; _sens/libdp_lon_oracle_r<quant><lerp><fma>o<order>.so) -- 72 combinations."""
+eight-corner sums) -- 72 combinations."""
 import os
 import sys
 
@@ -61,15 +61,6 @@ def random_case(seed):
     return p, ep, path.astype(np.float32), occ, inits
 
 
-def rule_oracle(quant, lerp, fma, order=0):
-    import subprocess
-    odir = os.path.join(O.ROOT, "oracle")
-    rel = f"_sens/libdp_lon_oracle_r{quant}{lerp}{fma}" + (f"o{order}" if order else "") + ".so"
-    if not os.path.exists(os.path.join(odir, rel)):
-        subprocess.check_call(["make", "-s", "-C", odir, rel])
-    return os.path.join(odir, rel)
-
-
 def run_case(seed, rules=False, orders=False):
     p, ep, path, occ, inits = random_case(seed)
     env = tpl_amd.DynProgEnvironment()
@@ -84,13 +75,13 @@ def run_case(seed, rules=False, orders=False):
         dp.set_contraction(bool(rule[2]))
         dp.set_filter_rule(rule[0], rule[1])
         dp.set_blend_order(rule[3])
-        O.use(rule_oracle(*rule))
+        O.set_rule(quant=rule[0], lerp=rule[1], fma=rule[2], order=rule[3])
     trajs = dp.update_batch(inits, path, env)
     try:
         tables, otrajs, dist = O.update(O.cparams(p), O.cparams(ep), path, occ, inits)
     finally:
         if rules:
-            O.use(None)
+            O.set_rule()
     assert np.array_equal(env.get_dist_map_path().view(np.uint32), dist.view(np.uint32)), f"seed {seed}: distance map"
     for t in range(1, p.t_steps):
         got = dp.copy_table(t)

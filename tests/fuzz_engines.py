@@ -96,14 +96,14 @@ def run_scene(seed, rules=False):
     if rules:
         rule = (int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 4)))
         ll.set_filter_rule(*rule)
-        oll.use(oll.variant(*rule))
+        oll.set_rule(*rule)
     ll.traj_dp[0] = st
     ll.update_traj_dp(env)
     try:
         tables, otraj = oll.update_traj_dp(qp, o.c, dl, o.ref, o.step, st)
     finally:
         if rules:
-            oll.use(None)
+            oll.set_rule()
     for t in range(1, qp.t_steps):
         g = ll.copy_backward_pass_tex(t)
         assert np.array_equal(g.view(np.uint32), tables[t].view(np.uint32)), f"seed {seed}: (s,ds,l) stage {t}"

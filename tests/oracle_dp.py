@@ -28,11 +28,59 @@ def lib():
 
 
 def use(path=None):
-    """Route this module's helpers through another build of the same restatement: a sensitivity
-    variant (oracle/_sens/, see the header of dp_lon_oracle.c) or the -O3 -march=native build the
-    cpu_baseline leg times (oracle/_native/).  ``None`` returns to the default checker."""
+    """Route this module's helpers through another BUILD of the same restatement: the -O3 -march=native
+    build the cpu_baseline leg times (oracle/_native/).  ``None`` returns to the default checker.  (The
+    arithmetic rules are run-time state of the one library: see ``rule``.)"""
     global _lib
     _lib = None if path is None else _declare(C.CDLL(path))
+
+
+# The arithmetic rule (R1 contraction, R2 weight quantisation, R3 blend form and order: header of
+# oracle/dp_lon_oracle.c) is a run-time setting of the ONE checker library.  DEFAULT_RULE is what the library
+# starts with and what the HIP planner computes by default; names are the ones DESIGN.md / the dump's variant
+# table use.
+DEFAULT_RULE = dict(quant=1, lerp=0, fma=1, order=0)
+NAMED_RULES = {
+    "default": {},
+    "unfused": dict(fma=0),                       # one rounding per source operation (the default until round 5)
+    "wfloor": dict(quant=2), "wnone": dict(quant=0),
+    "lerp1": dict(lerp=1), "lerp2": dict(lerp=2),
+    "order_sva": dict(order=1), "sum8_f32": dict(order=2), "sum8_wide": dict(order=3),
+}
+
+
+def set_rule(quant=None, lerp=None, fma=None, order=None):
+    """Select the rule every later call of the checker follows; arguments left out take DEFAULT_RULE."""
+    r = dict(DEFAULT_RULE)
+    for k, v in (("quant", quant), ("lerp", lerp), ("fma", fma), ("order", order)):
+        if v is not None:
+            r[k] = int(v)
+    rc = lib().dpo_set_rule(r["quant"], r["lerp"], r["fma"], r["order"])
+    assert rc == 0, f"dpo_set_rule refused {r}"
+    return r
+
+
+def get_rule():
+    out = (C.c_int * 4)()
+    lib().dpo_get_rule(out)
+    return dict(quant=out[0], lerp=out[1], fma=out[2], order=out[3])
+
+
+class rule:
+    """``with O.rule(fma=0, order=2): ...`` -- the checker under another rule, the default rule restored on exit.
+    ``O.rule("wfloor", fma=0)`` starts from a named rule."""
+
+    def __init__(self, name=None, **kw):
+        r = dict(NAMED_RULES[name or "default"])
+        r.update(kw)
+        self.r = r
+
+    def __enter__(self):
+        return set_rule(**self.r)
+
+    def __exit__(self, *exc):
+        set_rule()
+        return False
 
 
 def _declare(l):
@@ -41,6 +89,12 @@ def _declare(l):
         l.dpo_interp_dist_map_path.argtypes = [C.POINTER(TplDpEnvParams), _fp, C.c_float, C.c_float]
         l.dpo_table_floats.restype = C.c_size_t
         l.dpo_lon_dynamics.argtypes = [C.POINTER(TplLonState), C.c_float, C.c_float, C.POINTER(TplLonState)]
+        l.dpo_lon_dynamics_host.argtypes = [C.POINTER(TplLonState), C.c_float, C.c_float, C.POINTER(TplLonState)]
+        l.dpo_grid_point.restype = C.c_float
+        l.dpo_grid_point.argtypes = [C.c_float, C.c_float, C.c_float]
+        l.dpo_set_rule.restype = C.c_int
+        l.dpo_set_rule.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        l.dpo_get_rule.argtypes = [C.POINTER(C.c_int)]
         l.dpo_interp_path.argtypes = [_fp, C.c_float, C.c_float, C.c_int, C.POINTER(TplPathState)]
         l.dpo_read_node.argtypes = [C.POINTER(TplDpLonParams), _fp, C.c_float, C.c_float, C.c_float, _fp]
         l.dpo_eval_node.argtypes = [C.POINTER(TplDpLonParams), C.POINTER(TplDpEnvParams), C.c_int,
@@ -59,6 +113,11 @@ def _declare(l):
         l.dpo_update_step_sizes.argtypes = [C.POINTER(TplDpLonParams)]
         l.dpo_env_update_step_sizes.argtypes = [C.POINTER(TplDpEnvParams)]
     return l
+
+
+def grid_point(x_min, i, step):
+    """Grid point i of an axis as the sweep forms it (lon_planner.cu:196-199) under the current rule R1."""
+    return lib().dpo_grid_point(np.float32(x_min), np.float32(i), np.float32(step))
 
 
 def fptr(a):

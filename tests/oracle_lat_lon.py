@@ -18,32 +18,41 @@ STATE_F = ("t", "s", "ds", "dds", "ddds", "l", "dl", "ddl", "dddl", "cost", "con
 CART_F = ("t", "distance", "x", "y", "v", "a", "heading", "k", "cost", "constr", "flags_constr")
 
 
-_path = LIB
+DEFAULT_RULE = (1, 0, 0)
 
 
-def use(path=None):
-    """Switch to another build of the restatement (a texture-filter variant under oracle/_sens/: built on demand), or back to the
-    default with None."""
-    global _lib, _path
-    _path = path or LIB
-    _lib = None
-    if path and not os.path.exists(path):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), os.path.relpath(path, os.path.join(ROOT, "oracle"))])
+def set_rule(quant=1, lerp=0, order=0):
+    """The texture-filter rule (R2 weight rule, R3 blend form and order: header of oracle/lat_lon_oracle.c) every later call of
+    the ONE checker library follows; without arguments, the default."""
+    assert lib().llo_set_rule(int(quant), int(lerp), int(order)) == 0, (quant, lerp, order)
 
 
-def variant(quant, lerp, order):
-    return os.path.join(ROOT, "oracle", "_sens", f"liblat_lon_oracle_r{quant}{lerp}o{order}.so")
+class rule:
+    """``with oll.rule(quant, lerp, order): ...`` -- the checker under another filter rule, the default restored on exit."""
+
+    def __init__(self, quant=1, lerp=0, order=0):
+        self.r = (quant, lerp, order)
+
+    def __enter__(self):
+        set_rule(*self.r)
+        return self.r
+
+    def __exit__(self, *exc):
+        set_rule()
+        return False
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_path):
+        if not os.path.exists(LIB):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liblat_lon_oracle.so"])
-        l = C.CDLL(_path)
+        l = C.CDLL(LIB)
         PP, EP, SP, CP = (C.POINTER(TplLatLonParams), C.POINTER(TplDpEnvParams), C.POINTER(TplLatLonState),
                           C.POINTER(TplLatLonCartState))
         l.llo_dynamics.argtypes = [SP, C.c_float, C.c_float, C.c_float, SP]
+        l.llo_set_rule.restype = C.c_int
+        l.llo_set_rule.argtypes = [C.c_int, C.c_int, C.c_int]
         l.llo_update_traj_dp.argtypes = [PP, EP, _fp, _dp, C.c_int, C.c_float, _fp, SP]
         l.llo_reeval_traj.argtypes = [PP, EP, _fp, _dp, C.c_int, C.c_float, SP, C.c_int]
         l.llo_traj_state.argtypes = [SP, C.c_int, C.c_float, SP]

@@ -110,17 +110,9 @@ def test_skewed_traversal_writes_every_row(S, V, A, T, order, monkeypatch):
     dp.reinit_buffers(p)
     if order:
         dp.set_blend_order(order)
-        import os
-        import subprocess
-        lib = os.path.join(O.ROOT, "oracle", f"_sens/libdp_lon_oracle_r100o{order}.so")
-        if not os.path.exists(lib):
-            subprocess.check_call(["make", "-s", "-C", os.path.join(O.ROOT, "oracle"), f"_sens/libdp_lon_oracle_r100o{order}.so"])
-        O.use(lib)
-    try:
-        trajs = dp.update_batch(inits, path, env)
+    trajs = dp.update_batch(inits, path, env)
+    with O.rule(order=order):
         tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, inits)
-    finally:
-        O.use(None)
     info = dp.info()
     assert info["sweep"] == ("k_backward3o" if order else "k_backward3v") and info["skew_pairs_per_a_row"] > 0.0, info
     _assert_tables_equal(dp, tables, T)
@@ -293,10 +285,10 @@ def test_full_size_spot_checks(grid):
         ia = rng.integers(0, A, n); iv = rng.integers(0, V, n); i_s = rng.integers(0, S, n)
         for k in range(n):
             tp = TplLonState()
-            tp.t = np.float32(cp.dt_start) + np.float32(t - 1) * np.float32(cp.dt)
-            tp.s = np.float32(cp.s_min) + np.float32(i_s[k]) * np.float32(cp._s_step_size)
-            tp.v = np.float32(cp.v_min) + np.float32(iv[k]) * np.float32(cp._v_step_size)
-            tp.a = np.float32(cp.a_min) + np.float32(ia[k]) * np.float32(cp._a_step_size)
+            tp.t = O.grid_point(cp.dt_start, t - 1, cp.dt)
+            tp.s = O.grid_point(cp.s_min, i_s[k], cp._s_step_size)
+            tp.v = O.grid_point(cp.v_min, iv[k], cp._v_step_size)
+            tp.a = O.grid_point(cp.a_min, ia[k], cp._a_step_size)
             O.lib().dpo_eval_node(C.byref(cp), C.byref(cep), 9, C.byref(tp), O.fptr(nxt), O.fptr(path),
                                   O.fptr(dist), cp.dt, 1, 1 if t == T - 1 else 0)
             want = np.array([tp.cost, tp.constr, tp.j, 0.0], dtype=np.float32)
@@ -313,10 +305,10 @@ def test_full_size_spot_checks(grid):
         for ia in range(A):
             for iv in range(V):
                 tp = TplLonState()
-                tp.t = np.float32(cp.dt_start) + np.float32(t - 1) * np.float32(cp.dt)
-                tp.s = np.float32(cp.s_min) + np.float32(i_s) * np.float32(cp._s_step_size)
-                tp.v = np.float32(cp.v_min) + np.float32(iv) * np.float32(cp._v_step_size)
-                tp.a = np.float32(cp.a_min) + np.float32(ia) * np.float32(cp._a_step_size)
+                tp.t = O.grid_point(cp.dt_start, t - 1, cp.dt)
+                tp.s = O.grid_point(cp.s_min, i_s, cp._s_step_size)
+                tp.v = O.grid_point(cp.v_min, iv, cp._v_step_size)
+                tp.a = O.grid_point(cp.a_min, ia, cp._a_step_size)
                 O.lib().dpo_eval_node(C.byref(cp), C.byref(cep), 9, C.byref(tp), O.fptr(nxt), O.fptr(path),
                                       O.fptr(dist), cp.dt, 1, 0)
                 want = np.array([tp.cost, tp.constr, tp.j, 0.0], dtype=np.float32)
@@ -574,23 +566,17 @@ def test_unbounded_inputs_take_the_two_pass_kernel_and_still_match():
 BLEND_ORDER_KERNELS = {"k_backward3v": ("k_backward3o",), "k_backward3s": ("k_backward3o",), "k_backward": ("k_backward",)}
 
 
-@pytest.mark.parametrize("name,quant,lerp", [("wfloor", 2, 0), ("wnone", 0, 0), ("lerp1", 1, 1), ("lerp2", 1, 2),
-                                             ("wfloor_lerp1", 2, 1), ("wfloor_lerp2", 2, 2), ("wnone_lerp1", 0, 1),
-                                             ("wnone_lerp2", 0, 2)])
-def test_filter_rule_variants_match_their_oracle_builds(name, quant, lerp, monkeypatch):
+@pytest.mark.parametrize("name,quant,lerp,fma", [("wfloor", 2, 0, 1), ("wnone", 0, 0, 1), ("lerp1", 1, 1, 1), ("lerp2", 1, 2, 0),
+                                                 ("wfloor_lerp1", 2, 1, 0), ("wfloor_lerp2", 2, 2, 1), ("wnone_lerp1", 0, 1, 0),
+                                                 ("wnone_lerp2", 0, 2, 1), ("wfloor_unfused", 2, 0, 0)])
+def test_filter_rule_variants_match_the_oracle_under_the_same_rule(name, quant, lerp, fma, monkeypatch):
     """R2 (weight quantisation) and R3 (blend form) stand in for the reference's texture unit; they are run-time
     parameters of the HIP planner (tplhip_dp_lon_set_filter_rule) and template parameters of the plain-fp32 sweeps,
-    which are built for all nine combinations.  Each non-default rule must reproduce the sensitivity build of the CPU
-    restatement that makes the same choice (oracle/Makefile, _sens/) bit for bit -- tables, trajectories,
+    which are built for all nine combinations under both settings of R1.  Each non-default rule must reproduce the CPU
+    restatement under the same rule (ONE checker library, dpo_set_rule) bit for bit -- tables, trajectories,
     re-evaluation -- on a small and on a several-rounds-deep grid, ON THE SAME KERNEL as the default rule, with the
     Newton form of the divisions, with IEEE divisions, and on the general sweep; setting the default again must bring
     back the default result."""
-    import os
-    import subprocess
-    odir = os.path.join(O.ROOT, "oracle")
-    lib = os.path.join(odir, f"_sens/libdp_lon_oracle_{name}.so")
-    if not os.path.exists(lib):
-        subprocess.check_call(["make", "-s", "-C", odir, f"_sens/libdp_lon_oracle_{name}.so"])
     for (S, V, A, T), want_default in (((201, 37, 20, 6), "k_backward3s"), ((128, 64, 66, 3), "k_backward3v")):
         p = sc.lon_params(S, V, A, T)
         ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
@@ -598,11 +584,8 @@ def test_filter_rule_variants_match_their_oracle_builds(name, quant, lerp, monke
         occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
         inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(4, seed=3)
         cp, cep = O.cparams(p), O.cparams(ep)
-        O.use(lib)
-        try:
+        with O.rule(quant=quant, lerp=lerp, fma=fma):
             tables, otrajs, _ = O.update(cp, cep, path, occ, inits)
-        finally:
-            O.use(None)
         for dbg, want_kernel, want_forms in (("", want_default, (5, 5)), ("no_fastdiv", want_default, (0, 0)),
                                              ("no_v3,no_s3", "k_backward", None)):
             monkeypatch.setenv("TPLHIP_DEBUG", dbg)
@@ -611,7 +594,9 @@ def test_filter_rule_variants_match_their_oracle_builds(name, quant, lerp, monke
             env.set_occ_map(occ)
             dp = tpl_amd.DynProgLonPlanner()
             dp.reinit_buffers(p)
+            dp.set_contraction(bool(fma))
             dp.set_filter_rule(quant, lerp)
+            assert dp.info()["rule"] == {"quant": quant, "lerp": lerp, "fma": fma, "order": 0}, dp.info()
             trajs = dp.update_batch(inits, path, env)
             info = dp.info()
             assert info["sweep"] == want_kernel, info
@@ -623,6 +608,7 @@ def test_filter_rule_variants_match_their_oracle_builds(name, quant, lerp, monke
         monkeypatch.setenv("TPLHIP_DEBUG", "")
         # the default rule again: default tables, default kernel
         dp.set_filter_rule(1, 0)
+        dp.set_contraction(True)
         trajs = dp.update_batch(inits, path, env)
         assert dp.info()["sweep"] == "k_backward", dp.info()       # (this handle was created under no_v3,no_s3)
         tables0, otrajs0, _ = O.update(cp, cep, path, occ, inits)
@@ -632,19 +618,15 @@ def test_filter_rule_variants_match_their_oracle_builds(name, quant, lerp, monke
         dp.set_filter_rule(3, 0)
 
 
-@pytest.mark.parametrize("name,quant,lerp", [("fma_explicit", 1, 0), ("fma_explicit_wfloor", 2, 0)])
-def test_contraction_matches_its_oracle_build(name, quant, lerp, monkeypatch):
-    """R1 as a run-time choice (tplhip_dp_lon_set_contraction): the multiply-adds nvcc contracts by default, written out
-    as fma() on both sides -- no compiler decides what fuses.  The HIP planner with contraction on reproduces the
-    restatement built -DDPO_R1_FMA=1 bit for bit (distance map, tables, rollouts, re-evaluation) on a small and a
-    several-rounds-deep grid -- on the SAME plain-fp32 sweeps as the default (Newton-form and IEEE divisions) and on the
-    general sweep; switching it off again restores the default tables."""
-    import os
-    import subprocess
-    odir = os.path.join(O.ROOT, "oracle")
-    lib = os.path.join(odir, f"_sens/libdp_lon_oracle_{name}.so")
-    if not os.path.exists(lib):
-        subprocess.check_call(["make", "-s", "-C", odir, f"_sens/libdp_lon_oracle_{name}.so"])
+@pytest.mark.parametrize("name,quant,lerp", [("unfused", 1, 0), ("unfused_wfloor", 2, 0)])
+def test_unfused_arithmetic_matches_the_oracle_under_r1_0(name, quant, lerp, monkeypatch):
+    """R1 as a run-time choice (tplhip_dp_lon_set_contraction).  The default (since round 6) is the contraction nvcc applies
+    to the reference's device code, written out as fma() on both sides -- no compiler decides what fuses; R1 = 0 is one
+    rounding per operation of the source.  The HIP planner with contraction OFF reproduces the restatement under
+    dpo_set_rule(., ., 0, .) bit for bit (distance map, tables, rollouts, re-evaluation) on a small and a
+    several-rounds-deep grid -- on the SAME plain-fp32 sweeps as the default, with the same choice of division forms for the
+    default filter rule (both R1 settings are built with every form), with IEEE divisions, and on the general sweep; switching
+    it on again restores the default tables."""
     for (S, V, A, T), want_default, dt_start in (((201, 37, 20, 6), "k_backward3s", None), ((128, 64, 66, 3), "k_backward3v", 0.4)):
         p = sc.lon_params(S, V, A, T, dt_start=dt_start)
         ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31, dt_start=dt_start)
@@ -654,20 +636,21 @@ def test_contraction_matches_its_oracle_build(name, quant, lerp, monkeypatch):
         occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
         inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(4, seed=3)
         cp, cep = O.cparams(p), O.cparams(ep)
-        O.use(lib)
-        try:
+        with O.rule(quant=quant, lerp=lerp, fma=0):
             tables, otrajs, dist = O.update(cp, cep, path, occ, inits)
-        finally:
-            O.use(None)
-        for dbg, want_kernel, want_forms in (("", want_default, (5, 5)), ("no_fastdiv", want_default, (0, 0)),
-                                             ("no_v3,no_s3", "k_backward", None)):
+        ref = tpl_amd.DynProgLonPlanner()                               # the default rule's own choice of division forms on this grid
+        ref.reinit_buffers(p)
+        default_forms = (ref.info()["path_div3"], ref.info()["range_div3"])
+        del ref
+        for dbg, want_kernel, want_forms in (("", want_default, default_forms if (quant, lerp) == (1, 0) else (5, 5)),
+                                             ("no_fastdiv", want_default, (0, 0)), ("no_v3,no_s3", "k_backward", None)):
             monkeypatch.setenv("TPLHIP_DEBUG", dbg)
             env = tpl_amd.DynProgEnvironment()
             env.reinit_buffers(ep)
             env.set_occ_map(occ)
             dp = tpl_amd.DynProgLonPlanner()
             dp.reinit_buffers(p)
-            dp.set_contraction(True)
+            dp.set_contraction(False)
             dp.set_filter_rule(quant, lerp)
             trajs = dp.update_batch(inits, path, env)
             info = dp.info()
@@ -682,8 +665,8 @@ def test_contraction_matches_its_oracle_build(name, quant, lerp, monkeypatch):
                 again = _traj_np(dp.reeval_traj(tr, path, env))
                 assert np.array_equal(again[:, 5:].view(np.uint32), otrajs[r][:, 5:].view(np.uint32)), (name, dbg, "reeval", r)
         monkeypatch.setenv("TPLHIP_DEBUG", "")
-        # off again (and the default filter rule): default tables
-        dp.set_contraction(False)
+        # on again (and the default filter rule): default tables
+        dp.set_contraction(True)
         dp.set_filter_rule(1, 0)
         trajs = dp.update_batch(inits, path, env)
         tables0, otrajs0, _ = O.update(cp, cep, path, occ, inits)
@@ -693,22 +676,15 @@ def test_contraction_matches_its_oracle_build(name, quant, lerp, monkeypatch):
         dp.set_contraction(2)
 
 
-@pytest.mark.parametrize("name,order,quant,lerp,fma", [("order_sva", 1, 1, 0, 0), ("sum8_f32", 2, 1, 0, 0), ("sum8_wide", 3, 1, 0, 0),
-                                                        ("fma_explicit_order_sva", 1, 1, 0, 1), ("r210o1", 1, 2, 1, 0),
+@pytest.mark.parametrize("name,order,quant,lerp,fma", [("order_sva", 1, 1, 0, 1), ("sum8_f32", 2, 1, 0, 1), ("sum8_wide", 3, 1, 0, 1),
+                                                        ("unfused_order_sva", 1, 1, 0, 0), ("r210o1", 1, 2, 1, 0),
                                                         ("r020o1", 1, 0, 2, 0), ("r001o2", 2, 0, 0, 1), ("r200o3", 3, 2, 0, 0)])
-def test_blend_order_variants_match_their_oracle_builds(name, order, quant, lerp, fma, monkeypatch):
+def test_blend_order_variants_match_the_oracle_under_the_same_rule(name, order, quant, lerp, fma, monkeypatch):
     """R3's ORDER and form as a run-time choice (tplhip_dp_lon_set_blend_order): sequential blends s -> v -> a instead of
     a -> v -> s, and the symmetric eight-corner sum (fp32 accumulator / wide accumulator) the texture hardware's
-    documentation gives.  Each must reproduce the build of the CPU restatement that makes the same choice
-    (-DDPO_BLEND_ORDER=n, alone and combined with the other rules) bit for bit: distance map, tables, rollouts,
-    re-evaluation, on a small and on a several-rounds-deep grid; setting order 0 again restores the default tables AND
-    the default (plain-fp32) kernel."""
-    import os
-    import subprocess
-    odir = os.path.join(O.ROOT, "oracle")
-    lib = os.path.join(odir, f"_sens/libdp_lon_oracle_{name}.so")
-    if not os.path.exists(lib):
-        subprocess.check_call(["make", "-s", "-C", odir, f"_sens/libdp_lon_oracle_{name}.so"])
+    documentation gives.  Each must reproduce the CPU restatement under the same rule (dpo_set_rule(., ., ., n), alone
+    and combined with the other rules) bit for bit: distance map, tables, rollouts, re-evaluation, on a small and on a
+    several-rounds-deep grid; setting order 0 again restores the default tables AND the default (plain-fp32) kernel."""
     for (S, V, A, T), want_default, dt_start in (((201, 37, 20, 6), "k_backward3s", None), ((128, 64, 66, 3), "k_backward3v", 0.4)):
         p = sc.lon_params(S, V, A, T, dt_start=dt_start)
         ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31, dt_start=dt_start)
@@ -718,11 +694,8 @@ def test_blend_order_variants_match_their_oracle_builds(name, order, quant, lerp
         occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC)
         inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(4, seed=3)
         cp, cep = O.cparams(p), O.cparams(ep)
-        O.use(lib)
-        try:
+        with O.rule(quant=quant, lerp=lerp, fma=fma, order=order):
             tables, otrajs, dist = O.update(cp, cep, path, occ, inits)
-        finally:
-            O.use(None)
         for dbg in ("", "no_front", "no_v3,no_s3"):
             monkeypatch.setenv("TPLHIP_DEBUG", dbg)
             env = tpl_amd.DynProgEnvironment()
@@ -752,14 +725,8 @@ def test_blend_order_variants_match_their_oracle_builds(name, order, quant, lerp
         dp.set_filter_rule(quant, lerp)
         dp.set_blend_order(order)
         dp.set_blend_order(0)
-        base = os.path.join(odir, f"_sens/libdp_lon_oracle_r{quant}{lerp}{fma}.so")
-        if not os.path.exists(base):
-            subprocess.check_call(["make", "-s", "-C", odir, f"_sens/libdp_lon_oracle_r{quant}{lerp}{fma}.so"])
-        O.use(base)
-        try:
+        with O.rule(quant=quant, lerp=lerp, fma=fma):
             tables0, otrajs0, _ = O.update(cp, cep, path, occ, inits)
-        finally:
-            O.use(None)
         trajs = dp.update_batch(inits, path, env)
         assert dp.info()["sweep"] == want_default, dp.info()
         _assert_tables_equal(dp, tables0, T)
@@ -774,12 +741,7 @@ def test_blend_order_with_trivial_a_blends(S, V, A, T, dt_start, order):
     """k_backward3o requests and parks only the a0 rows of an action whose blend along a is trivial (ACT_SINGLE_A: both a-rows
     clamped to the same row, or a weight of exactly 0) and reads half the taps.  64 acceleration rows put the jerk grid on the
     acceleration grid (weight exactly 0 for three of the nine actions) next to the clamped ones; 20 rows have the clamped kind
-    only.  Full tables and rollouts against the oracle build of the order, raw bits."""
-    import os
-    import subprocess
-    lib = os.path.join(O.ROOT, "oracle", f"_sens/libdp_lon_oracle_r100o{order}.so")
-    if not os.path.exists(lib):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(O.ROOT, "oracle"), f"_sens/libdp_lon_oracle_r100o{order}.so"])
+    only.  Full tables and rollouts against the oracle under the same order, raw bits."""
     p = sc.lon_params(S, V, A, T, dt_start=dt_start)
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31, dt_start=dt_start)
     path = sc.straight_path(p.path_steps, p.path_step_size)
@@ -793,11 +755,8 @@ def test_blend_order_with_trivial_a_blends(S, V, A, T, dt_start, order):
     dp.set_blend_order(order)
     trajs = dp.update_batch(inits, path, env)
     assert dp.info()["sweep"] == "k_backward3o", dp.info()
-    O.use(lib)
-    try:
+    with O.rule(order=order):
         tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, inits)
-    finally:
-        O.use(None)
     _assert_tables_equal(dp, tables, T)
     for r, tr in enumerate(trajs):
         assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), r

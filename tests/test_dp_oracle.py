@@ -41,11 +41,12 @@ def test_lon_dynamics_closed_form():
 
 def test_lon_dynamics_mixed_precision():
     # the double literals of the reference promote the a/j terms: check one case
-    # against an explicit numpy restatement of the promotion rules
+    # against an explicit numpy restatement of the promotion rules (one rounding per
+    # operation: the host instantiation, which no rule R1 reaches)
     x0 = _state(s=np.float32(3.3), v=np.float32(7.7), a=np.float32(-1.1))
     j, dt = np.float32(0.7), np.float32(0.9)
     out = TplLonState()
-    O.lib().dpo_lon_dynamics(C.byref(x0), j, dt, C.byref(out))
+    O.lib().dpo_lon_dynamics_host(C.byref(x0), j, dt, C.byref(out))
     s, v, a = np.float32(3.3), np.float32(7.7), np.float32(-1.1)
     sf = np.float32(s + np.float32(v * dt))
     sd = np.float64(sf) + ((0.5 * np.float64(a)) * np.float64(dt)) * np.float64(dt)
@@ -258,7 +259,8 @@ def test_traj_state_brackets():
 
 
 def test_product_host_helpers_match_oracle():
-    # tplhip_lon_dynamics / tplhip_lon_traj_state run on the host inside libtplhip.so
+    # tplhip_lon_dynamics / tplhip_lon_traj_state run on the host inside libtplhip.so: the HOST instantiation of the
+    # reference's __interop__ lonDynamics (compiled for baseline x86-64: no fused multiply-add, whatever R1 says)
     import tpl_amd
     from tpl_amd import _capi
     lib = _capi.load()
@@ -267,7 +269,7 @@ def test_product_host_helpers_match_oracle():
         x0 = _state(t=rng.uniform(0, 5), s=rng.uniform(0, 200), v=rng.uniform(0, 36), a=rng.uniform(-3, 1.5))
         j, dt = float(rng.uniform(-3, 2)), float(rng.uniform(0.05, 2))
         a, b = TplLonState(), TplLonState()
-        O.lib().dpo_lon_dynamics(C.byref(x0), j, dt, C.byref(a))
+        O.lib().dpo_lon_dynamics_host(C.byref(x0), j, dt, C.byref(a))
         lib.tplhip_lon_dynamics(C.byref(x0), j, dt, C.byref(b))
         assert bytes(a) == bytes(b)
     traj = tpl_amd.LonTraj()
@@ -285,7 +287,7 @@ def test_product_host_helpers_match_oracle():
     assert many.shape == (2, 4)
 
 
-# ---- rule R1 = 1 (explicit contraction, -DDPO_R1_FMA=1): the variant's arithmetic pinned WITHOUT a libm or a compiler in the
+# ---- rule R1 = 1 (explicit contraction, the default): its arithmetic pinned WITHOUT a libm or a compiler in the
 # loop -- fused multiply-adds emulated in exact rational arithmetic with one round-to-nearest-even at the end
 def _rn(x, p, emin):
     """Round the exact rational x to a binary float with p significand bits (ties to even; subnormals below 2^emin)."""
@@ -315,25 +317,15 @@ def _f64(x):
     return _rn(x, 53, -1022)
 
 
-def _sens_lib(name):
-    import os
-    import subprocess
-    odir = os.path.join(O.ROOT, "oracle")
-    rel = f"_sens/libdp_lon_oracle_{name}.so"
-    if not os.path.exists(os.path.join(odir, rel)):
-        subprocess.check_call(["make", "-s", "-C", odir, rel])
-    return os.path.join(odir, rel)
-
-
 def test_explicit_contraction_of_lon_dynamics_and_interp_path_is_the_documented_one():
-    """lonDynamics (lon_planner.cu:240-250) and interpPath (common.cuh:124-136) of the -DDPO_R1_FMA=1 build against the rule
+    """lonDynamics (lon_planner.cu:240-250) and interpPath (common.cuh:124-136) under R1 = 1 (the default) against the rule
     written in the header of oracle/dp_lon_oracle.c -- fmaf(v, dt, s) -> fma((.5 a) dt, dt, .) -> fma(((j / 6) dt) dt, dt, .);
     fmaf(a, dt, v) -> fma((.5 j) dt, dt, .); fmaf(j, dt, a); fmaf(p0, 1 - alpha, p1 alpha) -- evaluated in exact
-    rationals, one rounding per (fused) operation.  And the default build is the same rule with every fma split in two."""
+    rationals, one rounding per (fused) operation.  And R1 = 0 is the same rule with every fma split in two."""
     from fractions import Fraction as F
     rng = np.random.default_rng(11)
     for fma in (1, 0):
-        O.use(_sens_lib("fma_explicit") if fma else None)
+        O.set_rule(fma=fma)
         try:
             for _ in range(200):
                 s, v, a, j, dt = (np.float32(x) for x in (rng.uniform(0, 150), rng.uniform(0, 30), rng.uniform(-3, 1.5),
@@ -377,13 +369,13 @@ def test_explicit_contraction_of_lon_dynamics_and_interp_path_is_the_documented_
                     want = _f32(p0 * ia + _f32(p1 * al)) if fma else _f32(_f32(p0 * ia) + _f32(p1 * al))
                     assert F(float(got)) == want, (fma, d, col)
         finally:
-            O.use(None)
+            O.set_rule()
 
 
 @pytest.mark.parametrize("name,order", [(None, 0), ("order_sva", 1), ("sum8_f32", 2), ("sum8_wide", 3)])
 def test_read_node_blend_orders_are_the_documented_ones(name, order):
-    """readNode (lon_planner.cu:26-38 through the software filter of rules R2 / R3) of the default build and of the three
-    blend-order builds (-DDPO_BLEND_ORDER=1 | 2 | 3) against the rule written in the header of oracle/dp_lon_oracle.c,
+    """readNode (lon_planner.cu:26-38 through the software filter of rules R2 / R3) under the default order and the three
+    other blend orders (dpo_set_rule(., ., ., 1 | 2 | 3)) against the rule written in the header of oracle/dp_lon_oracle.c,
     evaluated in exact rationals with one rounding per operation: three sequential blends fma(q, w, p (1 - w)) along
     a, v, s (default) or s, v, a (order 1); the eight-corner sum with weights (w_s w_v) w_a, corner index s + 2 v + 4 a,
     products and sums rounded in fp32 in that order (order 2) or exact products in a double accumulator and one final
@@ -411,7 +403,7 @@ def test_read_node_blend_orders_are_the_documented_ones(name, order):
     def lerp(pv, qv, w):
         return _f32(qv * w + _f32(pv * _f32(1 - w)))            # fmaf(q, w, p * (1 - w))
 
-    O.use(_sens_lib(name) if name else None)
+    O.set_rule(order=order)
     try:
         for _ in range(300):
             s = np.float32(rng.uniform(p.s_min, p.s_max))
@@ -448,7 +440,7 @@ def test_read_node_blend_orders_are_the_documented_ones(name, order):
                         want = _f32(acc)
                 assert F(float(out[ch])) == want, (order, ch, float(s), float(v), float(a), float(out[ch]), float(want))
     finally:
-        O.use(None)
+        O.set_rule()
 
 
 @pytest.mark.parametrize("name,order", [(None, 0), ("order_sva", 1), ("sum8_f32", 2), ("sum8_wide", 3)])
@@ -460,7 +452,7 @@ def test_dist_map_lookup_under_the_blend_orders(name, order):
     p, ep = _small()
     rng = np.random.default_rng(5)
     dist = rng.uniform(0.0, 120.0, size=(ep.t_steps, ep.s_steps)).astype(np.float32)
-    O.use(_sens_lib(name) if name else None)
+    O.set_rule(order=order)
     try:
         lib = O.lib()
         for _ in range(300):
@@ -489,4 +481,4 @@ def test_dist_map_lookup_under_the_blend_orders(name, order):
                 want = _f32(_f64(_f64(_f32(1 - w) * pv) + _f64(w * qv)))
             assert F(float(got)) == want, (order, it, float(s), got, float(want))
     finally:
-        O.use(None)
+        O.set_rule()

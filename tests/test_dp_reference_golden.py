@@ -38,47 +38,38 @@ def _oracle_plan(g):
     return O.states_to_np(out).reshape(n, p.t_steps, 7), {t: tables[t] for t in g["tables"]}
 
 
-# The binary-level choices the restatement freezes (R1 no contraction, R2 rint quantisation, R3 blend
-# form) and the sensitivity builds of oracle/dp_lon_oracle.c that make each one differently (oracle/Makefile).
-VARIANTS = [("contract", None, "the checker: no contraction, weight rint(a*256)/256, blend fma(q, w, p*(1-w))"),
-            ("fma", "_sens/libdp_lon_oracle_fma.so", "R1: multiply-adds contracted like nvcc -fmad=true"),
-            ("wfloor", "_sens/libdp_lon_oracle_wfloor.so", "R2: weight truncated to 8 fractional bits"),
-            ("wnone", "_sens/libdp_lon_oracle_wnone.so", "R2: weight not quantised"),
-            ("lerp1", "_sens/libdp_lon_oracle_lerp1.so", "R3: blend p*(1-w) + q*w, every operation rounded"),
-            ("lerp2", "_sens/libdp_lon_oracle_lerp2.so", "R3: blend p + w*(q-p)"),
-            ("fma_wfloor", "_sens/libdp_lon_oracle_fma_wfloor.so", "R1 + R2: contracted AND truncated weights"),
-            # the same flip of R1 WITHOUT a compiler in the loop: every contracted multiply-add written as fma()
-            # (left-to-right, as NVVM's DAG combiner folds them); the HIP planner follows with set_contraction(True)
-            ("fma_explicit", "_sens/libdp_lon_oracle_fma_explicit.so", "R1: explicit fma() at every site nvcc -fmad=true contracts -> DynProgLonPlanner.set_contraction(True)"),
-            ("fma_explicit_wfloor", "_sens/libdp_lon_oracle_fma_explicit_wfloor.so", "R1 + R2: explicit contraction AND truncated weights -> set_contraction(True) + set_filter_rule(2, 0)"),
+# The binary-level choices the restatement freezes (R1 contraction, R2 rint quantisation, R3 blend form
+# and order) and the run-time rules of oracle/dp_lon_oracle.c that make each one differently (dpo_set_rule: ONE checker
+# library).  Each row: name, rule overrides on the default {quant 1, lerp 0, fma 1, order 0}, what it means and the calls
+# with which the HIP planner follows.
+VARIANTS = [("default", {}, "the checker: nvcc-style contraction written out as fma(), weight rint(a*256)/256, blend fma(q, w, p*(1-w)), a -> v -> s"),
+            ("unfused", dict(fma=0), "R1: one rounding per source operation, nothing contracted -> DynProgLonPlanner.set_contraction(False)"),
+            ("wfloor", dict(quant=2), "R2: weight truncated to 8 fractional bits -> set_filter_rule(2, 0)"),
+            ("wnone", dict(quant=0), "R2: weight not quantised -> set_filter_rule(0, 0)"),
+            ("lerp1", dict(lerp=1), "R3: blend p*(1-w) + q*w, every operation rounded -> set_filter_rule(1, 1)"),
+            ("lerp2", dict(lerp=2), "R3: blend p + w*(q-p) -> set_filter_rule(1, 2)"),
+            ("unfused_wfloor", dict(fma=0, quant=2), "R1 + R2: nothing contracted AND truncated weights -> set_contraction(False) + set_filter_rule(2, 0)"),
+            ("unfused_wnone", dict(fma=0, quant=0), "R1 + R2: nothing contracted AND un-quantised weights -> set_contraction(False) + set_filter_rule(0, 0)"),
             # rule R3's ORDER and the symmetric sum (round 5): the HIP planner follows with set_blend_order(1 | 2 | 3)
-            ("order_sva", "_sens/libdp_lon_oracle_order_sva.so", "R3 order: sequential blends s -> v -> a (x first) -> DynProgLonPlanner.set_blend_order(1)"),
-            ("sum8_f32", "_sens/libdp_lon_oracle_sum8_f32.so", "R3 form: eight-corner weighted sum, fp32 accumulator in the documented term order -> set_blend_order(2)"),
-            ("sum8_wide", "_sens/libdp_lon_oracle_sum8_wide.so", "R3 form: eight-corner weighted sum, exact products, one rounding -> set_blend_order(3)"),
-            ("fma_explicit_order_sva", "_sens/libdp_lon_oracle_fma_explicit_order_sva.so", "R1 + R3 order: explicit contraction AND s -> v -> a -> set_contraction(True) + set_blend_order(1)"),
-            ("fma_explicit_sum8_f32", "_sens/libdp_lon_oracle_fma_explicit_sum8_f32.so", "R1 + R3 form: explicit contraction AND the fp32 eight-corner sum -> set_contraction(True) + set_blend_order(2)"),
-            ("fma_explicit_sum8_wide", "_sens/libdp_lon_oracle_fma_explicit_sum8_wide.so", "R1 + R3 form: explicit contraction AND the wide eight-corner sum -> set_contraction(True) + set_blend_order(3)")]
+            ("order_sva", dict(order=1), "R3 order: sequential blends s -> v -> a (x first) -> DynProgLonPlanner.set_blend_order(1)"),
+            ("sum8_f32", dict(order=2), "R3 form: eight-corner weighted sum, fp32 accumulator in the documented term order -> set_blend_order(2)"),
+            ("sum8_wide", dict(order=3), "R3 form: eight-corner weighted sum, exact products, one rounding -> set_blend_order(3)"),
+            ("unfused_order_sva", dict(fma=0, order=1), "R1 + R3 order: nothing contracted AND s -> v -> a -> set_contraction(False) + set_blend_order(1)"),
+            ("unfused_sum8_f32", dict(fma=0, order=2), "R1 + R3 form: nothing contracted AND the fp32 eight-corner sum -> set_contraction(False) + set_blend_order(2)"),
+            ("unfused_sum8_wide", dict(fma=0, order=3), "R1 + R3 form: nothing contracted AND the wide eight-corner sum -> set_contraction(False) + set_blend_order(3)"),
+            ("wfloor_sum8_f32", dict(quant=2, order=2), "R2 + R3 form: truncated weights AND the fp32 eight-corner sum -> set_filter_rule(2, 0) + set_blend_order(2)"),
+            ("wfloor_order_sva", dict(quant=2, order=1), "R2 + R3 order: truncated weights AND s -> v -> a -> set_filter_rule(2, 0) + set_blend_order(1)")]
+VARIANT_RULES = {name: kw for name, kw, _ in VARIANTS}
 
 
 def variant_table(g):
-    """Which rule to flip: every sensitivity build of the restatement against the dump, best match first.  A maintainer
+    """Which rule to flip: the restatement under every rule of VARIANTS against the dump, best match first.  A maintainer
     who drops a dump of the CUDA build into tests/golden/ and sees the checker fail reads the row with zero (or the
     fewest) other actions: that is what the reference binary does."""
-    import os
-    import subprocess
-    odir = os.path.join(O.ROOT, "oracle")
     rows = []
-    for name, rel, what in VARIANTS:
-        if rel is not None:
-            path = os.path.join(odir, rel)
-            if not os.path.exists(path) and subprocess.call(["make", "-s", "-C", odir, rel], stdout=subprocess.DEVNULL,
-                                                            stderr=subprocess.DEVNULL) != 0:
-                continue                                   # e.g. -mfma on a host without FMA3
-            O.use(path)
-        try:
+    for name, kw, what in VARIANTS:
+        with O.rule(**kw):
             trajs, tables = _oracle_plan(g)
-        finally:
-            O.use(None)
         rows.append(dict(G.score_against(g, trajs, tables), variant=name, what=what))
     rows.sort(key=lambda r: (r["table_cells_other_action"] + r["traj_nodes_other_action"], r["table_value_rel"], r["traj_value_rel"]))
     return rows
@@ -178,17 +169,11 @@ def test_loader_round_trip_and_bar(tmp_path):
         G.load(str(tmp_path / "dp_lon_broken.npz"))
 
 
-@pytest.mark.parametrize("who", ["wfloor", "order_sva", "sum8_f32", "sum8_wide"])
+@pytest.mark.parametrize("who", ["wfloor", "unfused", "order_sva", "sum8_f32", "sum8_wide"])
 def test_variant_table_names_the_rule(tmp_path, capsys, who):
-    """Day-one use of a dump: the table ranks the sensitivity builds against it.  Here the "dump" is written by ONE of
-    the variants (truncated filter weights; the blend order flipped; the eight-corner sums) standing in for the CUDA
+    """Day-one use of a dump: the table ranks the rules against it.  Here the "dump" is written by ONE of the variants
+    (truncated filter weights; nothing contracted; the blend order flipped; the eight-corner sums) standing in for the CUDA
     build: the checker fails on it, and the table puts exactly that variant first with zero other actions."""
-    import os
-    import subprocess
-    odir = os.path.join(O.ROOT, "oracle")
-    stand_in = os.path.join(odir, f"_sens/libdp_lon_oracle_{who}.so")
-    if not os.path.exists(stand_in):
-        subprocess.check_call(["make", "-s", "-C", odir, f"_sens/libdp_lon_oracle_{who}.so"])
     S, V, A, T = 65, 12, 9, 6
     p = sc.lon_params(S, V, A, T)
     ep = sc.env_params(t_steps=T, s_steps=101, l_steps=21)
@@ -196,11 +181,8 @@ def test_variant_table_names_the_rule(tmp_path, capsys, who):
     occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
     inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(15, seed=2)
     cp, cep = O.cparams(p), O.cparams(ep)
-    O.use(stand_in)
-    try:
+    with O.rule(**VARIANT_RULES[who]):
         tables, trajs, _ = O.update(cp, cep, path, occ, inits)
-    finally:
-        O.use(None)
     f = str(tmp_path / "dp_lon_standin.npz")
     G.save(f, cp, cep, path, occ, O.states_to_np([s._c for s in inits]), trajs, {t: tables[t] for t in range(1, T)})
     g = G.load(f)
@@ -212,8 +194,8 @@ def test_variant_table_names_the_rule(tmp_path, capsys, who):
     # the checker itself is NOT what wrote this dump: other actions, or at least other bits (on this small grid the order
     # variants move values by 1e-7 and no argmin -- inside the 1e-5 bar, so only the table's ranking tells them apart;
     # on configs[1] they flip 1e-4 .. 8e-3 of the cells, profiles/r05_dp_parity_sensitivity.json)
-    assert by["contract"]["table_cells_other_action"] > 0 or by["contract"]["table_value_rel"] > 0.0
-    if by["contract"]["table_cells_other_action"] > 0:
+    assert by["default"]["table_cells_other_action"] > 0 or by["default"]["table_value_rel"] > 0.0
+    if by["default"]["table_cells_other_action"] > 0:
         with pytest.raises(AssertionError, match="best first"):      # ... and its failure carries the table
             _check_cpu(f)
 
@@ -224,7 +206,7 @@ def _check_cpu(path):
     try:
         G.check_against(g, trajs, tables, who="oracle/dp_lon_oracle.c")
     except AssertionError as e:
-        raise AssertionError(f"{e}\n\nsensitivity variants of the restatement against this dump, best first:\n"
+        raise AssertionError(f"{e}\n\nthe restatement under every rule against this dump, best first:\n"
                              + format_variant_table(variant_table(g))) from None
 
 

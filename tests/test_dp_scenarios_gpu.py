@@ -67,13 +67,8 @@ def test_batched_scenarios_bit_exact(S, V, A, T, n, chunk, own_paths, monkeypatc
             monkeypatch.setenv("TPLHIP_DEBUG", "no_v3")
             want_kernel = "k_backward"
         own_paths = False
-        import os
-        import subprocess
-        lib = os.path.join(O.ROOT, "oracle", f"_sens/libdp_lon_oracle_r100o{order}.so")
-        if not os.path.exists(lib):
-            subprocess.check_call(["make", "-s", "-C", os.path.join(O.ROOT, "oracle"), f"_sens/libdp_lon_oracle_r100o{order}.so"])
-        O.use(lib)
-        request_cleanup.append(lambda: O.use(None))
+        O.set_rule(order=order)
+        request_cleanup.append(lambda: O.set_rule())
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
     occs, inits = _scenarios(n, ep, seed=S + n)
     if own_paths:

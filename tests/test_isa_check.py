@@ -2,6 +2,7 @@
 (tpl_amd/optim/isa_check.py) -- the root cause of round 4's max-ilp divergence (profiles/r05_ilqr_max_ilp_root_cause.txt): a
 register-allocator copy of the value a divergent loop computes, placed in the loop's exit block in front of the exec restore."""
 import os
+import time
 import shutil
 
 import pytest
@@ -96,6 +97,14 @@ def test_scheduler_policy_max_ilp_first_then_default(tmp_path, monkeypatch, caps
     assert seen == ["max-ilp"] and not os.path.exists(so)
     # check_isa=False keeps whatever the first strategy gave (A/B tools, the symptom test of round 4)
     assert genopt.compile_model(model, force=True, so_path=so, check_isa=False) == so and open(so).read() == "max-ilp"
+    # a CACHED library is reused only under the scheduler the caller names: the label is a marker in the file (built_scheduler)
+    seen = _fake_toolchain(monkeypatch, bad_under=())
+    open(so, "wb").write(b"...tplhip_ilqr_sched=default\0...")
+    os.utime(so, (time.time() + 10, time.time() + 10))
+    assert genopt.built_scheduler(so) == "default"
+    assert genopt.compile_model(model, so_path=so) == so and seen == []                          # fresh, no scheduler named: reused
+    assert genopt.compile_model(model, so_path=so, scheduler="default") == so and seen == []     # ... or named and matching
+    assert genopt.compile_model(model, so_path=so, scheduler="max-ilp") == so and seen == ["max-ilp"]   # another one: rebuilt
 
 
 def test_shipped_libraries_say_which_scheduler(tmp_path):
@@ -112,6 +121,7 @@ def test_shipped_libraries_say_which_scheduler(tmp_path):
     assert genopt.compile_model(model, force=True, so_path=so) == so
     blob = open(so, "rb").read()
     assert b"\"scheduler\": \"%s\"" in blob and (b"max-ilp\0" in blob or b"default\0" in blob)
+    assert genopt.built_scheduler(so) in genopt.SCHEDULERS
 
 
 def test_libtplhip_listings_pass_the_scan():

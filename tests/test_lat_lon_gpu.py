@@ -175,21 +175,18 @@ def test_errors():
 
 
 @pytest.mark.parametrize("quant,lerp,order", [(2, 0, 0), (1, 1, 0), (1, 0, 1), (1, 0, 2), (1, 0, 3), (2, 2, 1), (0, 1, 2)])
-def test_filter_rule_variants_match_their_oracle_builds(quant, lerp, order):
+def test_filter_rule_variants_match_the_oracle_under_the_same_rule(quant, lerp, order):
     """The texture filter's frozen arithmetic -- weight rule, blend form, blend order / eight-corner sums -- as a run-time choice of
     this planner too (tplhip_lat_lon_set_filter_rule; HP-1: tests/test_dp_gpu.py).  It reaches the forward pass' filtered fetch of
-    the value tables, the distance-map and the reference-line look-ups; each variant must reproduce the build of
-    oracle/lat_lon_oracle.c that makes the same choice (-DLLO_WEIGHT_QUANT / -DLLO_LERP_FORM / -DLLO_BLEND_ORDER) bit for bit:
+    the value tables, the distance-map and the reference-line look-ups; each variant must reproduce
+    oracle/lat_lon_oracle.c under the same rule (llo_set_rule: one library, the rule is run-time state) bit for bit:
     tables, the DP trajectory, the re-evaluated trajectory."""
     env, o, dist_lon = _env("arc", 1)
     p = _params()
     start = _start(l=0.37)
-    oll.use(oll.variant(quant, lerp, order))
-    try:
+    with oll.rule(quant, lerp, order):
         tables, otraj = oll.update_traj_dp(p, o.c, dist_lon, o.ref, o.step, start)
         ore = oll.reeval(p, o.c, dist_lon, o.ref, o.step, otraj)
-    finally:
-        oll.use(None)
     tables0, otraj0 = oll.update_traj_dp(p, o.c, dist_lon, o.ref, o.step, start)
     pl = tpl_amd.DynProgLatLonPlanner()
     pl.reinit_buffers(p)

@@ -51,6 +51,25 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
+def _worker8(rank, world, port, n, q):
+    """One rank of the 8-rank rehearsal: its block of scenario ids, the local reduction, ONE all-gather, and what the bench's
+    workers assert before timing -- the process group really holds `world` ranks (an all-reduce of ones)."""
+    sys.path.insert(0, ROOT)
+    from tpl_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ones = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    lo, hi = sharding.shard_range(n, rank, world)
+    best = sharding.local_best([_oracle_record(i) for i in range(lo, hi)])
+    glob = sharding.allgather_best(best, dist)
+    q.put((rank, lo, hi, int(ones.item()), best, glob))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -97,6 +116,40 @@ def test_two_rank_allgather_of_the_best_oracle_plan():
     assert all(not sharding.better(r, serial) for r in records)
     spans = sorted((lo, hi) for _, lo, hi, _ in results)
     assert spans[0][0] == 0 and spans[-1][1] == n and spans[0][1] == spans[1][0]
+
+
+def test_eight_rank_allgather_over_uneven_blocks():
+    """BASELINE configs[4] rehearsed on the CPU (no 8-GPU node was ever available to this repository): EIGHT gloo ranks
+    shard 8 190 scenario ids -- blocks of 1 024 and 1 023, the uneven case 8 192 never shows --, every rank plans its block
+    with the CPU oracle, reduces it to its best-plan record, ONE all-gather, and every rank must hold the same global
+    argmin with ranks_seen == 8.  The first run on hardware should fail, if it fails, on RCCL and nothing else."""
+    sys.path.insert(0, ROOT)
+    from tpl_amd import sharding
+    n, world = 8190, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    spans = [(lo, hi) for _, lo, hi, _, _, _ in results]
+    assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert sorted(hi - lo for lo, hi in spans) == [1023] * 2 + [1024] * 6
+    assert all(seen == world for _, _, _, seen, _, _ in results)
+    glob = results[0][5]
+    for rank, lo, hi, _, best, g in results:
+        assert np.array_equal(g, glob), rank                                   # identical argmin on every rank
+        assert lo <= best[2] < hi                                              # every rank contributed a plan of its own block
+    assert np.array_equal(glob, sharding.local_best([r[4] for r in results]))  # = the host-side reduction of the eight records
+    wid = int(glob[2])
+    assert np.array_equal(glob, _oracle_record(wid))                           # the record IS that scenario's plan
+    rng = np.random.default_rng(0)
+    for sid in rng.integers(0, n, 150):                                        # ... and no sampled scenario beats it
+        assert not sharding.better(_oracle_record(int(sid)), glob), sid
 
 
 def test_order_is_constraint_then_cost_then_id():

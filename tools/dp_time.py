@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench
 grid = sys.argv[1] if len(sys.argv) > 1 else "target"
 dp, env, p, *_ = bench.dp_setup(grid, 0)
+if os.environ.get("TPL_AB_R1") == "0":
+    dp.set_contraction(False)
 res = []
 for _ in range(5):
     dp.plan_resident(env); dp.sync()

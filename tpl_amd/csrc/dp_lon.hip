@@ -65,6 +65,8 @@ struct tplhip_dp_lon {
     bool fwd_pending[2] = {false, false};
     float* d_dist_fwd[2] = {nullptr, nullptr};   // the distance map a pending rollout reads (the environment's is rewritten)
     size_t dist_fwd_cap = 0;
+    float* d_in_fwd[2] = {nullptr, nullptr};     // ... and its own copy of path + initial states: the next upload need not wait for it
+    size_t in_fwd_cap = 0;                       // (floats)
     long plan_count = 0;
     bool overlap = false;               // set by plan_resident once the second table set exists
     ActDesc* d_acts = nullptr;          // [a*v][9]
@@ -145,8 +147,10 @@ struct tplhip_dp_lon {
     int v3_grid = 0;
     bool no_v3 = false, no_fwd_overlap = false, no_fwd_spec = false, no_front = false;   // TPLHIP_DEBUG overrides, read by reinit
     bool front_fused = true;                 // what the last plan did (info)
-    FilterRule rule = kDefaultRule;      // R2 / R3 of the arithmetic contract (tplhip_dp_lon_set_filter_rule)
-    bool rule_set = false;               // a non-default rule (the plain-fp32 sweeps then take the division forms (5, 5) or (0, 0))
+    FilterRule rule = kDefaultRule;      // R1 - R3 of the arithmetic contract (tplhip_dp_lon_set_filter_rule / _set_contraction / _set_blend_order)
+    bool rule_set = false;               // a rule other than kDefaultRule: the kernels that fold the default rule take it at run time
+    bool rule_all_forms = true;          // the texture-filter defaults (R2 rint, R3 fma form, a -> v -> s) under EITHER setting of R1: the
+                                         // plain-fp32 sweeps are built with every division form; any other rule takes (5, 5) or (0, 0)
     bool s3_first_early = false;         // k_backward3s requests its first round's rows ahead of its prologue (grids of >= 4 wavefronts per SIMD)
     int s3_kc = 0, s3_grid = 0;          // k_backward3s (grids that leave the chip mostly empty): actions per round (0 = not used), grid
     size_t s3_lds = 0;
@@ -156,6 +160,8 @@ struct tplhip_dp_lon {
     double sweep_ms = 0.0;
     int64_t sweep_launches = 0;
 };
+
+namespace tplhip { thread_local bool t_sweep_probe = false; }
 
 namespace {
 
@@ -259,8 +265,8 @@ int fwd_threads(const tplhip_dp_lon* h)
 }
 
 // The form of the two divisions by run-time constants in the plain-fp32 sweeps, from what k_verify_div proved.  The
-// default filter rule is built with every pair of forms: the cheapest proven one per divisor.  The other rules are built
-// with (5, 5) and (0, 0) only.
+// default filter rule -- under contracted arithmetic (R1 = 1, the default) and under one rounding per operation (R1 = 0) alike --
+// is built with every pair of forms: the cheapest proven one per divisor.  The other rules are built with (5, 5) and (0, 0) only.
 void pick_div_forms(tplhip_dp_lon* h)
 {
     auto best = [](int mask) { return (mask & 2) ? 4 : ((mask & 1) ? 3 : ((mask & 4) ? 5 : 0)); };
@@ -274,7 +280,7 @@ void pick_div_forms(tplhip_dp_lon* h)
         pd = only(h->verified_path3);
         rd = only(h->verified_range3);
     }
-    if (h->rule_set) {
+    if (!h->rule_all_forms) {
         const bool newton = (h->verified_path3 & 4) && (h->verified_range3 & 4) && (!forced_set || forced == 5);
         pd = rd = newton ? 5 : 0;
     }
@@ -297,7 +303,7 @@ bool use_v3(const tplhip_dp_lon* h)
            && backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps) <= 64 * 1024;
 }
 
-void launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
+bool launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
 {
     const size_t S = (size_t)h->params.s_steps;
     SweepArgs a;
@@ -314,7 +320,7 @@ void launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
     a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->range_aux;
     a.tile_v = h->tile_v3; a.tile_a = h->tile_a; a.skew_q16 = h->skew_q16;
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
-    launch_backward3v(h->rule, h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
+    return launch_backward3v(h->rule, h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
 }
 
 bool launch_backward3s_(tplhip_dp_lon* h, int idx_t, int nx)
@@ -355,8 +361,11 @@ void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
     const int kind = sweep_kind(h);
     if (terminal) {
         launch_backward<true, 1>(h, i, nx);                       // rule R4 (no division in it)
-    } else if (kind == 1) {
-        launch_backward3(h, i, nx);                                   // two rows per lane, plain-fp32 stream
+    } else if (kind == 1 && launch_backward3(h, i, nx)) {
+        // two rows per lane, plain-fp32 stream.  (A `false` means no instance is built for this (rule, division forms) pair:
+        // pick_div_forms / backward3o_built keep the host's choices inside what dp_sweep.hip builds -- tests/test_dp_gpu.py::
+        // test_every_selectable_rule_has_a_built_sweep -- and if they ever drift the stage is swept by the general kernel below
+        // instead of being skipped.)
     } else if (kind == 2 && launch_backward3s_(h, i, nx)) {
         // the plain-fp32 stream, one cell per lane
     } else if (h->kchunk == 3) {
@@ -451,13 +460,26 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState
     {
         hipStream_t fs = h->stream;
         const float* dist = env->d_dist;
+        const float* path_in = h->d_path;
+        const TplLonState* inits_in = h->d_inits;
         if (overlap) {
-            const size_t dist_b = sizeof(float) * (size_t)env->params.t_steps * env->params.s_steps;
-            HIP_TRY(hipMemcpyAsync(h->d_dist_fwd[par], env->d_dist, dist_b, hipMemcpyDeviceToDevice, h->stream), "distance map copy failed");
+            // everything the rollout reads besides its table set goes into buffers of the plan's parity, in ONE launch behind the
+            // sweeps: the distance map (the environment's is rewritten by the next plan's front), the path and the initial
+            // states (the next upload() overwrites them) -- a caller that replans with new inputs every cycle never waits for
+            // a rollout on the host
+            const unsigned dist_w = (unsigned)((size_t)env->params.t_steps * env->params.s_steps);
+            const unsigned path_w = 7u * (unsigned)p.path_steps, init_w = (unsigned)(sizeof(TplLonState) / 4 * (size_t)h->n_rollouts);
+            const unsigned blocks = std::min(64u, (dist_w + path_w + init_w + 255u) / 256u);
+            hipLaunchKernelGGL(k_copy_fwd_inputs, dim3(blocks), dim3(256), 0, h->stream,
+                               reinterpret_cast<const unsigned*>(env->d_dist), reinterpret_cast<unsigned*>(h->d_dist_fwd[par]), dist_w,
+                               reinterpret_cast<const unsigned*>(h->d_path), reinterpret_cast<unsigned*>(h->d_in_fwd[par]), path_w,
+                               reinterpret_cast<const unsigned*>(h->d_inits), reinterpret_cast<unsigned*>(h->d_in_fwd[par] + path_w), init_w);
             HIP_TRY(hipEventRecord(h->ev_swept, h->stream), "event record failed");
             HIP_TRY(hipStreamWaitEvent(h->fwd_stream, h->ev_swept, 0), "stream wait failed");
             fs = h->fwd_stream;
             dist = h->d_dist_fwd[par];
+            path_in = h->d_in_fwd[par];
+            inits_in = reinterpret_cast<const TplLonState*>(h->d_in_fwd[par] + path_w);
         }
         const size_t ring_b = sizeof(float) * 7 * FWD_RING;
         const size_t maps_b = sizeof(float) * ((size_t)p.path_steps * 7 + (size_t)env->params.t_steps * env->params.s_steps);
@@ -465,8 +487,8 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState
             const bool in_lds = ring_b + maps_b <= 60 * 1024, rt = h->rule_set;
             auto go = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(h->n_rollouts), dim3(fwd_threads(h)), in_lds ? ring_b + maps_b : ring_b, fs,
-                                   h->d_trajs, h->d_inits, h->d_tables, h->table_cells,
-                                   h->d_path, dist, p, env->params, (size_t)0, (size_t)0, (size_t)0, h->rule, mirror, done_flag, done_seq);
+                                   h->d_trajs, inits_in, h->d_tables, h->table_cells,
+                                   path_in, dist, p, env->params, (size_t)0, (size_t)0, (size_t)0, h->rule, mirror, done_flag, done_seq);
             };
             if (fwd_threads(h) == 64) {
                 if (in_lds) { if (rt) go(k_forward_seq<true, true>); else go(k_forward_seq<true, false>); }
@@ -488,8 +510,9 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState
 void try_enable_overlap(tplhip_dp_lon* h, tplhip_dp_env* env)
 {
     const size_t dist_elems = (size_t)env->params.t_steps * env->params.s_steps;
+    const size_t in_elems = 7 * (size_t)h->params.path_steps + sizeof(TplLonState) / 4 * (size_t)h->n_rollouts;
     if (h->no_fwd_overlap) { h->overlap = false; return; }
-    if (h->overlap && h->dist_fwd_cap >= dist_elems) return;
+    if (h->overlap && h->dist_fwd_cap >= dist_elems && h->in_fwd_cap >= in_elems) return;
     h->overlap = false;
     const size_t bytes = sizeof(Node) * h->table_cells * (size_t)h->params.t_steps;
     if (!h->d_table_set[1]) {
@@ -507,6 +530,14 @@ void try_enable_overlap(tplhip_dp_lon* h, tplhip_dp_env* env)
             if (hipMalloc(&h->d_dist_fwd[i], sizeof(float) * dist_elems) != hipSuccess) { (void)hipGetLastError(); h->dist_fwd_cap = 0; return; }
         }
         h->dist_fwd_cap = dist_elems;
+    }
+    if (h->in_fwd_cap < in_elems) {
+        if (hipStreamSynchronize(h->fwd_stream) != hipSuccess) return;
+        for (int i = 0; i < 2; ++i) {
+            (void)hipFree(h->d_in_fwd[i]); h->d_in_fwd[i] = nullptr;
+            if (hipMalloc(&h->d_in_fwd[i], sizeof(float) * in_elems) != hipSuccess) { (void)hipGetLastError(); h->in_fwd_cap = 0; return; }
+        }
+        h->in_fwd_cap = in_elems;
     }
     h->overlap = true;
 }
@@ -726,7 +757,7 @@ int tplhip_dp_lon_destroy(tplhip_dp_lon* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->fwd_stream) { (void)hipStreamSynchronize(h->fwd_stream); (void)hipStreamDestroy(h->fwd_stream); }
     if (h->ev_swept) (void)hipEventDestroy(h->ev_swept);
-    for (int i = 0; i < 2; ++i) { if (h->ev_fwd[i]) (void)hipEventDestroy(h->ev_fwd[i]); (void)hipFree(h->d_dist_fwd[i]); }
+    for (int i = 0; i < 2; ++i) { if (h->ev_fwd[i]) (void)hipEventDestroy(h->ev_fwd[i]); (void)hipFree(h->d_dist_fwd[i]); (void)hipFree(h->d_in_fwd[i]); }
     for (auto& ev : h->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     free_planner_buffers(h);
     free_scenarios_fwd(h);
@@ -1000,7 +1031,11 @@ int upload_impl(tplhip_dp_lon* h, int n, const TplLonState* inits, const float* 
     if (!h || !inits || !path || n < 1) return tplhip_fail(TPLHIP_EINVAL, "bad argument");
     if (!h->have_params) return tplhip_fail(TPLHIP_ESTATE, "reinit_buffers was never called on the planner");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
-    int rc = wait_pending_forwards(h);                      // they read the path and the initial states
+    // A pending rollout of the back-to-back mode reads its OWN copy of path and initial states (enqueue_plan), so a new upload
+    // only has to be ordered behind the previous plan on the stream -- unless the rollout buffers must grow, or the mode is off
+    // and the rollout reads d_path / d_inits themselves.
+    int rc = TPLHIP_OK;
+    if (!h->overlap || n > h->cap_rollouts || !h->d_trajs) rc = wait_pending_forwards(h);
     if (rc) return rc;
     rc = ensure_rollouts(h, n);
     if (rc) return rc;
@@ -1262,12 +1297,13 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
                   "{\"sweep\": \"%s\", \"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
                   "\"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"big\": %d, "
                   "\"bounded_inputs\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\", \"fwd_overlap\": %d, \"plan_front\": \"%s\", "
-                  "\"skew_pairs_per_a_row\": %.4f, \"tile_v3\": %d}",
+                  "\"skew_pairs_per_a_row\": %.4f, \"tile_v3\": %d, \"rule\": {\"quant\": %d, \"lerp\": %d, \"fma\": %d, \"order\": %d}}",
                   sweep, h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
                   (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->big ? 1 : 0,
                   (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
                   h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded && h->params_bounded) ? (h->rule.order != 0 ? "k_backward3o" : "k_backward3v") : "k_backward", h->overlap ? 1 : 0,
-                  h->front_fused && !h->no_front ? "k_plan_front" : "three launches", (double)h->skew_q16 / 65536.0, h->tile_v3);
+                  h->front_fused && !h->no_front ? "k_plan_front" : "three launches", (double)h->skew_q16 / 65536.0, h->tile_v3,
+                  h->rule.quant, h->rule.lerp, h->rule.fma, h->rule.order);
     return TPLHIP_OK;
 }
 
@@ -1281,7 +1317,8 @@ int apply_rule(tplhip_dp_lon* h, FilterRule r)
     int rc = wait_pending_forwards(h);
     if (rc) return rc;
     h->rule = r;
-    h->rule_set = !(r.quant == kDefaultRule.quant && r.lerp == kDefaultRule.lerp && r.fma == 0 && r.order == 0);
+    h->rule_set = !same_rule(r, kDefaultRule);
+    h->rule_all_forms = r.quant == kDefaultRule.quant && r.lerp == kDefaultRule.lerp && r.order == kDefaultRule.order;
     if (h->have_params) pick_div_forms(h);
     h->tables_valid = false;
     if (h->have_params && h->d_acts) {
@@ -1302,11 +1339,12 @@ int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_f
     return apply_rule(h, FilterRule{weight_quant, lerp_form, h->rule.fma, h->rule.order});
 }
 
-// R1: 0 = one rounding per operation of the reference source (the default), 1 = the multiply-adds nvcc's default -fmad=true
-// contracts, written out as fma() (FilterRule::fma; the sites are listed in the header of oracle/dp_lon_oracle.c).  A MODEL of
-// nvcc's fusion until it has been checked against a dump or the SASS of the reference build.  Every kernel
-// honours it: the plain-fp32 sweeps as template variants, the general sweep, rollout, re-evaluation, stage prelude and
-// distance map at run time.
+// R1: 1 = the multiply-adds nvcc's default -fmad=true contracts, written out as fma() (FilterRule::fma; the sites are listed in
+// the header of oracle/dp_lon_oracle.c) -- the DEFAULT since round 6, because that is how the reference's device code is built;
+// 0 = one rounding per operation of the reference source.  A MODEL of nvcc's fusion until it has been checked against a dump or
+// the SASS of the reference build.  Every kernel honours it: the plain-fp32 sweeps as template variants built
+// with every division form for both settings, the general sweep, rollout, re-evaluation, stage prelude and distance map at
+// run time (the instances that fold the default rule fold R1 = 1).
 int tplhip_dp_lon_set_contraction(tplhip_dp_lon* h, int on)
 {
     if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
@@ -1324,6 +1362,23 @@ int tplhip_dp_lon_set_blend_order(tplhip_dp_lon* h, int order)
     if (order < 0 || order > 3)
         return tplhip_fail(TPLHIP_EINVAL, "blend order: 0 (a -> v -> s), 1 (s -> v -> a), 2 (eight-corner sum, fp32), 3 (eight-corner sum, wide)");
     return apply_rule(h, FilterRule{h->rule.quant, h->rule.lerp, h->rule.fma, order});
+}
+
+// Diagnostics, host only (no device needed): is a plain-fp32 sweep instance built for this arithmetic rule and this pair of
+// division forms?  kind 1 = the two-rows-per-lane sweep (k_backward3v; k_backward3o when order != 0), 2 = one cell per lane
+// (k_backward3s, both prologue forms).  What pick_div_forms / use_v3 may select must be a subset of what this reports.
+int tplhip_dp_lon_sweep_built(int quant, int lerp, int fma, int order, int path_div, int range_div, int kind)
+{
+    const FilterRule r{quant, lerp, fma, order};
+    SweepArgs a{};
+    a.s_pad = 64;
+    t_sweep_probe = true;
+    bool ok = false;
+    if (kind == 1) ok = (order == 0 || backward3o_built(r)) && launch_backward3v(r, path_div, range_div, a, dim3(1, 1), 0, nullptr);
+    else if (kind == 2) ok = order == 0 && launch_backward3s(r, path_div, range_div, 3, false, a, dim3(1, 1), 0, nullptr)
+                              && launch_backward3s(r, path_div, range_div, 3, true, a, dim3(1, 1), 0, nullptr);
+    t_sweep_probe = false;
+    return ok ? 1 : 0;
 }
 
 int tplhip_dp_lon_timing_enable(tplhip_dp_lon* h, int enable)
@@ -1495,7 +1550,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
             hipLaunchKernelGGL((k_backward<true, 1, false>), dim3(h->grid, count), dim3(h->s_pad * h->rows_per_block), 0, h->stream,
                                out, out, h->d_acts, paths, pv, ps, h->d_pre_prog, p, h->s_pad, h->rows_per_block, h->nblocks,
                                h->tile_v, h->tile_a, tab_stride, pre_stride, path_stride, h->rule);
-        } else if (v3) {
+        } else if (v3 && [&] {
             SweepArgs a;
             a.next = next; a.out = out; a.acts = h->d_acts; a.path = paths; a.pre_vmax = pv; a.pre_sdist = ps;
             a.pre_prog = h->d_pre_prog; a.p = p; a.s_pad = h->vp_s_pad;
@@ -1503,8 +1558,10 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
             a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->range_aux;
             a.tile_v = h->tile_v3; a.tile_a = h->tile_a; a.skew_q16 = h->skew_q16;
             a.stride_tables = tab_stride; a.stride_pre = pre_stride; a.stride_path = path_stride;
-            launch_backward3v(h->rule, h->path_div3, h->range_div3, a, dim3(h->v3_grid, count),
-                              backward3v_lds_bytes(h->vp_s_pad, p.path_steps), h->stream);
+            return launch_backward3v(h->rule, h->path_div3, h->range_div3, a, dim3(h->v3_grid, count),
+                                     backward3v_lds_bytes(h->vp_s_pad, p.path_steps), h->stream);
+        }()) {
+            // (swept by the plain-fp32 kernel; no built instance for the pair -> the general sweep below, never a skipped stage)
         } else {
             auto go = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(h->grid, count), dim3(h->s_pad * h->rows_per_block), h->lds1_bytes, h->stream,

@@ -57,6 +57,10 @@ struct SweepArgs {
     size_t stride_tables, stride_pre, stride_path;
 };
 
+// true (on the calling thread only): the launchers below answer "is this combination built?" and launch nothing
+// (tplhip_dp_lon_sweep_built; tests/test_capi.py walks every (rule, division forms) pair the host can select)
+extern thread_local bool t_sweep_probe;
+
 // dp_sweep.hip.  path_div / range_div: the form of the two divisions by run-time constants -- 4 = power-of-two divisor
 // (one multiplication), 3 = two-float reciprocal (two plain fp32 instructions), 5 = reciprocal and one Newton step on the
 // quotient (three), each only after k_verify_div proved it equal to IEEE division on the whole range; 0 = IEEE division.

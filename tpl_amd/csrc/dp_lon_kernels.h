@@ -774,6 +774,21 @@ __global__ void __launch_bounds__(256) k_upload_words(const unsigned* __restrict
 }
 
 // ------------------------------------------------------------------------
+// What a rollout of the back-to-back mode reads besides its table set -- distance map, path, initial states -- into the
+// buffers of the plan's parity: three word copies in one launch (device to device).
+// ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_copy_fwd_inputs(const unsigned* __restrict__ src_a, unsigned* __restrict__ dst_a, unsigned words_a,
+                                                         const unsigned* __restrict__ src_b, unsigned* __restrict__ dst_b, unsigned words_b,
+                                                         const unsigned* __restrict__ src_c, unsigned* __restrict__ dst_c, unsigned words_c)
+{
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < words_a + words_b + words_c; i += gridDim.x * blockDim.x) {
+        if (i < words_a) dst_a[i] = src_a[i];
+        else if (i < words_a + words_b) dst_b[i - words_a] = src_b[i - words_a];
+        else dst_c[i - words_a - words_b] = src_c[i - words_a - words_b];
+    }
+}
+
+// ------------------------------------------------------------------------
 // updateDistMapPath, env.cu:131-158: ONE time slice of the distance map, by a whole workgroup (blockDim.x a multiple of
 // 64), into LDS.  occ: [l][s][t] (t fastest).
 // The reference walks idx_s from s_steps-1 down with d = occ > 0 ? 0 : d + step, d starting at 10000: at station i

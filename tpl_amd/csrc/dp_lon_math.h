@@ -2,8 +2,10 @@
 //
 // Every function states the reference lines it follows.  The arithmetic
 // contract (DESIGN.md "HP-1 arithmetic contract", rules R1-R4) is:
-//   R1  types exactly as the reference source promotes them, one rounding per
-//       operation, no FMA contraction (this TU is built -ffp-contract=off);
+//   R1  types exactly as the reference source promotes them; multiply-adds of one
+//       type contracted the way nvcc's default -fmad=true contracts device code,
+//       written out as fma() (madf / madd below); everything else one rounding per
+//       operation (this TU is built -ffp-contract=off: the compiler fuses nothing);
 //   R2  tex3D linear filter = floor/frac of (x-0.5), weight quantised to 8
 //       fractional bits, clamp addressing;
 //   R3  trilinear order a -> v -> s, lerp(p,q,w) = fmaf(q, w, p*(1-w));
@@ -26,20 +28,23 @@ __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x,
 // library (and the plain-fp32 sweeps of dp_sweep.hip) is built for the default rule: a default argument folds away.
 //   quant: 1 = weight rint(a * 256) / 256 (default), 2 = floor(a * 256) / 256, 0 = not quantised
 //   lerp : 0 = fma(q, w, p * (1 - w)) (default), 1 = p * (1 - w) + q * w with every operation rounded, 2 = p + w * (q - p)
-//   fma  : rule R1.  0 = one rounding per operation of the reference source (default), 1 = the contraction nvcc's default
-//          -fmad=true applies, written out: a*b + c -> fma(a, b, c), a*b + c*d -> fma(a, b, c*d), a - b*c -> fma(-b, c, a)
-//          wherever product and sum have the same type (madf / madd below; the sites are listed in the header of
-//          oracle/dp_lon_oracle.c, -DDPO_R1_FMA=1).  Set by tplhip_dp_lon_set_contraction; a run-time branch in the general
-//          kernels, a template bit of the plain-fp32 sweeps (kFma in dp_sweep.hip).
+//   fma  : rule R1.  1 = the contraction nvcc's default -fmad=true applies to the reference's device code (DEFAULT since
+//          round 6: the reference's build passes nothing that turns it off, library/CMakeLists.txt:89-99), written out:
+//          a*b + c -> fma(a, b, c), a*b + c*d -> fma(a, b, c*d), a - b*c -> fma(-b, c, a) wherever product and sum have the
+//          same type (madf / madd below; the sites are listed in the header of oracle/dp_lon_oracle.c) -- a MODEL of nvcc's
+//          fusion until checked against a dump;  0 = one rounding per operation of the reference source (the default until
+//          round 5).  Set by tplhip_dp_lon_set_contraction; a run-time branch in the general kernels, a template bit of the
+//          plain-fp32 sweeps (kFma in dp_sweep.hip) -- both settings are built with every division form.
 //   order: rule R3's ORDER / form (round 5; tplhip_dp_lon_set_blend_order).  0 = three sequential blends a -> v -> s (default:
 //          the order that lets the sweeps blend whole rows with row-uniform weights), 1 = s -> v -> a (the texture's x first),
 //          2 = the symmetric eight-corner sum  sum_c w_c T_c  with w_c = (w_s * w_v) * w_a (exact for 8-bit weights), products and
 //          sums rounded in fp32 in the order of the documented formula (corner = s + 2 v + 4 a), 3 = the same sum with exact
 //          products in a double accumulator and one rounding.  `lerp` does not apply to 2 and 3.  The distance map's 2-D
 //          lookup (x = t with weight 0, y = s) is the same for every sequential order and becomes a four-corner sum under 2 / 3.
-//          oracle/dp_lon_oracle.c -DDPO_BLEND_ORDER=n is the same arithmetic.
+//          oracle/dp_lon_oracle.c under dpo_set_rule(., ., ., n) is the same arithmetic.
 struct FilterRule { int quant, lerp, fma, order; };
-constexpr FilterRule kDefaultRule{1, 0, 0, 0};
+constexpr FilterRule kDefaultRule{1, 0, 1, 0};
+__host__ __device__ constexpr bool same_rule(FilterRule a, FilterRule b) { return a.quant == b.quant && a.lerp == b.lerp && a.fma == b.fma && a.order == b.order; }
 
 // a*b + c under rule R1 (this file is built -ffp-contract=off: the unfused form keeps its two roundings)
 __device__ __forceinline__ float madf(float a, float b, float c, FilterRule r) { return r.fma ? fmaf(a, b, c) : a * b + c; }

@@ -298,6 +298,8 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         for (int k = 0; k < N_BWD; ++k) {
             const ActDesc& x = d0[i * rs + k];
             const ActDesc& y = d0[(i + 1) * rs + k];
+            // (short-circuit on purpose: the same test with `&` -- every descriptor word of the nine actions requested at once, 100
+            // scalar registers -- LOSES, 38.5 -> 39.5 us per 256x128x64 sweep and 315 -> 333 on 512x256x128; profiles/r06_dp_contraction_ab.txt)
             const bool sh = x.r01 == y.r00 && x.r11 == y.r10 && __float_as_uint(x.wa) == __float_as_uint(y.wa);
             shared_mask |= (sh ? 1u : 0u) << (i * N_BWD + k);
         }
@@ -323,6 +325,14 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     int bk[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) { best[i] = 0x7f8000007f800000ull; bk[i] = 0; }
+    // The per-cell state terms are finished HERE, in front of the barrier (an empty `asm` on their registers).  Left alone the
+    // compiler sinks the whole block -- 35 instructions, 50 with the fp64 fma chains of contracted arithmetic -- into phase 1 of
+    // action 0, between a wave's row stores and the barrier its workgroup waits at: every workgroup's first barrier is late by
+    // that chain.  Round 6, same box, alone on the chip: R1 = 1 39.5-40.0 -> 38.4-38.8 us per 256x128x64 sweep, R1 = 0
+    // 38.9-39.5 -> 38.5-39.0 (profiles/r06_dp_contraction_ab.txt) -- what made the contracted instance, which has FEWER
+    // instructions, the slower of the two.
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(sc[i]), "+v"(sg[i]), "+v"(sd_base[i]));
     __syncthreads();                     // descriptors and path limits are in LDS
     // (the descriptor copy's LDS address stays in ONE vector register where there is one to spare: otherwise it is moved there
     // from a scalar one per action)
@@ -1068,11 +1078,12 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 
 } // namespace
 
-// ---- launchers.  This file is compiled five times (Makefile): TPL_SWEEP_RULESET 0 = the default rules with every
-// pair of division forms, 1 and 2 = four of the eight other (R2, R3) rules each, 3 and 4 = the nine (R2, R3) rules under
-// contracted arithmetic (R1 = 1), all of those with both divisions in the Newton form
-// (5, 5) or both as IEEE divisions (0, 0) -- a rule other than the default is only ever selected to follow a dump of the
-// reference build, and then runs on the same plain-fp32 sweeps as the default.
+// ---- launchers.  This file is compiled ten times (Makefile): TPL_SWEEP_RULESET 0 = the default rule (R1 = 1 contracted,
+// R2 rint, R3 fma form) with every pair of division forms, 9 = the same filter rule under R1 = 0 (one rounding per
+// operation: the default until round 5), also with every pair; 1 and 2 = four of the eight other (R2, R3) rules each under
+// R1 = 0, 3 and 4 = those eight under R1 = 1, all of those with both divisions in the Newton form (5, 5) or both as IEEE
+// divisions (0, 0) -- such a rule is only ever selected to follow a dump of the reference build, and then runs on the same
+// plain-fp32 sweeps as the default; 5 - 8 = the ordered sweeps k_backward3o.
 #ifndef TPL_SWEEP_RULESET
 #define TPL_SWEEP_RULESET 0
 #endif
@@ -1084,7 +1095,7 @@ bool pick_div_v(int path_div, int range_div, bool all_forms, Go go)
 {
     if (path_div == 5 && range_div == 5) return go(k_backward3v<5, 5, QUANT, LERP>);
     if (path_div == 0 && range_div == 0) return go(k_backward3v<0, 0, QUANT, LERP>);
-    if constexpr (QUANT == 1 && LERP == 0) {
+    if constexpr (QUANT == 1 && (LERP & 3) == 0) {
         if (all_forms) {
             if (path_div == 4 && range_div == 3) return go(k_backward3v<4, 3, QUANT, LERP>);
             if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3, QUANT, LERP>);
@@ -1110,7 +1121,7 @@ bool pick_div_s(int path_div, int range_div, bool all_forms, Go go)
 {
     if (path_div == 5 && range_div == 5) return go(k_backward3s<5, 5, QUANT, LERP, 3, FE>);
     if (path_div == 0 && range_div == 0) return go(k_backward3s<0, 0, QUANT, LERP, 3, FE>);
-    if constexpr (QUANT == 1 && LERP == 0) {
+    if constexpr (QUANT == 1 && (LERP & 3) == 0) {
         if (all_forms) {
             if (path_div == 4 && range_div == 3) return go(k_backward3s<4, 3, QUANT, LERP, 3, FE>);
             if (path_div == 3 && range_div == 3) return go(k_backward3s<3, 3, QUANT, LERP, 3, FE>);
@@ -1135,6 +1146,7 @@ template <int QUANT, int LERP>
 bool launch_v_rule(int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
     auto go = [&](auto kernel) {
+        if (t_sweep_probe) return true;
         hipLaunchKernelGGL(kernel, grid, dim3(a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
         return true;
     };
@@ -1145,6 +1157,7 @@ template <int QUANT, int LERP>
 bool launch_s_rule(int path_div, int range_div, bool first_early, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
     auto go = [&](auto kernel) {
+        if (t_sweep_probe) return true;
         hipLaunchKernelGGL(kernel, grid, dim3(a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
         return true;
     };
@@ -1156,6 +1169,7 @@ template <int QUANT, int LERP, int ORDER>
 bool launch_o_rule(int path_div, int range_div, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
     auto go = [&](auto kernel) {
+        if (t_sweep_probe) return true;
         hipLaunchKernelGGL(kernel, grid, dim3(a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
         return true;
     };
@@ -1183,8 +1197,8 @@ TPL_RULE_FILE(a, TPL_RULE_V(1, 1, 0) TPL_RULE_V(1, 2, 0) TPL_RULE_V(2, 0, 0) TPL
 TPL_RULE_FILE(b, TPL_RULE_V(2, 2, 0) TPL_RULE_V(0, 0, 0) TPL_RULE_V(0, 1, 0) TPL_RULE_V(0, 2, 0),
                  TPL_RULE_S(2, 2, 0) TPL_RULE_S(0, 0, 0) TPL_RULE_S(0, 1, 0) TPL_RULE_S(0, 2, 0))
 #elif TPL_SWEEP_RULESET == 3      /* contracted arithmetic (rule R1 = 1), first half */
-TPL_RULE_FILE(c, TPL_RULE_V(1, 0, 1) TPL_RULE_V(2, 0, 1) TPL_RULE_V(0, 0, 1) TPL_RULE_V(1, 1, 1) TPL_RULE_V(1, 2, 1),
-                 TPL_RULE_S(1, 0, 1) TPL_RULE_S(2, 0, 1) TPL_RULE_S(0, 0, 1) TPL_RULE_S(1, 1, 1) TPL_RULE_S(1, 2, 1))
+TPL_RULE_FILE(c, TPL_RULE_V(2, 0, 1) TPL_RULE_V(0, 0, 1) TPL_RULE_V(1, 1, 1) TPL_RULE_V(1, 2, 1),
+                 TPL_RULE_S(2, 0, 1) TPL_RULE_S(0, 0, 1) TPL_RULE_S(1, 1, 1) TPL_RULE_S(1, 2, 1))
 #elif TPL_SWEEP_RULESET == 4      /* contracted arithmetic, second half */
 TPL_RULE_FILE(d, TPL_RULE_V(2, 1, 1) TPL_RULE_V(2, 2, 1) TPL_RULE_V(0, 1, 1) TPL_RULE_V(0, 2, 1),
                  TPL_RULE_S(2, 1, 1) TPL_RULE_S(2, 2, 1) TPL_RULE_S(0, 1, 1) TPL_RULE_S(0, 2, 1))
@@ -1196,6 +1210,8 @@ TPL_ORDER_FILE(f, TPL_RULE_O(1, 0, 1, 1) TPL_RULE_O(1, 1, 1, 1) TPL_RULE_O(1, 2,
 TPL_ORDER_FILE(g, TPL_RULE_O(1, 0, 0, 2) TPL_RULE_O(2, 0, 0, 2) TPL_RULE_O(1, 0, 1, 2) TPL_RULE_O(2, 0, 1, 2))
 #elif TPL_SWEEP_RULESET == 8      /* the eight-corner sum, wide accumulator */
 TPL_ORDER_FILE(h, TPL_RULE_O(1, 0, 0, 3) TPL_RULE_O(2, 0, 0, 3) TPL_RULE_O(1, 0, 1, 3) TPL_RULE_O(2, 0, 1, 3))
+#elif TPL_SWEEP_RULESET == 9      /* the default filter rule under R1 = 0 (one rounding per operation), every division form */
+TPL_RULE_FILE(i, TPL_RULE_V(1, 0, 0), TPL_RULE_S(1, 0, 0))
 #else
 #define TPL_ORDER_DECL(NAME) \
     bool launch_backward3o_rules_##NAME(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
@@ -1203,7 +1219,7 @@ TPL_ORDER_DECL(e) TPL_ORDER_DECL(f) TPL_ORDER_DECL(g) TPL_ORDER_DECL(h)
 #define TPL_RULE_DECL(NAME) \
     bool launch_backward3v_rules_##NAME(FilterRule r, int pd, int rd, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st); \
     bool launch_backward3s_rules_##NAME(FilterRule r, int pd, int rd, bool fe, const SweepArgs& a, dim3 grid, size_t lds, hipStream_t st);
-TPL_RULE_DECL(a) TPL_RULE_DECL(b) TPL_RULE_DECL(c) TPL_RULE_DECL(d)
+TPL_RULE_DECL(a) TPL_RULE_DECL(b) TPL_RULE_DECL(c) TPL_RULE_DECL(d) TPL_RULE_DECL(i)
 
 size_t backward3v_lds_bytes(int s_pad, int path_steps)
 {
@@ -1229,8 +1245,9 @@ bool launch_backward3v(FilterRule rule, int path_div, int range_div, const Sweep
                || launch_backward3o_rules_g(rule, path_div, range_div, a, grid, lds, stream)
                || launch_backward3o_rules_h(rule, path_div, range_div, a, grid, lds, stream);
     }
-    if (rule.quant == kDefaultRule.quant && rule.lerp == kDefaultRule.lerp && !rule.fma)
-        return launch_v_rule<1, 0>(path_div, range_div, a, grid, lds_bytes, stream);
+    if (rule.quant == kDefaultRule.quant && rule.lerp == kDefaultRule.lerp)
+        return rule.fma ? launch_v_rule<1, 4>(path_div, range_div, a, grid, lds_bytes, stream)
+                        : launch_backward3v_rules_i(rule, path_div, range_div, a, grid, lds_bytes, stream);
     if (rule.fma)
         return launch_backward3v_rules_c(rule, path_div, range_div, a, grid, lds_bytes, stream)
                || launch_backward3v_rules_d(rule, path_div, range_div, a, grid, lds_bytes, stream);
@@ -1248,8 +1265,9 @@ size_t backward3s_lds_bytes(int kc, int s_pad, int path_steps)
 bool launch_backward3s(FilterRule rule, int path_div, int range_div, int kc, bool first_early, const SweepArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
     if (a.s_pad > 256 || lds_bytes > 64 * 1024 || kc != 3) return false;
-    if (rule.quant == kDefaultRule.quant && rule.lerp == kDefaultRule.lerp && !rule.fma)
-        return launch_s_rule<1, 0>(path_div, range_div, first_early, a, grid, lds_bytes, stream);
+    if (rule.quant == kDefaultRule.quant && rule.lerp == kDefaultRule.lerp)
+        return rule.fma ? launch_s_rule<1, 4>(path_div, range_div, first_early, a, grid, lds_bytes, stream)
+                        : launch_backward3s_rules_i(rule, path_div, range_div, first_early, a, grid, lds_bytes, stream);
     if (rule.fma)
         return launch_backward3s_rules_c(rule, path_div, range_div, first_early, a, grid, lds_bytes, stream)
                || launch_backward3s_rules_d(rule, path_div, range_div, first_early, a, grid, lds_bytes, stream);

@@ -175,7 +175,16 @@ TPL_HD inline double tpl_div_invariant(double a, double b)
 #if defined(__HIP_DEVICE_COMPILE__)
     const double r = 1.0 / b;
     const double q0 = a * r;
-    return fma(fma(-q0, b, a), r, q0);
+    double q = fma(fma(-q0, b, a), r, q0);
+    // Outside the domain of that identity the correction turns inf into NaN (a = +-inf: a line-search candidate that diverged;
+    // b = 0) -- the look-up would then read data[0] where `/` reads data[n - 1], which is what the oracle and the reference do.
+    // One compare and a branch no lane takes on the fast path (the guard idiom of this file); a NaN dividend takes it too.
+    // (A SUBNORMAL dividend can lose its last bit here: its quotient is an interpolation weight below 2^-1022 either way.)
+    if (TPL_ANY_LANE(!(fabs(q0) < 1.0e300))) {
+        TPL_SLOW_PATH();
+        if (!(fabs(q0) < 1.0e300)) q = a / b;
+    }
+    return q;
 #else
     return a / b;
 #endif

@@ -2926,6 +2926,12 @@ int tplhip_ilqr_download(tplhip_ilqr* h)
     return TPLHIP_OK;
 }
 
+#ifndef TPL_ILQR_SCHED
+#define TPL_ILQR_SCHED "default"
+#endif
+// the same label as a marker in the file itself: genopt.compile_model reads it (no GPU, no dlopen) before it reuses a cached library
+__attribute__((used)) static const char k_sched_marker[] = "tplhip_ilqr_sched=" TPL_ILQR_SCHED;
+
 int tplhip_ilqr_info(tplhip_ilqr* h, char* buf, int n)
 {
     if (!h || !buf || n < 1) return fail(TPLHIP_EINVAL, "bad argument");

@@ -577,7 +577,8 @@ class DynProgLonPlanner:
 
     def set_contraction(self, on=True):
         """R1 of the HP-1 arithmetic contract: the multiply-adds nvcc fuses by default (-fmad=true), written out as
-        fma() calls; off is the default.  See ``tplhip_dp_lon_set_contraction`` in include/tplhip.h."""
+        fma() calls.  ON is the default (it is how the reference's device code is built); ``False`` = one rounding per
+        source operation.  See ``tplhip_dp_lon_set_contraction`` in include/tplhip.h."""
         check(self._lib.tplhip_dp_lon_set_contraction(self._h, int(on)))
 
     def set_blend_order(self, order=0):

@@ -829,17 +829,21 @@ def compile_model(name, out_dir=None, force=False, extra_flags=None, so_path=Non
     if so_path:
         paths["so"] = so_path
     src = os.path.join(CSRC_ILQR, "ilqr_model.hip")
-    deps = [paths["inc"], src, os.path.abspath(__file__), os.path.join(CSRC_ILQR, "..", "tplhip_debug.h")] \
+    deps = [paths["inc"], src, os.path.abspath(__file__), os.path.join(os.path.dirname(os.path.abspath(__file__)), "isa_check.py"),
+            os.path.join(CSRC_ILQR, "..", "tplhip_debug.h")] \
         + [os.path.join(CSRC_ILQR, f) for f in os.listdir(CSRC_ILQR) if f.endswith(".h")]
+    if scheduler is not None and scheduler not in SCHEDULERS:
+        raise ValueError(f"scheduler must be one of {SCHEDULERS}")
     if not force and os.path.exists(paths["so"]):
-        if all(os.path.getmtime(paths["so"]) >= os.path.getmtime(d) for d in deps):
+        # a cached library is reused only if it is newer than everything it was built from AND, when the caller names a
+        # scheduler, was built under that one (the label is compiled into the library: TPL_ILQR_SCHED)
+        fresh = all(os.path.getmtime(paths["so"]) >= os.path.getmtime(d) for d in deps)
+        if fresh and (scheduler is None or built_scheduler(paths["so"]) == scheduler):
             return paths["so"]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = paths["so"] + f".tmp{os.getpid()}"
     import shutil
     import tempfile
-    if scheduler is not None and scheduler not in SCHEDULERS:
-        raise ValueError(f"scheduler must be one of {SCHEDULERS}")
     # a caller that names a strategy in its own flags (the tests of the scan do) gets exactly that build
     own = any("amdgpu-sched-strategy" in f for f in (extra_flags or []))
     order = ("as given",) if own else ((scheduler,) if scheduler else SCHEDULERS)
@@ -872,6 +876,19 @@ def compile_model(name, out_dir=None, force=False, extra_flags=None, so_path=Non
         finally:
             shutil.rmtree(work, ignore_errors=True)
     raise RuntimeError(failure)
+
+
+def built_scheduler(so):
+    """The scheduler label compiled into a solver library (-DTPL_ILQR_SCHED="..."; `Optim.info()["scheduler"]` reports the same
+    string on a GPU box), read from the file: no GPU, no dlopen.  None when the library carries no label."""
+    try:
+        blob = open(so, "rb").read()
+    except OSError:
+        return None
+    for label in SCHEDULERS:
+        if b"tplhip_ilqr_sched=" + label.encode() + b"\0" in blob:
+            return label
+    return None
 
 
 def exec0_hits(listing):

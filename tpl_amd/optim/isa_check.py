@@ -22,6 +22,13 @@ unrelated code (a change of builtins.h at the end of round 5 moved all nine mode
 of assuming: tpl_amd/optim/genopt.py runs it on every solver library it builds -- under max-ilp first (2 % faster on the heavy
 models), and on a hit the library is thrown away and built under the default strategy; only a second hit fails the build.
 
+LIMITS.  The scan recognises ONE code shape, the one the miscompile was observed in: `s_andn2_b64 exec, exec, ...` directly
+followed by `s_cbranch_execnz` with a fall-through exit, and vector instructions between that branch and the next write of
+EXEC.  It stops at the first `s_* exec, ...` write even if that write leaves EXEC at 0 (a second andn2 / and), at any branch,
+and after 400 lines; other ways of reaching EXEC = 0 (a `s_and_saveexec` whose mask is empty, structured `if` regions) are not
+modelled.  A clean scan therefore says "the known pattern is absent", NOT "no instruction executes at EXEC = 0": the bit-level
+tests (13 goldens x 4 launch forms, the other-scheduler test, the fuzzes) remain the proof of the build.
+
     python -m tpl_amd.optim.isa_check listing.s [...]      (or tools/find_exec0_spills.py) exit code 1 when anything is found
 """
 import re
