@@ -82,3 +82,36 @@ def test_param_surface_matches_reference_slots():
     assert list(s.as_numpy()) == [1.0, 2.0, 3.0, 4.0]
     with pytest.raises(AttributeError):
         p.nonexistent = 1
+
+
+def test_every_selectable_rule_has_a_built_sweep():
+    """Every (arithmetic rule, division forms) pair the host can select for a plain-fp32 sweep has a built kernel instance
+    (tplhip_dp_lon_sweep_built: host only, launches nothing).  pick_div_forms (dp_lon.hip) gives the texture-filter defaults
+    (R2 rint, R3 fma form, a -> v -> s) -- under BOTH settings of R1 -- the cheapest proven form per divisor, i.e. any pair of
+    {4, 3, 5, 0}; every other rule both divisions in the Newton form (5, 5) or both IEEE (0, 0); another blend order runs
+    k_backward3o for the weight rules rint and floor (un-quantised weights take the general sweep: use_v3) and has no
+    one-cell-per-lane form.  A selectable pair without an instance would send its stages to the general sweep silently
+    (ADVICE r5): this is the test that says the two sides agree."""
+    lib = _capi.load()
+    built = lib.tplhip_dp_lon_sweep_built
+    forms = (4, 3, 5, 0)
+    n = 0
+    for quant in (0, 1, 2):
+        for lerp in (0, 1, 2):
+            for fma in (0, 1):
+                for order in (0, 1, 2, 3):
+                    all_forms = (quant, lerp, order) == (1, 0, 0)
+                    pairs = [(a, b) for a in forms for b in forms] if all_forms else [(5, 5), (0, 0)]
+                    for pd, rd in pairs:
+                        if order == 0:
+                            assert built(quant, lerp, fma, order, pd, rd, 1) == 1, (quant, lerp, fma, order, pd, rd, "k_backward3v")
+                            assert built(quant, lerp, fma, order, pd, rd, 2) == 1, (quant, lerp, fma, order, pd, rd, "k_backward3s")
+                            n += 2
+                        elif quant in (1, 2):
+                            assert built(quant, lerp, fma, order, pd, rd, 1) == 1, (quant, lerp, fma, order, pd, rd, "k_backward3o")
+                            n += 1
+                        else:
+                            assert built(quant, lerp, fma, order, pd, rd, 1) == 0      # not built, and use_v3 never selects it
+    assert n == 2 * (2 * 16 + 16 * 2) + 3 * 2 * 3 * 2 * 2
+    # what is NOT selectable is not claimed: a non-default filter rule with a mixed pair of forms
+    assert built(2, 0, 1, 0, 4, 3, 1) == 0 and built(1, 0, 1, 0, 7, 7, 1) == 0
