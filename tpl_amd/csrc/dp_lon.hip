@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <algorithm>
 #include <cmath>
 #include <thread>
 #include <cstdarg>
@@ -145,6 +146,9 @@ struct tplhip_dp_lon {
     int sc_last_first = 0, sc_last_count = 0;
     bool v3_ok = false;                  // the two-rows-per-lane geometry of k_backward3v fits this grid
     int v3_grid = 0;
+    unsigned* d_v3_map = nullptr;        // v3_map_block per workgroup of that grid (SweepArgs::tile_map)
+    size_t v3_map_cap = 0;
+    int v3_map_key[6] = {0, 0, 0, 0, 0, 0};   // what the table was built for: v_steps, a_steps, tile_v3, tile_a, skew_q16, v3_grid
     bool no_v3 = false, no_fwd_overlap = false, no_fwd_spec = false, no_front = false;   // TPLHIP_DEBUG overrides, read by reinit
     bool front_fused = true;                 // what the last plan did (info)
     FilterRule rule = kDefaultRule;      // R1 - R3 of the arithmetic contract (tplhip_dp_lon_set_filter_rule / _set_contraction / _set_blend_order)
@@ -193,6 +197,7 @@ void free_planner_buffers(tplhip_dp_lon* h)
     h->d_table_set[0] = h->d_table_set[1] = nullptr; h->d_tables = nullptr;
     h->overlap = false; h->fwd_pending[0] = h->fwd_pending[1] = false;
     (void)hipFree(h->d_acts);      h->d_acts = nullptr;
+    (void)hipFree(h->d_v3_map);    h->d_v3_map = nullptr; h->v3_map_cap = 0;
     (void)hipFree(h->d_path);      h->d_path = nullptr;
     (void)hipFree(h->d_pre_vmax);  h->d_pre_vmax = nullptr;
     (void)hipFree(h->d_pre_sdist); h->d_pre_sdist = nullptr;
@@ -318,7 +323,7 @@ bool launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
     a.s_pad = h->vp_s_pad;
     a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->path_aux;
     a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->range_aux;
-    a.tile_v = h->tile_v3; a.tile_a = h->tile_a; a.skew_q16 = h->skew_q16;
+    a.tile_v = h->tile_v3; a.tile_a = h->tile_a; a.skew_q16 = h->skew_q16; a.tile_map = h->d_v3_map;
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
     return launch_backward3v(h->rule, h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
 }
@@ -338,7 +343,7 @@ bool launch_backward3s_(tplhip_dp_lon* h, int idx_t, int nx)
     a.s_pad = h->vp_s_pad;
     a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->path_aux;
     a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->range_aux;
-    a.tile_v = h->tile_v; a.tile_a = h->tile_a; a.skew_q16 = h->skew_q16;
+    a.tile_v = h->tile_v; a.tile_a = h->tile_a; a.skew_q16 = h->skew_q16; a.tile_map = nullptr;
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
     return launch_backward3s(h->rule, h->path_div3, h->range_div3, h->s3_kc, h->s3_first_early, a, dim3(h->s3_grid, 1), h->s3_lds, h->stream);
 }
@@ -948,6 +953,27 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
             }
             h->v3_ok = h->v3_ok && (h->tile_v3 % 2 == 0);
         }
+        // the traversal as a table: one word per workgroup (16 KB on 256x128x64), rebuilt whenever the geometry may have changed
+        const int key[6] = {p.v_steps, p.a_steps, h->tile_v3, h->tile_a, h->skew_q16, h->v3_grid};
+        if (h->d_v3_map && std::equal(key, key + 6, h->v3_map_key)) {
+            // (a reinit that changes no size -- what tpl's planner does every cycle -- keeps the table: no copy, no wait)
+        } else if (h->v3_ok && p.a_steps < 65536 && p.v_steps < 65536) {
+            std::vector<unsigned> map((size_t)h->v3_grid);
+            for (int bx = 0; bx < h->v3_grid; ++bx) {
+                int ia = 0, iv = 0;
+                map[(size_t)bx] = v3_map_block(bx, p.v_steps, p.a_steps, h->tile_v3, h->tile_a, h->skew_q16, ia, iv)
+                                      ? ((unsigned)ia << 16) | (unsigned)iv : V3_MAP_NONE;
+            }
+            if (map.size() > h->v3_map_cap) {
+                (void)hipFree(h->d_v3_map); h->d_v3_map = nullptr; h->v3_map_cap = 0;
+                HIP_TRY(hipMalloc(&h->d_v3_map, sizeof(unsigned) * map.size()), "traversal table allocation failed");
+                h->v3_map_cap = map.size();
+            }
+            HIP_TRY(hipMemcpy(h->d_v3_map, map.data(), sizeof(unsigned) * map.size(), hipMemcpyHostToDevice), "traversal table upload failed");
+            std::copy(key, key + 6, h->v3_map_key);
+        } else {
+            (void)hipFree(h->d_v3_map); h->d_v3_map = nullptr; h->v3_map_cap = 0;
+        }
     }
     // Grids that leave the chip mostly empty (the kchunk = 3 class above) with rows of at most 256 lanes: k_backward3s,
     // one cell per lane on the plain-fp32 instruction stream, three actions per barrier round (TPLHIP_DEBUG=no_s3: k_backward)
@@ -1556,7 +1582,7 @@ int tplhip_dp_lon_scenarios_plan(tplhip_dp_lon* h, int first, int count, int id_
             a.pre_prog = h->d_pre_prog; a.p = p; a.s_pad = h->vp_s_pad;
             a.rcp_path_hi = h->rcp_path_step; a.rcp_path_lo = h->path_aux;
             a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->range_aux;
-            a.tile_v = h->tile_v3; a.tile_a = h->tile_a; a.skew_q16 = h->skew_q16;
+            a.tile_v = h->tile_v3; a.tile_a = h->tile_a; a.skew_q16 = h->skew_q16; a.tile_map = h->d_v3_map;
             a.stride_tables = tab_stride; a.stride_pre = pre_stride; a.stride_path = path_stride;
             return launch_backward3v(h->rule, h->path_div3, h->range_div3, a, dim3(h->v3_grid, count),
                                      backward3v_lds_bytes(h->vp_s_pad, p.path_steps), h->stream);

@@ -16,6 +16,10 @@ constexpr int N_FWD = 21;   // evalNode<21>, lon_planner.cu:220
 // with themselves -- the same bits for half the row loads of such an action (a third to a half of all actions on the
 // benchmark grids: the jerk grid lands on the acceleration grid).
 constexpr int ACT_SINGLE_A = 1;
+// The row above -- (v + 1, a), the second row of this row's pair in the two-rows-per-lane sweeps; the row itself where v + 1 is
+// past the grid -- reads for this action, as the lower pair of its source window, this row's upper pair under the same weight
+// along a: "upper a-blend of row 0" IS "lower a-blend of row 1", one blend and two row loads less (dp_sweep.hip).
+constexpr int ACT_SHARED_UP = 2;
 
 // Per-(row, action) constants of the backward sweep.  Everything here depends
 // only on (v, a, jerk_k, dt) -- never on the station or the stage.
@@ -34,9 +38,42 @@ struct alignas(16) ActDesc {
     int r00, r10, r01, r11;   // next-stage rows (a*V + v) of the corners (a0,v0) (a1,v0) (a0,v1) (a1,v1)
     double a_term;      // ((0.5*a)*dt)*dt             lon_planner.cu:244   (the same for the nine actions of a row)
     float vdt;          // v*dt                                              (the same for the nine actions of a row)
-    int flags;          // bit 0: the blend along a is trivial -- both a-rows are the same row (clamped) or wa == 0 -- see ACT_SINGLE_A
+    int flags;          // bit 0: the blend along a is trivial -- both a-rows are the same row (clamped) or wa == 0 -- see ACT_SINGLE_A;
+                        // bit 1: ACT_SHARED_UP
 };
 static_assert(sizeof(ActDesc) == 80, "ActDesc must be 80 bytes");
+
+// Traversal of the two-rows-per-lane sweeps (k_backward3v / k_backward3o): workgroup bx -> the row pair (a, v), (a, v + 1).
+// XCD = bx & 7 owns a contiguous run of the row PAIRS of every a-slice (so any v_steps works; with an odd v_steps the last
+// "pair" is row V-1 twice); inside its share the workgroups walk strips of tile_v / 2 pairs a-major in tiles of tile_a rows.
+// Skew: the successor row of (a, v) under the action that leads to a' is v' = v + dt (a + a') / 2, so the source rows that
+// read the SAME next-stage rows lie on lines v + a dt / 2 = const.  The pairs of an a-row are rotated (inside the XCD's share, a
+// bijection per a-row) by that slope, skew_q16 / 65536 pairs per a-row: the workgroups resident on an XCD at one time -- a few
+// pairs by several dozen a-rows -- then touch a band of v' rows as narrow as the strip itself instead of one widened by the
+// a-extent (profiles/r04_dp_config4_skew.txt).  false: bx is past the XCD's share (the grid is sized for the widest one).
+// ONE definition for the host, which tabulates it once per reinit (tplhip_dp_lon::d_v3_map -> SweepArgs::tile_map: the three
+// integer divisions and the modulo are ~150 scalar instructions in front of a workgroup's first row request), and the kernels'
+// fallback without a table.
+__host__ __device__ inline bool v3_map_block(int bx, int V, int A, int tile_v, int tile_a, int skew_q16, int& ia, int& iv)
+{
+    const int xcd = bx & 7;
+    const int NP = (V + 1) / 2;
+    const int p_lo = (xcd * NP) >> 3, p_hi = ((xcd + 1) * NP) >> 3;
+    const int vx = p_hi - p_lo, tv = tile_v / 2 > 1 ? tile_v / 2 : 1;
+    const int q = bx >> 3;
+    if (q >= vx * A) return false;
+    const int full = vx / tv;
+    int strip = q / (A * tv), w = tv, rem = q - strip * (A * tv);
+    if (strip >= full) { strip = full; w = vx - full * tv; rem = q - full * (A * tv); }
+    const int tile = rem / (tile_a * w);
+    const int r = rem - tile * (tile_a * w);
+    ia = tile * tile_a + r / w;
+    int lp = strip * tv + (r - (r / w) * w);
+    if (skew_q16) { lp -= (int)(((long long)ia * skew_q16) >> 16) % vx; if (lp < 0) lp += vx; }
+    iv = 2 * (p_lo + lp);
+    return true;
+}
+constexpr unsigned V3_MAP_NONE = 0xffffffffu;
 
 // Everything a sweep launch needs besides the tables (filled by the host driver in dp_lon.hip).
 struct SweepArgs {
@@ -53,6 +90,7 @@ struct SweepArgs {
     float rcp_range_hi, rcp_range_lo;    // 1/(s_max - s_min) likewise
     int tile_v, tile_a;
     int skew_q16;              // k_backward3v: rotation of the row pairs of an a-row, pairs per a-row in 16.16 fixed point (0: none)
+    const unsigned* tile_map;  // k_backward3v / 3o: v3_map_block tabulated per workgroup, (a << 16) | v, V3_MAP_NONE past the share; null: computed
     // scenario batch (blockIdx.y): element strides between consecutive scenarios, 0 = shared
     size_t stride_tables, stride_pre, stride_path;
 };

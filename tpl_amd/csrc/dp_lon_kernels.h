@@ -18,16 +18,8 @@ namespace {
 // ------------------------------------------------------------------------
 // descriptor table: one thread per (row, action)
 // ------------------------------------------------------------------------
-__global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p, FilterRule rule)
+__device__ __forceinline__ ActDesc make_action_desc(const TplDpLonParams& p, FilterRule rule, int ia, int iv, int k)
 {
-    const int nrows = p.v_steps * p.a_steps;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nrows * N_BWD) return;
-    const int row = idx / N_BWD;
-    const int k = idx - row * N_BWD;
-    const int ia = row / p.v_steps;
-    const int iv = row - ia * p.v_steps;
-
     TplLonState tp;
     tp.t = 0.0f; tp.s = 0.0f; tp.j = 0.0f; tp.cost = 0.0f; tp.constr = 0.0f;
     tp.v = grid_pt(p.v_min, (float)iv, p._v_step_size, rule);      // lon_planner.cu:198
@@ -64,6 +56,24 @@ __global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p, Fi
     d.r11 = ta.i1 * p.v_steps + tv.i1;
     d.flags = ((d.r00 == d.r10 && d.r01 == d.r11) || d.wa == 0.0f) ? ACT_SINGLE_A : 0;
     d.tn_v_d = (double)tn.v;
+    return d;
+}
+
+__global__ void k_build_actions(ActDesc* __restrict__ acts, TplDpLonParams p, FilterRule rule)
+{
+    const int nrows = p.v_steps * p.a_steps;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * N_BWD) return;
+    const int row = idx / N_BWD;
+    const int k = idx - row * N_BWD;
+    const int ia = row / p.v_steps;
+    const int iv = row - ia * p.v_steps;
+    ActDesc d = make_action_desc(p, rule, ia, iv, k);
+    // ACT_SHARED_UP: the row the two-rows-per-lane sweeps pair this one with -- (v + 1, a), or this row again where v + 1 is past
+    // the grid -- takes for action k, as the LOWER pair of its 2 x 2 source window, exactly this row's UPPER pair under the same
+    // weight along a (the test the sweeps used to make per workgroup from both descriptors, up to 27 dependent scalar loads)
+    const ActDesc y = make_action_desc(p, rule, ia, iv + 1 < p.v_steps ? iv + 1 : iv, k);
+    if (d.r01 == y.r00 && d.r11 == y.r10 && __float_as_uint(d.wa) == __float_as_uint(y.wa)) d.flags |= ACT_SHARED_UP;
     acts[idx] = d;
 }
 

@@ -185,31 +185,14 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     const float* __restrict__ path = path_all + scn * a.stride_path;
 
     constexpr int NV = 2;
-    // traversal: as k_backward (XCD = blockIdx.x & 7 owns a v range, a-major tiles inside), in units of row PAIRS,
-    // so that any v_steps works: the pairs (0,1), (2,3), ... of an a-slice are dealt to the XCDs in contiguous runs;
-    // with an odd v_steps the last "pair" is row V-1 twice (second copy computed, not stored)
-    const int xcd = blockIdx.x & 7;
-    const int NP = (V + NV - 1) / NV;
-    const int p_lo = (xcd * NP) >> 3, p_hi = ((xcd + 1) * NP) >> 3;
-    const int vx = p_hi - p_lo, tv = max(1, a.tile_v / NV);
-    const int q = (int)(blockIdx.x >> 3);
-    if (q >= vx * A) return;
+    // traversal: v3_map_block (dp_lon_internal.h) -- read from the table the host filled at reinit, or computed
     int ia, iv;
-    {
-        const int full = vx / tv;
-        int strip = q / (A * tv), w = tv, rem = q - strip * (A * tv);
-        if (strip >= full) { strip = full; w = vx - full * tv; rem = q - full * (A * tv); }
-        const int tile = rem / (a.tile_a * w);
-        const int r = rem - tile * (a.tile_a * w);
-        ia = tile * a.tile_a + r / w;
-        // Skew: the successor row of (a, v) under the action that leads to a' is v' = v + dt (a + a') / 2, so the source rows
-        // that read the SAME next-stage rows lie on lines v + a dt / 2 = const.  The pairs of an a-row are rotated
-        // (inside the XCD's share, a bijection per a-row) by that slope, a.skew_q16 / 65536 pairs per a-row: the
-        // workgroups resident on an XCD at one time -- a few pairs by several dozen a-rows -- then touch a band of
-        // v' rows as narrow as the strip itself instead of one widened by the a-extent (profiles/r04_dp_config4_skew.txt).
-        int lp = strip * tv + (r - (r / w) * w);
-        if (a.skew_q16) { lp -= (int)(((long long)ia * a.skew_q16) >> 16) % vx; if (lp < 0) lp += vx; }
-        iv = NV * (p_lo + lp);
+    if (a.tile_map) {
+        const unsigned m = a.tile_map[blockIdx.x];
+        if (m == V3_MAP_NONE) return;
+        ia = (int)(m >> 16); iv = (int)(m & 0xffffu);
+    } else if (!v3_map_block((int)blockIdx.x, V, A, a.tile_v, a.tile_a, a.skew_q16, ia, iv)) {
+        return;
     }
     const int row0 = ia * V + iv;
     const int rs = (iv + 1 < V) ? N_BWD : 0;            // descriptor stride to the lane's second row (0: the row twice)
@@ -231,11 +214,13 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     };
     Node3 lo[2], up[NV][2];
     // scalar descriptor words of ONE action: the rows (lower pair of row 0, upper pair of every row) and the two doubles
-    struct ActScalars { int r00, r10, r01[NV], r11[NV], single; double j_term[NV], tn_v_d[NV]; };
+    struct ActScalars { int r00, r10, r01[NV], r11[NV], single, shared; double j_term[NV], tn_v_d[NV]; };
     auto fetch_scalars = [&](int k) {
         ActScalars x;
         x.r00 = d0[k].r00; x.r10 = d0[k].r10;
-        x.single = d0[k].flags & ACT_SINGLE_A;      // (a property of (a, k): the same for both rows of the pair)
+        const int fl = d0[k].flags;
+        x.single = fl & ACT_SINGLE_A;               // (a property of (a, k): the same for both rows of the pair)
+        x.shared = fl & ACT_SHARED_UP;              // row 1's lower a-blend IS row 0's upper one (k_build_actions compared the descriptors)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const ActDesc& e = d0[i * rs + k];
@@ -291,19 +276,11 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                                     : (double)(s + d0[i * rs].vdt) + d0[i * rs].a_term;
         }
     }
-    unsigned shared_mask = 0;
-#pragma unroll
-    for (int i = 0; i + 1 < NV; ++i) {
-#pragma unroll
-        for (int k = 0; k < N_BWD; ++k) {
-            const ActDesc& x = d0[i * rs + k];
-            const ActDesc& y = d0[(i + 1) * rs + k];
-            // (short-circuit on purpose: the same test with `&` -- every descriptor word of the nine actions requested at once, 100
-            // scalar registers -- LOSES, 38.5 -> 39.5 us per 256x128x64 sweep and 315 -> 333 on 512x256x128; profiles/r06_dp_contraction_ab.txt)
-            const bool sh = x.r01 == y.r00 && x.r11 == y.r10 && __float_as_uint(x.wa) == __float_as_uint(y.wa);
-            shared_mask |= (sh ? 1u : 0u) << (i * N_BWD + k);
-        }
-    }
+    static_assert(NV == 2, "ACT_SHARED_UP describes the pair (v, v + 1)");
+    // (which actions let row 1 reuse row 0's upper a-blend is a bit of the descriptor since round 6 -- ACT_SHARED_UP, tested by
+    // k_build_actions once per reinit.  Until then every workgroup compared the two rows' descriptors itself: up to 27 DEPENDENT
+    // scalar loads in its prologue; requesting them all at once instead -- 100 scalar registers -- lost, 38.5 -> 39.5 us per
+    // 256x128x64 sweep and 315 -> 333 on 512x256x128; profiles/r06_dp_contraction_ab.txt)
     const float s_min_v = in_vgpr(p.s_min);
     const float s_scale = (float)(S - 1);
     const float s_scale_v = in_vgpr(s_scale);
@@ -375,7 +352,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                     // the branch, keeps both blends alive across it and pays three moves per action and four registers for that)
                     if (i + 1 < NV) asm volatile("" : "+v"(r[i].c), "+v"(r[i].g), "+v"(r[i].j));
                     if (i + 1 < NV) {
-                        if ((shared_mask >> (i * N_BWD + k)) & 1u) {
+                        if (cur.shared) {
                             bl = bu;
                         } else {
                             const ActDesc& y = d0[(i + 1) * rs + k];
@@ -398,7 +375,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                     r[i] = lerp3<LERP>(bl, bu, w[i].z, w[i].w);
                     if (i + 1 < NV) asm volatile("" : "+v"(r[i].c), "+v"(r[i].g), "+v"(r[i].j));
                     if (i + 1 < NV) {
-                        if ((shared_mask >> (i * N_BWD + k)) & 1u) bl = bu;
+                        if (cur.shared) bl = bu;
                         else bl = load_row(d0[(i + 1) * rs + k].r00);
                     }
                 }
@@ -414,7 +391,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                     // the branch, keeps both blends alive across it and pays three moves per action and four registers for that)
                     if (i + 1 < NV) asm volatile("" : "+v"(r[i].c), "+v"(r[i].g), "+v"(r[i].j));
                     if (i + 1 < NV) {
-                        if ((shared_mask >> (i * N_BWD + k)) & 1u) {
+                        if (cur.shared) {
                             bl = bu;
                         } else {
                             const Node3 q00 = load_row(d0[(i + 1) * rs + k].r00);
@@ -613,24 +590,14 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     const float* __restrict__ path = path_all + scn * a.stride_path;
 
     constexpr int NV = 2;
-    // traversal: k_backward3v's (row pairs dealt to the XCDs, a-major tiles, optional skew)
-    const int xcd = blockIdx.x & 7;
-    const int NP = (V + NV - 1) / NV;
-    const int p_lo = (xcd * NP) >> 3, p_hi = ((xcd + 1) * NP) >> 3;
-    const int vx = p_hi - p_lo, tv = max(1, a.tile_v / NV);
-    const int q = (int)(blockIdx.x >> 3);
-    if (q >= vx * A) return;
+    // traversal: v3_map_block (dp_lon_internal.h) -- read from the table the host filled at reinit, or computed
     int ia, iv;
-    {
-        const int full = vx / tv;
-        int strip = q / (A * tv), w = tv, rem = q - strip * (A * tv);
-        if (strip >= full) { strip = full; w = vx - full * tv; rem = q - full * (A * tv); }
-        const int tile = rem / (a.tile_a * w);
-        const int r = rem - tile * (a.tile_a * w);
-        ia = tile * a.tile_a + r / w;
-        int lp = strip * tv + (r - (r / w) * w);
-        if (a.skew_q16) { lp -= (int)(((long long)ia * a.skew_q16) >> 16) % vx; if (lp < 0) lp += vx; }
-        iv = NV * (p_lo + lp);
+    if (a.tile_map) {
+        const unsigned m = a.tile_map[blockIdx.x];
+        if (m == V3_MAP_NONE) return;
+        ia = (int)(m >> 16); iv = (int)(m & 0xffffu);
+    } else if (!v3_map_block((int)blockIdx.x, V, A, a.tile_v, a.tile_a, a.skew_q16, ia, iv)) {
+        return;
     }
     const int row0 = ia * V + iv;
     const int rs = (iv + 1 < V) ? N_BWD : 0;            // descriptor stride to the lane's second row (0: the row twice)
@@ -651,11 +618,13 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         return Node3{x.x, x.y, x.z};
     };
     Node3 lo[2], up[NV][2];
-    struct ActScalars { int r00, r10, r01[NV], r11[NV], single; double j_term[NV], tn_v_d[NV]; };
+    struct ActScalars { int r00, r10, r01[NV], r11[NV], single, shared; double j_term[NV], tn_v_d[NV]; };
     auto fetch_scalars = [&](int k) {
         ActScalars x;
         x.r00 = d0[k].r00; x.r10 = d0[k].r10;
-        x.single = d0[k].flags & ACT_SINGLE_A;      // (a property of (a, k): the same for both rows of the pair)
+        const int fl = d0[k].flags;
+        x.single = fl & ACT_SINGLE_A;               // (a property of (a, k): the same for both rows of the pair)
+        x.shared = fl & ACT_SHARED_UP;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const ActDesc& e = d0[i * rs + k];
@@ -705,14 +674,6 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                                     : (double)(s + d0[i * rs].vdt) + d0[i * rs].a_term;
         }
     }
-    unsigned shared_mask = 0;
-#pragma unroll
-    for (int k = 0; k < N_BWD; ++k) {
-        const ActDesc& x = d0[k];
-        const ActDesc& y = d0[rs + k];
-        const bool sh = x.r01 == y.r00 && x.r11 == y.r10 && __float_as_uint(x.wa) == __float_as_uint(y.wa);
-        shared_mask |= (sh ? 1u : 0u) << k;
-    }
     const float s_min_v = in_vgpr(p.s_min);
     const float s_scale = (float)(S - 1);
     const float s_scale_v = in_vgpr(s_scale);
@@ -734,7 +695,7 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 #pragma unroll
     for (int k = 0; k < N_BWD; ++k) {
         // ---- phase 1: the raw rows of the pair into LDS
-        const bool shared = (shared_mask >> k) & 1u;
+        const bool shared = cur.shared != 0;           // ACT_SHARED_UP (k_build_actions)
         Node3 q00 = {0.0f, 0.0f, 0.0f}, q10 = {0.0f, 0.0f, 0.0f};
         __builtin_amdgcn_s_setprio(1);
         // (all six rows here: requesting the a0 rows a phase ahead, as k_backward3v does, costs nine registers across phase 2 and
@@ -998,6 +959,8 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     unsigned long long best = 0x7f8000007f800000ull;
     int bk = 0;
     const v4f* dsc4 = reinterpret_cast<const v4f*>(dsc);
+    // (k_backward3v's pin of the state terms in front of the first barrier gains nothing here: 10.4-10.8 us per 201x37x20 sweep
+    // either way, profiles/r06_dp_contraction_ab.txt)
 
 #pragma unroll
     for (int k0 = 0; k0 < N_BWD; k0 += KC) {
