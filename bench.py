@@ -548,7 +548,7 @@ def mc_rollouts(device, rank, world, dist, rehearsal, barrier, steps=2, warmup_c
 def traffic_block(roofline, key):
     """L2<->fabric bytes per sweep launch and the issue-model fractions from the committed PMC passes of this kernel
     (rocprofv3 cannot run inside the timed process; profiles/README.md has the commands).  `key`: "SxVxA" or "SxVxA@N"."""
-    for f in ("r05_dp_traffic.json", "r04_dp_traffic.json", "r03_dp_traffic.json", "r02_dp_traffic.json"):
+    for f in ("r06_dp_traffic.json", "r05_dp_traffic.json", "r04_dp_traffic.json", "r03_dp_traffic.json", "r02_dp_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", f)) as fd:
                 tr = json.load(fd).get(key)

@@ -118,7 +118,7 @@ def issue_block(roofline, problem, form, batch):
     (profiles/r0N_ilqr_issue.json, written by tools/profile_round.sh from rocprofv3 --pmc SQ_INSTS_VALU_*_F64 / SQ_INSTS_*;
     rocprofv3 cannot run inside the timed process): a constant of the repository, keyed by problem / launch form."""
     import json
-    for f in ("r05_ilqr_issue.json", "r04_ilqr_issue.json"):
+    for f in ("r06_ilqr_issue.json", "r05_ilqr_issue.json", "r04_ilqr_issue.json"):
         try:
             with open(os.path.join(ROOT, "profiles", f)) as fd:
                 tab = json.load(fd)

@@ -484,6 +484,46 @@ def test_plans_in_flight_on_two_planners_equal_the_oracle(S, V, A, T):
         _assert_tables_equal(dp, tables, T)
 
 
+@pytest.mark.parametrize("S,V,A,T", [(201, 37, 20, 10), (128, 64, 32, 12)])
+def test_replanning_with_new_path_start_and_environment_back_to_back(S, V, A, T):
+    """What a caller that replans every cycle does, without waiting for anything in between: upload(new start, NEW PATH),
+    plan_resident(ANOTHER environment), stage_download -- eight plans on ONE planner.  In the back-to-back mode the rollout of
+    plan k runs on its own stream while upload k + 1 overwrites the planner's path and start state and plan k + 1's front
+    rewrites a distance map: the rollout reads its own copies (round 6: no host wait in upload), so every plan must equal
+    the oracle's plan of ITS inputs -- start state, speed-limit profile of its path, obstacle set."""
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    obst = [sc.OBSTACLES_OVERTAKE, sc.OBSTACLES_OVERTAKE_TRAFFIC, sc.random_obstacles(4, 8), ()]
+    occs = [sc.occ_map(ep, o) for o in obst]
+    envs = []
+    for occ in occs:
+        env = tpl_amd.DynProgEnvironment()
+        env.reinit_buffers(ep)
+        env.set_occ_map(occ)
+        envs.append(env)
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p)
+    n = 8
+    jobs = []
+    for k in range(n):
+        path = sc.straight_path(p.path_steps, p.path_step_size)
+        path[:, 5] += np.float32(0.4 * k) - 0.2 * np.sin(np.arange(p.path_steps) / (5.0 + k)).astype(np.float32)   # its own speed limits
+        jobs.append((sc.initial_state(0.5 * k, 4.0 + 1.1 * k, 0.2 * (k % 3) - 0.2), path, k % len(envs)))
+    got = []
+    for k, (init, path, e) in enumerate(jobs):
+        if k > 0:
+            got.append(_traj_np(dp.collect_download((k - 1) & 1)[0]))
+        dp.upload([init], path)
+        dp.plan_resident(envs[e])
+        dp.stage_download(k & 1)
+    got.append(_traj_np(dp.collect_download((n - 1) & 1)[0]))
+    assert dp.info()["fwd_overlap"] == 1, dp.info()
+    for k, (init, path, e) in enumerate(jobs):
+        tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occs[e], [init])
+        assert np.array_equal(got[k].view(np.uint32), otrajs[0].view(np.uint32)), k
+    assert len({g.tobytes() for g in got}) == n, "the jobs are not different plans"
+
+
 def test_two_threads_with_their_own_engines():
     """Different engine objects may be driven from different threads (own non-blocking streams, thread-local error
     slot and bounce buffer; ctypes releases the GIL during the calls): two threads, each with its own environment
