@@ -244,6 +244,23 @@ __device__ __forceinline__ double dot_lds(PA a, int sa, PB b, int sb)
 }
 
 constexpr int ROLL_RING = 8;
+// Layout of the rollout ring.  The eight quads write the same (stage, entry) slot of their candidates in ONE instruction: with a
+// block per candidate -- ring_x[cand][stage][entry], blocks of ROLL_RING * NX = 56 doubles = 448 B, i.e. 64 B modulo the 128 B
+// of an LDS bank row -- four of the eight addresses fall on the same bank pair, and with ring_u's blocks of 16 doubles (128 B)
+// all eight do: half of the kernel's SQ_LDS_BANK_CONFLICT cycles (tools/micro/lds_conflict_probe.hip: a 64-bit access of
+// consecutive, broadcast or 7- / 9-strided doubles has NO conflict on gfx950, 16-byte-strided ones stall 8 cycles per
+// instruction; profiles/r06_ilqr_lds_conflicts.txt).  TRANSPOSED -- ring_x[stage][entry][cand], the candidate fastest -- the
+// eight addresses are 64 consecutive bytes, the flush reads the ring linearly (lane e: entry e / 8, candidate e % 8: a shift
+// and a mask instead of a division by 56) and a candidate's run in global memory is written 64 B at a time.  Same size: padding
+// the blocks instead (57 / 17 doubles) costs the fused form its trajectory mirrors -- the MPC's 1 479 + 500 doubles fit a
+// workgroup's 20 KB share with three doubles to spare -- and 10 % at 4 096 problems.  TPL_ILQR_RING_T=0: the block layout (A/B).
+#ifndef TPL_ILQR_RING_T
+#define TPL_ILQR_RING_T 1
+#endif
+__device__ __forceinline__ int ring_ix(int cand, int k, int i, int n_entry)       // slot of (candidate, stage k of the ring, entry i)
+{
+    return TPL_ILQR_RING_T ? (k * n_entry + i) * N_ALPHA + cand : (cand * ROLL_RING + k) * n_entry + i;
+}
 
 // LDS working set of one problem.  The Riccati pass and the line search never run at the same time (the terminal value
 // function is written after the last read of the cost block, the ring is first written after the last gain is stored):
@@ -920,7 +937,7 @@ __device__ __forceinline__ void line_search_rollouts_impl(const RolloutArgs& A, 
 #pragma unroll
                     for (int d = 0; d < NU; ++d) {
                         u[d] = (NU > 1 && NU <= 4) ? tpl_quad_bcast(ud, d) : ud;
-                        s->ring_u[(cand * ROLL_RING + k) * NU + d] = u[d];    // (all four lanes: same value, same slot)
+                        s->ring_u[ring_ix(cand, k, d, NU)] = u[d];    // (all four lanes: same value, same slot)
                     }
                 }
                 RSTAMP(0);
@@ -928,40 +945,35 @@ __device__ __forceinline__ void line_search_rollouts_impl(const RolloutArgs& A, 
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     x[i] = xn[i];
-                    s->ring_x[(cand * ROLL_RING + k) * NX + i] = xn[i];
+                    s->ring_x[ring_ix(cand, k, i, NX)] = xn[i];
                 }
                 RSTAMP(1);
             }
         }
         lds_sync();
-        // the ring goes out: candidate c, stages t0 .. t0+n-1 are n*NX (n*NU) consecutive doubles
-        // on both sides
+        // the ring goes out: candidate c, stages t0 .. t0+n-1 are n*NX (n*NU) consecutive doubles in global memory
+        const auto flush = [&](auto n_entry_c, GlbD dst, int64_t t_first, const LdsAS* sp, bool is_x, int e) {
+            constexpr int NE = decltype(n_entry_c)::value;
+            int c, off, slot;
+            if (TPL_ILQR_RING_T) { c = e & (N_ALPHA - 1); off = e / N_ALPHA; slot = e; }
+            else { c = e / (n * NE); off = e - c * (n * NE); slot = c * ROLL_RING * NE + off; }
+            dst[(int64_t)c * rows * NE + t_first * NE + off] = is_x ? sp->ring_x[slot] : sp->ring_u[slot];
+        };
+        static_assert((N_ALPHA & (N_ALPHA - 1)) == 0, "candidate index by mask");
         if (n == ROLL_RING) {
 #pragma unroll
             for (int q = 0; q < (N_ALPHA * ROLL_RING * NX + WAVE - 1) / WAVE; ++q) {
                 const int e = lane + q * WAVE;
-                if (e < N_ALPHA * ROLL_RING * NX) {
-                    const int c = e / (ROLL_RING * NX), off = e - c * (ROLL_RING * NX);
-                    CX[(int64_t)c * rows * NX + (int64_t)(t0 + 1) * NX + off] = s->ring_x[e];
-                }
+                if (e < N_ALPHA * ROLL_RING * NX) flush(std::integral_constant<int, NX>{}, CX, (int64_t)(t0 + 1), s, true, e);
             }
 #pragma unroll
             for (int q = 0; q < (N_ALPHA * ROLL_RING * NU + WAVE - 1) / WAVE; ++q) {
                 const int e = lane + q * WAVE;
-                if (e < N_ALPHA * ROLL_RING * NU) {
-                    const int c = e / (ROLL_RING * NU), off = e - c * (ROLL_RING * NU);
-                    CU[(int64_t)c * rows * NU + (int64_t)t0 * NU + off] = s->ring_u[e];
-                }
+                if (e < N_ALPHA * ROLL_RING * NU) flush(std::integral_constant<int, NU>{}, CU, (int64_t)t0, s, false, e);
             }
         } else {
-            for (int e = lane; e < N_ALPHA * n * NX; e += WAVE) {
-                const int c = e / (n * NX), off = e - c * (n * NX);
-                CX[(int64_t)c * rows * NX + (int64_t)(t0 + 1) * NX + off] = s->ring_x[c * ROLL_RING * NX + off];
-            }
-            for (int e = lane; e < N_ALPHA * n * NU; e += WAVE) {
-                const int c = e / (n * NU), off = e - c * (n * NU);
-                CU[(int64_t)c * rows * NU + (int64_t)t0 * NU + off] = s->ring_u[c * ROLL_RING * NU + off];
-            }
+            for (int e = lane; e < N_ALPHA * n * NX; e += WAVE) flush(std::integral_constant<int, NX>{}, CX, (int64_t)(t0 + 1), s, true, e);
+            for (int e = lane; e < N_ALPHA * n * NU; e += WAVE) flush(std::integral_constant<int, NU>{}, CU, (int64_t)t0, s, false, e);
         }
         lds_sync();
         RSTAMP(2);
