@@ -114,6 +114,8 @@ struct DevState {
     // LDS residency (decided by the host per launch, see plan_lds):
     int lds_traj;                      // 1: x, u, k, K, uMax, uMin of the problem are mirrored in LDS
     int n_lds_arrays;                  // array parameters copied into LDS
+    int roll_direct;                   // 1: the rollouts read nothing from global memory (mirrors AND every array parameter are in LDS): their stage
+                                       // results go straight to the candidate arrays instead of through the LDS ring (line_search_rollouts)
     const double* lds_src[TPL_N_PARAMS + 1];     // global source of array slot i (problem 0)
     long long lds_src_stride[TPL_N_PARAMS + 1];  // doubles between problems (0: shared)
     int lds_len[TPL_N_PARAMS + 1];               // doubles
@@ -823,6 +825,7 @@ struct RolloutArgs {
     double dt;
     int rows, opt_start, T, int_type;
     bool second_order;
+    int direct;                // DevState::roll_direct
     long long* stamp_acc;      // diagnostic builds only
 };
 
@@ -873,6 +876,13 @@ __device__ __forceinline__ void line_search_rollouts_impl(const RolloutArgs& A, 
 #endif
     const bool active = lane < 4 * N_ALPHA;
     const int cand = lane >> 2;
+    // Where a stage's results go.  DIRECT (round 6): the loop reads nothing from global memory, so its stores block nothing --
+    // every quad writes its candidate's (x_{t+1}, u_t) straight into the candidate arrays (all four lanes: same value, same
+    // address), nine stores and two pointer bumps per stage instead of nine ring writes plus a flush of 576 doubles every
+    // eight stages behind two fences.  Else through the ring (the reason it exists: see above).
+    const bool direct = LT && uni_i(A.direct) != 0;
+    GlbD px = CX + ((int64_t)(active ? cand : 0) * rows + opt_start + 1) * NX;
+    GlbD pu = CU + ((int64_t)(active ? cand : 0) * rows + opt_start) * NU;
     double a = 1.0;
     for (int i = 0; i < cand; ++i) a *= 10.0;
     a = 1.0 / a;                                       // 1.0 / pow(10, i)
@@ -935,21 +945,32 @@ __device__ __forceinline__ void line_search_rollouts_impl(const RolloutArgs& A, 
                         ud = ub - kff * a;
                     }
 #pragma unroll
-                    for (int d = 0; d < NU; ++d) {
-                        u[d] = (NU > 1 && NU <= 4) ? tpl_quad_bcast(ud, d) : ud;
-                        s->ring_u[ring_ix(cand, k, d, NU)] = u[d];    // (all four lanes: same value, same slot)
+                    for (int d = 0; d < NU; ++d) u[d] = (NU > 1 && NU <= 4) ? tpl_quad_bcast(ud, d) : ud;
+                    if (direct) {
+#pragma unroll
+                        for (int d = 0; d < NU; ++d) pu[d] = u[d];
+                        pu += NU;
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < NU; ++d) s->ring_u[ring_ix(cand, k, d, NU)] = u[d];    // (all four lanes: same value, same slot)
                     }
                 }
                 RSTAMP(0);
                 dynamics_quad(*P, x, u, t, dt, int_type, xn);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    x[i] = xn[i];
-                    s->ring_x[ring_ix(cand, k, i, NX)] = xn[i];
+                for (int i = 0; i < NX; ++i) x[i] = xn[i];
+                if (direct) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) px[i] = xn[i];
+                    px += NX;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) s->ring_x[ring_ix(cand, k, i, NX)] = xn[i];
                 }
                 RSTAMP(1);
             }
         }
+        if (direct) continue;
         lds_sync();
         // the ring goes out: candidate c, stages t0 .. t0+n-1 are n*NX (n*NU) consecutive doubles in global memory
         const auto flush = [&](auto n_entry_c, GlbD dst, int64_t t_first, const LdsAS* sp, bool is_x, int e) {
@@ -1485,7 +1506,7 @@ __global__ __launch_bounds__(WAVE) void k_ilqr_update(DevState st)
                 RolloutArgs ra;
                 ra.CX = CX; ra.CU = CU; ra.X_ = X_; ra.KFFr = KFFr; ra.Ur = Ur; ra.UMAXr = UMAXr; ra.UMINr = UMINr;
                 ra.KFBr = KFBr; ra.Xr = Xr; ra.P = P_mem; ra.dt = dt; ra.rows = st.rows; ra.opt_start = opt_start;
-                ra.T = T; ra.int_type = int_type; ra.second_order = second_order;
+                ra.T = T; ra.int_type = int_type; ra.second_order = second_order; ra.direct = st.roll_direct;
 #ifdef TPL_ILQR_STAMP
                 ra.stamp_acc = st.stamps ? st.stamps + (int64_t)b * 16 : nullptr;
 #else
@@ -1878,7 +1899,7 @@ __device__ __forceinline__ void ph_chain(const DevState* stp, int lg_in, int it_
         RolloutArgs ra;
         ra.CX = CX; ra.CU = CU; ra.X_ = X_; ra.KFFr = KFFr; ra.Ur = Ur; ra.UMAXr = UMAXr; ra.UMINr = UMINr;
         ra.KFBr = KFBr; ra.Xr = Xr; ra.P = P_mem; ra.dt = dt; ra.rows = st->rows; ra.opt_start = opt_start;
-        ra.T = T; ra.int_type = INT_TYPE; ra.second_order = SECOND_ORDER;
+        ra.T = T; ra.int_type = INT_TYPE; ra.second_order = SECOND_ORDER; ra.direct = st->roll_direct;
         ra.stamp_acc = nullptr;
         if constexpr (CHAIN_INLINE) {
             if (lt) line_search_rollouts_impl<true, SECOND_ORDER, INT_TYPE>(ra, sl);
@@ -2165,10 +2186,23 @@ size_t field_elems(const tplhip_ilqr* h, int f)
 // trajectory mirrors (x, u, k, K, uMin, uMax of all t_cap rows: 70 KB for X = 7, U = 2, 300 rows) then sit in LDS
 // too, instead of every stage of the dependent rollout and Riccati chains waiting on global memory.
 // Priority: array parameters (every ctDynamics waits on them), then the trajectory mirrors.
+// The rollouts may store their stage results straight to global memory when nothing in their loop LOADS from it (loads and
+// stores of a wavefront share one counter and complete in order: a load behind a store waits for the store's acknowledgement --
+// the reason the ring exists): the trajectory mirrors and every array parameter the model reads must be in LDS.
+int roll_direct_ok(const tplhip_ilqr* h, const DevState& d)
+{
+    if (!d.lds_traj || tplhip::debug_opt("ilqr_no_direct")) return 0;
+    int arrays = 0;
+    for (int i = 0; i < TPL_N_PARAMS; ++i)
+        if (g_params[i].is_array && h->parray[i].elems > 0 && h->parray[i].dev) ++arrays;
+    return arrays == d.n_lds_arrays ? 1 : 0;
+}
+
 void plan_lds(tplhip_ilqr* h)
 {
     DevState& d = h->dev;
     d.lds_traj = 0;
+    d.roll_direct = 0;
     d.n_lds_arrays = 0;
     d.lds_dyn_flat = 0;
     h->lds_dyn_bytes = 0;
@@ -2197,6 +2231,7 @@ void plan_lds(tplhip_ilqr* h)
     }
     h->lds_dyn_bytes = off * sizeof(double);
     d.lds_dyn_flat = h->lds_aperture + h->lds_static;
+    d.roll_direct = roll_direct_ok(h, d);
 }
 
 // The split-launch kernels keep everything in dynamic LDS: the Lds block at the head, then what fits of the array
@@ -2210,6 +2245,7 @@ void plan_lds_split(tplhip_ilqr* h)
     d.params = h->d_params_split;
     d.run = h->d_run;
     d.lds_traj = 0;
+    d.roll_direct = 0;
     d.n_lds_arrays = 0;
     d.lds_dyn_flat = 0;
     d.lds_base_flat = h->lds_aperture;
@@ -2242,6 +2278,10 @@ void plan_lds_split(tplhip_ilqr* h)
     }
     h->lds_dyn_bytes_split = (LDS_HEAD + off) * sizeof(double);
     d.lds_dyn_flat = h->lds_aperture + (unsigned long long)LDS_HEAD * sizeof(double);   // the split kernels have no static LDS
+    // (the ring stays in the two-wavefront forms: with a second wavefront's stores in the same queue the direct form LOSES there,
+    // 2 381 -> 2 345 batched it/s at 4 096, 1 233 -> 1 207 at 8 192, where the lone wavefront of the single launch gains 2 %;
+    // profiles/r06_ilqr_direct_store_ab.txt)
+    d.roll_direct = tplhip::debug_opt("ilqr_direct_split") ? roll_direct_ok(h, d) : 0;
 }
 
 // dev_split -> device memory (the split / fused kernels take a pointer), when it changed
