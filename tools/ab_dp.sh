@@ -4,7 +4,7 @@
 #   on the box:  gpurun -- 'bash tools/ab_dp.sh run [rounds] [grid]'
 set -eu
 cd "$(dirname "$0")/.."
-SRCS="common.hip dp_lon.hip dp_sweep.hip dp_sweep_rules_a.hip dp_sweep_rules_b.hip dp_sweep_rules_c.hip dp_sweep_rules_d.hip dp_sweep_rules_e.hip dp_sweep_rules_f.hip dp_sweep_rules_g.hip dp_sweep_rules_h.hip dp_env.hip poly_lat.hip lat_lon.hip planning.hip"
+SRCS="common.hip dp_lon.hip dp_sweep.hip dp_sweep_rules_a.hip dp_sweep_rules_b.hip dp_sweep_rules_c.hip dp_sweep_rules_d.hip dp_sweep_rules_e.hip dp_sweep_rules_f.hip dp_sweep_rules_g.hip dp_sweep_rules_h.hip dp_sweep_rules_i.hip dp_env.hip poly_lat.hip lat_lon.hip planning.hip"
 case "${1:-}" in
 build)
     shift
