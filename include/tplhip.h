@@ -187,11 +187,16 @@ TPLHIP_API int tplhip_dp_lon_reeval(tplhip_dp_lon* h, const TplLonState* traj, i
  * = (cost, constr, j*, 0) as surf3Dwrite stores it (lon_planner.cu:203-208). */
 TPLHIP_API int tplhip_dp_lon_copy_table(tplhip_dp_lon* h, int t, float* out);
 
-/* ---- device-resident stepping, for measurement (bench.py) --------------- */
+/* ---- enqueue-only planning: throughput callers and measurement (bench.py) --------------- */
 
-/* Upload path + initial states once; afterwards tplhip_dp_lon_plan_resident
- * enqueues one complete plan (dist map, t_steps-1 backward sweeps, n forward
- * rollouts) on the planner's stream without touching host memory. */
+/* Upload path + initial states; afterwards tplhip_dp_lon_plan_resident enqueues one complete plan (dist map,
+ * t_steps-1 backward sweeps, n forward rollouts) on the planner's stream without touching host memory.  Neither call
+ * waits for the device: a caller may replan with NEW inputs back to back -- upload, plan_resident(any environment),
+ * stage_download, upload, ... -- and a plan's rollout, which runs on a stream of its own behind the sweeps, reads its
+ * own copy of path, start states and distance map (since round 6; until then upload waited on the host for the
+ * previous rollout).  upload only waits when the rollout buffers must grow (more start states than ever before), and
+ * for the staging buffer of the upload before last.  Every plan is bit-identical to tplhip_dp_lon_update on the same
+ * inputs (tests/test_dp_gpu.py::test_replanning_with_new_path_start_and_environment_back_to_back). */
 TPLHIP_API int tplhip_dp_lon_upload(tplhip_dp_lon* h, int n, const TplLonState* inits,
                          const float* path);
 TPLHIP_API int tplhip_dp_lon_plan_resident(tplhip_dp_lon* h, tplhip_dp_env* env);
