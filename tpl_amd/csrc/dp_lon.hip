@@ -368,7 +368,7 @@ void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
         launch_backward<true, 1>(h, i, nx);                       // rule R4 (no division in it)
     } else if (kind == 1 && launch_backward3(h, i, nx)) {
         // two rows per lane, plain-fp32 stream.  (A `false` means no instance is built for this (rule, division forms) pair:
-        // pick_div_forms / backward3o_built keep the host's choices inside what dp_sweep.hip builds -- tests/test_dp_gpu.py::
+        // pick_div_forms / backward3o_built keep the host's choices inside what dp_sweep.hip builds -- tests/test_capi.py::
         // test_every_selectable_rule_has_a_built_sweep -- and if they ever drift the stage is swept by the general kernel below
         // instead of being skipped.)
     } else if (kind == 2 && launch_backward3s_(h, i, nx)) {
