@@ -275,7 +275,8 @@ def rank_scenario(rank):
 
 def scenario_deck(rank, ep):
     """The inputs the timed region deals to its plans: FOUR obstacle sets -- the rank's headline
-    scenario (rank_scenario), the reference's overtake scene without the faster car, and two seeded stress sets
+    scenario (rank_scenario), the reference's overtake scene 25 m nearer and 1.5 m/s faster (without the fifth car, which
+    never enters the 200 m map anyway), and two seeded stress sets
     (K = 8, s0 ~ U(30, 180), v ~ U(0, 10)) -- and SEVEN start states (the headline's (0, 8, 0) and six of
     SURVEY 8d's batch variants v0 ~ U(2, 14), a0 ~ U(-1, 1)): 28 different (obstacles, start) pairs, so the data-dependent
     arms of the sweep (ACT_SINGLE_A thirds, shared / not-shared rows, the obstacle rows of pre_sdist) and of the rollout
@@ -284,7 +285,7 @@ def scenario_deck(rank, ep):
     obst0, init0 = rank_scenario(rank)
     shift = 7.0 * rank
     sets = [obst0,
-            tuple((s0 + shift, v, ln) for (s0, v, ln) in sc.OBSTACLES_OVERTAKE),
+            tuple((s0 - 25.0 + shift, v + 1.5, ln) for (s0, v, ln) in sc.OBSTACLES_OVERTAKE),
             sc.random_obstacles(4 + rank, 8), sc.random_obstacles(9 + rank, 6)]
     return [sc.occ_map(ep, o) for o in sets], [init0] + sc.random_initial_states(6, seed=5 + rank)
 

@@ -482,3 +482,27 @@ def test_dist_map_lookup_under_the_blend_orders(name, order):
             assert F(float(got)) == want, (order, it, float(s), got, float(want))
     finally:
         O.set_rule()
+
+
+def test_rule_is_run_time_state_with_the_contracted_default():
+    """ONE checker library, the arithmetic rule a setting of it (round 6; until then one build per rule): the default is the
+    contracted rule {rint, fma form, R1 = 1, a -> v -> s}, `O.rule(...)` restores it on exit -- also when the body raises --,
+    values outside the rule's ranges are refused, and the rule really reaches the arithmetic (R1 moves a grid point)."""
+    assert O.get_rule() == O.DEFAULT_RULE == dict(quant=1, lerp=0, fma=1, order=0)
+    with O.rule("wfloor", fma=0, order=2) as r:
+        assert r == dict(quant=2, lerp=0, fma=0, order=2) == O.get_rule()
+    assert O.get_rule() == O.DEFAULT_RULE
+    with pytest.raises(ZeroDivisionError):
+        with O.rule(order=3):
+            1 / 0
+    assert O.get_rule() == O.DEFAULT_RULE
+    for bad in (dict(quant=3), dict(lerp=-1), dict(fma=2), dict(order=4)):
+        with pytest.raises(AssertionError):
+            O.set_rule(**bad)
+        assert O.get_rule() == O.DEFAULT_RULE                # a refused rule changes nothing
+    # fma(i, step, min) against RN(RN(i * step) + min): some grid point of the a-axis of configs[1] differs in its last bit
+    step = np.float32(4.5) / np.float32(31)
+    fused = [O.grid_point(-3.0, i, step) for i in range(32)]
+    with O.rule(fma=0):
+        plain = [O.grid_point(-3.0, i, step) for i in range(32)]
+    assert fused != plain and max(abs(a - b) for a, b in zip(fused, plain)) < 5e-7

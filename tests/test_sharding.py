@@ -237,3 +237,30 @@ def test_headline_scenarios_differ_between_ranks():
     from benchkit import scenarios as sc
     assert o0 == sc.OBSTACLES_OVERTAKE_TRAFFIC and (i0.s, i0.v, i0.a) == (0.0, 8.0, 0.0)
     assert o3 != o0 and i3.v == 9.5
+
+
+def test_bench_deck_deals_every_pair_to_every_lane():
+    """bench.py's timed region deals every plan its own (obstacle set, start state) pair by plan index: four sets and seven states
+    with coprime periods, the two planners in flight walking the deck with different offsets -- each lane sees all 28 pairs, two
+    consecutive plans of a lane never share set or state, and the deck's maps / states are really different (rank-dependent)."""
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import bench
+    from benchkit import scenarios as sc
+    for lanes in (1, 2):
+        seen = [set() for _ in range(lanes)]
+        last = [None] * lanes
+        for i in range(28 * lanes):
+            io, ist = bench.deal(i, lanes)
+            assert 0 <= io < 4 and 0 <= ist < 7
+            lane = i % lanes
+            if last[lane] is not None:
+                assert last[lane][0] != io and last[lane][1] != ist
+            last[lane] = (io, ist)
+            seen[lane].add((io, ist))
+        assert all(len(s) == 28 for s in seen)
+    ep = sc.env_params(t_steps=6, s_steps=101, l_steps=11)
+    occs, starts = bench.scenario_deck(0, ep)
+    assert len(occs) == 4 and len(starts) == 7
+    assert len({o.tobytes() for o in occs}) == 4 and len({(s.s, s.v, s.a) for s in starts}) == 7
+    occs3, starts3 = bench.scenario_deck(3, ep)
+    assert all(a.tobytes() != b.tobytes() for a, b in zip(occs, occs3)) and starts3[0].v == 9.5
