@@ -300,6 +300,11 @@ struct Lds {
 #ifndef TPL_ILQR_ABLATE
 #define TPL_ILQR_ABLATE 0
 #endif
+// 1: the gain solve's shared scalars by v_readlane from the lanes that formed them (riccati_backward_impl, phases C + D): the
+// cross-lane form of the B -> C exchange the round-5 review asked to be measured.  0 (shipped): through LDS.  Same bits.
+#ifndef TPL_ILQR_GAIN_READLANE
+#define TPL_ILQR_GAIN_READLANE 0
+#endif
 
 // ---- backward Riccati pass, optim.c:926-985, as a function of its own (NOT inlined) -- same reason as
 // line_search_rollouts: inside k_ilqr_update its loop ran with 85 AGPR moves, 30 SGPR-spill reloads
@@ -503,13 +508,16 @@ __device__ __forceinline__ void riccati_backward_impl(const RiccatiArgs& A, LdsA
 
         // phase B: Q = L + F^T W, q = l + F^T Vx.  Only the lower triangles of the symmetric blocks
         // are formed and then mirrored, like mul_symm (optim.c:159-180).
+        double b_val0 = 0.0, b_val1 = 0.0;               // (TPL_ILQR_GAIN_READLANE: the lane's own Q entry and its mirror image)
 #pragma unroll
         for (int q = 0; q < E_B; ++q) {
             // (no lane masks: lanes without an entry work on column 0 and write the dump slot; an
             // entry without a mirror image has dst1 == dst0 and l1 == l0: the same value twice)
             const double acc = dot_lds<NX>(&s->F[b_colF[q]], NXU, &s->W[b_colW[q]], WS);
-            *b_dst0[q] = r_l0[q] + acc;
-            *b_dst1[q] = r_l1[q] + acc;
+            const double v0 = r_l0[q] + acc, v1 = r_l1[q] + acc;
+            *b_dst0[q] = v0;
+            *b_dst1[q] = v1;
+            if (q == 0) { b_val0 = v0; b_val1 = v1; }
         }
         lds_sync();
         // F of stage t has been read for the last time: [fx | fu] of stage t-1 (in registers since
@@ -525,11 +533,37 @@ __device__ __forceinline__ void riccati_backward_impl(const RiccatiArgs& A, LdsA
         // sixteen (d, c) lanes also store them.  One LDS exchange per stage less.
         {
             double quu[NU * NU], qu[NU], Qi[NU], Qj[NU], Qc[NU];
+#if TPL_ILQR_GAIN_READLANE
+            // A/B leg (round 6): the six numbers every lane's gain solve shares -- Quu, Qu -- straight from the registers of the
+            // phase-B lanes that formed them (v_readlane into scalar registers) instead of through the LDS write -> read of the
+            // B -> C exchange; the division chain can start an LDS latency earlier.  Same values, same bits.
+            if constexpr (E_B == 1 && N_B <= WAVE) {
+                const auto bc = [](double v, int src) {
+                    const long long b = __double_as_longlong(v);
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+                    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                };
 #pragma unroll
-            for (int m = 0; m < NU * NU; ++m) quu[m] = s->Quu[m];
+                for (int hi = 0; hi < NU; ++hi)
+#pragma unroll
+                    for (int lo = 0; lo <= hi; ++lo) {
+                        const int src = N_XX + N_UX + hi * (hi + 1) / 2 + lo;
+                        quu[hi * NU + lo] = bc(b_val0, src);
+                        quu[lo * NU + hi] = bc(b_val1, src);
+                    }
+#pragma unroll
+                for (int m = 0; m < NU; ++m) qu[m] = bc(b_val0, N_XX + N_UX + N_UU + NX + m);
+            } else
+#endif
+            {
+#pragma unroll
+                for (int m = 0; m < NU * NU; ++m) quu[m] = s->Quu[m];
+#pragma unroll
+                for (int m = 0; m < NU; ++m) qu[m] = s->q[NX + m];
+            }
 #pragma unroll
             for (int m = 0; m < NU; ++m) {
-                qu[m] = s->q[NX + m];
                 Qi[m] = s->Qux[m * NX + d_i]; Qj[m] = s->Qux[m * NX + d_j]; Qc[m] = s->Qux[m * NX + c_col];
             }
             const double tail = *d_tail;
