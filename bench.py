@@ -700,6 +700,24 @@ def worker(args):
         dp.plan_resident(fleet[0][1][k])
     alone_ms, alone_launches = dp.timing_get()
     dp.timing_enable(False)
+    # ... and the same kernel under the OTHER setting of rule R1 (one rounding per operation; a template variant with the same
+    # division forms), same box, same minute: `roofline.launch_us_by_rule`.  Rank 0 only, outside the
+    # timed region, on a planner of its own that is released before timing starts.
+    other_rule_us = None
+    if rank == 0:
+        q0 = dp_setup(args.grid, local_rank, rank)[0]
+        q0.set_contraction(not bool(dp.info()["rule"]["fma"]))
+        for k in range(2):                              # (both table sets of the back-to-back mode touched before timing)
+            q0.upload([starts[k]], path)
+            q0.plan_resident(fleet[0][1][k])
+        q0.sync()
+        q0.timing_enable(True)
+        for k in range(4):
+            q0.upload([starts[k]], path)
+            q0.plan_resident(fleet[0][1][k])
+        ms0, n0 = q0.timing_get()
+        other_rule_us = (arithmetic_name(q0.info()).split(" ")[0], ms0 / max(1, n0) * 1e3)
+        del q0
     setup_s = {"headline": time.perf_counter() - t_setup0}
     for q, _ in fleet:
         q.timing_enable(True)
@@ -797,6 +815,8 @@ def worker(args):
                 # the kernel's duration ALONE on the chip (HIP events; the timed region's own average with one plan in flight): what
                 # a trace of `--in-flight 1` lists
                 "launch_us": launch_s * 1e6,
+                # the kernel alone under both settings of rule R1 (HIP events, plans on one stream just before the timed region)
+                "launch_us_by_rule": {arithmetic_name(dp.info()).split(" ")[0]: alone_s * 1e6, other_rule_us[0]: other_rule_us[1]},
                 "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
                 "achieved_is": "algorithmic bytes per launch / the launch's HIP-event duration alone on the chip"
                                + ("" if in_flight == 1 else " (four plans on one stream just before the timed region)"),

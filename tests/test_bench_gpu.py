@@ -48,6 +48,8 @@ def test_one_line_with_the_contract_fields():
     # (orders of magnitude only: on a 2-step run the margins between these three are ~15 % and noisy)
     assert fl["stream_us_per_launch"] > 20.0 and rf["launch_us"] > 20.0 and fl["effective_us_per_launch"] > 15.0
     assert fl["effective_us_per_launch"] < 1.25 * rf["launch_us"]
+    by_rule = rf["launch_us_by_rule"]                   # the kernel alone under both settings of R1, same box
+    assert set(by_rule) == {"R1=1", "R1=0"} and all(20.0 < v < 80.0 for v in by_rule.values()), by_rule
     # the arithmetic the sweeps ran under is named: the contracted default (nvcc's -fmad=true), rint weights, a -> v -> s
     assert d["config"]["arithmetic"].startswith("R1=1") and "R2=rint" in d["config"]["arithmetic"] and d["config"]["arithmetic"].endswith("avs")
     # every plan of the timed region had its own (obstacle set, start state) pair, and the last one per planner was checked
