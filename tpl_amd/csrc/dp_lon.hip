@@ -146,9 +146,8 @@ struct tplhip_dp_lon {
     int sc_last_first = 0, sc_last_count = 0;
     bool v3_ok = false;                  // the two-rows-per-lane geometry of k_backward3v fits this grid
     int v3_grid = 0;
-    unsigned* d_v3_map = nullptr;        // v3_map_block per workgroup of that grid (SweepArgs::tile_map)
+    V3Map* d_v3_map = nullptr;           // v3_map_block and action 0's first rows per workgroup of that grid (SweepArgs::tile_map)
     size_t v3_map_cap = 0;
-    int v3_map_key[6] = {0, 0, 0, 0, 0, 0};   // what the table was built for: v_steps, a_steps, tile_v3, tile_a, skew_q16, v3_grid
     bool no_v3 = false, no_fwd_overlap = false, no_fwd_spec = false, no_front = false;   // TPLHIP_DEBUG overrides, read by reinit
     bool front_fused = true;                 // what the last plan did (info)
     FilterRule rule = kDefaultRule;      // R1 - R3 of the arithmetic contract (tplhip_dp_lon_set_filter_rule / _set_contraction / _set_blend_order)
@@ -783,6 +782,23 @@ int tplhip_dp_lon_destroy(tplhip_dp_lon* h)
     return TPLHIP_OK;
 }
 
+namespace {
+// The action table of h->params under h->rule and, behind it on the same stream, the traversal table that copies from it.
+int build_action_tables(tplhip_dp_lon* h)
+{
+    const TplDpLonParams& p = h->params;
+    const int nrows = p.v_steps * p.a_steps;
+    hipLaunchKernelGGL(k_build_actions, dim3((nrows * N_BWD + 255) / 256), dim3(256), 0, h->stream, h->d_acts, p, h->rule);
+    HIP_TRY(hipGetLastError(), "action table launch failed");
+    if (h->d_v3_map) {
+        hipLaunchKernelGGL(k_fill_v3_map, dim3((h->v3_grid + 255) / 256), dim3(256), 0, h->stream, h->d_v3_map, h->v3_grid, h->d_acts,
+                           p.v_steps, p.a_steps, h->tile_v3, h->tile_a, h->skew_q16);
+        HIP_TRY(hipGetLastError(), "traversal table launch failed");
+    }
+    return TPLHIP_OK;
+}
+} // namespace
+
 int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
 {
     if (!h || !ps) return tplhip_fail(TPLHIP_EINVAL, "null argument");
@@ -953,24 +969,13 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
             }
             h->v3_ok = h->v3_ok && (h->tile_v3 % 2 == 0);
         }
-        // the traversal as a table: one word per workgroup (16 KB on 256x128x64), rebuilt whenever the geometry may have changed
-        const int key[6] = {p.v_steps, p.a_steps, h->tile_v3, h->tile_a, h->skew_q16, h->v3_grid};
-        if (h->d_v3_map && std::equal(key, key + 6, h->v3_map_key)) {
-            // (a reinit that changes no size -- what tpl's planner does every cycle -- keeps the table: no copy, no wait)
-        } else if (h->v3_ok && p.a_steps < 65536 && p.v_steps < 65536) {
-            std::vector<unsigned> map((size_t)h->v3_grid);
-            for (int bx = 0; bx < h->v3_grid; ++bx) {
-                int ia = 0, iv = 0;
-                map[(size_t)bx] = v3_map_block(bx, p.v_steps, p.a_steps, h->tile_v3, h->tile_a, h->skew_q16, ia, iv)
-                                      ? ((unsigned)ia << 16) | (unsigned)iv : V3_MAP_NONE;
-            }
-            if (map.size() > h->v3_map_cap) {
+        // the traversal as a table: one V3Map per workgroup (64 KB on 256x128x64), filled behind the action table (fill_v3_map)
+        if (h->v3_ok && p.a_steps < 65536 && p.v_steps < 65536) {
+            if ((size_t)h->v3_grid > h->v3_map_cap) {
                 (void)hipFree(h->d_v3_map); h->d_v3_map = nullptr; h->v3_map_cap = 0;
-                HIP_TRY(hipMalloc(&h->d_v3_map, sizeof(unsigned) * map.size()), "traversal table allocation failed");
-                h->v3_map_cap = map.size();
+                HIP_TRY(hipMalloc(&h->d_v3_map, sizeof(V3Map) * (size_t)h->v3_grid), "traversal table allocation failed");
+                h->v3_map_cap = (size_t)h->v3_grid;
             }
-            HIP_TRY(hipMemcpy(h->d_v3_map, map.data(), sizeof(unsigned) * map.size(), hipMemcpyHostToDevice), "traversal table upload failed");
-            std::copy(key, key + 6, h->v3_map_key);
         } else {
             (void)hipFree(h->d_v3_map); h->d_v3_map = nullptr; h->v3_map_cap = 0;
         }
@@ -994,8 +999,8 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     if (h->lds_bytes > 160 * 1024)
         return tplhip_fail(TPLHIP_EINVAL, "path_steps = %d does not fit in LDS next to the row buffers", p.path_steps);
 
-    hipLaunchKernelGGL(k_build_actions, dim3((nrows * N_BWD + 255) / 256), dim3(256), 0, h->stream, h->d_acts, p, h->rule);
-    HIP_TRY(hipGetLastError(), "action table launch failed");
+    int rc_acts = build_action_tables(h);
+    if (rc_acts) return rc_acts;
 
     // Division by the two run-time constants of the sweep (path step, station range): the plain-fp32 sweeps use a
     // cheap form only if it is proven bit-identical to IEEE division for every float the sweep can feed it.
@@ -1348,9 +1353,8 @@ int apply_rule(tplhip_dp_lon* h, FilterRule r)
     if (h->have_params) pick_div_forms(h);
     h->tables_valid = false;
     if (h->have_params && h->d_acts) {
-        const int nrows = h->params.v_steps * h->params.a_steps;
-        hipLaunchKernelGGL(k_build_actions, dim3((nrows * N_BWD + 255) / 256), dim3(256), 0, h->stream, h->d_acts, h->params, h->rule);
-        HIP_TRY(hipGetLastError(), "action table launch failed");
+        rc = build_action_tables(h);
+        if (rc) return rc;
     }
     return TPLHIP_OK;
 }

@@ -51,7 +51,7 @@ static_assert(sizeof(ActDesc) == 80, "ActDesc must be 80 bytes");
 // bijection per a-row) by that slope, skew_q16 / 65536 pairs per a-row: the workgroups resident on an XCD at one time -- a few
 // pairs by several dozen a-rows -- then touch a band of v' rows as narrow as the strip itself instead of one widened by the
 // a-extent (profiles/r04_dp_config4_skew.txt).  false: bx is past the XCD's share (the grid is sized for the widest one).
-// ONE definition for the host, which tabulates it once per reinit (tplhip_dp_lon::d_v3_map -> SweepArgs::tile_map: the three
+// ONE definition for k_fill_v3_map, which tabulates it per reinit (tplhip_dp_lon::d_v3_map -> SweepArgs::tile_map: the three
 // integer divisions and the modulo are ~150 scalar instructions in front of a workgroup's first row request), and the kernels'
 // fallback without a table.
 __host__ __device__ inline bool v3_map_block(int bx, int V, int A, int tile_v, int tile_a, int skew_q16, int& ia, int& iv)
@@ -74,6 +74,14 @@ __host__ __device__ inline bool v3_map_block(int bx, int V, int A, int tile_v, i
     return true;
 }
 constexpr unsigned V3_MAP_NONE = 0xffffffffu;
+// One entry of the tabulated traversal (k_fill_v3_map, dp_lon_kernels.h; launched behind every k_build_actions): where the
+// workgroup works and the next-stage rows its FIRST requests go to -- action 0 of the pair: the lower-a rows (a0, v0) of row 0
+// and (a0, v1) of both rows, ActDesc::r00 / r01.  One 16-byte scalar load.
+struct alignas(16) V3Map {
+    unsigned where;            // (a << 16) | v, V3_MAP_NONE past the XCD's share
+    int r00, r01_lo, r01_up;   // acts[(a V + v) 9].r00, .r01 and acts[(a V + v + 1) 9].r01 (row v again where v + 1 is past the grid)
+};
+static_assert(sizeof(V3Map) == 16, "V3Map is one dwordx4");
 
 // Everything a sweep launch needs besides the tables (filled by the host driver in dp_lon.hip).
 struct SweepArgs {
@@ -90,7 +98,7 @@ struct SweepArgs {
     float rcp_range_hi, rcp_range_lo;    // 1/(s_max - s_min) likewise
     int tile_v, tile_a;
     int skew_q16;              // k_backward3v: rotation of the row pairs of an a-row, pairs per a-row in 16.16 fixed point (0: none)
-    const unsigned* tile_map;  // k_backward3v / 3o: v3_map_block tabulated per workgroup, (a << 16) | v, V3_MAP_NONE past the share; null: computed
+    const V3Map* tile_map;     // k_backward3v / 3o: v3_map_block tabulated per workgroup (V3Map); null: computed
     // scenario batch (blockIdx.y): element strides between consecutive scenarios, 0 = shared
     size_t stride_tables, stride_pre, stride_path;
 };

@@ -799,6 +799,26 @@ __global__ void __launch_bounds__(256) k_copy_fwd_inputs(const unsigned* __restr
 }
 
 // ------------------------------------------------------------------------
+// The traversal of the two-rows-per-lane sweeps as a table (V3Map, dp_lon_internal.h), behind k_build_actions on the same
+// stream: entry bx = v3_map_block(bx) and the rows of action 0 the workgroup asks for first, copied from the action table.
+// ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fill_v3_map(V3Map* __restrict__ map, int n, const ActDesc* __restrict__ acts,
+                                                     int V, int A, int tile_v, int tile_a, int skew_q16)
+{
+    const int bx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bx >= n) return;
+    int ia = 0, iv = 0;
+    V3Map m{V3_MAP_NONE, 0, 0, 0};
+    if (v3_map_block(bx, V, A, tile_v, tile_a, skew_q16, ia, iv)) {
+        const ActDesc* d0 = acts + (size_t)(ia * V + iv) * N_BWD;
+        const ActDesc* d1 = iv + 1 < V ? d0 + N_BWD : d0;
+        m.where = ((unsigned)ia << 16) | (unsigned)iv;
+        m.r00 = d0->r00; m.r01_lo = d0->r01; m.r01_up = d1->r01;
+    }
+    map[bx] = m;
+}
+
+// ------------------------------------------------------------------------
 // updateDistMapPath, env.cu:131-158: ONE time slice of the distance map, by a whole workgroup (blockDim.x a multiple of
 // 64), into LDS.  occ: [l][s][t] (t fastest).
 // The reference walks idx_s from s_steps-1 down with d = occ > 0 ? 0 : d + step, d starting at 10000: at station i

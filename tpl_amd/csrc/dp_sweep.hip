@@ -185,12 +185,20 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     const float* __restrict__ path = path_all + scn * a.stride_path;
 
     constexpr int NV = 2;
-    // traversal: v3_map_block (dp_lon_internal.h) -- read from the table the host filled at reinit, or computed
+    // traversal: v3_map_block (dp_lon_internal.h) -- read from the table k_fill_v3_map wrote behind the action table, or computed.
+    // The table's entry also carries the three next-stage rows action 0 asks for first (V3Map): ONE scalar round trip between
+    // the kernel arguments and the workgroup's first row requests instead of two (traversal word, then the descriptor's rows).
     int ia, iv;
-    if (a.tile_map) {
-        const unsigned m = a.tile_map[blockIdx.x];
-        if (m == V3_MAP_NONE) return;
-        ia = (int)(m >> 16); iv = (int)(m & 0xffffu);
+    int first_rows[3];
+    const bool mapped = a.tile_map != nullptr;
+    if (mapped) {
+        // (one s_load_dwordx4: as four members the compiler loads `where`, branches, and only then asks for the rows)
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        v4i m = *reinterpret_cast<const v4i*>(a.tile_map + blockIdx.x);
+        asm volatile("" : "+s"(m));
+        if ((unsigned)m.x == V3_MAP_NONE) return;
+        ia = (int)((unsigned)m.x >> 16); iv = (int)((unsigned)m.x & 0xffffu);
+        first_rows[0] = m.y; first_rows[1] = m.z; first_rows[2] = m.w;
     } else if (!v3_map_block((int)blockIdx.x, V, A, a.tile_v, a.tile_a, a.skew_q16, ia, iv)) {
         return;
     }
@@ -241,8 +249,13 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
         }
     };
     // the rows of action 0 are requested before anything else: their latency passes under the prologue
+    static_assert(A0_ROWS == 0x15u, "V3Map carries lo[0], up[0][0], up[1][0]");
+    if (mapped) {
+        lo[0] = load_row(first_rows[0]); up[0][0] = load_row(first_rows[1]); up[1][0] = load_row(first_rows[2]);
+        __builtin_amdgcn_sched_barrier(0);           // (in front of the descriptor's scalar words, which nothing here waits for)
+    }
     ActScalars cur = fetch_scalars(0);
-    issue(cur, A0_ROWS);
+    if (!mapped) issue(cur, A0_ROWS);
     // ONE memory round trip for the prologue (see k_backward3s): requests first, LDS stores after
     const int bd = (int)blockDim.x;
     auto dsc_word = [&](int i) { return reinterpret_cast<const float*>(d0 + (i / (N_BWD * 8)) * rs + ((i >> 3) % N_BWD))[i & 7]; };
@@ -593,7 +606,7 @@ k_backward3o(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     // traversal: v3_map_block (dp_lon_internal.h) -- read from the table the host filled at reinit, or computed
     int ia, iv;
     if (a.tile_map) {
-        const unsigned m = a.tile_map[blockIdx.x];
+        const unsigned m = a.tile_map[blockIdx.x].where;
         if (m == V3_MAP_NONE) return;
         ia = (int)(m >> 16); iv = (int)(m & 0xffffu);
     } else if (!v3_map_block((int)blockIdx.x, V, A, a.tile_v, a.tile_a, a.skew_q16, ia, iv)) {
