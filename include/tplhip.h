@@ -243,6 +243,21 @@ TPLHIP_API int tplhip_dp_lon_set_contraction(tplhip_dp_lon* h, int on);
  * grid); un-quantised weights under another order, and inputs the plain-fp32 sweeps refuse, take the general sweep
  * ("k_backward"). */
 TPLHIP_API int tplhip_dp_lon_set_blend_order(tplhip_dp_lon* h, int order);
+/* Chained sweep (round 6): the stages of one plan behind the terminal one -- the reference's loop of lonBackwardStep launches,
+ * lon_planner.cu:347-361, with a device-wide wait after each -- in ONE launch of the two-rows-per-lane sweep.  A workgroup of
+ * stage t waits for the row pairs of stage t + 1 its nine actions read (flags at agent scope; the writers store their nodes
+ * through the XCD's L2); no kernel boundary between two stages: 256x128x64 one plan at a time 38-40 -> 35-37 us per stage
+ * sweep, 25.7 -> 28.3 k sweeps/s; same bits (tests/test_dp_gpu.py::test_chained_sweep...).  Two planners kept busy side by
+ * side LOSE 4 % with it (a waiting workgroup holds a slot the other plan could use), hence
+ *   mode -1 (default): the synchronous calls (tplhip_dp_lon_update / _update_batch: one plan at a time by construction);
+ *   mode  1: every plan of this handle, tplhip_dp_lon_plan_resident included;   mode 0: never.
+ * Taken where the sweep is "k_backward3v" under the default blend order, a table row is a multiple of 128 bytes
+ * (s_steps % 32 == 0), t_steps >= 4 and a stage table is at most 96 MB (beyond, the boundary is 1 % of a sweep)
+ * (tplhip_dp_lon_info -> "chained_sweep": 0 no / 1 synchronous calls / 2 every plan, "chained_launches").  No wait is
+ * unbounded: a workgroup that has waited 50 ms gives up and flags it, the call that hands out that plan's result fails with
+ * TPLHIP_EDEVICE ("plan again") and the handle sweeps stage by stage from then on.  It cannot happen while workgroups start
+ * in the order of their ids, which every use so far has shown. */
+TPLHIP_API int tplhip_dp_lon_set_chained_sweep(tplhip_dp_lon* h, int mode);
 /* Diagnostics, host only (works without a GPU): 1 if a plain-fp32 sweep instance is built for this arithmetic rule and this
  * pair of division forms (4 = one multiplication, 3 = two-float reciprocal, 5 = reciprocal + Newton step, 0 = IEEE division),
  * else 0.  kind 1 = the two-rows-per-lane sweep (k_backward3v; k_backward3o when order != 0), 2 = one cell per lane

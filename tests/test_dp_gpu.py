@@ -907,3 +907,97 @@ def test_reeval_after_resident_plans_waits_for_their_rollouts():
     rc = O.lib().dpo_reeval(C.byref(cp), C.byref(cep), O.fptr(other_path), O.fptr(dist2), O.fptr(tables), traj._as_array(), T, out)
     assert rc == 0
     assert np.array_equal(got_re.view(np.uint32), O.states_to_np(out).view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Chained sweep (SweepChain in dp_lon_internal.h): the stages of a plan behind the terminal one in ONE launch
+# ------------------------------------------------------------------------------------------------------------------------
+CHAIN_CASES = [
+    pytest.param(256, 40, 52, 8, sc.OBSTACLES_OVERTAKE_TRAFFIC, None, id="rows-of-256-eight-stages"),
+    pytest.param(128, 64, 66, 7, sc.random_obstacles(9, 7), 0.4, id="s128-v64-dt_start"),
+    pytest.param(128, 37, 120, 5, sc.random_obstacles(5, 6), None, id="odd-v-steps"),
+    pytest.param(512, 8, 6, 6, sc.random_obstacles(7, 5), None, id="rows-of-512-on-a-small-grid"),
+]
+
+
+@pytest.mark.parametrize("S,V,A,T,obst,dt_start", CHAIN_CASES)
+def test_chained_sweep_matches_the_oracle_and_the_stage_by_stage_launches(S, V, A, T, obst, dt_start):
+    """`update_batch` is one plan at a time: where the grid allows it (k_backward3v, rows of whole cache lines, four stages or
+    more) its T - 2 non-terminal sweeps go out as ONE launch whose workgroups wait for the row pairs of the stage before
+    them.  EVERY stage table and every trajectory against the oracle as raw bits; then the same plan stage by stage
+    (`set_chained_sweep(0)`): no chained launch, the same bits."""
+    p = sc.lon_params(S, V, A, T, dt_start=dt_start)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31, dt_start=dt_start)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, obst)
+    inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(4, seed=11)
+    dp, env, trajs, tables, otrajs, dist = _run_both(p, ep, path, occ, inits)
+    info = dp.info()
+    assert info["sweep"] == "k_backward3v" and info["chained_sweep"] == 1 and info["chained_launches"] == 1, info
+    _assert_tables_equal(dp, tables, T)
+    for r, tr in enumerate(trajs):
+        assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), r
+    dp.set_chained_sweep(0)
+    again = dp.update_batch(inits, path, env)
+    info = dp.info()
+    assert info["chained_sweep"] == 0 and info["chained_launches"] == 1, info
+    _assert_tables_equal(dp, tables, T)
+    for r, tr in enumerate(again):
+        assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), r
+
+
+def test_chained_sweep_is_on_request_for_plans_in_flight():
+    """`plan_resident` (plans back to back, possibly beside another planner's) sweeps stage by stage unless asked:
+    `set_chained_sweep(1)` chains those too.  Four plans with a new start state and obstacle set each, back to back on one
+    planner, against the oracle's trajectories; the launch counter tells which form ran."""
+    S, V, A, T = 256, 40, 52, 6
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    env = tpl_amd.DynProgEnvironment()
+    env.reinit_buffers(ep)
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p)
+    cp, cep = O.cparams(p), O.cparams(ep)
+    for mode, want_chained in ((-1, 0), (1, 4)):
+        dp.set_chained_sweep(mode)
+        before = dp.info()["chained_launches"]
+        for k in range(4):
+            occ = sc.occ_map(ep, sc.random_obstacles(3 + k, 5 + k))
+            inits = sc.random_initial_states(2, seed=20 + k)
+            env.set_occ_map(occ)
+            dp.upload(inits, path)
+            dp.plan_resident(env)
+            got = dp.download()
+            _, otrajs, _ = O.update(cp, cep, path, occ, inits)
+            for r, tr in enumerate(got):
+                assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (mode, k, r)
+        info = dp.info()
+        assert info["chained_launches"] - before == want_chained, (mode, info)
+        assert info["chained_sweep"] == (2 if mode == 1 else 1), info
+
+
+def test_a_chained_sweep_that_gives_up_fails_the_call_and_the_handle_recovers(monkeypatch):
+    """No wait inside the chained launch is unbounded: a workgroup that gives up flags it, the call that hands out the plan
+    fails loudly, and the handle sweeps stage by stage from then on.  TPLHIP_DEBUG=chain_fail_once makes the host read
+    that flag as set once (the device side cannot be provoked: workgroups start in the order of their ids)."""
+    monkeypatch.setenv("TPLHIP_DEBUG", "chain_fail_once")
+    S, V, A, T = 256, 40, 52, 5
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
+    inits = [sc.initial_state(0.0, 8.0, 0.0)]
+    env = tpl_amd.DynProgEnvironment()
+    env.reinit_buffers(ep)
+    env.set_occ_map(occ)
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p)
+    with pytest.raises(RuntimeError, match="plan again"):
+        dp.update_batch(inits, path, env)
+    assert dp.info()["chained_sweep"] == 0
+    trajs = dp.update_batch(inits, path, env)
+    tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, inits)
+    assert dp.info()["chained_launches"] == 1
+    _assert_tables_equal(dp, tables, T)
+    assert np.array_equal(_traj_np(trajs[0]).view(np.uint32), otrajs[0].view(np.uint32))

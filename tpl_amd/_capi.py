@@ -228,6 +228,7 @@ SIGNATURES = {
     "tplhip_dp_lon_set_contraction": (C.c_int, [_vp, C.c_int]),
     "tplhip_dp_lon_sweep_built": (C.c_int, [C.c_int] * 7),
     "tplhip_dp_lon_set_blend_order": (C.c_int, [_vp, C.c_int]),
+    "tplhip_dp_lon_set_chained_sweep": (C.c_int, [_vp, C.c_int]),
     "tplhip_dp_lon_timing_enable": (C.c_int, [_vp, C.c_int]),
     "tplhip_dp_lon_timing_get": (C.c_int, [_vp, _P(C.c_double), _P(C.c_int64)]),
     "tplhip_path_project": (C.c_int, [_P(C.c_double), C.c_int, C.c_int, C.c_int, _P(C.c_double), C.c_int, _P(TplProjection)]),

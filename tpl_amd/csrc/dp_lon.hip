@@ -148,6 +148,19 @@ struct tplhip_dp_lon {
     int v3_grid = 0;
     V3Map* d_v3_map = nullptr;           // v3_map_block and action 0's first rows per workgroup of that grid (SweepArgs::tile_map)
     size_t v3_map_cap = 0;
+    // chained sweep (SweepChain, dp_lon_internal.h): all stages of a plan behind the terminal one in ONE launch of k_backward3v
+    int chain_mode = -1;                 // tplhip_dp_lon_set_chained_sweep: -1 the synchronous calls only (default), 0 never, 1 every plan
+    bool chain_fail_once = false;        // TPLHIP_DEBUG=chain_fail_once: the next status read reports a wait that gave up (tests)
+    bool chain_ok = false;               // this grid and rule can be chained (set by reinit / apply_rule)
+    bool chain_broken = false;           // a wait gave up once: never again on this handle
+    int* d_chain_deps = nullptr;         // [v3_grid][CHAIN_DEPS]
+    size_t chain_deps_cap = 0;
+    unsigned* d_chain_flags = nullptr;   // [t_steps][pairs]
+    size_t chain_flags_cap = 0;
+    unsigned* d_chain_err = nullptr;     // [0] a wait gave up, [1] workgroups whose dependencies overflow CHAIN_DEPS
+    unsigned chain_epoch = 0;
+    bool chain_unchecked = false;        // a chained launch went out since d_chain_err was last read
+    unsigned long long chain_launches = 0, chain_failures = 0;
     bool no_v3 = false, no_fwd_overlap = false, no_fwd_spec = false, no_front = false;   // TPLHIP_DEBUG overrides, read by reinit
     bool front_fused = true;                 // what the last plan did (info)
     FilterRule rule = kDefaultRule;      // R1 - R3 of the arithmetic contract (tplhip_dp_lon_set_filter_rule / _set_contraction / _set_blend_order)
@@ -197,6 +210,10 @@ void free_planner_buffers(tplhip_dp_lon* h)
     h->overlap = false; h->fwd_pending[0] = h->fwd_pending[1] = false;
     (void)hipFree(h->d_acts);      h->d_acts = nullptr;
     (void)hipFree(h->d_v3_map);    h->d_v3_map = nullptr; h->v3_map_cap = 0;
+    (void)hipFree(h->d_chain_deps);  h->d_chain_deps = nullptr; h->chain_deps_cap = 0;
+    (void)hipFree(h->d_chain_flags); h->d_chain_flags = nullptr; h->chain_flags_cap = 0;
+    (void)hipFree(h->d_chain_err);   h->d_chain_err = nullptr;
+    h->chain_ok = false;
     (void)hipFree(h->d_path);      h->d_path = nullptr;
     (void)hipFree(h->d_pre_vmax);  h->d_pre_vmax = nullptr;
     (void)hipFree(h->d_pre_sdist); h->d_pre_sdist = nullptr;
@@ -307,7 +324,7 @@ bool use_v3(const tplhip_dp_lon* h)
            && backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps) <= 64 * 1024;
 }
 
-bool launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
+bool launch_backward3(tplhip_dp_lon* h, int idx_t, int nx, int chain_stages = 0)
 {
     const size_t S = (size_t)h->params.s_steps;
     SweepArgs a;
@@ -324,7 +341,21 @@ bool launch_backward3(tplhip_dp_lon* h, int idx_t, int nx)
     a.rcp_range_hi = h->rcp_range_hi; a.rcp_range_lo = h->range_aux;
     a.tile_v = h->tile_v3; a.tile_a = h->tile_a; a.skew_q16 = h->skew_q16; a.tile_map = h->d_v3_map;
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
-    return launch_backward3v(h->rule, h->path_div3, h->range_div3, a, dim3(h->v3_grid, 1), backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
+    dim3 grid(h->v3_grid, 1);
+    if (chain_stages > 0) {
+        // stages idx_t, idx_t - 1, ... in ONE launch (SweepChain): grid.y = stage, the latest first
+        a.chain.stages = chain_stages;
+        a.chain.epoch = ++h->chain_epoch;
+        a.chain.flags = h->d_chain_flags;
+        a.chain.first = idx_t;
+        a.chain.pairs = h->params.a_steps * ((h->params.v_steps + 1) / 2);
+        a.chain.deps = h->d_chain_deps;
+        a.chain.err = h->d_chain_err;
+        a.chain.table_cells = h->table_cells;
+        a.chain.budget = 5000000;                   // 50 ms of the 100 MHz counter
+        grid.y = (unsigned)chain_stages;
+    }
+    return launch_backward3v(h->rule, h->path_div3, h->range_div3, a, grid, backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
 }
 
 bool launch_backward3s_(tplhip_dp_lon* h, int idx_t, int nx)
@@ -360,6 +391,15 @@ int sweep_kind(const tplhip_dp_lon* h)
     return (h->v3_ok && !h->no_s3) ? 1 : 0;
 }
 
+// does a plan of this handle sweep its stages in one chained launch?
+// (synchronous: the call returns with the plan -- one plan at a time on this handle by construction, where the chained launch
+// wins 8-10 %; a caller that keeps several planners busy through plan_resident loses 4 % with it and gets it only on request)
+bool chain_plan(const tplhip_dp_lon* h, bool synchronous)
+{
+    return h->chain_ok && !h->chain_broken && (h->chain_mode == 1 || (h->chain_mode < 0 && synchronous)) && sweep_kind(h) == 1
+           && h->rule.order == 0 && h->d_chain_deps && h->d_chain_flags && h->d_chain_err;
+}
+
 void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
 {
     const int kind = sweep_kind(h);
@@ -390,6 +430,35 @@ int wait_pending_forwards(tplhip_dp_lon* h)
         h->fwd_pending[0] = h->fwd_pending[1] = false;
     }
     return TPLHIP_OK;
+}
+
+// A chained launch went out since the last look: did one of its waits give up (SweepChain)?  Called where a plan's results
+// are handed out, behind the wait for them.  It cannot happen while workgroups start in the order of their ids; if it ever
+// does, the plan's tables are not complete: the call fails, and the handle sweeps stage by stage from then on.
+int chain_check(tplhip_dp_lon* h)
+{
+    if (!h->chain_unchecked) return TPLHIP_OK;
+    h->chain_unchecked = false;
+    unsigned err = 0;
+    HIP_TRY(hipMemcpy(&err, h->d_chain_err, sizeof err, hipMemcpyDeviceToHost), "reading the chained sweep's status failed");
+    if (h->chain_fail_once) { err = 1; h->chain_fail_once = false; }
+#ifdef TPL_CHAIN_STATS
+    {
+        unsigned w[8];
+        (void)hipMemcpy(w, h->d_chain_err, sizeof w, hipMemcpyDeviceToHost);
+        unsigned long long ticks; std::memcpy(&ticks, w + 2, 8);
+        std::fprintf(stderr, "[chain] launches %llu: waits %u workgroups, %u of them > 3 us, mean %.2f us\n", h->chain_launches, w[5], w[4], w[5] ? ticks / 100.0 / w[5] : 0.0);
+        (void)hipMemset(h->d_chain_err + 2, 0, 4 * sizeof(unsigned));
+    }
+#endif
+    if (err == 0) return TPLHIP_OK;
+    h->chain_broken = true;
+    h->chain_ok = false;
+    h->chain_failures += 1;
+    h->tables_valid = false;
+    (void)hipMemset(h->d_chain_err, 0, sizeof(unsigned));
+    return tplhip_fail(TPLHIP_EDEVICE, "chained sweep: a workgroup waited %d ms for a row of the stage before it and gave up; this plan's "
+                       "result is not valid -- plan again (the handle sweeps stage by stage from now on)", 50);
 }
 
 int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState* mirror = nullptr,
@@ -453,6 +522,12 @@ int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState
     for (int i = T - 1; i > 0; --i) {
         const int nx = std::min(T - 1, i + 1);
         if (i == T - 1 && fused_front) continue;
+        if (i == T - 2 && i >= 2 && chain_plan(h, mirror != nullptr) && launch_backward3(h, i, nx, i)) {
+            // stages T-2 .. 1 in one launch (SweepChain)
+            h->chain_unchecked = true;
+            h->chain_launches += 1;
+            break;
+        }
         launch_stage(h, i, nx, i == T - 1);
     }
     if (h->timing) {
@@ -790,10 +865,39 @@ int build_action_tables(tplhip_dp_lon* h)
     const int nrows = p.v_steps * p.a_steps;
     hipLaunchKernelGGL(k_build_actions, dim3((nrows * N_BWD + 255) / 256), dim3(256), 0, h->stream, h->d_acts, p, h->rule);
     HIP_TRY(hipGetLastError(), "action table launch failed");
+    h->chain_ok = false;
     if (h->d_v3_map) {
+        // chained sweep: where asked for, for the default blend order, rows of whole cache lines (SweepChain), three stages or more
+        const int pairs = p.a_steps * ((p.v_steps + 1) / 2);
+        // (not on stage tables beyond 96 MB: there the launch boundary is 1 % of a sweep and the write-through stores cost
+        // 3 % -- 512x256x128: 325 -> 335 us, profiles/r06_dp_chained_sweep.txt)
+        bool chain = h->chain_mode != 0 && !h->chain_broken && h->rule.order == 0 && ((size_t)p.s_steps * sizeof(Node)) % 128 == 0
+                     && p.t_steps >= 4 && h->table_cells * sizeof(Node) <= ((size_t)96 << 20);
+        if (chain) {
+            const size_t nd = (size_t)h->v3_grid * CHAIN_DEPS, nf = (size_t)p.t_steps * pairs;
+            if (nd > h->chain_deps_cap) {
+                (void)hipFree(h->d_chain_deps); h->d_chain_deps = nullptr; h->chain_deps_cap = 0;
+                if (hipMalloc(&h->d_chain_deps, sizeof(int) * nd) == hipSuccess) h->chain_deps_cap = nd; else { (void)hipGetLastError(); chain = false; }
+            }
+            if (chain && nf > h->chain_flags_cap) {
+                (void)hipFree(h->d_chain_flags); h->d_chain_flags = nullptr; h->chain_flags_cap = 0;
+                if (hipMalloc(&h->d_chain_flags, sizeof(unsigned) * nf) == hipSuccess) h->chain_flags_cap = nf; else { (void)hipGetLastError(); chain = false; }
+                if (chain) HIP_TRY(hipMemsetAsync(h->d_chain_flags, 0, sizeof(unsigned) * nf, h->stream), "flag reset failed");
+            }
+            if (chain && !h->d_chain_err && hipMalloc(&h->d_chain_err, 8 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); h->d_chain_err = nullptr; chain = false; }
+            if (chain) HIP_TRY(hipMemsetAsync(h->d_chain_err, 0, 8 * sizeof(unsigned), h->stream), "flag reset failed");
+        }
         hipLaunchKernelGGL(k_fill_v3_map, dim3((h->v3_grid + 255) / 256), dim3(256), 0, h->stream, h->d_v3_map, h->v3_grid, h->d_acts,
-                           p.v_steps, p.a_steps, h->tile_v3, h->tile_a, h->skew_q16);
+                           p.v_steps, p.a_steps, h->tile_v3, h->tile_a, h->skew_q16, chain ? h->d_chain_deps : nullptr,
+                           chain ? h->d_chain_err + 1 : nullptr);
         HIP_TRY(hipGetLastError(), "traversal table launch failed");
+        if (chain) {
+            // (once per reinit of a chained planner: does every workgroup's dependency list fit?)
+            unsigned over = 0;
+            HIP_TRY(hipMemcpyAsync(&over, h->d_chain_err + 1, sizeof over, hipMemcpyDeviceToHost, h->stream), "dependency check failed");
+            HIP_TRY(hipStreamSynchronize(h->stream), "dependency check failed");
+            h->chain_ok = over == 0;
+        }
     }
     return TPLHIP_OK;
 }
@@ -920,6 +1024,11 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
     h->no_fwd_overlap = debug_opt("no_fwd_overlap");
     h->no_fwd_spec = debug_opt("no_fwd_spec");
     h->no_front = debug_opt("no_front");
+    {
+        int m = 0;
+        if (debug_opt("chain", &m)) h->chain_mode = m != 0 ? 1 : 0;          // TPLHIP_DEBUG=chain=1 | chain=0
+        h->chain_fail_once = debug_opt("chain_fail_once");
+    }
     // "bounded": every float parameter finite and < 1e6 in magnitude, at most 1e5 stages.  Then no
     // cost or constraint sum of the sweep can overflow (largest single term ~ w * (1e6)^2 = 1e18, at
     // most 1e5 of them), no infinity and hence no NaN can appear, and a running lexicographic argmin
@@ -1136,7 +1245,8 @@ int tplhip_dp_lon_sync(tplhip_dp_lon* h)
     if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     HIP_TRY(hipStreamSynchronize(h->stream), "lon planner pass failed");
-    return wait_pending_forwards(h);
+    int rc = wait_pending_forwards(h);
+    return rc ? rc : chain_check(h);
 }
 
 int tplhip_dp_lon_download(tplhip_dp_lon* h, TplLonState* out_trajs)
@@ -1159,6 +1269,10 @@ int tplhip_dp_lon_download(tplhip_dp_lon* h, TplLonState* out_trajs)
     HIP_TRY(hipStreamSynchronize(cs), "lon planner forward pass failed");
     if (on_fwd) h->fwd_pending[0] = h->fwd_pending[1] = false;
     h->up_inflight = false;                                  // the uploads were ordered before what just finished
+    {
+        int rc = chain_check(h);
+        if (rc) return rc;
+    }
     std::memcpy(out_trajs, h->h_dl, sizeof(TplLonState) * n);
     return TPLHIP_OK;
 }
@@ -1199,6 +1313,10 @@ int tplhip_dp_lon_collect_download(tplhip_dp_lon* h, int slot, TplLonState* out_
                            slot, h->stage_n[slot], (size_t)h->n_rollouts * h->params.t_steps);
     }
     HIP_TRY(hipEventSynchronize(h->stage_ev[slot]), "lon planner forward pass failed");
+    {
+        int rc = chain_check(h);
+        if (rc) { h->stage_busy[slot] = false; return rc; }
+    }
     std::memcpy(out_trajs, h->h_stage[slot], sizeof(TplLonState) * h->stage_n[slot]);
     h->stage_busy[slot] = false;
     return TPLHIP_OK;
@@ -1255,6 +1373,8 @@ int tplhip_dp_lon_update_batch(tplhip_dp_lon* h, int n, const TplLonState* inits
     }
     if (!seen) HIP_TRY(hipStreamSynchronize(h->stream), "lon planner forward pass failed");
     h->up_inflight = false;                                  // the uploads were ordered before what just finished
+    rc = chain_check(h);
+    if (rc) return rc;
     std::memcpy(out_trajs, h->h_dl, sizeof(TplLonState) * cnt);
     return TPLHIP_OK;
 }
@@ -1299,7 +1419,7 @@ int tplhip_dp_lon_reeval(tplhip_dp_lon* h, const TplLonState* traj, int len, con
     HIP_TRY(hipMemcpyAsync(out_traj, h->d_reeval, sizeof(TplLonState) * (size_t)len,
                            hipMemcpyDeviceToHost, h->stream), "copying reevaluted trajectory to cpu failed");
     HIP_TRY(hipStreamSynchronize(h->stream), "reeval pass failed");
-    return TPLHIP_OK;
+    return chain_check(h);
 }
 
 int tplhip_dp_lon_copy_table(tplhip_dp_lon* h, int t, float* out)
@@ -1309,6 +1429,10 @@ int tplhip_dp_lon_copy_table(tplhip_dp_lon* h, int t, float* out)
     if (t < 0 || t >= h->params.t_steps) return tplhip_fail(TPLHIP_EINVAL, "stage %d out of range", t);
     HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
     HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
+    {
+        int rc = chain_check(h);
+        if (rc) return rc;
+    }
     // the C-ABI hands out the reference's float4 cells (cost, constr, j, 0); the device keeps 12
     std::vector<Node> tmp(h->table_cells);
     HIP_TRY(hipMemcpy(tmp.data(), h->d_tables + (size_t)t * h->table_cells, sizeof(Node) * h->table_cells,
@@ -1328,13 +1452,15 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
                   "{\"sweep\": \"%s\", \"s_pad\": %d, \"rows_per_block\": %d, \"nblocks\": %d, \"kchunk\": %d, \"lds_bytes\": %zu, "
                   "\"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"big\": %d, "
                   "\"bounded_inputs\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\", \"fwd_overlap\": %d, \"plan_front\": \"%s\", "
-                  "\"skew_pairs_per_a_row\": %.4f, \"tile_v3\": %d, \"rule\": {\"quant\": %d, \"lerp\": %d, \"fma\": %d, \"order\": %d}}",
+                  "\"skew_pairs_per_a_row\": %.4f, \"tile_v3\": %d, \"rule\": {\"quant\": %d, \"lerp\": %d, \"fma\": %d, \"order\": %d}, "
+                  "\"chained_sweep\": %d, \"chained_launches\": %llu}",
                   sweep, h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
                   (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->big ? 1 : 0,
                   (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
                   h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded && h->params_bounded) ? (h->rule.order != 0 ? "k_backward3o" : "k_backward3v") : "k_backward", h->overlap ? 1 : 0,
                   h->front_fused && !h->no_front ? "k_plan_front" : "three launches", (double)h->skew_q16 / 65536.0, h->tile_v3,
-                  h->rule.quant, h->rule.lerp, h->rule.fma, h->rule.order);
+                  h->rule.quant, h->rule.lerp, h->rule.fma, h->rule.order,
+                  chain_plan(h, true) ? (h->chain_mode == 1 ? 2 : 1) : 0, h->chain_launches);
     return TPLHIP_OK;
 }
 
@@ -1359,6 +1485,24 @@ int apply_rule(tplhip_dp_lon* h, FilterRule r)
     return TPLHIP_OK;
 }
 } // namespace
+
+// Chained sweep (SweepChain): -1 = the synchronous calls only (default), 0 = never, 1 = every plan of this handle.
+int tplhip_dp_lon_set_chained_sweep(tplhip_dp_lon* h, int mode)
+{
+    if (!h) return tplhip_fail(TPLHIP_EINVAL, "null handle");
+    if (mode < -1 || mode > 1) return tplhip_fail(TPLHIP_EINVAL, "chained sweep: -1 synchronous calls only, 0 never, 1 every plan");
+    HIP_TRY(hipSetDevice(h->device), "hipSetDevice failed");
+    const bool had = h->chain_mode != 0;
+    h->chain_mode = mode;
+    if (mode != 0 && !had && h->have_params && h->d_acts) {
+        // the dependency lists are written with the traversal table
+        int rc = wait_pending_forwards(h);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream), "stream sync failed");
+        return build_action_tables(h);
+    }
+    return TPLHIP_OK;
+}
 
 // R2 / R3: the plain-fp32 sweeps are built for all nine (weight rule, blend form) pairs, so the choice of kernel does not change.
 int tplhip_dp_lon_set_filter_rule(tplhip_dp_lon* h, int weight_quant, int lerp_form)

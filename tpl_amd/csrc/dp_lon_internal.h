@@ -83,6 +83,28 @@ struct alignas(16) V3Map {
 };
 static_assert(sizeof(V3Map) == 16, "V3Map is one dwordx4");
 
+// SEVERAL dependent stages in ONE launch of k_backward3v (grid.y = stages, the latest first): no kernel boundary between two
+// sweeps, and the first workgroups of a stage run beside the last ones of the stage before.  Workgroups start in the order
+// of their linear id on every XCD (x fastest, then y; id & 7 = XCD since grid.x is a multiple of 8), so every workgroup a
+// waiting one depends on has already started -- and a wait that outlasts `budget` gives up, raises *err and lets the host
+// sweep the plan again stage by stage: no wave can wait for ever.  What a workgroup waits for: the row pairs of the next stage
+// its nine actions read (deps: up to CHAIN_DEPS flag indices per workgroup, -1 = none; k_fill_v3_map), each announced by
+// its writer -- node stores written THROUGH the XCD's L2 (sc1), completed, then flags[stage][pair] = epoch, all at agent
+// scope.  A reader's L2 cannot hold an older copy of such a row: rows are whole cache lines (the host chains only where a
+// row is a multiple of 128 bytes), every stage table is written once per plan, and it is first read after its flag.
+constexpr int CHAIN_DEPS = 64;
+struct SweepChain {
+    int stages = 0;            // 0: a plain launch (blockIdx.y = scenario)
+    unsigned epoch = 0;        // this launch's value of a set flag
+    unsigned* flags = nullptr; // [t_steps][pairs], pairs = a_steps * ((v_steps + 1) / 2)
+    int first = 0;             // stage index of blockIdx.y = 0
+    int pairs = 0;
+    const int* deps = nullptr; // [grid.x][CHAIN_DEPS]
+    unsigned* err = nullptr;   // device word: non-zero once a wait gave up
+    size_t table_cells = 0;    // nodes per stage table
+    long long budget = 0;      // s_memtime ticks a workgroup may wait
+};
+
 // Everything a sweep launch needs besides the tables (filled by the host driver in dp_lon.hip).
 struct SweepArgs {
     const Node* next;
@@ -101,6 +123,8 @@ struct SweepArgs {
     const V3Map* tile_map;     // k_backward3v / 3o: v3_map_block tabulated per workgroup (V3Map); null: computed
     // scenario batch (blockIdx.y): element strides between consecutive scenarios, 0 = shared
     size_t stride_tables, stride_pre, stride_path;
+    // chained sweep (k_backward3v, one scenario): blockIdx.y = c sweeps stage (this launch's first stage - c); see SweepChain
+    SweepChain chain;
 };
 
 // true (on the calling thread only): the launchers below answer "is this combination built?" and launch nothing

@@ -802,19 +802,43 @@ __global__ void __launch_bounds__(256) k_copy_fwd_inputs(const unsigned* __restr
 // The traversal of the two-rows-per-lane sweeps as a table (V3Map, dp_lon_internal.h), behind k_build_actions on the same
 // stream: entry bx = v3_map_block(bx) and the rows of action 0 the workgroup asks for first, copied from the action table.
 // ------------------------------------------------------------------------
+// deps (may be null): per workgroup the row PAIRS of the next stage its actions read, as flag indices a' * pairs_per_a + v' / 2
+// (SweepChain), without repeats, -1 behind the last; *deps_overflow counts workgroups with more than CHAIN_DEPS of them.
 __global__ void __launch_bounds__(256) k_fill_v3_map(V3Map* __restrict__ map, int n, const ActDesc* __restrict__ acts,
-                                                     int V, int A, int tile_v, int tile_a, int skew_q16)
+                                                     int V, int A, int tile_v, int tile_a, int skew_q16,
+                                                     int* __restrict__ deps, unsigned* __restrict__ deps_overflow)
 {
     const int bx = blockIdx.x * blockDim.x + threadIdx.x;
     if (bx >= n) return;
     int ia = 0, iv = 0;
     V3Map m{V3_MAP_NONE, 0, 0, 0};
+    int nd = 0;
+    int* my = deps ? deps + (size_t)bx * CHAIN_DEPS : nullptr;
     if (v3_map_block(bx, V, A, tile_v, tile_a, skew_q16, ia, iv)) {
         const ActDesc* d0 = acts + (size_t)(ia * V + iv) * N_BWD;
         const ActDesc* d1 = iv + 1 < V ? d0 + N_BWD : d0;
         m.where = ((unsigned)ia << 16) | (unsigned)iv;
         m.r00 = d0->r00; m.r01_lo = d0->r01; m.r01_up = d1->r01;
+        if (my) {
+            const int NP = (V + 1) / 2;
+            bool over = false;
+            for (int i = 0; i < 2; ++i) {
+                const ActDesc* d = i ? d1 : d0;
+                for (int k = 0; k < N_BWD; ++k) {
+                    const int rows[4] = {d[k].r00, d[k].r10, d[k].r01, d[k].r11};
+                    for (int r : rows) {
+                        const int f = (r / V) * NP + ((r % V) >> 1);
+                        bool seen = false;
+                        for (int q = 0; q < nd; ++q) seen = seen || my[q] == f;
+                        if (seen) continue;
+                        if (nd < CHAIN_DEPS) my[nd++] = f; else over = true;
+                    }
+                }
+            }
+            if (over) atomicAdd(deps_overflow, 1u);
+        }
     }
+    if (my) for (int q = nd; q < CHAIN_DEPS; ++q) my[q] = -1;
     map[bx] = m;
 }
 

@@ -177,11 +177,15 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     const int nrows = V * A;
     const int is = threadIdx.x;
     const int s_pad = a.s_pad;
-    const size_t scn = blockIdx.y;
-    const Node* __restrict__ next = next_all + scn * a.stride_tables;
-    Node* __restrict__ out = out_all + scn * a.stride_tables;
-    const float* __restrict__ pre_vmax = pre_vmax_all + scn * a.stride_pre;
-    const float* __restrict__ pre_sdist = pre_sdist_all + scn * a.stride_pre;
+    // blockIdx.y: the scenario of a batch, or -- chained sweep (SweepChain) -- how many stages behind the launch's first one
+    const bool chained = a.chain.stages != 0;
+    const size_t scn = chained ? 0 : blockIdx.y;
+    const int cstage = chained ? (int)blockIdx.y : 0;
+    const size_t back = chained ? (size_t)cstage * a.chain.table_cells : 0;
+    const Node* __restrict__ next = next_all + scn * a.stride_tables - back;
+    Node* __restrict__ out = out_all + scn * a.stride_tables - back;
+    const float* __restrict__ pre_vmax = pre_vmax_all + scn * a.stride_pre - (size_t)cstage * S;
+    const float* __restrict__ pre_sdist = pre_sdist_all + scn * a.stride_pre - (size_t)cstage * S;
     const float* __restrict__ path = path_all + scn * a.stride_path;
 
     constexpr int NV = 2;
@@ -248,9 +252,14 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             if ((m >> (3 + 2 * i)) & 1u) up[i][1] = load_row(x.r11[i]);
         }
     };
+    // chained sweep: the next stage's table is being written by this very launch -- this workgroup's rows are requested behind
+    // the wait at the first barrier (chain_wait below); what it waits for is asked for here
+    const bool wait_first = chained && cstage > 0;
+    int dep = -1;
+    if (wait_first && is < 64) dep = a.chain.deps[(size_t)blockIdx.x * CHAIN_DEPS + is];
     // the rows of action 0 are requested before anything else: their latency passes under the prologue
     static_assert(A0_ROWS == 0x15u, "V3Map carries lo[0], up[0][0], up[1][0]");
-    if (mapped) {
+    if (mapped && !wait_first) {
         lo[0] = load_row(first_rows[0]); up[0][0] = load_row(first_rows[1]); up[1][0] = load_row(first_rows[2]);
         __builtin_amdgcn_sched_barrier(0);           // (in front of the descriptor's scalar words, which nothing here waits for)
     }
@@ -323,7 +332,37 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     // instructions, the slower of the two.
 #pragma unroll
     for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(sc[i]), "+v"(sg[i]), "+v"(sd_base[i]));
-    __syncthreads();                     // descriptors and path limits are in LDS
+    if (wait_first) {
+        // chain_wait: the first wavefront polls the flags of the row pairs the nine actions read (agent scope: past this XCD's
+        // L2) until all carry this launch's epoch; it gives up after `budget` ticks of the 100 MHz counter, or as soon as any
+        // workgroup has, and says so in *err -- the host then discards the plan (dp_lon.hip: chain_check)
+        if (is < 64) {
+            const unsigned* fl = a.chain.flags + (size_t)(a.chain.first - cstage + 1) * a.chain.pairs;
+            const long long t0 = (long long)wall_clock64();
+            for (;;) {
+                const bool ok = dep < 0 || __hip_atomic_load(fl + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.chain.epoch;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                const long long waited = (long long)wall_clock64() - t0;
+                if (waited > 1000 && (waited > a.chain.budget || __hip_atomic_load(a.chain.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    if (is == 0) __hip_atomic_store(a.chain.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+#ifdef TPL_CHAIN_STATS
+            if (is == 0) {
+                const long long waited = (long long)wall_clock64() - t0;
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.chain.err + 2), (unsigned long long)waited);
+                if (waited > 300) atomicAdd(a.chain.err + 4, 1u);
+                atomicAdd(a.chain.err + 5, 1u);
+            }
+#endif
+        }
+    }
+    __syncthreads();                     // descriptors and path limits are in LDS (chained: and the rows this workgroup reads are complete)
+    if (wait_first) {
+        lo[0] = load_row(first_rows[0]); up[0][0] = load_row(first_rows[1]); up[1][0] = load_row(first_rows[2]);
+    }
     // (the descriptor copy's LDS address stays in ONE vector register where there is one to spare: otherwise it is moved there
     // from a scalar one per action)
     unsigned dsc_addr = (unsigned)(unsigned long long)dsc;
@@ -494,11 +533,30 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 #pragma unroll
         for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(best[i]), "+v"(bk[i]));
     }
-    if (active) {
+    if (!chained) {
+        if (active) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (i == 0 || rs) st_node(out + (size_t)(row0 + i) * S + is, __uint_as_float((unsigned)best[i]), __uint_as_float((unsigned)(best[i] >> 32)),
-                    action_jerk(p, bk[i], N_BWD, FilterRule{QUANT, LERP & 3, kFma<LERP> ? 1 : 0}));
+            for (int i = 0; i < NV; ++i)
+                if (i == 0 || rs) st_node(out + (size_t)(row0 + i) * S + is, __uint_as_float((unsigned)best[i]), __uint_as_float((unsigned)(best[i] >> 32)),
+                        action_jerk(p, bk[i], N_BWD, FilterRule{QUANT, LERP & 3, kFma<LERP> ? 1 : 0}));
+        }
+    } else {
+        // chained: the nodes go THROUGH this XCD's L2 (agent scope), and once every wave's stores have completed the pair is announced
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (i == 0 || rs) {
+                    const v3f n = {__uint_as_float((unsigned)best[i]), __uint_as_float((unsigned)(best[i] >> 32)),
+                                   action_jerk(p, bk[i], N_BWD, FilterRule{QUANT, LERP & 3, kFma<LERP> ? 1 : 0})};
+                    Node* q = out + (size_t)(row0 + i) * S + is;
+                    asm volatile("global_store_dwordx3 %0, %1, off sc1" :: "v"(q), "v"(n) : "memory");
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (is == 0)
+            __hip_atomic_store(a.chain.flags + (size_t)(a.chain.first - cstage) * a.chain.pairs + (size_t)ia * ((V + 1) / 2) + (iv >> 1),
+                               a.chain.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -586,6 +586,13 @@ class DynProgLonPlanner:
         eight-corner sum with an fp32 / a wide accumulator.  See ``tplhip_dp_lon_set_blend_order`` in include/tplhip.h."""
         check(self._lib.tplhip_dp_lon_set_blend_order(self._h, int(order)))
 
+    def set_chained_sweep(self, mode=-1):
+        """All stages of a plan behind the terminal one in ONE launch of the large-grid sweep (no kernel boundary per
+        stage): -1 = ``update`` / ``update_batch`` only (default), 1 = every plan incl. ``plan_resident``, 0 = never.
+        Same bits; see ``tplhip_dp_lon_set_chained_sweep`` in include/tplhip.h for when it applies and what it costs a
+        caller that keeps several planners busy."""
+        check(self._lib.tplhip_dp_lon_set_chained_sweep(self._h, int(mode)))
+
     def timing_enable(self, enable=True):
         check(self._lib.tplhip_dp_lon_timing_enable(self._h, 1 if enable else 0))
 
