@@ -647,9 +647,12 @@ def worker(args):
     in_flight = args.in_flight if args.in_flight is not None else (1 if args.grid == "config4" else PLANS_IN_FLIGHT)
     in_flight = max(1, min(in_flight, plans_per_step))
     occs, starts = scenario_deck(rank, ep)
+    # one plan at a time (what a tpl caller does): all stages of a plan in ONE launch; plans in flight: stage by stage
+    chained = in_flight == 1 if args.chained == "auto" else args.chained == "1"
     fleet = []
     for lane in range(in_flight):
         q = dp if lane == 0 else dp_setup(args.grid, local_rank, rank)[0]
+        q.set_chained_sweep(1 if chained else 0)
         envs = []
         for o in occs:
             e = tpl_amd.DynProgEnvironment(local_rank)
@@ -700,6 +703,21 @@ def worker(args):
         dp.plan_resident(fleet[0][1][k])
     alone_ms, alone_launches = dp.timing_get()
     dp.timing_enable(False)
+    # ... the same four plans with the OTHER launch form (chained <-> stage by stage), microseconds per stage sweep:
+    # `roofline.stage_us_by_launch_form`
+    dp.set_chained_sweep(0 if chained else 1)
+    for k in range(2):
+        dp.upload([starts[k]], path)
+        dp.plan_resident(fleet[0][1][k])
+    dp.sync()
+    other_form_chained = bool(dp.info()["chained_sweep"])
+    dp.timing_enable(True)
+    for k in range(4):
+        dp.upload([starts[k]], path)
+        dp.plan_resident(fleet[0][1][k])
+    form_ms, form_launches = dp.timing_get()
+    dp.timing_enable(False)
+    dp.set_chained_sweep(1 if chained else 0)
     # ... and the same kernel under the OTHER setting of rule R1 (one rounding per operation; a template variant with the same
     # division forms), same box, same minute: `roofline.launch_us_by_rule`.  Rank 0 only, outside the
     # timed region, on a planner of its own that is released before timing starts.
@@ -802,6 +820,9 @@ def worker(args):
                 "grid": [p.s_steps, p.v_steps, p.a_steps], "t_steps": p.t_steps,
                 "plans_per_step_per_gpu": plans_per_step, "ms_per_plan": elapsed / args.steps / plans_per_step * 1e3,
                 "plans_in_flight_per_gpu": in_flight,
+                # all stages of a plan behind the terminal one in ONE launch (tplhip_dp_lon_set_chained_sweep): the launch form of
+                # the timed region's plans -- chosen with one plan in flight, not with two
+                "chained_sweep": bool(dp.info()["chained_sweep"]) and chained,
                 # the HP-1 arithmetic contract the sweeps ran under (tplhip_dp_lon_info): R1 = 1 is nvcc's default
                 # contraction of the reference's device code, the best estimate of what the reference binary computes
                 "arithmetic": arithmetic_name(dp.info()),
@@ -817,8 +838,16 @@ def worker(args):
                 "launch_us": launch_s * 1e6,
                 # the kernel alone under both settings of rule R1 (HIP events, plans on one stream just before the timed region)
                 "launch_us_by_rule": {arithmetic_name(dp.info()).split(" ")[0]: alone_s * 1e6, other_rule_us[0]: other_rule_us[1]},
+                # microseconds per STAGE SWEEP of one plan at a time under both launch forms (HIP events around a plan's sweeps /
+                # its stages; a chained launch sweeps `stages_per_chained_launch` stages, which is what a kernel trace lists)
+                "stage_us_by_launch_form": {
+                    ("chained" if chained else "stage_by_stage"): alone_s * 1e6,
+                    ("stage_by_stage" if chained else ("chained" if other_form_chained else "stage_by_stage_again")):
+                        form_ms / max(1, form_launches) * 1e3},
+                "stages_per_chained_launch": max(0, p.t_steps - 2),
                 "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
-                "achieved_is": "algorithmic bytes per launch / the launch's HIP-event duration alone on the chip"
+                "achieved_is": ("algorithmic bytes of one stage sweep / (the HIP-event span of a plan's chained launch / its stages), alone on the chip"
+                                if chained else "algorithmic bytes per launch / the launch's HIP-event duration alone on the chip")
                                + ("" if in_flight == 1 else " (four plans on one stream just before the timed region)"),
                 # the whole timed region: with two plans in flight launches overlap for their whole life -- the events of a stream
                 # also span the waits behind the other stream's launches (`stream_us_per_launch`), and a trace lists start-to-end
@@ -972,6 +1001,9 @@ def main():
     ap.add_argument("--grid", default="target", help="target (256x128x64, default) | config2 | config4 | default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--chained", default="auto", choices=["auto", "0", "1"],
+                    help="chained sweep (all stages of a plan in one launch, DynProgLonPlanner.set_chained_sweep): auto = with "
+                         "one plan in flight (+8-10 %% there), not with two (-4 %%); 0 / 1 force it")
     ap.add_argument("--in-flight", type=int, default=None,
                     help=f"planners (streams) a step's plans are dealt to; 1 = every plan behind the previous one "
                          f"(default {PLANS_IN_FLIGHT}; 1 on config4, whose sweeps are 16 residency rounds deep and gain nothing)")

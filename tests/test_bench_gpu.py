@@ -50,6 +50,12 @@ def test_one_line_with_the_contract_fields():
     assert fl["effective_us_per_launch"] < 1.25 * rf["launch_us"]
     by_rule = rf["launch_us_by_rule"]                   # the kernel alone under both settings of R1, same box
     assert set(by_rule) == {"R1=1", "R1=0"} and all(20.0 < v < 80.0 for v in by_rule.values()), by_rule
+    # plans in flight are swept stage by stage; the same four plans one at a time under BOTH launch forms sit beside it
+    assert d["config"]["chained_sweep"] is False
+    forms = rf["stage_us_by_launch_form"]
+    assert set(forms) == {"stage_by_stage", "chained"} and all(20.0 < v < 80.0 for v in forms.values()), forms
+    assert forms["chained"] < 1.02 * forms["stage_by_stage"], forms
+    assert rf["stages_per_chained_launch"] == d["config"]["t_steps"] - 2
     # the arithmetic the sweeps ran under is named: the contracted default (nvcc's -fmad=true), rint weights, a -> v -> s
     assert d["config"]["arithmetic"].startswith("R1=1") and "R2=rint" in d["config"]["arithmetic"] and d["config"]["arithmetic"].endswith("avs")
     # every plan of the timed region had its own (obstacle set, start state) pair, and the last one per planner was checked
@@ -62,6 +68,10 @@ def test_one_plan_in_flight_keeps_the_per_launch_roofline():
     assert rf["in_flight"]["launches_in_flight"] == 1
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["launch_us"] * 1e-6) / 1e9) / rf["achieved"] < 1e-6
     assert abs(rf["launch_us"] - rf["in_flight"]["stream_us_per_launch"]) / rf["launch_us"] < 1e-9
+    # one plan at a time takes the chained launch (all stages of a plan in one launch); `launch_us` is then per STAGE SWEEP
+    assert d["config"]["chained_sweep"] is True and set(rf["stage_us_by_launch_form"]) == {"stage_by_stage", "chained"}
+    d0 = _bench({}, "--no-secondary", "--in-flight", "1", "--chained", "0")
+    assert d0["config"]["chained_sweep"] is False
 
 
 def test_collectives_run_through_rccl_with_one_rank():
