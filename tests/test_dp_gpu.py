@@ -913,10 +913,11 @@ def test_reeval_after_resident_plans_waits_for_their_rollouts():
 # Chained sweep (SweepChain in dp_lon_internal.h): the stages of a plan behind the terminal one in ONE launch
 # ------------------------------------------------------------------------------------------------------------------------
 CHAIN_CASES = [
-    pytest.param(256, 40, 52, 8, sc.OBSTACLES_OVERTAKE_TRAFFIC, None, id="rows-of-256-eight-stages"),
-    pytest.param(128, 64, 66, 7, sc.random_obstacles(9, 7), 0.4, id="s128-v64-dt_start"),
-    pytest.param(128, 37, 120, 5, sc.random_obstacles(5, 6), None, id="odd-v-steps"),
-    pytest.param(512, 8, 6, 6, sc.random_obstacles(7, 5), None, id="rows-of-512-on-a-small-grid"),
+    # (one residency round of workgroups per stage or more: 8 192 wavefronts on 256 compute units)
+    pytest.param(256, 64, 64, 7, sc.OBSTACLES_OVERTAKE_TRAFFIC, None, id="rows-of-256-seven-stages"),
+    pytest.param(128, 128, 64, 5, sc.random_obstacles(9, 7), 0.4, id="rows-of-128-dt_start"),
+    pytest.param(128, 65, 128, 5, sc.random_obstacles(5, 6), None, id="odd-v-steps"),
+    pytest.param(512, 64, 32, 5, sc.random_obstacles(7, 5), None, id="rows-of-512"),
 ]
 
 
@@ -950,7 +951,7 @@ def test_chained_sweep_is_on_request_for_plans_in_flight():
     """`plan_resident` (plans back to back, possibly beside another planner's) sweeps stage by stage unless asked:
     `set_chained_sweep(1)` chains those too.  Four plans with a new start state and obstacle set each, back to back on one
     planner, against the oracle's trajectories; the launch counter tells which form ran."""
-    S, V, A, T = 256, 40, 52, 6
+    S, V, A, T = 256, 64, 64, 5
     p = sc.lon_params(S, V, A, T)
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
     path = sc.straight_path(p.path_steps, p.path_step_size)
@@ -982,7 +983,7 @@ def test_a_chained_sweep_that_gives_up_fails_the_call_and_the_handle_recovers(mo
     fails loudly, and the handle sweeps stage by stage from then on.  TPLHIP_DEBUG=chain_fail_once makes the host read
     that flag as set once (the device side cannot be provoked: workgroups start in the order of their ids)."""
     monkeypatch.setenv("TPLHIP_DEBUG", "chain_fail_once")
-    S, V, A, T = 256, 40, 52, 5
+    S, V, A, T = 256, 64, 64, 5
     p = sc.lon_params(S, V, A, T)
     ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
     path = sc.straight_path(p.path_steps, p.path_step_size)
@@ -1001,3 +1002,21 @@ def test_a_chained_sweep_that_gives_up_fails_the_call_and_the_handle_recovers(mo
     assert dp.info()["chained_launches"] == 1
     _assert_tables_equal(dp, tables, T)
     assert np.array_equal(_traj_np(trajs[0]).view(np.uint32), otrajs[0].view(np.uint32))
+
+
+def test_a_stage_that_leaves_half_the_chip_empty_is_not_chained():
+    """Below one residency round of workgroups per stage the chained launch LOSES (the waiting workgroups of later stages take
+    the free slots and every stage runs packed on part of the chip: 256x40x52 14.2 -> 19.1 us per stage sweep), and rows that
+    are not whole cache lines cannot be chained at all: both sweep stage by stage, whatever the caller asks for."""
+    for S, V, A, T in ((256, 40, 52, 5), (300, 128, 64, 5)):
+        p = sc.lon_params(S, V, A, T)
+        ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+        env = tpl_amd.DynProgEnvironment()
+        env.reinit_buffers(ep)
+        env.set_occ_map(sc.occ_map(ep, sc.OBSTACLES_OVERTAKE))
+        dp = tpl_amd.DynProgLonPlanner()
+        dp.reinit_buffers(p)
+        dp.set_chained_sweep(1)
+        dp.update(sc.initial_state(0.0, 8.0, 0.0), sc.straight_path(p.path_steps, p.path_step_size), env)
+        info = dp.info()
+        assert info["sweep"] == "k_backward3v" and info["chained_sweep"] == 0 and info["chained_launches"] == 0, info

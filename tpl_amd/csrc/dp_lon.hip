@@ -158,6 +158,7 @@ struct tplhip_dp_lon {
     unsigned* d_chain_flags = nullptr;   // [t_steps][pairs]
     size_t chain_flags_cap = 0;
     unsigned* d_chain_err = nullptr;     // [0] a wait gave up, [1] workgroups whose dependencies overflow CHAIN_DEPS
+    unsigned* h_chain_err = nullptr;     // page-locked, device-mapped: set with d_chain_err[0], read by chain_check without a copy
     unsigned chain_epoch = 0;
     bool chain_unchecked = false;        // a chained launch went out since d_chain_err was last read
     unsigned long long chain_launches = 0, chain_failures = 0;
@@ -213,6 +214,8 @@ void free_planner_buffers(tplhip_dp_lon* h)
     (void)hipFree(h->d_chain_deps);  h->d_chain_deps = nullptr; h->chain_deps_cap = 0;
     (void)hipFree(h->d_chain_flags); h->d_chain_flags = nullptr; h->chain_flags_cap = 0;
     (void)hipFree(h->d_chain_err);   h->d_chain_err = nullptr;
+    if (h->h_chain_err) (void)hipHostFree(h->h_chain_err);
+    h->h_chain_err = nullptr;
     h->chain_ok = false;
     (void)hipFree(h->d_path);      h->d_path = nullptr;
     (void)hipFree(h->d_pre_vmax);  h->d_pre_vmax = nullptr;
@@ -351,6 +354,7 @@ bool launch_backward3(tplhip_dp_lon* h, int idx_t, int nx, int chain_stages = 0)
         a.chain.pairs = h->params.a_steps * ((h->params.v_steps + 1) / 2);
         a.chain.deps = h->d_chain_deps;
         a.chain.err = h->d_chain_err;
+        a.chain.err_host = h->h_chain_err;
         a.chain.table_cells = h->table_cells;
         a.chain.budget = 5000000;                   // 50 ms of the 100 MHz counter
         grid.y = (unsigned)chain_stages;
@@ -397,7 +401,7 @@ int sweep_kind(const tplhip_dp_lon* h)
 bool chain_plan(const tplhip_dp_lon* h, bool synchronous)
 {
     return h->chain_ok && !h->chain_broken && (h->chain_mode == 1 || (h->chain_mode < 0 && synchronous)) && sweep_kind(h) == 1
-           && h->rule.order == 0 && h->d_chain_deps && h->d_chain_flags && h->d_chain_err;
+           && h->rule.order == 0 && h->d_chain_deps && h->d_chain_flags && h->d_chain_err && h->h_chain_err;
 }
 
 void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
@@ -439,8 +443,9 @@ int chain_check(tplhip_dp_lon* h)
 {
     if (!h->chain_unchecked) return TPLHIP_OK;
     h->chain_unchecked = false;
-    unsigned err = 0;
-    HIP_TRY(hipMemcpy(&err, h->d_chain_err, sizeof err, hipMemcpyDeviceToHost), "reading the chained sweep's status failed");
+    // (the word is page-locked host memory the giving-up workgroup writes through its device mapping; every caller of this
+    // function has just waited for the stream the launch ran on)
+    unsigned err = __atomic_load_n(h->h_chain_err, __ATOMIC_ACQUIRE);
     if (h->chain_fail_once) { err = 1; h->chain_fail_once = false; }
 #ifdef TPL_CHAIN_STATS
     {
@@ -457,6 +462,7 @@ int chain_check(tplhip_dp_lon* h)
     h->chain_failures += 1;
     h->tables_valid = false;
     (void)hipMemset(h->d_chain_err, 0, sizeof(unsigned));
+    *h->h_chain_err = 0;
     return tplhip_fail(TPLHIP_EDEVICE, "chained sweep: a workgroup waited %d ms for a row of the stage before it and gave up; this plan's "
                        "result is not valid -- plan again (the handle sweeps stage by stage from now on)", 50);
 }
@@ -872,7 +878,12 @@ int build_action_tables(tplhip_dp_lon* h)
         // (not on stage tables beyond 96 MB: there the launch boundary is 1 % of a sweep and the write-through stores cost
         // 3 % -- 512x256x128: 325 -> 335 us, profiles/r06_dp_chained_sweep.txt)
         bool chain = h->chain_mode != 0 && !h->chain_broken && h->rule.order == 0 && ((size_t)p.s_steps * sizeof(Node)) % 128 == 0
-                     && p.t_steps >= 4 && h->table_cells * sizeof(Node) <= ((size_t)96 << 20);
+                     && p.t_steps >= 4 && h->table_cells * sizeof(Node) <= ((size_t)96 << 20)
+                     // ... and not where a stage leaves half the chip empty: the workgroups of the stages behind it, resident and
+                     // waiting, take the free slots, and every stage then runs packed on the compute units its turn found free
+                     // instead of spread over all of them (256x40x52: 14.2 -> 19.1 us per stage sweep; from one residency round
+                     // up the chained launch wins: 256x64x64 21.9 -> 20.3, 512x64x32 24.5 -> 22.0, 256x128x64 37.6 -> 34.3)
+                     && (size_t)h->v3_grid * (size_t)(h->vp_s_pad / 64) >= (size_t)h->n_cu * 32;
         if (chain) {
             const size_t nd = (size_t)h->v3_grid * CHAIN_DEPS, nf = (size_t)p.t_steps * pairs;
             if (nd > h->chain_deps_cap) {
@@ -885,6 +896,10 @@ int build_action_tables(tplhip_dp_lon* h)
                 if (chain) HIP_TRY(hipMemsetAsync(h->d_chain_flags, 0, sizeof(unsigned) * nf, h->stream), "flag reset failed");
             }
             if (chain && !h->d_chain_err && hipMalloc(&h->d_chain_err, 8 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); h->d_chain_err = nullptr; chain = false; }
+            if (chain && !h->h_chain_err) {
+                if (hipHostMalloc(&h->h_chain_err, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) *h->h_chain_err = 0;
+                else { (void)hipGetLastError(); h->h_chain_err = nullptr; chain = false; }
+            }
             if (chain) HIP_TRY(hipMemsetAsync(h->d_chain_err, 0, 8 * sizeof(unsigned), h->stream), "flag reset failed");
         }
         hipLaunchKernelGGL(k_fill_v3_map, dim3((h->v3_grid + 255) / 256), dim3(256), 0, h->stream, h->d_v3_map, h->v3_grid, h->d_acts,

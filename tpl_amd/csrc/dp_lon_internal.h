@@ -86,8 +86,8 @@ static_assert(sizeof(V3Map) == 16, "V3Map is one dwordx4");
 // SEVERAL dependent stages in ONE launch of k_backward3v (grid.y = stages, the latest first): no kernel boundary between two
 // sweeps, and the first workgroups of a stage run beside the last ones of the stage before.  Workgroups start in the order
 // of their linear id on every XCD (x fastest, then y; id & 7 = XCD since grid.x is a multiple of 8), so every workgroup a
-// waiting one depends on has already started -- and a wait that outlasts `budget` gives up, raises *err and lets the host
-// sweep the plan again stage by stage: no wave can wait for ever.  What a workgroup waits for: the row pairs of the next stage
+// waiting one depends on has already started -- and a wait that outlasts `budget` gives up and raises *err: the host discards
+// the plan and sweeps stage by stage from then on; no wave can wait for ever.  What a workgroup waits for: the row pairs of the next stage
 // its nine actions read (deps: up to CHAIN_DEPS flag indices per workgroup, -1 = none; k_fill_v3_map), each announced by
 // its writer -- node stores written THROUGH the XCD's L2 (sc1), completed, then flags[stage][pair] = epoch, all at agent
 // scope.  A reader's L2 cannot hold an older copy of such a row: rows are whole cache lines (the host chains only where a
@@ -100,7 +100,8 @@ struct SweepChain {
     int first = 0;             // stage index of blockIdx.y = 0
     int pairs = 0;
     const int* deps = nullptr; // [grid.x][CHAIN_DEPS]
-    unsigned* err = nullptr;   // device word: non-zero once a wait gave up
+    unsigned* err = nullptr;   // device word: non-zero once a wait gave up (what waiting workgroups look at)
+    unsigned* err_host = nullptr;   // the same news in page-locked host memory (what the host looks at: no copy per plan)
     size_t table_cells = 0;    // nodes per stage table
     long long budget = 0;      // s_memtime ticks a workgroup may wait
 };

@@ -60,6 +60,10 @@
 //    (256x128x64), 319.6 -> 350.3 (512x256x128), bit-identical.  The sweep is at its plateau for this decomposition.
 
 
+#ifndef TPL_CHAIN_SLEEP
+#define TPL_CHAIN_SLEEP 8      /* x 64 cycles between two polls of a chained sweep's wait (A/B'd: profiles/r06_dp_chained_sweep.txt) */
+#endif
+
 namespace tplhip {
 namespace {
 
@@ -344,10 +348,13 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                 const long long waited = (long long)wall_clock64() - t0;
                 if (waited > 1000 && (waited > a.chain.budget || __hip_atomic_load(a.chain.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                    if (is == 0) __hip_atomic_store(a.chain.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (is == 0) {
+                        __hip_atomic_store(a.chain.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.chain.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(TPL_CHAIN_SLEEP);
             }
 #ifdef TPL_CHAIN_STATS
             if (is == 0) {
