@@ -703,21 +703,25 @@ def worker(args):
         dp.plan_resident(fleet[0][1][k])
     alone_ms, alone_launches = dp.timing_get()
     dp.timing_enable(False)
+    chained_ran = chained and bool(dp.info()["chained_sweep"])       # (asked for AND this grid can be chained)
     # ... the same four plans with the OTHER launch form (chained <-> stage by stage), microseconds per stage sweep:
     # `roofline.stage_us_by_launch_form`
-    dp.set_chained_sweep(0 if chained else 1)
-    for k in range(2):
-        dp.upload([starts[k]], path)
-        dp.plan_resident(fleet[0][1][k])
-    dp.sync()
-    other_form_chained = bool(dp.info()["chained_sweep"])
-    dp.timing_enable(True)
-    for k in range(4):
-        dp.upload([starts[k]], path)
-        dp.plan_resident(fleet[0][1][k])
-    form_ms, form_launches = dp.timing_get()
-    dp.timing_enable(False)
-    dp.set_chained_sweep(1 if chained else 0)
+    # (--no-form-ab: skipped, for kernel traces -- both forms run the same kernel, and a trace's average would mix them)
+    form_ms, form_launches, other_form_chained = 0.0, 0, False
+    if not args.no_form_ab:
+        dp.set_chained_sweep(0 if chained_ran else 1)
+        for k in range(2):
+            dp.upload([starts[k]], path)
+            dp.plan_resident(fleet[0][1][k])
+        dp.sync()
+        other_form_chained = bool(dp.info()["chained_sweep"])
+        dp.timing_enable(True)
+        for k in range(4):
+            dp.upload([starts[k]], path)
+            dp.plan_resident(fleet[0][1][k])
+        form_ms, form_launches = dp.timing_get()
+        dp.timing_enable(False)
+        dp.set_chained_sweep(1 if chained else 0)
     # ... and the same kernel under the OTHER setting of rule R1 (one rounding per operation; a template variant with the same
     # division forms), same box, same minute: `roofline.launch_us_by_rule`.  Rank 0 only, outside the
     # timed region, on a planner of its own that is released before timing starts.
@@ -822,7 +826,7 @@ def worker(args):
                 "plans_in_flight_per_gpu": in_flight,
                 # all stages of a plan behind the terminal one in ONE launch (tplhip_dp_lon_set_chained_sweep): the launch form of
                 # the timed region's plans -- chosen with one plan in flight, not with two
-                "chained_sweep": bool(dp.info()["chained_sweep"]) and chained,
+                "chained_sweep": chained_ran,
                 # the HP-1 arithmetic contract the sweeps ran under (tplhip_dp_lon_info): R1 = 1 is nvcc's default
                 # contraction of the reference's device code, the best estimate of what the reference binary computes
                 "arithmetic": arithmetic_name(dp.info()),
@@ -840,14 +844,14 @@ def worker(args):
                 "launch_us_by_rule": {arithmetic_name(dp.info()).split(" ")[0]: alone_s * 1e6, other_rule_us[0]: other_rule_us[1]},
                 # microseconds per STAGE SWEEP of one plan at a time under both launch forms (HIP events around a plan's sweeps /
                 # its stages; a chained launch sweeps `stages_per_chained_launch` stages, which is what a kernel trace lists)
-                "stage_us_by_launch_form": {
-                    ("chained" if chained else "stage_by_stage"): alone_s * 1e6,
-                    ("stage_by_stage" if chained else ("chained" if other_form_chained else "stage_by_stage_again")):
-                        form_ms / max(1, form_launches) * 1e3},
+                "stage_us_by_launch_form": dict(
+                    [(("chained" if chained_ran else "stage_by_stage"), alone_s * 1e6)]
+                    + ([(("stage_by_stage" if chained_ran else ("chained" if other_form_chained else "stage_by_stage_again")),
+                         form_ms / max(1, form_launches) * 1e3)] if form_launches else [])),
                 "stages_per_chained_launch": max(0, p.t_steps - 2),
                 "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
                 "achieved_is": ("algorithmic bytes of one stage sweep / (the HIP-event span of a plan's chained launch / its stages), alone on the chip"
-                                if chained else "algorithmic bytes per launch / the launch's HIP-event duration alone on the chip")
+                                if chained_ran else "algorithmic bytes per launch / the launch's HIP-event duration alone on the chip")
                                + ("" if in_flight == 1 else " (four plans on one stream just before the timed region)"),
                 # the whole timed region: with two plans in flight launches overlap for their whole life -- the events of a stream
                 # also span the waits behind the other stream's launches (`stream_us_per_launch`), and a trace lists start-to-end
@@ -1004,6 +1008,7 @@ def main():
     ap.add_argument("--chained", default="auto", choices=["auto", "0", "1"],
                     help="chained sweep (all stages of a plan in one launch, DynProgLonPlanner.set_chained_sweep): auto = with "
                          "one plan in flight (+8-10 %% there), not with two (-4 %%); 0 / 1 force it")
+    ap.add_argument("--no-form-ab", action="store_true", help="skip the four plans under the other launch form (kernel traces)")
     ap.add_argument("--in-flight", type=int, default=None,
                     help=f"planners (streams) a step's plans are dealt to; 1 = every plan behind the previous one "
                          f"(default {PLANS_IN_FLIGHT}; 1 on config4, whose sweeps are 16 residency rounds deep and gain nothing)")

@@ -251,8 +251,9 @@ TPLHIP_API int tplhip_dp_lon_set_blend_order(tplhip_dp_lon* h, int order);
  * side LOSE 4 % with it (a waiting workgroup holds a slot the other plan could use), hence
  *   mode -1 (default): the synchronous calls (tplhip_dp_lon_update / _update_batch: one plan at a time by construction);
  *   mode  1: every plan of this handle, tplhip_dp_lon_plan_resident included;   mode 0: never.
- * Taken where the sweep is "k_backward3v" under the default blend order, a table row is a multiple of 128 bytes
- * (s_steps % 32 == 0), t_steps >= 4 and a stage table is at most 96 MB (beyond, the boundary is 1 % of a sweep)
+ * Taken where the sweep is "k_backward3v" under the default filter rule and blend order (either setting of R1), a table row
+ * is a multiple of 128 bytes (s_steps % 32 == 0), t_steps >= 4, a stage fills the chip at least once (workgroups x
+ * wavefronts >= 32 x compute units: below that the chained launch loses) and a stage table is at most 96 MB
  * (tplhip_dp_lon_info -> "chained_sweep": 0 no / 1 synchronous calls / 2 every plan, "chained_launches").  No wait is
  * unbounded: a workgroup that has waited 50 ms gives up and flags it, the call that hands out that plan's result fails with
  * TPLHIP_EDEVICE ("plan again") and the handle sweeps stage by stage from then on.  It cannot happen while workgroups start

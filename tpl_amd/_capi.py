@@ -263,7 +263,12 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C tpl_amd/csrc`. tpl_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    # (TPLHIP_LIB_PARTIAL=1, tuning only: an OLDER build named by TPLHIP_LIB may lack entry points declared since -- same-box
+    # A/Bs against it use what it has; calling a missing one raises AttributeError at the call)
+    partial = bool(os.environ.get("TPLHIP_LIB")) and os.environ.get("TPLHIP_LIB_PARTIAL") == "1"
     for name, (res, args) in SIGNATURES.items():
+        if partial and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args

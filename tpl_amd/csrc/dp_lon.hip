@@ -401,7 +401,7 @@ int sweep_kind(const tplhip_dp_lon* h)
 bool chain_plan(const tplhip_dp_lon* h, bool synchronous)
 {
     return h->chain_ok && !h->chain_broken && (h->chain_mode == 1 || (h->chain_mode < 0 && synchronous)) && sweep_kind(h) == 1
-           && h->rule.order == 0 && h->d_chain_deps && h->d_chain_flags && h->d_chain_err && h->h_chain_err;
+           && h->rule_all_forms && h->d_chain_deps && h->d_chain_flags && h->d_chain_err && h->h_chain_err;
 }
 
 void launch_stage(tplhip_dp_lon* h, int i, int nx, bool terminal)
@@ -873,11 +873,12 @@ int build_action_tables(tplhip_dp_lon* h)
     HIP_TRY(hipGetLastError(), "action table launch failed");
     h->chain_ok = false;
     if (h->d_v3_map) {
-        // chained sweep: where asked for, for the default blend order, rows of whole cache lines (SweepChain), three stages or more
+        // chained sweep: where asked for, for the default filter rule and blend order under either R1 (the instances dp_sweep.hip
+        // builds the chained form for), rows of whole cache lines (SweepChain), four stages or more
         const int pairs = p.a_steps * ((p.v_steps + 1) / 2);
         // (not on stage tables beyond 96 MB: there the launch boundary is 1 % of a sweep and the write-through stores cost
         // 3 % -- 512x256x128: 325 -> 335 us, profiles/r06_dp_chained_sweep.txt)
-        bool chain = h->chain_mode != 0 && !h->chain_broken && h->rule.order == 0 && ((size_t)p.s_steps * sizeof(Node)) % 128 == 0
+        bool chain = h->chain_mode != 0 && !h->chain_broken && h->rule_all_forms && ((size_t)p.s_steps * sizeof(Node)) % 128 == 0
                      && p.t_steps >= 4 && h->table_cells * sizeof(Node) <= ((size_t)96 << 20)
                      // ... and not where a stage leaves half the chip empty: the workgroups of the stages behind it, resident and
                      // waiting, take the free slots, and every stage then runs packed on the compute units its turn found free

@@ -169,7 +169,10 @@ __device__ __forceinline__ float s_weight(float fr)
 // i.e. eight waves per SIMD, which beat the two-buffer / one-barrier / loads-in-flight-across-the-barrier form
 // (68-70 registers, seven waves) by 2 % -- 42.1 against 42.9 us per 256x128x64 sweep on the same box.
 // ------------------------------------------------------------------------
-template <int PATH_DIV, int RANGE_DIV, int QUANT, int LERP>
+// CHAIN: the chained sweep (SweepChain, dp_lon_internal.h) -- a template parameter, not a run-time branch: with the branch in it
+// the plain launch ran 4-5 % slower on the same box (38.0-38.8 -> 39.9-40.9 us, profiles/r06_dp_chained_sweep.txt); built for the
+// default filter rule under both settings of R1.
+template <int PATH_DIV, int RANGE_DIV, int QUANT, int LERP, bool CHAIN = false>
 __global__ void __launch_bounds__(1024)
 k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, const ActDesc* __restrict__ acts,
               const float* __restrict__ path_all, const float* __restrict__ pre_vmax_all,
@@ -182,7 +185,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
     const int is = threadIdx.x;
     const int s_pad = a.s_pad;
     // blockIdx.y: the scenario of a batch, or -- chained sweep (SweepChain) -- how many stages behind the launch's first one
-    const bool chained = a.chain.stages != 0;
+    constexpr bool chained = CHAIN;
     const size_t scn = chained ? 0 : blockIdx.y;
     const int cstage = chained ? (int)blockIdx.y : 0;
     const size_t back = chained ? (size_t)cstage * a.chain.table_cells : 0;
@@ -1131,27 +1134,27 @@ k_backward3s(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
 
 namespace {
 
-template <int QUANT, int LERP, class Go>
+template <int QUANT, int LERP, bool CHAIN, class Go>
 bool pick_div_v(int path_div, int range_div, bool all_forms, Go go)
 {
-    if (path_div == 5 && range_div == 5) return go(k_backward3v<5, 5, QUANT, LERP>);
-    if (path_div == 0 && range_div == 0) return go(k_backward3v<0, 0, QUANT, LERP>);
+    if (path_div == 5 && range_div == 5) return go(k_backward3v<5, 5, QUANT, LERP, CHAIN>);
+    if (path_div == 0 && range_div == 0) return go(k_backward3v<0, 0, QUANT, LERP, CHAIN>);
     if constexpr (QUANT == 1 && (LERP & 3) == 0) {
         if (all_forms) {
-            if (path_div == 4 && range_div == 3) return go(k_backward3v<4, 3, QUANT, LERP>);
-            if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3, QUANT, LERP>);
-            if (path_div == 4 && range_div == 4) return go(k_backward3v<4, 4, QUANT, LERP>);
-            if (path_div == 3 && range_div == 4) return go(k_backward3v<3, 4, QUANT, LERP>);
-            if (path_div == 4 && range_div == 5) return go(k_backward3v<4, 5, QUANT, LERP>);
-            if (path_div == 3 && range_div == 5) return go(k_backward3v<3, 5, QUANT, LERP>);
-            if (path_div == 5 && range_div == 3) return go(k_backward3v<5, 3, QUANT, LERP>);
-            if (path_div == 5 && range_div == 4) return go(k_backward3v<5, 4, QUANT, LERP>);
-            if (path_div == 4 && range_div == 0) return go(k_backward3v<4, 0, QUANT, LERP>);
-            if (path_div == 3 && range_div == 0) return go(k_backward3v<3, 0, QUANT, LERP>);
-            if (path_div == 5 && range_div == 0) return go(k_backward3v<5, 0, QUANT, LERP>);
-            if (path_div == 0 && range_div == 3) return go(k_backward3v<0, 3, QUANT, LERP>);
-            if (path_div == 0 && range_div == 4) return go(k_backward3v<0, 4, QUANT, LERP>);
-            if (path_div == 0 && range_div == 5) return go(k_backward3v<0, 5, QUANT, LERP>);
+            if (path_div == 4 && range_div == 3) return go(k_backward3v<4, 3, QUANT, LERP, CHAIN>);
+            if (path_div == 3 && range_div == 3) return go(k_backward3v<3, 3, QUANT, LERP, CHAIN>);
+            if (path_div == 4 && range_div == 4) return go(k_backward3v<4, 4, QUANT, LERP, CHAIN>);
+            if (path_div == 3 && range_div == 4) return go(k_backward3v<3, 4, QUANT, LERP, CHAIN>);
+            if (path_div == 4 && range_div == 5) return go(k_backward3v<4, 5, QUANT, LERP, CHAIN>);
+            if (path_div == 3 && range_div == 5) return go(k_backward3v<3, 5, QUANT, LERP, CHAIN>);
+            if (path_div == 5 && range_div == 3) return go(k_backward3v<5, 3, QUANT, LERP, CHAIN>);
+            if (path_div == 5 && range_div == 4) return go(k_backward3v<5, 4, QUANT, LERP, CHAIN>);
+            if (path_div == 4 && range_div == 0) return go(k_backward3v<4, 0, QUANT, LERP, CHAIN>);
+            if (path_div == 3 && range_div == 0) return go(k_backward3v<3, 0, QUANT, LERP, CHAIN>);
+            if (path_div == 5 && range_div == 0) return go(k_backward3v<5, 0, QUANT, LERP, CHAIN>);
+            if (path_div == 0 && range_div == 3) return go(k_backward3v<0, 3, QUANT, LERP, CHAIN>);
+            if (path_div == 0 && range_div == 4) return go(k_backward3v<0, 4, QUANT, LERP, CHAIN>);
+            if (path_div == 0 && range_div == 5) return go(k_backward3v<0, 5, QUANT, LERP, CHAIN>);
         }
     }
     return false;
@@ -1191,7 +1194,12 @@ bool launch_v_rule(int path_div, int range_div, const SweepArgs& a, dim3 grid, s
         hipLaunchKernelGGL(kernel, grid, dim3(a.s_pad), lds_bytes, stream, a.next, a.out, a.acts, a.path, a.pre_vmax, a.pre_sdist, a.pre_prog, a);
         return true;
     };
-    return pick_div_v<QUANT, LERP>(path_div, range_div, true, go);
+    if (a.chain.stages != 0) {
+        // (the chained form exists for the default filter rule only: dp_lon.hip asks for it under nothing else)
+        if constexpr (QUANT == 1 && (LERP & 3) == 0) return pick_div_v<QUANT, LERP, true>(path_div, range_div, true, go);
+        else return false;
+    }
+    return pick_div_v<QUANT, LERP, false>(path_div, range_div, true, go);
 }
 
 template <int QUANT, int LERP>
