@@ -356,7 +356,8 @@ bool launch_backward3(tplhip_dp_lon* h, int idx_t, int nx, int chain_stages = 0)
         a.chain.err = h->d_chain_err;
         a.chain.err_host = h->h_chain_err;
         a.chain.table_cells = h->table_cells;
-        a.chain.budget = 5000000;                   // 50 ms of the 100 MHz counter
+        a.chain.budget = 100000000;                 // 1 s of the 100 MHz counter: three orders of magnitude above any wait seen (a
+                                                    // plan of this size takes 2 ms), short of every watchdog
         grid.y = (unsigned)chain_stages;
     }
     return launch_backward3v(h->rule, h->path_div3, h->range_div3, a, grid, backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
@@ -463,8 +464,8 @@ int chain_check(tplhip_dp_lon* h)
     h->tables_valid = false;
     (void)hipMemset(h->d_chain_err, 0, sizeof(unsigned));
     *h->h_chain_err = 0;
-    return tplhip_fail(TPLHIP_EDEVICE, "chained sweep: a workgroup waited %d ms for a row of the stage before it and gave up; this plan's "
-                       "result is not valid -- plan again (the handle sweeps stage by stage from now on)", 50);
+    return tplhip_fail(TPLHIP_EDEVICE, "chained sweep: a workgroup waited a second for a row of the stage before it and gave up; this plan's "
+                       "result is not valid -- plan again (the handle sweeps stage by stage from now on)");
 }
 
 int enqueue_plan(tplhip_dp_lon* h, tplhip_dp_env* env, bool overlap, TplLonState* mirror = nullptr,
