@@ -91,7 +91,7 @@ def run_case(seed, rules=False, orders=False):
         got = np.array([[s.t, s.s, s.v, s.a, s.j, s.cost, s.constr] for s in tr.states], dtype=np.float32)
         assert np.array_equal(got.view(np.uint32), otrajs[r].view(np.uint32)), f"seed {seed}: trajectory {r}"
     info = dp.info()
-    return info["sweep"]
+    return info["sweep"] + (" (chained)" if info.get("chained_launches", 0) else "")
 
 
 def main():

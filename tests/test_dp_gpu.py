@@ -1020,3 +1020,34 @@ def test_a_stage_that_leaves_half_the_chip_empty_is_not_chained():
         dp.update(sc.initial_state(0.0, 8.0, 0.0), sc.straight_path(p.path_steps, p.path_step_size), env)
         info = dp.info()
         assert info["sweep"] == "k_backward3v" and info["chained_sweep"] == 0 and info["chained_launches"] == 0, info
+
+
+@pytest.mark.parametrize("debug,path_step", [("big=1,chain_any", 0.7), ("big=1,chain_any", 1.3), ("big=1,chain_any,no_fastdiv", 1.0), ("big=1,chain_any,skew=1", 2.0)])
+def test_chained_sweep_under_every_division_form(debug, path_step, monkeypatch):
+    """The chained form is a template instance per pair of division forms (reciprocal pair, Newton step, IEEE): a path step that is
+    not a power of two / `no_fastdiv` select them, `big=1,chain_any` put a grid the oracle sweeps whole on the chained large-grid
+    kernel; R1 = 0 as well (the other family of instances).  Every stage table against the oracle."""
+    monkeypatch.setenv("TPLHIP_DEBUG", debug)
+    S, V, A, T = 128, 21, 14, 6
+    for fma in (1, 0):
+        p = sc.lon_params(S, V, A, T)
+        p.path_step_size = path_step
+        p.path_steps = int(np.ceil(p.s_max / path_step)) + 5
+        ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+        path = sc.straight_path(p.path_steps, p.path_step_size)
+        occ = sc.occ_map(ep, sc.random_obstacles(12, 6))
+        inits = [sc.initial_state(0.0, 8.0, 0.0)] + sc.random_initial_states(2, seed=3)
+        env = tpl_amd.DynProgEnvironment()
+        env.reinit_buffers(ep)
+        env.set_occ_map(occ)
+        dp = tpl_amd.DynProgLonPlanner()
+        dp.reinit_buffers(p)
+        dp.set_contraction(bool(fma))
+        trajs = dp.update_batch(inits, path, env)
+        with O.rule(fma=fma):
+            tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, inits)
+        info = dp.info()
+        assert info["sweep"] == "k_backward3v" and info["chained_launches"] == 1, info
+        _assert_tables_equal(dp, tables, T)
+        for r, tr in enumerate(trajs):
+            assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (fma, r)

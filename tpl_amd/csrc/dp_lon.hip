@@ -150,6 +150,7 @@ struct tplhip_dp_lon {
     size_t v3_map_cap = 0;
     // chained sweep (SweepChain, dp_lon_internal.h): all stages of a plan behind the terminal one in ONE launch of k_backward3v
     int chain_mode = -1;                 // tplhip_dp_lon_set_chained_sweep: -1 the synchronous calls only (default), 0 never, 1 every plan
+    bool chain_any = false;              // TPLHIP_DEBUG=chain_any: no minimum grid size for the chained launch
     bool chain_fail_once = false;        // TPLHIP_DEBUG=chain_fail_once: the next status read reports a wait that gave up (tests)
     bool chain_ok = false;               // this grid and rule can be chained (set by reinit / apply_rule)
     bool chain_broken = false;           // a wait gave up once: never again on this handle
@@ -885,7 +886,7 @@ int build_action_tables(tplhip_dp_lon* h)
                      // waiting, take the free slots, and every stage then runs packed on the compute units its turn found free
                      // instead of spread over all of them (256x40x52: 14.2 -> 19.1 us per stage sweep; from one residency round
                      // up the chained launch wins: 256x64x64 21.9 -> 20.3, 512x64x32 24.5 -> 22.0, 256x128x64 37.6 -> 34.3)
-                     && (size_t)h->v3_grid * (size_t)(h->vp_s_pad / 64) >= (size_t)h->n_cu * 32;
+                     && ((size_t)h->v3_grid * (size_t)(h->vp_s_pad / 64) >= (size_t)h->n_cu * 32 || h->chain_any);
         if (chain) {
             const size_t nd = (size_t)h->v3_grid * CHAIN_DEPS, nf = (size_t)p.t_steps * pairs;
             if (nd > h->chain_deps_cap) {
@@ -1045,6 +1046,7 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         int m = 0;
         if (debug_opt("chain", &m)) h->chain_mode = m != 0 ? 1 : 0;          // TPLHIP_DEBUG=chain=1 | chain=0
         h->chain_fail_once = debug_opt("chain_fail_once");
+        h->chain_any = debug_opt("chain_any");               // tests / fuzzing: chain grids of any size (the bits do not depend on it)
     }
     // "bounded": every float parameter finite and < 1e6 in magnitude, at most 1e5 stages.  Then no
     // cost or constraint sum of the sweep can overflow (largest single term ~ w * (1e6)^2 = 1e18, at
