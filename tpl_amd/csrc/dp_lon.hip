@@ -347,6 +347,7 @@ bool launch_backward3(tplhip_dp_lon* h, int idx_t, int nx, int chain_stages = 0)
     a.stride_tables = 0; a.stride_pre = 0; a.stride_path = 0;
     dim3 grid(h->v3_grid, 1);
     if (chain_stages > 0) {
+        if (!a.tile_map) return false;              // (a chained workgroup takes its first rows from the traversal entry, behind its wait)
         // stages idx_t, idx_t - 1, ... in ONE launch (SweepChain): grid.y = stage, the latest first
         a.chain.stages = chain_stages;
         a.chain.epoch = ++h->chain_epoch;
