@@ -694,17 +694,21 @@ def worker(args):
     assert len(set(want.values())) > len(want) // 2, "the deck's plans are (nearly) all the same: inputs are not varied"
     run(args.warmup)
     sync_all()
-    # the sweep kernel ALONE on the chip (one plan at a time on one stream, the deck's first four pairs): the launch
+    # the sweep kernel ALONE on the chip (one plan at a time on one stream, six plans behind two untimed ones): the launch
     # duration the roofline's per-launch figures are quoted on -- with two plans in flight a launch shares the chip and
     # its duration says little by itself
-    dp.timing_enable(True)
-    for k in range(4):
+    for k in range(2):                                  # (one plan at a time from here on: two untimed ones first)
         dp.upload([starts[k]], path)
         dp.plan_resident(fleet[0][1][k])
+    dp.sync()
+    dp.timing_enable(True)
+    for k in range(6):
+        dp.upload([starts[k]], path)
+        dp.plan_resident(fleet[0][1][k % len(fleet[0][1])])
     alone_ms, alone_launches = dp.timing_get()
     dp.timing_enable(False)
     chained_ran = chained and bool(dp.info()["chained_sweep"])       # (asked for AND this grid can be chained)
-    # ... the same four plans with the OTHER launch form (chained <-> stage by stage), microseconds per stage sweep:
+    # ... the same six plans with the OTHER launch form (chained <-> stage by stage), microseconds per stage sweep:
     # `roofline.stage_us_by_launch_form`
     # (--no-form-ab: skipped, for kernel traces -- both forms run the same kernel, and a trace's average would mix them)
     form_ms, form_launches, other_form_chained = 0.0, 0, False
@@ -716,9 +720,9 @@ def worker(args):
         dp.sync()
         other_form_chained = bool(dp.info()["chained_sweep"])
         dp.timing_enable(True)
-        for k in range(4):
+        for k in range(6):
             dp.upload([starts[k]], path)
-            dp.plan_resident(fleet[0][1][k])
+            dp.plan_resident(fleet[0][1][k % len(fleet[0][1])])
         form_ms, form_launches = dp.timing_get()
         dp.timing_enable(False)
         dp.set_chained_sweep(1 if chained else 0)
@@ -729,14 +733,14 @@ def worker(args):
     if rank == 0:
         q0 = dp_setup(args.grid, local_rank, rank)[0]
         q0.set_contraction(not bool(dp.info()["rule"]["fma"]))
-        for k in range(2):                              # (both table sets of the back-to-back mode touched before timing)
+        for k in range(4):                              # (both table sets of the back-to-back mode touched before timing)
             q0.upload([starts[k]], path)
             q0.plan_resident(fleet[0][1][k])
         q0.sync()
         q0.timing_enable(True)
-        for k in range(4):
+        for k in range(6):
             q0.upload([starts[k]], path)
-            q0.plan_resident(fleet[0][1][k])
+            q0.plan_resident(fleet[0][1][k % len(fleet[0][1])])
         ms0, n0 = q0.timing_get()
         other_rule_us = (arithmetic_name(q0.info()).split(" ")[0], ms0 / max(1, n0) * 1e3)
         del q0
@@ -852,7 +856,7 @@ def worker(args):
                 "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
                 "achieved_is": ("algorithmic bytes of one stage sweep / (the HIP-event span of a plan's chained launch / its stages), alone on the chip"
                                 if chained_ran else "algorithmic bytes per launch / the launch's HIP-event duration alone on the chip")
-                               + ("" if in_flight == 1 else " (four plans on one stream just before the timed region)"),
+                               + ("" if in_flight == 1 else " (six plans on one stream just before the timed region)"),
                 # the whole timed region: with two plans in flight launches overlap for their whole life -- the events of a stream
                 # also span the waits behind the other stream's launches (`stream_us_per_launch`), and a trace lists start-to-end
                 # durations of launches that share the chip (profiles/README.md); the chip's rate is the bytes of ALL the rank's
@@ -1008,7 +1012,7 @@ def main():
     ap.add_argument("--chained", default="auto", choices=["auto", "0", "1"],
                     help="chained sweep (all stages of a plan in one launch, DynProgLonPlanner.set_chained_sweep): auto = with "
                          "one plan in flight (+8-10 %% there), not with two (-4 %%); 0 / 1 force it")
-    ap.add_argument("--no-form-ab", action="store_true", help="skip the four plans under the other launch form (kernel traces)")
+    ap.add_argument("--no-form-ab", action="store_true", help="skip the six plans under the other launch form (kernel traces)")
     ap.add_argument("--in-flight", type=int, default=None,
                     help=f"planners (streams) a step's plans are dealt to; 1 = every plan behind the previous one "
                          f"(default {PLANS_IN_FLIGHT}; 1 on config4, whose sweeps are 16 residency rounds deep and gain nothing)")

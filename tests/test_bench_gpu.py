@@ -50,7 +50,7 @@ def test_one_line_with_the_contract_fields():
     assert fl["effective_us_per_launch"] < 1.25 * rf["launch_us"]
     by_rule = rf["launch_us_by_rule"]                   # the kernel alone under both settings of R1, same box
     assert set(by_rule) == {"R1=1", "R1=0"} and all(20.0 < v < 80.0 for v in by_rule.values()), by_rule
-    # plans in flight are swept stage by stage; the same four plans one at a time under BOTH launch forms sit beside it
+    # plans in flight are swept stage by stage; the same six plans one at a time under BOTH launch forms sit beside it
     assert d["config"]["chained_sweep"] is False
     forms = rf["stage_us_by_launch_form"]
     assert set(forms) == {"stage_by_stage", "chained"} and all(20.0 < v < 80.0 for v in forms.values()), forms
