@@ -1051,3 +1051,31 @@ def test_chained_sweep_under_every_division_form(debug, path_step, monkeypatch):
         _assert_tables_equal(dp, tables, T)
         for r, tr in enumerate(trajs):
             assert np.array_equal(_traj_np(tr).view(np.uint32), otrajs[r].view(np.uint32)), (fma, r)
+
+
+def test_a_chained_launch_whose_flags_never_come_drains_and_is_reported(monkeypatch):
+    """The device side of the same safety net: under TPLHIP_DEBUG=chain_stall the workgroups of the next chained launch wait for
+    flag values nobody writes.  Every one of them gives up (after 20 us of the 100 MHz counter, or at once when it sees that
+    another has), the launch drains, the status word in page-locked memory says so, the call fails, and the next plan -- swept
+    stage by stage -- matches the oracle."""
+    monkeypatch.setenv("TPLHIP_DEBUG", "chain_stall")
+    S, V, A, T = 256, 64, 64, 5
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    occ = sc.occ_map(ep, sc.OBSTACLES_OVERTAKE)
+    inits = [sc.initial_state(0.0, 8.0, 0.0)]
+    env = tpl_amd.DynProgEnvironment()
+    env.reinit_buffers(ep)
+    env.set_occ_map(occ)
+    dp = tpl_amd.DynProgLonPlanner()
+    dp.reinit_buffers(p)
+    with pytest.raises(RuntimeError, match="plan again"):
+        dp.update_batch(inits, path, env)
+    info = dp.info()
+    assert info["chained_launches"] == 1 and info["chained_sweep"] == 0, info
+    trajs = dp.update_batch(inits, path, env)
+    tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, inits)
+    assert dp.info()["chained_launches"] == 1
+    _assert_tables_equal(dp, tables, T)
+    assert np.array_equal(_traj_np(trajs[0]).view(np.uint32), otrajs[0].view(np.uint32))

@@ -151,6 +151,7 @@ struct tplhip_dp_lon {
     // chained sweep (SweepChain, dp_lon_internal.h): all stages of a plan behind the terminal one in ONE launch of k_backward3v
     int chain_mode = -1;                 // tplhip_dp_lon_set_chained_sweep: -1 the synchronous calls only (default), 0 never, 1 every plan
     bool chain_any = false;              // TPLHIP_DEBUG=chain_any: no minimum grid size for the chained launch
+    bool chain_stall = false;            // TPLHIP_DEBUG=chain_stall: the next chained launch waits for flags nobody writes (tests)
     bool chain_fail_once = false;        // TPLHIP_DEBUG=chain_fail_once: the next status read reports a wait that gave up (tests)
     bool chain_ok = false;               // this grid and rule can be chained (set by reinit / apply_rule)
     bool chain_broken = false;           // a wait gave up once: never again on this handle
@@ -351,6 +352,7 @@ bool launch_backward3(tplhip_dp_lon* h, int idx_t, int nx, int chain_stages = 0)
         // stages idx_t, idx_t - 1, ... in ONE launch (SweepChain): grid.y = stage, the latest first
         a.chain.stages = chain_stages;
         a.chain.epoch = ++h->chain_epoch;
+        a.chain.wait_epoch = a.chain.epoch;
         a.chain.flags = h->d_chain_flags;
         a.chain.first = idx_t;
         a.chain.pairs = h->params.a_steps * ((h->params.v_steps + 1) / 2);
@@ -360,6 +362,13 @@ bool launch_backward3(tplhip_dp_lon* h, int idx_t, int nx, int chain_stages = 0)
         a.chain.table_cells = h->table_cells;
         a.chain.budget = 100000000;                 // 1 s of the 100 MHz counter: three orders of magnitude above any wait seen (a
                                                     // plan of this size takes 2 ms), short of every watchdog
+        if (h->chain_stall) {
+            // (tests: the flags every waiting workgroup looks for are never written -- each gives up after 20 us of the
+            // counter or as soon as it sees that another has: the device side of chain_check's failure path)
+            a.chain.wait_epoch = a.chain.epoch + 0x40000000u;
+            a.chain.budget = 2000;
+            h->chain_stall = false;
+        }
         grid.y = (unsigned)chain_stages;
     }
     return launch_backward3v(h->rule, h->path_div3, h->range_div3, a, grid, backward3v_lds_bytes(h->vp_s_pad, h->params.path_steps), h->stream);
@@ -1047,6 +1056,7 @@ int tplhip_dp_lon_reinit(tplhip_dp_lon* h, TplDpLonParams* ps)
         int m = 0;
         if (debug_opt("chain", &m)) h->chain_mode = m != 0 ? 1 : 0;          // TPLHIP_DEBUG=chain=1 | chain=0
         h->chain_fail_once = debug_opt("chain_fail_once");
+        h->chain_stall = debug_opt("chain_stall");
         h->chain_any = debug_opt("chain_any");               // tests / fuzzing: chain grids of any size (the bits do not depend on it)
     }
     // "bounded": every float parameter finite and < 1e6 in magnitude, at most 1e5 stages.  Then no

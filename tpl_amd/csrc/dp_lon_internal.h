@@ -96,6 +96,7 @@ constexpr int CHAIN_DEPS = 64;
 struct SweepChain {
     int stages = 0;            // 0: a plain launch (blockIdx.y = scenario)
     unsigned epoch = 0;        // this launch's value of a set flag
+    unsigned wait_epoch = 0;   // what a waiting workgroup looks for: `epoch` (TPLHIP_DEBUG=chain_stall: a value nobody writes -- tests)
     unsigned* flags = nullptr; // [t_steps][pairs], pairs = a_steps * ((v_steps + 1) / 2)
     int first = 0;             // stage index of blockIdx.y = 0
     int pairs = 0;

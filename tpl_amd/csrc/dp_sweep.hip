@@ -347,7 +347,7 @@ k_backward3v(const Node* __restrict__ next_all, Node* __restrict__ out_all, cons
             const unsigned* fl = a.chain.flags + (size_t)(a.chain.first - cstage + 1) * a.chain.pairs;
             const long long t0 = (long long)wall_clock64();
             for (;;) {
-                const bool ok = dep < 0 || __hip_atomic_load(fl + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.chain.epoch;
+                const bool ok = dep < 0 || __hip_atomic_load(fl + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.chain.wait_epoch;
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                 const long long waited = (long long)wall_clock64() - t0;
                 if (waited > 1000 && (waited > a.chain.budget || __hip_atomic_load(a.chain.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
