@@ -943,7 +943,11 @@ def worker(args):
                 out["roofline"]["ilqr"]["cpu_baseline"] = il["cpu_baseline"]
             if "plan_latency" in secondary:
                 pl = secondary["plan_latency"]
-                lat = {"dp_default_grid": pl["dp_default_plan"]["p50_ms"], "mpc_tick": pl["mpc_closed_loop"]["p50_ms"],
+                lat = {"dp_default_grid": pl["dp_default_plan"]["p50_ms"],
+                       # update() on the headline grid: the call's default (chained sweep) and the same call stage by stage
+                       "dp_target_grid": pl["dp_target_plan"]["p50_ms"],
+                       "dp_target_grid_stage_by_stage": pl["dp_target_plan"]["p50_ms_stage_by_stage"],
+                       "mpc_tick": pl["mpc_closed_loop"]["p50_ms"],
                        "env_update": pl["env_update"]["p50_ms"], "poly_lat_update": pl["poly_lat_update"]["p50_ms"],
                        "lat_lon_update": pl["lat_lon_update"]["p50_ms"],
                        "what": "p50 wall time of one call through the drop-in surface, host buffers in and out (benchkit/latency.py); "

@@ -61,6 +61,39 @@ def dp_default_plan(device=0, plans=60):
                     "host path in, host trajectory out"}
 
 
+def dp_target_plan(device=0, plans=20):
+    """`DynProgLonPlanner.update` on the headline grid (256 x 128 x 64, 50 stages), one plan at a time through the drop-in
+    surface: the call takes the chained sweep by default (all stages of the plan in one launch); the same call with
+    `set_chained_sweep(0)` beside it."""
+    import tpl_amd
+    from . import scenarios as sc
+    S, V, A, T = sc.GRIDS["target"]
+    p = sc.lon_params(S, V, A, T)
+    ep = sc.env_params(t_steps=T, s_steps=201, l_steps=31)
+    path = sc.straight_path(p.path_steps, p.path_step_size)
+    env = tpl_amd.DynProgEnvironment(device)
+    env.reinit_buffers(ep)
+    env.set_occ_map(sc.occ_map(ep, sc.OBSTACLES_OVERTAKE_TRAFFIC))
+    dp = tpl_amd.DynProgLonPlanner(device)
+    dp.reinit_buffers(p)
+    init = sc.initial_state(0.0, 8.0, 0.0)
+    out = {}
+    for rnd in range(2):                                # (the two forms in turn, twice: the better median of each)
+        for name, mode in (("chained", -1), ("stage_by_stage", 0)):
+            dp.set_chained_sweep(mode)
+            lat = []
+            for k in range(plans):
+                t0 = time.perf_counter()
+                dp.update(init, path, env)
+                lat.append((time.perf_counter() - t0) * 1e3)
+            out[name] = min(out.get(name, 1e9), float(np.percentile(np.array(lat[4:]), 50)))
+            out[name + "_ran"] = bool(dp.info()["chained_sweep"])
+    return {"p50_ms": out["chained"], "p50_ms_stage_by_stage": out["stage_by_stage"], "chained_sweep": out["chained_ran"],
+            "plans": 2 * (plans - 4),
+            "what": "DynProgLonPlanner.update on 256x128x64, 50 stages, host path in, host trajectory out; the default (all "
+                    "stages of the plan in one chained launch) and set_chained_sweep(0)"}
+
+
 def env_update(device=0, updates=60, n_objects=10):
     """The occupancy pipeline as dp_env.py:128-170 drives it per planning cycle:
     reinit_buffers + set_ref_line + insert_geometry per predicted object + update()."""
@@ -186,7 +219,7 @@ def planner_cycles(device=0, cycles=80):
 
 
 def run(device=0):
-    res = {"mpc_closed_loop": mpc_closed_loop(device), "dp_default_plan": dp_default_plan(device),
+    res = {"mpc_closed_loop": mpc_closed_loop(device), "dp_default_plan": dp_default_plan(device), "dp_target_plan": dp_target_plan(device),
            "env_update": env_update(device), "poly_lat_update": poly_lat_update(device),
            "lat_lon_update": lat_lon_update(device)}
     res.update(planner_cycles(device))

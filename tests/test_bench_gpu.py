@@ -88,6 +88,8 @@ def test_collectives_run_through_rccl_with_one_rank():
     assert il["kernel"].startswith("k_ilqr") and il["ms_per_update"] > 0
     lat = d["config"]["p50_plan_latency_ms"]
     assert lat["dp_default_grid"] > 0 and lat["mpc_tick"] > 0
+    # update() on the headline grid takes the chained sweep by default: not slower than the same call stage by stage
+    assert 0.5 < lat["dp_target_grid"] < 1.05 * lat["dp_target_grid_stage_by_stage"] < 10.0, lat
 
 
 def test_two_ranks_on_one_device_rehearsal():
