@@ -1015,7 +1015,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--chained", default="auto", choices=["auto", "0", "1"],
                     help="chained sweep (all stages of a plan in one launch, DynProgLonPlanner.set_chained_sweep): auto = with "
-                         "one plan in flight (+8-10 %% there), not with two (-4 %%); 0 / 1 force it")
+                         "one plan in flight (+7-10 %% sweeps/s there), not with two (-4 %%); 0 / 1 force it")
     ap.add_argument("--no-form-ab", action="store_true", help="skip the six plans under the other launch form (kernel traces)")
     ap.add_argument("--in-flight", type=int, default=None,
                     help=f"planners (streams) a step's plans are dealt to; 1 = every plan behind the previous one "

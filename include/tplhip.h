@@ -246,8 +246,8 @@ TPLHIP_API int tplhip_dp_lon_set_blend_order(tplhip_dp_lon* h, int order);
 /* Chained sweep (round 6): the stages of one plan behind the terminal one -- the reference's loop of lonBackwardStep launches,
  * lon_planner.cu:347-361, with a device-wide wait after each -- in ONE launch of the two-rows-per-lane sweep.  A workgroup of
  * stage t waits for the row pairs of stage t + 1 its nine actions read (flags at agent scope; the writers store their nodes
- * through the XCD's L2); no kernel boundary between two stages: 256x128x64 one plan at a time 38-40 -> 35-37 us per stage
- * sweep, 25.7 -> 28.3 k sweeps/s; same bits (tests/test_dp_gpu.py::test_chained_sweep...).  Two planners kept busy side by
+ * through the XCD's L2); no kernel boundary between two stages: 256x128x64 one plan at a time 35-40 -> 34-37 us per stage
+ * sweep (by box: what varies is the cost of a boundary), 27.4 -> 29.2 k sweeps/s; same bits (tests/test_dp_gpu.py::test_chained_sweep...).  Two planners kept busy side by
  * side LOSE 4 % with it (a waiting workgroup holds a slot the other plan could use), hence
  *   mode -1 (default): the synchronous calls (tplhip_dp_lon_update / _update_batch: one plan at a time by construction);
  *   mode  1: every plan of this handle, tplhip_dp_lon_plan_resident included;   mode 0: never.

@@ -409,7 +409,7 @@ int sweep_kind(const tplhip_dp_lon* h)
 
 // does a plan of this handle sweep its stages in one chained launch?
 // (synchronous: the call returns with the plan -- one plan at a time on this handle by construction, where the chained launch
-// wins 8-10 %; a caller that keeps several planners busy through plan_resident loses 4 % with it and gets it only on request)
+// wins 4-10 %; a caller that keeps several planners busy through plan_resident loses 4 % with it and gets it only on request)
 bool chain_plan(const tplhip_dp_lon* h, bool synchronous)
 {
     return h->chain_ok && !h->chain_broken && (h->chain_mode == 1 || (h->chain_mode < 0 && synchronous)) && sweep_kind(h) == 1
