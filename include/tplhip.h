@@ -262,7 +262,8 @@ TPLHIP_API int tplhip_dp_lon_set_chained_sweep(tplhip_dp_lon* h, int mode);
 /* Diagnostics, host only (works without a GPU): 1 if a plain-fp32 sweep instance is built for this arithmetic rule and this
  * pair of division forms (4 = one multiplication, 3 = two-float reciprocal, 5 = reciprocal + Newton step, 0 = IEEE division),
  * else 0.  kind 1 = the two-rows-per-lane sweep (k_backward3v; k_backward3o when order != 0), 2 = one cell per lane
- * (k_backward3s).  The planner only ever selects built combinations (tests/test_capi.py walks them all); should that ever
+ * (k_backward3s), 3 = the chained form of k_backward3v (tplhip_dp_lon_set_chained_sweep: the default filter rule and blend order
+ * under either R1).  The planner only ever selects built combinations (tests/test_capi.py walks them all); should that ever
  * drift, a stage without an instance is swept by the general kernel, never skipped. */
 TPLHIP_API int tplhip_dp_lon_sweep_built(int weight_quant, int lerp_form, int contraction, int order, int path_div, int range_div, int kind);
 /* HIP-event timing of the backward sweeps (events recorded on the planner's

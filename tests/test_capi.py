@@ -113,5 +113,24 @@ def test_every_selectable_rule_has_a_built_sweep():
                         else:
                             assert built(quant, lerp, fma, order, pd, rd, 1) == 0      # not built, and use_v3 never selects it
     assert n == 2 * (2 * 16 + 16 * 2) + 3 * 2 * 3 * 2 * 2
+    # the chained form of k_backward3v (kind 3): every pair of forms under the default filter rule and order, either R1 -- what
+    # build_action_tables (dp_lon.hip) makes eligible -- and nothing else
+    for quant in (0, 1, 2):
+        for lerp in (0, 1, 2):
+            for fma in (0, 1):
+                for pd in forms:
+                    for rd in forms:
+                        assert built(quant, lerp, fma, 0, pd, rd, 3) == (1 if (quant, lerp) == (1, 0) else 0), (quant, lerp, fma, pd, rd)
+    assert built(1, 0, 1, 1, 5, 5, 3) == 0
     # what is NOT selectable is not claimed: a non-default filter rule with a mixed pair of forms
     assert built(2, 0, 1, 0, 4, 3, 1) == 0 and built(1, 0, 1, 0, 7, 7, 1) == 0
+
+
+def test_switches_refuse_a_null_handle():
+    """The run-time switches of the planner (filter rule, contraction, blend order, chained sweep) check their handle before
+    touching a device: callable without a GPU."""
+    lib = _capi.load()
+    for call in (lambda: lib.tplhip_dp_lon_set_chained_sweep(None, 1), lambda: lib.tplhip_dp_lon_set_filter_rule(None, 1, 0),
+                 lambda: lib.tplhip_dp_lon_set_contraction(None, 1), lambda: lib.tplhip_dp_lon_set_blend_order(None, 0)):
+        assert call() == _capi.TPLHIP_EINVAL
+        assert "null handle" in _capi.last_error()

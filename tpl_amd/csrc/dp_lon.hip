@@ -1581,6 +1581,7 @@ int tplhip_dp_lon_sweep_built(int quant, int lerp, int fma, int order, int path_
     if (kind == 1) ok = (order == 0 || backward3o_built(r)) && launch_backward3v(r, path_div, range_div, a, dim3(1, 1), 0, nullptr);
     else if (kind == 2) ok = order == 0 && launch_backward3s(r, path_div, range_div, 3, false, a, dim3(1, 1), 0, nullptr)
                               && launch_backward3s(r, path_div, range_div, 3, true, a, dim3(1, 1), 0, nullptr);
+    else if (kind == 3) { a.chain.stages = 2; ok = order == 0 && launch_backward3v(r, path_div, range_div, a, dim3(1, 2), 0, nullptr); }   // the chained form of k_backward3v
     t_sweep_probe = false;
     return ok ? 1 : 0;
 }
