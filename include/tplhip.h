@@ -254,7 +254,7 @@ TPLHIP_API int tplhip_dp_lon_set_blend_order(tplhip_dp_lon* h, int order);
  * Taken where the sweep is "k_backward3v" under the default filter rule and blend order (either setting of R1), a table row
  * is a multiple of 128 bytes (s_steps % 32 == 0), t_steps >= 4, a stage fills the chip at least once (workgroups x
  * wavefronts >= 32 x compute units: below that the chained launch loses) and a stage table is at most 96 MB
- * (tplhip_dp_lon_info -> "chained_sweep": 0 no / 1 synchronous calls / 2 every plan, "chained_launches").  No wait is
+ * (tplhip_dp_lon_info -> "chained_sweep": 0 no / 1 synchronous calls / 2 every plan, "chained_launches", "chained_failures").  No wait is
  * unbounded: a workgroup that has waited 1 s gives up and flags it, the call that hands out that plan's result fails with
  * TPLHIP_EDEVICE ("plan again") and the handle sweeps stage by stage from then on.  It cannot happen while workgroups start
  * in the order of their ids, which every use so far has shown. */

@@ -1073,7 +1073,7 @@ def test_a_chained_launch_whose_flags_never_come_drains_and_is_reported(monkeypa
     with pytest.raises(RuntimeError, match="plan again"):
         dp.update_batch(inits, path, env)
     info = dp.info()
-    assert info["chained_launches"] == 1 and info["chained_sweep"] == 0, info
+    assert info["chained_launches"] == 1 and info["chained_failures"] == 1 and info["chained_sweep"] == 0, info
     trajs = dp.update_batch(inits, path, env)
     tables, otrajs, _ = O.update(O.cparams(p), O.cparams(ep), path, occ, inits)
     assert dp.info()["chained_launches"] == 1

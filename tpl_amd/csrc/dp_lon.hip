@@ -1483,14 +1483,14 @@ int tplhip_dp_lon_info(tplhip_dp_lon* h, char* buf, int n)
                   "\"div_verified_up_to\": %g, \"tile_v\": %d, \"tile_a\": %d, \"grid\": %d, \"big\": %d, "
                   "\"bounded_inputs\": %d, \"path_div3\": %d, \"range_div3\": %d, \"scenario_kernel\": \"%s\", \"fwd_overlap\": %d, \"plan_front\": \"%s\", "
                   "\"skew_pairs_per_a_row\": %.4f, \"tile_v3\": %d, \"rule\": {\"quant\": %d, \"lerp\": %d, \"fma\": %d, \"order\": %d}, "
-                  "\"chained_sweep\": %d, \"chained_launches\": %llu}",
+                  "\"chained_sweep\": %d, \"chained_launches\": %llu, \"chained_failures\": %llu}",
                   sweep, h->s_pad, h->rows_per_block, h->nblocks, h->kchunk, h->lds_bytes,
                   (double)h->verified_xmax, h->tile_v, h->tile_a, h->grid, h->big ? 1 : 0,
                   (h->params_bounded && h->path_bounded && h->env_bounded) ? 1 : 0,
                   h->path_div3, h->range_div3, (h->v3_ok && use_v3(h) && h->sc_bounded && h->params_bounded) ? (h->rule.order != 0 ? "k_backward3o" : "k_backward3v") : "k_backward", h->overlap ? 1 : 0,
                   h->front_fused && !h->no_front ? "k_plan_front" : "three launches", (double)h->skew_q16 / 65536.0, h->tile_v3,
                   h->rule.quant, h->rule.lerp, h->rule.fma, h->rule.order,
-                  chain_plan(h, true) ? (h->chain_mode == 1 ? 2 : 1) : 0, h->chain_launches);
+                  chain_plan(h, true) ? (h->chain_mode == 1 ? 2 : 1) : 0, h->chain_launches, h->chain_failures);
     return TPLHIP_OK;
 }
 
